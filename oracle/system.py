@@ -80,6 +80,15 @@ class System:
     def ok(self):
         return self._objective_set
 
+    _LAZY = ("L", "l_p", "r_p", "l_i", "r_i", "l_s", "r_s", "v_lb", "v_ub", "c_lb", "c_ub", "n_c", "F_c", "F_o")
+
+    def __getattr__(self, name):
+        # layout attributes are built on first use (the reference rebuilds them eagerly in its setters)
+        if name in System._LAZY and not self.__dict__.get("_ready", False):
+            self.prepare()
+            return self.__dict__[name]
+        raise AttributeError(name)
+
     @property
     def n_p(self):
         return len(self.p)
