@@ -1,0 +1,121 @@
+/* pockit_hip.h -- C ABI of the MI355X NLP-callback evaluator (libpockit_hip.so).
+ *
+ * Drop-in boundary: these entry points are what a host binding for pockit's evaluator path
+ * binds.  Each eval function replaces one method of the reference's cyipopt ``problem_obj``
+ * (class SystemBase in /root/reference/pockit/base/systembase.py):
+ *
+ *   pk_eval_f     <-  SystemBase.objective(x)                     systembase.py:602-605
+ *   pk_eval_grad  <-  SystemBase.gradient(x)                      systembase.py:646-657
+ *   pk_eval_g     <-  SystemBase.constraints(x)                   systembase.py:613-623
+ *   pk_eval_jac   <-  SystemBase.jacobian(x)                      systembase.py:676-693
+ *   pk_eval_hess  <-  SystemBase.hessian(x, lagrange, obj_factor) systembase.py:820-835
+ *   pk_get_structure <- jacobianstructure()/hessianstructure()    systembase.py:671-674,811-818
+ * and the caller they serve is cyipopt.Problem(...) built in
+ * /root/reference/pockit/optimizer/ipopt.py:41-53.
+ *
+ * Conventions: every function returns 0 on success and a non-zero code on error, with a message
+ * retrievable through pk_last_error(); the caller owns all host buffers; the library owns device
+ * memory, its stream and the loaded code object; ``x`` is never written (the reference mutates
+ * boundary slots in place, phasebase.py:840-847 -- we evaluate as if, without touching x); one
+ * context per GPU, calls on one context are serialized by the caller (as IPOPT does).
+ * No function falls back to the CPU: without a GPU / code object every eval returns an error.
+ *
+ * The *_dev variants take device pointers (e.g. torch tensors' data_ptr()) and a hipStream_t
+ * (NULL = the context's stream); they enqueue only and do not synchronize.
+ */
+#ifndef POCKIT_HIP_H
+#define POCKIT_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct pk_ctx pk_ctx;
+
+/* Compile-time facts of a generated model (pockit_amd/codegen.py) the runtime needs to launch it. */
+typedef struct pk_model_desc {
+  int32_t n_phase;
+  int32_t n_I;          /* number of integral symbols (length of the device I buffer)            */
+  int32_t nred;         /* PK_NRED the code object was compiled with                             */
+  int32_t lds_g;        /* LDS doubles per wave for eval_g / eval_jac / eval_hess                */
+  int32_t lds_j;
+  int32_t lds_h;
+  int32_t ne_j;         /* number of boundary/system scalar expressions of eval_jac / eval_hess  */
+  int32_t ne_h;
+  int32_t prepass_f;    /* 1 if the callback needs the integral pre-pass (pk_int + pk_intfin)     */
+  int32_t prepass_grad;
+  int32_t prepass_g;
+  int32_t prepass_jac;
+  int32_t prepass_hess;
+  int32_t reserved[3];
+} pk_model_desc;
+
+/* One (model, mesh) instance: sizes plus the table blobs built by pockit_amd/evaluator.py.
+ * ``phases``/``tiles``/``kinds``/``items_*`` are arrays of the PkPhase/PkTile/PkKind/PkItem
+ * structs of pockit_amd/csrc/pk_abi.h passed as raw bytes. */
+typedef struct pk_problem_desc {
+  int32_t n, m, n_sys, n_s, l_s;
+  int32_t n_phase, n_tiles, n_kinds;
+  int64_t nnz_J, nnz_H;
+  const void* phases;
+  const void* tiles;
+  const void* kinds;
+  const void* items_jac;
+  int32_t n_items_jac;
+  const void* items_hess;
+  int32_t n_items_hess;
+  const int32_t* ib;
+  int64_t n_ib;
+  const double* db;
+  int64_t n_db;
+  const int64_t* lb;
+  int64_t n_lb;
+  int32_t gz_off, n_gz;
+  /* optional COO structure in the reference's order (copied; may be NULL) */
+  const int32_t* jac_row;
+  const int32_t* jac_col;
+  const int32_t* hess_row;
+  const int32_t* hess_col;
+} pk_problem_desc;
+
+int pk_create(pk_ctx** out, int device_id);
+void pk_destroy(pk_ctx* ctx);
+const char* pk_last_error(pk_ctx* ctx); /* ctx may be NULL: last error of a failed pk_create */
+int pk_device_count(void);
+
+int pk_load_model(pk_ctx* ctx, const void* code_object, size_t len, const pk_model_desc* md);
+int pk_set_problem(pk_ctx* ctx, const pk_problem_desc* pd);
+int pk_get_structure(pk_ctx* ctx, int32_t* jac_row, int32_t* jac_col, int32_t* hess_row, int32_t* hess_col);
+
+/* host-buffer API (what the cyipopt shim calls): H2D, launch, D2H, synchronize */
+int pk_eval_f(pk_ctx* ctx, const double* x, double* f);
+int pk_eval_grad(pk_ctx* ctx, const double* x, double* grad /* n */);
+int pk_eval_g(pk_ctx* ctx, const double* x, double* g /* m */);
+int pk_eval_jac(pk_ctx* ctx, const double* x, double* vals /* nnz_J */);
+int pk_eval_hess(pk_ctx* ctx, const double* x, const double* lambda, double sigma, double* vals /* nnz_H */);
+
+/* device-pointer API: enqueue on ``stream`` (hipStream_t, NULL = context stream), no sync */
+int pk_eval_f_dev(pk_ctx* ctx, const double* d_x, double* d_f, void* stream);
+int pk_eval_grad_dev(pk_ctx* ctx, const double* d_x, double* d_grad, void* stream);
+int pk_eval_g_dev(pk_ctx* ctx, const double* d_x, double* d_g, void* stream);
+int pk_eval_jac_dev(pk_ctx* ctx, const double* d_x, double* d_vals, void* stream);
+int pk_eval_hess_dev(pk_ctx* ctx, const double* d_x, const double* d_lambda, double sigma, double* d_vals,
+                     void* stream);
+/* one NLP-callback cycle f, grad f, g, J, H on the same x (IPOPT's per-iteration pattern) */
+int pk_eval_cycle_dev(pk_ctx* ctx, const double* d_x, const double* d_lambda, double sigma, double* d_f,
+                      double* d_grad, double* d_g, double* d_jac, double* d_hess, void* stream);
+int pk_sync(pk_ctx* ctx, void* stream);
+
+/* HIP-event timing of the individual kernels on the launch stream.
+ * kernel ids: 0 pk_int, 1 pk_intfin, 2 pk_g, 3 pk_grad, 4 pk_gradfin, 5 pk_jac, 6 pk_hess */
+int pk_profile(pk_ctx* ctx, int enable);
+int pk_profile_read(pk_ctx* ctx, int kernel_id, int64_t* launches, double* total_ms);
+const char* pk_kernel_name(int kernel_id);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* POCKIT_HIP_H */

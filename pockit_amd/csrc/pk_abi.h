@@ -1,0 +1,87 @@
+// pk_abi.h -- plain-data structures shared by the host runtime (pk_runtime.cpp) and the device
+// code (pk_kernels.hip.h + generated model code).  Everything is POD; offsets index into three
+// device "blob" arrays (int32 ib[], double db[], int64 lb[]) uploaded once per (model, mesh).
+#pragma once
+#include <stdint.h>
+
+#define PK_WAVE 64
+#define PK_WAVES_PER_BLOCK 4
+#define PK_BLOCK (PK_WAVE * PK_WAVES_PER_BLOCK)
+
+// One phase of the problem on its mesh.
+struct PkPhase {
+  int32_t scheme;      // 0 = LGR, 1 = LGL
+  int32_t n_x, n_u, n_c;
+  int32_t L_m;         // middle-stage nodes
+  int32_t L_d;         // defect rows per state
+  int32_t state_len;   // L_m + 1 (LGR) or L_m (LGL)
+  int32_t L;           // length of the phase block of x (states, controls, t0, tf)
+  int32_t x_off;       // start of the phase block in x
+  int32_t g_off;       // first defect row in g / lambda
+  int32_t path_off;    // first path-constraint row in g / lambda
+  int32_t mid_lo, mid_hi;   // middle node range [mid_lo, mid_hi)
+  int32_t tile_lo, tile_hi; // tiles of this phase
+  int32_t tau_off;     // db: node positions tau[L_m] in [0,1]
+  int32_t w_off;       // db: quadrature weights w[L_m]
+  int32_t width_off;   // db: interval widths d[N]
+  int32_t jseg_off;    // lb: base offset in J of every Jacobian segment of the phase (I then N)
+  int32_t jt_off;      // lb: base offset in J of the constant translation piece of every state
+  int32_t hseg_off;    // lb: base offset in H of every Hessian segment of the phase (I then N)
+  int32_t red_off;     // ib: NLP index of every gradient reduction slot of the phase
+  int32_t pad0, pad1;
+};
+
+// A run of `nj` consecutive intervals of one kind handled by one wavefront (<= 64 nodes).
+struct PkTile {
+  int32_t phase;
+  int32_t j0, nj;      // first interval, number of intervals
+  int32_t kid;         // kind with front/back columns dropped (Jacobian / Hessian)
+  int32_t kidf;        // full kind (constraint values)
+  int32_t q0;          // first node
+  int32_t r0;          // first defect row (within a state)
+  int32_t offI;        // position of the tile inside every I-expanded segment
+  int32_t offT;        // position of the tile inside every translation piece
+  int32_t K;           // points per interval
+  int32_t last;        // 1 if the tile ends the phase
+  int32_t pad;
+};
+
+// Entry tables of one interval pattern (unit width).
+struct PkKind {
+  int32_t K, R;        // points, defect rows
+  int32_t nnzI, nnzT;  // entries of the integration / translation block after dropping columns
+  int32_t irc_off;     // ib: (r, c) pairs of the integration entries, row-major
+  int32_t iv_off;      // db: values of those entries
+  int32_t tv_off;      // db: values (+1/-1) of the translation entries
+  int32_t full_off;    // db: dense R x K integration block
+};
+
+// out[pos] = coef * E[eid] * (lam >= 0 ? lambda[lam] : 1)   (boundary nodes, system level)
+struct PkItem {
+  int64_t pos;
+  double coef;
+  int32_t eid;
+  int32_t lam;
+};
+
+struct PkArgs {
+  const double* x;        // NLP variables (device)
+  const double* lam;      // constraint multipliers (device; Hessian only)
+  double* out;            // f | grad[n] | g[m] | J[nnz_J] | H[nnz_H]
+  double sigma;           // objective factor (Hessian only)
+  const PkPhase* phase;
+  const PkTile* tile;
+  const PkKind* kind;
+  const PkItem* items;
+  const int32_t* ib;
+  const double* db;
+  const int64_t* lb;
+  double* Ibuf;           // integrals I_k (pre-pass result)
+  double* partial;        // [n_tiles][PK_NRED] per-wave partial sums
+  int32_t n_tiles, n_items;
+  int32_t n_phase, n;
+  int32_t l_s, n_s, n_sys, m;
+  int32_t gz_off, n_gz;   // ib: gradient slots the finalize kernel zero-fills
+  int32_t flags;          // bit 0: finalize kernel writes f
+  int32_t pad;
+};

@@ -1,0 +1,396 @@
+// pk_runtime.cpp -- host runtime behind the C ABI of include/pockit_hip.h.
+//
+// Owns: the HIP context objects of one GPU (stream, loaded code object, kernel handles), the
+// device copies of the per-(model, mesh) tables, and device work buffers (x, lambda, outputs,
+// integrals, per-tile partial sums).  It launches the kernels of the generated code object
+// (pockit_amd/codegen.py + csrc/pk_kernels.hip.h) in the order each NLP callback needs:
+//
+//   eval_f     [pk_int, pk_intfin(write f)]
+//   eval_grad  [pk_int, pk_intfin]?  pk_grad, pk_gradfin
+//   eval_g     [pk_int, pk_intfin]?  pk_g
+//   eval_jac   [pk_int, pk_intfin]?  pk_jac
+//   eval_hess  [pk_int, pk_intfin]?  pk_hess
+// ("?" = only when a system-level function is nonlinear in the integrals, pk_model_desc.prepass_*).
+//
+// There is no CPU evaluation path: every entry point fails with an error code when no device /
+// code object / problem is present.
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/pockit_hip.h"
+#include "pk_abi.h"
+
+namespace {
+
+enum { K_INT = 0, K_INTFIN, K_G, K_GRAD, K_GRADFIN, K_JAC, K_HESS, K_COUNT };
+const char* const kKernelNames[K_COUNT] = {"pk_int", "pk_intfin", "pk_g", "pk_grad", "pk_gradfin", "pk_jac", "pk_hess"};
+
+thread_local std::string g_create_error;
+
+struct EventPair {
+  hipEvent_t a, b;
+};
+
+}  // namespace
+
+struct pk_ctx {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  hipModule_t module = nullptr;
+  hipFunction_t fn[K_COUNT] = {};
+  bool have_model = false, have_problem = false;
+  pk_model_desc md{};
+  // problem
+  int32_t n = 0, m = 0, n_sys = 0, n_s = 0, l_s = 0, n_phase = 0, n_tiles = 0;
+  int64_t nnz_J = 0, nnz_H = 0;
+  int32_t n_items_jac = 0, n_items_hess = 0, gz_off = 0, n_gz = 0;
+  void *d_phases = nullptr, *d_tiles = nullptr, *d_kinds = nullptr, *d_items_jac = nullptr, *d_items_hess = nullptr;
+  int32_t* d_ib = nullptr;
+  double* d_db = nullptr;
+  int64_t* d_lb = nullptr;
+  // work buffers
+  double *d_x = nullptr, *d_lam = nullptr, *d_f = nullptr, *d_grad = nullptr, *d_g = nullptr, *d_J = nullptr,
+         *d_H = nullptr, *d_I = nullptr, *d_partial = nullptr;
+  std::vector<int32_t> jac_row, jac_col, hess_row, hess_col;
+  // profiling
+  bool profiling = false;
+  std::vector<EventPair> pending[K_COUNT];
+  int64_t launches[K_COUNT] = {};
+  double total_ms[K_COUNT] = {};
+  std::string error;
+};
+
+namespace {
+
+int fail(pk_ctx* c, int code, const char* fmt, ...) {
+  char buf[1024];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof buf, fmt, ap);
+  va_end(ap);
+  if (c) c->error = buf; else g_create_error = buf;
+  return code;
+}
+
+#define PK_HIP(c, call)                                                                                  \
+  do {                                                                                                   \
+    hipError_t e_ = (call);                                                                              \
+    if (e_ != hipSuccess) return fail((c), 100 + (int)e_, "%s failed: %s", #call, hipGetErrorString(e_)); \
+  } while (0)
+
+template <class T>
+void release(T*& p) {
+  if (p) (void)hipFree(p);
+  p = nullptr;
+}
+
+void free_problem(pk_ctx* c) {
+  release(c->d_phases); release(c->d_tiles); release(c->d_kinds); release(c->d_items_jac); release(c->d_items_hess);
+  release(c->d_ib); release(c->d_db); release(c->d_lb);
+  release(c->d_x); release(c->d_lam); release(c->d_f); release(c->d_grad); release(c->d_g); release(c->d_J);
+  release(c->d_H); release(c->d_I); release(c->d_partial);
+  c->have_problem = false;
+}
+
+int upload(pk_ctx* c, void** dst, const void* src, size_t bytes) {
+  *dst = nullptr;
+  const size_t alloc = bytes ? bytes : 8;
+  PK_HIP(c, hipMalloc(dst, alloc));
+  if (bytes) PK_HIP(c, hipMemcpy(*dst, src, bytes, hipMemcpyHostToDevice));
+  return 0;
+}
+
+int ready(pk_ctx* c) {
+  if (!c) return fail(nullptr, 1, "null context");
+  if (!c->have_model) return fail(c, 2, "no model loaded (pk_load_model)");
+  if (!c->have_problem) return fail(c, 3, "no problem set (pk_set_problem)");
+  return 0;
+}
+
+PkArgs base_args(pk_ctx* c, const double* d_x, const double* d_lam, double sigma, double* d_out) {
+  PkArgs A;
+  std::memset(&A, 0, sizeof A);
+  A.x = d_x; A.lam = d_lam; A.out = d_out; A.sigma = sigma;
+  A.phase = (const PkPhase*)c->d_phases; A.tile = (const PkTile*)c->d_tiles; A.kind = (const PkKind*)c->d_kinds;
+  A.items = nullptr; A.ib = c->d_ib; A.db = c->d_db; A.lb = c->d_lb;
+  A.Ibuf = c->d_I; A.partial = c->d_partial;
+  A.n_tiles = c->n_tiles; A.n_items = 0; A.n_phase = c->n_phase; A.n = c->n;
+  A.l_s = c->l_s; A.n_s = c->n_s; A.n_sys = c->n_sys; A.m = c->m;
+  A.gz_off = c->gz_off; A.n_gz = c->n_gz; A.flags = 0;
+  return A;
+}
+
+int launch(pk_ctx* c, int k, PkArgs& A, unsigned grid, size_t lds_bytes, hipStream_t st) {
+  size_t sz = sizeof(PkArgs);
+  void* config[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &A, HIP_LAUNCH_PARAM_BUFFER_SIZE, &sz, HIP_LAUNCH_PARAM_END};
+  EventPair ev{};
+  if (c->profiling) {
+    PK_HIP(c, hipEventCreate(&ev.a));
+    PK_HIP(c, hipEventCreate(&ev.b));
+    PK_HIP(c, hipEventRecord(ev.a, st));
+  }
+  PK_HIP(c, hipModuleLaunchKernel(c->fn[k], grid, 1, 1, PK_BLOCK, 1, 1, (unsigned)lds_bytes, st, nullptr, config));
+  if (c->profiling) {
+    PK_HIP(c, hipEventRecord(ev.b, st));
+    c->pending[k].push_back(ev);
+  }
+  return 0;
+}
+
+unsigned tile_blocks(const pk_ctx* c) { return (unsigned)((c->n_tiles + PK_WAVES_PER_BLOCK - 1) / PK_WAVES_PER_BLOCK); }
+
+int prepass(pk_ctx* c, const double* d_x, const double* d_lam, double sigma, double* d_f, bool write_f, hipStream_t st) {
+  PkArgs A = base_args(c, d_x, d_lam, sigma, d_f);
+  int rc = launch(c, K_INT, A, tile_blocks(c), 0, st);
+  if (rc) return rc;
+  A.flags = write_f ? 1 : 0;
+  return launch(c, K_INTFIN, A, 1, 0, st);
+}
+
+hipStream_t pick(pk_ctx* c, void* stream) { return stream ? (hipStream_t)stream : c->stream; }
+
+}  // namespace
+
+extern "C" {
+
+int pk_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+  return n;
+}
+
+const char* pk_kernel_name(int k) { return (k >= 0 && k < K_COUNT) ? kKernelNames[k] : ""; }
+
+int pk_create(pk_ctx** out, int device_id) {
+  if (!out) return fail(nullptr, 1, "pk_create: null output pointer");
+  *out = nullptr;
+  int ndev = 0;
+  hipError_t e = hipGetDeviceCount(&ndev);
+  if (e != hipSuccess || ndev == 0)
+    return fail(nullptr, 10, "pk_create: no HIP device available (%s); the evaluator has no CPU path",
+                e == hipSuccess ? "device count 0" : hipGetErrorString(e));
+  if (device_id < 0 || device_id >= ndev) return fail(nullptr, 11, "pk_create: device %d out of range [0,%d)", device_id, ndev);
+  pk_ctx* c = new pk_ctx();
+  c->device = device_id;
+  if ((e = hipSetDevice(device_id)) != hipSuccess || (e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)) != hipSuccess) {
+    int rc = fail(nullptr, 12, "pk_create: %s", hipGetErrorString(e));
+    delete c;
+    return rc;
+  }
+  *out = c;
+  return 0;
+}
+
+void pk_destroy(pk_ctx* c) {
+  if (!c) return;
+  (void)hipSetDevice(c->device);
+  (void)hipStreamSynchronize(c->stream);
+  for (int k = 0; k < K_COUNT; ++k)
+    for (auto& ev : c->pending[k]) { (void)hipEventDestroy(ev.a); (void)hipEventDestroy(ev.b); }
+  free_problem(c);
+  if (c->module) (void)hipModuleUnload(c->module);
+  if (c->stream) (void)hipStreamDestroy(c->stream);
+  delete c;
+}
+
+const char* pk_last_error(pk_ctx* c) { return c ? c->error.c_str() : g_create_error.c_str(); }
+
+int pk_load_model(pk_ctx* c, const void* code_object, size_t len, const pk_model_desc* md) {
+  if (!c) return fail(nullptr, 1, "null context");
+  if (!code_object || len == 0 || !md) return fail(c, 20, "pk_load_model: empty code object or descriptor");
+  PK_HIP(c, hipSetDevice(c->device));
+  if (c->module) { (void)hipModuleUnload(c->module); c->module = nullptr; c->have_model = false; }
+  PK_HIP(c, hipModuleLoadData(&c->module, code_object));
+  for (int k = 0; k < K_COUNT; ++k) PK_HIP(c, hipModuleGetFunction(&c->fn[k], c->module, kKernelNames[k]));
+  c->md = *md;
+  const size_t lds_max = 160 * 1024;
+  const size_t need[3] = {(size_t)md->lds_g, (size_t)md->lds_j, (size_t)md->lds_h};
+  for (size_t v : need)
+    if (v * PK_WAVES_PER_BLOCK * sizeof(double) > lds_max)
+      return fail(c, 21, "pk_load_model: model needs %zu bytes of LDS per workgroup (> 160 KiB)", v * PK_WAVES_PER_BLOCK * sizeof(double));
+  c->have_model = true;
+  return 0;
+}
+
+int pk_set_problem(pk_ctx* c, const pk_problem_desc* pd) {
+  if (!c) return fail(nullptr, 1, "null context");
+  if (!c->have_model) return fail(c, 2, "pk_set_problem: load a model first");
+  if (!pd) return fail(c, 30, "pk_set_problem: null descriptor");
+  if (pd->n_phase != c->md.n_phase) return fail(c, 31, "pk_set_problem: %d phases but the model was generated for %d", pd->n_phase, c->md.n_phase);
+  PK_HIP(c, hipSetDevice(c->device));
+  PK_HIP(c, hipStreamSynchronize(c->stream));
+  free_problem(c);
+  c->n = pd->n; c->m = pd->m; c->n_sys = pd->n_sys; c->n_s = pd->n_s; c->l_s = pd->l_s;
+  c->n_phase = pd->n_phase; c->n_tiles = pd->n_tiles; c->nnz_J = pd->nnz_J; c->nnz_H = pd->nnz_H;
+  c->n_items_jac = pd->n_items_jac; c->n_items_hess = pd->n_items_hess; c->gz_off = pd->gz_off; c->n_gz = pd->n_gz;
+  int rc;
+  if ((rc = upload(c, &c->d_phases, pd->phases, sizeof(PkPhase) * (size_t)pd->n_phase))) return rc;
+  if ((rc = upload(c, &c->d_tiles, pd->tiles, sizeof(PkTile) * (size_t)pd->n_tiles))) return rc;
+  if ((rc = upload(c, &c->d_kinds, pd->kinds, sizeof(PkKind) * (size_t)pd->n_kinds))) return rc;
+  if ((rc = upload(c, &c->d_items_jac, pd->items_jac, sizeof(PkItem) * (size_t)pd->n_items_jac))) return rc;
+  if ((rc = upload(c, &c->d_items_hess, pd->items_hess, sizeof(PkItem) * (size_t)pd->n_items_hess))) return rc;
+  if ((rc = upload(c, (void**)&c->d_ib, pd->ib, sizeof(int32_t) * (size_t)pd->n_ib))) return rc;
+  if ((rc = upload(c, (void**)&c->d_db, pd->db, sizeof(double) * (size_t)pd->n_db))) return rc;
+  if ((rc = upload(c, (void**)&c->d_lb, pd->lb, sizeof(int64_t) * (size_t)pd->n_lb))) return rc;
+  auto dalloc = [&](double** p, size_t count) -> int {
+    PK_HIP(c, hipMalloc((void**)p, sizeof(double) * (count ? count : 1)));
+    PK_HIP(c, hipMemset(*p, 0, sizeof(double) * (count ? count : 1)));
+    return 0;
+  };
+  if ((rc = dalloc(&c->d_x, c->n)) || (rc = dalloc(&c->d_lam, c->m)) || (rc = dalloc(&c->d_f, 1)) ||
+      (rc = dalloc(&c->d_grad, c->n)) || (rc = dalloc(&c->d_g, c->m)) || (rc = dalloc(&c->d_J, (size_t)c->nnz_J)) ||
+      (rc = dalloc(&c->d_H, (size_t)c->nnz_H)) || (rc = dalloc(&c->d_I, c->md.n_I)) ||
+      (rc = dalloc(&c->d_partial, (size_t)c->n_tiles * (size_t)c->md.nred)))
+    return rc;
+  auto keep = [](std::vector<int32_t>& v, const int32_t* src, int64_t cnt) {
+    v.clear();
+    if (src) v.assign(src, src + cnt);
+  };
+  keep(c->jac_row, pd->jac_row, pd->nnz_J); keep(c->jac_col, pd->jac_col, pd->nnz_J);
+  keep(c->hess_row, pd->hess_row, pd->nnz_H); keep(c->hess_col, pd->hess_col, pd->nnz_H);
+  c->have_problem = true;
+  return 0;
+}
+
+int pk_get_structure(pk_ctx* c, int32_t* jr, int32_t* jc, int32_t* hr, int32_t* hc) {
+  int rc = ready(c);
+  if (rc) return rc;
+  if (c->jac_row.empty() && c->nnz_J) return fail(c, 40, "pk_get_structure: no structure was supplied to pk_set_problem");
+  if (jr) std::memcpy(jr, c->jac_row.data(), sizeof(int32_t) * c->jac_row.size());
+  if (jc) std::memcpy(jc, c->jac_col.data(), sizeof(int32_t) * c->jac_col.size());
+  if (hr) std::memcpy(hr, c->hess_row.data(), sizeof(int32_t) * c->hess_row.size());
+  if (hc) std::memcpy(hc, c->hess_col.data(), sizeof(int32_t) * c->hess_col.size());
+  return 0;
+}
+
+// ---------------------------------------------------------------- device-pointer API
+int pk_eval_f_dev(pk_ctx* c, const double* d_x, double* d_f, void* stream) {
+  int rc = ready(c);
+  if (rc) return rc;
+  return prepass(c, d_x, nullptr, 0.0, d_f, true, pick(c, stream));
+}
+
+int pk_eval_grad_dev(pk_ctx* c, const double* d_x, double* d_grad, void* stream) {
+  int rc = ready(c);
+  if (rc) return rc;
+  hipStream_t st = pick(c, stream);
+  if (c->md.prepass_grad && (rc = prepass(c, d_x, nullptr, 0.0, c->d_f, false, st))) return rc;
+  PkArgs A = base_args(c, d_x, nullptr, 0.0, d_grad);
+  if ((rc = launch(c, K_GRAD, A, tile_blocks(c), 0, st))) return rc;
+  return launch(c, K_GRADFIN, A, 1, 0, st);
+}
+
+int pk_eval_g_dev(pk_ctx* c, const double* d_x, double* d_g, void* stream) {
+  int rc = ready(c);
+  if (rc) return rc;
+  hipStream_t st = pick(c, stream);
+  if (c->md.prepass_g && (rc = prepass(c, d_x, nullptr, 0.0, c->d_f, false, st))) return rc;
+  PkArgs A = base_args(c, d_x, nullptr, 0.0, d_g);
+  return launch(c, K_G, A, tile_blocks(c) + 1, sizeof(double) * PK_WAVES_PER_BLOCK * (size_t)c->md.lds_g, st);
+}
+
+int pk_eval_jac_dev(pk_ctx* c, const double* d_x, double* d_vals, void* stream) {
+  int rc = ready(c);
+  if (rc) return rc;
+  hipStream_t st = pick(c, stream);
+  if (c->md.prepass_jac && (rc = prepass(c, d_x, nullptr, 0.0, c->d_f, false, st))) return rc;
+  PkArgs A = base_args(c, d_x, nullptr, 0.0, d_vals);
+  A.items = (const PkItem*)c->d_items_jac;
+  A.n_items = c->n_items_jac;
+  size_t lds = sizeof(double) * PK_WAVES_PER_BLOCK * (size_t)c->md.lds_j;
+  if (lds < sizeof(double) * (size_t)c->md.ne_j) lds = sizeof(double) * (size_t)c->md.ne_j;
+  return launch(c, K_JAC, A, tile_blocks(c) + 1, lds, st);
+}
+
+int pk_eval_hess_dev(pk_ctx* c, const double* d_x, const double* d_lam, double sigma, double* d_vals, void* stream) {
+  int rc = ready(c);
+  if (rc) return rc;
+  if (!d_lam) return fail(c, 50, "pk_eval_hess: lambda is required");
+  hipStream_t st = pick(c, stream);
+  if (c->md.prepass_hess && (rc = prepass(c, d_x, d_lam, sigma, c->d_f, false, st))) return rc;
+  PkArgs A = base_args(c, d_x, d_lam, sigma, d_vals);
+  A.items = (const PkItem*)c->d_items_hess;
+  A.n_items = c->n_items_hess;
+  size_t lds = sizeof(double) * PK_WAVES_PER_BLOCK * (size_t)c->md.lds_h;
+  if (lds < sizeof(double) * (size_t)c->md.ne_h) lds = sizeof(double) * (size_t)c->md.ne_h;
+  return launch(c, K_HESS, A, tile_blocks(c) + 1, lds, st);
+}
+
+int pk_eval_cycle_dev(pk_ctx* c, const double* d_x, const double* d_lam, double sigma, double* d_f, double* d_grad,
+                      double* d_g, double* d_jac, double* d_hess, void* stream) {
+  int rc;
+  if ((rc = pk_eval_f_dev(c, d_x, d_f, stream))) return rc;
+  if ((rc = pk_eval_grad_dev(c, d_x, d_grad, stream))) return rc;
+  if ((rc = pk_eval_g_dev(c, d_x, d_g, stream))) return rc;
+  if ((rc = pk_eval_jac_dev(c, d_x, d_jac, stream))) return rc;
+  return pk_eval_hess_dev(c, d_x, d_lam, sigma, d_hess, stream);
+}
+
+int pk_sync(pk_ctx* c, void* stream) {
+  if (!c) return fail(nullptr, 1, "null context");
+  PK_HIP(c, hipStreamSynchronize(pick(c, stream)));
+  return 0;
+}
+
+// ---------------------------------------------------------------- host-buffer API
+#define PK_HOST_EVAL(IN_COPY, CALL, D_OUT, OUT, COUNT)                                                      \
+  int rc = ready(c);                                                                                        \
+  if (rc) return rc;                                                                                        \
+  if (!x || !(OUT)) return fail(c, 60, "null host buffer");                                                 \
+  PK_HIP(c, hipSetDevice(c->device));                                                                       \
+  PK_HIP(c, hipMemcpyAsync(c->d_x, x, sizeof(double) * (size_t)c->n, hipMemcpyHostToDevice, c->stream));    \
+  IN_COPY;                                                                                                  \
+  if ((rc = (CALL))) return rc;                                                                             \
+  PK_HIP(c, hipMemcpyAsync((OUT), (D_OUT), sizeof(double) * (size_t)(COUNT), hipMemcpyDeviceToHost, c->stream)); \
+  PK_HIP(c, hipStreamSynchronize(c->stream));                                                               \
+  return 0;
+
+int pk_eval_f(pk_ctx* c, const double* x, double* f) { PK_HOST_EVAL((void)0, pk_eval_f_dev(c, c->d_x, c->d_f, nullptr), c->d_f, f, 1) }
+
+int pk_eval_grad(pk_ctx* c, const double* x, double* grad) {
+  PK_HOST_EVAL((void)0, pk_eval_grad_dev(c, c->d_x, c->d_grad, nullptr), c->d_grad, grad, c->n)
+}
+
+int pk_eval_g(pk_ctx* c, const double* x, double* g) { PK_HOST_EVAL((void)0, pk_eval_g_dev(c, c->d_x, c->d_g, nullptr), c->d_g, g, c->m) }
+
+int pk_eval_jac(pk_ctx* c, const double* x, double* vals) {
+  PK_HOST_EVAL((void)0, pk_eval_jac_dev(c, c->d_x, c->d_J, nullptr), c->d_J, vals, c->nnz_J)
+}
+
+int pk_eval_hess(pk_ctx* c, const double* x, const double* lambda, double sigma, double* vals) {
+  if (c && !lambda) return fail(c, 50, "pk_eval_hess: lambda is required");
+  PK_HOST_EVAL(PK_HIP(c, hipMemcpyAsync(c->d_lam, lambda, sizeof(double) * (size_t)c->m, hipMemcpyHostToDevice, c->stream)),
+               pk_eval_hess_dev(c, c->d_x, c->d_lam, sigma, c->d_H, nullptr), c->d_H, vals, c->nnz_H)
+}
+
+// ---------------------------------------------------------------- profiling
+int pk_profile(pk_ctx* c, int enable) {
+  if (!c) return fail(nullptr, 1, "null context");
+  c->profiling = enable != 0;
+  return 0;
+}
+
+int pk_profile_read(pk_ctx* c, int k, int64_t* launches, double* total_ms) {
+  if (!c) return fail(nullptr, 1, "null context");
+  if (k < 0 || k >= K_COUNT) return fail(c, 70, "pk_profile_read: bad kernel id %d", k);
+  for (auto& ev : c->pending[k]) {
+    float ms = 0.f;
+    PK_HIP(c, hipEventSynchronize(ev.b));
+    PK_HIP(c, hipEventElapsedTime(&ms, ev.a, ev.b));
+    c->total_ms[k] += ms;
+    c->launches[k] += 1;
+    (void)hipEventDestroy(ev.a);
+    (void)hipEventDestroy(ev.b);
+  }
+  c->pending[k].clear();
+  if (launches) *launches = c->launches[k];
+  if (total_ms) *total_ms = c->total_ms[k];
+  return 0;
+}
+
+}  // extern "C"

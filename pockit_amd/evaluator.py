@@ -1,0 +1,232 @@
+"""GPU evaluator of one transcribed system: plan -> code object + device tables -> callbacks.
+
+``Evaluator(plan)`` generates the model's HIP source, compiles (or fetches from cache) its gfx950
+code object, flattens the mesh-dependent tables into the blobs of csrc/pk_abi.h, uploads
+everything through the C ABI and then serves the five NLP callbacks with host NumPy arrays
+(pk_eval_*), or with device pointers and a stream for callers that keep data resident (pk_eval_*_dev).
+
+Mirrors the callback semantics of /root/reference/pockit/base/systembase.py:602-835: callbacks
+return freshly allocated float64 arrays; ``x`` is borrowed and never written.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+import os
+
+import numpy as np
+
+from . import hipbuild, runtime
+from .codegen import ModelSource
+from .transcription import SystemPlan
+
+TARGET_TILES = int(os.environ.get("POCKIT_AMD_TARGET_TILES", "2048"))
+
+
+def _intervals_per_wave(plan, override=None):
+    """Intervals per wavefront: as few as keeps ~TARGET_TILES waves in flight, so that small
+    meshes still fill the 256 CUs (1 interval per wave below ~2k intervals) while large meshes
+    use more lanes per wave for the model evaluation."""
+    if override:
+        return int(override)
+    env = os.environ.get("POCKIT_AMD_IPW")
+    if env:
+        return int(env)
+    n_int = sum(pp.layout.N for pp in plan.phase_plans)
+    return max(1, math.ceil(n_int / TARGET_TILES))
+
+
+class Tables:
+    """Mesh-dependent tables of a plan in the layout of csrc/pk_abi.h (host NumPy arrays).
+
+    ``tile_filter(phase_index, tiles) -> tiles`` lets a rank keep only its shard of the tiles."""
+
+    def __init__(self, plan: SystemPlan, src: ModelSource, intervals_per_wave=None, tile_filter=None):
+        ib, db, lb = [], [], []
+
+        def put(store, arr, dtype):
+            arr = np.asarray(arr, dtype=dtype).ravel()
+            off = sum(len(a) for a in store)
+            store.append(arr)
+            return off
+
+        nP = len(plan.phase_plans)
+        phases = np.zeros(nP, dtype=runtime.PHASE_DTYPE)
+        kinds, tiles = [], []
+        ipw = _intervals_per_wave(plan, intervals_per_wave)
+        for k, pp in enumerate(plan.phase_plans):
+            lay = pp.layout
+            kind0 = len(kinds)
+            for kd in lay.kinds:
+                rec = np.zeros((), dtype=runtime.KIND_DTYPE)
+                rec["K"], rec["R"], rec["nnzI"], rec["nnzT"] = kd.K, kd.R, kd.nnzI, kd.nnzT
+                rec["irc_off"] = put(ib, np.stack([kd.I_r, kd.I_c], axis=1) if kd.nnzI else np.zeros((0, 2)), np.int32)
+                rec["iv_off"] = put(db, kd.I_v, np.float64)
+                rec["tv_off"] = put(db, kd.T_v, np.float64)
+                rec["full_off"] = put(db, kd.full, np.float64)
+                kinds.append(rec)
+            tl = lay.tiles(ipw)
+            if tile_filter is not None:
+                tl = tile_filter(k, tl)
+            ph = phases[k]
+            ph["scheme"] = 0 if lay.scheme == "lgr" else 1
+            ph["n_x"], ph["n_u"], ph["n_c"] = pp.nx, pp.nu, pp.phase.n_c
+            ph["L_m"], ph["L_d"], ph["state_len"], ph["L"] = lay.L_m, lay.L_d, lay.state_len, lay.L
+            ph["x_off"], ph["g_off"], ph["path_off"] = plan.l_p[k], plan.g_off[k], plan.path_off[k]
+            ph["mid_lo"], ph["mid_hi"] = lay.mid_lo, lay.mid_hi
+            ph["tile_lo"], ph["tile_hi"] = len(tiles), len(tiles) + len(tl)
+            ph["tau_off"] = put(db, lay.tau, np.float64)
+            ph["w_off"] = put(db, lay.w, np.float64)
+            ph["width_off"] = put(db, lay.width, np.float64)
+            for cbname, field in (("jac", "jseg_off"), ("hess", "hseg_off")):
+                segs = getattr(plan, cbname).segs[k]
+                bases = [s.base for s in segs if s.kind == "I"] + [s.base for s in segs if s.kind == "N"]
+                ph[field] = put(lb, bases, np.int64)
+            ph["jt_off"] = put(lb, plan.jac.tconst[k], np.int64)
+            red = [plan.l_p[k] + s if s >= 0 else plan.r_s + s for s in plan.grad_red_slots[k]]
+            ph["red_off"] = put(ib, red, np.int32)
+            for row in tl:
+                j0, nj, kid, kidf, q0, r0, offI, offT = (int(v) for v in row)
+                rec = np.zeros((), dtype=runtime.TILE_DTYPE)
+                rec["phase"], rec["j0"], rec["nj"] = k, j0, nj
+                rec["kid"], rec["kidf"] = kind0 + kid, kind0 + kidf
+                rec["q0"], rec["r0"], rec["offI"], rec["offT"] = q0, r0, offI, offT
+                rec["K"] = int(lay.K[j0])
+                rec["last"] = 1 if j0 + nj == lay.N else 0
+                tiles.append(rec)
+        # gradient slots no tile writes: state end slots (LGR), t0/tf, static parameters
+        gz = []
+        for k, pp in enumerate(plan.phase_plans):
+            lay = pp.layout
+            if lay.scheme == "lgr":
+                gz += [plan.l_p[k] + lay.l_v[i] + lay.L_m for i in range(pp.nx)]
+            gz += [plan.l_p[k] + lay.L - 2, plan.l_p[k] + lay.L - 1]
+        gz += list(range(plan.l_s, plan.r_s))
+        self.gz_off, self.n_gz = put(ib, gz, np.int32), len(gz)
+
+        def items(cbname):
+            cb = getattr(plan, cbname)
+            off = src.list_off[cbname]
+            arr = np.zeros(len(cb.items), dtype=runtime.ITEM_DTYPE)
+            for i, it in enumerate(cb.items):
+                arr[i] = (it.pos, it.coef, off[it.lst] + it.eid, it.lam)
+            return arr
+
+        self.items_jac, self.items_hess = items("jac"), items("hess")
+        self.phases = phases
+        self.kinds = np.array(kinds, dtype=runtime.KIND_DTYPE) if kinds else np.zeros(0, runtime.KIND_DTYPE)
+        self.tiles = np.array(tiles, dtype=runtime.TILE_DTYPE) if tiles else np.zeros(0, runtime.TILE_DTYPE)
+        cat = lambda store, dt: np.concatenate(store).astype(dt) if store else np.zeros(0, dt)  # noqa: E731
+        self.ib, self.db, self.lb = cat(ib, np.int32), cat(db, np.float64), cat(lb, np.int64)
+        self.intervals_per_wave = ipw
+
+
+class Evaluator:
+    def __init__(self, plan: SystemPlan, device: int = 0, intervals_per_wave=None, tile_filter=None):
+        self.plan = plan
+        if not plan.phase_plans:
+            raise NotImplementedError("systems without phases have no GPU work; not supported by the HIP evaluator")
+        self.src = ModelSource(plan)
+        self.ctx = runtime.Context(device)            # raises RuntimeError without a GPU
+        lib, h = self.ctx.lib, self.ctx.handle
+        code = hipbuild.compile_model(self.src.source, fastmath=plan.system._fastmath)
+        md = runtime.ModelDesc()
+        md.n_phase, md.n_I, md.nred = self.src.nphase, max(len(plan.I_syms), 1), self.src.nred
+        md.lds_g, md.lds_j, md.lds_h = self.src.lds_g, self.src.lds_j, self.src.lds_h
+        md.ne_j, md.ne_h = self.src.list_off["jac"]["total"], self.src.list_off["hess"]["total"]
+        md.prepass_f = 1
+        md.prepass_grad = int(plan.needs_I_grad)
+        md.prepass_g = int(plan.needs_I_con)
+        md.prepass_jac = int(plan.jac.needs_I)
+        md.prepass_hess = int(plan.hess.needs_I)
+        self._code = code
+        self.ctx.check(lib.pk_load_model(h, code, len(code), C.byref(md)))
+        self.model_desc = md
+        self.set_tables(Tables(plan, self.src, intervals_per_wave, tile_filter))
+
+    def set_tables(self, tb: Tables):
+        plan, lib, h = self.plan, self.ctx.lib, self.ctx.handle
+        self.tables = tb
+        pd = runtime.ProblemDesc()
+        pd.n, pd.m, pd.n_sys, pd.n_s, pd.l_s = plan.n, plan.m, plan.n_sys, plan.n_s, plan.l_s
+        pd.n_phase, pd.n_tiles, pd.n_kinds = len(tb.phases), len(tb.tiles), len(tb.kinds)
+        pd.nnz_J, pd.nnz_H = plan.nnz_J, plan.nnz_H
+        vp = lambda a: a.ctypes.data_as(C.c_void_p)  # noqa: E731
+        pd.phases, pd.tiles, pd.kinds = vp(tb.phases), vp(tb.tiles), vp(tb.kinds)
+        pd.items_jac, pd.n_items_jac = vp(tb.items_jac), len(tb.items_jac)
+        pd.items_hess, pd.n_items_hess = vp(tb.items_hess), len(tb.items_hess)
+        pd.ib, pd.n_ib = tb.ib.ctypes.data_as(runtime.c_int32_p), len(tb.ib)
+        pd.db, pd.n_db = tb.db.ctypes.data_as(runtime.c_double_p), len(tb.db)
+        pd.lb, pd.n_lb = tb.lb.ctypes.data_as(C.POINTER(C.c_int64)), len(tb.lb)
+        pd.gz_off, pd.n_gz = tb.gz_off, tb.n_gz
+        self._struct = [np.ascontiguousarray(a, dtype=np.int32) for a in
+                        (plan.jac_row, plan.jac_col, plan.hess_row, plan.hess_col)]
+        pd.jac_row, pd.jac_col, pd.hess_row, pd.hess_col = (a.ctypes.data_as(runtime.c_int32_p) for a in self._struct)
+        self.ctx.check(lib.pk_set_problem(h, C.byref(pd)))
+
+    def close(self):
+        if self.ctx is not None:
+            self.ctx.close()
+            self.ctx = None
+
+    # ------------------------------------------------------------------ host-array callbacks
+    def _x(self, x):
+        x = np.ascontiguousarray(x, dtype=np.float64)
+        if x.shape != (self.plan.n,):
+            raise ValueError(f"x must have shape ({self.plan.n},)")
+        return x
+
+    def objective(self, x):
+        x = self._x(x)
+        out = np.empty(1)
+        self.ctx.check(self.ctx.lib.pk_eval_f(self.ctx.handle, runtime.as_dp(x), runtime.as_dp(out)))
+        return np.float64(out[0])
+
+    def gradient(self, x):
+        x = self._x(x)
+        out = np.empty(self.plan.n)
+        self.ctx.check(self.ctx.lib.pk_eval_grad(self.ctx.handle, runtime.as_dp(x), runtime.as_dp(out)))
+        return out
+
+    def constraints(self, x):
+        x = self._x(x)
+        out = np.empty(self.plan.m)
+        self.ctx.check(self.ctx.lib.pk_eval_g(self.ctx.handle, runtime.as_dp(x), runtime.as_dp(out)))
+        return out
+
+    def jacobian(self, x):
+        x = self._x(x)
+        out = np.empty(self.plan.nnz_J)
+        self.ctx.check(self.ctx.lib.pk_eval_jac(self.ctx.handle, runtime.as_dp(x), runtime.as_dp(out)))
+        return out
+
+    def hessian(self, x, lagrange, obj_factor):
+        x = self._x(x)
+        lam = np.ascontiguousarray(lagrange, dtype=np.float64)
+        if lam.shape != (self.plan.m,):
+            raise ValueError(f"lagrange must have shape ({self.plan.m},)")
+        out = np.empty(self.plan.nnz_H)
+        self.ctx.check(self.ctx.lib.pk_eval_hess(self.ctx.handle, runtime.as_dp(x), runtime.as_dp(lam),
+                                                 float(obj_factor), runtime.as_dp(out)))
+        return out
+
+    # ------------------------------------------------------------------ device-pointer API
+    def cycle_dev(self, d_x, d_lam, sigma, d_f, d_grad, d_g, d_jac, d_hess, stream=None):
+        """Enqueue one full callback cycle on device pointers (ints); no synchronization."""
+        self.ctx.check(self.ctx.lib.pk_eval_cycle_dev(self.ctx.handle, d_x, d_lam, float(sigma), d_f, d_grad, d_g,
+                                                      d_jac, d_hess, stream))
+
+    def sync(self, stream=None):
+        self.ctx.check(self.ctx.lib.pk_sync(self.ctx.handle, stream))
+
+    def profile(self, enable=True):
+        self.ctx.check(self.ctx.lib.pk_profile(self.ctx.handle, int(enable)))
+
+    def profile_read(self):
+        """{kernel name: (launches, total_ms)} accumulated while profiling was enabled."""
+        out = {}
+        for k, name in enumerate(runtime.KERNELS):
+            n, ms = C.c_int64(), C.c_double()
+            self.ctx.check(self.ctx.lib.pk_profile_read(self.ctx.handle, k, C.byref(n), C.byref(ms)))
+            out[name] = (n.value, ms.value)
+        return out

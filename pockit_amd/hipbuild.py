@@ -1,0 +1,83 @@
+"""Build helpers: the C-ABI runtime library and per-model gfx950 code objects.
+
+* ``build_runtime()``  hipcc -shared csrc/pk_runtime.cpp -> pockit_amd/libpockit_hip.so  (in-tree, so the
+  built library travels with the repository snapshot to the GPU box).
+* ``compile_model(source)``  generated HIP source -> code object for gfx950 (``hipcc --genco``), cached in
+  pockit_amd/_cache/<sha>.hsaco keyed by the source hash.  The generated source is mesh-independent, so
+  one code object serves every mesh of a model -- the analogue of the reference's FastFunc cache
+  (/root/reference/pockit/base/fastfunc.py:126-131,196-223).
+"""
+from __future__ import annotations
+
+import hashlib
+import os
+import shutil
+import subprocess
+import tempfile
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+LIB_PATH = os.path.join(HERE, "libpockit_hip.so")
+CACHE_DIR = os.environ.get("POCKIT_AMD_CACHE", os.path.join(HERE, "_cache"))
+ARCH = "gfx950"
+
+
+def _hipcc():
+    exe = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(exe):
+        raise RuntimeError("hipcc not found: the MI355X evaluator needs the ROCm toolchain to build its kernels")
+    return exe
+
+
+def _run(cmd):
+    res = subprocess.run(cmd, capture_output=True, text=True)
+    if res.returncode != 0:
+        raise RuntimeError("command failed: " + " ".join(cmd) + "\n" + res.stderr[-4000:])
+    return res
+
+
+def _stale(target, sources):
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(s) > t for s in sources)
+
+
+def build_runtime(force=False):
+    """Compile libpockit_hip.so (host C++ against libamdhip64)."""
+    srcs = [os.path.join(CSRC, "pk_runtime.cpp"), os.path.join(CSRC, "pk_abi.h"),
+            os.path.join(os.path.dirname(HERE), "include", "pockit_hip.h")]
+    if force or _stale(LIB_PATH, srcs):
+        _run([_hipcc(), "-O2", "-fPIC", "-shared", "-std=c++17", srcs[0], "-o", LIB_PATH])
+    return LIB_PATH
+
+
+def _kernel_header_hash():
+    h = hashlib.sha256()
+    for name in ("pk_kernels.hip.h", "pk_abi.h"):
+        with open(os.path.join(CSRC, name), "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:12]
+
+
+def compile_model(source: str, fastmath: bool = False, keep_source: bool = True) -> bytes:
+    """Return the gfx950 code object of a generated model source (compiling on a cache miss)."""
+    key = hashlib.sha256((source + _kernel_header_hash() + str(bool(fastmath))).encode()).hexdigest()[:32]
+    os.makedirs(CACHE_DIR, exist_ok=True)
+    path = os.path.join(CACHE_DIR, key + ".hsaco")
+    if not os.path.exists(path):
+        with tempfile.TemporaryDirectory() as tmp:
+            src = os.path.join(tmp, "model.hip")
+            with open(src, "w") as fh:
+                fh.write(source)
+            cmd = [_hipcc(), f"--offload-arch={ARCH}", "-O3", "-std=c++17", "--genco", f"-I{CSRC}", src, "-o",
+                   os.path.join(tmp, "model.hsaco")]
+            if fastmath:  # reassociation subset of fast-math (reference: numba fastmath=True, fastfunc.py:24,35)
+                cmd += ["-fassociative-math", "-freciprocal-math", "-fno-signed-zeros", "-fno-trapping-math"]
+            _run(cmd)
+            shutil.move(os.path.join(tmp, "model.hsaco"), path + ".tmp")
+            os.replace(path + ".tmp", path)
+            if keep_source:
+                shutil.copy(src, os.path.join(CACHE_DIR, key + ".hip"))
+    with open(path, "rb") as fh:
+        return fh.read()

@@ -1,0 +1,135 @@
+"""ctypes binding of libpockit_hip.so (the C ABI of include/pockit_hip.h).
+
+Thin by design: structures, prototypes and error translation only.  A missing library, a missing
+GPU or a failing HIP call raises ``RuntimeError`` -- the package has no CPU evaluation path.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import hipbuild
+
+c_double_p = C.POINTER(C.c_double)
+c_int32_p = C.POINTER(C.c_int32)
+
+
+class ModelDesc(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in
+                ("n_phase", "n_I", "nred", "lds_g", "lds_j", "lds_h", "ne_j", "ne_h", "prepass_f", "prepass_grad",
+                 "prepass_g", "prepass_jac", "prepass_hess")] + [("reserved", C.c_int32 * 3)]
+
+
+class ProblemDesc(C.Structure):
+    _fields_ = [
+        ("n", C.c_int32), ("m", C.c_int32), ("n_sys", C.c_int32), ("n_s", C.c_int32), ("l_s", C.c_int32),
+        ("n_phase", C.c_int32), ("n_tiles", C.c_int32), ("n_kinds", C.c_int32),
+        ("nnz_J", C.c_int64), ("nnz_H", C.c_int64),
+        ("phases", C.c_void_p), ("tiles", C.c_void_p), ("kinds", C.c_void_p),
+        ("items_jac", C.c_void_p), ("n_items_jac", C.c_int32),
+        ("items_hess", C.c_void_p), ("n_items_hess", C.c_int32),
+        ("ib", c_int32_p), ("n_ib", C.c_int64),
+        ("db", c_double_p), ("n_db", C.c_int64),
+        ("lb", C.POINTER(C.c_int64)), ("n_lb", C.c_int64),
+        ("gz_off", C.c_int32), ("n_gz", C.c_int32),
+        ("jac_row", c_int32_p), ("jac_col", c_int32_p), ("hess_row", c_int32_p), ("hess_col", c_int32_p),
+    ]
+
+
+# numpy mirrors of csrc/pk_abi.h
+PHASE_FIELDS = ["scheme", "n_x", "n_u", "n_c", "L_m", "L_d", "state_len", "L", "x_off", "g_off", "path_off",
+                "mid_lo", "mid_hi", "tile_lo", "tile_hi", "tau_off", "w_off", "width_off", "jseg_off", "jt_off",
+                "hseg_off", "red_off", "pad0", "pad1"]
+PHASE_DTYPE = np.dtype([(n, np.int32) for n in PHASE_FIELDS])
+TILE_FIELDS = ["phase", "j0", "nj", "kid", "kidf", "q0", "r0", "offI", "offT", "K", "last", "pad"]
+TILE_DTYPE = np.dtype([(n, np.int32) for n in TILE_FIELDS])
+KIND_FIELDS = ["K", "R", "nnzI", "nnzT", "irc_off", "iv_off", "tv_off", "full_off"]
+KIND_DTYPE = np.dtype([(n, np.int32) for n in KIND_FIELDS])
+ITEM_DTYPE = np.dtype([("pos", np.int64), ("coef", np.float64), ("eid", np.int32), ("lam", np.int32)])
+
+KERNELS = ["pk_int", "pk_intfin", "pk_g", "pk_grad", "pk_gradfin", "pk_jac", "pk_hess"]
+EXPORTS = ["pk_create", "pk_destroy", "pk_last_error", "pk_device_count", "pk_load_model", "pk_set_problem",
+           "pk_get_structure", "pk_eval_f", "pk_eval_grad", "pk_eval_g", "pk_eval_jac", "pk_eval_hess",
+           "pk_eval_f_dev", "pk_eval_grad_dev", "pk_eval_g_dev", "pk_eval_jac_dev", "pk_eval_hess_dev",
+           "pk_eval_cycle_dev", "pk_sync", "pk_profile", "pk_profile_read", "pk_kernel_name"]
+
+_lib = None
+
+
+def load_library():
+    """Load (building if the sources are newer) libpockit_hip.so and declare prototypes."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    path = hipbuild.LIB_PATH
+    if not os.path.exists(path):
+        path = hipbuild.build_runtime()
+    try:
+        lib = C.CDLL(path)
+    except OSError as exc:
+        raise RuntimeError(f"cannot load {path}: {exc}; the MI355X evaluator has no CPU fallback") from exc
+    vp, dp = C.c_void_p, c_double_p
+    lib.pk_create.argtypes = [C.POINTER(vp), C.c_int]
+    lib.pk_destroy.argtypes = [vp]
+    lib.pk_destroy.restype = None
+    lib.pk_last_error.argtypes = [vp]
+    lib.pk_last_error.restype = C.c_char_p
+    lib.pk_device_count.restype = C.c_int
+    lib.pk_load_model.argtypes = [vp, vp, C.c_size_t, C.POINTER(ModelDesc)]
+    lib.pk_set_problem.argtypes = [vp, C.POINTER(ProblemDesc)]
+    lib.pk_get_structure.argtypes = [vp, c_int32_p, c_int32_p, c_int32_p, c_int32_p]
+    lib.pk_eval_f.argtypes = [vp, dp, dp]
+    lib.pk_eval_grad.argtypes = [vp, dp, dp]
+    lib.pk_eval_g.argtypes = [vp, dp, dp]
+    lib.pk_eval_jac.argtypes = [vp, dp, dp]
+    lib.pk_eval_hess.argtypes = [vp, dp, dp, C.c_double, dp]
+    lib.pk_eval_f_dev.argtypes = [vp, vp, vp, vp]
+    lib.pk_eval_grad_dev.argtypes = [vp, vp, vp, vp]
+    lib.pk_eval_g_dev.argtypes = [vp, vp, vp, vp]
+    lib.pk_eval_jac_dev.argtypes = [vp, vp, vp, vp]
+    lib.pk_eval_hess_dev.argtypes = [vp, vp, vp, C.c_double, vp, vp]
+    lib.pk_eval_cycle_dev.argtypes = [vp, vp, vp, C.c_double, vp, vp, vp, vp, vp, vp]
+    lib.pk_sync.argtypes = [vp, vp]
+    lib.pk_profile.argtypes = [vp, C.c_int]
+    lib.pk_profile_read.argtypes = [vp, C.c_int, C.POINTER(C.c_int64), dp]
+    lib.pk_kernel_name.argtypes = [C.c_int]
+    lib.pk_kernel_name.restype = C.c_char_p
+    for name in EXPORTS:
+        if name not in ("pk_destroy", "pk_last_error", "pk_kernel_name"):
+            getattr(lib, name).restype = C.c_int
+    _lib = lib
+    return lib
+
+
+def as_dp(a):
+    return a.ctypes.data_as(c_double_p)
+
+
+class Context:
+    """One GPU context (pk_ctx)."""
+
+    def __init__(self, device=0):
+        self.lib = load_library()
+        self.handle = C.c_void_p()
+        rc = self.lib.pk_create(C.byref(self.handle), int(device))
+        if rc != 0:
+            msg = self.lib.pk_last_error(None).decode()
+            self.handle = None
+            raise RuntimeError(f"pk_create failed ({rc}): {msg}")
+
+    def check(self, rc):
+        if rc != 0:
+            raise RuntimeError(f"libpockit_hip error {rc}: {self.lib.pk_last_error(self.handle).decode()}")
+
+    def close(self):
+        if getattr(self, "handle", None):
+            self.lib.pk_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
