@@ -1,0 +1,267 @@
+#!/usr/bin/env python3
+"""Benchmark of the NLP-callback hot path: cycles/sec of (f, grad f, g, J, H) on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+A *step* is one NLP-callback cycle -- objective, gradient, constraints, Jacobian, Hessian of the
+Lagrangian on the same x, in IPOPT's order -- with x and lambda already
+resident in HBM and all outputs left in HBM.
+
+Workload (BASELINE.json metric: "at 10k LGR nodes"): planar_quadrotor re-meshed on LGR 2000
+intervals x 6 points = 12 000 nodes (configs[2], the ~10k-node headline of BASELINE.md), x =
+example guess * (1 + 1e-3 U), lambda ~ N(0,1), sigma = 1, all seeded.  For N > 1 the mesh is
+2000*N intervals of the same model, sharded by mesh interval over the N GPUs (weak scaling: 2000
+intervals per GPU) with RCCL reassembly of grad/g/J/H on every rank; ``value`` is then reported in
+12k-node-equivalent cycles/s (= N * steps / time).
+
+One JSON line is printed by rank 0 (see the repository prompt for the contract), carrying
+``roofline`` for the dominant kernel (HIP-event timed on the launch stream inside the timed
+region) and ``cpu_baseline`` (the oracle = CPU restatement of the reference, timed on the host).
+"""
+import os
+
+for _v in ("OMP_NUM_THREADS", "OPENBLAS_NUM_THREADS", "MKL_NUM_THREADS", "NUMEXPR_NUM_THREADS"):
+    os.environ.setdefault(_v, "1")
+
+import argparse  # noqa: E402
+import ctypes as C  # noqa: E402
+import json  # noqa: E402
+import sys  # noqa: E402
+import time  # noqa: E402
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for p in (ROOT, os.path.join(ROOT, "tests")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+import numpy as np  # noqa: E402
+
+HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+KERNEL_IDS = {"pk_int": 0, "pk_intfin": 1, "pk_g": 2, "pk_grad": 3, "pk_gradfin": 4, "pk_jac": 5, "pk_hess": 6}
+
+
+def algorithmic_bytes(plan):
+    """Per-kernel algorithmic traffic of one cycle:
+    B = 8 (5n + m + 1 + n + m + nnz_J + nnz_H): x read by each callback, lambda once, outputs once."""
+    n, m = plan.n, plan.m
+    per = {
+        "f": 8 * (n + 1),
+        "grad": 8 * (n + n),
+        "g": 8 * (n + m),
+        "jac": 8 * (n + plan.nnz_J),
+        "hess": 8 * (n + m + plan.nnz_H),
+    }
+    per["cycle"] = sum(per.values())
+    return per
+
+
+def build_workload(name, intervals, ns):
+    import models
+
+    if name == "planar_quadrotor":
+        return models.planar_quadrotor(ns, intervals, 6)
+    if name == "brachistochrone":
+        return models.brachistochrone(ns, intervals, 8)
+    if name == "two_stage_rocket":
+        return models.two_stage_rocket(ns, intervals, 4)
+    if name == "humanoid_wbc":
+        return models.humanoid_wbc(ns, intervals, 8)
+    raise ValueError(name)
+
+
+def cpu_baseline(name, intervals, budget_s=12.0, max_cycles=200):
+    """The oracle (NumPy restatement of the reference algorithm, single thread) on the same workload."""
+    import models
+    import oracle.radau
+
+    system, _, guess = build_workload(name, intervals, oracle.radau)
+    x, lam, sigma = models.bench_inputs(system, guess)
+
+    def cycle():
+        system.objective(x)
+        system.gradient(x)
+        system.constraints(x)
+        system.jacobian(x)
+        system.hessian(x, lam, sigma)
+
+    for _ in range(2):
+        cycle()
+    t0 = time.perf_counter()
+    n = 0
+    while n < max_cycles and time.perf_counter() - t0 < budget_s:
+        cycle()
+        n += 1
+    dt = time.perf_counter() - t0
+    return {"value": n / dt, "unit": "cycles/s", "cores": 1, "kind": "port",
+            "sample": f"{n} full cycles of the same workload ({name} LGR {intervals} intervals) in {dt:.1f} s, "
+                      f"NumPy oracle, 1 thread of {os.cpu_count()} host CPUs"}
+
+
+def run_gpu(name, intervals, steps, warmup, rank, world, dist, time_kernel=None):
+    """Returns dict(ms_per_step, kernel timings, plan facts) for one workload on this rank."""
+    import torch
+
+    import models
+    import pockit_amd.radau as radau
+    from pockit_amd.sharding import ShardedEvaluator
+
+    t0 = time.perf_counter()
+    system, _, guess = build_workload(name, intervals, radau)
+    plan = system.plan
+    x, lam, sigma = models.bench_inputs(system, guess)
+    dev = torch.device("cuda", torch.cuda.current_device())
+    sev = ShardedEvaluator(plan, rank, world, device=dev.index)
+    setup_s = time.perf_counter() - t0
+    ev = sev.ev
+    lib, h = ev.ctx.lib, ev.ctx.handle
+    dx = torch.from_numpy(x).to(dev)
+    dlam = torch.from_numpy(lam).to(dev)
+    o = sev.out
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    ptr = lambda t: C.c_void_p(t.data_ptr())  # noqa: E731
+
+    if world == 1:
+        def step():
+            ev.ctx.check(lib.pk_eval_cycle_dev(h, ptr(dx), ptr(dlam), float(sigma), ptr(o["f"]), ptr(o["grad"]),
+                                               ptr(o["g"]), ptr(o["J"]), ptr(o["H"]), st))
+        ev.ctx.check(lib.pk_set_shard(h, 0, 0, None))
+    else:
+        def step():
+            sev.cycle(dx, dlam, sigma, dist)
+
+    B = algorithmic_bytes(plan)
+    dominant = "pk_jac" if B["jac"] >= B["hess"] else "pk_hess"
+    for _ in range(warmup):
+        step()
+    torch.cuda.synchronize()
+    if dist is not None and world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    ev.profile(1 << KERNEL_IDS[time_kernel or dominant])
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    torch.cuda.synchronize()
+    if dist is not None and world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    prof = ev.profile_read()
+    ev.profile(0)
+    launches, total_ms = prof[time_kernel or dominant]
+    # per-kernel event timing of every kernel, outside the timed region (diagnostic)
+    ev.profile(0x7F)
+    for _ in range(min(steps, 50)):
+        step()
+    torch.cuda.synchronize()
+    allk = {k: (v[1] / v[0] * 1e3 if v[0] else 0.0) for k, v in ev.profile_read().items()}
+    ev.profile(0)
+    # correctness spot-check against what the kernels are supposed to produce: finite outputs
+    finite = all(bool(torch.isfinite(o[k]).all()) for k in ("f", "grad", "g", "J", "H"))
+    res = dict(name=name, intervals=intervals, nodes=int(sum(pp.layout.L_m for pp in plan.phase_plans)),
+               n=plan.n, m=plan.m, nnz_J=plan.nnz_J, nnz_H=plan.nnz_H, elapsed=elapsed, steps=steps,
+               ms_per_step=elapsed / steps * 1e3, setup_s=setup_s, bytes=B, dominant=dominant,
+               dominant_us=(total_ms / launches * 1e3 if launches else None), kernel_us=allk, finite=finite,
+               tiles=int(len(ev.tables.tiles)), ipw=int(ev.tables.intervals_per_wave))
+    ev.close()
+    return res
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=300)
+    ap.add_argument("--warmup", type=int, default=30)
+    ap.add_argument("--workload", default="planar_quadrotor")
+    ap.add_argument("--intervals", type=int, default=2000)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extra", action="store_true", help="skip the supplementary workloads")
+    args = ap.parse_args()
+
+    import torch
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (no CPU path in pockit_amd)")
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world)
+    n_gpus = world
+
+    intervals = args.intervals * n_gpus          # weak scaling: per-GPU share stays args.intervals
+    res = run_gpu(args.workload, intervals, args.steps, args.warmup, rank, world, dist)
+    t = torch.tensor([res["elapsed"]], dtype=torch.float64, device="cuda")
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    elapsed = float(t.item())
+
+    if rank == 0:
+        ms = elapsed / args.steps * 1e3
+        value = n_gpus * args.steps / elapsed
+        dom_bytes = res["bytes"]["jac" if res["dominant"] == "pk_jac" else "hess"] / n_gpus
+        dom_us = res["dominant_us"]
+        achieved = dom_bytes / (dom_us * 1e-6) / 1e9 if dom_us else None
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+        if os.path.exists(tpath):
+            try:
+                traffic = json.load(open(tpath)).get(f"{args.workload}_{intervals}", {}).get(res["dominant"])
+            except Exception:
+                traffic = None
+        line = {
+            "metric": "NLP-callback cycles/sec (f + grad f + g + J + H)",
+            "value": value,
+            "unit": "cycles/s" if n_gpus == 1 else "12k-node-equivalent cycles/s",
+            "n_gpus": n_gpus, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f64", "data": "synthetic",
+            "config": {"workload": f"{args.workload} LGR {intervals} intervals x "
+                                   f"{6 if args.workload == 'planar_quadrotor' else 8 if args.workload != 'two_stage_rocket' else 4}"
+                                   f" points ({res['nodes']} nodes; n={res['n']}, m={res['m']}, nnz_J={res['nnz_J']}, "
+                                   f"nnz_H={res['nnz_H']})",
+                       "sharding": "single GPU" if n_gpus == 1 else f"mesh intervals over {n_gpus} GPUs, RCCL all-reduce "
+                                                                    f"reassembly of grad/g/J/H",
+                       "tiles": res["tiles"], "intervals_per_wave": res["ipw"],
+                       "inputs": "example guess*(1+1e-3 U(-1,1)) seed 0; lambda N(0,1) seed 1; sigma 1"},
+            "roofline": {"bound": "hbm", "kernel": res["dominant"], "achieved": achieved, "peak": HBM_PEAK_GBPS,
+                         "unit": "GB/s", "frac": (achieved / HBM_PEAK_GBPS if achieved else None), "traffic": traffic,
+                         "algorithmic_bytes_per_launch": dom_bytes, "avg_launch_us": dom_us},
+            "kernel_us": res["kernel_us"],
+            "cycle_algorithmic_bytes": res["bytes"]["cycle"],
+            "setup_s": res["setup_s"],
+            "outputs_finite": res["finite"],
+        }
+        if not args.no_cpu_baseline and n_gpus == 1:
+            cb = cpu_baseline(args.workload, intervals)
+            line["cpu_baseline"] = cb
+            line["speedup_vs_cpu_baseline"] = value / cb["value"]
+        if not args.no_extra and n_gpus == 1:
+            extra = {}
+            for nm, iv in (("brachistochrone", 1250), ("brachistochrone", 200), ("two_stage_rocket", 1000),
+                           ("humanoid_wbc", 5000)):
+                try:
+                    r = run_gpu(nm, iv, max(20, args.steps // 3), max(5, args.warmup // 3), 0, 1, None)
+                    b = r["bytes"]["jac" if r["dominant"] == "pk_jac" else "hess"]
+                    extra[f"{nm}_{iv}"] = {
+                        "nodes": r["nodes"], "cycles_per_s": 1e3 / r["ms_per_step"], "ms_per_step": r["ms_per_step"],
+                        "dominant": r["dominant"], "dominant_us": r["dominant_us"],
+                        "dominant_GBps": b / (r["dominant_us"] * 1e-6) / 1e9 if r["dominant_us"] else None,
+                        "kernel_us": r["kernel_us"], "cycle_bytes": r["bytes"]["cycle"], "setup_s": r["setup_s"]}
+                except Exception as exc:  # keep the headline line even if a side workload fails
+                    extra[f"{nm}_{iv}"] = {"error": repr(exc)}
+            line["other_workloads"] = extra
+        print(json.dumps(line))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

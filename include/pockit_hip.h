@@ -109,9 +109,18 @@ int pk_eval_cycle_dev(pk_ctx* ctx, const double* d_x, const double* d_lambda, do
                       double* d_grad, double* d_g, double* d_jac, double* d_hess, void* stream);
 int pk_sync(pk_ctx* ctx, void* stream);
 
+/* Mesh-interval sharding across GPUs (one context per GPU, each holding its shard of the tiles):
+ * ``secondary`` shards skip the boundary-node / system-level work (done once, on the primary);
+ * with ``external_prepass`` the callbacks do not run the integral pre-pass themselves: the caller
+ * runs pk_eval_integrals_dev, sums ``d_integrals`` (n_I doubles, caller-owned) across shards
+ * (RCCL all-reduce) and only then calls the callbacks / pk_eval_f_from_integrals_dev. */
+int pk_set_shard(pk_ctx* ctx, int secondary, int external_prepass, double* d_integrals);
+int pk_eval_integrals_dev(pk_ctx* ctx, const double* d_x, void* stream);
+int pk_eval_f_from_integrals_dev(pk_ctx* ctx, const double* d_x, double* d_f, void* stream);
+
 /* HIP-event timing of the individual kernels on the launch stream.
  * kernel ids: 0 pk_int, 1 pk_intfin, 2 pk_g, 3 pk_grad, 4 pk_gradfin, 5 pk_jac, 6 pk_hess */
-int pk_profile(pk_ctx* ctx, int enable);
+int pk_profile(pk_ctx* ctx, int kernel_mask /* bit k: time kernel k; 0 = off */);
 int pk_profile_read(pk_ctx* ctx, int kernel_id, int64_t* launches, double* total_ms);
 const char* pk_kernel_name(int kernel_id);
 

@@ -82,6 +82,7 @@ struct PkArgs {
   int32_t n_phase, n;
   int32_t l_s, n_s, n_sys, m;
   int32_t gz_off, n_gz;   // ib: gradient slots the finalize kernel zero-fills
-  int32_t flags;          // bit 0: finalize kernel writes f
+  int32_t flags;          // bit 0: pk_intfin writes f; bit 1: secondary shard (no system-level / boundary work);
+                          // bit 2: pk_intfin skips the reduction (Ibuf already holds the global integrals)
   int32_t pad;
 };

@@ -354,7 +354,7 @@ __device__ __forceinline__ double block_sum_partials(const PkArgs& A, int lo, in
   if (ti < A.n_tiles) {                                                               \
     tl = A.tile[ti];                                                                  \
   } else {                                                                            \
-    tl = A.tile[A.n_tiles - 1];                                                       \
+    tl = A.tile[A.n_tiles > 0 ? A.n_tiles - 1 : 0];                                   \
     tl.nj = 0;                                                                        \
   }
 
@@ -368,7 +368,7 @@ __device__ __forceinline__ void kernel_int(const PkArgs& A) {
 template <class Gen>
 __device__ __forceinline__ void kernel_intfin(const PkArgs& A) {
   __shared__ double red[PK_WAVES_PER_BLOCK];
-  for (int n = 0; n < Gen::N_INT; ++n) {
+  for (int n = 0; n < Gen::N_INT && !(A.flags & 4); ++n) {
     const int k = Gen::int_phase(n);
     const double sum = block_sum_partials(A, A.phase[k].tile_lo, A.phase[k].tile_hi, Gen::int_slot(n), red);
     if (threadIdx.x == 0) A.Ibuf[Gen::int_global(n)] = sum * Gen::phase_dt(k, A);
@@ -384,7 +384,7 @@ __device__ __forceinline__ void kernel_intfin(const PkArgs& A) {
 template <class Gen>
 __device__ __forceinline__ void kernel_g(const PkArgs& A) {
   if ((int)blockIdx.x == (A.n_tiles + PK_WAVES_PER_BLOCK - 1) / PK_WAVES_PER_BLOCK) {
-    if (threadIdx.x == 0 && A.n_sys > 0) {   // system constraints C(I, s)   (systembase.py:607-611)
+    if (threadIdx.x == 0 && A.n_sys > 0 && !(A.flags & 2)) {   // system constraints C(I, s)   (systembase.py:607-611)
       const PkSys sy{A.x + A.l_s, A.Ibuf, A.sigma, A.lam};
       Gen::sys_constraints(sy, A.out);
     }
@@ -415,10 +415,12 @@ __device__ __forceinline__ void kernel_gradfin(const PkArgs& A) {
     for (int z = 0; z < A.n_gz; ++z) A.out[A.ib[A.gz_off + z]] = 0.0;
     for (int k = 0; k < PK_NPHASE; ++k)
       for (int r = 0; r < Gen::gr_nr(k); ++r) A.out[A.ib[A.phase[k].red_off + r]] += tot[k * PK_NRED + r];
-    const PkSys sy{A.x + A.l_s, A.Ibuf, A.sigma, A.lam};
-    double gs[PK_NS];
-    Gen::sys_grad_static(sy, gs);
-    for (int i = 0; i < A.n_s; ++i) A.out[A.l_s + i] += gs[i];
+    if (!(A.flags & 2)) {
+      const PkSys sy{A.x + A.l_s, A.Ibuf, A.sigma, A.lam};
+      double gs[PK_NS];
+      Gen::sys_grad_static(sy, gs);
+      for (int i = 0; i < A.n_s; ++i) A.out[A.l_s + i] += gs[i];
+    }
   }
 }
 
@@ -428,6 +430,7 @@ __device__ __forceinline__ void kernel_jac(const PkArgs& A) {
     extern __shared__ double pk_lds[];
     const PkSys sy{A.x + A.l_s, A.Ibuf, A.sigma, A.lam};
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    if (A.flags & 2) return;   // secondary shard: boundary nodes / system level belong to the primary
     for (int li = wave; li < Gen::NLISTS; li += PK_WAVES_PER_BLOCK)
       if (lane == 0) Gen::edge_jac(li, A, sy, pk_lds);
     __syncthreads();
@@ -444,6 +447,7 @@ __device__ __forceinline__ void kernel_hess(const PkArgs& A) {
     extern __shared__ double pk_lds[];
     const PkSys sy{A.x + A.l_s, A.Ibuf, A.sigma, A.lam};
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    if (A.flags & 2) return;
     for (int li = wave; li < Gen::NLISTS; li += PK_WAVES_PER_BLOCK)
       if (lane == 0) Gen::edge_hess(li, A, sy, pk_lds);
     __syncthreads();

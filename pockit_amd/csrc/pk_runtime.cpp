@@ -44,6 +44,10 @@ struct pk_ctx {
   hipModule_t module = nullptr;
   hipFunction_t fn[K_COUNT] = {};
   bool have_model = false, have_problem = false;
+  int shard_flags = 0;          // OR-ed into PkArgs.flags (bit 1: secondary shard)
+  bool external_prepass = false; // sharded mode: the caller all-reduces the integrals itself
+  double* ext_I = nullptr;      // caller-owned integral buffer (sharded mode)
+  unsigned profile_mask = 0;
   pk_model_desc md{};
   // problem
   int32_t n = 0, m = 0, n_sys = 0, n_s = 0, l_s = 0, n_phase = 0, n_tiles = 0;
@@ -118,10 +122,10 @@ PkArgs base_args(pk_ctx* c, const double* d_x, const double* d_lam, double sigma
   A.x = d_x; A.lam = d_lam; A.out = d_out; A.sigma = sigma;
   A.phase = (const PkPhase*)c->d_phases; A.tile = (const PkTile*)c->d_tiles; A.kind = (const PkKind*)c->d_kinds;
   A.items = nullptr; A.ib = c->d_ib; A.db = c->d_db; A.lb = c->d_lb;
-  A.Ibuf = c->d_I; A.partial = c->d_partial;
+  A.Ibuf = c->ext_I ? c->ext_I : c->d_I; A.partial = c->d_partial;
   A.n_tiles = c->n_tiles; A.n_items = 0; A.n_phase = c->n_phase; A.n = c->n;
   A.l_s = c->l_s; A.n_s = c->n_s; A.n_sys = c->n_sys; A.m = c->m;
-  A.gz_off = c->gz_off; A.n_gz = c->n_gz; A.flags = 0;
+  A.gz_off = c->gz_off; A.n_gz = c->n_gz; A.flags = c->shard_flags;
   return A;
 }
 
@@ -129,13 +133,15 @@ int launch(pk_ctx* c, int k, PkArgs& A, unsigned grid, size_t lds_bytes, hipStre
   size_t sz = sizeof(PkArgs);
   void* config[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &A, HIP_LAUNCH_PARAM_BUFFER_SIZE, &sz, HIP_LAUNCH_PARAM_END};
   EventPair ev{};
-  if (c->profiling) {
+  if (grid == 0) return 0;
+  const bool timed = c->profiling && ((c->profile_mask >> k) & 1u);
+  if (timed) {
     PK_HIP(c, hipEventCreate(&ev.a));
     PK_HIP(c, hipEventCreate(&ev.b));
     PK_HIP(c, hipEventRecord(ev.a, st));
   }
   PK_HIP(c, hipModuleLaunchKernel(c->fn[k], grid, 1, 1, PK_BLOCK, 1, 1, (unsigned)lds_bytes, st, nullptr, config));
-  if (c->profiling) {
+  if (timed) {
     PK_HIP(c, hipEventRecord(ev.b, st));
     c->pending[k].push_back(ev);
   }
@@ -148,7 +154,7 @@ int prepass(pk_ctx* c, const double* d_x, const double* d_lam, double sigma, dou
   PkArgs A = base_args(c, d_x, d_lam, sigma, d_f);
   int rc = launch(c, K_INT, A, tile_blocks(c), 0, st);
   if (rc) return rc;
-  A.flags = write_f ? 1 : 0;
+  A.flags |= write_f ? 1 : 0;
   return launch(c, K_INTFIN, A, 1, 0, st);
 }
 
@@ -275,11 +281,35 @@ int pk_eval_f_dev(pk_ctx* c, const double* d_x, double* d_f, void* stream) {
   return prepass(c, d_x, nullptr, 0.0, d_f, true, pick(c, stream));
 }
 
+// sharded mode, step 1: this shard's contribution to every integral -> integral buffer
+int pk_eval_integrals_dev(pk_ctx* c, const double* d_x, void* stream) {
+  int rc = ready(c);
+  if (rc) return rc;
+  return prepass(c, d_x, nullptr, 0.0, c->d_f, false, pick(c, stream));
+}
+
+// sharded mode, step 2 (after the caller all-reduced the integral buffer): f = F_o(I, s)
+int pk_eval_f_from_integrals_dev(pk_ctx* c, const double* d_x, double* d_f, void* stream) {
+  int rc = ready(c);
+  if (rc) return rc;
+  PkArgs A = base_args(c, d_x, nullptr, 0.0, d_f);
+  A.flags |= 1 | 4;
+  return launch(c, K_INTFIN, A, 1, 0, pick(c, stream));
+}
+
+int pk_set_shard(pk_ctx* c, int secondary, int external_prepass, double* d_integrals) {
+  if (!c) return fail(nullptr, 1, "null context");
+  c->shard_flags = secondary ? 2 : 0;
+  c->external_prepass = external_prepass != 0;
+  c->ext_I = d_integrals;
+  return 0;
+}
+
 int pk_eval_grad_dev(pk_ctx* c, const double* d_x, double* d_grad, void* stream) {
   int rc = ready(c);
   if (rc) return rc;
   hipStream_t st = pick(c, stream);
-  if (c->md.prepass_grad && (rc = prepass(c, d_x, nullptr, 0.0, c->d_f, false, st))) return rc;
+  if (c->md.prepass_grad && !c->external_prepass && (rc = prepass(c, d_x, nullptr, 0.0, c->d_f, false, st))) return rc;
   PkArgs A = base_args(c, d_x, nullptr, 0.0, d_grad);
   if ((rc = launch(c, K_GRAD, A, tile_blocks(c), 0, st))) return rc;
   return launch(c, K_GRADFIN, A, 1, 0, st);
@@ -289,7 +319,7 @@ int pk_eval_g_dev(pk_ctx* c, const double* d_x, double* d_g, void* stream) {
   int rc = ready(c);
   if (rc) return rc;
   hipStream_t st = pick(c, stream);
-  if (c->md.prepass_g && (rc = prepass(c, d_x, nullptr, 0.0, c->d_f, false, st))) return rc;
+  if (c->md.prepass_g && !c->external_prepass && (rc = prepass(c, d_x, nullptr, 0.0, c->d_f, false, st))) return rc;
   PkArgs A = base_args(c, d_x, nullptr, 0.0, d_g);
   return launch(c, K_G, A, tile_blocks(c) + 1, sizeof(double) * PK_WAVES_PER_BLOCK * (size_t)c->md.lds_g, st);
 }
@@ -298,7 +328,7 @@ int pk_eval_jac_dev(pk_ctx* c, const double* d_x, double* d_vals, void* stream) 
   int rc = ready(c);
   if (rc) return rc;
   hipStream_t st = pick(c, stream);
-  if (c->md.prepass_jac && (rc = prepass(c, d_x, nullptr, 0.0, c->d_f, false, st))) return rc;
+  if (c->md.prepass_jac && !c->external_prepass && (rc = prepass(c, d_x, nullptr, 0.0, c->d_f, false, st))) return rc;
   PkArgs A = base_args(c, d_x, nullptr, 0.0, d_vals);
   A.items = (const PkItem*)c->d_items_jac;
   A.n_items = c->n_items_jac;
@@ -312,7 +342,7 @@ int pk_eval_hess_dev(pk_ctx* c, const double* d_x, const double* d_lam, double s
   if (rc) return rc;
   if (!d_lam) return fail(c, 50, "pk_eval_hess: lambda is required");
   hipStream_t st = pick(c, stream);
-  if (c->md.prepass_hess && (rc = prepass(c, d_x, d_lam, sigma, c->d_f, false, st))) return rc;
+  if (c->md.prepass_hess && !c->external_prepass && (rc = prepass(c, d_x, d_lam, sigma, c->d_f, false, st))) return rc;
   PkArgs A = base_args(c, d_x, d_lam, sigma, d_vals);
   A.items = (const PkItem*)c->d_items_hess;
   A.n_items = c->n_items_hess;
@@ -372,6 +402,7 @@ int pk_eval_hess(pk_ctx* c, const double* x, const double* lambda, double sigma,
 int pk_profile(pk_ctx* c, int enable) {
   if (!c) return fail(nullptr, 1, "null context");
   c->profiling = enable != 0;
+  c->profile_mask = (unsigned)enable;   /* bit k set: time kernel id k */
   return 0;
 }
 

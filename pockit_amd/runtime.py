@@ -53,7 +53,8 @@ KERNELS = ["pk_int", "pk_intfin", "pk_g", "pk_grad", "pk_gradfin", "pk_jac", "pk
 EXPORTS = ["pk_create", "pk_destroy", "pk_last_error", "pk_device_count", "pk_load_model", "pk_set_problem",
            "pk_get_structure", "pk_eval_f", "pk_eval_grad", "pk_eval_g", "pk_eval_jac", "pk_eval_hess",
            "pk_eval_f_dev", "pk_eval_grad_dev", "pk_eval_g_dev", "pk_eval_jac_dev", "pk_eval_hess_dev",
-           "pk_eval_cycle_dev", "pk_sync", "pk_profile", "pk_profile_read", "pk_kernel_name"]
+           "pk_eval_cycle_dev", "pk_sync", "pk_profile", "pk_profile_read", "pk_kernel_name",
+           "pk_set_shard", "pk_eval_integrals_dev", "pk_eval_f_from_integrals_dev"]
 
 _lib = None
 
@@ -92,6 +93,9 @@ def load_library():
     lib.pk_eval_hess_dev.argtypes = [vp, vp, vp, C.c_double, vp, vp]
     lib.pk_eval_cycle_dev.argtypes = [vp, vp, vp, C.c_double, vp, vp, vp, vp, vp, vp]
     lib.pk_sync.argtypes = [vp, vp]
+    lib.pk_set_shard.argtypes = [vp, C.c_int, C.c_int, vp]
+    lib.pk_eval_integrals_dev.argtypes = [vp, vp, vp]
+    lib.pk_eval_f_from_integrals_dev.argtypes = [vp, vp, vp, vp]
     lib.pk_profile.argtypes = [vp, C.c_int]
     lib.pk_profile_read.argtypes = [vp, C.c_int, C.POINTER(C.c_int64), dp]
     lib.pk_kernel_name.argtypes = [C.c_int]
