@@ -38,7 +38,7 @@ for p in (ROOT, os.path.join(ROOT, "tests")):
 import numpy as np  # noqa: E402
 
 HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
-KERNEL_IDS = {"pk_int": 0, "pk_intfin": 1, "pk_g": 2, "pk_grad": 3, "pk_gradfin": 4, "pk_jac": 5, "pk_hess": 6}
+KERNEL_IDS = {"pk_int": 0, "pk_fin": 1, "pk_g": 2, "pk_grad": 3, "pk_jac": 4, "pk_hess": 5, "pk_xall": 6}
 
 
 def algorithmic_bytes(plan):
@@ -53,6 +53,8 @@ def algorithmic_bytes(plan):
         "hess": 8 * (n + m + plan.nnz_H),
     }
     per["cycle"] = sum(per.values())
+    # fused x-kernel (pk_xall): x is read once, f partials + grad + g + J written once
+    per["xall"] = 8 * (n + 1 + n + m + plan.nnz_J)
     return per
 
 
@@ -131,7 +133,11 @@ def run_gpu(name, intervals, steps, warmup, rank, world, dist, time_kernel=None)
             sev.cycle(dx, dlam, sigma, dist)
 
     B = algorithmic_bytes(plan)
-    dominant = "pk_jac" if B["jac"] >= B["hess"] else "pk_hess"
+    fused = world == 1 and not (plan.needs_I_grad or plan.needs_I_con or plan.jac.needs_I or plan.hess.needs_I)
+    if fused:
+        dominant = "pk_xall" if B["xall"] >= B["hess"] else "pk_hess"
+    else:
+        dominant = "pk_jac" if B["jac"] >= B["hess"] else "pk_hess"
     for _ in range(warmup):
         step()
     torch.cuda.synchronize()
@@ -205,7 +211,7 @@ def main():
     if rank == 0:
         ms = elapsed / args.steps * 1e3
         value = n_gpus * args.steps / elapsed
-        dom_bytes = res["bytes"]["jac" if res["dominant"] == "pk_jac" else "hess"] / n_gpus
+        dom_bytes = res["bytes"][res["dominant"][3:]] / n_gpus
         dom_us = res["dominant_us"]
         achieved = dom_bytes / (dom_us * 1e-6) / 1e9 if dom_us else None
         traffic = None
@@ -248,7 +254,7 @@ def main():
                            ("humanoid_wbc", 5000)):
                 try:
                     r = run_gpu(nm, iv, max(20, args.steps // 3), max(5, args.warmup // 3), 0, 1, None)
-                    b = r["bytes"]["jac" if r["dominant"] == "pk_jac" else "hess"]
+                    b = r["bytes"][r["dominant"][3:]]
                     extra[f"{nm}_{iv}"] = {
                         "nodes": r["nodes"], "cycles_per_s": 1e3 / r["ms_per_step"], "ms_per_step": r["ms_per_step"],
                         "dominant": r["dominant"], "dominant_us": r["dominant_us"],

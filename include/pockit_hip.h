@@ -45,12 +45,13 @@ typedef struct pk_model_desc {
   int32_t lds_h;
   int32_t ne_j;         /* number of boundary/system scalar expressions of eval_jac / eval_hess  */
   int32_t ne_h;
-  int32_t prepass_f;    /* 1 if the callback needs the integral pre-pass (pk_int + pk_intfin)     */
+  int32_t prepass_f;    /* 1 if the callback needs the integral pre-pass (pk_int)                 */
   int32_t prepass_grad;
   int32_t prepass_g;
   int32_t prepass_jac;
   int32_t prepass_hess;
-  int32_t reserved[3];
+  int32_t lds_x;        /* LDS doubles per wave of the fused x-kernel (pk_xall)                   */
+  int32_t reserved[2];
 } pk_model_desc;
 
 /* One (model, mesh) instance: sizes plus the table blobs built by pockit_amd/evaluator.py.
@@ -97,6 +98,10 @@ int pk_eval_g(pk_ctx* ctx, const double* x, double* g /* m */);
 int pk_eval_jac(pk_ctx* ctx, const double* x, double* vals /* nnz_J */);
 int pk_eval_hess(pk_ctx* ctx, const double* x, const double* lambda, double sigma, double* vals /* nnz_H */);
 
+/* all five outputs of one cycle on the same x (fused x-kernel + Hessian), host buffers */
+int pk_eval_cycle(pk_ctx* ctx, const double* x, const double* lambda, double sigma, double* f, double* grad,
+                  double* g, double* jac, double* hess);
+
 /* device-pointer API: enqueue on ``stream`` (hipStream_t, NULL = context stream), no sync */
 int pk_eval_f_dev(pk_ctx* ctx, const double* d_x, double* d_f, void* stream);
 int pk_eval_grad_dev(pk_ctx* ctx, const double* d_x, double* d_grad, void* stream);
@@ -104,7 +109,8 @@ int pk_eval_g_dev(pk_ctx* ctx, const double* d_x, double* d_g, void* stream);
 int pk_eval_jac_dev(pk_ctx* ctx, const double* d_x, double* d_vals, void* stream);
 int pk_eval_hess_dev(pk_ctx* ctx, const double* d_x, const double* d_lambda, double sigma, double* d_vals,
                      void* stream);
-/* one NLP-callback cycle f, grad f, g, J, H on the same x (IPOPT's per-iteration pattern) */
+/* one NLP-callback cycle f, grad f, g, J, H on the same x (IPOPT's per-iteration pattern): the x-only
+ * outputs come from ONE fused launch (pk_xall: each node evaluated once) + pk_fin, then pk_hess */
 int pk_eval_cycle_dev(pk_ctx* ctx, const double* d_x, const double* d_lambda, double sigma, double* d_f,
                       double* d_grad, double* d_g, double* d_jac, double* d_hess, void* stream);
 int pk_sync(pk_ctx* ctx, void* stream);
@@ -119,7 +125,7 @@ int pk_eval_integrals_dev(pk_ctx* ctx, const double* d_x, void* stream);
 int pk_eval_f_from_integrals_dev(pk_ctx* ctx, const double* d_x, double* d_f, void* stream);
 
 /* HIP-event timing of the individual kernels on the launch stream.
- * kernel ids: 0 pk_int, 1 pk_intfin, 2 pk_g, 3 pk_grad, 4 pk_gradfin, 5 pk_jac, 6 pk_hess */
+ * kernel ids: 0 pk_int, 1 pk_fin, 2 pk_g, 3 pk_grad, 4 pk_jac, 5 pk_hess, 6 pk_xall */
 int pk_profile(pk_ctx* ctx, int kernel_mask /* bit k: time kernel k; 0 = off */);
 int pk_profile_read(pk_ctx* ctx, int kernel_id, int64_t* launches, double* total_ms);
 const char* pk_kernel_name(int kernel_id);

@@ -158,6 +158,7 @@ class ModelSource:
         S.append(f"  static constexpr int NX = {nx}, NU = {nu}, NS = {ns}, NC = {nc};")
         S.append(f"  static constexpr int NARG = {nx + nu + 1 + ns};")
         S.append(f"  static constexpr int SCHEME = {0 if lay.scheme == 'lgr' else 1};")
+        S.append(f"  static constexpr int INDEX = {k};")
 
         # ---- boundary substitution (reference: phasebase.py:830-847) ----
         snm = _Names()
@@ -237,6 +238,22 @@ class ModelSource:
                 outs += [(f"orr[{r}]", plan.grad_red[k][w].get(s, sp.Integer(0))) for r, s in enumerate(slots)]
                 S.append(_emit_body(outs, base, nm))
             S.append("  }")
+        # ---- fused x-callbacks: g values, Jacobian segments, gradient entries, integrands; ONE CSE ----
+        jsegs = plan.jac.segs[k]
+        ji = [sg for sg in jsegs if sg.kind == "I"]
+        jn = [sg for sg in jsegs if sg.kind == "N"]
+        outs = [(f"og[{i}]", fr.F) for i, fr in enumerate(pp.dyn)]
+        outs += [(f"og[{nx + j}]", fr.F) for j, fr in enumerate(pp.path)]
+        outs += [(f"oj[{e}]", sg.expr) for e, sg in enumerate(ji + jn)]
+        outs += [(f"ov[{a}]", e) for a, e in enumerate(plan.grad_var[k]["m"])]
+        outs += [(f"ot[{r}]", plan.grad_red[k]["m"].get(sl, sp.Integer(0))) for r, sl in enumerate(slots)]
+        outs += [(f"op[{r}]", pp.integ[plan.I_owner[a][1]].F) for r, a in enumerate(loc)]
+        S.append("  __device__ static __forceinline__ void mid_xall(const double* __restrict__ a, double pk_tau, "
+                 "double pk_dt, double pk_w, const PkSys& sy, double* __restrict__ og, double* __restrict__ oj, "
+                 "double* __restrict__ ov, double* __restrict__ ot, double* __restrict__ op) {")
+        S.append("    const double* lp = nullptr; (void)lp;")
+        S.append(_emit_body(outs, base, nm))
+        S.append("  }")
         S.append("};")
         return "\n".join(S)
 
@@ -295,11 +312,14 @@ class ModelSource:
         self.lds_g = 64 * max([1] + [pp.nx for pp in plan.phase_plans])
         self.lds_j = 64 * max([1] + [sum(1 for sg in plan.jac.segs[k] if sg.kind == "I") for k in range(nP)])
         self.lds_h = 64 * max([1] + [sum(1 for sg in plan.hess.segs[k] if sg.kind == "I") for k in range(nP)])
-        S.append(f"  static constexpr int LDS_G = {self.lds_g}, LDS_J = {self.lds_j}, LDS_H = {self.lds_h};")
-        for name in ("int", "g", "grad", "jac", "hess"):
+        self.lds_x = 64 * max([1] + [pp.nx + sum(1 for sg in plan.jac.segs[k] if sg.kind == "I")
+                                     for k, pp in enumerate(plan.phase_plans)])
+        S.append(f"  static constexpr int LDS_G = {self.lds_g}, LDS_J = {self.lds_j}, LDS_H = {self.lds_h}, "
+                 f"LDS_X = {self.lds_x};")
+        for name in ("int", "g", "grad", "jac", "hess", "xall"):
             S.append(f"  __device__ static __forceinline__ void tile_{name}(int phase, const PkArgs& A, const PkTile& tl, "
-                     f"double* __restrict__ lds, int lane) {{")
-            S.append(switch(f"pk::tile_{name}<{{P}}>(A, tl, lds, lane)"))
+                     f"double* __restrict__ lds, double* __restrict__ wint, double* __restrict__ wgrad, int lane) {{")
+            S.append(switch(f"pk::tile_{name}<{{P}}>(A, tl, lds, wint, wgrad, lane)"))
             S.append("  }")
         ncmax = max([1] + [pp.phase.n_c for pp in plan.phase_plans])
         for cbname, tag in (("jac", "J"), ("hess", "H")):
@@ -318,7 +338,7 @@ class ModelSource:
                     continue
                 wname = "front" if key[0] == "f" else "back"
                 S.append(f"      case {li}: {{ double s_[PK_NS], a[P{k}::NARG], tau, dt, w, lp[{ncmax}];")
-                S.append(f"        pk::load_edge<P{k}>(A, {k}, {1 if key[0] == 'b' else 0}, s_, a, tau, dt, w, lp);")
+                S.append(f"        pk::load_edge<P{k}>(A, {1 if key[0] == 'b' else 0}, s_, a, tau, dt, w, lp);")
                 S.append(f"        const PkSys sy2{{s_, sy.I, sy.sigma, sy.lams}};")
                 S.append(f"        P{k}::{wname}_{cbname}(a, tau, dt, w, sy2, lp, E + {off[key]}); }} break;")
             S.append("      default: break;\n    }\n  }")
@@ -330,7 +350,7 @@ class ModelSource:
         S.append(table_fn("int_slot", [r for _, _, r in ints]))
         S.append(table_fn("gr_nr", [len(v) for v in plan.grad_red_slots]))
         S.append("  __device__ static __forceinline__ double phase_dt(int phase, const PkArgs& A) {")
-        S.append(switch("return pk::phase_dt<{P}>(A, {k})"))
+        S.append(switch("return pk::phase_dt<{P}>(A)"))
         S.append("    return 0.0;\n  }")
         S.append("  __device__ static __forceinline__ double sys_objective(const PkSys& sy) { return pkgen::sys_objective(sy); }")
         S.append("  __device__ static __forceinline__ void sys_constraints(const PkSys& sy, double* g) { pkgen::sys_constraints(sy, g); }")

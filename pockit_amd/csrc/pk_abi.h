@@ -20,7 +20,7 @@ struct PkPhase {
   int32_t g_off;       // first defect row in g / lambda
   int32_t path_off;    // first path-constraint row in g / lambda
   int32_t mid_lo, mid_hi;   // middle node range [mid_lo, mid_hi)
-  int32_t tile_lo, tile_hi; // tiles of this phase
+  int32_t tile_lo, tile_hi; // tiles of this phase; both multiples of PK_WAVES_PER_BLOCK (padded with empty tiles)
   int32_t tau_off;     // db: node positions tau[L_m] in [0,1]
   int32_t w_off;       // db: quadrature weights w[L_m]
   int32_t width_off;   // db: interval widths d[N]
@@ -43,6 +43,12 @@ struct PkTile {
   int32_t offT;        // position of the tile inside every translation piece
   int32_t K;           // points per interval
   int32_t last;        // 1 if the tile ends the phase
+  // copy of the two kinds' table locations (saves a dependent load per tile)
+  int32_t nnzI, nnzT;  // entries per interval of kind `kid`
+  int32_t irc_off;     // ib: (r, c) pairs of kind `kid`
+  int32_t iv_off;      // db: values of kind `kid`
+  int32_t tv_off;      // db: translation values of kind `kid`
+  int32_t full_off;    // db: dense R x K block of kind `kidf`
   int32_t pad;
 };
 
@@ -64,10 +70,16 @@ struct PkItem {
   int32_t lam;
 };
 
+#define PK_MAX_PHASES 8
+
 struct PkArgs {
   const double* x;        // NLP variables (device)
   const double* lam;      // constraint multipliers (device; Hessian only)
-  double* out;            // f | grad[n] | g[m] | J[nnz_J] | H[nnz_H]
+  double* o_f;            // outputs (device); a launch writes only the ones its kernel produces
+  double* o_grad;         // [n]
+  double* o_g;            // [m]
+  double* o_jac;          // [nnz_J]
+  double* o_hess;         // [nnz_H]
   double sigma;           // objective factor (Hessian only)
   const PkPhase* phase;
   const PkTile* tile;
@@ -77,12 +89,14 @@ struct PkArgs {
   const double* db;
   const int64_t* lb;
   double* Ibuf;           // integrals I_k (pre-pass result)
-  double* partial;        // [n_tiles][PK_NRED] per-wave partial sums
+  double* partial;        // [workgroups][PK_NRED] per-workgroup partial sums of the integrands
+  double* partial2;       // [workgroups][PK_NRED] per-workgroup partial sums of the shared gradient slots
   int32_t n_tiles, n_items;
   int32_t n_phase, n;
   int32_t l_s, n_s, n_sys, m;
   int32_t gz_off, n_gz;   // ib: gradient slots the finalize kernel zero-fills
-  int32_t flags;          // bit 0: pk_intfin writes f; bit 1: secondary shard (no system-level / boundary work);
-                          // bit 2: pk_intfin skips the reduction (Ibuf already holds the global integrals)
+  int32_t flags;          // bit 0: pk_fin writes f; bit 1: secondary shard (no system-level / boundary work);
+                          // bit 3: pk_fin reduces the integrals into Ibuf; bit 4: pk_fin reduces the gradient slots
   int32_t pad;
+  PkPhase ph[PK_MAX_PHASES];   // the phases by value (kernarg segment): no dependent global load
 };

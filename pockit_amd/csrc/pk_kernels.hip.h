@@ -1,19 +1,23 @@
 // pk_kernels.hip.h -- hand-written CDNA4 (gfx950) kernels of the NLP-callback evaluator.
 //
 // The generated model code (pockit_amd/codegen.py) supplies, per phase, a struct P with
-// straight-line fp64 functions (mid_g, mid_int, mid_jac, front_jac, ...) and a struct Gen that
-// dispatches on the phase id.  Everything about *how* the work is mapped to the GPU lives here.
+// straight-line fp64 functions (mid_g, mid_int, mid_jac, mid_xall, front_jac, ...) and a struct Gen
+// that dispatches on the phase id.  Everything about *how* the work is mapped to the GPU lives here.
 //
 // Work decomposition: a *tile* is a run of consecutive mesh intervals of
 // one pattern with at most 64 collocation nodes; one 64-lane wavefront owns one tile:
 //   phase A  lane = node: coalesced 8-byte loads of the trajectory vector (states/controls are
 //            stored node-contiguous per variable), model evaluation in registers, the per-node
-//            derivative values that are needed K times are staged in LDS ([segment][lane]);
+//            values that are needed by all K rows of the interval are staged in LDS ([segment][lane]);
 //   phase B  lane = output position: every I-expanded segment of the tile is a contiguous run of
 //            nj * K^2 doubles in the output array; the wave streams them out in 512-byte coalesced
 //            stores, reading the staged values from LDS (broadcast within an interval).
 // Four independent waves share a 256-thread workgroup (one __syncthreads between the phases).
 // One extra workgroup per launch handles the boundary nodes and the system-level scalars.
+// Sums over all nodes (integrals, gradient entries of t0/tf/static parameters) are reduced
+// wave -> workgroup in the tile kernels and workgroup -> total by the single-workgroup pk_fin, in a
+// fixed order (bit-reproducible).  (An in-launch "last workgroup finalizes" variant was measured
+// slower: the agent-scope hand-off costs 5-6 dependent memory round trips)
 //
 // Reference semantics restated by each kernel are cited at the kernel.
 #pragma once
@@ -50,9 +54,9 @@ __device__ __forceinline__ void phase_scalars(const PkArgs& A, const PkPhase& ph
 }
 
 template <class P>
-__device__ __forceinline__ double phase_dt(const PkArgs& A, int phase) {
+__device__ __forceinline__ double phase_dt(const PkArgs& A) {
   double s[PK_NS], dt, mt;
-  phase_scalars<P>(A, A.phase[phase], s, dt, mt);
+  phase_scalars<P>(A, A.ph[P::INDEX], s, dt, mt);
   return dt;
 }
 
@@ -91,13 +95,114 @@ __device__ __forceinline__ TileGeom tile_geom(const PkTile& tl) {
   return g;
 }
 
+// ---- shared pieces of the tile kernels ---------------------------------------------------------
+
+// collocation defects of the tile's rows:  (x_q - x_end) - dt * sum_c (I_hat[r,c] d/2) f_i(c)
+// f staged in LDS as fsv[i * 64 + lane]                  (phasebase.py:1008-1012; batched small GEMV)
+template <class P>
+__device__ __forceinline__ void write_defects(const PkArgs& A, const PkPhase& ph, const PkTile& tl,
+                                              const TileGeom& g, const double* s, double dt,
+                                              const double* __restrict__ fsv, const double* xr, int lane) {
+  const int nrows = tl.nj * g.R;
+  if (lane >= nrows) return;
+  const int jj = lane / g.R, r = lane - jj * g.R;
+  const double* __restrict__ full = A.db + tl.full_off + r * g.K;
+  const double width = A.db[ph.width_off + tl.j0 + jj];
+  const int endslot = tl.q0 + (jj + 1) * g.stride;
+  const int back_slot = P::SCHEME ? ph.L_m - 1 : ph.L_m;
+  const double* __restrict__ xp = A.x + ph.x_off;
+  const double* __restrict__ f = fsv + jj * g.stride;
+  double acc[P::NX], xe[P::NX];
+#pragma unroll
+  for (int i = 0; i < P::NX; ++i) {
+    acc[i] = 0.0;
+    xe[i] = xp[i * ph.state_len + endslot];
+  }
+#pragma unroll 4
+  for (int c = 0; c < g.K; ++c) {
+    const double a = full[c] * width * 0.5;      // (I_hat * d) / 2 as the reference scales it
+#pragma unroll
+    for (int i = 0; i < P::NX; ++i) acc[i] += a * f[i * PK_WAVE + c];
+  }
+#pragma unroll
+  for (int i = 0; i < P::NX; ++i) {
+    if (endslot == back_slot) xe[i] = P::back_value(i, xe[i], s);
+    A.o_g[ph.g_off + i * ph.L_d + tl.r0 + lane] = (xr[i] - xe[i]) - acc[i] * dt;
+  }
+}
+
+// constant translation entries of every state (phasebase.py:1077)
+template <class P>
+__device__ __forceinline__ void write_translation(const PkArgs& A, const PkPhase& ph, const PkTile& tl, int lane) {
+  const int tot = tl.nj * tl.nnzT;
+  const double* __restrict__ tv = A.db + tl.tv_off;
+  const int64_t* __restrict__ tb = A.lb + ph.jt_off;
+  for (int p = lane; p < tot; p += PK_WAVE) {
+    const double v = tv[p % tl.nnzT];
+#pragma unroll
+    for (int i = 0; i < P::NX; ++i) A.o_jac[tb[i] + tl.offT + p] = v;
+  }
+}
+
+// streaming phase: out[base_e + offI + p] = -(I_hat[t] d/2) * sv_e[col(p)] (* lambda[row(p)])
+// (phasebase.py:1120-1124 and 1280-1285 -- the gather-multiply-concatenate that dominates the reference)
+template <class P, int NI, bool HESS>
+__device__ __forceinline__ void stream_expanded(const PkArgs& A, const PkPhase& ph, const PkTile& tl,
+                                                const TileGeom& g, const double* __restrict__ sv,
+                                                const int64_t* __restrict__ segb, double* __restrict__ out,
+                                                int lane) {
+  if (NI == 0) return;
+  const int nnz = tl.nnzI;
+  const int tot = tl.nj * nnz;
+  if (tot == 0) return;
+  const int32_t* __restrict__ rc = A.ib + tl.irc_off;
+  const double* __restrict__ iv = A.db + tl.iv_off;
+  const double* __restrict__ wd = A.db + ph.width_off + tl.j0;
+  const uint32_t magic = 0xFFFFFFFFu / (uint32_t)nnz + 1u;   // p / nnz for p < 2^16
+  for (int p = lane; p < tot; p += PK_WAVE) {
+    const int jj = (int)__umulhi((uint32_t)p, magic);
+    const int t = p - jj * nnz;
+    const int r = rc[2 * t], c = rc[2 * t + 1];
+    const double val = -(iv[t] * wd[jj] * 0.5);
+    const double* __restrict__ col = sv + jj * g.stride + c;
+    const size_t at = (size_t)tl.offI + p;
+    if (HESS) {
+      const double* __restrict__ lam = A.lam + ph.g_off + tl.r0 + jj * g.R + r;
+#pragma unroll
+      for (int e = 0; e < NI; ++e) out[segb[e] + at] = val * lam[P::H_state(e) * ph.L_d] * col[e * PK_WAVE];
+    } else {
+#pragma unroll
+      for (int e = 0; e < NI; ++e) out[segb[e] + at] = val * col[e * PK_WAVE];
+    }
+  }
+}
+
+// per-node gradient entries: own variable slots directly, shared slots into orr   (systembase.py:646-657)
+template <class P>
+__device__ __forceinline__ void node_gradient(const PkArgs& A, const PkPhase& ph, int q, const double* a,
+                                              double tau, double dt, double w, const PkSys& sy, double* ov,
+                                              double* orr, bool have_mid) {
+  if (q == 0)
+    P::front_grad(a, tau, dt, w, sy, nullptr, ov, orr);
+  else if (P::SCHEME == 1 && q == ph.L_m - 1)
+    P::back_grad(a, tau, dt, w, sy, nullptr, ov, orr);
+  else if (!have_mid)
+    P::mid_grad(a, tau, dt, w, sy, nullptr, ov, orr);
+  double* __restrict__ gp = A.o_grad + ph.x_off;
+#pragma unroll
+  for (int i = 0; i < P::NX; ++i) gp[i * ph.state_len + q] = ov[i];
+#pragma unroll
+  for (int i = 0; i < P::NU; ++i) gp[P::NX * ph.state_len + i * ph.L_m + q] = ov[P::NX + i];
+}
+
 // ============================================================================================
-// pre-pass: integrand values -> per-tile partial sums of w * phi      (phasebase.py:997-1006)
+// integrand values -> per-wave sums of w * phi      (phasebase.py:997-1006)
 // ============================================================================================
 template <class P>
-__device__ __forceinline__ void tile_int(const PkArgs& A, const PkTile& tl, double* __restrict__, int lane) {
+__device__ __forceinline__ void tile_int(const PkArgs& A, const PkTile& tl, double* __restrict__,
+                                         double* __restrict__ wint, double* __restrict__, int lane) {
   if (P::INT_N == 0) return;
-  const PkPhase& ph = A.phase[tl.phase];
+  const PkPhase& ph = A.ph[P::INDEX];
   const TileGeom g = tile_geom<P>(tl);
   double s[PK_NS], dt, mt;
   phase_scalars<P>(A, ph, s, dt, mt);
@@ -111,21 +216,20 @@ __device__ __forceinline__ void tile_int(const PkArgs& A, const PkTile& tl, doub
 #pragma unroll
     for (int r = 0; r < P::INT_N; ++r) o[r] *= w;
   }
-  const int t = blockIdx.x * PK_WAVES_PER_BLOCK + (threadIdx.x >> 6);
 #pragma unroll
   for (int r = 0; r < P::INT_N; ++r) {
     const double v = wave_sum(o[r]);
-    if (lane == 0 && tl.nj > 0) A.partial[(size_t)t * PK_NRED + r] = v;
+    if (lane == 0) wint[r] = v;
   }
 }
 
 // ============================================================================================
-// constraints: collocation defects  x_q - x_end - dt * (d/2) * I_hat f   and path-constraint values
-// (phasebase.py:1008-1021; the K x K block product is the batched small GEMV of the path)
+// constraints: collocation defects and path-constraint values      (phasebase.py:1008-1021)
 // ============================================================================================
 template <class P>
-__device__ __forceinline__ void tile_g(const PkArgs& A, const PkTile& tl, double* __restrict__ sv, int lane) {
-  const PkPhase& ph = A.phase[tl.phase];
+__device__ __forceinline__ void tile_g(const PkArgs& A, const PkTile& tl, double* __restrict__ sv,
+                                       double* __restrict__, double* __restrict__, int lane) {
+  const PkPhase& ph = A.ph[P::INDEX];
   const TileGeom g = tile_geom<P>(tl);
   double s[PK_NS], dt, mt;
   phase_scalars<P>(A, ph, s, dt, mt);
@@ -142,38 +246,20 @@ __device__ __forceinline__ void tile_g(const PkArgs& A, const PkTile& tl, double
     }
     if (lane < g.nown) {
 #pragma unroll
-      for (int j = 0; j < P::NC; ++j) A.out[ph.path_off + j * ph.L_m + q] = o[P::NX + j];
+      for (int j = 0; j < P::NC; ++j) A.o_g[ph.path_off + j * ph.L_m + q] = o[P::NX + j];
     }
   }
   __syncthreads();
-  const int nrows = tl.nj * g.R;
-  if (lane < nrows) {
-    const int jj = lane / g.R, r = lane - jj * g.R;
-    const PkKind& kd = A.kind[tl.kidf];
-    const double* __restrict__ full = A.db + kd.full_off + r * g.K;
-    const double width = A.db[ph.width_off + tl.j0 + jj];
-    const int endslot = tl.q0 + (jj + 1) * g.stride;
-    const int back_slot = P::SCHEME ? ph.L_m - 1 : ph.L_m;
-    const double* __restrict__ xp = A.x + ph.x_off;
-    const double* __restrict__ f = sv + jj * g.stride;
-#pragma unroll
-    for (int i = 0; i < P::NX; ++i) {
-      double acc = 0.0;
-      for (int c = 0; c < g.K; ++c) acc += (full[c] * width * 0.5) * f[i * PK_WAVE + c];
-      double xe = xp[i * ph.state_len + endslot];
-      if (endslot == back_slot) xe = P::back_value(i, xe, s);
-      A.out[ph.g_off + i * ph.L_d + tl.r0 + lane] = (xr[i] - xe) - acc * dt;
-    }
-  }
+  write_defects<P>(A, ph, tl, g, s, dt, sv, xr, lane);
 }
 
 // ============================================================================================
-// dense objective gradient: per-node variable slots + per-tile partial sums for the slots shared
-// by all nodes (t0, tf, static parameters)              (phasebase.py:1036-1068, systembase.py:625-657)
+// dense objective gradient      (phasebase.py:1036-1068, systembase.py:625-657)
 // ============================================================================================
 template <class P>
-__device__ __forceinline__ void tile_grad(const PkArgs& A, const PkTile& tl, double* __restrict__, int lane) {
-  const PkPhase& ph = A.phase[tl.phase];
+__device__ __forceinline__ void tile_grad(const PkArgs& A, const PkTile& tl, double* __restrict__,
+                                          double* __restrict__, double* __restrict__ wgrad, int lane) {
+  const PkPhase& ph = A.ph[P::INDEX];
   const TileGeom g = tile_geom<P>(tl);
   double s[PK_NS], dt, mt;
   phase_scalars<P>(A, ph, s, dt, mt);
@@ -185,66 +271,22 @@ __device__ __forceinline__ void tile_grad(const PkArgs& A, const PkTile& tl, dou
     const int q = tl.q0 + lane;
     double a[P::NARG], tau, w, ov[P::NX + P::NU];
     load_node<P>(A, ph, s, dt, mt, q, a, tau, w);
-    if (q == 0)
-      P::front_grad(a, tau, dt, w, sy, nullptr, ov, orr);
-    else if (P::SCHEME == 1 && q == ph.L_m - 1)
-      P::back_grad(a, tau, dt, w, sy, nullptr, ov, orr);
-    else
-      P::mid_grad(a, tau, dt, w, sy, nullptr, ov, orr);
-    double* __restrict__ gp = A.out + ph.x_off;
-#pragma unroll
-    for (int i = 0; i < P::NX; ++i) gp[i * ph.state_len + q] = ov[i];
-#pragma unroll
-    for (int i = 0; i < P::NU; ++i) gp[P::NX * ph.state_len + i * ph.L_m + q] = ov[P::NX + i];
+    node_gradient<P>(A, ph, q, a, tau, dt, w, sy, ov, orr, false);
   }
-  const int t = blockIdx.x * PK_WAVES_PER_BLOCK + (threadIdx.x >> 6);
 #pragma unroll
   for (int r = 0; r < P::GR_NR; ++r) {
     const double v = wave_sum(orr[r]);
-    if (lane == 0 && tl.nj > 0) A.partial[(size_t)t * PK_NRED + r] = v;
+    if (lane == 0) wgrad[r] = v;
   }
 }
 
 // ============================================================================================
-// Jacobian / Hessian streaming phase: out[base_e + offI + p] = -(I_hat[t] d/2) * sv_e[col(p)] (* lambda[row(p)])
-// (phasebase.py:1120-1124 and 1280-1285 -- the gather-multiply-concatenate that dominates the reference)
+// Jacobian      (phasebase.py:1070-1152)
 // ============================================================================================
-template <class P, int NI, bool WITH_LAMBDA>  // WITH_LAMBDA: Hessian (uses P::H_state)
-__device__ __forceinline__ void stream_expanded(const PkArgs& A, const PkPhase& ph, const PkTile& tl,
-                                                const TileGeom& g, const double* __restrict__ sv,
-                                                const int64_t* __restrict__ segb, int lane) {
-  if (NI == 0) return;
-  const PkKind& kd = A.kind[tl.kid];
-  const int nnz = kd.nnzI;
-  const int tot = tl.nj * nnz;
-  if (tot == 0) return;
-  const int32_t* __restrict__ rc = A.ib + kd.irc_off;
-  const double* __restrict__ iv = A.db + kd.iv_off;
-  const double* __restrict__ wd = A.db + ph.width_off + tl.j0;
-  const uint32_t magic = 0xFFFFFFFFu / (uint32_t)nnz + 1u;   // p / nnz for p < 2^16
-  double* __restrict__ out = A.out;
-  for (int p = lane; p < tot; p += PK_WAVE) {
-    const int jj = (int)__umulhi((uint32_t)p, magic);
-    const int t = p - jj * nnz;
-    const int r = rc[2 * t], c = rc[2 * t + 1];
-    const double val = -(iv[t] * wd[jj] * 0.5);
-    const double* __restrict__ col = sv + jj * g.stride + c;
-    const size_t at = (size_t)tl.offI + p;
-    if (WITH_LAMBDA) {
-      const double* __restrict__ lam = A.lam + ph.g_off + tl.r0 + jj * g.R + r;
-#pragma unroll
-      for (int e = 0; e < NI; ++e)
-        out[segb[e] + at] = val * lam[P::H_state(e) * ph.L_d] * col[e * PK_WAVE];
-    } else {
-#pragma unroll
-      for (int e = 0; e < NI; ++e) out[segb[e] + at] = val * col[e * PK_WAVE];
-    }
-  }
-}
-
 template <class P>
-__device__ __forceinline__ void tile_jac(const PkArgs& A, const PkTile& tl, double* __restrict__ sv, int lane) {
-  const PkPhase& ph = A.phase[tl.phase];
+__device__ __forceinline__ void tile_jac(const PkArgs& A, const PkTile& tl, double* __restrict__ sv,
+                                         double* __restrict__, double* __restrict__, int lane) {
+  const PkPhase& ph = A.ph[P::INDEX];
   const TileGeom g = tile_geom<P>(tl);
   double s[PK_NS], dt, mt;
   phase_scalars<P>(A, ph, s, dt, mt);
@@ -259,28 +301,22 @@ __device__ __forceinline__ void tile_jac(const PkArgs& A, const PkTile& tl, doub
     for (int e = 0; e < P::J_NI; ++e) sv[e * PK_WAVE + lane] = o[e];
     if (lane < g.nown && q >= ph.mid_lo && q < ph.mid_hi) {
 #pragma unroll
-      for (int e = 0; e < P::J_NN; ++e) A.out[segb[P::J_NI + e] + (q - ph.mid_lo)] = o[P::J_NI + e];
+      for (int e = 0; e < P::J_NN; ++e) A.o_jac[segb[P::J_NI + e] + (q - ph.mid_lo)] = o[P::J_NI + e];
     }
   }
   __syncthreads();
   if (tl.nj == 0) return;
-  {  // constant translation entries of every state (phasebase.py:1077)
-    const PkKind& kd = A.kind[tl.kid];
-    const int tot = tl.nj * kd.nnzT;
-    const double* __restrict__ tv = A.db + kd.tv_off;
-    const int64_t* __restrict__ tb = A.lb + ph.jt_off;
-    for (int p = lane; p < tot; p += PK_WAVE) {
-      const double v = tv[p % kd.nnzT];
-#pragma unroll
-      for (int i = 0; i < P::NX; ++i) A.out[tb[i] + tl.offT + p] = v;
-    }
-  }
-  stream_expanded<P, P::J_NI, false>(A, ph, tl, g, sv, segb, lane);
+  write_translation<P>(A, ph, tl, lane);
+  stream_expanded<P, P::J_NI, false>(A, ph, tl, g, sv, segb, A.o_jac, lane);
 }
 
+// ============================================================================================
+// Hessian of the Lagrangian      (phasebase.py:1211-1337, systembase.py:735-835)
+// ============================================================================================
 template <class P>
-__device__ __forceinline__ void tile_hess(const PkArgs& A, const PkTile& tl, double* __restrict__ sv, int lane) {
-  const PkPhase& ph = A.phase[tl.phase];
+__device__ __forceinline__ void tile_hess(const PkArgs& A, const PkTile& tl, double* __restrict__ sv,
+                                          double* __restrict__, double* __restrict__, int lane) {
+  const PkPhase& ph = A.ph[P::INDEX];
   const TileGeom g = tile_geom<P>(tl);
   double s[PK_NS], dt, mt;
   phase_scalars<P>(A, ph, s, dt, mt);
@@ -297,19 +333,85 @@ __device__ __forceinline__ void tile_hess(const PkArgs& A, const PkTile& tl, dou
     for (int e = 0; e < P::H_NI; ++e) sv[e * PK_WAVE + lane] = o[e];
     if (lane < g.nown && q >= ph.mid_lo && q < ph.mid_hi) {
 #pragma unroll
-      for (int e = 0; e < P::H_NN; ++e) A.out[segb[P::H_NI + e] + (q - ph.mid_lo)] = o[P::H_NI + e];
+      for (int e = 0; e < P::H_NN; ++e) A.o_hess[segb[P::H_NI + e] + (q - ph.mid_lo)] = o[P::H_NI + e];
     }
   }
   __syncthreads();
   if (tl.nj == 0) return;
-  stream_expanded<P, P::H_NI, true>(A, ph, tl, g, sv, segb, lane);
+  stream_expanded<P, P::H_NI, true>(A, ph, tl, g, sv, segb, A.o_hess, lane);
+}
+
+// ============================================================================================
+// fused x-callbacks: f (integrand sums), grad f, g and J of one tile from ONE evaluation of the node
+// (one joint CSE over all model functions; x read once).  Used by pk_eval_cycle_dev.
+// LDS: [NX dynamics values | J_NI Jacobian segments] x 64 lanes.
+// ============================================================================================
+template <class P>
+__device__ __forceinline__ void tile_xall(const PkArgs& A, const PkTile& tl, double* __restrict__ sv,
+                                          double* __restrict__ wint, double* __restrict__ wgrad, int lane) {
+  const PkPhase& ph = A.ph[P::INDEX];
+  const TileGeom g = tile_geom<P>(tl);
+  double s[PK_NS], dt, mt;
+  phase_scalars<P>(A, ph, s, dt, mt);
+  const PkSys sy{s, A.Ibuf, A.sigma, A.lam};
+  const int64_t* __restrict__ segb = A.lb + ph.jseg_off;
+  double* __restrict__ jsv = sv + P::NX * PK_WAVE;
+  double xr[P::NX];
+  double oi[P::INT_N > 0 ? P::INT_N : 1], orr[P::GR_NR > 0 ? P::GR_NR : 1];
+#pragma unroll
+  for (int r = 0; r < P::INT_N; ++r) oi[r] = 0.0;
+#pragma unroll
+  for (int r = 0; r < P::GR_NR; ++r) orr[r] = 0.0;
+  if (lane < g.nq) {
+    const int q = tl.q0 + lane;
+    double a[P::NARG], tau, w;
+    double og[P::G_NOUT], oj[P::J_NI + P::J_NN + 1], ov[P::NX + P::NU], ot[P::GR_NR > 0 ? P::GR_NR : 1],
+        op[P::INT_N > 0 ? P::INT_N : 1];
+    load_node<P>(A, ph, s, dt, mt, q, a, tau, w);
+    P::mid_xall(a, tau, dt, w, sy, og, oj, ov, ot, op);
+#pragma unroll
+    for (int i = 0; i < P::NX; ++i) {
+      sv[i * PK_WAVE + lane] = og[i];
+      xr[i] = a[i];
+    }
+#pragma unroll
+    for (int e = 0; e < P::J_NI; ++e) jsv[e * PK_WAVE + lane] = oj[e];
+    if (lane < g.nown) {
+#pragma unroll
+      for (int j = 0; j < P::NC; ++j) A.o_g[ph.path_off + j * ph.L_m + q] = og[P::NX + j];
+      if (q >= ph.mid_lo && q < ph.mid_hi) {
+#pragma unroll
+        for (int e = 0; e < P::J_NN; ++e) A.o_jac[segb[P::J_NI + e] + (q - ph.mid_lo)] = oj[P::J_NI + e];
+      }
+#pragma unroll
+      for (int r = 0; r < P::INT_N; ++r) oi[r] = op[r] * w;
+#pragma unroll
+      for (int r = 0; r < P::GR_NR; ++r) orr[r] = ot[r];
+      node_gradient<P>(A, ph, q, a, tau, dt, w, sy, ov, orr, true);   // boundary nodes re-evaluate their own entries
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < P::INT_N; ++r) {
+    const double v = wave_sum(oi[r]);
+    if (lane == 0) wint[r] = v;
+  }
+#pragma unroll
+  for (int r = 0; r < P::GR_NR; ++r) {
+    const double v = wave_sum(orr[r]);
+    if (lane == 0) wgrad[r] = v;
+  }
+  __syncthreads();
+  write_defects<P>(A, ph, tl, g, s, dt, sv, xr, lane);
+  if (tl.nj == 0) return;
+  write_translation<P>(A, ph, tl, lane);
+  stream_expanded<P, P::J_NI, false>(A, ph, tl, g, jsv, segb, A.o_jac, lane);
 }
 
 // ---- boundary-node evaluation for the edge workgroup -----------------------------------------
 template <class P>
-__device__ __forceinline__ void load_edge(const PkArgs& A, int phase, int back, double* s, double* a, double& tau,
+__device__ __forceinline__ void load_edge(const PkArgs& A, int back, double* s, double* a, double& tau,
                                           double& dt, double& w, double* lp) {
-  const PkPhase& ph = A.phase[phase];
+  const PkPhase& ph = A.ph[P::INDEX];
   double mt;
   phase_scalars<P>(A, ph, s, dt, mt);
   const int q = back ? ph.L_m - 1 : 0;
@@ -320,26 +422,41 @@ __device__ __forceinline__ void load_edge(const PkArgs& A, int phase, int back, 
   }
 }
 
-__device__ __forceinline__ void scatter_items(const PkArgs& A, const double* __restrict__ E) {
+__device__ __forceinline__ void scatter_items(const PkArgs& A, const double* __restrict__ E, double* __restrict__ out) {
   for (int it = threadIdx.x; it < A.n_items; it += PK_BLOCK) {
     const PkItem m = A.items[it];
     double v = m.coef * E[m.eid];
     if (m.lam >= 0) v *= A.lam[m.lam];
-    A.out[m.pos] = v;
+    out[m.pos] = v;
   }
 }
 
-// deterministic block sum of partial[t * PK_NRED + r], t in [lo, hi)
-__device__ __forceinline__ double block_sum_partials(const PkArgs& A, int lo, int hi, int r, double* red) {
+// The four wave sums of a workgroup -> one partial per workgroup.  The host pads every phase's tile
+// list to a multiple of PK_WAVES_PER_BLOCK (empty tiles), so a workgroup never mixes phases.
+__device__ __forceinline__ void publish_block_partials(double* __restrict__ partial, const double* __restrict__ wred) {
+  __syncthreads();
+  if ((int)threadIdx.x < PK_NRED) {
+    double v = 0.0;
+#pragma unroll
+    for (int w = 0; w < PK_WAVES_PER_BLOCK; ++w) v += wred[w * PK_NRED + threadIdx.x];
+    partial[(size_t)blockIdx.x * PK_NRED + threadIdx.x] = v;
+  }
+}
+
+// deterministic sum over the workgroups of phase k (fixed shape: strided thread sums, wave shuffle
+// tree, 4-way LDS combine)
+__device__ __forceinline__ double block_sum_partials(const PkArgs& A, const double* __restrict__ partial, int k,
+                                                     int r, double* red) {
+  const int blo = A.ph[k].tile_lo / PK_WAVES_PER_BLOCK, bhi = A.ph[k].tile_hi / PK_WAVES_PER_BLOCK;
   double v = 0.0;
-  for (int t = lo + (int)threadIdx.x; t < hi; t += PK_BLOCK) v += A.partial[(size_t)t * PK_NRED + r];
+  for (int b = blo + (int)threadIdx.x; b < bhi; b += PK_BLOCK) v += partial[(size_t)b * PK_NRED + r];
   v = wave_sum(v);
   __syncthreads();
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
   __syncthreads();
   double tot = 0.0;
 #pragma unroll
-  for (int k = 0; k < PK_WAVES_PER_BLOCK; ++k) tot += red[k];
+  for (int w = 0; w < PK_WAVES_PER_BLOCK; ++w) tot += red[w];
   return tot;
 }
 
@@ -348,6 +465,8 @@ __device__ __forceinline__ double block_sum_partials(const PkArgs& A, int lo, in
 // ============================================================================================
 #define PK_TILE_PROLOGUE()                                                            \
   extern __shared__ double pk_lds[];                                                  \
+  __shared__ double wint[PK_WAVES_PER_BLOCK * PK_NRED];                               \
+  __shared__ double wgrad[PK_WAVES_PER_BLOCK * PK_NRED];                              \
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;                         \
   const int ti = blockIdx.x * PK_WAVES_PER_BLOCK + wave;                              \
   PkTile tl;                                                                          \
@@ -356,115 +475,122 @@ __device__ __forceinline__ double block_sum_partials(const PkArgs& A, int lo, in
   } else {                                                                            \
     tl = A.tile[A.n_tiles > 0 ? A.n_tiles - 1 : 0];                                   \
     tl.nj = 0;                                                                        \
+  }                                                                                   \
+  if (lane < PK_NRED) {                                                               \
+    wint[wave * PK_NRED + lane] = 0.0;                                                \
+    wgrad[wave * PK_NRED + lane] = 0.0;                                               \
   }
+
+#define PK_IS_EDGE_BLOCK() ((int)blockIdx.x == (A.n_tiles + PK_WAVES_PER_BLOCK - 1) / PK_WAVES_PER_BLOCK)
+
+template <class Gen>
+__device__ __forceinline__ void edge_block(const PkArgs& A, bool hess, bool with_g) {
+  extern __shared__ double pk_lds[];
+  const PkSys sy{A.x + A.l_s, A.Ibuf, A.sigma, A.lam};
+  if (A.flags & 2) return;   // secondary shard: boundary nodes / system level belong to the primary
+  if (with_g && threadIdx.x == PK_BLOCK - 1 && A.n_sys > 0) Gen::sys_constraints(sy, A.o_g);   // systembase.py:607-611
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  for (int li = wave; li < Gen::NLISTS; li += PK_WAVES_PER_BLOCK)
+    if (lane == 0) {
+      if (hess) Gen::edge_hess(li, A, sy, pk_lds); else Gen::edge_jac(li, A, sy, pk_lds);
+    }
+  __syncthreads();
+  scatter_items(A, pk_lds, hess ? A.o_hess : A.o_jac);
+}
 
 template <class Gen>
 __device__ __forceinline__ void kernel_int(const PkArgs& A) {
   PK_TILE_PROLOGUE();
-  Gen::tile_int(tl.phase, A, tl, pk_lds, lane);
-}
-
-// single workgroup: I_k = dt * sum of partials; optionally f = F_o(I, s)   (systembase.py:592-605)
-template <class Gen>
-__device__ __forceinline__ void kernel_intfin(const PkArgs& A) {
-  __shared__ double red[PK_WAVES_PER_BLOCK];
-  for (int n = 0; n < Gen::N_INT && !(A.flags & 4); ++n) {
-    const int k = Gen::int_phase(n);
-    const double sum = block_sum_partials(A, A.phase[k].tile_lo, A.phase[k].tile_hi, Gen::int_slot(n), red);
-    if (threadIdx.x == 0) A.Ibuf[Gen::int_global(n)] = sum * Gen::phase_dt(k, A);
-  }
-  __syncthreads();
-  if (threadIdx.x == 0 && (A.flags & 1)) {
-    __threadfence_block();
-    const PkSys sy{A.x + A.l_s, A.Ibuf, A.sigma, A.lam};
-    A.out[0] = Gen::sys_objective(sy);
-  }
+  Gen::tile_int(tl.phase, A, tl, pk_lds, wint + wave * PK_NRED, wgrad + wave * PK_NRED, lane);
+  publish_block_partials(A.partial, wint);
 }
 
 template <class Gen>
 __device__ __forceinline__ void kernel_g(const PkArgs& A) {
-  if ((int)blockIdx.x == (A.n_tiles + PK_WAVES_PER_BLOCK - 1) / PK_WAVES_PER_BLOCK) {
-    if (threadIdx.x == 0 && A.n_sys > 0 && !(A.flags & 2)) {   // system constraints C(I, s)   (systembase.py:607-611)
+  if (PK_IS_EDGE_BLOCK()) {
+    if (threadIdx.x == 0 && A.n_sys > 0 && !(A.flags & 2)) {
       const PkSys sy{A.x + A.l_s, A.Ibuf, A.sigma, A.lam};
-      Gen::sys_constraints(sy, A.out);
+      Gen::sys_constraints(sy, A.o_g);
     }
     return;
   }
   PK_TILE_PROLOGUE();
-  Gen::tile_g(tl.phase, A, tl, pk_lds + wave * Gen::LDS_G, lane);
+  Gen::tile_g(tl.phase, A, tl, pk_lds + wave * Gen::LDS_G, wint, wgrad, lane);
 }
 
 template <class Gen>
 __device__ __forceinline__ void kernel_grad(const PkArgs& A) {
   PK_TILE_PROLOGUE();
-  Gen::tile_grad(tl.phase, A, tl, pk_lds, lane);
-}
-
-// single workgroup: reduce the per-tile partials into the shared slots  (systembase.py:654-657)
-template <class Gen>
-__device__ __forceinline__ void kernel_gradfin(const PkArgs& A) {
-  __shared__ double red[PK_WAVES_PER_BLOCK];
-  __shared__ double tot[PK_NPHASE * PK_NRED];
-  for (int k = 0; k < PK_NPHASE; ++k)
-    for (int r = 0; r < Gen::gr_nr(k); ++r) {
-      const double v = block_sum_partials(A, A.phase[k].tile_lo, A.phase[k].tile_hi, r, red);
-      if (threadIdx.x == 0) tot[k * PK_NRED + r] = v;
-    }
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    for (int z = 0; z < A.n_gz; ++z) A.out[A.ib[A.gz_off + z]] = 0.0;
-    for (int k = 0; k < PK_NPHASE; ++k)
-      for (int r = 0; r < Gen::gr_nr(k); ++r) A.out[A.ib[A.phase[k].red_off + r]] += tot[k * PK_NRED + r];
-    if (!(A.flags & 2)) {
-      const PkSys sy{A.x + A.l_s, A.Ibuf, A.sigma, A.lam};
-      double gs[PK_NS];
-      Gen::sys_grad_static(sy, gs);
-      for (int i = 0; i < A.n_s; ++i) A.out[A.l_s + i] += gs[i];
-    }
-  }
+  Gen::tile_grad(tl.phase, A, tl, pk_lds, wint + wave * PK_NRED, wgrad + wave * PK_NRED, lane);
+  publish_block_partials(A.partial2, wgrad);
 }
 
 template <class Gen>
 __device__ __forceinline__ void kernel_jac(const PkArgs& A) {
-  if ((int)blockIdx.x == (A.n_tiles + PK_WAVES_PER_BLOCK - 1) / PK_WAVES_PER_BLOCK) {
-    extern __shared__ double pk_lds[];
-    const PkSys sy{A.x + A.l_s, A.Ibuf, A.sigma, A.lam};
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    if (A.flags & 2) return;   // secondary shard: boundary nodes / system level belong to the primary
-    for (int li = wave; li < Gen::NLISTS; li += PK_WAVES_PER_BLOCK)
-      if (lane == 0) Gen::edge_jac(li, A, sy, pk_lds);
-    __syncthreads();
-    scatter_items(A, pk_lds);
-    return;
-  }
+  if (PK_IS_EDGE_BLOCK()) return edge_block<Gen>(A, false, false);
   PK_TILE_PROLOGUE();
-  Gen::tile_jac(tl.phase, A, tl, pk_lds + wave * Gen::LDS_J, lane);
+  Gen::tile_jac(tl.phase, A, tl, pk_lds + wave * Gen::LDS_J, wint, wgrad, lane);
 }
 
 template <class Gen>
 __device__ __forceinline__ void kernel_hess(const PkArgs& A) {
-  if ((int)blockIdx.x == (A.n_tiles + PK_WAVES_PER_BLOCK - 1) / PK_WAVES_PER_BLOCK) {
-    extern __shared__ double pk_lds[];
-    const PkSys sy{A.x + A.l_s, A.Ibuf, A.sigma, A.lam};
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    if (A.flags & 2) return;
-    for (int li = wave; li < Gen::NLISTS; li += PK_WAVES_PER_BLOCK)
-      if (lane == 0) Gen::edge_hess(li, A, sy, pk_lds);
-    __syncthreads();
-    scatter_items(A, pk_lds);
-    return;
-  }
+  if (PK_IS_EDGE_BLOCK()) return edge_block<Gen>(A, true, false);
   PK_TILE_PROLOGUE();
-  Gen::tile_hess(tl.phase, A, tl, pk_lds + wave * Gen::LDS_H, lane);
+  Gen::tile_hess(tl.phase, A, tl, pk_lds + wave * Gen::LDS_H, wint, wgrad, lane);
+}
+
+template <class Gen>
+__device__ __forceinline__ void kernel_xall(const PkArgs& A) {
+  if (PK_IS_EDGE_BLOCK()) return edge_block<Gen>(A, false, true);
+  PK_TILE_PROLOGUE();
+  Gen::tile_xall(tl.phase, A, tl, pk_lds + wave * Gen::LDS_X, wint + wave * PK_NRED, wgrad + wave * PK_NRED, lane);
+  publish_block_partials(A.partial, wint);
+  publish_block_partials(A.partial2, wgrad);
+}
+
+// single workgroup.  flags bit 3: I_k = dt * sum of partials -> Ibuf; bit 0: f = F_o(I, s) -> o_f
+// (systembase.py:592-605); bit 4: gradient slots shared by all nodes (systembase.py:654-657)
+template <class Gen>
+__device__ __forceinline__ void kernel_fin(const PkArgs& A) {
+  __shared__ double red[PK_WAVES_PER_BLOCK];
+  __shared__ double tot[PK_NPHASE * PK_NRED];
+  if (A.flags & 8) {
+    for (int n = 0; n < Gen::N_INT; ++n) {
+      const int k = Gen::int_phase(n);
+      const double sum = block_sum_partials(A, A.partial, k, Gen::int_slot(n), red);
+      if (threadIdx.x == 0) A.Ibuf[Gen::int_global(n)] = sum * Gen::phase_dt(k, A);
+    }
+  }
+  if (A.flags & 16) {
+    for (int k = 0; k < PK_NPHASE; ++k)
+      for (int r = 0; r < Gen::gr_nr(k); ++r) {
+        const double v = block_sum_partials(A, A.partial2, k, r, red);
+        if (threadIdx.x == 0) tot[k * PK_NRED + r] = v;
+      }
+  }
+  __syncthreads();
+  if (threadIdx.x != 0) return;
+  const PkSys sy{A.x + A.l_s, A.Ibuf, A.sigma, A.lam};
+  if (A.flags & 1) A.o_f[0] = Gen::sys_objective(sy);
+  if (A.flags & 16) {
+    for (int z = 0; z < A.n_gz; ++z) A.o_grad[A.ib[A.gz_off + z]] = 0.0;
+    for (int k = 0; k < PK_NPHASE; ++k)
+      for (int r = 0; r < Gen::gr_nr(k); ++r) A.o_grad[A.ib[A.ph[k].red_off + r]] += tot[k * PK_NRED + r];
+    if (!(A.flags & 2)) {
+      double gs[PK_NS];
+      Gen::sys_grad_static(sy, gs);
+      for (int i = 0; i < A.n_s; ++i) A.o_grad[A.l_s + i] += gs[i];
+    }
+  }
 }
 
 }  // namespace pk
 
-#define PK_DEFINE_KERNELS(GEN)                                                                       \
-  extern "C" __global__ __launch_bounds__(PK_BLOCK) void pk_int(PkArgs A) { pk::kernel_int<GEN>(A); }         \
-  extern "C" __global__ __launch_bounds__(PK_BLOCK) void pk_intfin(PkArgs A) { pk::kernel_intfin<GEN>(A); }   \
-  extern "C" __global__ __launch_bounds__(PK_BLOCK) void pk_g(PkArgs A) { pk::kernel_g<GEN>(A); }             \
-  extern "C" __global__ __launch_bounds__(PK_BLOCK) void pk_grad(PkArgs A) { pk::kernel_grad<GEN>(A); }       \
-  extern "C" __global__ __launch_bounds__(PK_BLOCK) void pk_gradfin(PkArgs A) { pk::kernel_gradfin<GEN>(A); } \
-  extern "C" __global__ __launch_bounds__(PK_BLOCK) void pk_jac(PkArgs A) { pk::kernel_jac<GEN>(A); }         \
-  extern "C" __global__ __launch_bounds__(PK_BLOCK) void pk_hess(PkArgs A) { pk::kernel_hess<GEN>(A); }
+#define PK_DEFINE_KERNELS(GEN)                                                                         \
+  extern "C" __global__ __launch_bounds__(PK_BLOCK) void pk_int(PkArgs A) { pk::kernel_int<GEN>(A); }   \
+  extern "C" __global__ __launch_bounds__(PK_BLOCK) void pk_fin(PkArgs A) { pk::kernel_fin<GEN>(A); }   \
+  extern "C" __global__ __launch_bounds__(PK_BLOCK) void pk_g(PkArgs A) { pk::kernel_g<GEN>(A); }       \
+  extern "C" __global__ __launch_bounds__(PK_BLOCK) void pk_grad(PkArgs A) { pk::kernel_grad<GEN>(A); } \
+  extern "C" __global__ __launch_bounds__(PK_BLOCK) void pk_jac(PkArgs A) { pk::kernel_jac<GEN>(A); }   \
+  extern "C" __global__ __launch_bounds__(PK_BLOCK) void pk_hess(PkArgs A) { pk::kernel_hess<GEN>(A); } \
+  extern "C" __global__ __launch_bounds__(PK_BLOCK) void pk_xall(PkArgs A) { pk::kernel_xall<GEN>(A); }

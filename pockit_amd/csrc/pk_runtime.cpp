@@ -5,11 +5,13 @@
 // integrals, per-tile partial sums).  It launches the kernels of the generated code object
 // (pockit_amd/codegen.py + csrc/pk_kernels.hip.h) in the order each NLP callback needs:
 //
-//   eval_f     [pk_int, pk_intfin(write f)]
-//   eval_grad  [pk_int, pk_intfin]?  pk_grad, pk_gradfin
-//   eval_g     [pk_int, pk_intfin]?  pk_g
-//   eval_jac   [pk_int, pk_intfin]?  pk_jac
-//   eval_hess  [pk_int, pk_intfin]?  pk_hess
+//   eval_f     pk_int, pk_fin(integrals, f)
+//   eval_grad  [pk_int, pk_fin(integrals)]?  pk_grad, pk_fin(gradient slots)
+//   eval_g     [pk_int, pk_fin(integrals)]?  pk_g
+//   eval_jac   [pk_int, pk_fin(integrals)]?  pk_jac
+//   eval_hess  [pk_int, pk_fin(integrals)]?  pk_hess
+//   cycle      pk_xall (f partials, grad f, g, J from one node evaluation), pk_fin(integrals, f, gradient
+//              slots), pk_hess
 // ("?" = only when a system-level function is nonlinear in the integrals, pk_model_desc.prepass_*).
 //
 // There is no CPU evaluation path: every entry point fails with an error code when no device /
@@ -27,8 +29,9 @@
 
 namespace {
 
-enum { K_INT = 0, K_INTFIN, K_G, K_GRAD, K_GRADFIN, K_JAC, K_HESS, K_COUNT };
-const char* const kKernelNames[K_COUNT] = {"pk_int", "pk_intfin", "pk_g", "pk_grad", "pk_gradfin", "pk_jac", "pk_hess"};
+enum { K_INT = 0, K_FIN, K_G, K_GRAD, K_JAC, K_HESS, K_XALL, K_COUNT };
+const char* const kKernelNames[K_COUNT] = {"pk_int", "pk_fin", "pk_g", "pk_grad", "pk_jac", "pk_hess", "pk_xall"};
+enum { F_WRITE_F = 1, F_SECONDARY = 2, F_FIN_INT = 8, F_FIN_GRAD = 16 };
 
 thread_local std::string g_create_error;
 
@@ -59,7 +62,9 @@ struct pk_ctx {
   int64_t* d_lb = nullptr;
   // work buffers
   double *d_x = nullptr, *d_lam = nullptr, *d_f = nullptr, *d_grad = nullptr, *d_g = nullptr, *d_J = nullptr,
-         *d_H = nullptr, *d_I = nullptr, *d_partial = nullptr;
+         *d_H = nullptr, *d_I = nullptr, *d_partial = nullptr, *d_partial2 = nullptr;
+  std::vector<PkPhase> h_phases;
+  std::vector<EventPair> free_events;
   std::vector<int32_t> jac_row, jac_col, hess_row, hess_col;
   // profiling
   bool profiling = false;
@@ -97,7 +102,7 @@ void free_problem(pk_ctx* c) {
   release(c->d_phases); release(c->d_tiles); release(c->d_kinds); release(c->d_items_jac); release(c->d_items_hess);
   release(c->d_ib); release(c->d_db); release(c->d_lb);
   release(c->d_x); release(c->d_lam); release(c->d_f); release(c->d_grad); release(c->d_g); release(c->d_J);
-  release(c->d_H); release(c->d_I); release(c->d_partial);
+  release(c->d_H); release(c->d_I); release(c->d_partial); release(c->d_partial2);
   c->have_problem = false;
 }
 
@@ -116,16 +121,17 @@ int ready(pk_ctx* c) {
   return 0;
 }
 
-PkArgs base_args(pk_ctx* c, const double* d_x, const double* d_lam, double sigma, double* d_out) {
+PkArgs base_args(pk_ctx* c, const double* d_x, const double* d_lam, double sigma) {
   PkArgs A;
   std::memset(&A, 0, sizeof A);
-  A.x = d_x; A.lam = d_lam; A.out = d_out; A.sigma = sigma;
+  A.x = d_x; A.lam = d_lam; A.sigma = sigma;
   A.phase = (const PkPhase*)c->d_phases; A.tile = (const PkTile*)c->d_tiles; A.kind = (const PkKind*)c->d_kinds;
   A.items = nullptr; A.ib = c->d_ib; A.db = c->d_db; A.lb = c->d_lb;
-  A.Ibuf = c->ext_I ? c->ext_I : c->d_I; A.partial = c->d_partial;
+  A.Ibuf = c->ext_I ? c->ext_I : c->d_I; A.partial = c->d_partial; A.partial2 = c->d_partial2;
   A.n_tiles = c->n_tiles; A.n_items = 0; A.n_phase = c->n_phase; A.n = c->n;
   A.l_s = c->l_s; A.n_s = c->n_s; A.n_sys = c->n_sys; A.m = c->m;
   A.gz_off = c->gz_off; A.n_gz = c->n_gz; A.flags = c->shard_flags;
+  for (size_t k = 0; k < c->h_phases.size(); ++k) A.ph[k] = c->h_phases[k];
   return A;
 }
 
@@ -136,8 +142,13 @@ int launch(pk_ctx* c, int k, PkArgs& A, unsigned grid, size_t lds_bytes, hipStre
   if (grid == 0) return 0;
   const bool timed = c->profiling && ((c->profile_mask >> k) & 1u);
   if (timed) {
-    PK_HIP(c, hipEventCreate(&ev.a));
-    PK_HIP(c, hipEventCreate(&ev.b));
+    if (!c->free_events.empty()) {
+      ev = c->free_events.back();
+      c->free_events.pop_back();
+    } else {
+      PK_HIP(c, hipEventCreate(&ev.a));
+      PK_HIP(c, hipEventCreate(&ev.b));
+    }
     PK_HIP(c, hipEventRecord(ev.a, st));
   }
   PK_HIP(c, hipModuleLaunchKernel(c->fn[k], grid, 1, 1, PK_BLOCK, 1, 1, (unsigned)lds_bytes, st, nullptr, config));
@@ -151,11 +162,12 @@ int launch(pk_ctx* c, int k, PkArgs& A, unsigned grid, size_t lds_bytes, hipStre
 unsigned tile_blocks(const pk_ctx* c) { return (unsigned)((c->n_tiles + PK_WAVES_PER_BLOCK - 1) / PK_WAVES_PER_BLOCK); }
 
 int prepass(pk_ctx* c, const double* d_x, const double* d_lam, double sigma, double* d_f, bool write_f, hipStream_t st) {
-  PkArgs A = base_args(c, d_x, d_lam, sigma, d_f);
+  PkArgs A = base_args(c, d_x, d_lam, sigma);
+  A.o_f = d_f;
   int rc = launch(c, K_INT, A, tile_blocks(c), 0, st);
   if (rc) return rc;
-  A.flags |= write_f ? 1 : 0;
-  return launch(c, K_INTFIN, A, 1, 0, st);
+  A.flags |= F_FIN_INT | (write_f ? F_WRITE_F : 0);
+  return launch(c, K_FIN, A, 1, 0, st);
 }
 
 hipStream_t pick(pk_ctx* c, void* stream) { return stream ? (hipStream_t)stream : c->stream; }
@@ -198,6 +210,7 @@ void pk_destroy(pk_ctx* c) {
   (void)hipStreamSynchronize(c->stream);
   for (int k = 0; k < K_COUNT; ++k)
     for (auto& ev : c->pending[k]) { (void)hipEventDestroy(ev.a); (void)hipEventDestroy(ev.b); }
+  for (auto& ev : c->free_events) { (void)hipEventDestroy(ev.a); (void)hipEventDestroy(ev.b); }
   free_problem(c);
   if (c->module) (void)hipModuleUnload(c->module);
   if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -215,7 +228,7 @@ int pk_load_model(pk_ctx* c, const void* code_object, size_t len, const pk_model
   for (int k = 0; k < K_COUNT; ++k) PK_HIP(c, hipModuleGetFunction(&c->fn[k], c->module, kKernelNames[k]));
   c->md = *md;
   const size_t lds_max = 160 * 1024;
-  const size_t need[3] = {(size_t)md->lds_g, (size_t)md->lds_j, (size_t)md->lds_h};
+  const size_t need[4] = {(size_t)md->lds_g, (size_t)md->lds_j, (size_t)md->lds_h, (size_t)md->lds_x};
   for (size_t v : need)
     if (v * PK_WAVES_PER_BLOCK * sizeof(double) > lds_max)
       return fail(c, 21, "pk_load_model: model needs %zu bytes of LDS per workgroup (> 160 KiB)", v * PK_WAVES_PER_BLOCK * sizeof(double));
@@ -227,6 +240,7 @@ int pk_set_problem(pk_ctx* c, const pk_problem_desc* pd) {
   if (!c) return fail(nullptr, 1, "null context");
   if (!c->have_model) return fail(c, 2, "pk_set_problem: load a model first");
   if (!pd) return fail(c, 30, "pk_set_problem: null descriptor");
+  if (pd->n_phase > PK_MAX_PHASES) return fail(c, 32, "pk_set_problem: at most %d phases are supported", PK_MAX_PHASES);
   if (pd->n_phase != c->md.n_phase) return fail(c, 31, "pk_set_problem: %d phases but the model was generated for %d", pd->n_phase, c->md.n_phase);
   PK_HIP(c, hipSetDevice(c->device));
   PK_HIP(c, hipStreamSynchronize(c->stream));
@@ -236,6 +250,8 @@ int pk_set_problem(pk_ctx* c, const pk_problem_desc* pd) {
   c->n_items_jac = pd->n_items_jac; c->n_items_hess = pd->n_items_hess; c->gz_off = pd->gz_off; c->n_gz = pd->n_gz;
   int rc;
   if ((rc = upload(c, &c->d_phases, pd->phases, sizeof(PkPhase) * (size_t)pd->n_phase))) return rc;
+  c->h_phases.assign((const PkPhase*)pd->phases, (const PkPhase*)pd->phases + pd->n_phase);
+
   if ((rc = upload(c, &c->d_tiles, pd->tiles, sizeof(PkTile) * (size_t)pd->n_tiles))) return rc;
   if ((rc = upload(c, &c->d_kinds, pd->kinds, sizeof(PkKind) * (size_t)pd->n_kinds))) return rc;
   if ((rc = upload(c, &c->d_items_jac, pd->items_jac, sizeof(PkItem) * (size_t)pd->n_items_jac))) return rc;
@@ -251,7 +267,8 @@ int pk_set_problem(pk_ctx* c, const pk_problem_desc* pd) {
   if ((rc = dalloc(&c->d_x, c->n)) || (rc = dalloc(&c->d_lam, c->m)) || (rc = dalloc(&c->d_f, 1)) ||
       (rc = dalloc(&c->d_grad, c->n)) || (rc = dalloc(&c->d_g, c->m)) || (rc = dalloc(&c->d_J, (size_t)c->nnz_J)) ||
       (rc = dalloc(&c->d_H, (size_t)c->nnz_H)) || (rc = dalloc(&c->d_I, c->md.n_I)) ||
-      (rc = dalloc(&c->d_partial, (size_t)c->n_tiles * (size_t)c->md.nred)))
+      (rc = dalloc(&c->d_partial, ((size_t)c->n_tiles / PK_WAVES_PER_BLOCK + 2) * (size_t)c->md.nred)) ||
+      (rc = dalloc(&c->d_partial2, ((size_t)c->n_tiles / PK_WAVES_PER_BLOCK + 2) * (size_t)c->md.nred)))
     return rc;
   auto keep = [](std::vector<int32_t>& v, const int32_t* src, int64_t cnt) {
     v.clear();
@@ -292,14 +309,15 @@ int pk_eval_integrals_dev(pk_ctx* c, const double* d_x, void* stream) {
 int pk_eval_f_from_integrals_dev(pk_ctx* c, const double* d_x, double* d_f, void* stream) {
   int rc = ready(c);
   if (rc) return rc;
-  PkArgs A = base_args(c, d_x, nullptr, 0.0, d_f);
-  A.flags |= 1 | 4;
-  return launch(c, K_INTFIN, A, 1, 0, pick(c, stream));
+  PkArgs A = base_args(c, d_x, nullptr, 0.0);
+  A.o_f = d_f;
+  A.flags |= F_WRITE_F;
+  return launch(c, K_FIN, A, 1, 0, pick(c, stream));
 }
 
 int pk_set_shard(pk_ctx* c, int secondary, int external_prepass, double* d_integrals) {
   if (!c) return fail(nullptr, 1, "null context");
-  c->shard_flags = secondary ? 2 : 0;
+  c->shard_flags = secondary ? F_SECONDARY : 0;
   c->external_prepass = external_prepass != 0;
   c->ext_I = d_integrals;
   return 0;
@@ -310,9 +328,11 @@ int pk_eval_grad_dev(pk_ctx* c, const double* d_x, double* d_grad, void* stream)
   if (rc) return rc;
   hipStream_t st = pick(c, stream);
   if (c->md.prepass_grad && !c->external_prepass && (rc = prepass(c, d_x, nullptr, 0.0, c->d_f, false, st))) return rc;
-  PkArgs A = base_args(c, d_x, nullptr, 0.0, d_grad);
+  PkArgs A = base_args(c, d_x, nullptr, 0.0);
+  A.o_grad = d_grad;
   if ((rc = launch(c, K_GRAD, A, tile_blocks(c), 0, st))) return rc;
-  return launch(c, K_GRADFIN, A, 1, 0, st);
+  A.flags |= F_FIN_GRAD;
+  return launch(c, K_FIN, A, 1, 0, st);
 }
 
 int pk_eval_g_dev(pk_ctx* c, const double* d_x, double* d_g, void* stream) {
@@ -320,7 +340,8 @@ int pk_eval_g_dev(pk_ctx* c, const double* d_x, double* d_g, void* stream) {
   if (rc) return rc;
   hipStream_t st = pick(c, stream);
   if (c->md.prepass_g && !c->external_prepass && (rc = prepass(c, d_x, nullptr, 0.0, c->d_f, false, st))) return rc;
-  PkArgs A = base_args(c, d_x, nullptr, 0.0, d_g);
+  PkArgs A = base_args(c, d_x, nullptr, 0.0);
+  A.o_g = d_g;
   return launch(c, K_G, A, tile_blocks(c) + 1, sizeof(double) * PK_WAVES_PER_BLOCK * (size_t)c->md.lds_g, st);
 }
 
@@ -329,7 +350,8 @@ int pk_eval_jac_dev(pk_ctx* c, const double* d_x, double* d_vals, void* stream) 
   if (rc) return rc;
   hipStream_t st = pick(c, stream);
   if (c->md.prepass_jac && !c->external_prepass && (rc = prepass(c, d_x, nullptr, 0.0, c->d_f, false, st))) return rc;
-  PkArgs A = base_args(c, d_x, nullptr, 0.0, d_vals);
+  PkArgs A = base_args(c, d_x, nullptr, 0.0);
+  A.o_jac = d_vals;
   A.items = (const PkItem*)c->d_items_jac;
   A.n_items = c->n_items_jac;
   size_t lds = sizeof(double) * PK_WAVES_PER_BLOCK * (size_t)c->md.lds_j;
@@ -343,7 +365,8 @@ int pk_eval_hess_dev(pk_ctx* c, const double* d_x, const double* d_lam, double s
   if (!d_lam) return fail(c, 50, "pk_eval_hess: lambda is required");
   hipStream_t st = pick(c, stream);
   if (c->md.prepass_hess && !c->external_prepass && (rc = prepass(c, d_x, d_lam, sigma, c->d_f, false, st))) return rc;
-  PkArgs A = base_args(c, d_x, d_lam, sigma, d_vals);
+  PkArgs A = base_args(c, d_x, d_lam, sigma);
+  A.o_hess = d_vals;
   A.items = (const PkItem*)c->d_items_hess;
   A.n_items = c->n_items_hess;
   size_t lds = sizeof(double) * PK_WAVES_PER_BLOCK * (size_t)c->md.lds_h;
@@ -353,11 +376,28 @@ int pk_eval_hess_dev(pk_ctx* c, const double* d_x, const double* d_lam, double s
 
 int pk_eval_cycle_dev(pk_ctx* c, const double* d_x, const double* d_lam, double sigma, double* d_f, double* d_grad,
                       double* d_g, double* d_jac, double* d_hess, void* stream) {
-  int rc;
-  if ((rc = pk_eval_f_dev(c, d_x, d_f, stream))) return rc;
-  if ((rc = pk_eval_grad_dev(c, d_x, d_grad, stream))) return rc;
-  if ((rc = pk_eval_g_dev(c, d_x, d_g, stream))) return rc;
-  if ((rc = pk_eval_jac_dev(c, d_x, d_jac, stream))) return rc;
+  int rc = ready(c);
+  if (rc) return rc;
+  if (!d_lam) return fail(c, 50, "pk_eval_cycle: lambda is required");
+  hipStream_t st = pick(c, stream);
+  const bool needs_I = c->md.prepass_grad || c->md.prepass_g || c->md.prepass_jac || c->md.prepass_hess;
+  if (needs_I || c->external_prepass || c->shard_flags) {   // general path: the five callbacks one after the other
+    if (!c->external_prepass && (rc = pk_eval_f_dev(c, d_x, d_f, stream))) return rc;
+    if ((rc = pk_eval_grad_dev(c, d_x, d_grad, stream))) return rc;
+    if ((rc = pk_eval_g_dev(c, d_x, d_g, stream))) return rc;
+    if ((rc = pk_eval_jac_dev(c, d_x, d_jac, stream))) return rc;
+    return pk_eval_hess_dev(c, d_x, d_lam, sigma, d_hess, stream);
+  }
+  // fused path: every x-only output from one evaluation of each node, then the reductions, then H
+  PkArgs A = base_args(c, d_x, nullptr, 0.0);
+  A.o_f = d_f; A.o_grad = d_grad; A.o_g = d_g; A.o_jac = d_jac;
+  A.items = (const PkItem*)c->d_items_jac;
+  A.n_items = c->n_items_jac;
+  size_t lds = sizeof(double) * PK_WAVES_PER_BLOCK * (size_t)c->md.lds_x;
+  if (lds < sizeof(double) * (size_t)c->md.ne_j) lds = sizeof(double) * (size_t)c->md.ne_j;
+  if ((rc = launch(c, K_XALL, A, tile_blocks(c) + 1, lds, st))) return rc;
+  A.flags |= F_FIN_INT | F_WRITE_F | F_FIN_GRAD;
+  if ((rc = launch(c, K_FIN, A, 1, 0, st))) return rc;
   return pk_eval_hess_dev(c, d_x, d_lam, sigma, d_hess, stream);
 }
 
@@ -398,6 +438,24 @@ int pk_eval_hess(pk_ctx* c, const double* x, const double* lambda, double sigma,
                pk_eval_hess_dev(c, c->d_x, c->d_lam, sigma, c->d_H, nullptr), c->d_H, vals, c->nnz_H)
 }
 
+int pk_eval_cycle(pk_ctx* c, const double* x, const double* lambda, double sigma, double* f, double* grad, double* g,
+                  double* jac, double* hess) {
+  int rc = ready(c);
+  if (rc) return rc;
+  if (!x || !lambda || !f || !grad || !g || !jac || !hess) return fail(c, 60, "null host buffer");
+  PK_HIP(c, hipSetDevice(c->device));
+  PK_HIP(c, hipMemcpyAsync(c->d_x, x, sizeof(double) * (size_t)c->n, hipMemcpyHostToDevice, c->stream));
+  PK_HIP(c, hipMemcpyAsync(c->d_lam, lambda, sizeof(double) * (size_t)c->m, hipMemcpyHostToDevice, c->stream));
+  if ((rc = pk_eval_cycle_dev(c, c->d_x, c->d_lam, sigma, c->d_f, c->d_grad, c->d_g, c->d_J, c->d_H, nullptr))) return rc;
+  PK_HIP(c, hipMemcpyAsync(f, c->d_f, sizeof(double), hipMemcpyDeviceToHost, c->stream));
+  PK_HIP(c, hipMemcpyAsync(grad, c->d_grad, sizeof(double) * (size_t)c->n, hipMemcpyDeviceToHost, c->stream));
+  PK_HIP(c, hipMemcpyAsync(g, c->d_g, sizeof(double) * (size_t)c->m, hipMemcpyDeviceToHost, c->stream));
+  PK_HIP(c, hipMemcpyAsync(jac, c->d_J, sizeof(double) * (size_t)c->nnz_J, hipMemcpyDeviceToHost, c->stream));
+  PK_HIP(c, hipMemcpyAsync(hess, c->d_H, sizeof(double) * (size_t)c->nnz_H, hipMemcpyDeviceToHost, c->stream));
+  PK_HIP(c, hipStreamSynchronize(c->stream));
+  return 0;
+}
+
 // ---------------------------------------------------------------- profiling
 int pk_profile(pk_ctx* c, int enable) {
   if (!c) return fail(nullptr, 1, "null context");
@@ -415,8 +473,7 @@ int pk_profile_read(pk_ctx* c, int k, int64_t* launches, double* total_ms) {
     PK_HIP(c, hipEventElapsedTime(&ms, ev.a, ev.b));
     c->total_ms[k] += ms;
     c->launches[k] += 1;
-    (void)hipEventDestroy(ev.a);
-    (void)hipEventDestroy(ev.b);
+    c->free_events.push_back(ev);
   }
   c->pending[k].clear();
   if (launches) *launches = c->launches[k];

@@ -93,7 +93,15 @@ class Tables:
                 rec["q0"], rec["r0"], rec["offI"], rec["offT"] = q0, r0, offI, offT
                 rec["K"] = int(lay.K[j0])
                 rec["last"] = 1 if j0 + nj == lay.N else 0
+                for f in ("nnzI", "nnzT", "irc_off", "iv_off", "tv_off"):
+                    rec[f] = kinds[kind0 + kid][f]
+                rec["full_off"] = kinds[kind0 + kidf]["full_off"]
                 tiles.append(rec)
+            while len(tiles) % runtime.WAVES_PER_BLOCK:      # a workgroup never mixes phases: pad with empty tiles
+                rec = np.zeros((), dtype=runtime.TILE_DTYPE)
+                rec["phase"], rec["K"] = k, 1
+                tiles.append(rec)
+            ph["tile_hi"] = len(tiles)
         # gradient slots no tile writes: state end slots (LGR), t0/tf, static parameters
         gz = []
         for k, pp in enumerate(plan.phase_plans):
@@ -132,7 +140,7 @@ class Evaluator:
         code = hipbuild.compile_model(self.src.source, fastmath=plan.system._fastmath)
         md = runtime.ModelDesc()
         md.n_phase, md.n_I, md.nred = self.src.nphase, max(len(plan.I_syms), 1), self.src.nred
-        md.lds_g, md.lds_j, md.lds_h = self.src.lds_g, self.src.lds_j, self.src.lds_h
+        md.lds_g, md.lds_j, md.lds_h, md.lds_x = self.src.lds_g, self.src.lds_j, self.src.lds_h, self.src.lds_x
         md.ne_j, md.ne_h = self.src.list_off["jac"]["total"], self.src.list_off["hess"]["total"]
         md.prepass_f = 1
         md.prepass_grad = int(plan.needs_I_grad)
@@ -209,6 +217,18 @@ class Evaluator:
         self.ctx.check(self.ctx.lib.pk_eval_hess(self.ctx.handle, runtime.as_dp(x), runtime.as_dp(lam),
                                                  float(obj_factor), runtime.as_dp(out)))
         return out
+
+    def cycle(self, x, lagrange, obj_factor):
+        """All five outputs on the same x from the fused path (pk_xall + pk_fin + pk_hess):
+        returns (f, grad, g, J, H)."""
+        x = self._x(x)
+        lam = np.ascontiguousarray(lagrange, dtype=np.float64)
+        f, grad, g = np.empty(1), np.empty(self.plan.n), np.empty(self.plan.m)
+        J, H = np.empty(self.plan.nnz_J), np.empty(self.plan.nnz_H)
+        dp = runtime.as_dp
+        self.ctx.check(self.ctx.lib.pk_eval_cycle(self.ctx.handle, dp(x), dp(lam), float(obj_factor), dp(f), dp(grad),
+                                                  dp(g), dp(J), dp(H)))
+        return np.float64(f[0]), grad, g, J, H
 
     # ------------------------------------------------------------------ device-pointer API
     def cycle_dev(self, d_x, d_lam, sigma, d_f, d_grad, d_g, d_jac, d_hess, stream=None):

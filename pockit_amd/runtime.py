@@ -19,7 +19,7 @@ c_int32_p = C.POINTER(C.c_int32)
 class ModelDesc(C.Structure):
     _fields_ = [(n, C.c_int32) for n in
                 ("n_phase", "n_I", "nred", "lds_g", "lds_j", "lds_h", "ne_j", "ne_h", "prepass_f", "prepass_grad",
-                 "prepass_g", "prepass_jac", "prepass_hess")] + [("reserved", C.c_int32 * 3)]
+                 "prepass_g", "prepass_jac", "prepass_hess", "lds_x")] + [("reserved", C.c_int32 * 2)]
 
 
 class ProblemDesc(C.Structure):
@@ -43,18 +43,20 @@ PHASE_FIELDS = ["scheme", "n_x", "n_u", "n_c", "L_m", "L_d", "state_len", "L", "
                 "mid_lo", "mid_hi", "tile_lo", "tile_hi", "tau_off", "w_off", "width_off", "jseg_off", "jt_off",
                 "hseg_off", "red_off", "pad0", "pad1"]
 PHASE_DTYPE = np.dtype([(n, np.int32) for n in PHASE_FIELDS])
-TILE_FIELDS = ["phase", "j0", "nj", "kid", "kidf", "q0", "r0", "offI", "offT", "K", "last", "pad"]
+TILE_FIELDS = ["phase", "j0", "nj", "kid", "kidf", "q0", "r0", "offI", "offT", "K", "last",
+               "nnzI", "nnzT", "irc_off", "iv_off", "tv_off", "full_off", "pad"]
 TILE_DTYPE = np.dtype([(n, np.int32) for n in TILE_FIELDS])
 KIND_FIELDS = ["K", "R", "nnzI", "nnzT", "irc_off", "iv_off", "tv_off", "full_off"]
 KIND_DTYPE = np.dtype([(n, np.int32) for n in KIND_FIELDS])
 ITEM_DTYPE = np.dtype([("pos", np.int64), ("coef", np.float64), ("eid", np.int32), ("lam", np.int32)])
 
-KERNELS = ["pk_int", "pk_intfin", "pk_g", "pk_grad", "pk_gradfin", "pk_jac", "pk_hess"]
+WAVES_PER_BLOCK = 4  # PK_WAVES_PER_BLOCK of csrc/pk_abi.h
+KERNELS = ["pk_int", "pk_fin", "pk_g", "pk_grad", "pk_jac", "pk_hess", "pk_xall"]
 EXPORTS = ["pk_create", "pk_destroy", "pk_last_error", "pk_device_count", "pk_load_model", "pk_set_problem",
            "pk_get_structure", "pk_eval_f", "pk_eval_grad", "pk_eval_g", "pk_eval_jac", "pk_eval_hess",
            "pk_eval_f_dev", "pk_eval_grad_dev", "pk_eval_g_dev", "pk_eval_jac_dev", "pk_eval_hess_dev",
            "pk_eval_cycle_dev", "pk_sync", "pk_profile", "pk_profile_read", "pk_kernel_name",
-           "pk_set_shard", "pk_eval_integrals_dev", "pk_eval_f_from_integrals_dev"]
+           "pk_set_shard", "pk_eval_integrals_dev", "pk_eval_f_from_integrals_dev", "pk_eval_cycle"]
 
 _lib = None
 
@@ -86,6 +88,7 @@ def load_library():
     lib.pk_eval_g.argtypes = [vp, dp, dp]
     lib.pk_eval_jac.argtypes = [vp, dp, dp]
     lib.pk_eval_hess.argtypes = [vp, dp, dp, C.c_double, dp]
+    lib.pk_eval_cycle.argtypes = [vp, dp, dp, C.c_double, dp, dp, dp, dp, dp]
     lib.pk_eval_f_dev.argtypes = [vp, vp, vp, vp]
     lib.pk_eval_grad_dev.argtypes = [vp, vp, vp, vp]
     lib.pk_eval_g_dev.argtypes = [vp, vp, vp, vp]

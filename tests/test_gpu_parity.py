@@ -72,6 +72,13 @@ def test_tilings_match_oracle(case, ipw, monkeypatch):
     close(system.constraints(x), ref.constraints(x), what="g")
     close(system.jacobian(x), ref.jacobian(x), what="J")
     close(system.hessian(x, lam, sigma), ref.hessian(x, lam, sigma), what="H")
+    # the fused cycle path (one node evaluation for f, grad f, g, J) must give the same five outputs
+    f, grad, g, J, H = system.evaluator.cycle(x, lam, sigma)
+    close(f, ref.objective(x), what="cycle f")
+    close(grad, ref.gradient(x), what="cycle grad")
+    close(g, ref.constraints(x), what="cycle g")
+    close(J, ref.jacobian(x), what="cycle J")
+    close(H, ref.hessian(x, lam, sigma), what="cycle H")
 
 
 def test_ragged_mesh_matches_oracle():
@@ -114,3 +121,20 @@ def test_full_size_configs_match_reference_summary():
         check(system.jacobian(x), gold["J"], name + " J")
         check(system.hessian(x, lam, sigma), gold["H"], name + " H")
         system._invalidate()
+
+
+def test_repeated_evaluation_with_changing_x():
+    """The in-launch finalize (per-tile partials handed to the last-arriving workgroup) must see the
+    *current* launch's partials: alternate between two points on one evaluator."""
+    system, _, guess = models.two_stage_rocket(_ns("radau", "pockit_amd"), 300, 4)
+    ref, _, _ = models.two_stage_rocket(_ns("radau", "oracle"), 300, 4)
+    x1, lam, sigma = models.bench_inputs(system, guess)
+    x2 = x1 * (1.0 + 0.05 * np.random.default_rng(7).uniform(-1, 1, x1.shape))
+    want = {id(x): (ref.objective(x), ref.gradient(x)) for x in (x1, x2)}
+    for x in (x1, x2, x1, x2, x2, x1):
+        for _ in range(3):
+            close(system.objective(x), want[id(x)][0], what="f")
+            close(system.gradient(x), want[id(x)][1], what="grad")
+        f, grad, _, _, _ = system.evaluator.cycle(x, lam, sigma)
+        close(f, want[id(x)][0], what="cycle f")
+        close(grad, want[id(x)][1], what="cycle grad")
