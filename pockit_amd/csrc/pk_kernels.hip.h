@@ -362,7 +362,7 @@ __device__ __forceinline__ void tile_xall(const PkArgs& A, const PkTile& tl, dou
   for (int r = 0; r < P::INT_N; ++r) oi[r] = 0.0;
 #pragma unroll
   for (int r = 0; r < P::GR_NR; ++r) orr[r] = 0.0;
-  if (lane < g.nq) {
+  if (lane < g.nq && !(A.flags & 512)) {   // (bit 9: diagnostic switch, skip the evaluation phase)
     const int q = tl.q0 + lane;
     double a[P::NARG], tau, w;
     double og[P::G_NOUT], oj[P::J_NI + P::J_NN + 1], ov[P::NX + P::NU], ot[P::GR_NR > 0 ? P::GR_NR : 1],
@@ -401,6 +401,7 @@ __device__ __forceinline__ void tile_xall(const PkArgs& A, const PkTile& tl, dou
     if (lane == 0) wgrad[r] = v;
   }
   __syncthreads();
+  if (A.flags & 256) return;   // diagnostic build switch: skip the streaming phase
   write_defects<P>(A, ph, tl, g, s, dt, sv, xr, lane);
   if (tl.nj == 0) return;
   write_translation<P>(A, ph, tl, lane);
@@ -433,13 +434,14 @@ __device__ __forceinline__ void scatter_items(const PkArgs& A, const double* __r
 
 // The four wave sums of a workgroup -> one partial per workgroup.  The host pads every phase's tile
 // list to a multiple of PK_WAVES_PER_BLOCK (empty tiles), so a workgroup never mixes phases.
-__device__ __forceinline__ void publish_block_partials(double* __restrict__ partial, const double* __restrict__ wred) {
+__device__ __forceinline__ void publish_block_partials(double* __restrict__ partial, const double* __restrict__ wred,
+                                                       int blk) {
   __syncthreads();
   if ((int)threadIdx.x < PK_NRED) {
     double v = 0.0;
 #pragma unroll
     for (int w = 0; w < PK_WAVES_PER_BLOCK; ++w) v += wred[w * PK_NRED + threadIdx.x];
-    partial[(size_t)blockIdx.x * PK_NRED + threadIdx.x] = v;
+    partial[(size_t)blk * PK_NRED + threadIdx.x] = v;
   }
 }
 
@@ -463,12 +465,15 @@ __device__ __forceinline__ double block_sum_partials(const PkArgs& A, const doub
 // ============================================================================================
 // kernels
 // ============================================================================================
-#define PK_TILE_PROLOGUE()                                                            \
+// EDGE = 1: workgroup 0 is the boundary/system workgroup (dispatched first: its serial chain is the
+// longest of the launch), tile workgroups follow.
+#define PK_TILE_PROLOGUE(EDGE)                                                        \
   extern __shared__ double pk_lds[];                                                  \
   __shared__ double wint[PK_WAVES_PER_BLOCK * PK_NRED];                               \
   __shared__ double wgrad[PK_WAVES_PER_BLOCK * PK_NRED];                              \
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;                         \
-  const int ti = blockIdx.x * PK_WAVES_PER_BLOCK + wave;                              \
+  const int blk = (int)blockIdx.x - (EDGE);                                           \
+  const int ti = blk * PK_WAVES_PER_BLOCK + wave;                                     \
   PkTile tl;                                                                          \
   if (ti < A.n_tiles) {                                                               \
     tl = A.tile[ti];                                                                  \
@@ -481,7 +486,7 @@ __device__ __forceinline__ double block_sum_partials(const PkArgs& A, const doub
     wgrad[wave * PK_NRED + lane] = 0.0;                                               \
   }
 
-#define PK_IS_EDGE_BLOCK() ((int)blockIdx.x == (A.n_tiles + PK_WAVES_PER_BLOCK - 1) / PK_WAVES_PER_BLOCK)
+#define PK_IS_EDGE_BLOCK() (blockIdx.x == 0)
 
 template <class Gen>
 __device__ __forceinline__ void edge_block(const PkArgs& A, bool hess, bool with_g) {
@@ -498,11 +503,12 @@ __device__ __forceinline__ void edge_block(const PkArgs& A, bool hess, bool with
   scatter_items(A, pk_lds, hess ? A.o_hess : A.o_jac);
 }
 
+
 template <class Gen>
 __device__ __forceinline__ void kernel_int(const PkArgs& A) {
-  PK_TILE_PROLOGUE();
+  PK_TILE_PROLOGUE(0);
   Gen::tile_int(tl.phase, A, tl, pk_lds, wint + wave * PK_NRED, wgrad + wave * PK_NRED, lane);
-  publish_block_partials(A.partial, wint);
+  publish_block_partials(A.partial, wint, blk);
 }
 
 template <class Gen>
@@ -514,51 +520,64 @@ __device__ __forceinline__ void kernel_g(const PkArgs& A) {
     }
     return;
   }
-  PK_TILE_PROLOGUE();
+  PK_TILE_PROLOGUE(1);
   Gen::tile_g(tl.phase, A, tl, pk_lds + wave * Gen::LDS_G, wint, wgrad, lane);
 }
 
 template <class Gen>
 __device__ __forceinline__ void kernel_grad(const PkArgs& A) {
-  PK_TILE_PROLOGUE();
+  PK_TILE_PROLOGUE(0);
   Gen::tile_grad(tl.phase, A, tl, pk_lds, wint + wave * PK_NRED, wgrad + wave * PK_NRED, lane);
-  publish_block_partials(A.partial2, wgrad);
+  publish_block_partials(A.partial2, wgrad, blk);
 }
 
 template <class Gen>
 __device__ __forceinline__ void kernel_jac(const PkArgs& A) {
   if (PK_IS_EDGE_BLOCK()) return edge_block<Gen>(A, false, false);
-  PK_TILE_PROLOGUE();
+  PK_TILE_PROLOGUE(1);
   Gen::tile_jac(tl.phase, A, tl, pk_lds + wave * Gen::LDS_J, wint, wgrad, lane);
 }
 
 template <class Gen>
+__device__ __forceinline__ void fin_body(const PkArgs& A);
+
+template <class Gen>
 __device__ __forceinline__ void kernel_hess(const PkArgs& A) {
-  if (PK_IS_EDGE_BLOCK()) return edge_block<Gen>(A, true, false);
-  PK_TILE_PROLOGUE();
+  if (PK_IS_EDGE_BLOCK()) {
+    // cycle mode: the reductions of the preceding pk_xall launch ride along in this workgroup
+    if (A.flags & (8 | 16)) fin_body<Gen>(A);
+    __syncthreads();
+    return edge_block<Gen>(A, true, false);
+  }
+  PK_TILE_PROLOGUE(1);
   Gen::tile_hess(tl.phase, A, tl, pk_lds + wave * Gen::LDS_H, wint, wgrad, lane);
 }
 
 template <class Gen>
 __device__ __forceinline__ void kernel_xall(const PkArgs& A) {
   if (PK_IS_EDGE_BLOCK()) return edge_block<Gen>(A, false, true);
-  PK_TILE_PROLOGUE();
+  PK_TILE_PROLOGUE(1);
   Gen::tile_xall(tl.phase, A, tl, pk_lds + wave * Gen::LDS_X, wint + wave * PK_NRED, wgrad + wave * PK_NRED, lane);
-  publish_block_partials(A.partial, wint);
-  publish_block_partials(A.partial2, wgrad);
+  publish_block_partials(A.partial, wint, blk);
+  publish_block_partials(A.partial2, wgrad, blk);
 }
 
-// single workgroup.  flags bit 3: I_k = dt * sum of partials -> Ibuf; bit 0: f = F_o(I, s) -> o_f
-// (systembase.py:592-605); bit 4: gradient slots shared by all nodes (systembase.py:654-657)
+// The reductions over all workgroups, by ONE workgroup (all 256 threads must call it).
+// flags bit 3: I_k = dt * sum of partials -> Ibuf; bit 0: f = F_o(I, s) -> o_f (systembase.py:592-605);
+// bit 4: the gradient slots shared by all nodes (systembase.py:654-657).
 template <class Gen>
-__device__ __forceinline__ void kernel_fin(const PkArgs& A) {
+__device__ __forceinline__ void fin_body(const PkArgs& A) {
   __shared__ double red[PK_WAVES_PER_BLOCK];
   __shared__ double tot[PK_NPHASE * PK_NRED];
+  __shared__ double dts[PK_NPHASE];
+  if ((int)threadIdx.x < PK_NPHASE) dts[threadIdx.x] = Gen::phase_dt(threadIdx.x, A);   // one phase per thread
+  if (A.flags & 16)                                                                       // dead / shared slots start at 0
+    for (int z = threadIdx.x; z < A.n_gz; z += PK_BLOCK) A.o_grad[A.ib[A.gz_off + z]] = 0.0;
   if (A.flags & 8) {
     for (int n = 0; n < Gen::N_INT; ++n) {
       const int k = Gen::int_phase(n);
       const double sum = block_sum_partials(A, A.partial, k, Gen::int_slot(n), red);
-      if (threadIdx.x == 0) A.Ibuf[Gen::int_global(n)] = sum * Gen::phase_dt(k, A);
+      if (threadIdx.x == 0) A.Ibuf[Gen::int_global(n)] = sum * dts[k];
     }
   }
   if (A.flags & 16) {
@@ -573,7 +592,6 @@ __device__ __forceinline__ void kernel_fin(const PkArgs& A) {
   const PkSys sy{A.x + A.l_s, A.Ibuf, A.sigma, A.lam};
   if (A.flags & 1) A.o_f[0] = Gen::sys_objective(sy);
   if (A.flags & 16) {
-    for (int z = 0; z < A.n_gz; ++z) A.o_grad[A.ib[A.gz_off + z]] = 0.0;
     for (int k = 0; k < PK_NPHASE; ++k)
       for (int r = 0; r < Gen::gr_nr(k); ++r) A.o_grad[A.ib[A.ph[k].red_off + r]] += tot[k * PK_NRED + r];
     if (!(A.flags & 2)) {
@@ -582,6 +600,11 @@ __device__ __forceinline__ void kernel_fin(const PkArgs& A) {
       for (int i = 0; i < A.n_s; ++i) A.o_grad[A.l_s + i] += gs[i];
     }
   }
+}
+
+template <class Gen>
+__device__ __forceinline__ void kernel_fin(const PkArgs& A) {
+  fin_body<Gen>(A);
 }
 
 }  // namespace pk

@@ -10,8 +10,8 @@
 //   eval_g     [pk_int, pk_fin(integrals)]?  pk_g
 //   eval_jac   [pk_int, pk_fin(integrals)]?  pk_jac
 //   eval_hess  [pk_int, pk_fin(integrals)]?  pk_hess
-//   cycle      pk_xall (f partials, grad f, g, J from one node evaluation), pk_fin(integrals, f, gradient
-//              slots), pk_hess
+//   cycle      pk_xall (f partials, grad f, g, J from one node evaluation), pk_hess (whose boundary
+//              workgroup also does pk_fin's reductions: integrals, f, shared gradient slots)
 // ("?" = only when a system-level function is nonlinear in the integrals, pk_model_desc.prepass_*).
 //
 // There is no CPU evaluation path: every entry point fails with an error code when no device /
@@ -20,6 +20,7 @@
 
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -51,6 +52,7 @@ struct pk_ctx {
   bool external_prepass = false; // sharded mode: the caller all-reduces the integrals itself
   double* ext_I = nullptr;      // caller-owned integral buffer (sharded mode)
   unsigned profile_mask = 0;
+  int debug_flags = 0;          // diagnostic kernel switches (POCKIT_AMD_DEBUG_FLAGS), never set in production
   pk_model_desc md{};
   // problem
   int32_t n = 0, m = 0, n_sys = 0, n_s = 0, l_s = 0, n_phase = 0, n_tiles = 0;
@@ -130,7 +132,7 @@ PkArgs base_args(pk_ctx* c, const double* d_x, const double* d_lam, double sigma
   A.Ibuf = c->ext_I ? c->ext_I : c->d_I; A.partial = c->d_partial; A.partial2 = c->d_partial2;
   A.n_tiles = c->n_tiles; A.n_items = 0; A.n_phase = c->n_phase; A.n = c->n;
   A.l_s = c->l_s; A.n_s = c->n_s; A.n_sys = c->n_sys; A.m = c->m;
-  A.gz_off = c->gz_off; A.n_gz = c->n_gz; A.flags = c->shard_flags;
+  A.gz_off = c->gz_off; A.n_gz = c->n_gz; A.flags = c->shard_flags | c->debug_flags;
   for (size_t k = 0; k < c->h_phases.size(); ++k) A.ph[k] = c->h_phases[k];
   return A;
 }
@@ -195,6 +197,7 @@ int pk_create(pk_ctx** out, int device_id) {
   if (device_id < 0 || device_id >= ndev) return fail(nullptr, 11, "pk_create: device %d out of range [0,%d)", device_id, ndev);
   pk_ctx* c = new pk_ctx();
   c->device = device_id;
+  if (const char* dbg = getenv("POCKIT_AMD_DEBUG_FLAGS")) c->debug_flags = atoi(dbg) & (256 | 512);
   if ((e = hipSetDevice(device_id)) != hipSuccess || (e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)) != hipSuccess) {
     int rc = fail(nullptr, 12, "pk_create: %s", hipGetErrorString(e));
     delete c;
@@ -396,9 +399,15 @@ int pk_eval_cycle_dev(pk_ctx* c, const double* d_x, const double* d_lam, double 
   size_t lds = sizeof(double) * PK_WAVES_PER_BLOCK * (size_t)c->md.lds_x;
   if (lds < sizeof(double) * (size_t)c->md.ne_j) lds = sizeof(double) * (size_t)c->md.ne_j;
   if ((rc = launch(c, K_XALL, A, tile_blocks(c) + 1, lds, st))) return rc;
-  A.flags |= F_FIN_INT | F_WRITE_F | F_FIN_GRAD;
-  if ((rc = launch(c, K_FIN, A, 1, 0, st))) return rc;
-  return pk_eval_hess_dev(c, d_x, d_lam, sigma, d_hess, stream);
+  // pk_hess's boundary workgroup also performs pk_fin's reductions (f, shared gradient slots)
+  PkArgs H = base_args(c, d_x, d_lam, sigma);
+  H.o_f = d_f; H.o_grad = d_grad; H.o_hess = d_hess;
+  H.items = (const PkItem*)c->d_items_hess;
+  H.n_items = c->n_items_hess;
+  H.flags |= F_FIN_INT | F_WRITE_F | F_FIN_GRAD;
+  lds = sizeof(double) * PK_WAVES_PER_BLOCK * (size_t)c->md.lds_h;
+  if (lds < sizeof(double) * (size_t)c->md.ne_h) lds = sizeof(double) * (size_t)c->md.ne_h;
+  return launch(c, K_HESS, H, tile_blocks(c) + 1, lds, st);
 }
 
 int pk_sync(pk_ctx* c, void* stream) {

@@ -20,7 +20,7 @@ from . import hipbuild, runtime
 from .codegen import ModelSource
 from .transcription import SystemPlan
 
-TARGET_TILES = int(os.environ.get("POCKIT_AMD_TARGET_TILES", "2048"))
+TARGET_TILES = int(os.environ.get("POCKIT_AMD_TARGET_TILES", "1024"))
 
 
 def _intervals_per_wave(plan, override=None):
