@@ -51,7 +51,8 @@ typedef struct pk_model_desc {
   int32_t prepass_jac;
   int32_t prepass_hess;
   int32_t lds_x;        /* LDS doubles per wave of the fused x-kernel (pk_xall)                   */
-  int32_t reserved[2];
+  int32_t ne_a;         /* scalar expressions of the auxiliary pass (outer-product Hessian path)  */
+  int32_t reserved[1];
 } pk_model_desc;
 
 /* One (model, mesh) instance: sizes plus the table blobs built by pockit_amd/evaluator.py.
@@ -75,6 +76,12 @@ typedef struct pk_problem_desc {
   const int64_t* lb;
   int64_t n_lb;
   int32_t gz_off, n_gz;
+  /* outer-product path (objective / system constraints nonlinear in the integrals); all may be empty */
+  const void* items_aux;
+  int32_t n_items_aux;
+  const void* outer;      /* PkOuter[n_outer] */
+  int32_t n_outer;
+  int32_t n_aux;          /* length of the auxiliary buffer */
   /* optional COO structure in the reference's order (copied; may be NULL) */
   const int32_t* jac_row;
   const int32_t* jac_col;
@@ -125,7 +132,7 @@ int pk_eval_integrals_dev(pk_ctx* ctx, const double* d_x, void* stream);
 int pk_eval_f_from_integrals_dev(pk_ctx* ctx, const double* d_x, double* d_f, void* stream);
 
 /* HIP-event timing of the individual kernels on the launch stream.
- * kernel ids: 0 pk_int, 1 pk_fin, 2 pk_g, 3 pk_grad, 4 pk_jac, 5 pk_hess, 6 pk_xall */
+ * kernel ids: 0 pk_int, 1 pk_fin, 2 pk_g, 3 pk_grad, 4 pk_jac, 5 pk_hess, 6 pk_xall, 7 pk_aux, 8 pk_outer */
 int pk_profile(pk_ctx* ctx, int kernel_mask /* bit k: time kernel k; 0 = off */);
 int pk_profile_read(pk_ctx* ctx, int kernel_id, int64_t* launches, double* total_ms);
 const char* pk_kernel_name(int kernel_id);

@@ -107,7 +107,7 @@ class ModelSource:
             self.list_keys += [("f", k), ("b", k)]
         self.list_keys.append(("s",))
         self.list_off = {}
-        for cbname in ("jac", "hess"):
+        for cbname in ("jac", "hess", "aux"):
             cb = getattr(plan, cbname)
             off, table = 0, {}
             for key in self.list_keys:
@@ -207,7 +207,7 @@ class ModelSource:
         S.append("  }")
 
         # ---- Jacobian / Hessian segments ----
-        for cbname, tag in (("jac", "J"), ("hess", "H")):
+        for cbname, tag in (("jac", "J"), ("hess", "H"), ("aux", "A")):
             cb = getattr(plan, cbname)
             segs = cb.segs[k]
             isegs = [s for s in segs if s.kind == "I"]
@@ -271,7 +271,7 @@ class ModelSource:
         S.append(_emit_body([(f"gs[{i}]", plan.grad_static.get(i, sp.Integer(0))) for i in range(plan.n_s)],
                             {}, nm, "  "))
         S.append("}")
-        for cbname in ("jac", "hess"):
+        for cbname in ("jac", "hess", "aux"):
             exprs = getattr(plan, cbname).lists.get(("s",), [])
             S.append(f"__device__ static __forceinline__ void sys_{cbname}(const PkSys& sy, double* __restrict__ E) {{")
             S.append(_emit_body([(f"E[{e}]", ex) for e, ex in enumerate(exprs)], {}, nm, "  "))
@@ -316,13 +316,13 @@ class ModelSource:
                                      for k, pp in enumerate(plan.phase_plans)])
         S.append(f"  static constexpr int LDS_G = {self.lds_g}, LDS_J = {self.lds_j}, LDS_H = {self.lds_h}, "
                  f"LDS_X = {self.lds_x};")
-        for name in ("int", "g", "grad", "jac", "hess", "xall"):
+        for name in ("int", "g", "grad", "jac", "hess", "xall", "aux"):
             S.append(f"  __device__ static __forceinline__ void tile_{name}(int phase, const PkArgs& A, const PkTile& tl, "
                      f"double* __restrict__ lds, double* __restrict__ wint, double* __restrict__ wgrad, int lane) {{")
             S.append(switch(f"pk::tile_{name}<{{P}}>(A, tl, lds, wint, wgrad, lane)"))
             S.append("  }")
         ncmax = max([1] + [pp.phase.n_c for pp in plan.phase_plans])
-        for cbname, tag in (("jac", "J"), ("hess", "H")):
+        for cbname, tag in (("jac", "J"), ("hess", "H"), ("aux", "A")):
             off = self.list_off[cbname]
             S.append(f"  static constexpr int {tag}_NE = {max(off['total'], 1)};")
             S.append(f"  __device__ static __forceinline__ void edge_{cbname}(int li, const PkArgs& A, const PkSys& sy, "

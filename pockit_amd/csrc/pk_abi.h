@@ -28,7 +28,8 @@ struct PkPhase {
   int32_t jt_off;      // lb: base offset in J of the constant translation piece of every state
   int32_t hseg_off;    // lb: base offset in H of every Hessian segment of the phase (I then N)
   int32_t red_off;     // ib: NLP index of every gradient reduction slot of the phase
-  int32_t pad0, pad1;
+  int32_t aseg_off;    // lb: base offset in the auxiliary buffer of every auxiliary segment of the phase
+  int32_t pad1;
 };
 
 // A run of `nj` consecutive intervals of one kind handled by one wavefront (<= 64 nodes).
@@ -70,6 +71,19 @@ struct PkItem {
   int32_t lam;
 };
 
+// One outer-product block of a system-level Hessian (objective / system constraints nonlinear in the
+// integrals; reference: easyderiv.py:323-355,393-430).  A, B: runs of quadrature-weighted gradient entries
+// in the auxiliary buffer; M: location of the scalar multiplier.
+//   kron:  out[pos + i*lenB + j] = A[i] * B[j] * m
+//   tril:  A' = collapseA ? {sum A} : A (same for B); for (i >= j) in row-major lower-triangular order:
+//          out[pos + t] = A'[i] * B'[j] * m, and if `second` out[pos + ntri + t] = B'[i] * A'[j] * m
+struct PkOuter {
+  int64_t pos;
+  int32_t offA, lenA, offB, lenB, offM;
+  int32_t flags;       // bit 0 tril, bit 1 collapseA, bit 2 collapseB, bit 3 second
+  int32_t count, pad;
+};
+
 #define PK_MAX_PHASES 8
 
 struct PkArgs {
@@ -80,6 +94,8 @@ struct PkArgs {
   double* o_g;            // [m]
   double* o_jac;          // [nnz_J]
   double* o_hess;         // [nnz_H]
+  double* o_aux;          // auxiliary buffer (integral gradient entries x w, multipliers); outer-product path only
+  const PkOuter* outer;
   double sigma;           // objective factor (Hessian only)
   const PkPhase* phase;
   const PkTile* tile;
@@ -97,6 +113,6 @@ struct PkArgs {
   int32_t gz_off, n_gz;   // ib: gradient slots the finalize kernel zero-fills
   int32_t flags;          // bit 0: pk_fin writes f; bit 1: secondary shard (no system-level / boundary work);
                           // bit 3: pk_fin reduces the integrals into Ibuf; bit 4: pk_fin reduces the gradient slots
-  int32_t pad;
+  int32_t n_outer;
   PkPhase ph[PK_MAX_PHASES];   // the phases by value (kernarg segment): no dependent global load
 };

@@ -408,6 +408,32 @@ __device__ __forceinline__ void tile_xall(const PkArgs& A, const PkTile& tl, dou
   stream_expanded<P, P::J_NI, false>(A, ph, tl, g, jsv, segb, A.o_jac, lane);
 }
 
+// ============================================================================================
+// auxiliary pass of the outer-product path: quadrature-weighted gradient entries of the integrals
+// (one value per middle node), consumed by pk_outer       (systembase.py:625-644; easyderiv.py:393-430)
+// ============================================================================================
+template <class P>
+__device__ __forceinline__ void tile_aux(const PkArgs& A, const PkTile& tl, double* __restrict__,
+                                         double* __restrict__, double* __restrict__, int lane) {
+  if (P::A_NN == 0) return;
+  const PkPhase& ph = A.ph[P::INDEX];
+  const TileGeom g = tile_geom<P>(tl);
+  double s[PK_NS], dt, mt;
+  phase_scalars<P>(A, ph, s, dt, mt);
+  const PkSys sy{s, A.Ibuf, A.sigma, A.lam};
+  const int64_t* __restrict__ segb = A.lb + ph.aseg_off;
+  if (lane < g.nown) {
+    const int q = tl.q0 + lane;
+    if (q >= ph.mid_lo && q < ph.mid_hi) {
+      double a[P::NARG], tau, w, o[P::A_NN + 1];
+      load_node<P>(A, ph, s, dt, mt, q, a, tau, w);
+      P::mid_aux(a, tau, dt, w, sy, nullptr, o);
+#pragma unroll
+      for (int e = 0; e < P::A_NN; ++e) A.o_aux[segb[e] + (q - ph.mid_lo)] = o[e];
+    }
+  }
+}
+
 // ---- boundary-node evaluation for the edge workgroup -----------------------------------------
 template <class P>
 __device__ __forceinline__ void load_edge(const PkArgs& A, int back, double* s, double* a, double& tau,
@@ -488,8 +514,9 @@ __device__ __forceinline__ double block_sum_partials(const PkArgs& A, const doub
 
 #define PK_IS_EDGE_BLOCK() (blockIdx.x == 0)
 
+// mode 0: Jacobian, 1: Hessian, 2: auxiliary buffer
 template <class Gen>
-__device__ __forceinline__ void edge_block(const PkArgs& A, bool hess, bool with_g) {
+__device__ __forceinline__ void edge_block(const PkArgs& A, int mode, bool with_g) {
   extern __shared__ double pk_lds[];
   const PkSys sy{A.x + A.l_s, A.Ibuf, A.sigma, A.lam};
   if (A.flags & 2) return;   // secondary shard: boundary nodes / system level belong to the primary
@@ -497,10 +524,12 @@ __device__ __forceinline__ void edge_block(const PkArgs& A, bool hess, bool with
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   for (int li = wave; li < Gen::NLISTS; li += PK_WAVES_PER_BLOCK)
     if (lane == 0) {
-      if (hess) Gen::edge_hess(li, A, sy, pk_lds); else Gen::edge_jac(li, A, sy, pk_lds);
+      if (mode == 1) Gen::edge_hess(li, A, sy, pk_lds);
+      else if (mode == 2) Gen::edge_aux(li, A, sy, pk_lds);
+      else Gen::edge_jac(li, A, sy, pk_lds);
     }
   __syncthreads();
-  scatter_items(A, pk_lds, hess ? A.o_hess : A.o_jac);
+  scatter_items(A, pk_lds, mode == 1 ? A.o_hess : (mode == 2 ? A.o_aux : A.o_jac));
 }
 
 
@@ -533,7 +562,7 @@ __device__ __forceinline__ void kernel_grad(const PkArgs& A) {
 
 template <class Gen>
 __device__ __forceinline__ void kernel_jac(const PkArgs& A) {
-  if (PK_IS_EDGE_BLOCK()) return edge_block<Gen>(A, false, false);
+  if (PK_IS_EDGE_BLOCK()) return edge_block<Gen>(A, 0, false);
   PK_TILE_PROLOGUE(1);
   Gen::tile_jac(tl.phase, A, tl, pk_lds + wave * Gen::LDS_J, wint, wgrad, lane);
 }
@@ -547,15 +576,71 @@ __device__ __forceinline__ void kernel_hess(const PkArgs& A) {
     // cycle mode: the reductions of the preceding pk_xall launch ride along in this workgroup
     if (A.flags & (8 | 16)) fin_body<Gen>(A);
     __syncthreads();
-    return edge_block<Gen>(A, true, false);
+    return edge_block<Gen>(A, 1, false);
   }
   PK_TILE_PROLOGUE(1);
   Gen::tile_hess(tl.phase, A, tl, pk_lds + wave * Gen::LDS_H, wint, wgrad, lane);
 }
 
 template <class Gen>
+__device__ __forceinline__ void kernel_aux(const PkArgs& A) {
+  if (PK_IS_EDGE_BLOCK()) return edge_block<Gen>(A, 2, false);
+  PK_TILE_PROLOGUE(1);
+  Gen::tile_aux(tl.phase, A, tl, pk_lds, wint, wgrad, lane);
+}
+
+// One workgroup per outer-product block (generic, table driven; O(n^2) outputs exist only for
+// objectives / system constraints that are nonlinear in the integrals -- small problems in practice).
+__device__ __forceinline__ void kernel_outer(const PkArgs& A) {
+  __shared__ double red[PK_WAVES_PER_BLOCK];
+  __shared__ double sums[2];
+  for (int b = blockIdx.x; b < A.n_outer; b += gridDim.x) {
+    const PkOuter d = A.outer[b];
+    const double* __restrict__ GA = A.o_aux + d.offA;
+    const double* __restrict__ GB = A.o_aux + d.offB;
+    const double m = A.o_aux[d.offM];
+    double* __restrict__ out = A.o_hess + d.pos;
+    if (!(d.flags & 1)) {
+      const int tot = d.lenA * d.lenB;
+      for (int t = threadIdx.x; t < tot; t += PK_BLOCK) {
+        const int i = t / d.lenB, j = t - i * d.lenB;
+        out[t] = GA[i] * GB[j] * m;
+      }
+      continue;
+    }
+    for (int which = 0; which < 2; ++which) {          // collapsed runs: deterministic block sums
+      const bool need = which == 0 ? (d.flags & 2) : (d.flags & 4);
+      if (!need) continue;                              // (uniform across the workgroup)
+      const double* __restrict__ G = which == 0 ? GA : GB;
+      const int len = which == 0 ? d.lenA : d.lenB;
+      double v = 0.0;
+      for (int t = threadIdx.x; t < len; t += PK_BLOCK) v += G[t];
+      v = wave_sum(v);
+      __syncthreads();
+      if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+      __syncthreads();
+      if (threadIdx.x == 0) sums[which] = red[0] + red[1] + red[2] + red[3];
+    }
+    __syncthreads();
+    const int n = (d.flags & 2) ? 1 : d.lenA;
+    const int ntri = n * (n + 1) / 2;
+    for (int t = threadIdx.x; t < ntri; t += PK_BLOCK) {
+      int i = (int)((sqrt(8.0 * (double)t + 1.0) - 1.0) * 0.5);
+      while ((i + 1) * (i + 2) / 2 <= t) ++i;
+      while (i * (i + 1) / 2 > t) --i;
+      const int j = t - i * (i + 1) / 2;
+      const double ai = (d.flags & 2) ? sums[0] : GA[i], aj = (d.flags & 2) ? sums[0] : GA[j];
+      const double bi = (d.flags & 4) ? sums[1] : GB[i], bj = (d.flags & 4) ? sums[1] : GB[j];
+      out[t] = ai * bj * m;
+      if (d.flags & 8) out[ntri + t] = bi * aj * m;
+    }
+    __syncthreads();
+  }
+}
+
+template <class Gen>
 __device__ __forceinline__ void kernel_xall(const PkArgs& A) {
-  if (PK_IS_EDGE_BLOCK()) return edge_block<Gen>(A, false, true);
+  if (PK_IS_EDGE_BLOCK()) return edge_block<Gen>(A, 0, true);
   PK_TILE_PROLOGUE(1);
   Gen::tile_xall(tl.phase, A, tl, pk_lds + wave * Gen::LDS_X, wint + wave * PK_NRED, wgrad + wave * PK_NRED, lane);
   publish_block_partials(A.partial, wint, blk);
@@ -616,4 +701,6 @@ __device__ __forceinline__ void kernel_fin(const PkArgs& A) {
   extern "C" __global__ __launch_bounds__(PK_BLOCK) void pk_grad(PkArgs A) { pk::kernel_grad<GEN>(A); } \
   extern "C" __global__ __launch_bounds__(PK_BLOCK) void pk_jac(PkArgs A) { pk::kernel_jac<GEN>(A); }   \
   extern "C" __global__ __launch_bounds__(PK_BLOCK) void pk_hess(PkArgs A) { pk::kernel_hess<GEN>(A); } \
-  extern "C" __global__ __launch_bounds__(PK_BLOCK) void pk_xall(PkArgs A) { pk::kernel_xall<GEN>(A); }
+  extern "C" __global__ __launch_bounds__(PK_BLOCK) void pk_xall(PkArgs A) { pk::kernel_xall<GEN>(A); } \
+  extern "C" __global__ __launch_bounds__(PK_BLOCK) void pk_aux(PkArgs A) { pk::kernel_aux<GEN>(A); }   \
+  extern "C" __global__ __launch_bounds__(PK_BLOCK) void pk_outer(PkArgs A) { pk::kernel_outer(A); }

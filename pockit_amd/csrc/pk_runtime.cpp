@@ -30,8 +30,9 @@
 
 namespace {
 
-enum { K_INT = 0, K_FIN, K_G, K_GRAD, K_JAC, K_HESS, K_XALL, K_COUNT };
-const char* const kKernelNames[K_COUNT] = {"pk_int", "pk_fin", "pk_g", "pk_grad", "pk_jac", "pk_hess", "pk_xall"};
+enum { K_INT = 0, K_FIN, K_G, K_GRAD, K_JAC, K_HESS, K_XALL, K_AUX, K_OUTER, K_COUNT };
+const char* const kKernelNames[K_COUNT] = {"pk_int", "pk_fin", "pk_g", "pk_grad", "pk_jac", "pk_hess", "pk_xall",
+                                           "pk_aux", "pk_outer"};
 enum { F_WRITE_F = 1, F_SECONDARY = 2, F_FIN_INT = 8, F_FIN_GRAD = 16 };
 
 thread_local std::string g_create_error;
@@ -57,8 +58,10 @@ struct pk_ctx {
   // problem
   int32_t n = 0, m = 0, n_sys = 0, n_s = 0, l_s = 0, n_phase = 0, n_tiles = 0;
   int64_t nnz_J = 0, nnz_H = 0;
-  int32_t n_items_jac = 0, n_items_hess = 0, gz_off = 0, n_gz = 0;
-  void *d_phases = nullptr, *d_tiles = nullptr, *d_kinds = nullptr, *d_items_jac = nullptr, *d_items_hess = nullptr;
+  int32_t n_items_jac = 0, n_items_hess = 0, n_items_aux = 0, n_outer = 0, n_aux = 0, gz_off = 0, n_gz = 0;
+  void *d_phases = nullptr, *d_tiles = nullptr, *d_kinds = nullptr, *d_items_jac = nullptr, *d_items_hess = nullptr,
+       *d_items_aux = nullptr, *d_outer = nullptr;
+  double* d_aux = nullptr;
   int32_t* d_ib = nullptr;
   double* d_db = nullptr;
   int64_t* d_lb = nullptr;
@@ -101,7 +104,7 @@ void release(T*& p) {
 }
 
 void free_problem(pk_ctx* c) {
-  release(c->d_phases); release(c->d_tiles); release(c->d_kinds); release(c->d_items_jac); release(c->d_items_hess);
+  release(c->d_phases); release(c->d_tiles); release(c->d_kinds); release(c->d_items_jac); release(c->d_items_hess); release(c->d_items_aux); release(c->d_outer); release(c->d_aux);
   release(c->d_ib); release(c->d_db); release(c->d_lb);
   release(c->d_x); release(c->d_lam); release(c->d_f); release(c->d_grad); release(c->d_g); release(c->d_J);
   release(c->d_H); release(c->d_I); release(c->d_partial); release(c->d_partial2);
@@ -129,7 +132,7 @@ PkArgs base_args(pk_ctx* c, const double* d_x, const double* d_lam, double sigma
   A.x = d_x; A.lam = d_lam; A.sigma = sigma;
   A.phase = (const PkPhase*)c->d_phases; A.tile = (const PkTile*)c->d_tiles; A.kind = (const PkKind*)c->d_kinds;
   A.items = nullptr; A.ib = c->d_ib; A.db = c->d_db; A.lb = c->d_lb;
-  A.Ibuf = c->ext_I ? c->ext_I : c->d_I; A.partial = c->d_partial; A.partial2 = c->d_partial2;
+  A.Ibuf = c->ext_I ? c->ext_I : c->d_I; A.partial = c->d_partial; A.partial2 = c->d_partial2; A.o_aux = c->d_aux; A.outer = (const PkOuter*)c->d_outer; A.n_outer = c->n_outer;
   A.n_tiles = c->n_tiles; A.n_items = 0; A.n_phase = c->n_phase; A.n = c->n;
   A.l_s = c->l_s; A.n_s = c->n_s; A.n_sys = c->n_sys; A.m = c->m;
   A.gz_off = c->gz_off; A.n_gz = c->n_gz; A.flags = c->shard_flags | c->debug_flags;
@@ -251,6 +254,7 @@ int pk_set_problem(pk_ctx* c, const pk_problem_desc* pd) {
   c->n = pd->n; c->m = pd->m; c->n_sys = pd->n_sys; c->n_s = pd->n_s; c->l_s = pd->l_s;
   c->n_phase = pd->n_phase; c->n_tiles = pd->n_tiles; c->nnz_J = pd->nnz_J; c->nnz_H = pd->nnz_H;
   c->n_items_jac = pd->n_items_jac; c->n_items_hess = pd->n_items_hess; c->gz_off = pd->gz_off; c->n_gz = pd->n_gz;
+  c->n_items_aux = pd->n_items_aux; c->n_outer = pd->n_outer; c->n_aux = pd->n_aux;
   int rc;
   if ((rc = upload(c, &c->d_phases, pd->phases, sizeof(PkPhase) * (size_t)pd->n_phase))) return rc;
   c->h_phases.assign((const PkPhase*)pd->phases, (const PkPhase*)pd->phases + pd->n_phase);
@@ -259,6 +263,8 @@ int pk_set_problem(pk_ctx* c, const pk_problem_desc* pd) {
   if ((rc = upload(c, &c->d_kinds, pd->kinds, sizeof(PkKind) * (size_t)pd->n_kinds))) return rc;
   if ((rc = upload(c, &c->d_items_jac, pd->items_jac, sizeof(PkItem) * (size_t)pd->n_items_jac))) return rc;
   if ((rc = upload(c, &c->d_items_hess, pd->items_hess, sizeof(PkItem) * (size_t)pd->n_items_hess))) return rc;
+  if ((rc = upload(c, &c->d_items_aux, pd->items_aux, sizeof(PkItem) * (size_t)pd->n_items_aux))) return rc;
+  if ((rc = upload(c, &c->d_outer, pd->outer, sizeof(PkOuter) * (size_t)pd->n_outer))) return rc;
   if ((rc = upload(c, (void**)&c->d_ib, pd->ib, sizeof(int32_t) * (size_t)pd->n_ib))) return rc;
   if ((rc = upload(c, (void**)&c->d_db, pd->db, sizeof(double) * (size_t)pd->n_db))) return rc;
   if ((rc = upload(c, (void**)&c->d_lb, pd->lb, sizeof(int64_t) * (size_t)pd->n_lb))) return rc;
@@ -269,7 +275,7 @@ int pk_set_problem(pk_ctx* c, const pk_problem_desc* pd) {
   };
   if ((rc = dalloc(&c->d_x, c->n)) || (rc = dalloc(&c->d_lam, c->m)) || (rc = dalloc(&c->d_f, 1)) ||
       (rc = dalloc(&c->d_grad, c->n)) || (rc = dalloc(&c->d_g, c->m)) || (rc = dalloc(&c->d_J, (size_t)c->nnz_J)) ||
-      (rc = dalloc(&c->d_H, (size_t)c->nnz_H)) || (rc = dalloc(&c->d_I, c->md.n_I)) ||
+      (rc = dalloc(&c->d_H, (size_t)c->nnz_H)) || (rc = dalloc(&c->d_aux, (size_t)c->n_aux)) || (rc = dalloc(&c->d_I, c->md.n_I)) ||
       (rc = dalloc(&c->d_partial, ((size_t)c->n_tiles / PK_WAVES_PER_BLOCK + 2) * (size_t)c->md.nred)) ||
       (rc = dalloc(&c->d_partial2, ((size_t)c->n_tiles / PK_WAVES_PER_BLOCK + 2) * (size_t)c->md.nred)))
     return rc;
@@ -374,7 +380,17 @@ int pk_eval_hess_dev(pk_ctx* c, const double* d_x, const double* d_lam, double s
   A.n_items = c->n_items_hess;
   size_t lds = sizeof(double) * PK_WAVES_PER_BLOCK * (size_t)c->md.lds_h;
   if (lds < sizeof(double) * (size_t)c->md.ne_h) lds = sizeof(double) * (size_t)c->md.ne_h;
-  return launch(c, K_HESS, A, tile_blocks(c) + 1, lds, st);
+  if ((rc = launch(c, K_HESS, A, tile_blocks(c) + 1, lds, st))) return rc;
+  if (c->n_outer > 0) {   // objective / system constraints nonlinear in the integrals: outer-product blocks
+    PkArgs X = base_args(c, d_x, d_lam, sigma);
+    X.o_hess = d_vals;
+    X.items = (const PkItem*)c->d_items_aux;
+    X.n_items = c->n_items_aux;
+    if ((rc = launch(c, K_AUX, X, tile_blocks(c) + 1, sizeof(double) * (size_t)(c->md.ne_a > 0 ? c->md.ne_a : 1), st))) return rc;
+    const unsigned grid = (unsigned)(c->n_outer < 4096 ? c->n_outer : 4096);
+    return launch(c, K_OUTER, X, grid, 0, st);
+  }
+  return 0;
 }
 
 int pk_eval_cycle_dev(pk_ctx* c, const double* d_x, const double* d_lam, double sigma, double* d_f, double* d_grad,

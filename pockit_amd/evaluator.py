@@ -78,7 +78,7 @@ class Tables:
             ph["tau_off"] = put(db, lay.tau, np.float64)
             ph["w_off"] = put(db, lay.w, np.float64)
             ph["width_off"] = put(db, lay.width, np.float64)
-            for cbname, field in (("jac", "jseg_off"), ("hess", "hseg_off")):
+            for cbname, field in (("jac", "jseg_off"), ("hess", "hseg_off"), ("aux", "aseg_off")):
                 segs = getattr(plan, cbname).segs[k]
                 bases = [s.base for s in segs if s.kind == "I"] + [s.base for s in segs if s.kind == "N"]
                 ph[field] = put(lb, bases, np.int64)
@@ -120,7 +120,11 @@ class Tables:
                 arr[i] = (it.pos, it.coef, off[it.lst] + it.eid, it.lam)
             return arr
 
-        self.items_jac, self.items_hess = items("jac"), items("hess")
+        self.items_jac, self.items_hess, self.items_aux = items("jac"), items("hess"), items("aux")
+        self.outer = np.zeros(len(plan.outer), dtype=runtime.OUTER_DTYPE)
+        for i, b in enumerate(plan.outer):
+            flags = (1 if b.tril else 0) | (2 if b.collapseA else 0) | (4 if b.collapseB else 0) | (8 if b.second else 0)
+            self.outer[i] = (b.pos, b.offA, b.lenA, b.offB, b.lenB, b.offM, flags, b.count, 0)
         self.phases = phases
         self.kinds = np.array(kinds, dtype=runtime.KIND_DTYPE) if kinds else np.zeros(0, runtime.KIND_DTYPE)
         self.tiles = np.array(tiles, dtype=runtime.TILE_DTYPE) if tiles else np.zeros(0, runtime.TILE_DTYPE)
@@ -142,6 +146,7 @@ class Evaluator:
         md.n_phase, md.n_I, md.nred = self.src.nphase, max(len(plan.I_syms), 1), self.src.nred
         md.lds_g, md.lds_j, md.lds_h, md.lds_x = self.src.lds_g, self.src.lds_j, self.src.lds_h, self.src.lds_x
         md.ne_j, md.ne_h = self.src.list_off["jac"]["total"], self.src.list_off["hess"]["total"]
+        md.ne_a = self.src.list_off["aux"]["total"]
         md.prepass_f = 1
         md.prepass_grad = int(plan.needs_I_grad)
         md.prepass_g = int(plan.needs_I_con)
@@ -167,6 +172,8 @@ class Evaluator:
         pd.db, pd.n_db = tb.db.ctypes.data_as(runtime.c_double_p), len(tb.db)
         pd.lb, pd.n_lb = tb.lb.ctypes.data_as(C.POINTER(C.c_int64)), len(tb.lb)
         pd.gz_off, pd.n_gz = tb.gz_off, tb.n_gz
+        pd.items_aux, pd.n_items_aux = vp(tb.items_aux), len(tb.items_aux)
+        pd.outer, pd.n_outer, pd.n_aux = vp(tb.outer), len(tb.outer), plan.n_aux
         self._struct = [np.ascontiguousarray(a, dtype=np.int32) for a in
                         (plan.jac_row, plan.jac_col, plan.hess_row, plan.hess_col)]
         pd.jac_row, pd.jac_col, pd.hess_row, pd.hess_col = (a.ctypes.data_as(runtime.c_int32_p) for a in self._struct)

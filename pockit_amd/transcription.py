@@ -212,6 +212,24 @@ class Item:
     lam: int = -1
 
 
+@dataclass
+class OuterBlock:
+    """One outer-product block of a system-level Hessian (objective / system constraint nonlinear in
+    the integrals; reference: easyderiv.py:323-355,393-430).  A and B are gradient-entry value runs in
+    the auxiliary buffer; m is the location of the scalar multiplier factor * d2F/da db."""
+    pos: int
+    offA: int
+    lenA: int
+    offB: int
+    lenB: int
+    offM: int
+    tril: bool = False        # False: kron(A, B); True: lower-triangular products of (collapsed) A and B
+    collapseA: bool = False   # replace the run by its sum (a dense column met the same column)
+    collapseB: bool = False
+    second: bool = False      # tril only: also emit the transposed products (off-diagonal local pair)
+    count: int = 0            # number of output entries
+
+
 class CallbackPlan:
     def __init__(self, nphase):
         self.segs = [[] for _ in range(nphase)]        # per phase: list[Seg]
@@ -260,6 +278,10 @@ class SystemPlan:
 
         self.jac = CallbackPlan(nP)
         self.hess = CallbackPlan(nP)
+        self.aux = CallbackPlan(nP)       # auxiliary buffer: integral gradient entries (x w) and multipliers
+        self.outer: list[OuterBlock] = []
+        self.n_aux = 0
+        self._aux_entries = {}
         self._plan_jacobian()
         self._plan_hessian()
         self._plan_values_and_gradient()
@@ -319,6 +341,44 @@ class SystemPlan:
             return self.l_p[k] + lay.l_v[idx[1]] + np.asarray(q, dtype=np.int64)
         c = int(idx[1])
         return np.int64(self.l_p[k] + c if c >= 0 else self.r_s + c)
+
+    # ------------------------------------------------------------------ auxiliary buffer
+    def _aux_scalar(self, key, expr):
+        off = self.n_aux
+        self.aux.items.append(Item(off, 1.0, key, self.aux.entry(key, expr)))
+        self.n_aux += 1
+        return off
+
+    def _arg_entries(self, a):
+        """[(NLP index array, (offset, length) in the auxiliary buffer)] of system argument a: the
+        quadrature-weighted gradient entries of an integral (front | middle | back, as
+        systembase.py:376-408) or the single unit entry of a static parameter."""
+        if a in self._aux_entries:
+            return self._aux_entries[a]
+        nI = len(self.I_syms)
+        out = []
+        if a >= nI:
+            out.append((np.array([self.l_s + (a - nI)], dtype=np.int64), (self._aux_scalar(("s",), sp.Integer(1)), 1)))
+        else:
+            k, i = self.I_owner[a]
+            pp = self.phase_plans[k]
+            lay = pp.layout
+            nodes = pp.int_nodes[i]
+            q = np.arange(lay.mid_lo, lay.mid_hi)
+            for idx, e in nodes["f"].G:
+                out.append((np.array([self.col(k, idx, 0)], dtype=np.int64), (self._aux_scalar(("f", k), WQ * e), 1)))
+            for idx, e in nodes["m"].G:
+                if lay.L_mid == 0:
+                    continue
+                self.aux.segs[k].append(Seg(WQ * e, "N", self.n_aux))
+                out.append((np.broadcast_to(self.col(k, idx, q), q.shape).astype(np.int64), (self.n_aux, lay.L_mid)))
+                self.n_aux += lay.L_mid
+            if lay.has_back:
+                for idx, e in nodes["b"].G:
+                    out.append((np.array([self.col(k, idx, lay.L_m - 1)], dtype=np.int64),
+                                (self._aux_scalar(("b", k), WQ * e), 1)))
+        self._aux_entries[a] = out
+        return out
 
     def _uses_I(self, expr):
         return bool(sp.sympify(expr).free_symbols & set(self.I_syms))
@@ -446,13 +506,37 @@ class SystemPlan:
                         scalar(self.col(k, r, lay.L_m - 1), self.col(k, c, lay.L_m - 1), 1.0, ("b", k),
                                factor * m * WQ * e)
             for pr, pc, h in zip(fn.H_index_row.tolist(), fn.H_index_col.tolist(), fn.hess):   # h-G part
-                if pr < nI or pc < nI:
-                    raise NotImplementedError(
-                        "objective / system constraints that are nonlinear in the integrals I_k need the "
-                        "outer-product Hessian blocks (reference easyderiv.py:323-459); not supported by "
-                        "the HIP evaluator yet")
                 cb.needs_I |= self._uses_I(h)
-                scalar(self.l_s + (pr - nI), self.l_s + (pc - nI), 1.0, ("s",), factor * h)
+                if pr >= nI and pc >= nI:
+                    scalar(self.l_s + (pr - nI), self.l_s + (pc - nI), 1.0, ("s",), factor * h)
+                    continue
+                # outer products of whole gradient-entry runs (reference: easyderiv.py:323-355,393-430)
+                cb.needs_I = True
+                offM = self._aux_scalar(("s",), factor * h)
+                diag = pr == pc
+                for ri, (offA, lenA) in self._arg_entries(pr):
+                    for ci, (offB, lenB) in self._arg_entries(pc):
+                        a_i, a_o, a_l, b_i, b_o, b_l = ri, offA, lenA, ci, offB, lenB
+                        if a_i[0] < b_i[0]:
+                            if diag:
+                                continue
+                            a_i, a_o, a_l, b_i, b_o, b_l = b_i, b_o, b_l, a_i, a_o, a_l
+                        if a_i[0] > b_i[0]:
+                            rows.append(np.repeat(a_i, len(b_i)))
+                            cols.append(np.tile(b_i, len(a_i)))
+                            blk = OuterBlock(pos, a_o, a_l, b_o, b_l, offM, count=a_l * b_l)
+                        else:
+                            ca = len(a_i) > 1 and a_i[0] == a_i[-1]
+                            cbb = len(b_i) > 1 and b_i[0] == b_i[-1]
+                            idx = a_i[:1] if ca else a_i
+                            tr, tc = np.tril_indices(len(idx))
+                            rows.append(idx[tr]); cols.append(idx[tc])
+                            if not diag:
+                                rows.append(idx[tr]); cols.append(idx[tc])
+                            blk = OuterBlock(pos, a_o, a_l, b_o, b_l, offM, tril=True, collapseA=ca, collapseB=cbb,
+                                             second=not diag, count=len(tr) * (1 if diag else 2))
+                        self.outer.append(blk)
+                        pos += blk.count
 
         system_function(self.F_o, SIG)
         self.nnz_H_obj = pos

@@ -90,7 +90,7 @@ class Interp:
             vals[lam_sys(c)] = self.lam[c]
         return [float(sp.sympify(e).subs(vals)) for e in exprs]
 
-    def _run(self, cb, nnz, with_lambda):
+    def _run(self, cb, nnz, with_lambda, complete=True):
         plan = self.plan
         out = np.full(nnz, np.nan)
         for k, pp in enumerate(plan.phase_plans):
@@ -124,14 +124,33 @@ class Interp:
             if it.lam >= 0:
                 v *= self.lam[it.lam]
             out[it.pos] = v
-        assert not np.isnan(out).any(), "plan does not cover every output slot"
+        if complete:
+            assert not np.isnan(out).any(), "plan does not cover every output slot"
         return out
 
     def jacobian(self):
         return self._run(self.plan.jac, self.plan.nnz_J, False)
 
     def hessian(self):
-        return self._run(self.plan.hess, self.plan.nnz_H, True)
+        plan = self.plan
+        out = self._run(plan.hess, plan.nnz_H, True, complete=not plan.outer)
+        if plan.outer:
+            gi = self._run(plan.aux, plan.n_aux, False)          # integral gradient entries x w, multipliers
+            for b in plan.outer:
+                A, B, m = gi[b.offA: b.offA + b.lenA], gi[b.offB: b.offB + b.lenB], gi[b.offM]
+                if not b.tril:
+                    vals = np.kron(A, B) * m
+                else:
+                    A2 = np.array([A.sum()]) if b.collapseA else A
+                    B2 = np.array([B.sum()]) if b.collapseB else B
+                    tr, tc = np.tril_indices(len(A2))
+                    vals = A2[tr] * B2[tc] * m
+                    if b.second:
+                        vals = np.concatenate([vals, B2[tr] * A2[tc] * m])
+                assert len(vals) == b.count
+                out[b.pos: b.pos + b.count] = vals
+            assert not np.isnan(out).any(), "plan does not cover every output slot"
+        return out
 
     def objective(self):
         return self._eval_sys([self.plan.F_o.expr])[0]

@@ -29,6 +29,7 @@ def test_struct_sizes_match_the_c_abi():
     assert runtime.TILE_DTYPE.itemsize == 18 * 4
     assert runtime.KIND_DTYPE.itemsize == 8 * 4
     assert runtime.ITEM_DTYPE.itemsize == 24
+    assert runtime.OUTER_DTYPE.itemsize == 40
     assert C.sizeof(runtime.ModelDesc) == 16 * 4
 
 

@@ -30,7 +30,7 @@ def _ns(scheme, pkg):
 
 
 def _supported(name):
-    return not (name.startswith("derivative_") or name.startswith("functimes_"))
+    return True
 
 
 @pytest.mark.parametrize("name", sorted(n for n in models.SMALL_CASES if _supported(n)))

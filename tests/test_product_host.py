@@ -186,7 +186,7 @@ def test_setter_errors_match_reference_messages():
 
 
 # ------------------------------------------------------------------ transcription compiler
-@pytest.mark.parametrize("name", sorted(n for n in models.SMALL_CASES if not n.startswith(NONLINEAR_IN_I)))
+@pytest.mark.parametrize("name", sorted(models.SMALL_CASES))
 def test_plan_reproduces_reference(name):
     """Triplet structure identical to the reference; the evaluation plan (executed in NumPy exactly
     as the kernels consume it) reproduces the reference's f, grad f, g, J, H."""
@@ -208,7 +208,13 @@ def test_plan_reproduces_reference(name):
     close(it.hessian(), gold["H"])
 
 
-def test_nonlinear_in_integrals_fails_loudly():
+def test_nonlinear_in_integrals_uses_outer_blocks():
+    """Objective (I0+I1+s0)^2 and constraint s1/2*I0 of the reference's FD test model need the
+    outer-product Hessian blocks (easyderiv.py:323-459); their counts must add up to the layout."""
     system, _, _ = models.derivative_model(radau)
-    with pytest.raises(NotImplementedError):
-        system.plan  # noqa: B018
+    plan = system.plan
+    assert plan.outer and plan.hess.needs_I and plan.jac.needs_I and plan.needs_I_grad
+    covered = sum(b.count for b in plan.outer) + len(plan.hess.items)
+    covered += sum(pp.layout.L_mid for k, pp in enumerate(plan.phase_plans) for sg in plan.hess.segs[k] if sg.kind == "N")
+    covered += sum(pp.layout.nnzI_mid for k, pp in enumerate(plan.phase_plans) for sg in plan.hess.segs[k] if sg.kind == "I")
+    assert covered == plan.nnz_H
