@@ -72,7 +72,7 @@ def build_workload(name, intervals, ns):
     raise ValueError(name)
 
 
-def cpu_baseline(name, intervals, budget_s=12.0, max_cycles=200):
+def cpu_baseline(name, intervals, budget_s=12.0, max_cycles=5000):
     """The oracle (NumPy restatement of the reference algorithm, single thread) on the same workload."""
     import models
     import oracle.radau

@@ -17,6 +17,7 @@
 // There is no CPU evaluation path: every entry point fails with an error code when no device /
 // code object / problem is present.
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 
 #include <cstdarg>
 #include <cstdio>
@@ -147,6 +148,9 @@ int launch(pk_ctx* c, int k, PkArgs& A, unsigned grid, size_t lds_bytes, hipStre
   if (grid == 0) return 0;
   const bool timed = c->profiling && ((c->profile_mask >> k) & 1u);
   if (timed) {
+    // Timed launch: hipExtModuleLaunchKernel attaches the events to the dispatch packet itself, so
+    // elapsed(a, b) is the kernel's own start->end on this stream (what rocprofv3 reports), without
+    // the command-processor gaps a hipEventRecord pair around the launch would add.
     if (!c->free_events.empty()) {
       ev = c->free_events.back();
       c->free_events.pop_back();
@@ -154,13 +158,12 @@ int launch(pk_ctx* c, int k, PkArgs& A, unsigned grid, size_t lds_bytes, hipStre
       PK_HIP(c, hipEventCreate(&ev.a));
       PK_HIP(c, hipEventCreate(&ev.b));
     }
-    PK_HIP(c, hipEventRecord(ev.a, st));
+    PK_HIP(c, hipExtModuleLaunchKernel(c->fn[k], grid * PK_BLOCK, 1, 1, PK_BLOCK, 1, 1, lds_bytes, st, nullptr, config,
+                                       ev.a, ev.b, 0));
+    c->pending[k].push_back(ev);
+    return 0;
   }
   PK_HIP(c, hipModuleLaunchKernel(c->fn[k], grid, 1, 1, PK_BLOCK, 1, 1, (unsigned)lds_bytes, st, nullptr, config));
-  if (timed) {
-    PK_HIP(c, hipEventRecord(ev.b, st));
-    c->pending[k].push_back(ev);
-  }
   return 0;
 }
 

@@ -35,7 +35,11 @@ def tile_filter(rank: int, world: int):
 
 
 class ShardedEvaluator:
-    """Rank-local evaluator + collectives.  ``dist`` is an initialised torch.distributed module."""
+    """Rank-local evaluator + collectives.  ``dist`` is an initialised torch.distributed module.
+
+    All rank-local results live in ONE packed device buffer ``[I | grad | g | J | H]`` so that the
+    reassembly is a single collective per cycle (xGMI collectives are latency-bound at these sizes:
+    five ~MB-sized all-reduces cost several times one packed all-reduce)."""
 
     def __init__(self, plan, rank, world, device=0, intervals_per_wave=None):
         import torch
@@ -46,16 +50,19 @@ class ShardedEvaluator:
         self.ev = Evaluator(plan, device=device, intervals_per_wave=intervals_per_wave,
                             tile_filter=tile_filter(rank, world) if world > 1 else None)
         dev = torch.device("cuda", device)
-        self.I = torch.zeros(max(len(plan.I_syms), 1), dtype=torch.float64, device=dev)
+        n_I = max(len(plan.I_syms), 1)
+        # integrals that later kernels need (models nonlinear in I) must be global *before* those kernels
+        self.early_I = bool(plan.needs_I_grad or plan.needs_I_con or plan.jac.needs_I or plan.hess.needs_I)
+        sizes = [("I", n_I), ("grad", plan.n), ("g", plan.m), ("J", plan.nnz_J), ("H", plan.nnz_H)]
+        self.pack = torch.zeros(sum(n for _, n in sizes), dtype=torch.float64, device=dev)
+        self.out, off = {}, 0
+        for name, n in sizes:
+            self.out[name] = self.pack[off: off + n]
+            off += n
+        self.out["f"] = torch.zeros(1, dtype=torch.float64, device=dev)
+        self.I = self.out["I"]
         lib, h = self.ev.ctx.lib, self.ev.ctx.handle
         self.ev.ctx.check(lib.pk_set_shard(h, int(rank != 0), 1, C.c_void_p(self.I.data_ptr())))
-        self.out = {
-            "f": torch.zeros(1, dtype=torch.float64, device=dev),
-            "grad": torch.zeros(plan.n, dtype=torch.float64, device=dev),
-            "g": torch.zeros(plan.m, dtype=torch.float64, device=dev),
-            "J": torch.zeros(plan.nnz_J, dtype=torch.float64, device=dev),
-            "H": torch.zeros(plan.nnz_H, dtype=torch.float64, device=dev),
-        }
 
     def cycle(self, x, lam, sigma, dist=None):
         """One f, grad f, g, J, H cycle on device tensors; results (reference order, complete on
@@ -66,18 +73,19 @@ class ShardedEvaluator:
         o = self.out
         sharded = dist is not None and self.world > 1
         if sharded:
-            for k in ("grad", "g", "J", "H"):
-                o[k].zero_()
+            self.pack.zero_()
         px = C.c_void_p(x.data_ptr())
-        chk(lib.pk_eval_integrals_dev(h, px, st))
-        if sharded:
+        chk(lib.pk_eval_integrals_dev(h, px, st))                      # this shard's share of every integral
+        if sharded and self.early_I:
             dist.all_reduce(self.I)
-        chk(lib.pk_eval_f_from_integrals_dev(h, px, C.c_void_p(o["f"].data_ptr()), st))
         chk(lib.pk_eval_grad_dev(h, px, C.c_void_p(o["grad"].data_ptr()), st))
         chk(lib.pk_eval_g_dev(h, px, C.c_void_p(o["g"].data_ptr()), st))
         chk(lib.pk_eval_jac_dev(h, px, C.c_void_p(o["J"].data_ptr()), st))
         chk(lib.pk_eval_hess_dev(h, px, C.c_void_p(lam.data_ptr()), float(sigma), C.c_void_p(o["H"].data_ptr()), st))
         if sharded:
-            for k in ("grad", "g", "J", "H"):
-                dist.all_reduce(o[k])
+            if self.early_I:
+                dist.all_reduce(self.pack[self.I.numel():])
+            else:
+                dist.all_reduce(self.pack)                             # integrals ride along
+        chk(lib.pk_eval_f_from_integrals_dev(h, px, C.c_void_p(o["f"].data_ptr()), st))
         return o

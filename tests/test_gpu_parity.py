@@ -101,7 +101,8 @@ def test_full_size_configs_match_reference_summary():
     import json
 
     full = json.load(open(os.path.join(HERE, "golden", "full.json")))
-    for name in ("C2_brach_lgr_200x8", "S_brach_lgr_1250x8", "C3_quad_lgr_2000x6", "C4_rocket_lgr_2x1000x4"):
+    for name in ("C2_brach_lgr_200x8", "S_brach_lgr_1250x8", "C3_quad_lgr_2000x6", "C4_rocket_lgr_2x1000x4",
+                 "C5_humanoid_lgr_5000x8"):
         gold = full[name]
         builder, scheme, kw = models.FULL_CASES[name]
         system, _, guess = builder(_ns(scheme, "pockit_amd"), **kw)
@@ -168,6 +169,7 @@ def test_two_shards_on_one_gpu_reassemble_to_the_oracle():
         outs.append({k: torch.zeros(n, dtype=torch.float64, device=dev) for k, n in
                      (("f", 1), ("grad", plan.n), ("g", plan.m), ("J", plan.nnz_J), ("H", plan.nnz_H))})
     p = lambda t: C.c_void_p(t.data_ptr())  # noqa: E731
+    torch.cuda.synchronize()             # torch's zero-fills run on its own stream; the contexts use theirs
     for ev in evs:
         ev.ctx.check(ev.ctx.lib.pk_eval_integrals_dev(ev.ctx.handle, p(dx), None))
         ev.sync()
