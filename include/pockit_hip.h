@@ -109,6 +109,17 @@ int pk_eval_hess(pk_ctx* ctx, const double* x, const double* lambda, double sigm
 int pk_eval_cycle(pk_ctx* ctx, const double* x, const double* lambda, double sigma, double* f, double* grad,
                   double* g, double* jac, double* hess);
 
+/* "new x" protocol for host shims (IPOPT calls f, grad f, g, J separately but on the same iterate):
+ * pk_prepare_x uploads x once and runs the fused x-kernel; pk_fetch copies one result out
+ * (what: 0 f, 1 grad[n], 2 g[m], 3 jac[nnz_J]); pk_eval_hess_prepared reuses the uploaded x. */
+int pk_prepare_x(pk_ctx* ctx, const double* x);
+int pk_fetch(pk_ctx* ctx, int what, double* out);
+int pk_eval_hess_prepared(pk_ctx* ctx, const double* lambda, double sigma, double* vals);
+/* Pinned (page-locked) result buffers owned by the context: what = 0 f, 1 grad, 2 g, 3 jac, 4 hess.  Passing
+ * out == NULL / vals == NULL to pk_fetch / pk_eval_hess_prepared leaves the result there: one DMA at full PCIe
+ * rate and no second host copy.  The buffers are reused by the next call for the same output. */
+int pk_host_buffer(pk_ctx* ctx, int what, double** ptr, int64_t* count);
+
 /* device-pointer API: enqueue on ``stream`` (hipStream_t, NULL = context stream), no sync */
 int pk_eval_f_dev(pk_ctx* ctx, const double* d_x, double* d_f, void* stream);
 int pk_eval_grad_dev(pk_ctx* ctx, const double* d_x, double* d_grad, void* stream);

@@ -72,6 +72,8 @@ struct pk_ctx {
   std::vector<PkPhase> h_phases;
   std::vector<EventPair> free_events;
   std::vector<int32_t> jac_row, jac_col, hess_row, hess_col;
+  // pinned host staging (zero-copy results for host shims): x, lambda, f, grad, g, J, H
+  double *h_x = nullptr, *h_lam = nullptr, *h_out[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
   // profiling
   bool profiling = false;
   std::vector<EventPair> pending[K_COUNT];
@@ -109,6 +111,13 @@ void free_problem(pk_ctx* c) {
   release(c->d_ib); release(c->d_db); release(c->d_lb);
   release(c->d_x); release(c->d_lam); release(c->d_f); release(c->d_grad); release(c->d_g); release(c->d_J);
   release(c->d_H); release(c->d_I); release(c->d_partial); release(c->d_partial2);
+  if (c->h_x) (void)hipHostFree(c->h_x);
+  if (c->h_lam) (void)hipHostFree(c->h_lam);
+  c->h_x = c->h_lam = nullptr;
+  for (auto& p : c->h_out) {
+    if (p) (void)hipHostFree(p);
+    p = nullptr;
+  }
   c->have_problem = false;
 }
 
@@ -282,6 +291,13 @@ int pk_set_problem(pk_ctx* c, const pk_problem_desc* pd) {
       (rc = dalloc(&c->d_partial, ((size_t)c->n_tiles / PK_WAVES_PER_BLOCK + 2) * (size_t)c->md.nred)) ||
       (rc = dalloc(&c->d_partial2, ((size_t)c->n_tiles / PK_WAVES_PER_BLOCK + 2) * (size_t)c->md.nred)))
     return rc;
+  {
+    const size_t cnt[5] = {1, (size_t)c->n, (size_t)c->m, (size_t)c->nnz_J, (size_t)c->nnz_H};
+    PK_HIP(c, hipHostMalloc((void**)&c->h_x, sizeof(double) * (size_t)(c->n ? c->n : 1), hipHostMallocDefault));
+    PK_HIP(c, hipHostMalloc((void**)&c->h_lam, sizeof(double) * (size_t)(c->m ? c->m : 1), hipHostMallocDefault));
+    for (int k = 0; k < 5; ++k)
+      PK_HIP(c, hipHostMalloc((void**)&c->h_out[k], sizeof(double) * (cnt[k] ? cnt[k] : 1), hipHostMallocDefault));
+  }
   auto keep = [](std::vector<int32_t>& v, const int32_t* src, int64_t cnt) {
     v.clear();
     if (src) v.assign(src, src + cnt);
@@ -481,6 +497,73 @@ int pk_eval_cycle(pk_ctx* c, const double* x, const double* lambda, double sigma
   PK_HIP(c, hipMemcpyAsync(jac, c->d_J, sizeof(double) * (size_t)c->nnz_J, hipMemcpyDeviceToHost, c->stream));
   PK_HIP(c, hipMemcpyAsync(hess, c->d_H, sizeof(double) * (size_t)c->nnz_H, hipMemcpyDeviceToHost, c->stream));
   PK_HIP(c, hipStreamSynchronize(c->stream));
+  return 0;
+}
+
+// "new x" protocol of the host shim: one upload + one fused launch serves objective, gradient, constraints and
+// Jacobian of the same x (IPOPT evaluates them separately but on the same iterate); pk_fetch copies one out.
+int pk_prepare_x(pk_ctx* c, const double* x) {
+  int rc = ready(c);
+  if (rc) return rc;
+  if (!x) return fail(c, 60, "null host buffer");
+  PK_HIP(c, hipSetDevice(c->device));
+  PK_HIP(c, hipStreamSynchronize(c->stream));              // the previous upload must have left the staging buffer
+  std::memcpy(c->h_x, x, sizeof(double) * (size_t)c->n);
+  PK_HIP(c, hipMemcpyAsync(c->d_x, c->h_x, sizeof(double) * (size_t)c->n, hipMemcpyHostToDevice, c->stream));
+  const bool needs_I = c->md.prepass_grad || c->md.prepass_g || c->md.prepass_jac || c->md.prepass_hess;
+  if (needs_I || c->external_prepass || c->shard_flags) {
+    if ((rc = pk_eval_f_dev(c, c->d_x, c->d_f, nullptr))) return rc;
+    if ((rc = pk_eval_grad_dev(c, c->d_x, c->d_grad, nullptr))) return rc;
+    if ((rc = pk_eval_g_dev(c, c->d_x, c->d_g, nullptr))) return rc;
+    return pk_eval_jac_dev(c, c->d_x, c->d_J, nullptr);
+  }
+  PkArgs A = base_args(c, c->d_x, nullptr, 0.0);
+  A.o_f = c->d_f; A.o_grad = c->d_grad; A.o_g = c->d_g; A.o_jac = c->d_J;
+  A.items = (const PkItem*)c->d_items_jac;
+  A.n_items = c->n_items_jac;
+  size_t lds = sizeof(double) * PK_WAVES_PER_BLOCK * (size_t)c->md.lds_x;
+  if (lds < sizeof(double) * (size_t)c->md.ne_j) lds = sizeof(double) * (size_t)c->md.ne_j;
+  if ((rc = launch(c, K_XALL, A, tile_blocks(c) + 1, lds, c->stream))) return rc;
+  A.flags |= F_FIN_INT | F_WRITE_F | F_FIN_GRAD;
+  return launch(c, K_FIN, A, 1, 0, c->stream);
+}
+
+int pk_fetch(pk_ctx* c, int what, double* out) {
+  int rc = ready(c);
+  if (rc) return rc;
+  const double* src[4] = {c->d_f, c->d_grad, c->d_g, c->d_J};
+  const size_t cnt[4] = {1, (size_t)c->n, (size_t)c->m, (size_t)c->nnz_J};
+  if (what < 0 || what > 3) return fail(c, 61, "pk_fetch: what must be 0 (f), 1 (grad), 2 (g) or 3 (jac)");
+  // out == NULL: leave the result in the context's pinned buffer (pk_host_buffer), no second copy
+  PK_HIP(c, hipMemcpyAsync(out ? out : c->h_out[what], src[what], sizeof(double) * cnt[what], hipMemcpyDeviceToHost,
+                           c->stream));
+  PK_HIP(c, hipStreamSynchronize(c->stream));
+  return 0;
+}
+
+// Hessian on the x of the last pk_prepare_x (no re-upload of x); vals == NULL: result stays in the pinned buffer
+int pk_eval_hess_prepared(pk_ctx* c, const double* lambda, double sigma, double* vals) {
+  int rc = ready(c);
+  if (rc) return rc;
+  if (!lambda) return fail(c, 60, "null host buffer");
+  PK_HIP(c, hipStreamSynchronize(c->stream));
+  std::memcpy(c->h_lam, lambda, sizeof(double) * (size_t)c->m);
+  PK_HIP(c, hipMemcpyAsync(c->d_lam, c->h_lam, sizeof(double) * (size_t)c->m, hipMemcpyHostToDevice, c->stream));
+  if ((rc = pk_eval_hess_dev(c, c->d_x, c->d_lam, sigma, c->d_H, nullptr))) return rc;
+  PK_HIP(c, hipMemcpyAsync(vals ? vals : c->h_out[4], c->d_H, sizeof(double) * (size_t)c->nnz_H, hipMemcpyDeviceToHost,
+                           c->stream));
+  PK_HIP(c, hipStreamSynchronize(c->stream));
+  return 0;
+}
+
+// pinned host result buffers of the context: what = 0 f, 1 grad, 2 g, 3 jac, 4 hess
+int pk_host_buffer(pk_ctx* c, int what, double** ptr, int64_t* count) {
+  int rc = ready(c);
+  if (rc) return rc;
+  if (what < 0 || what > 4 || !ptr) return fail(c, 62, "pk_host_buffer: bad arguments");
+  const int64_t cnt[5] = {1, c->n, c->m, c->nnz_J, c->nnz_H};
+  *ptr = c->h_out[what];
+  if (count) *count = cnt[what];
   return 0;
 }
 

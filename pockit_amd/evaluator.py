@@ -153,6 +153,9 @@ class Evaluator:
         md.prepass_jac = int(plan.jac.needs_I)
         md.prepass_hess = int(plan.hess.needs_I)
         self._code = code
+        self._x_cached = None
+        self._views = {}
+        self.zero_copy = False   # True: callbacks return views of pinned buffers (set by the IPOPT adapter)
         self.ctx.check(lib.pk_load_model(h, code, len(code), C.byref(md)))
         self.model_desc = md
         self.set_tables(Tables(plan, self.src, intervals_per_wave, tile_filter))
@@ -160,6 +163,8 @@ class Evaluator:
     def set_tables(self, tb: Tables):
         plan, lib, h = self.plan, self.ctx.lib, self.ctx.handle
         self.tables = tb
+        self._x_cached = None
+        self._views = {}
         pd = runtime.ProblemDesc()
         pd.n, pd.m, pd.n_sys, pd.n_s, pd.l_s = plan.n, plan.m, plan.n_sys, plan.n_s, plan.l_s
         pd.n_phase, pd.n_tiles, pd.n_kinds = len(tb.phases), len(tb.tiles), len(tb.kinds)
@@ -191,35 +196,90 @@ class Evaluator:
             raise ValueError(f"x must have shape ({self.plan.n},)")
         return x
 
+    # IPOPT calls objective / gradient / constraints / jacobian one after the other on the same iterate:
+    # the first call on a new x uploads it and runs the fused x-kernel, the others only copy their result.
+    def _prepare(self, x):
+        x = self._x(x)
+        if self._x_cached is None or not np.array_equal(x, self._x_cached):
+            self.ctx.check(self.ctx.lib.pk_prepare_x(self.ctx.handle, runtime.as_dp(x)))
+            self._x_cached = x.copy()
+
+    def _pinned(self, what):
+        """NumPy view of the context's pinned result buffer ``what`` (0 f, 1 grad, 2 g, 3 jac, 4 hess)."""
+        if what not in self._views:
+            ptr, cnt = runtime.c_double_p(), C.c_int64()
+            self.ctx.check(self.ctx.lib.pk_host_buffer(self.ctx.handle, what, C.byref(ptr), C.byref(cnt)))
+            self._views[what] = np.ctypeslib.as_array(ptr, shape=(max(cnt.value, 1),))[: cnt.value]
+        return self._views[what]
+
+    def _fetch(self, what, count):
+        # DMA into pinned memory at full PCIe rate; ``zero_copy`` hands out that buffer itself (valid until
+        # the next call for the same output -- cyipopt copies it at once), otherwise a fresh array as the
+        # reference's callbacks return.
+        if self.zero_copy:
+            self.ctx.check(self.ctx.lib.pk_fetch(self.ctx.handle, what, None))
+            return self._pinned(what)
+        out = np.empty(count)
+        self.ctx.check(self.ctx.lib.pk_fetch(self.ctx.handle, what, runtime.as_dp(out)))
+        return out
+
     def objective(self, x):
+        self._prepare(x)
+        return np.float64(self._fetch(0, 1)[0])
+
+    def gradient(self, x):
+        self._prepare(x)
+        return self._fetch(1, self.plan.n)
+
+    def constraints(self, x):
+        self._prepare(x)
+        return self._fetch(2, self.plan.m)
+
+    def jacobian(self, x):
+        self._prepare(x)
+        return self._fetch(3, self.plan.nnz_J)
+
+    def hessian(self, x, lagrange, obj_factor):
+        lam = np.ascontiguousarray(lagrange, dtype=np.float64)
+        if lam.shape != (self.plan.m,):
+            raise ValueError(f"lagrange must have shape ({self.plan.m},)")
+        self._prepare(x)
+        if self.zero_copy:
+            self.ctx.check(self.ctx.lib.pk_eval_hess_prepared(self.ctx.handle, runtime.as_dp(lam), float(obj_factor), None))
+            return self._pinned(4)
+        out = np.empty(self.plan.nnz_H)
+        self.ctx.check(self.ctx.lib.pk_eval_hess_prepared(self.ctx.handle, runtime.as_dp(lam), float(obj_factor),
+                                                          runtime.as_dp(out)))
+        return out
+
+    # one-shot variants without the x cache (each uploads x and runs only its own kernels)
+    def objective_direct(self, x):
         x = self._x(x)
         out = np.empty(1)
         self.ctx.check(self.ctx.lib.pk_eval_f(self.ctx.handle, runtime.as_dp(x), runtime.as_dp(out)))
         return np.float64(out[0])
 
-    def gradient(self, x):
+    def gradient_direct(self, x):
         x = self._x(x)
         out = np.empty(self.plan.n)
         self.ctx.check(self.ctx.lib.pk_eval_grad(self.ctx.handle, runtime.as_dp(x), runtime.as_dp(out)))
         return out
 
-    def constraints(self, x):
+    def constraints_direct(self, x):
         x = self._x(x)
         out = np.empty(self.plan.m)
         self.ctx.check(self.ctx.lib.pk_eval_g(self.ctx.handle, runtime.as_dp(x), runtime.as_dp(out)))
         return out
 
-    def jacobian(self, x):
+    def jacobian_direct(self, x):
         x = self._x(x)
         out = np.empty(self.plan.nnz_J)
         self.ctx.check(self.ctx.lib.pk_eval_jac(self.ctx.handle, runtime.as_dp(x), runtime.as_dp(out)))
         return out
 
-    def hessian(self, x, lagrange, obj_factor):
+    def hessian_direct(self, x, lagrange, obj_factor):
         x = self._x(x)
         lam = np.ascontiguousarray(lagrange, dtype=np.float64)
-        if lam.shape != (self.plan.m,):
-            raise ValueError(f"lagrange must have shape ({self.plan.m},)")
         out = np.empty(self.plan.nnz_H)
         self.ctx.check(self.ctx.lib.pk_eval_hess(self.ctx.handle, runtime.as_dp(x), runtime.as_dp(lam),
                                                  float(obj_factor), runtime.as_dp(out)))

@@ -16,5 +16,11 @@ def solve(system, guess, optimizer_options=None):
                              ub=system.v_ub, cl=system.c_lb, cu=system.c_ub)
     for k, v in optimizer_options.items():
         solver.add_option(k, v)
-    x, info = solver.solve(x_0)
+    # cyipopt copies every callback result into Ipopt's own arrays immediately, so the evaluator may hand out
+    # its pinned DMA buffers instead of fresh copies while the solver runs
+    system.evaluator.zero_copy = True
+    try:
+        x, info = solver.solve(x_0)
+    finally:
+        system.evaluator.zero_copy = False
     return postprocess(system, x, guess_is_variable), info

@@ -60,9 +60,31 @@ EXPORTS = ["pk_create", "pk_destroy", "pk_last_error", "pk_device_count", "pk_lo
            "pk_get_structure", "pk_eval_f", "pk_eval_grad", "pk_eval_g", "pk_eval_jac", "pk_eval_hess",
            "pk_eval_f_dev", "pk_eval_grad_dev", "pk_eval_g_dev", "pk_eval_jac_dev", "pk_eval_hess_dev",
            "pk_eval_cycle_dev", "pk_sync", "pk_profile", "pk_profile_read", "pk_kernel_name",
-           "pk_set_shard", "pk_eval_integrals_dev", "pk_eval_f_from_integrals_dev", "pk_eval_cycle"]
+           "pk_set_shard", "pk_eval_integrals_dev", "pk_eval_f_from_integrals_dev", "pk_eval_cycle",
+           "pk_prepare_x", "pk_fetch", "pk_eval_hess_prepared", "pk_host_buffer"]
 
 _lib = None
+
+
+def _preload_hip_runtime():
+    """One HIP runtime per process.  PyTorch-ROCm wheels bundle their own libamdhip64.so (same SONAME as
+    the system one); if our library pulled in /opt/rocm's copy first, a later ``import torch`` would bind to
+    it and fail to find the GPU ("No HIP GPUs are available").  So when torch is installed, load ITS runtime
+    first (without importing torch); our library's DT_NEEDED libamdhip64.so.7 then resolves to it by SONAME."""
+    import importlib.util
+
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        spec = None
+    if spec is None or not spec.submodule_search_locations:
+        return
+    cand = os.path.join(list(spec.submodule_search_locations)[0], "lib", "libamdhip64.so")
+    if os.path.exists(cand):
+        try:
+            C.CDLL(cand, mode=C.RTLD_GLOBAL)
+        except OSError:
+            pass
 
 
 def load_library():
@@ -73,6 +95,7 @@ def load_library():
     path = hipbuild.LIB_PATH
     if not os.path.exists(path):
         path = hipbuild.build_runtime()
+    _preload_hip_runtime()
     try:
         lib = C.CDLL(path)
     except OSError as exc:
@@ -93,6 +116,10 @@ def load_library():
     lib.pk_eval_jac.argtypes = [vp, dp, dp]
     lib.pk_eval_hess.argtypes = [vp, dp, dp, C.c_double, dp]
     lib.pk_eval_cycle.argtypes = [vp, dp, dp, C.c_double, dp, dp, dp, dp, dp]
+    lib.pk_prepare_x.argtypes = [vp, dp]
+    lib.pk_fetch.argtypes = [vp, C.c_int, dp]
+    lib.pk_eval_hess_prepared.argtypes = [vp, dp, C.c_double, dp]
+    lib.pk_host_buffer.argtypes = [vp, C.c_int, C.POINTER(dp), C.POINTER(C.c_int64)]
     lib.pk_eval_f_dev.argtypes = [vp, vp, vp, vp]
     lib.pk_eval_grad_dev.argtypes = [vp, vp, vp, vp]
     lib.pk_eval_g_dev.argtypes = [vp, vp, vp, vp]

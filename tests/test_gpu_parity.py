@@ -49,6 +49,12 @@ def test_small_case_matches_reference_golden(name):
     close(system.constraints(x), gold["g"], what="g")
     close(system.jacobian(x), gold["J"], what="J")
     close(system.hessian(x, lam, sigma), gold["H"], what="H")
+    ev = system.evaluator                      # the stand-alone kernels of each callback (no x cache, no fusion)
+    close(ev.objective_direct(x), gold["f"], what="f direct")
+    close(ev.gradient_direct(x), gold["grad"], what="grad direct")
+    close(ev.constraints_direct(x), gold["g"], what="g direct")
+    close(ev.jacobian_direct(x), gold["J"], what="J direct")
+    close(ev.hessian_direct(x, lam, sigma), gold["H"], what="H direct")
     close(system.hessian_o(x), gold["Ho"], what="Ho")
     close(system.hessian_c(x, lam), gold["Hc"], what="Hc")
     assert np.array_equal(x, x_before), "x must not be written"
