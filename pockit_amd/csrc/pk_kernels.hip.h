@@ -449,8 +449,26 @@ __device__ __forceinline__ void load_edge(const PkArgs& A, int back, double* s, 
   }
 }
 
-__device__ __forceinline__ void scatter_items(const PkArgs& A, const double* __restrict__ E, double* __restrict__ out) {
-  for (int it = threadIdx.x; it < A.n_items; it += PK_BLOCK) {
+// item `threadIdx.x` and its multiplier are fetched before the boundary expressions are evaluated
+struct ItemPref {
+  PkItem m;
+  double lam;
+  bool ok;
+};
+__device__ __forceinline__ ItemPref prefetch_item(const PkArgs& A) {
+  ItemPref ip;
+  ip.ok = (int)threadIdx.x < A.n_items;
+  ip.lam = 1.0;
+  if (ip.ok) {
+    ip.m = A.items[threadIdx.x];
+    if (ip.m.lam >= 0) ip.lam = A.lam[ip.m.lam];
+  }
+  return ip;
+}
+__device__ __forceinline__ void scatter_items(const PkArgs& A, const ItemPref& ip, const double* __restrict__ E,
+                                              double* __restrict__ out) {
+  if (ip.ok) out[ip.m.pos] = ip.m.coef * E[ip.m.eid] * ip.lam;
+  for (int it = threadIdx.x + PK_BLOCK; it < A.n_items; it += PK_BLOCK) {
     const PkItem m = A.items[it];
     double v = m.coef * E[m.eid];
     if (m.lam >= 0) v *= A.lam[m.lam];
@@ -521,6 +539,7 @@ __device__ __forceinline__ void edge_block(const PkArgs& A, int mode, bool with_
   const PkSys sy{A.x + A.l_s, A.Ibuf, A.sigma, A.lam};
   if (A.flags & 2) return;   // secondary shard: boundary nodes / system level belong to the primary
   if (with_g && threadIdx.x == PK_BLOCK - 1 && A.n_sys > 0) Gen::sys_constraints(sy, A.o_g);   // systembase.py:607-611
+  const ItemPref ip = prefetch_item(A);
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   for (int li = wave; li < Gen::NLISTS; li += PK_WAVES_PER_BLOCK)
     if (lane == 0) {
@@ -529,7 +548,7 @@ __device__ __forceinline__ void edge_block(const PkArgs& A, int mode, bool with_
       else Gen::edge_jac(li, A, sy, pk_lds);
     }
   __syncthreads();
-  scatter_items(A, pk_lds, mode == 1 ? A.o_hess : (mode == 2 ? A.o_aux : A.o_jac));
+  scatter_items(A, ip, pk_lds, mode == 1 ? A.o_hess : (mode == 2 ? A.o_aux : A.o_jac));
 }
 
 
@@ -572,13 +591,13 @@ __device__ __forceinline__ void fin_body(const PkArgs& A);
 
 template <class Gen>
 __device__ __forceinline__ void kernel_hess(const PkArgs& A) {
-  if (PK_IS_EDGE_BLOCK()) {
-    // cycle mode: the reductions of the preceding pk_xall launch ride along in this workgroup
+  if (PK_IS_EDGE_BLOCK()) return edge_block<Gen>(A, 1, false);
+  if (blockIdx.x == 1) {
+    // cycle mode: the reductions of the preceding pk_xall launch ride along in a workgroup of their own
     if (A.flags & (8 | 16)) fin_body<Gen>(A);
-    __syncthreads();
-    return edge_block<Gen>(A, 1, false);
+    return;
   }
-  PK_TILE_PROLOGUE(1);
+  PK_TILE_PROLOGUE(2);
   Gen::tile_hess(tl.phase, A, tl, pk_lds + wave * Gen::LDS_H, wint, wgrad, lane);
 }
 

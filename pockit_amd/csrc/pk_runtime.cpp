@@ -399,7 +399,7 @@ int pk_eval_hess_dev(pk_ctx* c, const double* d_x, const double* d_lam, double s
   A.n_items = c->n_items_hess;
   size_t lds = sizeof(double) * PK_WAVES_PER_BLOCK * (size_t)c->md.lds_h;
   if (lds < sizeof(double) * (size_t)c->md.ne_h) lds = sizeof(double) * (size_t)c->md.ne_h;
-  if ((rc = launch(c, K_HESS, A, tile_blocks(c) + 1, lds, st))) return rc;
+  if ((rc = launch(c, K_HESS, A, tile_blocks(c) + 2, lds, st))) return rc;
   if (c->n_outer > 0) {   // objective / system constraints nonlinear in the integrals: outer-product blocks
     PkArgs X = base_args(c, d_x, d_lam, sigma);
     X.o_hess = d_vals;
@@ -442,7 +442,7 @@ int pk_eval_cycle_dev(pk_ctx* c, const double* d_x, const double* d_lam, double 
   H.flags |= F_FIN_INT | F_WRITE_F | F_FIN_GRAD;
   lds = sizeof(double) * PK_WAVES_PER_BLOCK * (size_t)c->md.lds_h;
   if (lds < sizeof(double) * (size_t)c->md.ne_h) lds = sizeof(double) * (size_t)c->md.ne_h;
-  return launch(c, K_HESS, H, tile_blocks(c) + 1, lds, st);
+  return launch(c, K_HESS, H, tile_blocks(c) + 2, lds, st);
 }
 
 int pk_sync(pk_ctx* c, void* stream) {
