@@ -12,7 +12,7 @@ Workload (BASELINE.json metric: "at 10k LGR nodes"): planar_quadrotor re-meshed 
 intervals x 6 points = 12 000 nodes (configs[2], the ~10k-node headline of BASELINE.md), x =
 example guess * (1 + 1e-3 U), lambda ~ N(0,1), sigma = 1, all seeded.  For N > 1 the mesh is
 2000*N intervals of the same model, sharded by mesh interval over the N GPUs (weak scaling: 2000
-intervals per GPU) with RCCL reassembly of grad/g/J/H on every rank; ``value`` is then reported in
+intervals per GPU) with RCCL all-gather reassembly of grad/g/J/H on every rank; ``value`` is then reported in
 12k-node-equivalent cycles/s (= N * steps / time).
 
 One JSON line is printed by rank 0 (see the repository prompt for the contract), carrying
@@ -232,8 +232,8 @@ def main():
                                    f"{6 if args.workload == 'planar_quadrotor' else 8 if args.workload != 'two_stage_rocket' else 4}"
                                    f" points ({res['nodes']} nodes; n={res['n']}, m={res['m']}, nnz_J={res['nnz_J']}, "
                                    f"nnz_H={res['nnz_H']})",
-                       "sharding": "single GPU" if n_gpus == 1 else f"mesh intervals over {n_gpus} GPUs, RCCL all-reduce "
-                                                                    f"reassembly of grad/g/J/H",
+                       "sharding": "single GPU" if n_gpus == 1 else f"mesh intervals over {n_gpus} GPUs, RCCL all-gather "
+                                                                    f"of the owned runs of grad/g/J/H + tiny all-reduce",
                        "tiles": res["tiles"], "intervals_per_wave": res["ipw"],
                        "inputs": "example guess*(1+1e-3 U(-1,1)) seed 0; lambda N(0,1) seed 1; sigma 1"},
             "roofline": {"bound": "hbm", "kernel": res["dominant"], "achieved": achieved, "peak": HBM_PEAK_GBPS,

@@ -3,10 +3,13 @@
 Every defect row, path row, Jacobian and Hessian triplet belongs to exactly one mesh interval of
 one phase (block-diagonal integration/translation matrices), so the tiles of every phase are
 split into ``world`` contiguous ranges; rank r evaluates only its tiles, writing into full-size
-output arrays at the reference positions (all other positions stay zero).  Reassembly is a sum
-over ranks of arrays with disjoint support -- an RCCL all-reduce over xGMI issued through
-``torch.distributed`` (backend "nccl" = RCCL on ROCm; "gloo" in the CPU tests).  The objective's
-integrals are partial sums per rank and are all-reduced before F_o(I, s) is evaluated.
+output arrays at the reference positions.  Reassembly (``Reassembler``) is an RCCL *all-gather* over
+xGMI issued through ``torch.distributed`` (backend "nccl" = RCCL on ROCm; "gloo" in the CPU tests): every
+rank packs the positions it owns (a few dozen contiguous runs: its slice of every segment), the padded
+packs are all-gathered, and the other ranks' packs are scattered to their reference positions -- RCCL has
+no gather-v, so the pack/unpack index maps play that role.  Only the handful of sums over all nodes (the
+objective's integrals and the gradient entries of t0/tf/static parameters) need a reduction: one tiny
+all-reduce.
 
 The boundary-node and system-level scalars are computed once, by rank 0 (``pk_set_shard``).
 Reference: the reference is single-process; this is the build's own
@@ -34,33 +37,142 @@ def tile_filter(rank: int, world: int):
     return keep
 
 
-class ShardedEvaluator:
-    """Rank-local evaluator + collectives.  ``dist`` is an initialised torch.distributed module.
+def owned_runs(plan, tables, primary):
+    """Contiguous runs [(start, stop)] of the packed output layout ``[grad | g | J | H]`` written by the tiles
+    in ``tables`` (one rank's shard), derived from the same tables the kernels consume.  ``primary`` adds
+    the boundary-node / system-level scalars (computed by rank 0 only)."""
+    off = {"grad": 0, "g": plan.n, "J": plan.n + plan.m, "H": plan.n + plan.m + plan.nnz_J}
+    runs = []
+    tiles = tables.tiles
+    for k, pp in enumerate(plan.phase_plans):
+        lay = pp.layout
+        mine = tiles[(tiles["phase"] == k) & (tiles["nj"] > 0)]
+        if len(mine) == 0:
+            continue
+        first, last = mine[0], mine[-1]
+        stride = int(lay.stride[int(last["j0"])])
+        R = stride
+        i_lo, i_hi = int(first["offI"]), int(last["offI"]) + int(last["nj"]) * int(last["nnzI"])
+        t_lo, t_hi = int(first["offT"]), int(last["offT"]) + int(last["nj"]) * int(last["nnzT"])
+        r_lo, r_hi = int(first["r0"]), int(last["r0"]) + int(last["nj"]) * R
+        q_lo = int(first["q0"])
+        nq = int(last["nj"]) * stride + (1 if lay.scheme == "lgl" else 0)
+        q_hi = int(last["q0"]) + (nq - 1 if (lay.scheme == "lgl" and not last["last"]) else nq)
+        m_lo, m_hi = max(q_lo, lay.mid_lo), min(q_hi, lay.mid_hi)          # owned middle nodes
+        for cbname, key in (("jac", "J"), ("hess", "H")):
+            for sg in getattr(plan, cbname).segs[k]:
+                if sg.kind == "I":
+                    runs.append((off[key] + sg.base + i_lo, off[key] + sg.base + i_hi))
+                elif m_hi > m_lo:
+                    runs.append((off[key] + sg.base + m_lo - lay.mid_lo, off[key] + sg.base + m_hi - lay.mid_lo))
+        for base in plan.jac.tconst[k]:
+            runs.append((off["J"] + base + t_lo, off["J"] + base + t_hi))
+        for i in range(pp.nx):
+            g0 = off["g"] + plan.g_off[k] + i * lay.L_d
+            runs.append((g0 + r_lo, g0 + r_hi))
+            v0 = off["grad"] + plan.l_p[k] + int(lay.l_v[i])
+            runs.append((v0 + q_lo, v0 + q_hi))
+        for i in range(pp.nu):
+            v0 = off["grad"] + plan.l_p[k] + int(lay.l_v[pp.nx + i])
+            runs.append((v0 + q_lo, v0 + q_hi))
+        for j in range(pp.phase.n_c):
+            p0 = off["g"] + plan.path_off[k] + j * lay.L_m
+            runs.append((p0 + q_lo, p0 + q_hi))
+    if primary:
+        single = [off["J"] + it.pos for it in plan.jac.items] + [off["H"] + it.pos for it in plan.hess.items]
+        single += [off["H"] + b.pos + t for b in plan.outer for t in range(b.count)]
+        single += [off["g"] + c for c in range(plan.n_sys)]
+        runs += [(p, p + 1) for p in single]
+    return [(a, b) for a, b in runs if b > a]
 
-    All rank-local results live in ONE packed device buffer ``[I | grad | g | J | H]`` so that the
-    reassembly is a single collective per cycle (xGMI collectives are latency-bound at these sizes:
-    five ~MB-sized all-reduces cost several times one packed all-reduce)."""
+
+def shared_gradient_slots(plan):
+    """Gradient entries that are sums over all nodes (t0/tf of every phase, static parameters) plus the
+    slots no node writes (LGR state end points): every rank's kernels write their own partial there."""
+    slots = []
+    for k, pp in enumerate(plan.phase_plans):
+        lay = pp.layout
+        if lay.scheme == "lgr":
+            slots += [plan.l_p[k] + int(lay.l_v[i]) + lay.L_m for i in range(pp.nx)]
+        slots += [plan.l_p[k] + lay.L - 2, plan.l_p[k] + lay.L - 1]
+    slots += list(range(plan.l_s, plan.r_s))
+    return np.array(sorted(set(int(v) for v in slots)), dtype=np.int64)
+
+
+class Reassembler:
+    """All-gather based reassembly of the packed outputs ``[grad | g | J | H]`` (device agnostic: CUDA
+    tensors with RCCL on the GPUs, CPU tensors with gloo in the tests)."""
+
+    def __init__(self, torch, plan, runs_per_rank, rank, world, device):
+        self.torch, self.rank, self.world = torch, rank, world
+        idx = [np.concatenate([np.arange(a, b, dtype=np.int64) for a, b in runs]) if runs else np.zeros(0, np.int64)
+               for runs in runs_per_rank]
+        self.total = plan.n + plan.m + plan.nnz_J + plan.nnz_H
+        covered = np.zeros(self.total, dtype=np.int32)
+        for ix in idx:
+            np.add.at(covered, ix, 1)
+        shared = shared_gradient_slots(plan)
+        covered[shared] += 1
+        if not np.all(covered == 1):
+            raise RuntimeError("internal error: the shards do not partition the output positions")
+        self.pad = max(len(ix) for ix in idx)
+        dummy = self.total                      # padded tail of a pack lands in one scratch element
+        padded = [np.concatenate([ix, np.full(self.pad - len(ix), dummy, dtype=np.int64)]) for ix in idx]
+        self.own_idx = torch.from_numpy(padded[rank]).to(device)
+        self.all_idx = torch.from_numpy(np.concatenate(padded)).to(device)
+        self.shared_idx = torch.from_numpy(shared).to(device)
+        self.recv = torch.empty(self.pad * world, dtype=torch.float64, device=device)
+
+    def exchange(self, full, small, dist):
+        """``full``: packed buffer of length total + 1 (last element is scratch); ``small``: the small
+        reduction buffer [integrals | shared gradient slots] (already filled with this rank's partials).
+        One tiny all-reduce + one all-gather; afterwards ``full`` is complete on every rank."""
+        n_sh = self.shared_idx.numel()
+        if n_sh:
+            small[-n_sh:] = full.index_select(0, self.shared_idx)
+        dist.all_reduce(small)
+        send = full.index_select(0, self.own_idx)
+        dist.all_gather_into_tensor(self.recv, send)
+        full.index_copy_(0, self.all_idx, self.recv)
+        if n_sh:
+            full.index_copy_(0, self.shared_idx, small[-n_sh:])
+
+
+class ShardedEvaluator:
+    """Rank-local evaluator + collectives.  ``dist`` is an initialised torch.distributed module."""
 
     def __init__(self, plan, rank, world, device=0, intervals_per_wave=None):
         import torch
 
-        from .evaluator import Evaluator
+        from .codegen import ModelSource
+        from .evaluator import Evaluator, Tables
 
         self.torch, self.rank, self.world, self.plan = torch, rank, world, plan
+        if world > 1 and plan.outer:
+            raise NotImplementedError("objectives / system constraints nonlinear in the integrals (outer-product "
+                                      "Hessian blocks) are evaluated on one GPU only; they are O(n^2) and small")
         self.ev = Evaluator(plan, device=device, intervals_per_wave=intervals_per_wave,
                             tile_filter=tile_filter(rank, world) if world > 1 else None)
         dev = torch.device("cuda", device)
         n_I = max(len(plan.I_syms), 1)
         # integrals that later kernels need (models nonlinear in I) must be global *before* those kernels
         self.early_I = bool(plan.needs_I_grad or plan.needs_I_con or plan.jac.needs_I or plan.hess.needs_I)
-        sizes = [("I", n_I), ("grad", plan.n), ("g", plan.m), ("J", plan.nnz_J), ("H", plan.nnz_H)]
-        self.pack = torch.zeros(sum(n for _, n in sizes), dtype=torch.float64, device=dev)
+        sizes = [("grad", plan.n), ("g", plan.m), ("J", plan.nnz_J), ("H", plan.nnz_H)]
+        self.full = torch.zeros(sum(n for _, n in sizes) + 1, dtype=torch.float64, device=dev)
         self.out, off = {}, 0
         for name, n in sizes:
-            self.out[name] = self.pack[off: off + n]
+            self.out[name] = self.full[off: off + n]
             off += n
         self.out["f"] = torch.zeros(1, dtype=torch.float64, device=dev)
-        self.I = self.out["I"]
+        self.re = None
+        if world > 1:
+            ipw = self.ev.tables.intervals_per_wave
+            src = self.ev.src
+            runs = [owned_runs(plan, Tables(plan, src, ipw, tile_filter(r, world)), r == 0) for r in range(world)]
+            self.re = Reassembler(torch, plan, runs, rank, world, dev)
+        n_sh = self.re.shared_idx.numel() if self.re else 0
+        self.small = torch.zeros(n_I + n_sh, dtype=torch.float64, device=dev)
+        self.I = self.small[:n_I]
         lib, h = self.ev.ctx.lib, self.ev.ctx.handle
         self.ev.ctx.check(lib.pk_set_shard(h, int(rank != 0), 1, C.c_void_p(self.I.data_ptr())))
 
@@ -72,8 +184,6 @@ class ShardedEvaluator:
         st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
         o = self.out
         sharded = dist is not None and self.world > 1
-        if sharded:
-            self.pack.zero_()
         px = C.c_void_p(x.data_ptr())
         chk(lib.pk_eval_integrals_dev(h, px, st))                      # this shard's share of every integral
         if sharded and self.early_I:
@@ -83,9 +193,11 @@ class ShardedEvaluator:
         chk(lib.pk_eval_jac_dev(h, px, C.c_void_p(o["J"].data_ptr()), st))
         chk(lib.pk_eval_hess_dev(h, px, C.c_void_p(lam.data_ptr()), float(sigma), C.c_void_p(o["H"].data_ptr()), st))
         if sharded:
-            if self.early_I:
-                dist.all_reduce(self.pack[self.I.numel():])
+            if self.early_I:           # integrals are already global: keep them out of the second reduction
+                keep = self.I.clone()
+                self.re.exchange(self.full, self.small, dist)
+                self.I.copy_(keep)
             else:
-                dist.all_reduce(self.pack)                             # integrals ride along
+                self.re.exchange(self.full, self.small, dist)
         chk(lib.pk_eval_f_from_integrals_dev(h, px, C.c_void_p(o["f"].data_ptr()), st))
         return o

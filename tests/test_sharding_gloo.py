@@ -1,52 +1,20 @@
-"""world_size-2 test of the mesh-interval sharding logic on CPU (gloo).
+"""world_size-2 test of the mesh-interval sharding data path on CPU (gloo).
 
-Each rank takes its share of the tiles (pockit_amd.sharding.tile_filter), "evaluates" only the
-output positions those tiles own -- taken from the NumPy plan interpreter, masked by tile ownership
-computed from the same tables the kernels consume -- and the ranks reassemble with an all-reduce,
-exactly the data path of ShardedEvaluator (RCCL on the GPUs).  The result must equal the unsharded
-arrays, i.e. the shards are disjoint and cover everything, and only rank 0 emits the boundary /
-system-level entries."""
+Each rank takes its share of the tiles (pockit_amd.sharding.tile_filter).  Its kernels' outputs are
+emulated with the NumPy plan interpreter: the positions the rank's tiles own carry the true values,
+every other position is poisoned (NaN), the gradient's shared slots carry the rank's partial sums.  The
+REAL exchange code of the product (pockit_amd.sharding.Reassembler: pack by owned runs, all-gather,
+unpack, tiny all-reduce of the shared slots) then reassembles over gloo exactly as it does over RCCL on
+the GPUs.  Result must equal the unsharded arrays on every rank."""
 import os
 import socket
 
 import numpy as np
-import pytest
 import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
 import models
-
-
-def _owned_mask(plan, tables, cbname, nnz, primary):
-    """Positions of the J/H value array written by this shard's tiles (+ scalar items on the primary)."""
-    cb = getattr(plan, cbname)
-    mask = np.zeros(nnz, dtype=bool)
-    for t in tables.tiles:
-        k = int(t["phase"])
-        lay = plan.phase_plans[k].layout
-        kd = lay.kinds[int(t["kid"]) - sum(len(pp.layout.kinds) for pp in plan.phase_plans[:k])]
-        nj, j0 = int(t["nj"]), int(t["j0"])
-        stride = int(lay.stride[j0])
-        q0 = int(t["q0"])
-        nq = nj * stride + (1 if lay.scheme == "lgl" else 0)
-        nown = nq - 1 if (lay.scheme == "lgl" and not t["last"]) else nq
-        for seg in cb.segs[k]:
-            if seg.kind == "I":
-                lo = seg.base + int(t["offI"])
-                mask[lo: lo + nj * kd.nnzI] = True
-            else:
-                for q in range(q0, q0 + nown):
-                    if lay.mid_lo <= q < lay.mid_hi:
-                        mask[seg.base + q - lay.mid_lo] = True
-        if cbname == "jac":
-            for base in cb.tconst[k]:
-                lo = base + int(t["offT"])
-                mask[lo: lo + nj * kd.nnzT] = True
-    if primary:
-        for it in cb.items:
-            mask[it.pos] = True
-    return mask
 
 
 def _worker(rank, world, port, ret):
@@ -57,24 +25,30 @@ def _worker(rank, world, port, ret):
     from plan_interp import Interp
     from pockit_amd.codegen import ModelSource
     from pockit_amd.evaluator import Tables
-    from pockit_amd.sharding import tile_filter
+    from pockit_amd.sharding import Reassembler, owned_runs, shared_gradient_slots, tile_filter
 
     system, _, guess = models.two_stage_rocket(radau, 7, 3)
     plan = system.plan
     x, lam, sigma = models.bench_inputs(system, guess)
     src = ModelSource(plan)
-    tb = Tables(plan, src, intervals_per_wave=2, tile_filter=tile_filter(rank, world))
+    runs = [owned_runs(plan, Tables(plan, src, 2, tile_filter(r, world)), r == 0) for r in range(world)]
+    re = Reassembler(torch, plan, runs, rank, world, torch.device("cpu"))
     it = Interp(plan, x, lam, sigma)
-    full = {"jac": it.jacobian(), "hess": it.hessian()}
-    ok = True
-    for cbname, nnz in (("jac", plan.nnz_J), ("hess", plan.nnz_H)):
-        mask = _owned_mask(plan, tb, cbname, nnz, primary=(rank == 0))
-        mine = torch.from_numpy(np.where(mask, full[cbname], 0.0))
-        count = torch.from_numpy(mask.astype(np.float64))
-        dist.all_reduce(mine)
-        dist.all_reduce(count)
-        ok &= bool(np.all(count.numpy() == 1.0))          # disjoint and complete
-        ok &= bool(np.array_equal(mine.numpy(), full[cbname]))
+    truth = np.concatenate([it.gradient(), it.constraints(), it.jacobian(), it.hessian()])
+    shared = shared_gradient_slots(plan)
+    # what this rank's kernels would have produced
+    mine = np.full(len(truth) + 1, np.nan)
+    for a, b in runs[rank]:
+        mine[a:b] = truth[a:b]
+    share = 0.25 if rank == 0 else 0.75            # the shared slots are partial sums per rank
+    mine[shared] = truth[shared] * share
+    full = torch.from_numpy(mine.copy())
+    small = torch.zeros(1 + len(shared), dtype=torch.float64)
+    small[0] = 1.0 + rank                           # stands for a partial integral
+    re.exchange(full, small, dist)
+    got = full.numpy()[:-1]
+    ok = bool(np.array_equal(got, truth) or np.allclose(got, truth, rtol=0, atol=1e-15 * np.abs(truth).max()))
+    ok &= bool(abs(float(small[0]) - 3.0) < 1e-15)  # integrals summed over the two ranks
     flag = torch.tensor([1.0 if ok else 0.0])
     dist.all_reduce(flag, op=dist.ReduceOp.MIN)
     if rank == 0:
@@ -95,6 +69,27 @@ def test_two_rank_sharding_reassembles_exactly():
         p.join(300)
         assert p.exitcode == 0
     assert ret.get() == 1.0
+
+
+def test_owned_runs_partition_every_output_position():
+    """For 1..5 ranks, LGR and LGL, multi-phase: the ranks' runs + the shared gradient slots cover every
+    position of [grad | g | J | H] exactly once (Reassembler raises otherwise)."""
+    import pockit_amd.lobatto as lobatto
+    import pockit_amd.radau as radau
+    from pockit_amd.codegen import ModelSource
+    from pockit_amd.evaluator import Tables
+    from pockit_amd.sharding import Reassembler, owned_runs, tile_filter
+
+    for ns, builder, kw in ((radau, models.two_stage_rocket, dict(mesh=9, num_point=3)),
+                            (lobatto, models.brachistochrone, dict(mesh=11, num_point=4)),
+                            (lobatto, models.two_stage_rocket, dict(mesh=5, num_point=3)),
+                            (radau, models.derivative_model, {})):
+        system, _, _ = builder(ns, **kw)
+        plan = system.plan
+        src = ModelSource(plan)
+        for world in (1, 2, 3, 5):
+            runs = [owned_runs(plan, Tables(plan, src, 1, tile_filter(r, world)), r == 0) for r in range(world)]
+            Reassembler(torch, plan, runs, 0, world, torch.device("cpu"))
 
 
 def test_contiguous_share_partitions():
