@@ -659,6 +659,8 @@ __device__ __forceinline__ void kernel_outer(const PkArgs& A) {
 
 template <class Gen>
 __device__ __forceinline__ void kernel_xall(const PkArgs& A) {
+  if (A.flags & 1024) return;                                   // diagnostic switches (POCKIT_AMD_DEBUG_FLAGS)
+  if (PK_IS_EDGE_BLOCK() && (A.flags & 2048)) return;
   if (PK_IS_EDGE_BLOCK()) return edge_block<Gen>(A, 0, true);
   PK_TILE_PROLOGUE(1);
   Gen::tile_xall(tl.phase, A, tl, pk_lds + wave * Gen::LDS_X, wint + wave * PK_NRED, wgrad + wave * PK_NRED, lane);
