@@ -124,9 +124,14 @@ def run_gpu(name, intervals, steps, warmup, rank, world, dist, time_kernel=None)
     ptr = lambda t: C.c_void_p(t.data_ptr())  # noqa: E731
 
     if world == 1:
+        cycle_fn = lib.pk_eval_cycle_dev
+        cycle_args = (h, ptr(dx), ptr(dlam), C.c_double(float(sigma)), ptr(o["f"]), ptr(o["grad"]), ptr(o["g"]),
+                      ptr(o["J"]), ptr(o["H"]), st)       # built once: the loop below is host-launch bound
+
         def step():
-            ev.ctx.check(lib.pk_eval_cycle_dev(h, ptr(dx), ptr(dlam), float(sigma), ptr(o["f"]), ptr(o["grad"]),
-                                               ptr(o["g"]), ptr(o["J"]), ptr(o["H"]), st))
+            rc = cycle_fn(*cycle_args)
+            if rc:
+                ev.ctx.check(rc)
         ev.ctx.check(lib.pk_set_shard(h, 0, 0, None))
     else:
         def step():
