@@ -52,7 +52,7 @@ typedef struct pk_model_desc {
   int32_t prepass_hess;
   int32_t lds_x;        /* LDS doubles per wave of the fused x-kernel (pk_xall)                   */
   int32_t ne_a;         /* scalar expressions of the auxiliary pass (outer-product Hessian path)  */
-  int32_t reserved[1];
+  int32_t ne_hc;        /* scalar expressions of the compact Hessian                              */
 } pk_model_desc;
 
 /* One (model, mesh) instance: sizes plus the table blobs built by pockit_amd/evaluator.py.
@@ -82,6 +82,10 @@ typedef struct pk_problem_desc {
   const void* outer;      /* PkOuter[n_outer] */
   int32_t n_outer;
   int32_t n_aux;          /* length of the auxiliary buffer */
+  /* compact (coalesced) Hessian layout, optional (nnz_Hc = 0: not available) */
+  const void* items_hessc;
+  int32_t n_items_hessc;
+  int64_t nnz_Hc;
   /* optional COO structure in the reference's order (copied; may be NULL) */
   const int32_t* jac_row;
   const int32_t* jac_col;
@@ -120,6 +124,14 @@ int pk_eval_hess_prepared(pk_ctx* ctx, const double* lambda, double sigma, doubl
  * rate and no second host copy.  The buffers are reused by the next call for the same output. */
 int pk_host_buffer(pk_ctx* ctx, int what, double** ptr, int64_t* count);
 
+/* Compact Hessian of the Lagrangian: the reference repeats every dynamics entry for
+ * each nonzero of the integration matrix (phasebase.py:923-928,1280-1285; 10-20x duplication); here lambda is
+ * contracted first (mu = I^T lambda) and entries of a node with equal (row, col) are summed, so one value per
+ * distinct position is produced.  Layout: pockit_amd.transcription.SystemPlan.hessc_row/col. */
+int pk_eval_hessc(pk_ctx* ctx, const double* x, const double* lambda, double sigma, double* vals /* nnz_Hc */);
+int pk_eval_hessc_dev(pk_ctx* ctx, const double* d_x, const double* d_lambda, double sigma, double* d_vals,
+                      void* stream);
+
 /* device-pointer API: enqueue on ``stream`` (hipStream_t, NULL = context stream), no sync */
 int pk_eval_f_dev(pk_ctx* ctx, const double* d_x, double* d_f, void* stream);
 int pk_eval_grad_dev(pk_ctx* ctx, const double* d_x, double* d_grad, void* stream);
@@ -143,7 +155,8 @@ int pk_eval_integrals_dev(pk_ctx* ctx, const double* d_x, void* stream);
 int pk_eval_f_from_integrals_dev(pk_ctx* ctx, const double* d_x, double* d_f, void* stream);
 
 /* HIP-event timing of the individual kernels on the launch stream.
- * kernel ids: 0 pk_int, 1 pk_fin, 2 pk_g, 3 pk_grad, 4 pk_jac, 5 pk_hess, 6 pk_xall, 7 pk_aux, 8 pk_outer */
+ * kernel ids: 0 pk_int, 1 pk_fin, 2 pk_g, 3 pk_grad, 4 pk_jac, 5 pk_hess, 6 pk_xall, 7 pk_aux, 8 pk_outer,
+ * 9 pk_hessc */
 int pk_profile(pk_ctx* ctx, int kernel_mask /* bit k: time kernel k; 0 = off */);
 int pk_profile_read(pk_ctx* ctx, int kernel_id, int64_t* launches, double* total_ms);
 const char* pk_kernel_name(int kernel_id);

@@ -21,7 +21,7 @@ import sympy as sp
 from sympy.printing.c import C99CodePrinter
 
 from .model import FIXED, FREE, FUNC
-from .transcription import DT, SIG, TAU, WQ, SystemPlan, lam_path, lam_sys
+from .transcription import DT, SIG, TAU, WQ, SystemPlan, lam_path, lam_sys, ltb_sym, ltf_sym, mu_sym
 
 
 class _CPrinter(C99CodePrinter):
@@ -107,7 +107,8 @@ class ModelSource:
             self.list_keys += [("f", k), ("b", k)]
         self.list_keys.append(("s",))
         self.list_off = {}
-        for cbname in ("jac", "hess", "aux"):
+        self.compact = not plan.outer          # compact Hessian functions exist unless outer-product blocks are needed
+        for cbname in ("jac", "hess", "aux") + (("hessc",) if self.compact else ()):
             cb = getattr(plan, cbname)
             off, table = 0, {}
             for key in self.list_keys:
@@ -131,6 +132,10 @@ class ModelSource:
         nm.add(WQ, "pk_w")
         for j in range(p.n_c):
             nm.add(lam_path(j), f"lp[{j}]")
+        for i in range(p.n_x):
+            nm.add(mu_sym(i), f"mu[{i}]")
+            nm.add(ltf_sym(i), f"ltf[{i}]")
+            nm.add(ltb_sym(i), f"ltb[{i}]")
         return nm
 
     def _sys_names(self, nm, with_s=False):
@@ -228,6 +233,24 @@ class ModelSource:
                 S.append(_emit_body(outs, base, nm))
                 S.append("  }")
 
+        # ---- compact Hessian: one value per distinct (row, col) class of a node ----
+        sig_c = sig_node + (", const double* __restrict__ mu, const double* __restrict__ ltf, "
+                            "const double* __restrict__ ltb")
+        if self.compact:
+            cb = plan.hessc
+            S.append(f"  static constexpr int HC_NN = {len(cb.segs[k])};")
+            S.append(f"  __device__ static __forceinline__ void mid_hessc({sig_c}, double* __restrict__ o) {{")
+            S.append(_emit_body([(f"o[{e}]", sg.expr) for e, sg in enumerate(cb.segs[k])], base, nm))
+            S.append("  }")
+            for w, wname in (("f", "front"), ("b", "back")):
+                exprs = cb.lists.get((w, k), [])
+                S.append(f"  __device__ static __forceinline__ void {wname}_hessc({sig_c}, double* __restrict__ E) {{")
+                S.append(_emit_body([(f"E[{e}]", ex) for e, ex in enumerate(exprs)], base, nm))
+                S.append("  }")
+        else:
+            S.append("  static constexpr int HC_NN = 0;")
+            S.append(f"  __device__ static __forceinline__ void mid_hessc({sig_c}, double* __restrict__ o) {{}}")
+
         # ---- dense objective gradient ----
         slots = plan.grad_red_slots[k]
         S.append(f"  static constexpr int GR_NR = {len(slots)};")
@@ -271,7 +294,7 @@ class ModelSource:
         S.append(_emit_body([(f"gs[{i}]", plan.grad_static.get(i, sp.Integer(0))) for i in range(plan.n_s)],
                             {}, nm, "  "))
         S.append("}")
-        for cbname in ("jac", "hess", "aux"):
+        for cbname in ("jac", "hess", "aux") + (("hessc",) if self.compact else ()):
             exprs = getattr(plan, cbname).lists.get(("s",), [])
             S.append(f"__device__ static __forceinline__ void sys_{cbname}(const PkSys& sy, double* __restrict__ E) {{")
             S.append(_emit_body([(f"E[{e}]", ex) for e, ex in enumerate(exprs)], {}, nm, "  "))
@@ -316,7 +339,7 @@ class ModelSource:
                                      for k, pp in enumerate(plan.phase_plans)])
         S.append(f"  static constexpr int LDS_G = {self.lds_g}, LDS_J = {self.lds_j}, LDS_H = {self.lds_h}, "
                  f"LDS_X = {self.lds_x};")
-        for name in ("int", "g", "grad", "jac", "hess", "xall", "aux"):
+        for name in ("int", "g", "grad", "jac", "hess", "xall", "aux", "hessc"):
             S.append(f"  __device__ static __forceinline__ void tile_{name}(int phase, const PkArgs& A, const PkTile& tl, "
                      f"double* __restrict__ lds, double* __restrict__ wint, double* __restrict__ wgrad, int lane) {{")
             S.append(switch(f"pk::tile_{name}<{{P}}>(A, tl, lds, wint, wgrad, lane)"))
@@ -342,6 +365,30 @@ class ModelSource:
                 S.append(f"        const PkSys sy2{{s_, sy.I, sy.sigma, sy.lams}};")
                 S.append(f"        P{k}::{wname}_{cbname}(a, tau, dt, w, sy2, lp, E + {off[key]}); }} break;")
             S.append("      default: break;\n    }\n  }")
+        if self.compact:
+            off = self.list_off["hessc"]
+            S.append(f"  static constexpr int HC_NE = {max(off['total'], 1)};")
+            S.append("  __device__ static __forceinline__ void edge_hessc(int li, const PkArgs& A, const PkSys& sy, "
+                     "double* __restrict__ E) {")
+            S.append("    switch (li) {")
+            for li, key in enumerate(self.list_keys):
+                if key[0] == "s":
+                    S.append(f"      case {li}: sys_hessc(sy, E + {off[key]}); break;")
+                    continue
+                k = key[1]
+                if not plan.hessc.lists.get(key):
+                    continue
+                wname = "front" if key[0] == "f" else "back"
+                nxk = plan.phase_plans[k].nx
+                S.append(f"      case {li}: {{ double s_[PK_NS], a[P{k}::NARG], tau, dt, w, lp[{ncmax}], mu[{nxk}], "
+                         f"ltf[{nxk}], ltb[{nxk}];")
+                S.append(f"        pk::load_edge_c<P{k}>(A, {1 if key[0] == 'b' else 0}, s_, a, tau, dt, w, lp, mu, ltf, ltb);")
+                S.append(f"        const PkSys sy2{{s_, sy.I, sy.sigma, sy.lams}};")
+                S.append(f"        P{k}::{wname}_hessc(a, tau, dt, w, sy2, lp, mu, ltf, ltb, E + {off[key]}); }} break;")
+            S.append("      default: break;\n    }\n  }")
+        else:
+            S.append("  static constexpr int HC_NE = 1;")
+            S.append("  __device__ static __forceinline__ void edge_hessc(int, const PkArgs&, const PkSys&, double*) {}")
         S.append(f"  static constexpr int NLISTS = {len(self.list_keys)};")
         ints = [(a, plan.I_owner[a][0], self.int_local[plan.I_owner[a][0]].index(a)) for a in self.int_needed]
         S.append(f"  static constexpr int N_INT = {len(ints)};")

@@ -29,7 +29,11 @@ struct PkPhase {
   int32_t hseg_off;    // lb: base offset in H of every Hessian segment of the phase (I then N)
   int32_t red_off;     // ib: NLP index of every gradient reduction slot of the phase
   int32_t aseg_off;    // lb: base offset in the auxiliary buffer of every auxiliary segment of the phase
-  int32_t pad1;
+  int32_t hcseg_off;   // lb: base offset in the compact Hessian of every compact segment of the phase
+  int32_t ivK_off;     // ib: points per interval K[N]
+  int32_t ivfull_off;  // ib: db offset of the dense R x K integration block of every interval
+  int32_t ivld_off;    // ib: first defect row (within a state) of every interval
+  int32_t n_int;       // number of mesh intervals N
 };
 
 // A run of `nj` consecutive intervals of one kind handled by one wavefront (<= 64 nodes).

@@ -434,6 +434,90 @@ __device__ __forceinline__ void tile_aux(const PkArgs& A, const PkTile& tl, doub
   }
 }
 
+// ============================================================================================
+// compact Hessian: the multipliers are contracted with the integration block first,
+//   mu_i(node) = sum_r (I_hat[r, c] d/2) * lambda[row r of state i]      (a K-term product per node and state)
+// and every (row, col) position of a node gets ONE value (entries summed symbolically), so the output is
+// one run of L_m - 1 doubles per distinct position class instead of N*K^2 triplets per derivative entry.
+// ============================================================================================
+template <class P>
+__device__ __forceinline__ void interval_mu(const PkArgs& A, const PkPhase& ph, int K, const double* __restrict__ full,
+                                            double width, int ld, int c, double* mu) {
+  const int R = K - P::SCHEME;
+  const double* __restrict__ lam = A.lam + ph.g_off + ld;
+  for (int r = 0; r < R; ++r) {
+    const double a = full[r * K + c] * width * 0.5;
+#pragma unroll
+    for (int i = 0; i < P::NX; ++i) mu[i] += a * lam[i * ph.L_d + r];
+  }
+}
+
+// mu of node q (phase-local), summed over the one (LGR) or two (LGL interior mesh point) intervals holding it
+template <class P>
+__device__ __forceinline__ void node_mu(const PkArgs& A, const PkPhase& ph, int j, int c, double* mu) {
+#pragma unroll
+  for (int i = 0; i < P::NX; ++i) mu[i] = 0.0;
+  const int32_t* __restrict__ ivK = A.ib + ph.ivK_off;
+  const int32_t* __restrict__ ivF = A.ib + ph.ivfull_off;
+  const int32_t* __restrict__ ivL = A.ib + ph.ivld_off;
+  interval_mu<P>(A, ph, ivK[j], A.db + ivF[j], A.db[ph.width_off + j], ivL[j], c, mu);
+  if (P::SCHEME == 1 && c == 0 && j > 0)
+    interval_mu<P>(A, ph, ivK[j - 1], A.db + ivF[j - 1], A.db[ph.width_off + j - 1], ivL[j - 1], ivK[j - 1] - 1, mu);
+}
+
+template <class P>
+__device__ __forceinline__ void tile_hessc(const PkArgs& A, const PkTile& tl, double* __restrict__,
+                                           double* __restrict__, double* __restrict__, int lane) {
+  if (P::HC_NN == 0) return;
+  const PkPhase& ph = A.ph[P::INDEX];
+  const TileGeom g = tile_geom<P>(tl);
+  double s[PK_NS], dt, mt;
+  phase_scalars<P>(A, ph, s, dt, mt);
+  const PkSys sy{s, A.Ibuf, A.sigma, A.lam};
+  const int64_t* __restrict__ segb = A.lb + ph.hcseg_off;
+  if (lane < g.nown) {
+    const int q = tl.q0 + lane;
+    if (q >= ph.mid_lo && q < ph.mid_hi) {
+      double a[P::NARG], tau, w, o[P::HC_NN + 1], lp[P::NC > 0 ? P::NC : 1], mu[P::NX];
+      load_node<P>(A, ph, s, dt, mt, q, a, tau, w);
+#pragma unroll
+      for (int j = 0; j < P::NC; ++j) lp[j] = A.lam[ph.path_off + j * ph.L_m + q];
+      const int jj = lane / g.stride;
+      node_mu<P>(A, ph, tl.j0 + jj, lane - jj * g.stride, mu);
+      P::mid_hessc(a, tau, dt, w, sy, lp, mu, nullptr, nullptr, o);
+#pragma unroll
+      for (int e = 0; e < P::HC_NN; ++e) A.o_hess[segb[e] + (q - ph.mid_lo)] = o[e];
+    }
+  }
+}
+
+// boundary node of the compact Hessian: also the contracted multipliers of the boundary columns
+template <class P>
+__device__ __forceinline__ void load_edge_c(const PkArgs& A, int back, double* s, double* a, double& tau, double& dt,
+                                            double& w, double* lp, double* mu, double* ltf, double* ltb) {
+  const PkPhase& ph = A.ph[P::INDEX];
+  double mt;
+  phase_scalars<P>(A, ph, s, dt, mt);
+  const int q = back ? ph.L_m - 1 : 0;
+  load_node<P>(A, ph, s, dt, mt, q, a, tau, w);
+#pragma unroll
+  for (int j = 0; j < P::NC; ++j) lp[j] = A.lam[ph.path_off + j * ph.L_m + q];
+  const int N = ph.n_int;
+  const int32_t* __restrict__ ivK = A.ib + ph.ivK_off;
+  const int32_t* __restrict__ ivL = A.ib + ph.ivld_off;
+  if (back && P::SCHEME == 1) node_mu<P>(A, ph, N - 1, ivK[N - 1] - 1, mu);
+  else node_mu<P>(A, ph, 0, 0, mu);
+  const int Rl = ivK[N - 1] - P::SCHEME;
+#pragma unroll
+  for (int i = 0; i < P::NX; ++i) {
+    const double* __restrict__ lam = A.lam + ph.g_off + i * ph.L_d;
+    ltf[i] = lam[0];                                 // T_f = (row 0, +1)
+    double sum = 0.0;
+    for (int r = 0; r < Rl; ++r) sum += lam[ivL[N - 1] + r];
+    ltb[i] = -sum;                                   // T_b = (rows of the last interval, -1)
+  }
+}
+
 // ---- boundary-node evaluation for the edge workgroup -----------------------------------------
 template <class P>
 __device__ __forceinline__ void load_edge(const PkArgs& A, int back, double* s, double* a, double& tau,
@@ -532,7 +616,7 @@ __device__ __forceinline__ double block_sum_partials(const PkArgs& A, const doub
 
 #define PK_IS_EDGE_BLOCK() (blockIdx.x == 0)
 
-// mode 0: Jacobian, 1: Hessian, 2: auxiliary buffer
+// mode 0: Jacobian, 1: Hessian, 2: auxiliary buffer, 3: compact Hessian
 template <class Gen>
 __device__ __forceinline__ void edge_block(const PkArgs& A, int mode, bool with_g) {
   extern __shared__ double pk_lds[];
@@ -545,10 +629,11 @@ __device__ __forceinline__ void edge_block(const PkArgs& A, int mode, bool with_
     if (lane == 0) {
       if (mode == 1) Gen::edge_hess(li, A, sy, pk_lds);
       else if (mode == 2) Gen::edge_aux(li, A, sy, pk_lds);
+      else if (mode == 3) Gen::edge_hessc(li, A, sy, pk_lds);
       else Gen::edge_jac(li, A, sy, pk_lds);
     }
   __syncthreads();
-  scatter_items(A, ip, pk_lds, mode == 1 ? A.o_hess : (mode == 2 ? A.o_aux : A.o_jac));
+  scatter_items(A, ip, pk_lds, (mode == 1 || mode == 3) ? A.o_hess : (mode == 2 ? A.o_aux : A.o_jac));
 }
 
 
@@ -599,6 +684,13 @@ __device__ __forceinline__ void kernel_hess(const PkArgs& A) {
   }
   PK_TILE_PROLOGUE(2);
   Gen::tile_hess(tl.phase, A, tl, pk_lds + wave * Gen::LDS_H, wint, wgrad, lane);
+}
+
+template <class Gen>
+__device__ __forceinline__ void kernel_hessc(const PkArgs& A) {
+  if (PK_IS_EDGE_BLOCK()) return edge_block<Gen>(A, 3, false);
+  PK_TILE_PROLOGUE(1);
+  Gen::tile_hessc(tl.phase, A, tl, pk_lds, wint, wgrad, lane);
 }
 
 template <class Gen>
@@ -724,4 +816,5 @@ __device__ __forceinline__ void kernel_fin(const PkArgs& A) {
   extern "C" __global__ __launch_bounds__(PK_BLOCK) void pk_hess(PkArgs A) { pk::kernel_hess<GEN>(A); } \
   extern "C" __global__ __launch_bounds__(PK_BLOCK) void pk_xall(PkArgs A) { pk::kernel_xall<GEN>(A); } \
   extern "C" __global__ __launch_bounds__(PK_BLOCK) void pk_aux(PkArgs A) { pk::kernel_aux<GEN>(A); }   \
-  extern "C" __global__ __launch_bounds__(PK_BLOCK) void pk_outer(PkArgs A) { pk::kernel_outer(A); }
+  extern "C" __global__ __launch_bounds__(PK_BLOCK) void pk_outer(PkArgs A) { pk::kernel_outer(A); }     \
+  extern "C" __global__ __launch_bounds__(PK_BLOCK) void pk_hessc(PkArgs A) { pk::kernel_hessc<GEN>(A); }

@@ -31,9 +31,9 @@
 
 namespace {
 
-enum { K_INT = 0, K_FIN, K_G, K_GRAD, K_JAC, K_HESS, K_XALL, K_AUX, K_OUTER, K_COUNT };
+enum { K_INT = 0, K_FIN, K_G, K_GRAD, K_JAC, K_HESS, K_XALL, K_AUX, K_OUTER, K_HESSC, K_COUNT };
 const char* const kKernelNames[K_COUNT] = {"pk_int", "pk_fin", "pk_g", "pk_grad", "pk_jac", "pk_hess", "pk_xall",
-                                           "pk_aux", "pk_outer"};
+                                           "pk_aux", "pk_outer", "pk_hessc"};
 enum { F_WRITE_F = 1, F_SECONDARY = 2, F_FIN_INT = 8, F_FIN_GRAD = 16 };
 
 thread_local std::string g_create_error;
@@ -60,9 +60,11 @@ struct pk_ctx {
   int32_t n = 0, m = 0, n_sys = 0, n_s = 0, l_s = 0, n_phase = 0, n_tiles = 0;
   int64_t nnz_J = 0, nnz_H = 0;
   int32_t n_items_jac = 0, n_items_hess = 0, n_items_aux = 0, n_outer = 0, n_aux = 0, gz_off = 0, n_gz = 0;
+  int32_t n_items_hessc = 0;
+  int64_t nnz_Hc = 0;
   void *d_phases = nullptr, *d_tiles = nullptr, *d_kinds = nullptr, *d_items_jac = nullptr, *d_items_hess = nullptr,
-       *d_items_aux = nullptr, *d_outer = nullptr;
-  double* d_aux = nullptr;
+       *d_items_aux = nullptr, *d_outer = nullptr, *d_items_hessc = nullptr;
+  double *d_aux = nullptr, *d_Hc = nullptr;
   int32_t* d_ib = nullptr;
   double* d_db = nullptr;
   int64_t* d_lb = nullptr;
@@ -107,7 +109,7 @@ void release(T*& p) {
 }
 
 void free_problem(pk_ctx* c) {
-  release(c->d_phases); release(c->d_tiles); release(c->d_kinds); release(c->d_items_jac); release(c->d_items_hess); release(c->d_items_aux); release(c->d_outer); release(c->d_aux);
+  release(c->d_phases); release(c->d_tiles); release(c->d_kinds); release(c->d_items_jac); release(c->d_items_hess); release(c->d_items_aux); release(c->d_outer); release(c->d_aux); release(c->d_items_hessc); release(c->d_Hc);
   release(c->d_ib); release(c->d_db); release(c->d_lb);
   release(c->d_x); release(c->d_lam); release(c->d_f); release(c->d_grad); release(c->d_g); release(c->d_J);
   release(c->d_H); release(c->d_I); release(c->d_partial); release(c->d_partial2);
@@ -267,6 +269,7 @@ int pk_set_problem(pk_ctx* c, const pk_problem_desc* pd) {
   c->n_phase = pd->n_phase; c->n_tiles = pd->n_tiles; c->nnz_J = pd->nnz_J; c->nnz_H = pd->nnz_H;
   c->n_items_jac = pd->n_items_jac; c->n_items_hess = pd->n_items_hess; c->gz_off = pd->gz_off; c->n_gz = pd->n_gz;
   c->n_items_aux = pd->n_items_aux; c->n_outer = pd->n_outer; c->n_aux = pd->n_aux;
+  c->n_items_hessc = pd->n_items_hessc; c->nnz_Hc = pd->nnz_Hc;
   int rc;
   if ((rc = upload(c, &c->d_phases, pd->phases, sizeof(PkPhase) * (size_t)pd->n_phase))) return rc;
   c->h_phases.assign((const PkPhase*)pd->phases, (const PkPhase*)pd->phases + pd->n_phase);
@@ -277,6 +280,7 @@ int pk_set_problem(pk_ctx* c, const pk_problem_desc* pd) {
   if ((rc = upload(c, &c->d_items_hess, pd->items_hess, sizeof(PkItem) * (size_t)pd->n_items_hess))) return rc;
   if ((rc = upload(c, &c->d_items_aux, pd->items_aux, sizeof(PkItem) * (size_t)pd->n_items_aux))) return rc;
   if ((rc = upload(c, &c->d_outer, pd->outer, sizeof(PkOuter) * (size_t)pd->n_outer))) return rc;
+  if ((rc = upload(c, &c->d_items_hessc, pd->items_hessc, sizeof(PkItem) * (size_t)pd->n_items_hessc))) return rc;
   if ((rc = upload(c, (void**)&c->d_ib, pd->ib, sizeof(int32_t) * (size_t)pd->n_ib))) return rc;
   if ((rc = upload(c, (void**)&c->d_db, pd->db, sizeof(double) * (size_t)pd->n_db))) return rc;
   if ((rc = upload(c, (void**)&c->d_lb, pd->lb, sizeof(int64_t) * (size_t)pd->n_lb))) return rc;
@@ -287,7 +291,7 @@ int pk_set_problem(pk_ctx* c, const pk_problem_desc* pd) {
   };
   if ((rc = dalloc(&c->d_x, c->n)) || (rc = dalloc(&c->d_lam, c->m)) || (rc = dalloc(&c->d_f, 1)) ||
       (rc = dalloc(&c->d_grad, c->n)) || (rc = dalloc(&c->d_g, c->m)) || (rc = dalloc(&c->d_J, (size_t)c->nnz_J)) ||
-      (rc = dalloc(&c->d_H, (size_t)c->nnz_H)) || (rc = dalloc(&c->d_aux, (size_t)c->n_aux)) || (rc = dalloc(&c->d_I, c->md.n_I)) ||
+      (rc = dalloc(&c->d_H, (size_t)c->nnz_H)) || (rc = dalloc(&c->d_aux, (size_t)c->n_aux)) || (rc = dalloc(&c->d_Hc, (size_t)c->nnz_Hc)) || (rc = dalloc(&c->d_I, c->md.n_I)) ||
       (rc = dalloc(&c->d_partial, ((size_t)c->n_tiles / PK_WAVES_PER_BLOCK + 2) * (size_t)c->md.nred)) ||
       (rc = dalloc(&c->d_partial2, ((size_t)c->n_tiles / PK_WAVES_PER_BLOCK + 2) * (size_t)c->md.nred)))
     return rc;
@@ -409,6 +413,34 @@ int pk_eval_hess_dev(pk_ctx* c, const double* d_x, const double* d_lam, double s
     const unsigned grid = (unsigned)(c->n_outer < 4096 ? c->n_outer : 4096);
     return launch(c, K_OUTER, X, grid, 0, st);
   }
+  return 0;
+}
+
+// compact (coalesced) Hessian of the Lagrangian: one value per distinct (row, col) class of a node
+int pk_eval_hessc_dev(pk_ctx* c, const double* d_x, const double* d_lam, double sigma, double* d_vals, void* stream) {
+  int rc = ready(c);
+  if (rc) return rc;
+  if (!d_lam) return fail(c, 50, "pk_eval_hessc: lambda is required");
+  if (c->nnz_Hc <= 0) return fail(c, 51, "pk_eval_hessc: no compact Hessian layout was supplied to pk_set_problem");
+  hipStream_t st = pick(c, stream);
+  if (c->md.prepass_hess && !c->external_prepass && (rc = prepass(c, d_x, d_lam, sigma, c->d_f, false, st))) return rc;
+  PkArgs A = base_args(c, d_x, d_lam, sigma);
+  A.o_hess = d_vals;
+  A.items = (const PkItem*)c->d_items_hessc;
+  A.n_items = c->n_items_hessc;
+  return launch(c, K_HESSC, A, tile_blocks(c) + 1, sizeof(double) * (size_t)(c->md.ne_hc > 0 ? c->md.ne_hc : 1), st);
+}
+
+int pk_eval_hessc(pk_ctx* c, const double* x, const double* lambda, double sigma, double* vals) {
+  int rc = ready(c);
+  if (rc) return rc;
+  if (!x || !lambda || !vals) return fail(c, 60, "null host buffer");
+  PK_HIP(c, hipSetDevice(c->device));
+  PK_HIP(c, hipMemcpyAsync(c->d_x, x, sizeof(double) * (size_t)c->n, hipMemcpyHostToDevice, c->stream));
+  PK_HIP(c, hipMemcpyAsync(c->d_lam, lambda, sizeof(double) * (size_t)c->m, hipMemcpyHostToDevice, c->stream));
+  if ((rc = pk_eval_hessc_dev(c, c->d_x, c->d_lam, sigma, c->d_Hc, nullptr))) return rc;
+  PK_HIP(c, hipMemcpyAsync(vals, c->d_Hc, sizeof(double) * (size_t)c->nnz_Hc, hipMemcpyDeviceToHost, c->stream));
+  PK_HIP(c, hipStreamSynchronize(c->stream));
   return 0;
 }
 

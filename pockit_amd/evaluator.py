@@ -78,7 +78,15 @@ class Tables:
             ph["tau_off"] = put(db, lay.tau, np.float64)
             ph["w_off"] = put(db, lay.w, np.float64)
             ph["width_off"] = put(db, lay.width, np.float64)
-            for cbname, field in (("jac", "jseg_off"), ("hess", "hseg_off"), ("aux", "aseg_off")):
+            ph["n_int"] = lay.N
+            ph["ivK_off"] = put(ib, lay.K, np.int32)
+            ph["ivld_off"] = put(ib, lay.ld, np.int32)
+            full_pos = [int(kinds[kind0 + int(kf)]["full_off"]) for kf in lay.kid_full]
+            ph["ivfull_off"] = put(ib, full_pos, np.int32)
+            cbs = [("jac", "jseg_off"), ("hess", "hseg_off"), ("aux", "aseg_off")]
+            if src.compact:
+                cbs.append(("hessc", "hcseg_off"))
+            for cbname, field in cbs:
                 segs = getattr(plan, cbname).segs[k]
                 bases = [s.base for s in segs if s.kind == "I"] + [s.base for s in segs if s.kind == "N"]
                 ph[field] = put(lb, bases, np.int64)
@@ -121,6 +129,7 @@ class Tables:
             return arr
 
         self.items_jac, self.items_hess, self.items_aux = items("jac"), items("hess"), items("aux")
+        self.items_hessc = items("hessc") if src.compact else np.zeros(0, dtype=runtime.ITEM_DTYPE)
         self.outer = np.zeros(len(plan.outer), dtype=runtime.OUTER_DTYPE)
         for i, b in enumerate(plan.outer):
             flags = (1 if b.tril else 0) | (2 if b.collapseA else 0) | (4 if b.collapseB else 0) | (8 if b.second else 0)
@@ -147,6 +156,7 @@ class Evaluator:
         md.lds_g, md.lds_j, md.lds_h, md.lds_x = self.src.lds_g, self.src.lds_j, self.src.lds_h, self.src.lds_x
         md.ne_j, md.ne_h = self.src.list_off["jac"]["total"], self.src.list_off["hess"]["total"]
         md.ne_a = self.src.list_off["aux"]["total"]
+        md.ne_hc = self.src.list_off["hessc"]["total"] if self.src.compact else 0
         md.prepass_f = 1
         md.prepass_grad = int(plan.needs_I_grad)
         md.prepass_g = int(plan.needs_I_con)
@@ -179,6 +189,8 @@ class Evaluator:
         pd.gz_off, pd.n_gz = tb.gz_off, tb.n_gz
         pd.items_aux, pd.n_items_aux = vp(tb.items_aux), len(tb.items_aux)
         pd.outer, pd.n_outer, pd.n_aux = vp(tb.outer), len(tb.outer), plan.n_aux
+        pd.items_hessc, pd.n_items_hessc = vp(tb.items_hessc), len(tb.items_hessc)
+        pd.nnz_Hc = plan.nnz_Hc if self.src.compact else 0
         self._struct = [np.ascontiguousarray(a, dtype=np.int32) for a in
                         (plan.jac_row, plan.jac_col, plan.hess_row, plan.hess_col)]
         pd.jac_row, pd.jac_col, pd.hess_row, pd.hess_col = (a.ctypes.data_as(runtime.c_int32_p) for a in self._struct)
@@ -283,6 +295,17 @@ class Evaluator:
         out = np.empty(self.plan.nnz_H)
         self.ctx.check(self.ctx.lib.pk_eval_hess(self.ctx.handle, runtime.as_dp(x), runtime.as_dp(lam),
                                                  float(obj_factor), runtime.as_dp(out)))
+        return out
+
+    def hessian_compact(self, x, lagrange, obj_factor):
+        """Values of the compact (coalesced) Hessian layout ``plan.hessc_row/col``."""
+        if not self.src.compact:
+            raise NotImplementedError("compact Hessian layout is not available for this model")
+        x = self._x(x)
+        lam = np.ascontiguousarray(lagrange, dtype=np.float64)
+        out = np.empty(self.plan.nnz_Hc)
+        self.ctx.check(self.ctx.lib.pk_eval_hessc(self.ctx.handle, runtime.as_dp(x), runtime.as_dp(lam),
+                                                  float(obj_factor), runtime.as_dp(out)))
         return out
 
     def cycle(self, x, lagrange, obj_factor):

@@ -275,6 +275,7 @@ class SystemBase:
         self._phase_set = self._objective_set = self._system_constraint_set = False
         self._evaluator = None
         self._built_for = None
+        self._hessian_layout = "reference"
         self.set_phase([])
         self.set_system_constraint([], np.array([]), np.array([]))
 
@@ -308,6 +309,15 @@ class SystemBase:
         self._system_constraint_user_upper_bound = upper_bound
         self._system_constraint_set = True
         return self._invalidate()
+
+    def set_hessian_layout(self, layout: str):
+        """``"reference"`` (default): the reference's triplet list, duplicates included (drop-in).
+        ``"compact"``: one triplet per distinct (row, col) of every node -- 10-20x fewer values for IPOPT to
+        receive and assemble; ``hessianstructure()`` / ``hessian()`` switch together, the matrices are equal."""
+        if layout not in ("reference", "compact"):
+            raise ValueError('layout must be "reference" or "compact"')
+        self._hessian_layout = layout
+        return self
 
     def update(self) -> None:
         """Re-transcribe after changing any phase (e.g. a new mesh)."""
@@ -382,23 +392,36 @@ class SystemBase:
         return self.evaluator.jacobian(x)
 
     def hessianstructure(self):
+        if self._hessian_layout == "compact":
+            self.plan.hessc  # noqa: B018  (builds the compact plan)
+            return self.plan.hessc_row, self.plan.hessc_col
         return self.plan.hess_row, self.plan.hess_col
 
     def hessian(self, x, lagrange, obj_factor):
+        if self._hessian_layout == "compact":
+            return self.evaluator.hessian_compact(x, lagrange, obj_factor)
         return self.evaluator.hessian(x, lagrange, obj_factor)
 
     # split Hessians used by the SciPy adapter (reference: systembase.py:726-809)
     def hessianstructure_o(self):
+        if self._hessian_layout == "compact":
+            return self.hessianstructure()
         n = self.plan.nnz_H_obj
         return self.plan.hess_row[:n], self.plan.hess_col[:n]
 
     def hessian_o(self, x):
         m = len(self.plan.c_lb)
+        if self._hessian_layout == "compact":       # same pattern for both parts; the values split by sigma / lambda
+            return self.evaluator.hessian_compact(x, np.zeros(m), 1.0)
         return self.evaluator.hessian(x, np.zeros(m), 1.0)[: self.plan.nnz_H_obj]
 
     def hessianstructure_c(self):
+        if self._hessian_layout == "compact":
+            return self.hessianstructure()
         n = self.plan.nnz_H_obj
         return self.plan.hess_row[n:], self.plan.hess_col[n:]
 
     def hessian_c(self, x, fct_c):
+        if self._hessian_layout == "compact":
+            return self.evaluator.hessian_compact(x, fct_c, 0.0)
         return self.evaluator.hessian(x, fct_c, 0.0)[self.plan.nnz_H_obj:]

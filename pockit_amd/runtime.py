@@ -19,7 +19,7 @@ c_int32_p = C.POINTER(C.c_int32)
 class ModelDesc(C.Structure):
     _fields_ = [(n, C.c_int32) for n in
                 ("n_phase", "n_I", "nred", "lds_g", "lds_j", "lds_h", "ne_j", "ne_h", "prepass_f", "prepass_grad",
-                 "prepass_g", "prepass_jac", "prepass_hess", "lds_x", "ne_a")] + [("reserved", C.c_int32 * 1)]
+                 "prepass_g", "prepass_jac", "prepass_hess", "lds_x", "ne_a", "ne_hc")]
 
 
 class ProblemDesc(C.Structure):
@@ -36,6 +36,7 @@ class ProblemDesc(C.Structure):
         ("gz_off", C.c_int32), ("n_gz", C.c_int32),
         ("items_aux", C.c_void_p), ("n_items_aux", C.c_int32),
         ("outer", C.c_void_p), ("n_outer", C.c_int32), ("n_aux", C.c_int32),
+        ("items_hessc", C.c_void_p), ("n_items_hessc", C.c_int32), ("nnz_Hc", C.c_int64),
         ("jac_row", c_int32_p), ("jac_col", c_int32_p), ("hess_row", c_int32_p), ("hess_col", c_int32_p),
     ]
 
@@ -43,7 +44,7 @@ class ProblemDesc(C.Structure):
 # numpy mirrors of csrc/pk_abi.h
 PHASE_FIELDS = ["scheme", "n_x", "n_u", "n_c", "L_m", "L_d", "state_len", "L", "x_off", "g_off", "path_off",
                 "mid_lo", "mid_hi", "tile_lo", "tile_hi", "tau_off", "w_off", "width_off", "jseg_off", "jt_off",
-                "hseg_off", "red_off", "aseg_off", "pad1"]
+                "hseg_off", "red_off", "aseg_off", "hcseg_off", "ivK_off", "ivfull_off", "ivld_off", "n_int"]
 PHASE_DTYPE = np.dtype([(n, np.int32) for n in PHASE_FIELDS])
 TILE_FIELDS = ["phase", "j0", "nj", "kid", "kidf", "q0", "r0", "offI", "offT", "K", "last",
                "nnzI", "nnzT", "irc_off", "iv_off", "tv_off", "full_off", "pad"]
@@ -55,13 +56,13 @@ OUTER_DTYPE = np.dtype([("pos", np.int64), ("offA", np.int32), ("lenA", np.int32
                         ("offM", np.int32), ("flags", np.int32), ("count", np.int32), ("pad", np.int32)])
 
 WAVES_PER_BLOCK = 4  # PK_WAVES_PER_BLOCK of csrc/pk_abi.h
-KERNELS = ["pk_int", "pk_fin", "pk_g", "pk_grad", "pk_jac", "pk_hess", "pk_xall", "pk_aux", "pk_outer"]
+KERNELS = ["pk_int", "pk_fin", "pk_g", "pk_grad", "pk_jac", "pk_hess", "pk_xall", "pk_aux", "pk_outer", "pk_hessc"]
 EXPORTS = ["pk_create", "pk_destroy", "pk_last_error", "pk_device_count", "pk_load_model", "pk_set_problem",
            "pk_get_structure", "pk_eval_f", "pk_eval_grad", "pk_eval_g", "pk_eval_jac", "pk_eval_hess",
            "pk_eval_f_dev", "pk_eval_grad_dev", "pk_eval_g_dev", "pk_eval_jac_dev", "pk_eval_hess_dev",
            "pk_eval_cycle_dev", "pk_sync", "pk_profile", "pk_profile_read", "pk_kernel_name",
            "pk_set_shard", "pk_eval_integrals_dev", "pk_eval_f_from_integrals_dev", "pk_eval_cycle",
-           "pk_prepare_x", "pk_fetch", "pk_eval_hess_prepared", "pk_host_buffer"]
+           "pk_prepare_x", "pk_fetch", "pk_eval_hess_prepared", "pk_host_buffer", "pk_eval_hessc", "pk_eval_hessc_dev"]
 
 _lib = None
 
@@ -120,6 +121,8 @@ def load_library():
     lib.pk_fetch.argtypes = [vp, C.c_int, dp]
     lib.pk_eval_hess_prepared.argtypes = [vp, dp, C.c_double, dp]
     lib.pk_host_buffer.argtypes = [vp, C.c_int, C.POINTER(dp), C.POINTER(C.c_int64)]
+    lib.pk_eval_hessc.argtypes = [vp, dp, dp, C.c_double, dp]
+    lib.pk_eval_hessc_dev.argtypes = [vp, vp, vp, C.c_double, vp, vp]
     lib.pk_eval_f_dev.argtypes = [vp, vp, vp, vp]
     lib.pk_eval_grad_dev.argtypes = [vp, vp, vp, vp]
     lib.pk_eval_g_dev.argtypes = [vp, vp, vp, vp]

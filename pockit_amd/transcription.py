@@ -50,6 +50,22 @@ def lam_path(j):
     return sp.Symbol(f"pk_lp{j}")
 
 
+# compact Hessian mode: multipliers already contracted with the integration / translation blocks
+def mu_sym(i):
+    """mu_i(node) = sum_r (I_hat[r, c] d/2) * lambda[defect row r of state i]  over the interval(s) holding the node"""
+    return sp.Symbol(f"pk_mu{i}")
+
+
+def ltf_sym(i):
+    """sum over the front translation entries of state i: T_f * lambda   (= lambda of its first defect row)"""
+    return sp.Symbol(f"pk_ltf{i}")
+
+
+def ltb_sym(i):
+    """sum over the back translation entries of state i: T_b * lambda   (= -sum of lambda over the last interval)"""
+    return sp.Symbol(f"pk_ltb{i}")
+
+
 # ---------------------------------------------------------------------------------------------
 # symbolic derivative nodes
 # ---------------------------------------------------------------------------------------------
@@ -589,6 +605,92 @@ class SystemPlan:
         self.nnz_H = pos
         self.hess_row = np.concatenate(rows) if rows else np.zeros(0, np.int64)
         self.hess_col = np.concatenate(cols) if cols else np.zeros(0, np.int64)
+
+    # ------------------------------------------------------------------ compact Hessian
+    @property
+    def hessc(self):
+        """Compact (coalesced) Hessian plan, built on first use: the K-fold duplication of every dynamics
+        entry over the rows of the integration block (phasebase.py:923-928,1280-1285) is contracted into
+        mu = I^T lambda per node, and entries of one node that hit the same (row, col) are summed
+        symbolically.  Structure/values differ from the reference's triplet list but scatter-add to the
+        same matrix."""
+        if getattr(self, "_hessc", None) is None:
+            self._plan_hessian_compact()
+        return self._hessc
+
+    def _plan_hessian_compact(self):
+        if self.outer:
+            raise NotImplementedError("compact Hessian layout is not available for objectives / system "
+                                      "constraints that are nonlinear in the integrals")
+        nP = len(self.phase_plans)
+        cb = CallbackPlan(nP)
+        rows, cols, pos = [], [], 0
+        nI = len(self.I_syms)
+        sys_funcs = [(self.F_o, SIG)] + [(fc, lam_sys(c)) for c, fc in enumerate(self.F_c)]
+
+        def emit_scalars(key, table):
+            nonlocal pos
+            for (r, c), expr in table.items():
+                rows.append(np.array([r], dtype=np.int64))
+                cols.append(np.array([c], dtype=np.int64))
+                cb.items.append(Item(pos, 1.0, key, cb.entry(key, expr)))
+                pos += 1
+
+        # system level: static-static pairs
+        sys_tab = {}
+        for fn, factor in sys_funcs:
+            for pr, pc, h in zip(fn.H_index_row.tolist(), fn.H_index_col.tolist(), fn.hess):
+                key = (self.l_s + (pr - nI), self.l_s + (pc - nI))
+                sys_tab[key] = sys_tab.get(key, sp.Integer(0)) + factor * h
+                cb.needs_I |= self._uses_I(h)
+        emit_scalars(("s",), sys_tab)
+
+        for k, pp in enumerate(self.phase_plans):
+            lay = pp.layout
+            mid, edge = {}, {"f": {}, "b": {}}
+
+            def add(w, r, c, expr, k=k, lay=lay, mid=mid, edge=edge):
+                if w == "m":
+                    mid[(r, c)] = mid.get((r, c), sp.Integer(0)) + expr
+                else:
+                    qn = 0 if w == "f" else lay.L_m - 1
+                    key = (int(self.col(k, r, qn)), int(self.col(k, c, qn)))
+                    edge[w][key] = edge[w].get(key, sp.Integer(0)) + expr
+
+            for fn, factor in sys_funcs:                              # integrand Hessians
+                for a, m in zip(fn.G_index.tolist(), fn.grad):
+                    if a >= nI or self.I_owner[a][0] != k:
+                        continue
+                    cb.needs_I |= self._uses_I(m)
+                    nodes = pp.int_nodes[self.I_owner[a][1]]
+                    for w in pp.where:
+                        for r, c, e in nodes[w].H:
+                            add(w, r, c, factor * m * WQ * e)
+            for i in range(pp.nx):                                    # FUNC boundary values
+                for r, c, e in pp.x_f[i].H:
+                    add("f", r, c, ltf_sym(i) * e)
+                for r, c, e in pp.x_b[i].H:
+                    add("b", r, c, ltb_sym(i) * e)
+            for i in range(pp.nx):                                    # dynamics, contracted with mu
+                for w in pp.where:
+                    for r, c, e in pp.dyn_nodes[i][w].H:
+                        add(w, r, c, -mu_sym(i) * e)
+            for j in range(len(pp.path)):                             # path constraints
+                for w in pp.where:
+                    for r, c, e in pp.path_nodes[j][w].H:
+                        add(w, r, c, lam_path(j) * e)
+            emit_scalars(("f", k), edge["f"])
+            q = np.arange(lay.mid_lo, lay.mid_hi)
+            for (r, c), expr in mid.items():
+                cb.segs[k].append(Seg(expr, "N", pos))
+                rows.append(np.broadcast_to(self.col(k, r, q), q.shape).astype(np.int64))
+                cols.append(np.broadcast_to(self.col(k, c, q), q.shape).astype(np.int64))
+                pos += lay.L_mid
+            emit_scalars(("b", k), edge["b"])
+        self._hessc = cb
+        self.nnz_Hc = pos
+        self.hessc_row = np.concatenate(rows) if rows else np.zeros(0, np.int64)
+        self.hessc_col = np.concatenate(cols) if cols else np.zeros(0, np.int64)
 
     # ------------------------------------------------------------------ f, grad f, g
     def _plan_values_and_gradient(self):

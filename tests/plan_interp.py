@@ -9,7 +9,7 @@ import numpy as np
 import sympy as sp
 
 from pockit_amd.model import FIXED, FREE
-from pockit_amd.transcription import DT, SIG, TAU, WQ, lam_path, lam_sys
+from pockit_amd.transcription import DT, SIG, TAU, WQ, lam_path, lam_sys, ltb_sym, ltf_sym, mu_sym
 
 
 def _bc_value(info, cur, sdict):
@@ -25,6 +25,7 @@ class Interp:
         self.plan, self.x = plan, np.asarray(x, dtype=np.float64)
         self.lam = np.zeros(plan.m) if lam is None else np.asarray(lam, dtype=np.float64)
         self.sigma = sigma
+        self._mu_cache = {}
         self.s = self.x[plan.l_s: plan.r_s]
         self.sdict = dict(zip(plan.s_syms, self.s))
         self.ph = [self._phase_env(k) for k in range(len(plan.phase_plans))]
@@ -76,11 +77,33 @@ class Interp:
             vals[lam_path(j)] = self.lam[plan.path_off[k] + j * lay.L_m + q]
         for sym, v in self.Ivals.items():
             vals[sym] = np.full(len(q), v)
+        mu = self._mu(k)
+        for i in range(p.n_x):
+            vals[mu_sym(i)] = mu[i][q]
+            r0 = plan.g_off[k] + lay.l_d[i]
+            vals[ltf_sym(i)] = np.full(len(q), float(np.dot(lay.Tf_val, self.lam[r0 + lay.Tf_row])))
+            vals[ltb_sym(i)] = np.full(len(q), float(np.dot(lay.Tb_val, self.lam[r0 + lay.Tb_row])))
         syms = list(vals)
         full = [sp.sympify(e).subs(env["base"]) for e in exprs]
         fn = sp.lambdify(syms, full, modules="numpy")
         out = fn(*[vals[s_] for s_ in syms])
         return [np.broadcast_to(np.asarray(o, dtype=np.float64), q.shape) for o in out]
+
+    def _mu(self, k):
+        """mu_i(node) = sum over the intervals holding the node of sum_r (I_hat d/2)[r, c] * lambda[row]."""
+        if k not in self._mu_cache:
+            plan = self.plan
+            pp = plan.phase_plans[k]
+            lay = pp.layout
+            mu = np.zeros((pp.nx, lay.L_m))
+            for j in range(lay.N):
+                A = lay.kinds[lay.kid_full[j]].full * lay.width[j] * 0.5
+                nodes = lay.lm[j] + np.arange(int(lay.K[j]))
+                for i in range(pp.nx):
+                    lam = self.lam[plan.g_off[k] + lay.l_d[i] + lay.ld[j] + np.arange(A.shape[0])]
+                    mu[i, nodes] += A.T @ lam
+            self._mu_cache[k] = mu
+        return self._mu_cache[k]
 
     def _eval_sys(self, exprs):
         vals = dict(self.sdict)
@@ -151,6 +174,11 @@ class Interp:
                 out[b.pos: b.pos + b.count] = vals
             assert not np.isnan(out).any(), "plan does not cover every output slot"
         return out
+
+    def hessian_compact(self):
+        plan = self.plan
+        cb = plan.hessc
+        return self._run(cb, plan.nnz_Hc, False)
 
     def objective(self):
         return self._eval_sys([self.plan.F_o.expr])[0]

@@ -219,3 +219,36 @@ def test_scipy_trust_constr_solves_lqr_on_the_gpu_evaluator():
     optimum = ric.y[0, -1] * 1.0 ** 2
     assert abs(res.fun - optimum) <= 2e-6 * max(1.0, abs(optimum))
     assert abs(var.x[0][-1] - s[0]) < 1e-9 and abs(var.x[0][0] - 1.0) < 1e-12
+
+
+@pytest.mark.parametrize("case", [("brachistochrone", "radau", dict(mesh=37, num_point=5)),
+                                  ("brachistochrone", "lobatto", dict(mesh=23, num_point=6)),
+                                  ("brachistochrone", "radau", dict(mesh=[0, 0.1, 0.15, 0.5, 0.9, 1.0], num_point=[3, 7, 2, 5, 1])),
+                                  ("two_stage_rocket", "radau", dict(mesh=40, num_point=3)),
+                                  ("two_stage_rocket", "lobatto", dict(mesh=11, num_point=4)),
+                                  ("planar_quadrotor", "lobatto", dict(mesh=19, num_point=4)),
+                                  ("planar_quadrotor", "radau", dict(mesh=300, num_point=6)),
+                                  ("humanoid_wbc", "radau", dict(mesh=9, num_point=7)),
+                                  ("humanoid_wbc", "lobatto", dict(mesh=6, num_point=5))])
+def test_compact_hessian_equals_coalesced_oracle(case):
+    """pk_hessc: one value per distinct position; scatter-added it must equal the scatter-add of the
+    oracle's (= the reference's) duplicate-laden triplet list."""
+    import scipy.sparse as ssp
+
+    bname, scheme, kw = case
+    system, _, guess = getattr(models, bname)(_ns(scheme, "pockit_amd"), **kw)
+    ref, _, _ = getattr(models, bname)(_ns(scheme, "oracle"), **kw)
+    x, lam, sigma = models.bench_inputs(system, guess)
+    n = system.plan.n
+    hr, hc = ref.hessianstructure()
+    want = ssp.coo_array((ref.hessian(x, lam, sigma), (hr, hc)), shape=(n, n)).tocsr()
+    system.set_hessian_layout("compact")
+    cr, cc = system.hessianstructure()
+    vals = system.hessian(x, lam, sigma)
+    assert len(vals) == len(cr) < len(hr) or bname == "lqr"
+    got = ssp.coo_array((vals, (cr, cc)), shape=(n, n)).tocsr()
+    diff = abs(got - want)
+    scale = max(1.0, abs(want).max())
+    assert (diff.max() if diff.nnz else 0.0) <= TOL * scale
+    system.set_hessian_layout("reference")
+    close(system.hessian(x, lam, sigma), ref.hessian(x, lam, sigma), what="reference layout still served")

@@ -218,3 +218,24 @@ def test_nonlinear_in_integrals_uses_outer_blocks():
     covered += sum(pp.layout.L_mid for k, pp in enumerate(plan.phase_plans) for sg in plan.hess.segs[k] if sg.kind == "N")
     covered += sum(pp.layout.nnzI_mid for k, pp in enumerate(plan.phase_plans) for sg in plan.hess.segs[k] if sg.kind == "I")
     assert covered == plan.nnz_H
+
+
+@pytest.mark.parametrize("name", sorted(n for n in models.SMALL_CASES if not n.startswith(NONLINEAR_IN_I)))
+def test_compact_hessian_plan_coalesces_to_the_reference_matrix(name):
+    """Compact layout (mu = I^T lambda, entries of a node summed per position): fewer triplets, same matrix
+    as the scatter-add of the reference's triplets (the accumulation IPOPT performs)."""
+    import scipy.sparse as ssp
+
+    builder, scheme, kw = models.SMALL_CASES[name]
+    gold = np.load(os.path.join(HERE, "golden", "small", name + ".npz"))
+    system, _, _ = builder(NS[scheme], **kw)
+    plan = system.plan
+    plan.hessc  # noqa: B018
+    assert np.all(plan.hessc_row >= plan.hessc_col) and plan.nnz_Hc <= plan.nnz_H
+    it = Interp(plan, gold["x"], gold["lam"], float(gold["sigma"]))
+    n = plan.n
+    want = ssp.coo_array((gold["H"], (gold["hr"], gold["hc"])), shape=(n, n)).toarray()
+    got = ssp.coo_array((it.hessian_compact(), (plan.hessc_row, plan.hessc_col)), shape=(n, n)).toarray()
+    close(got, want)
+    if "brach" in name:                 # K-fold (and more) reduction where the dynamics are nonlinear
+        assert plan.nnz_Hc * 4 <= plan.nnz_H
