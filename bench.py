@@ -168,13 +168,26 @@ def run_gpu(name, intervals, steps, warmup, rank, world, dist, time_kernel=None)
     torch.cuda.synchronize()
     allk = {k: (v[1] / v[0] * 1e3 if v[0] else 0.0) for k, v in ev.profile_read().items()}
     ev.profile(0)
+    # compact Hessian layout (optional mode): kernel time and size beside the reference layout
+    compact = None
+    if ev.src.compact and world == 1:
+        hc = torch.zeros(max(plan.nnz_Hc, 1), dtype=torch.float64, device=dev)
+        hargs = (h, ptr(dx), ptr(dlam), C.c_double(float(sigma)), ptr(hc), st)
+        ev.profile(1 << 9)
+        for _ in range(50):
+            lib.pk_eval_hessc_dev(*hargs)
+        torch.cuda.synchronize()
+        n_l, ms_l = ev.profile_read()["pk_hessc"]
+        ev.profile(0)
+        compact = {"nnz_H_compact": int(plan.nnz_Hc), "nnz_H_reference": int(plan.nnz_H),
+                   "pk_hessc_us": ms_l / max(n_l, 1) * 1e3, "finite": bool(torch.isfinite(hc).all())}
     # correctness spot-check against what the kernels are supposed to produce: finite outputs
     finite = all(bool(torch.isfinite(o[k]).all()) for k in ("f", "grad", "g", "J", "H"))
     res = dict(name=name, intervals=intervals, nodes=int(sum(pp.layout.L_m for pp in plan.phase_plans)),
                n=plan.n, m=plan.m, nnz_J=plan.nnz_J, nnz_H=plan.nnz_H, elapsed=elapsed, steps=steps,
                ms_per_step=elapsed / steps * 1e3, setup_s=setup_s, bytes=B, dominant=dominant,
                dominant_us=(total_ms / launches * 1e3 if launches else None), kernel_us=allk, finite=finite,
-               tiles=int(len(ev.tables.tiles)), ipw=int(ev.tables.intervals_per_wave))
+               tiles=int(len(ev.tables.tiles)), ipw=int(ev.tables.intervals_per_wave), compact=compact)
     ev.close()
     return res
 
@@ -248,6 +261,7 @@ def main():
             "cycle_algorithmic_bytes": res["bytes"]["cycle"],
             "setup_s": res["setup_s"],
             "outputs_finite": res["finite"],
+            "compact_hessian_mode": res["compact"],
         }
         if not args.no_cpu_baseline and n_gpus == 1:
             cb = cpu_baseline(args.workload, intervals)
@@ -264,7 +278,8 @@ def main():
                         "nodes": r["nodes"], "cycles_per_s": 1e3 / r["ms_per_step"], "ms_per_step": r["ms_per_step"],
                         "dominant": r["dominant"], "dominant_us": r["dominant_us"],
                         "dominant_GBps": b / (r["dominant_us"] * 1e-6) / 1e9 if r["dominant_us"] else None,
-                        "kernel_us": r["kernel_us"], "cycle_bytes": r["bytes"]["cycle"], "setup_s": r["setup_s"]}
+                        "kernel_us": r["kernel_us"], "cycle_bytes": r["bytes"]["cycle"], "setup_s": r["setup_s"],
+                        "compact_hessian_mode": r["compact"]}
                 except Exception as exc:  # keep the headline line even if a side workload fails
                     extra[f"{nm}_{iv}"] = {"error": repr(exc)}
             line["other_workloads"] = extra

@@ -108,11 +108,8 @@ class Reassembler:
         idx = [np.concatenate([np.arange(a, b, dtype=np.int64) for a, b in runs]) if runs else np.zeros(0, np.int64)
                for runs in runs_per_rank]
         self.total = plan.n + plan.m + plan.nnz_J + plan.nnz_H
-        covered = np.zeros(self.total, dtype=np.int32)
-        for ix in idx:
-            np.add.at(covered, ix, 1)
         shared = shared_gradient_slots(plan)
-        covered[shared] += 1
+        covered = np.bincount(np.concatenate(idx + [shared]), minlength=self.total)
         if not np.all(covered == 1):
             raise RuntimeError("internal error: the shards do not partition the output positions")
         self.pad = max(len(ix) for ix in idx)
