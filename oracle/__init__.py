@@ -19,6 +19,7 @@ Layout
   mesh.py        per-phase index partitions, T/I COO splits           (reference: */discretization.py Discretization)
   phase.py       per-phase values/gradients/Hessians + layout         (reference: base/phasebase.py:41-1337)
   system.py      NLP assembly + the 7 cyipopt callbacks               (reference: base/systembase.py:16-835)
+  refine.py      mesh error estimation + continuous hp-refinement    (reference: base/phasebase.py:1339-1437,1522-1617)
   variable.py    minimal Variable + constant/linear guesses           (reference: base/variablebase.py:92-470)
   radau.py / lobatto.py   the two user-facing namespaces (System, Phase, Variable, guesses)
 """

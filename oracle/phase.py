@@ -174,6 +174,23 @@ class Phase:
     def ok(self):
         return {"dynamics", "boundary", "mesh"} <= self._have
 
+    # ------------------------------------------------------------------ mesh error check / refinement
+    def check_continuous(self, variable, static_parameter=None, absolute_tolerance_continuous=1e-8,
+                         relative_tolerance_continuous=1e-8, tolerance_mesh=1e-4):
+        from . import refine
+
+        return refine.check_continuous(self, variable, static_parameter, absolute_tolerance_continuous,
+                                       relative_tolerance_continuous, tolerance_mesh)
+
+    def refine_continuous(self, variable, static_parameter=None, absolute_tolerance_continuous=1e-8,
+                          relative_tolerance_continuous=1e-8, num_point_min=6, num_point_max=12,
+                          mesh_length_min=1e-3, mesh_length_max=1.0):
+        from . import refine
+
+        refine.refine_continuous(self, variable, static_parameter, absolute_tolerance_continuous,
+                                 relative_tolerance_continuous, num_point_min, num_point_max, mesh_length_min,
+                                 mesh_length_max)
+
     # ------------------------------------------------------------------ structure (setup)
     def prepare(self):
         if self._ready:

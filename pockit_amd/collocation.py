@@ -136,3 +136,45 @@ def lgr_integration_matrix(K: int):
 def lgl_integration_matrix(K: int):
     x, _ = lgl_nodes_weights(K)
     return _integration_matrix(x, x[:-1])                      # (K-1) x K
+
+
+# ------------------------------------------------------------------------------ mesh error estimation tables
+def _lagrange_matrix(nodes, points):
+    """M[r, c] = L_c(points[r]) for the Lagrange basis on ``nodes`` (barycentric form, exact at the nodes)."""
+    nodes, points = np.asarray(nodes, dtype=np.float64), np.asarray(points, dtype=np.float64)
+    n = len(nodes)
+    bw = np.array([1.0 / np.prod(nodes[j] - np.delete(nodes, j)) for j in range(n)])
+    d = points[:, None] - nodes[None, :]
+    hit = np.abs(d) < 1e-14
+    d[hit] = 1.0
+    terms = bw[None, :] / d
+    M = terms / terms.sum(axis=1, keepdims=True)
+    rows = hit.any(axis=1)
+    M[rows] = hit[rows].astype(np.float64)
+    return M
+
+
+@functools.lru_cache(maxsize=None)
+def lgr_error_tables(K: int):
+    """One LGR interval with one more point (reference: radau/discretization.py:285-360): V_x (K+1)x(K+1) from
+    the K nodes + end point to the K+1 augmented nodes, V_u (K+1)xK, T = values - value at +1, I = I_lgr(K+1)."""
+    x, _ = lgr_nodes_weights(K)
+    x1 = np.concatenate((x, [1.0]))
+    xa, _ = lgr_nodes_weights(K + 1)
+    Vx = _lagrange_matrix(x1, xa)
+    Vu = _lagrange_matrix(x, xa)
+    T = Vx.copy()
+    T[:, K] -= 1.0                                            # L_c(+1) = delta_{c,K}
+    return Vx, Vu, T, lgr_integration_matrix(K + 1), xa
+
+
+@functools.lru_cache(maxsize=None)
+def lgl_error_tables(K: int):
+    """One LGL interval with one more point (reference: lobatto/discretization.py:255-305): V (K+1)xK for states
+    and controls, T KxK = values at the first K augmented nodes - value at +1, I = I_lgl(K+1) (K x (K+1))."""
+    x, _ = lgl_nodes_weights(K)
+    xa, _ = lgl_nodes_weights(K + 1)
+    V = _lagrange_matrix(x, xa)
+    T = V[:-1].copy()
+    T[:, K - 1] -= 1.0
+    return V, V, T, lgl_integration_matrix(K + 1), xa

@@ -11,6 +11,7 @@ is copied: only inputs (x, lambda, sigma) and the outputs of its NLP callbacks a
 
 Outputs (committed):
   tests/golden/small/<case>.npz     full callback vectors for the small cases of tests/models.py
+  tests/golden/error/<case>.npz     mesh error estimation data, per-interval verdicts and refined meshes
   tests/golden/tables.npz           xw_lgr/I_lgr/xw_lgl/I_lgl for K = 1..12
   tests/golden/full.json            sizes, structure hashes, checksums and strided samples for the
                                     BASELINE.json configs at full size   (--full; takes minutes)
@@ -89,6 +90,30 @@ def small_case(name):
     return out
 
 
+def error_case(name):
+    """Mesh error estimation + continuous refinement of the reference on the small case's evaluation point
+    (phasebase.py:1339-1437,1522-1617): per phase T_x_aug, I_f_aug, the per-interval verdicts and the refined
+    mesh for two tolerance settings."""
+    builder, scheme, kw = models.ERROR_CASES[name]
+    system, phases, guess = builder(NS[scheme], **kw)
+    x, _, _ = models.bench_inputs(system, guess)
+    s = x[system.l_s: system.r_s].copy()
+    out = {"x": x}
+    for k, p in enumerate(phases):
+        xp = x[system.l_p[k]: system.r_p[k]].copy()
+        T, I = p._error_estimation_data_continuous(xp.copy(), s.copy())
+        out[f"T_{k}"], out[f"I_{k}"] = T, I
+        for tag, (atol, rtol) in (("a", (1e-3, 1e-3)), ("b", (1e-7, 1e-6))):
+            out[f"ok_{tag}_{k}"] = p._error_check_interval_continuous(T, I, atol, rtol, 1e-4)
+            var = NS[scheme].Variable(p, xp.copy())
+            mesh0, K0 = p._mesh.copy(), p._num_point.copy()
+            p.refine_continuous(var, s.copy() if len(s) else None, atol, rtol, num_point_min=3, num_point_max=7,
+                                mesh_length_min=1e-3, mesh_length_max=1.0)
+            out[f"mesh_{tag}_{k}"], out[f"K_{tag}_{k}"] = p._mesh.copy(), p._num_point.copy()
+            p.set_discretization(mesh0, K0)          # restore
+    return out
+
+
 def sha(a):
     return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
 
@@ -143,6 +168,13 @@ def main():
         np.savez_compressed(os.path.join(HERE, "small", name + ".npz"), **out)
         print(f"{name:24s} n={int(out['n']):5d} m={int(out['m']):5d} "
               f"nnzJ={len(out['J']):6d} nnzH={len(out['H']):6d}")
+
+    os.makedirs(os.path.join(HERE, "error"), exist_ok=True)
+    for name in models.ERROR_CASES:
+        if args.only and args.only not in name:
+            continue
+        np.savez_compressed(os.path.join(HERE, "error", name + ".npz"), **error_case(name))
+        print("error-estimation fixture", name)
 
     tabs = {}
     for K in range(1, 13):

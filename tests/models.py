@@ -449,6 +449,14 @@ SMALL_CASES = {
     "humanoid_lgl_2x4": (humanoid_wbc, "lobatto", dict(mesh=2, num_point=4)),
 }
 
+# mesh error estimation / continuous refinement fixtures (K >= 2 everywhere: the reference's refinement
+# formula divides by log(K), phasebase.py:1579-1587)
+ERROR_CASES = {k: SMALL_CASES[k] for k in (
+    "brach_lgr_3x4", "brach_lgl_3x4", "quad_lgr_3x4", "quad_lgl_4x5", "rocket_lgr_3x4", "rocket_lgl_3x3",
+    "humanoid_lgr_2x3", "humanoid_lgl_2x4", "worked_lgr", "lqr_lgl_10x10")}
+ERROR_CASES["brach_lgr_hp"] = (brachistochrone, "radau", dict(mesh=[0, 0.2, 0.5, 1.0], num_point=[3, 2, 6]))
+ERROR_CASES["rocket_lgl_hp"] = (two_stage_rocket, "lobatto", dict(mesh=[0, 0.3, 0.4, 1.0], num_point=[4, 2, 5]))
+
 # BASELINE.json configs (model re-meshed on LGR) + the exact-10k supplemental.
 FULL_CASES = {
     "C2_brach_lgr_200x8": (brachistochrone, "radau", dict(mesh=200, num_point=8)),

@@ -103,3 +103,29 @@ def test_full_size_config_matches_reference_summary(name):
     check(system.constraints(x), gold["g"])
     check(system.jacobian(x), gold["J"])
     check(system.hessian(x, lam, sigma), gold["H"])
+
+
+@pytest.mark.parametrize("name", sorted(models.ERROR_CASES))
+def test_mesh_error_estimation_and_refinement_match_reference(name):
+    """T_x_aug / I_f_aug, per-interval verdicts and refined meshes of phasebase.py:1339-1437,1522-1617."""
+    from oracle import refine
+
+    builder, scheme, kw = models.ERROR_CASES[name]
+    gold = np.load(os.path.join(HERE, "golden", "error", name + ".npz"))
+    system, phases, _ = builder(NS[scheme], **kw)
+    system.prepare()
+    x = gold["x"]
+    s = x[system.l_s: system.r_s]
+    for k, p in enumerate(phases):
+        xp = x[system.l_p[k]: system.r_p[k]]
+        T, I = refine.error_data(p, xp, s)
+        close(T, gold[f"T_{k}"], 1e-13)
+        close(I, gold[f"I_{k}"], 1e-13)
+        for tag, (atol, rtol) in (("a", (1e-3, 1e-3)), ("b", (1e-7, 1e-6))):
+            assert np.array_equal(refine.check_intervals(p, T, I, atol, rtol, 1e-4), gold[f"ok_{tag}_{k}"])
+            mesh0, K0 = p._mesh.copy(), p._num_point.copy()
+            p.refine_continuous(NS[scheme].Variable(p, xp.copy()), s if len(s) else None, atol, rtol, num_point_min=3,
+                                num_point_max=7, mesh_length_min=1e-3, mesh_length_max=1.0)
+            assert np.allclose(p._mesh, gold[f"mesh_{tag}_{k}"], rtol=0, atol=1e-15)
+            assert np.array_equal(p._num_point, gold[f"K_{tag}_{k}"])
+            p.set_discretization(mesh0, K0)
