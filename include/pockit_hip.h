@@ -53,6 +53,7 @@ typedef struct pk_model_desc {
   int32_t lds_x;        /* LDS doubles per wave of the fused x-kernel (pk_xall)                   */
   int32_t ne_a;         /* scalar expressions of the auxiliary pass (outer-product Hessian path)  */
   int32_t ne_hc;        /* scalar expressions of the compact Hessian                              */
+  int32_t lds_e;        /* LDS doubles per wave of the mesh error estimation kernel (pk_err)      */
 } pk_model_desc;
 
 /* One (model, mesh) instance: sizes plus the table blobs built by pockit_amd/evaluator.py.
@@ -131,6 +132,20 @@ int pk_host_buffer(pk_ctx* ctx, int what, double** ptr, int64_t* count);
 int pk_eval_hessc(pk_ctx* ctx, const double* x, const double* lambda, double sigma, double* vals /* nnz_Hc */);
 int pk_eval_hessc_dev(pk_ctx* ctx, const double* d_x, const double* d_lambda, double sigma, double* d_vals,
                       void* stream);
+
+/* Mesh error estimation (reference: phasebase.py:1339-1372
+ * _error_estimation_data_continuous, called by check_continuous / refine_continuous, phasebase.py:1374-1437,
+ * 1522-1617): every mesh interval is re-collocated with one more point; the kernel (pk_err, one wavefront per
+ * interval) interpolates states/controls to the augmented nodes, evaluates the dynamics there and returns both
+ * sides of the integral-form collocation equation,  T = T_aug x  and  I = dt (I_aug d/2) f, per phase as
+ * [n_x][rows] (rows = sum_j (K_j + 1) for LGR, sum_j K_j for LGL).  The per-interval comparison and the
+ * hp-refinement decision are host logic (pockit_amd/refine.py).
+ * ``intervals``: array of PkErrIv (csrc/pk_abi.h), padded per phase to a multiple of 4 records with K = 0;
+ * ``tables``: the interpolation / translation / integration blocks they index; ``n_out``: doubles per output. */
+int pk_set_mesh_error_tables(pk_ctx* ctx, const void* intervals, int32_t n_intervals, const double* tables,
+                             int64_t n_tables, int64_t n_out);
+int pk_eval_mesh_error(pk_ctx* ctx, const double* x, double* T /* n_out */, double* I /* n_out */);
+int pk_eval_mesh_error_dev(pk_ctx* ctx, const double* d_x, double* d_T, double* d_I, void* stream);
 
 /* device-pointer API: enqueue on ``stream`` (hipStream_t, NULL = context stream), no sync */
 int pk_eval_f_dev(pk_ctx* ctx, const double* d_x, double* d_f, void* stream);

@@ -337,8 +337,13 @@ class ModelSource:
         self.lds_h = 64 * max([1] + [sum(1 for sg in plan.hess.segs[k] if sg.kind == "I") for k in range(nP)])
         self.lds_x = 64 * max([1] + [pp.nx + sum(1 for sg in plan.jac.segs[k] if sg.kind == "I")
                                      for k, pp in enumerate(plan.phase_plans)])
+        self.lds_e = 64 * max([1] + [2 * pp.nx + pp.nu for pp in plan.phase_plans])
         S.append(f"  static constexpr int LDS_G = {self.lds_g}, LDS_J = {self.lds_j}, LDS_H = {self.lds_h}, "
-                 f"LDS_X = {self.lds_x};")
+                 f"LDS_X = {self.lds_x}, LDS_E = {self.lds_e};")
+        S.append("  __device__ static __forceinline__ void interval_err(int phase, const PkArgs& A, const PkErrIv& iv, "
+                 "bool valid, double* __restrict__ lds, int lane) {")
+        S.append(switch("pk::interval_err<{P}>(A, iv, valid, lds, lane)"))
+        S.append("  }")
         for name in ("int", "g", "grad", "jac", "hess", "xall", "aux", "hessc"):
             S.append(f"  __device__ static __forceinline__ void tile_{name}(int phase, const PkArgs& A, const PkTile& tl, "
                      f"double* __restrict__ lds, double* __restrict__ wint, double* __restrict__ wgrad, int lane) {{")

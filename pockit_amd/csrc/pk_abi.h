@@ -88,6 +88,24 @@ struct PkOuter {
   int32_t count, pad;
 };
 
+// One mesh interval of the error-estimation pass (pk_err): the interval is re-collocated with K + 1
+// points (reference: phasebase.py:1339-1372).  Offsets index the error-table blob `errdb`:
+//   tab_off -> [V_x (K+1) x ncx | V_u (K+1) x K | T nr x ncx | I nr x (K+1)]   (row-major, unit interval)
+//   tau_off -> position in [0, 1] of the K + 1 augmented nodes of this interval
+// with ncx = K + 1, nr = K + 1 (LGR) or ncx = nr = K (LGL).
+struct PkErrIv {
+  int32_t phase;
+  int32_t K;
+  int32_t lm;          // first node of the interval (state / control slot)
+  int32_t row0;        // first output row (within a state)
+  int32_t tab_off;
+  int32_t tau_off;
+  int32_t rows;        // output rows per state of the phase
+  int32_t pad;
+  int64_t out_off;     // start of the phase in the two output arrays ([n_x][rows] each)
+  double width;        // interval width (fraction of the phase)
+};
+
 #define PK_MAX_PHASES 8
 
 struct PkArgs {
@@ -111,6 +129,10 @@ struct PkArgs {
   double* Ibuf;           // integrals I_k (pre-pass result)
   double* partial;        // [workgroups][PK_NRED] per-workgroup partial sums of the integrands
   double* partial2;       // [workgroups][PK_NRED] per-workgroup partial sums of the shared gradient slots
+  const PkErrIv* erriv;   // mesh error estimation (pk_err only)
+  const double* errdb;
+  double* o_errT;         // T_aug x      per phase [n_x][rows]
+  double* o_errI;         // dt I_aug f   per phase [n_x][rows]
   int32_t n_tiles, n_items;
   int32_t n_phase, n;
   int32_t l_s, n_s, n_sys, m;
@@ -118,5 +140,6 @@ struct PkArgs {
   int32_t flags;          // bit 0: pk_fin writes f; bit 1: secondary shard (no system-level / boundary work);
                           // bit 3: pk_fin reduces the integrals into Ibuf; bit 4: pk_fin reduces the gradient slots
   int32_t n_outer;
+  int32_t n_erriv;
   PkPhase ph[PK_MAX_PHASES];   // the phases by value (kernarg segment): no dependent global load
 };

@@ -700,6 +700,106 @@ __device__ __forceinline__ void kernel_aux(const PkArgs& A) {
   Gen::tile_aux(tl.phase, A, tl, pk_lds, wint, wgrad, lane);
 }
 
+
+// ---- mesh error estimation (reference: phasebase.py:1339-1372  _error_estimation_data_continuous) -----
+// One wavefront per mesh interval.  The interval's K (+1) state values and K control values are
+// staged in LDS, interpolated to the K + 1 nodes of the augmented rule (lane = augmented node), the
+// dynamics are evaluated there, and the two sides of the integral-form collocation equation on the
+// augmented rule are written out:  T_aug x  and  dt (I_aug d/2) f.  The host compares them per
+// interval (np.allclose semantics) and runs the hp-refinement logic (pockit_amd/refine.py).
+// LDS per wave: (2 NX + NU) x 64 doubles.  Barriers are unconditional; loads/stores are predicated.
+template <class P>
+__device__ __forceinline__ void interval_err(const PkArgs& A, const PkErrIv& iv, bool valid,
+                                             double* __restrict__ lds, int lane) {
+  const PkPhase& ph = A.ph[P::INDEX];
+  double s[PK_NS], dt, mt;
+  phase_scalars<P>(A, ph, s, dt, mt);
+  const int K = iv.K;
+  const int ncx = K + 1 - P::SCHEME, na = K + 1, nr = K + 1 - P::SCHEME;
+  const double* __restrict__ Vx = A.errdb + iv.tab_off;
+  const double* __restrict__ Vu = Vx + na * ncx;
+  const double* __restrict__ Tm = Vu + na * K;
+  const double* __restrict__ Im = Tm + nr * ncx;
+  const double* __restrict__ xp = A.x + ph.x_off;
+  const double* __restrict__ up = xp + P::NX * ph.state_len;
+  const int back_slot = P::SCHEME ? ph.L_m - 1 : ph.L_m;
+  double* __restrict__ xs = lds;
+  double* __restrict__ us = lds + P::NX * PK_WAVE;
+  double* __restrict__ fs = lds + (P::NX + P::NU) * PK_WAVE;
+  if (valid && lane < ncx) {
+    const int slot = iv.lm + lane;
+#pragma unroll
+    for (int i = 0; i < P::NX; ++i) {
+      double v = xp[i * ph.state_len + slot];
+      if (slot == 0) v = P::front_value(i, v, s);
+      if (slot == back_slot) v = P::back_value(i, v, s);
+      xs[i * PK_WAVE + lane] = v;
+    }
+  }
+  if (valid && lane < K) {
+#pragma unroll
+    for (int i = 0; i < P::NU; ++i) us[i * PK_WAVE + lane] = up[i * ph.L_m + iv.lm + lane];
+  }
+  __syncthreads();
+  if (valid && lane < na) {
+    double a[P::NARG], o[P::G_NOUT];
+#pragma unroll
+    for (int i = 0; i < P::NX; ++i) a[i] = 0.0;
+#pragma unroll
+    for (int i = 0; i < P::NU; ++i) a[P::NX + i] = 0.0;
+    for (int c = 0; c < ncx; ++c) {
+      const double v = Vx[lane * ncx + c];
+#pragma unroll
+      for (int i = 0; i < P::NX; ++i) a[i] += v * xs[i * PK_WAVE + c];
+    }
+    for (int c = 0; c < K; ++c) {
+      const double v = Vu[lane * K + c];
+#pragma unroll
+      for (int i = 0; i < P::NU; ++i) a[P::NX + i] += v * us[i * PK_WAVE + c];
+    }
+    const double tau = A.errdb[iv.tau_off + lane];
+    a[P::NX + P::NU] = (tau - 0.5) * dt + mt;
+#pragma unroll
+    for (int i = 0; i < P::NS; ++i) a[P::NX + P::NU + 1 + i] = s[i];
+    P::mid_g(a, o);
+#pragma unroll
+    for (int i = 0; i < P::NX; ++i) fs[i * PK_WAVE + lane] = o[i];
+  }
+  __syncthreads();
+  if (valid && lane < nr) {
+    double tx[P::NX], itf[P::NX];
+#pragma unroll
+    for (int i = 0; i < P::NX; ++i) tx[i] = itf[i] = 0.0;
+    for (int c = 0; c < ncx; ++c) {
+      const double v = Tm[lane * ncx + c];
+#pragma unroll
+      for (int i = 0; i < P::NX; ++i) tx[i] += v * xs[i * PK_WAVE + c];
+    }
+    for (int c = 0; c < na; ++c) {
+      const double v = Im[lane * na + c] * iv.width * 0.5;
+#pragma unroll
+      for (int i = 0; i < P::NX; ++i) itf[i] += v * fs[i * PK_WAVE + c];
+    }
+#pragma unroll
+    for (int i = 0; i < P::NX; ++i) {
+      const int64_t pos = iv.out_off + (int64_t)i * iv.rows + iv.row0 + lane;
+      A.o_errT[pos] = tx[i];
+      A.o_errI[pos] = itf[i] * dt;
+    }
+  }
+}
+
+template <class Gen>
+__device__ __forceinline__ void kernel_err(const PkArgs& A) {
+  extern __shared__ double pk_lds[];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int g = (int)blockIdx.x * PK_WAVES_PER_BLOCK + wave;
+  const bool valid = g < A.n_erriv;
+  // a workgroup never mixes phases (the host pads every phase to a multiple of 4 intervals with K = 0 records)
+  const PkErrIv iv = A.erriv[valid ? g : (A.n_erriv > 0 ? A.n_erriv - 1 : 0)];
+  Gen::interval_err(iv.phase, A, iv, valid && iv.K > 0, pk_lds + wave * Gen::LDS_E, lane);
+}
+
 // One workgroup per outer-product block (generic, table driven; O(n^2) outputs exist only for
 // objectives / system constraints that are nonlinear in the integrals -- small problems in practice).
 __device__ __forceinline__ void kernel_outer(const PkArgs& A) {
@@ -817,4 +917,5 @@ __device__ __forceinline__ void kernel_fin(const PkArgs& A) {
   extern "C" __global__ __launch_bounds__(PK_BLOCK) void pk_xall(PkArgs A) { pk::kernel_xall<GEN>(A); } \
   extern "C" __global__ __launch_bounds__(PK_BLOCK) void pk_aux(PkArgs A) { pk::kernel_aux<GEN>(A); }   \
   extern "C" __global__ __launch_bounds__(PK_BLOCK) void pk_outer(PkArgs A) { pk::kernel_outer(A); }     \
-  extern "C" __global__ __launch_bounds__(PK_BLOCK) void pk_hessc(PkArgs A) { pk::kernel_hessc<GEN>(A); }
+  extern "C" __global__ __launch_bounds__(PK_BLOCK) void pk_hessc(PkArgs A) { pk::kernel_hessc<GEN>(A); } \
+  extern "C" __global__ __launch_bounds__(PK_BLOCK) void pk_err(PkArgs A) { pk::kernel_err<GEN>(A); }

@@ -31,9 +31,9 @@
 
 namespace {
 
-enum { K_INT = 0, K_FIN, K_G, K_GRAD, K_JAC, K_HESS, K_XALL, K_AUX, K_OUTER, K_HESSC, K_COUNT };
+enum { K_INT = 0, K_FIN, K_G, K_GRAD, K_JAC, K_HESS, K_XALL, K_AUX, K_OUTER, K_HESSC, K_ERR, K_COUNT };
 const char* const kKernelNames[K_COUNT] = {"pk_int", "pk_fin", "pk_g", "pk_grad", "pk_jac", "pk_hess", "pk_xall",
-                                           "pk_aux", "pk_outer", "pk_hessc"};
+                                           "pk_aux", "pk_outer", "pk_hessc", "pk_err"};
 enum { F_WRITE_F = 1, F_SECONDARY = 2, F_FIN_INT = 8, F_FIN_GRAD = 16 };
 
 thread_local std::string g_create_error;
@@ -65,6 +65,11 @@ struct pk_ctx {
   void *d_phases = nullptr, *d_tiles = nullptr, *d_kinds = nullptr, *d_items_jac = nullptr, *d_items_hess = nullptr,
        *d_items_aux = nullptr, *d_outer = nullptr, *d_items_hessc = nullptr;
   double *d_aux = nullptr, *d_Hc = nullptr;
+  // mesh error estimation (pk_set_mesh_error_tables)
+  void* d_erriv = nullptr;
+  double *d_errdb = nullptr, *d_errT = nullptr, *d_errI = nullptr;
+  int32_t n_erriv = 0;
+  int64_t n_err_out = 0;
   int32_t* d_ib = nullptr;
   double* d_db = nullptr;
   int64_t* d_lb = nullptr;
@@ -110,6 +115,8 @@ void release(T*& p) {
 
 void free_problem(pk_ctx* c) {
   release(c->d_phases); release(c->d_tiles); release(c->d_kinds); release(c->d_items_jac); release(c->d_items_hess); release(c->d_items_aux); release(c->d_outer); release(c->d_aux); release(c->d_items_hessc); release(c->d_Hc);
+  release(c->d_erriv); release(c->d_errdb); release(c->d_errT); release(c->d_errI);
+  c->n_erriv = 0; c->n_err_out = 0;
   release(c->d_ib); release(c->d_db); release(c->d_lb);
   release(c->d_x); release(c->d_lam); release(c->d_f); release(c->d_grad); release(c->d_g); release(c->d_J);
   release(c->d_H); release(c->d_I); release(c->d_partial); release(c->d_partial2);
@@ -429,6 +436,73 @@ int pk_eval_hessc_dev(pk_ctx* c, const double* d_x, const double* d_lam, double 
   A.items = (const PkItem*)c->d_items_hessc;
   A.n_items = c->n_items_hessc;
   return launch(c, K_HESSC, A, tile_blocks(c) + 1, sizeof(double) * (size_t)(c->md.ne_hc > 0 ? c->md.ne_hc : 1), st);
+}
+
+// ---------------------------------------------------------------- mesh error estimation
+int pk_set_mesh_error_tables(pk_ctx* c, const void* intervals, int32_t n_intervals, const double* tables,
+                             int64_t n_tables, int64_t n_out) {
+  int rc = ready(c);
+  if (rc) return rc;
+  if (!intervals || n_intervals <= 0 || !tables || n_tables <= 0 || n_out <= 0)
+    return fail(c, 70, "pk_set_mesh_error_tables: empty tables");
+  if (n_intervals % PK_WAVES_PER_BLOCK)
+    return fail(c, 71, "pk_set_mesh_error_tables: interval records must be padded to a multiple of %d per phase", PK_WAVES_PER_BLOCK);
+  if ((size_t)c->md.lds_e * PK_WAVES_PER_BLOCK * sizeof(double) > 160 * 1024)
+    return fail(c, 72, "pk_set_mesh_error_tables: model needs more than 160 KiB of LDS per workgroup");
+  // host-side validation of everything the kernel indexes with (a faulting kernel can take the node down)
+  const PkErrIv* iv = (const PkErrIv*)intervals;
+  for (int32_t g = 0; g < n_intervals; ++g) {
+    const PkErrIv& r = iv[g];
+    if (r.phase < 0 || r.phase >= c->n_phase) return fail(c, 73, "pk_set_mesh_error_tables: record %d: bad phase", g);
+    if (r.K == 0) continue;   // padding
+    const PkPhase& ph = c->h_phases[r.phase];
+    const int na = r.K + 1, ncx = r.K + 1 - ph.scheme, nr = ncx;
+    const int64_t tab = (int64_t)na * ncx + (int64_t)na * r.K + (int64_t)nr * ncx + (int64_t)nr * na;
+    if (r.K < 1 || na > PK_WAVE || r.lm < 0 || r.lm + ncx > ph.state_len || r.lm + r.K > ph.L_m || r.tab_off < 0 ||
+        r.tab_off + tab > n_tables || r.tau_off < 0 || r.tau_off + na > n_tables || r.row0 < 0 || r.row0 + nr > r.rows ||
+        r.out_off < 0 || r.out_off + (int64_t)ph.n_x * r.rows > n_out)
+      return fail(c, 74, "pk_set_mesh_error_tables: record %d is inconsistent with the problem", g);
+  }
+  PK_HIP(c, hipSetDevice(c->device));
+  PK_HIP(c, hipStreamSynchronize(c->stream));
+  release(c->d_erriv); release(c->d_errdb); release(c->d_errT); release(c->d_errI);
+  c->n_erriv = 0; c->n_err_out = 0;
+  if ((rc = upload(c, &c->d_erriv, intervals, sizeof(PkErrIv) * (size_t)n_intervals))) return rc;
+  if ((rc = upload(c, (void**)&c->d_errdb, tables, sizeof(double) * (size_t)n_tables))) return rc;
+  PK_HIP(c, hipMalloc((void**)&c->d_errT, sizeof(double) * (size_t)n_out));
+  PK_HIP(c, hipMalloc((void**)&c->d_errI, sizeof(double) * (size_t)n_out));
+  PK_HIP(c, hipMemset(c->d_errT, 0, sizeof(double) * (size_t)n_out));
+  PK_HIP(c, hipMemset(c->d_errI, 0, sizeof(double) * (size_t)n_out));
+  c->n_erriv = n_intervals;
+  c->n_err_out = n_out;
+  return 0;
+}
+
+int pk_eval_mesh_error_dev(pk_ctx* c, const double* d_x, double* d_T, double* d_I, void* stream) {
+  int rc = ready(c);
+  if (rc) return rc;
+  if (c->n_erriv <= 0) return fail(c, 75, "pk_eval_mesh_error: call pk_set_mesh_error_tables first");
+  PkArgs A = base_args(c, d_x, nullptr, 0.0);
+  A.erriv = (const PkErrIv*)c->d_erriv;
+  A.errdb = c->d_errdb;
+  A.n_erriv = c->n_erriv;
+  A.o_errT = d_T;
+  A.o_errI = d_I;
+  return launch(c, K_ERR, A, (unsigned)(c->n_erriv / PK_WAVES_PER_BLOCK),
+                sizeof(double) * PK_WAVES_PER_BLOCK * (size_t)c->md.lds_e, pick(c, stream));
+}
+
+int pk_eval_mesh_error(pk_ctx* c, const double* x, double* T, double* I) {
+  int rc = ready(c);
+  if (rc) return rc;
+  if (!x || !T || !I) return fail(c, 60, "null host buffer");
+  PK_HIP(c, hipSetDevice(c->device));
+  PK_HIP(c, hipMemcpyAsync(c->d_x, x, sizeof(double) * (size_t)c->n, hipMemcpyHostToDevice, c->stream));
+  if ((rc = pk_eval_mesh_error_dev(c, c->d_x, c->d_errT, c->d_errI, nullptr))) return rc;
+  PK_HIP(c, hipMemcpyAsync(T, c->d_errT, sizeof(double) * (size_t)c->n_err_out, hipMemcpyDeviceToHost, c->stream));
+  PK_HIP(c, hipMemcpyAsync(I, c->d_errI, sizeof(double) * (size_t)c->n_err_out, hipMemcpyDeviceToHost, c->stream));
+  PK_HIP(c, hipStreamSynchronize(c->stream));
+  return 0;
 }
 
 int pk_eval_hessc(pk_ctx* c, const double* x, const double* lambda, double sigma, double* vals) {

@@ -157,6 +157,8 @@ class Evaluator:
         md.ne_j, md.ne_h = self.src.list_off["jac"]["total"], self.src.list_off["hess"]["total"]
         md.ne_a = self.src.list_off["aux"]["total"]
         md.ne_hc = self.src.list_off["hessc"]["total"] if self.src.compact else 0
+        md.lds_e = self.src.lds_e
+        self._err_views = None
         md.prepass_f = 1
         md.prepass_grad = int(plan.needs_I_grad)
         md.prepass_g = int(plan.needs_I_con)
@@ -307,6 +309,24 @@ class Evaluator:
         self.ctx.check(self.ctx.lib.pk_eval_hessc(self.ctx.handle, runtime.as_dp(x), runtime.as_dp(lam),
                                                   float(obj_factor), runtime.as_dp(out)))
         return out
+
+    def mesh_error(self, x):
+        """Mesh error estimation data of every phase at the NLP point ``x`` (one pk_err launch): a list of
+        ``(T, I)`` with shape (n_x, rows) each -- the two sides of the collocation equation on every interval
+        re-collocated with one more point (reference: phasebase.py:1339-1372)."""
+        from . import refine
+
+        lib, h = self.ctx.lib, self.ctx.handle
+        if self._err_views is None:
+            recs, tables, n_out, views = refine.error_tables(self.plan)
+            self.ctx.check(lib.pk_set_mesh_error_tables(h, recs.ctypes.data, len(recs), runtime.as_dp(tables),
+                                                        len(tables), n_out))
+            self._err_views, self._err_len = views, n_out
+        x = self._x(x)
+        T, I = np.empty(self._err_len), np.empty(self._err_len)
+        self.ctx.check(lib.pk_eval_mesh_error(h, runtime.as_dp(x), runtime.as_dp(T), runtime.as_dp(I)))
+        return [(T[o: o + nx * rows].reshape(nx, rows), I[o: o + nx * rows].reshape(nx, rows))
+                for o, nx, rows in self._err_views]
 
     def cycle(self, x, lagrange, obj_factor):
         """All five outputs on the same x from the fused path (pk_xall + pk_fin + pk_hess):

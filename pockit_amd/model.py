@@ -14,6 +14,7 @@ Symbol naming (``name^{(id)}``, ``t^{(id)}``, ``I_k^{(id)}``) follows phasebase.
 """
 from __future__ import annotations
 
+import weakref
 from typing import Iterable, Optional
 
 import numpy as np
@@ -181,6 +182,69 @@ class PhaseBase:
         self._discretization_set = True
         return self._changed()
 
+    # ------------------------------------------------------------------ mesh error check / refinement
+    # (reference: phasebase.py:1374-1437 check_continuous, 1522-1617 refine_continuous).  The error data come from
+    # the GPU evaluator of the system the phase belongs to (pk_err); the decision logic is pockit_amd/refine.py.
+    def _owner(self):
+        system = self._system() if getattr(self, "_system", None) is not None else None
+        if system is None:
+            raise ValueError("the phase must be part of a System (System.set_phase) before its mesh error can be "
+                             "evaluated: the evaluator lives at system level")
+        return system
+
+    def _substitute_boundary(self, data, s):
+        """Write the FIXED / FUNC boundary values and times into ``data`` in place (the reference does this to the
+        caller's array whenever it evaluates a phase, phasebase.py:839-851; ``refine_continuous`` then adapts the
+        substituted values)."""
+        lay = self.layout
+        for i in range(self.n_x):
+            data[lay.l_v[i]] = self._value_boundary_condition(self.info_bc_0[i], data[lay.l_v[i]], s)
+            data[lay.r_v[i] - 1] = self._value_boundary_condition(self.info_bc_f[i], data[lay.r_v[i] - 1], s)
+        data[-2] = self._value_boundary_condition(self.info_t_0, data[-2], s)
+        data[-1] = self._value_boundary_condition(self.info_t_f, data[-1], s)
+
+    def _error_data(self, variable, static_parameter):
+        if self.n_s and static_parameter is None:
+            raise ValueError("phase has static parameters, but the value of static parameters is not given")
+        self._substitute_boundary(variable.data, [] if static_parameter is None else list(static_parameter))
+        system = self._owner()
+        k = next(i for i, p in enumerate(system.p) if p is self)
+        plan = system.plan
+        x = np.zeros(plan.n)
+        for i, p in enumerate(system.p):        # other phases: any finite point on their own time axis
+            x[plan.r_p[i] - 1] = 1.0
+        x[plan.l_p[k]: plan.r_p[k]] = variable.data
+        if self.n_s:
+            x[plan.l_s: plan.r_s] = np.asarray(list(static_parameter), dtype=np.float64)
+        return system.evaluator.mesh_error(x)[k]
+
+    def check_continuous(self, variable, static_parameter=None, absolute_tolerance_continuous=1.0e-8,
+                         relative_tolerance_continuous=1.0e-8, tolerance_mesh=1.0e-4) -> bool:
+        from . import refine
+
+        T, I = self._error_data(variable, static_parameter)
+        return bool(np.all(refine.interval_ok(self.layout, T, I, absolute_tolerance_continuous,
+                                              relative_tolerance_continuous, tolerance_mesh)))
+
+    def _refine_from(self, T, I, atol, rtol, num_point_min, num_point_max, mesh_length_min, mesh_length_max):
+        from . import refine
+
+        ok = refine.interval_ok(self.layout, T, I, atol, rtol, mesh_length_min)
+        if np.all(ok):
+            return
+        mesh, num_point = refine.refined_discretization(self.layout, T, I, ok, rtol, num_point_min, num_point_max,
+                                                        mesh_length_min, mesh_length_max)
+        self.set_discretization(mesh, num_point)
+
+    def refine_continuous(self, variable, static_parameter=None, absolute_tolerance_continuous=1.0e-8,
+                          relative_tolerance_continuous=1.0e-8, num_point_min=6, num_point_max=12,
+                          mesh_length_min=1.0e-3, mesh_length_max=1.0) -> None:
+        """Adjust mesh and interpolation degrees in place (call ``System.update()`` afterwards, as with the
+        reference)."""
+        T, I = self._error_data(variable, static_parameter)
+        self._refine_from(T, I, absolute_tolerance_continuous, relative_tolerance_continuous, num_point_min,
+                          num_point_max, mesh_length_min, mesh_length_max)
+
     # ------------------------------------------------------------------ read-only views
     n_x = property(lambda self: len(self._symbol_state))
     n_u = property(lambda self: len(self._symbol_control))
@@ -291,6 +355,8 @@ class SystemBase:
                 raise ValueError(
                     f"Dynamics, boundary conditions, or discretization scheme of phase {i} are not fully set")
         self._phase = list(phase)
+        for p in self._phase:
+            p._system = weakref.ref(self)
         self._phase_set = True
         return self._invalidate()
 
@@ -425,3 +491,63 @@ class SystemBase:
         if self._hessian_layout == "compact":
             return self.evaluator.hessian_compact(x, fct_c, 0.0)
         return self.evaluator.hessian(x, fct_c, 0.0)[self.plan.nnz_H_obj:]
+
+    # ------------------------------------------------------------------ mesh error check / refinement
+    # (reference: systembase.py:837-889 check_continuous, 982-1069 refine_continuous)
+    def _split_value(self, value):
+        from .variable import Variable
+
+        if not self.ok:
+            raise ValueError("system is not fully configured")
+        single = isinstance(value, Variable)
+        if single:
+            value = [value]
+        if not self.n_s and len(value) != self.n_p:
+            raise ValueError("len(value) must be equal to the number of phases")
+        if self.n_s and len(value) != self.n_p + 1:
+            raise ValueError("len(value) must be equal to the number of phases + 1 (for static variables)")
+        return list(value), single
+
+    def _mesh_error(self, value):
+        plan = self.plan
+        x = np.empty(plan.n)
+        s = [float(v) for v in value[-1]] if self.n_s else []
+        for k in range(self.n_p):
+            self._phase[k]._substitute_boundary(value[k].data, s)
+            x[plan.l_p[k]: plan.r_p[k]] = value[k].data
+        if self.n_s:
+            x[plan.l_s: plan.r_s] = np.array(list(value[-1]), dtype=np.float64)
+        return self.evaluator.mesh_error(x)
+
+    def check_continuous(self, value, absolute_tolerance_continuous=1.0e-8, relative_tolerance_continuous=1.0e-8,
+                         tolerance_mesh=1.0e-4) -> bool:
+        from . import refine
+
+        value, _ = self._split_value(value)
+        data = self._mesh_error(value)
+        return all(bool(np.all(refine.interval_ok(p.layout, T, I, absolute_tolerance_continuous,
+                                                  relative_tolerance_continuous, tolerance_mesh)))
+                   for p, (T, I) in zip(self._phase, data))
+
+    def refine_continuous(self, value, absolute_tolerance_continuous=1.0e-8, relative_tolerance_continuous=1.0e-8,
+                          num_point_min=6, num_point_max=12, mesh_length_min=1.0e-3, mesh_length_max=1.0):
+        """One hp-refinement sweep over all phases from a single error-estimation launch; returns the values
+        interpolated onto the new discretization (the input itself when every interval already passes)."""
+        from . import refine
+
+        original = value
+        value, single = self._split_value(value)
+        data = self._mesh_error(value)
+        if all(bool(np.all(refine.interval_ok(p.layout, T, I, absolute_tolerance_continuous,
+                                              relative_tolerance_continuous, mesh_length_min)))
+               for p, (T, I) in zip(self._phase, data)):
+            return original
+        adapted = []
+        for p, v, (T, I) in zip(self._phase, value, data):
+            p._refine_from(T, I, absolute_tolerance_continuous, relative_tolerance_continuous, num_point_min,
+                           num_point_max, mesh_length_min, mesh_length_max)
+            adapted.append(v.adapt(p))
+        self.update()
+        if single:
+            return adapted[0]
+        return adapted + value[self.n_p:]

@@ -19,7 +19,7 @@ c_int32_p = C.POINTER(C.c_int32)
 class ModelDesc(C.Structure):
     _fields_ = [(n, C.c_int32) for n in
                 ("n_phase", "n_I", "nred", "lds_g", "lds_j", "lds_h", "ne_j", "ne_h", "prepass_f", "prepass_grad",
-                 "prepass_g", "prepass_jac", "prepass_hess", "lds_x", "ne_a", "ne_hc")]
+                 "prepass_g", "prepass_jac", "prepass_hess", "lds_x", "ne_a", "ne_hc", "lds_e")]
 
 
 class ProblemDesc(C.Structure):
@@ -54,15 +54,19 @@ KIND_DTYPE = np.dtype([(n, np.int32) for n in KIND_FIELDS])
 ITEM_DTYPE = np.dtype([("pos", np.int64), ("coef", np.float64), ("eid", np.int32), ("lam", np.int32)])
 OUTER_DTYPE = np.dtype([("pos", np.int64), ("offA", np.int32), ("lenA", np.int32), ("offB", np.int32), ("lenB", np.int32),
                         ("offM", np.int32), ("flags", np.int32), ("count", np.int32), ("pad", np.int32)])
+ERRIV_DTYPE = np.dtype([("phase", np.int32), ("K", np.int32), ("lm", np.int32), ("row0", np.int32),
+                        ("tab_off", np.int32), ("tau_off", np.int32), ("rows", np.int32), ("pad", np.int32),
+                        ("out_off", np.int64), ("width", np.float64)])
 
 WAVES_PER_BLOCK = 4  # PK_WAVES_PER_BLOCK of csrc/pk_abi.h
-KERNELS = ["pk_int", "pk_fin", "pk_g", "pk_grad", "pk_jac", "pk_hess", "pk_xall", "pk_aux", "pk_outer", "pk_hessc"]
+KERNELS = ["pk_int", "pk_fin", "pk_g", "pk_grad", "pk_jac", "pk_hess", "pk_xall", "pk_aux", "pk_outer", "pk_hessc", "pk_err"]
 EXPORTS = ["pk_create", "pk_destroy", "pk_last_error", "pk_device_count", "pk_load_model", "pk_set_problem",
            "pk_get_structure", "pk_eval_f", "pk_eval_grad", "pk_eval_g", "pk_eval_jac", "pk_eval_hess",
            "pk_eval_f_dev", "pk_eval_grad_dev", "pk_eval_g_dev", "pk_eval_jac_dev", "pk_eval_hess_dev",
            "pk_eval_cycle_dev", "pk_sync", "pk_profile", "pk_profile_read", "pk_kernel_name",
            "pk_set_shard", "pk_eval_integrals_dev", "pk_eval_f_from_integrals_dev", "pk_eval_cycle",
-           "pk_prepare_x", "pk_fetch", "pk_eval_hess_prepared", "pk_host_buffer", "pk_eval_hessc", "pk_eval_hessc_dev"]
+           "pk_prepare_x", "pk_fetch", "pk_eval_hess_prepared", "pk_host_buffer", "pk_eval_hessc", "pk_eval_hessc_dev",
+           "pk_set_mesh_error_tables", "pk_eval_mesh_error", "pk_eval_mesh_error_dev"]
 
 _lib = None
 
@@ -123,6 +127,9 @@ def load_library():
     lib.pk_host_buffer.argtypes = [vp, C.c_int, C.POINTER(dp), C.POINTER(C.c_int64)]
     lib.pk_eval_hessc.argtypes = [vp, dp, dp, C.c_double, dp]
     lib.pk_eval_hessc_dev.argtypes = [vp, vp, vp, C.c_double, vp, vp]
+    lib.pk_set_mesh_error_tables.argtypes = [vp, vp, C.c_int32, dp, C.c_int64, C.c_int64]
+    lib.pk_eval_mesh_error.argtypes = [vp, dp, dp, dp]
+    lib.pk_eval_mesh_error_dev.argtypes = [vp, vp, vp, vp, vp]
     lib.pk_eval_f_dev.argtypes = [vp, vp, vp, vp]
     lib.pk_eval_grad_dev.argtypes = [vp, vp, vp, vp]
     lib.pk_eval_g_dev.argtypes = [vp, vp, vp, vp]

@@ -103,6 +103,14 @@ def error_case(name):
         xp = x[system.l_p[k]: system.r_p[k]].copy()
         T, I = p._error_estimation_data_continuous(xp.copy(), s.copy())
         out[f"T_{k}"], out[f"I_{k}"] = T, I
+        # interpolation / differentiation matrices of the Variable at sample times that include interior mesh
+        # points once and twice (variablebase.py:137-317)
+        v0 = NS[scheme].Variable(p, xp.copy())
+        tm = v0.t_0 + p._mesh[1:-1] * (v0.t_f - v0.t_0)
+        t_out = np.sort(np.concatenate([np.linspace(v0.t_0, v0.t_f, 23), tm, tm[::2]]))
+        out[f"tout_{k}"] = t_out
+        for nm in ("V_x", "V_u", "D_x", "D_u"):
+            out[f"{nm}_{k}"] = getattr(v0, nm)(t_out.copy()).toarray()
         for tag, (atol, rtol) in (("a", (1e-3, 1e-3)), ("b", (1e-7, 1e-6))):
             out[f"ok_{tag}_{k}"] = p._error_check_interval_continuous(T, I, atol, rtol, 1e-4)
             var = NS[scheme].Variable(p, xp.copy())
@@ -110,6 +118,7 @@ def error_case(name):
             p.refine_continuous(var, s.copy() if len(s) else None, atol, rtol, num_point_min=3, num_point_max=7,
                                 mesh_length_min=1e-3, mesh_length_max=1.0)
             out[f"mesh_{tag}_{k}"], out[f"K_{tag}_{k}"] = p._mesh.copy(), p._num_point.copy()
+            out[f"adapt_{tag}_{k}"] = var.adapt(p).data.copy()     # variablebase.py:365-391
             p.set_discretization(mesh0, K0)          # restore
     return out
 

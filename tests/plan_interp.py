@@ -226,3 +226,47 @@ class Interp:
         for i, m in plan.grad_static.items():
             grad[plan.l_s + i] += self._eval_sys([m])[0]
         return grad
+
+
+def mesh_error(plan, x):
+    """NumPy execution of the error-estimation tables exactly as the device kernel pk_err decodes them
+    (csrc/pk_kernels.hip.h interval_err): per interval stage x/u, interpolate to the augmented nodes, evaluate the
+    dynamics, apply the T and I blocks.  Returns [(T, I)] per phase, shape (n_x, rows)."""
+    from pockit_amd import refine
+
+    it = Interp(plan, x)
+    recs, tab, n_out, views = refine.error_tables(plan)
+    outT, outI = np.zeros(n_out), np.zeros(n_out)
+    for rec in recs:
+        K = int(rec["K"])
+        if K == 0:
+            continue
+        k = int(rec["phase"])
+        pp, env = plan.phase_plans[k], it.ph[k]
+        p, lay = pp.phase, pp.layout
+        sch = 0 if lay.scheme == "lgr" else 1
+        ncx, na, nr = K + 1 - sch, K + 1, K + 1 - sch
+        o = int(rec["tab_off"])
+        Vx = tab[o: o + na * ncx].reshape(na, ncx); o += na * ncx
+        Vu = tab[o: o + na * K].reshape(na, K); o += na * K
+        Tm = tab[o: o + nr * ncx].reshape(nr, ncx); o += nr * ncx
+        Im = tab[o: o + nr * na].reshape(nr, na)
+        tau = tab[int(rec["tau_off"]): int(rec["tau_off"]) + na]
+        lm = int(rec["lm"])
+        xs = [env["xp"][lay.l_v[i] + lm: lay.l_v[i] + lm + ncx] for i in range(p.n_x)]
+        us = [env["xp"][lay.l_v[p.n_x + i] + lm: lay.l_v[p.n_x + i] + lm + K] for i in range(p.n_u)]
+        vals = {sym: Vx @ xs[i] for i, sym in enumerate(p.x)}
+        vals.update({sym: Vu @ us[i] for i, sym in enumerate(p.u)})
+        tm = (env["xp"][-1] + env["xp"][-2]) / 2
+        vals[p.t] = (tau - 0.5) * env["dt"] + tm
+        for sym, v in it.sdict.items():
+            vals[sym] = np.full(na, v)
+        syms = list(vals)
+        fn = sp.lambdify(syms, [sp.sympify(fr.F).subs(env["base"]) for fr in pp.dyn], modules="numpy")
+        f = [np.broadcast_to(np.asarray(v, dtype=np.float64), (na,)) for v in fn(*[vals[s_] for s_ in syms])]
+        for i in range(p.n_x):
+            pos = int(rec["out_off"]) + i * int(rec["rows"]) + int(rec["row0"])
+            outT[pos: pos + nr] = Tm @ xs[i]
+            outI[pos: pos + nr] = ((Im * rec["width"] * 0.5) @ f[i]) * env["dt"]
+    return [(outT[o: o + nx * rows].reshape(nx, rows), outI[o: o + nx * rows].reshape(nx, rows))
+            for o, nx, rows in views]

@@ -30,7 +30,29 @@ def test_struct_sizes_match_the_c_abi():
     assert runtime.KIND_DTYPE.itemsize == 8 * 4
     assert runtime.ITEM_DTYPE.itemsize == 24
     assert runtime.OUTER_DTYPE.itemsize == 40
-    assert C.sizeof(runtime.ModelDesc) == 16 * 4
+    assert runtime.ERRIV_DTYPE.itemsize == 48
+    assert C.sizeof(runtime.ModelDesc) == 17 * 4
+
+
+def test_numpy_mirrors_agree_with_the_compiled_structs(tmp_path):
+    """sizeof / offsetof of csrc/pk_abi.h and include/pockit_hip.h as g++ lays them out."""
+    import subprocess
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    src = tmp_path / "sizes.cpp"
+    src.write_text(
+        '#include <cstdio>\n#include <cstddef>\n#include "pockit_amd/csrc/pk_abi.h"\n#include "include/pockit_hip.h"\n'
+        'int main() { std::printf("%zu %zu %zu %zu %zu %zu %zu %zu %zu %zu\\n", sizeof(PkPhase), sizeof(PkTile), '
+        "sizeof(PkKind), sizeof(PkItem), sizeof(PkOuter), sizeof(PkErrIv), offsetof(PkErrIv, out_off), "
+        "offsetof(PkErrIv, width), sizeof(pk_model_desc), sizeof(pk_problem_desc)); }\n")
+    exe = tmp_path / "sizes"
+    subprocess.run(["g++", "-I", root, str(src), "-o", str(exe)], check=True)
+    got = [int(v) for v in subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.split()]
+    want = [runtime.PHASE_DTYPE.itemsize, runtime.TILE_DTYPE.itemsize, runtime.KIND_DTYPE.itemsize,
+            runtime.ITEM_DTYPE.itemsize, runtime.OUTER_DTYPE.itemsize, runtime.ERRIV_DTYPE.itemsize,
+            runtime.ERRIV_DTYPE.fields["out_off"][1], runtime.ERRIV_DTYPE.fields["width"][1],
+            C.sizeof(runtime.ModelDesc), C.sizeof(runtime.ProblemDesc)]
+    assert got == want
 
 
 def test_no_gpu_means_loud_failure():

@@ -252,3 +252,83 @@ def test_compact_hessian_equals_coalesced_oracle(case):
     assert (diff.max() if diff.nnz else 0.0) <= TOL * scale
     system.set_hessian_layout("reference")
     close(system.hessian(x, lam, sigma), ref.hessian(x, lam, sigma), what="reference layout still served")
+
+
+# ---------------------------------------------------------------------------------------------------------
+# mesh error estimation on device + hp-refinement
+ERR_TOLS = {"a": (1e-3, 1e-3), "b": (1e-7, 1e-6)}
+REFINE_KW = dict(num_point_min=3, num_point_max=7, mesh_length_min=1e-3, mesh_length_max=1.0)
+
+
+def _values(system, phases, ns, x):
+    plan = system.plan
+    value = [ns.Variable(p, x[plan.l_p[k]: plan.r_p[k]].copy()) for k, p in enumerate(phases)]
+    if system.n_s:
+        value.append(x[plan.l_s: plan.r_s].copy())
+    return value
+
+
+@pytest.mark.parametrize("name", sorted(models.ERROR_CASES))
+def test_mesh_error_kernel_matches_reference_golden(name):
+    """pk_err (T_aug x, dt I_aug f per interval) against the reference's _error_estimation_data_continuous, the
+    check against its verdicts, and one refine_continuous sweep (new mesh + adapted values) end to end."""
+    builder, scheme, kw = models.ERROR_CASES[name]
+    gold = np.load(os.path.join(HERE, "golden", "error", name + ".npz"))
+    ns = _ns(scheme, "pockit_amd")
+    system, phases, _ = builder(ns, **kw)
+    x = gold["x"]
+    data = system.evaluator.mesh_error(x)
+    for k, (T, I) in enumerate(data):
+        close(T, gold[f"T_{k}"], what=f"T phase {k}")
+        close(I, gold[f"I_{k}"], what=f"I phase {k}")
+    for tag, (atol, rtol) in ERR_TOLS.items():
+        expect = all(bool(np.all(gold[f"ok_{tag}_{k}"])) for k in range(len(phases)))
+        assert system.check_continuous(_values(system, phases, ns, x), atol, rtol, 1e-4) == expect
+        for k, p in enumerate(phases):      # phase-level entry point
+            s = x[system.plan.l_s: system.plan.r_s] if system.n_s else None
+            v = ns.Variable(p, x[system.plan.l_p[k]: system.plan.r_p[k]].copy())
+            assert p.check_continuous(v, s, atol, rtol, 1e-4) == bool(np.all(gold[f"ok_{tag}_{k}"]))
+    for tag, (atol, rtol) in ERR_TOLS.items():
+        system, phases, _ = builder(ns, **kw)
+        value = _values(system, phases, ns, x)
+        out = system.refine_continuous(value if len(value) > 1 else value[0], atol, rtol, **REFINE_KW)
+        changed = any(not np.array_equal(p._num_point, gold[f"K_{tag}_{k}"]) or len(p._mesh) != len(gold[f"mesh_{tag}_{k}"])
+                      for k, p in enumerate(phases))
+        assert not changed
+        if all(bool(np.all(gold[f"ok_{tag}_{k}"])) for k in range(len(phases))):
+            continue            # nothing to refine at this tolerance: the input is returned as is
+        out = out if isinstance(out, list) else [out]
+        for k, p in enumerate(phases):
+            assert np.allclose(p._mesh, gold[f"mesh_{tag}_{k}"], rtol=0, atol=1e-15)
+            close(out[k].data, gold[f"adapt_{tag}_{k}"], 1e-10, what=f"adapt {tag} phase {k}")
+        # the system is usable on the new discretization
+        x_new = np.concatenate([v.data for v in out[: len(phases)]] + ([np.asarray(out[-1])] if system.n_s else []))
+        assert len(x_new) == system.L and np.isfinite(system.objective(x_new))
+
+
+def test_mesh_error_full_size_matches_oracle():
+    """Quadrotor 2000 x 6 (LGR) and a ragged LGL hp mesh against the oracle's per-interval restatement."""
+    from oracle import refine as oref
+
+    rng = np.random.default_rng(11)
+    K = rng.integers(2, 12, size=57).tolist()
+    mesh = np.concatenate(([0.0], np.cumsum(rng.uniform(0.2, 1.0, size=57)))).tolist()
+    for builder, scheme, kw in ((models.planar_quadrotor, "radau", dict(mesh=2000, num_point=6)),
+                                (models.brachistochrone, "lobatto", dict(mesh=mesh, num_point=K)),
+                                (models.two_stage_rocket, "radau", dict(mesh=mesh, num_point=K))):
+        system, phases, guess = builder(_ns(scheme, "pockit_amd"), **kw)
+        ref, rphases, _ = builder(_ns(scheme, "oracle"), **kw)
+        ref.prepare()
+        x, _, _ = models.bench_inputs(system, guess)
+        data = system.evaluator.mesh_error(x)
+        s = x[ref.l_s: ref.r_s]
+        for k, rp in enumerate(rphases):
+            T, I = oref.error_data(rp, x[ref.l_p[k]: ref.r_p[k]].copy(), s)
+            close(data[k][0], T, what="T")
+            close(data[k][1], I, what="I")
+            for atol, rtol in ((1e-3, 1e-3), (1e-9, 1e-9)):
+                from pockit_amd import refine as pref
+
+                assert np.array_equal(pref.interval_ok(phases[k].layout, data[k][0], data[k][1], atol, rtol, 1e-4),
+                                      oref.check_intervals(rp, T, I, atol, rtol, 1e-4))
+        system._invalidate()
