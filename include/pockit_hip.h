@@ -158,6 +158,9 @@ int pk_eval_hess_dev(pk_ctx* ctx, const double* d_x, const double* d_lambda, dou
  * outputs come from ONE fused launch (pk_xall: each node evaluated once) + pk_fin, then pk_hess */
 int pk_eval_cycle_dev(pk_ctx* ctx, const double* d_x, const double* d_lambda, double sigma, double* d_f,
                       double* d_grad, double* d_g, double* d_jac, double* d_hess, void* stream);
+/* Replay the fused cycle from a cached hipGraph while its pointers, sigma and stream do not change (a solver's
+ * steady state); any change re-captures.  Off by default. */
+int pk_set_cycle_graph(pk_ctx* ctx, int enable);
 int pk_sync(pk_ctx* ctx, void* stream);
 
 /* Mesh-interval sharding across GPUs (one context per GPU, each holding its shard of the tiles):
@@ -171,8 +174,10 @@ int pk_eval_f_from_integrals_dev(pk_ctx* ctx, const double* d_x, double* d_f, vo
 
 /* HIP-event timing of the individual kernels on the launch stream.
  * kernel ids: 0 pk_int, 1 pk_fin, 2 pk_g, 3 pk_grad, 4 pk_jac, 5 pk_hess, 6 pk_xall, 7 pk_aux, 8 pk_outer,
- * 9 pk_hessc */
+ * 9 pk_hessc, 10 pk_err.  pk_profile_sampling(n): only every n-th launch of a selected kernel is timed (a timed
+ * launch costs ~2-3 us more than a plain one, so timing every launch slows the loop being measured). */
 int pk_profile(pk_ctx* ctx, int kernel_mask /* bit k: time kernel k; 0 = off */);
+int pk_profile_sampling(pk_ctx* ctx, int period);
 int pk_profile_read(pk_ctx* ctx, int kernel_id, int64_t* launches, double* total_ms);
 const char* pk_kernel_name(int kernel_id);
 

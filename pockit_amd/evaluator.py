@@ -349,8 +349,15 @@ class Evaluator:
     def sync(self, stream=None):
         self.ctx.check(self.ctx.lib.pk_sync(self.ctx.handle, stream))
 
-    def profile(self, enable=True):
+    def profile(self, enable=True, period=1):
+        """Time the kernels whose bit is set in ``enable`` with HIP events; only every ``period``-th launch."""
+        self.ctx.check(self.ctx.lib.pk_profile_sampling(self.ctx.handle, int(period)))
         self.ctx.check(self.ctx.lib.pk_profile(self.ctx.handle, int(enable)))
+
+    def set_cycle_graph(self, enable=True):
+        """Replay the fused cycle from a cached hipGraph (measured slower than plain launches on MI355X /
+        ROCm 7.2 -- DESIGN.md section 5 -- so it is off by default)."""
+        self.ctx.check(self.ctx.lib.pk_set_cycle_graph(self.ctx.handle, int(bool(enable))))
 
     def profile_read(self):
         """{kernel name: (launches, total_ms)} accumulated while profiling was enabled."""

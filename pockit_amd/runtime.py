@@ -66,7 +66,7 @@ EXPORTS = ["pk_create", "pk_destroy", "pk_last_error", "pk_device_count", "pk_lo
            "pk_eval_cycle_dev", "pk_sync", "pk_profile", "pk_profile_read", "pk_kernel_name",
            "pk_set_shard", "pk_eval_integrals_dev", "pk_eval_f_from_integrals_dev", "pk_eval_cycle",
            "pk_prepare_x", "pk_fetch", "pk_eval_hess_prepared", "pk_host_buffer", "pk_eval_hessc", "pk_eval_hessc_dev",
-           "pk_set_mesh_error_tables", "pk_eval_mesh_error", "pk_eval_mesh_error_dev"]
+           "pk_set_mesh_error_tables", "pk_eval_mesh_error", "pk_eval_mesh_error_dev", "pk_set_cycle_graph", "pk_profile_sampling"]
 
 _lib = None
 
@@ -130,6 +130,8 @@ def load_library():
     lib.pk_set_mesh_error_tables.argtypes = [vp, vp, C.c_int32, dp, C.c_int64, C.c_int64]
     lib.pk_eval_mesh_error.argtypes = [vp, dp, dp, dp]
     lib.pk_eval_mesh_error_dev.argtypes = [vp, vp, vp, vp, vp]
+    lib.pk_set_cycle_graph.argtypes = [vp, C.c_int]
+    lib.pk_profile_sampling.argtypes = [vp, C.c_int]
     lib.pk_eval_f_dev.argtypes = [vp, vp, vp, vp]
     lib.pk_eval_grad_dev.argtypes = [vp, vp, vp, vp]
     lib.pk_eval_g_dev.argtypes = [vp, vp, vp, vp]

@@ -332,3 +332,37 @@ def test_mesh_error_full_size_matches_oracle():
                 assert np.array_equal(pref.interval_ok(phases[k].layout, data[k][0], data[k][1], atol, rtol, 1e-4),
                                       oref.check_intervals(rp, T, I, atol, rtol, 1e-4))
         system._invalidate()
+
+
+def test_cycle_graph_replay_gives_identical_results():
+    """pk_set_cycle_graph: the cached hipGraph of the fused cycle reproduces the plain launches bit for bit, and a
+    change of sigma (re-capture) is honoured."""
+    import ctypes as C
+
+    import torch
+
+    system, _, guess = models.brachistochrone(_ns("radau", "pockit_amd"), mesh=37, num_point=5)
+    plan, ev = system.plan, system.evaluator
+    x, lam, _ = models.bench_inputs(system, guess)
+    dev = torch.device("cuda", 0)
+    dx, dlam = torch.from_numpy(x).to(dev), torch.from_numpy(lam).to(dev)
+    sizes = (("f", 1), ("grad", plan.n), ("g", plan.m), ("J", plan.nnz_J), ("H", plan.nnz_H))
+    torch.cuda.synchronize()
+
+    def run(sigma):
+        o = {k: torch.zeros(n, dtype=torch.float64, device=dev) for k, n in sizes}
+        torch.cuda.synchronize()
+        for _ in range(3):
+            ev.cycle_dev(dx.data_ptr(), dlam.data_ptr(), sigma, *[o[k].data_ptr() for k, _ in sizes])
+        ev.sync()
+        return {k: v.cpu().numpy() for k, v in o.items()}, o
+
+    plain = {s: run(s)[0] for s in (1.0, 0.25)}
+    ev.set_cycle_graph(True)
+    try:
+        for s in (1.0, 0.25, 1.0):
+            got, keep = run(s)
+            for k, _ in sizes:
+                assert np.array_equal(got[k], plain[s][k]), (k, s)
+    finally:
+        ev.set_cycle_graph(False)
