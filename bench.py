@@ -201,6 +201,24 @@ def run_gpu(name, intervals, steps, warmup, rank, world, dist, time_kernel=None)
         ev.profile(0)
         mesh_err = {"pk_err_us": ms_l / max(n_l, 1) * 1e3, "rows": int(ev._err_len),
                     "finite": bool(torch.isfinite(eT).all() and torch.isfinite(eI).all())}
+    # device-resident CSR hand-off: gather of the cycle's J / H triplets into CSR order
+    csr = None
+    if world == 1:
+        mj, mh = ev.csr_map("jac"), ev.csr_map("hess")
+        cj = torch.zeros(mj.nnz, dtype=torch.float64, device=dev)
+        ch = torch.zeros(mh.nnz, dtype=torch.float64, device=dev)
+        torch.cuda.synchronize()
+        csr = {"nnz_J_csr": int(mj.nnz), "nnz_H_csr": int(mh.nnz)}
+        for which, src, dst in ((0, o["J"], cj), (1, o["H"], ch)):
+            ev.profile(1 << 11)
+            n0, ms0 = ev.profile_read()["pk_csr"]
+            for _ in range(50):
+                lib.pk_gather_csr_dev(h, which, ptr(src), ptr(dst), st)
+            torch.cuda.synchronize()
+            n1, ms1 = ev.profile_read()["pk_csr"]
+            ev.profile(0)
+            csr["pk_csr_J_us" if which == 0 else "pk_csr_H_us"] = (ms1 - ms0) / max(n1 - n0, 1) * 1e3
+        csr["finite"] = bool(torch.isfinite(cj).all() and torch.isfinite(ch).all())
     # correctness spot-check against what the kernels are supposed to produce: finite outputs
     finite = all(bool(torch.isfinite(o[k]).all()) for k in ("f", "grad", "g", "J", "H"))
     res = dict(name=name, intervals=intervals, nodes=int(sum(pp.layout.L_m for pp in plan.phase_plans)),
@@ -208,7 +226,7 @@ def run_gpu(name, intervals, steps, warmup, rank, world, dist, time_kernel=None)
                ms_per_step=elapsed / steps * 1e3, setup_s=setup_s, bytes=B, dominant=dominant,
                dominant_us=(total_ms / launches * 1e3 if launches else None), kernel_us=allk, finite=finite,
                tiles=int(len(ev.tables.tiles)), ipw=int(ev.tables.intervals_per_wave), compact=compact,
-               mesh_err=mesh_err)
+               mesh_err=mesh_err, csr=csr)
     ev.close()
     return res
 
@@ -285,6 +303,7 @@ def main():
             "outputs_finite": res["finite"],
             "compact_hessian_mode": res["compact"],
             "mesh_error_estimation": res["mesh_err"],
+            "csr_handoff": res["csr"],
         }
         if not args.no_cpu_baseline and n_gpus == 1:
             cb = cpu_baseline(args.workload, intervals)

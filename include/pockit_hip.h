@@ -147,6 +147,21 @@ int pk_set_mesh_error_tables(pk_ctx* ctx, const void* intervals, int32_t n_inter
 int pk_eval_mesh_error(pk_ctx* ctx, const double* x, double* T /* n_out */, double* I /* n_out */);
 int pk_eval_mesh_error_dev(pk_ctx* ctx, const double* d_x, double* d_T, double* d_I, void* stream);
 
+/* Device-resident CSR hand-off (the reference hands host triplets to IPOPT,
+ * optimizer/ipopt.py:41-53).  The triplet values of J (which = 0) or H (which = 1, lower triangle) are gathered
+ * into CSR order on the device, repeated (row, col) entries summed in triplet order: the matrices can feed a
+ * GPU KKT solve without crossing PCIe.  ``perm[q]``: triplet index of the q-th entry in (row, col) order;
+ * ``seg[p] .. seg[p+1]``: the run of q belonging to CSR entry p (NULL when no entry repeats).  The CSR
+ * structure itself (indptr, indices) is host data: pockit_amd/csr.py. */
+int pk_set_csr_map(pk_ctx* ctx, int which, const int32_t* seg /* n_unique + 1 or NULL */, const int32_t* perm,
+                   int64_t n_unique, int64_t n_triplets);
+int pk_gather_csr_dev(pk_ctx* ctx, int which, const double* d_triplets, double* d_csr, void* stream);
+int pk_eval_jac_csr_dev(pk_ctx* ctx, const double* d_x, double* d_csr, void* stream);
+int pk_eval_hess_csr_dev(pk_ctx* ctx, const double* d_x, const double* d_lambda, double sigma, double* d_csr,
+                         void* stream);
+int pk_eval_jac_csr(pk_ctx* ctx, const double* x, double* vals /* n_unique */);
+int pk_eval_hess_csr(pk_ctx* ctx, const double* x, const double* lambda, double sigma, double* vals);
+
 /* device-pointer API: enqueue on ``stream`` (hipStream_t, NULL = context stream), no sync */
 int pk_eval_f_dev(pk_ctx* ctx, const double* d_x, double* d_f, void* stream);
 int pk_eval_grad_dev(pk_ctx* ctx, const double* d_x, double* d_grad, void* stream);
@@ -174,7 +189,7 @@ int pk_eval_f_from_integrals_dev(pk_ctx* ctx, const double* d_x, double* d_f, vo
 
 /* HIP-event timing of the individual kernels on the launch stream.
  * kernel ids: 0 pk_int, 1 pk_fin, 2 pk_g, 3 pk_grad, 4 pk_jac, 5 pk_hess, 6 pk_xall, 7 pk_aux, 8 pk_outer,
- * 9 pk_hessc, 10 pk_err.  pk_profile_sampling(n): only every n-th launch of a selected kernel is timed (a timed
+ * 9 pk_hessc, 10 pk_err, 11 pk_csr.  pk_profile_sampling(n): only every n-th launch of a selected kernel is timed (a timed
  * launch costs ~2-3 us more than a plain one, so timing every launch slows the loop being measured). */
 int pk_profile(pk_ctx* ctx, int kernel_mask /* bit k: time kernel k; 0 = off */);
 int pk_profile_sampling(pk_ctx* ctx, int period);

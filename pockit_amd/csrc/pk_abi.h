@@ -133,6 +133,10 @@ struct PkArgs {
   const double* errdb;
   double* o_errT;         // T_aug x      per phase [n_x][rows]
   double* o_errI;         // dt I_aug f   per phase [n_x][rows]
+  const double* csr_in;   // triplet values -> CSR values (pk_csr only): out[p] = sum_{q in [seg[p], seg[p+1])} in[perm[q]]
+  const int32_t* csr_seg; // nullptr when no (row, col) repeats: out[p] = in[perm[p]]
+  const int32_t* csr_perm;
+  double* csr_out;
   int32_t n_tiles, n_items;
   int32_t n_phase, n;
   int32_t l_s, n_s, n_sys, m;
@@ -141,5 +145,6 @@ struct PkArgs {
                           // bit 3: pk_fin reduces the integrals into Ibuf; bit 4: pk_fin reduces the gradient slots
   int32_t n_outer;
   int32_t n_erriv;
+  int32_t n_csr;          // CSR entries
   PkPhase ph[PK_MAX_PHASES];   // the phases by value (kernarg segment): no dependent global load
 };

@@ -800,6 +800,23 @@ __device__ __forceinline__ void kernel_err(const PkArgs& A) {
   Gen::interval_err(iv.phase, A, iv, valid && iv.K > 0, pk_lds + wave * Gen::LDS_E, lane);
 }
 
+// Triplet list -> CSR values on device (hand J / H to a GPU linear solver without a
+// PCIe round trip).  The (row, col) sort, the duplicate runs and the permutation are computed once per mesh
+// on the host (pockit_amd/csr.py); duplicates are summed in triplet order (deterministic).
+__device__ __forceinline__ void kernel_csr(const PkArgs& A) {
+  const int stride = (int)gridDim.x * PK_BLOCK;
+  for (int p = (int)blockIdx.x * PK_BLOCK + (int)threadIdx.x; p < A.n_csr; p += stride) {
+    if (A.csr_seg == nullptr) {
+      A.csr_out[p] = A.csr_in[A.csr_perm[p]];
+      continue;
+    }
+    const int lo = A.csr_seg[p], hi = A.csr_seg[p + 1];
+    double acc = 0.0;
+    for (int q = lo; q < hi; ++q) acc += A.csr_in[A.csr_perm[q]];
+    A.csr_out[p] = acc;
+  }
+}
+
 // One workgroup per outer-product block (generic, table driven; O(n^2) outputs exist only for
 // objectives / system constraints that are nonlinear in the integrals -- small problems in practice).
 __device__ __forceinline__ void kernel_outer(const PkArgs& A) {
@@ -918,4 +935,5 @@ __device__ __forceinline__ void kernel_fin(const PkArgs& A) {
   extern "C" __global__ __launch_bounds__(PK_BLOCK) void pk_aux(PkArgs A) { pk::kernel_aux<GEN>(A); }   \
   extern "C" __global__ __launch_bounds__(PK_BLOCK) void pk_outer(PkArgs A) { pk::kernel_outer(A); }     \
   extern "C" __global__ __launch_bounds__(PK_BLOCK) void pk_hessc(PkArgs A) { pk::kernel_hessc<GEN>(A); } \
-  extern "C" __global__ __launch_bounds__(PK_BLOCK) void pk_err(PkArgs A) { pk::kernel_err<GEN>(A); }
+  extern "C" __global__ __launch_bounds__(PK_BLOCK) void pk_err(PkArgs A) { pk::kernel_err<GEN>(A); }     \
+  extern "C" __global__ __launch_bounds__(PK_BLOCK) void pk_csr(PkArgs A) { pk::kernel_csr(A); }

@@ -19,7 +19,9 @@
 #include <hip/hip_runtime.h>
 #include <hip/hip_ext.h>
 
+#include <climits>
 #include <cstdarg>
+#include <cstdint>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -31,9 +33,9 @@
 
 namespace {
 
-enum { K_INT = 0, K_FIN, K_G, K_GRAD, K_JAC, K_HESS, K_XALL, K_AUX, K_OUTER, K_HESSC, K_ERR, K_COUNT };
+enum { K_INT = 0, K_FIN, K_G, K_GRAD, K_JAC, K_HESS, K_XALL, K_AUX, K_OUTER, K_HESSC, K_ERR, K_CSR, K_COUNT };
 const char* const kKernelNames[K_COUNT] = {"pk_int", "pk_fin", "pk_g", "pk_grad", "pk_jac", "pk_hess", "pk_xall",
-                                           "pk_aux", "pk_outer", "pk_hessc", "pk_err"};
+                                           "pk_aux", "pk_outer", "pk_hessc", "pk_err", "pk_csr"};
 enum { F_WRITE_F = 1, F_SECONDARY = 2, F_FIN_INT = 8, F_FIN_GRAD = 16 };
 
 thread_local std::string g_create_error;
@@ -79,6 +81,12 @@ struct pk_ctx {
              sigma == o.sigma && st == o.st;
     }
   } cyc_key{};
+  // triplet -> CSR maps (pk_set_csr_map): [0] Jacobian, [1] Hessian of the Lagrangian (lower triangle)
+  struct CsrMap {
+    int32_t *d_seg = nullptr, *d_perm = nullptr;
+    double* d_vals = nullptr;
+    int64_t n_unique = 0, n_triplets = 0;
+  } csr[2];
   // mesh error estimation (pk_set_mesh_error_tables)
   void* d_erriv = nullptr;
   double *d_errdb = nullptr, *d_errT = nullptr, *d_errI = nullptr;
@@ -136,6 +144,7 @@ void free_problem(pk_ctx* c) {
   release(c->d_erriv); release(c->d_errdb); release(c->d_errT); release(c->d_errI);
   c->n_erriv = 0; c->n_err_out = 0;
   drop_cycle_graph(c);
+  for (auto& m : c->csr) { release(m.d_seg); release(m.d_perm); release(m.d_vals); m.n_unique = m.n_triplets = 0; }
   release(c->d_ib); release(c->d_db); release(c->d_lb);
   release(c->d_x); release(c->d_lam); release(c->d_f); release(c->d_grad); release(c->d_g); release(c->d_J);
   release(c->d_H); release(c->d_I); release(c->d_partial); release(c->d_partial2);
@@ -478,6 +487,86 @@ int pk_eval_hessc_dev(pk_ctx* c, const double* d_x, const double* d_lam, double 
   A.items = (const PkItem*)c->d_items_hessc;
   A.n_items = c->n_items_hessc;
   return launch(c, K_HESSC, A, tile_blocks(c) + 1, sizeof(double) * (size_t)(c->md.ne_hc > 0 ? c->md.ne_hc : 1), st);
+}
+
+// ---------------------------------------------------------------- device-resident CSR hand-off
+int pk_set_csr_map(pk_ctx* c, int which, const int32_t* seg, const int32_t* perm, int64_t n_unique, int64_t n_triplets) {
+  int rc = ready(c);
+  if (rc) return rc;
+  if (which < 0 || which > 1) return fail(c, 80, "pk_set_csr_map: which must be 0 (Jacobian) or 1 (Hessian)");
+  const int64_t expect = which == 0 ? c->nnz_J : c->nnz_H;
+  if (!perm || n_unique <= 0 || n_unique > n_triplets || n_triplets != expect || n_triplets > INT32_MAX)
+    return fail(c, 81, "pk_set_csr_map: map does not match the problem (%lld triplets expected)", (long long)expect);
+  // validate on the host: the kernel indexes with these
+  for (int64_t q = 0; q < n_triplets; ++q)
+    if (perm[q] < 0 || perm[q] >= n_triplets) return fail(c, 82, "pk_set_csr_map: perm[%lld] out of range", (long long)q);
+  if (seg) {
+    if (seg[0] != 0 || seg[n_unique] != n_triplets) return fail(c, 83, "pk_set_csr_map: segment table does not cover the triplets");
+    for (int64_t p = 0; p < n_unique; ++p)
+      if (seg[p + 1] <= seg[p]) return fail(c, 83, "pk_set_csr_map: empty or decreasing segment %lld", (long long)p);
+  } else if (n_unique != n_triplets) {
+    return fail(c, 83, "pk_set_csr_map: a segment table is required when entries repeat");
+  }
+  PK_HIP(c, hipSetDevice(c->device));
+  PK_HIP(c, hipStreamSynchronize(c->stream));
+  auto& m = c->csr[which];
+  release(m.d_seg); release(m.d_perm); release(m.d_vals);
+  m.n_unique = m.n_triplets = 0;
+  if (seg && (rc = upload(c, (void**)&m.d_seg, seg, sizeof(int32_t) * (size_t)(n_unique + 1)))) return rc;
+  if ((rc = upload(c, (void**)&m.d_perm, perm, sizeof(int32_t) * (size_t)n_triplets))) return rc;
+  PK_HIP(c, hipMalloc((void**)&m.d_vals, sizeof(double) * (size_t)n_unique));
+  m.n_unique = n_unique;
+  m.n_triplets = n_triplets;
+  return 0;
+}
+
+int pk_gather_csr_dev(pk_ctx* c, int which, const double* d_triplets, double* d_csr, void* stream) {
+  int rc = ready(c);
+  if (rc) return rc;
+  if (which < 0 || which > 1 || c->csr[which].n_unique == 0) return fail(c, 84, "pk_gather_csr: call pk_set_csr_map first");
+  const auto& m = c->csr[which];
+  PkArgs A = base_args(c, nullptr, nullptr, 0.0);
+  A.csr_in = d_triplets; A.csr_seg = m.d_seg; A.csr_perm = m.d_perm; A.csr_out = d_csr; A.n_csr = (int32_t)m.n_unique;
+  unsigned grid = (unsigned)((m.n_unique + PK_BLOCK - 1) / PK_BLOCK);
+  if (grid > 4096) grid = 4096;
+  return launch(c, K_CSR, A, grid, 0, pick(c, stream));
+}
+
+int pk_eval_jac_csr_dev(pk_ctx* c, const double* d_x, double* d_csr, void* stream) {
+  int rc = pk_eval_jac_dev(c, d_x, c ? c->d_J : nullptr, stream);
+  return rc ? rc : pk_gather_csr_dev(c, 0, c->d_J, d_csr, stream);
+}
+
+int pk_eval_hess_csr_dev(pk_ctx* c, const double* d_x, const double* d_lam, double sigma, double* d_csr, void* stream) {
+  int rc = pk_eval_hess_dev(c, d_x, d_lam, sigma, c ? c->d_H : nullptr, stream);
+  return rc ? rc : pk_gather_csr_dev(c, 1, c->d_H, d_csr, stream);
+}
+
+int pk_eval_jac_csr(pk_ctx* c, const double* x, double* vals) {
+  int rc = ready(c);
+  if (rc) return rc;
+  if (!x || !vals) return fail(c, 60, "null host buffer");
+  if (c->csr[0].n_unique == 0) return fail(c, 84, "pk_eval_jac_csr: call pk_set_csr_map first");
+  PK_HIP(c, hipSetDevice(c->device));
+  PK_HIP(c, hipMemcpyAsync(c->d_x, x, sizeof(double) * (size_t)c->n, hipMemcpyHostToDevice, c->stream));
+  if ((rc = pk_eval_jac_csr_dev(c, c->d_x, c->csr[0].d_vals, nullptr))) return rc;
+  PK_HIP(c, hipMemcpyAsync(vals, c->csr[0].d_vals, sizeof(double) * (size_t)c->csr[0].n_unique, hipMemcpyDeviceToHost, c->stream));
+  PK_HIP(c, hipStreamSynchronize(c->stream));
+  return 0;
+}
+
+int pk_eval_hess_csr(pk_ctx* c, const double* x, const double* lambda, double sigma, double* vals) {
+  int rc = ready(c);
+  if (rc) return rc;
+  if (!x || !lambda || !vals) return fail(c, 60, "null host buffer");
+  if (c->csr[1].n_unique == 0) return fail(c, 84, "pk_eval_hess_csr: call pk_set_csr_map first");
+  PK_HIP(c, hipSetDevice(c->device));
+  PK_HIP(c, hipMemcpyAsync(c->d_x, x, sizeof(double) * (size_t)c->n, hipMemcpyHostToDevice, c->stream));
+  PK_HIP(c, hipMemcpyAsync(c->d_lam, lambda, sizeof(double) * (size_t)c->m, hipMemcpyHostToDevice, c->stream));
+  if ((rc = pk_eval_hess_csr_dev(c, c->d_x, c->d_lam, sigma, c->csr[1].d_vals, nullptr))) return rc;
+  PK_HIP(c, hipMemcpyAsync(vals, c->csr[1].d_vals, sizeof(double) * (size_t)c->csr[1].n_unique, hipMemcpyDeviceToHost, c->stream));
+  PK_HIP(c, hipStreamSynchronize(c->stream));
+  return 0;
 }
 
 // ---------------------------------------------------------------- mesh error estimation

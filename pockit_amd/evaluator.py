@@ -159,6 +159,7 @@ class Evaluator:
         md.ne_hc = self.src.list_off["hessc"]["total"] if self.src.compact else 0
         md.lds_e = self.src.lds_e
         self._err_views = None
+        self._csr = {}
         md.prepass_f = 1
         md.prepass_grad = int(plan.needs_I_grad)
         md.prepass_g = int(plan.needs_I_con)
@@ -327,6 +328,58 @@ class Evaluator:
         self.ctx.check(lib.pk_eval_mesh_error(h, runtime.as_dp(x), runtime.as_dp(T), runtime.as_dp(I)))
         return [(T[o: o + nx * rows].reshape(nx, rows), I[o: o + nx * rows].reshape(nx, rows))
                 for o, nx, rows in self._err_views]
+
+    # ------------------------------------------------------------------ device-resident CSR hand-off
+    def csr_map(self, which):
+        """``CsrMap`` of the Jacobian (``"jac"``) or of the lower triangle of the Hessian of the Lagrangian
+        (``"hess"``, reference layout); built and uploaded on first use."""
+        from .csr import CsrMap
+
+        if which not in ("jac", "hess"):
+            raise ValueError('which must be "jac" or "hess"')
+        if which not in self._csr:
+            plan = self.plan
+            if which == "jac":
+                m = CsrMap(plan.jac_row, plan.jac_col, (plan.m, plan.n))
+            else:
+                m = CsrMap(plan.hess_row, plan.hess_col, (plan.n, plan.n))
+            seg = None if m.seg is None else m.seg.ctypes.data_as(runtime.c_int32_p)
+            self.ctx.check(self.ctx.lib.pk_set_csr_map(self.ctx.handle, 0 if which == "jac" else 1, seg,
+                                                       m.perm.ctypes.data_as(runtime.c_int32_p), m.nnz, m.n_triplets))
+            self._csr[which] = m
+        return self._csr[which]
+
+    def jacobian_csr(self, x):
+        """CSR values of the constraint Jacobian (structure: ``csr_map("jac")``), gathered on the device."""
+        m = self.csr_map("jac")
+        x = self._x(x)
+        out = np.empty(m.nnz)
+        self.ctx.check(self.ctx.lib.pk_eval_jac_csr(self.ctx.handle, runtime.as_dp(x), runtime.as_dp(out)))
+        return out
+
+    def hessian_csr(self, x, lagrange, obj_factor):
+        """CSR values of the lower triangle of the Hessian of the Lagrangian (``csr_map("hess")``)."""
+        m = self.csr_map("hess")
+        x = self._x(x)
+        lam = np.ascontiguousarray(lagrange, dtype=np.float64)
+        out = np.empty(m.nnz)
+        self.ctx.check(self.ctx.lib.pk_eval_hess_csr(self.ctx.handle, runtime.as_dp(x), runtime.as_dp(lam),
+                                                     float(obj_factor), runtime.as_dp(out)))
+        return out
+
+    def jacobian_csr_dev(self, d_x, d_out, stream=None):
+        self.csr_map("jac")
+        self.ctx.check(self.ctx.lib.pk_eval_jac_csr_dev(self.ctx.handle, d_x, d_out, stream))
+
+    def hessian_csr_dev(self, d_x, d_lam, sigma, d_out, stream=None):
+        self.csr_map("hess")
+        self.ctx.check(self.ctx.lib.pk_eval_hess_csr_dev(self.ctx.handle, d_x, d_lam, float(sigma), d_out, stream))
+
+    def gather_csr_dev(self, which, d_triplets, d_out, stream=None):
+        """Triplet values already on the device (e.g. from ``cycle_dev``) -> CSR values."""
+        self.csr_map(which)
+        self.ctx.check(self.ctx.lib.pk_gather_csr_dev(self.ctx.handle, 0 if which == "jac" else 1, d_triplets, d_out,
+                                                      stream))
 
     def cycle(self, x, lagrange, obj_factor):
         """All five outputs on the same x from the fused path (pk_xall + pk_fin + pk_hess):

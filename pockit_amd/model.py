@@ -492,6 +492,18 @@ class SystemBase:
             return self.evaluator.hessian_compact(x, fct_c, 0.0)
         return self.evaluator.hessian(x, fct_c, 0.0)[self.plan.nnz_H_obj:]
 
+    # ------------------------------------------------------------------ CSR hand-off
+    def jacobian_csr(self, x):
+        """The constraint Jacobian as ``scipy.sparse.csr_array`` (values gathered into CSR order on the GPU)."""
+        ev = self.evaluator
+        return ev.csr_map("jac").to_scipy(ev.jacobian_csr(x))
+
+    def hessian_csr(self, x, lagrange, obj_factor):
+        """The lower triangle of the Hessian of the Lagrangian as ``scipy.sparse.csr_array`` (repeated triplets of
+        the reference layout summed on the GPU)."""
+        ev = self.evaluator
+        return ev.csr_map("hess").to_scipy(ev.hessian_csr(x, lagrange, obj_factor))
+
     # ------------------------------------------------------------------ mesh error check / refinement
     # (reference: systembase.py:837-889 check_continuous, 982-1069 refine_continuous)
     def _split_value(self, value):

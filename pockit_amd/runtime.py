@@ -59,14 +59,16 @@ ERRIV_DTYPE = np.dtype([("phase", np.int32), ("K", np.int32), ("lm", np.int32), 
                         ("out_off", np.int64), ("width", np.float64)])
 
 WAVES_PER_BLOCK = 4  # PK_WAVES_PER_BLOCK of csrc/pk_abi.h
-KERNELS = ["pk_int", "pk_fin", "pk_g", "pk_grad", "pk_jac", "pk_hess", "pk_xall", "pk_aux", "pk_outer", "pk_hessc", "pk_err"]
+KERNELS = ["pk_int", "pk_fin", "pk_g", "pk_grad", "pk_jac", "pk_hess", "pk_xall", "pk_aux", "pk_outer", "pk_hessc", "pk_err", "pk_csr"]
 EXPORTS = ["pk_create", "pk_destroy", "pk_last_error", "pk_device_count", "pk_load_model", "pk_set_problem",
            "pk_get_structure", "pk_eval_f", "pk_eval_grad", "pk_eval_g", "pk_eval_jac", "pk_eval_hess",
            "pk_eval_f_dev", "pk_eval_grad_dev", "pk_eval_g_dev", "pk_eval_jac_dev", "pk_eval_hess_dev",
            "pk_eval_cycle_dev", "pk_sync", "pk_profile", "pk_profile_read", "pk_kernel_name",
            "pk_set_shard", "pk_eval_integrals_dev", "pk_eval_f_from_integrals_dev", "pk_eval_cycle",
            "pk_prepare_x", "pk_fetch", "pk_eval_hess_prepared", "pk_host_buffer", "pk_eval_hessc", "pk_eval_hessc_dev",
-           "pk_set_mesh_error_tables", "pk_eval_mesh_error", "pk_eval_mesh_error_dev", "pk_set_cycle_graph", "pk_profile_sampling"]
+           "pk_set_mesh_error_tables", "pk_eval_mesh_error", "pk_eval_mesh_error_dev", "pk_set_cycle_graph", "pk_profile_sampling",
+           "pk_set_csr_map", "pk_gather_csr_dev", "pk_eval_jac_csr_dev", "pk_eval_hess_csr_dev", "pk_eval_jac_csr",
+           "pk_eval_hess_csr"]
 
 _lib = None
 
@@ -132,6 +134,12 @@ def load_library():
     lib.pk_eval_mesh_error_dev.argtypes = [vp, vp, vp, vp, vp]
     lib.pk_set_cycle_graph.argtypes = [vp, C.c_int]
     lib.pk_profile_sampling.argtypes = [vp, C.c_int]
+    lib.pk_set_csr_map.argtypes = [vp, C.c_int, c_int32_p, c_int32_p, C.c_int64, C.c_int64]
+    lib.pk_gather_csr_dev.argtypes = [vp, C.c_int, vp, vp, vp]
+    lib.pk_eval_jac_csr_dev.argtypes = [vp, vp, vp, vp]
+    lib.pk_eval_hess_csr_dev.argtypes = [vp, vp, vp, C.c_double, vp, vp]
+    lib.pk_eval_jac_csr.argtypes = [vp, dp, dp]
+    lib.pk_eval_hess_csr.argtypes = [vp, dp, dp, C.c_double, dp]
     lib.pk_eval_f_dev.argtypes = [vp, vp, vp, vp]
     lib.pk_eval_grad_dev.argtypes = [vp, vp, vp, vp]
     lib.pk_eval_g_dev.argtypes = [vp, vp, vp, vp]
