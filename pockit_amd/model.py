@@ -74,6 +74,7 @@ class PhaseBase:
 
     def _changed(self):
         self._version += 1
+        self._discontinuous_check_passed = False      # reference: phasebase.py:229-231,827-828
         return self
 
     # ------------------------------------------------------------------ setters
@@ -113,13 +114,20 @@ class PhaseBase:
             flags = [bang_bang_control] * len(phase_constraint)
         else:
             flags = list(bang_bang_control)
-        for lb, ub, bb in zip(lower_bound, upper_bound, flags):
+        # bang-bang constraints, scaled to [0, 1] at check time (reference: phasebase.py:388-412): where the value
+        # of each one comes from -- a path-constraint row block or a variable / time / static-parameter slot
+        self._bang_bang = []
+        n_path = 0
+        for c, lb, ub, bb in zip(phase_constraint, lower_bound, upper_bound, flags):
             if bb:
                 if np.isinf(lb) or np.isinf(ub):
                     raise ValueError("lower_bound and upper_bound must be finite for bang-bang control constraint")
                 if ub <= lb + 1e-10:
                     raise ValueError(
                         "lower_bound must be strictly less than upper_bound for bang-bang control constraint")
+                self._bang_bang.append(("symbol", self._symbols.index(c), lb, ub) if c.is_symbol
+                                       else ("path", n_path, lb, ub))
+            n_path += 0 if c.is_symbol else 1
         self._func_phase_constraint = [SparseFunc(e, self._symbols, self._simplify) for e in exprs]
         self._lower_bound_phase_constraint = np.array(lo, dtype=np.float64)
         self._upper_bound_phase_constraint = np.array(hi, dtype=np.float64)
@@ -234,7 +242,102 @@ class PhaseBase:
             return
         mesh, num_point = refine.refined_discretization(self.layout, T, I, ok, rtol, num_point_min, num_point_max,
                                                         mesh_length_min, mesh_length_max)
+        passed = self._discontinuous_check_passed       # survives a continuous refinement (phasebase.py:1615-1617)
         self.set_discretization(mesh, num_point)
+        self._discontinuous_check_passed = passed
+
+    # bang-bang (discontinuous) check: reference phasebase.py:1368-1400,1439-1474
+    n_b = property(lambda self: len(self._bang_bang))
+
+    def _bang_bang_values(self, data, s, g_path):
+        """(n_b, L_m): every bang-bang constraint scaled to [0, 1] at the collocation nodes.  ``g_path``: this
+        phase's path-constraint values (n_c, L_m) as the constraints callback returned them."""
+        lay = self.layout
+        out = np.empty((self.n_b, lay.L_m))
+        for b, (kind, idx, lb, ub) in enumerate(self._bang_bang):
+            if kind == "path":
+                v = g_path[idx]
+            elif idx < self.n:
+                v = data[lay.l_v[idx]: lay.l_v[idx] + lay.L_m]
+            elif idx == self.n:
+                v = (lay.tau - 0.5) * (data[-1] - data[-2]) + (data[-1] + data[-2]) / 2
+            else:
+                v = np.full(lay.L_m, s[idx - self.n - 1])
+            out[b] = (v - lb) / (ub - lb)
+        return out
+
+    def _discontinuous_ok(self, f_bb, dtol, mtol):
+        lay = self.layout
+        ok = np.ones(lay.N, dtype=bool)
+        for j in range(lay.N):
+            if lay.width[j] < mtol:
+                continue
+            part = f_bb[:, lay.lm[j]: lay.rm[j]]
+            ok[j] = bool(np.all(np.all(part < dtol, axis=1) | np.all(part > 1 - dtol, axis=1)))
+        return ok
+
+    def _require_radau(self):
+        if self.scheme == "lgl":
+            raise NotImplementedError("Lobatto nodes cannot approximate discontinuous functions precisely.")
+
+    def _path_values(self, variable, static_parameter):
+        """This phase's path-constraint values at the nodes, from the system's constraints callback (GPU)."""
+        if self.n_s and static_parameter is None:
+            raise ValueError("phase has static parameters, but the value of static parameters is not given")
+        s = [] if static_parameter is None else [float(v) for v in static_parameter]
+        self._substitute_boundary(variable.data, s)
+        if not any(kind == "path" for kind, *_ in self._bang_bang):
+            return None, s
+        system = self._owner()
+        k = next(i for i, p in enumerate(system.p) if p is self)
+        plan = system.plan
+        x = np.zeros(plan.n)
+        for i in range(len(system.p)):
+            x[plan.r_p[i] - 1] = 1.0
+        x[plan.l_p[k]: plan.r_p[k]] = variable.data
+        x[plan.l_s: plan.r_s] = s
+        g = system.evaluator.constraints(x)
+        L_m = self.layout.L_m
+        return g[plan.path_off[k]: plan.path_off[k] + self.n_c * L_m].reshape(self.n_c, L_m), s
+
+    def check_discontinuous(self, variable, static_parameter=None, tolerance_discontinuous=1e-3,
+                            tolerance_mesh=1e-4) -> bool:
+        self._require_radau()
+        g_path, s = self._path_values(variable, static_parameter)
+        f_bb = self._bang_bang_values(variable.data, s, g_path)
+        passed = bool(np.all(self._discontinuous_ok(f_bb, tolerance_discontinuous, tolerance_mesh)))
+        if passed:
+            self._discontinuous_check_passed = True
+        return passed
+
+    def check(self, variable, static_parameter=None, absolute_tolerance_continuous=1e-8,
+              relative_tolerance_continuous=1e-8, tolerance_discontinuous=1e-3, tolerance_mesh=1e-4) -> bool:
+        if self.scheme == "lgr" and not self._discontinuous_check_passed and not self.check_discontinuous(
+                variable, static_parameter, tolerance_discontinuous, tolerance_mesh):
+            return False
+        return self.check_continuous(variable, static_parameter, absolute_tolerance_continuous,
+                                     relative_tolerance_continuous, tolerance_mesh)
+
+    def refine_discontinuous(self, variable, static_parameter=None, tolerance_discontinuous=1e-3, num_point_min=6,
+                             num_point_max=12, mesh_length_min=1e-3, mesh_length_max=1.0) -> None:
+        self._require_radau()
+        if self.check_discontinuous(variable, static_parameter, tolerance_discontinuous, mesh_length_min):
+            return
+        raise NotImplementedError("switch-point mesh refinement for bang-bang constraints (reference: "
+                                  "phasebase.py:1619-1868) is not part of this build; use refine_continuous")
+
+    def refine(self, variable, static_parameter=None, absolute_tolerance_continuous=1e-8,
+               relative_tolerance_continuous=1e-8, tolerance_discontinuous=1e-3, num_point_min=6, num_point_max=12,
+               mesh_length_min=1e-3, mesh_length_max=1.0) -> None:
+        """At most one refinement: for the bang-bang error if that check fails, else for the continuous error."""
+        if self.scheme == "lgr" and not self._discontinuous_check_passed and not self.check_discontinuous(
+                variable, static_parameter, tolerance_discontinuous, mesh_length_min):
+            self.refine_discontinuous(variable, static_parameter, tolerance_discontinuous, num_point_min,
+                                      num_point_max, mesh_length_min, mesh_length_max)
+        else:
+            self.refine_continuous(variable, static_parameter, absolute_tolerance_continuous,
+                                   relative_tolerance_continuous, num_point_min, num_point_max, mesh_length_min,
+                                   mesh_length_max)
 
     def refine_continuous(self, variable, static_parameter=None, absolute_tolerance_continuous=1.0e-8,
                           relative_tolerance_continuous=1.0e-8, num_point_min=6, num_point_max=12,
@@ -563,3 +666,56 @@ class SystemBase:
         if single:
             return adapted[0]
         return adapted + value[self.n_p:]
+
+    def _static_of(self, value):
+        return np.array(list(value[-1]), dtype=np.float64) if self.n_s else None
+
+    def check_discontinuous(self, value, tolerance_discontinuous=1.0e-3, tolerance_mesh=1.0e-4) -> bool:
+        """Bang-bang check of every phase (reference: systembase.py:891-939); Radau only, as in the reference."""
+        value, _ = self._split_value(value)
+        s = self._static_of(value)
+        return bool(np.all([p.check_discontinuous(v, s, tolerance_discontinuous, tolerance_mesh)
+                            for p, v in zip(self._phase, value)]))
+
+    def check(self, value, absolute_tolerance_continuous=1.0e-8, relative_tolerance_continuous=1.0e-8,
+              tolerance_discontinuous=1.0e-3, tolerance_mesh=1.0e-4) -> bool:
+        """Continuous and (Radau) discontinuous error check (reference: systembase.py:941-980,
+        lobatto/system.py:31-58)."""
+        lgl = any(p.scheme == "lgl" for p in self._phase)
+        return self.check_continuous(value, absolute_tolerance_continuous, relative_tolerance_continuous,
+                                     tolerance_mesh) and (lgl or self.check_discontinuous(
+                                         value, tolerance_discontinuous, tolerance_mesh))
+
+    def refine_discontinuous(self, value, tolerance_discontinuous=1.0e-3, num_point_min=6, num_point_max=12,
+                             mesh_length_min=1.0e-3, mesh_length_max=1.0):
+        original = value
+        if self.check_discontinuous(value, tolerance_discontinuous, mesh_length_min):
+            return original
+        value, single = self._split_value(value)
+        s = self._static_of(value)
+        adapted = []
+        for p, v in zip(self._phase, value):
+            p.refine_discontinuous(v, s, tolerance_discontinuous, num_point_min, num_point_max, mesh_length_min,
+                                   mesh_length_max)
+            adapted.append(v.adapt(p))
+        self.update()
+        return adapted[0] if single else adapted + value[self.n_p:]
+
+    def refine(self, value, absolute_tolerance_continuous=1.0e-8, relative_tolerance_continuous=1.0e-8,
+               tolerance_discontinuous=1.0e-3, num_point_min=6, num_point_max=12, mesh_length_min=1.0e-3,
+               mesh_length_max=1.0):
+        """One refinement sweep (reference: systembase.py:1134-1212): per phase the bang-bang refinement if that
+        check fails, else the continuous one; returns the values on the new discretization."""
+        original = value
+        if self.check(value, absolute_tolerance_continuous, relative_tolerance_continuous, tolerance_discontinuous,
+                      mesh_length_min):
+            return original
+        value, single = self._split_value(value)
+        s = self._static_of(value)
+        adapted = []
+        for p, v in zip(self._phase, value):
+            p.refine(v, s, absolute_tolerance_continuous, relative_tolerance_continuous, tolerance_discontinuous,
+                     num_point_min, num_point_max, mesh_length_min, mesh_length_max)
+            adapted.append(v.adapt(p))
+        self.update()
+        return adapted[0] if single else adapted + value[self.n_p:]

@@ -416,3 +416,81 @@ def test_device_csr_full_size_matches_host_gather():
     assert mj.seg is None and mh.seg is not None
     assert np.array_equal(ev.jacobian_csr(x), mj.gather(J))
     close(ev.hessian_csr(x, lam, sigma), mh.gather(H), 1e-14, what="H csr")
+
+
+# ---------------------------------------------------------------------------------------------------------
+# the reference's own check tests (tests/test_radau/test_check_radau.py, tests/test_labatto/test_check_lobatto.py)
+# restated against the GPU-backed API
+def _check_model(ns, num_point):
+    s = ns.System(1)
+    p = s.new_phase(1, 1)
+    p.set_dynamics([p.u[0]])
+    p.set_boundary_condition([None], [None], None, None)
+    p.set_phase_constraint([p.u[0] + p.s[0]], [0.0], [2.0], [True])
+    p.set_discretization([0, 0.1, 1], num_point)
+    s.set_phase([p])
+    s.set_objective(s.s[0])
+    return s, p
+
+
+def test_reference_check_discontinuous_radau():
+    ns = _ns("radau", "pockit_amd")
+    s, p = _check_model(ns, [2, 3])
+    v = ns.constant_guess(p, 0.0)
+    assert isinstance(s.check_discontinuous([v, [2.0]]), bool)
+    assert s.check_discontinuous([v, [2.0]])
+    assert s.check_discontinuous([v, [2.01]])
+    assert not s.check_discontinuous([v, [1.99]])
+    v.u[0] = np.array([-1, -1, 1, 1, 1], dtype=np.float64)
+    assert s.check_discontinuous([v, [1.0]])
+    assert not s.check_discontinuous([v, [1.01]])
+    v.u[0] = np.array([0, 0.01, 2, 2, 2], dtype=np.float64)
+    assert not s.check_discontinuous([v, [0.0]])
+    with pytest.raises(ValueError):
+        s.check_discontinuous(v)
+
+
+@pytest.mark.parametrize("scheme,num_point", [("radau", [2, 3]), ("lobatto", [3, 4])])
+def test_reference_check_continuous(scheme, num_point):
+    ns = _ns(scheme, "pockit_amd")
+    s, p = _check_model(ns, num_point)
+    v = ns.constant_guess(p, 1.0)
+    v.x[0] = v.t_x
+    assert isinstance(s.check_continuous([v, [0.0]]), bool)
+    assert s.check_continuous([v, [0.0]])
+    v.u[0] = v.t_u * 2
+    v.x[0] = v.t_x**2
+    assert s.check_continuous([v, [0.0]])
+    v.u[0][0] += 0.01
+    assert not s.check_continuous([v, [0.0]])
+    v.u[0] = v.t_u * 1.99
+    assert not s.check_continuous([v, [0.0]])
+
+
+def test_reference_check_discontinuous_lobatto_is_not_implemented():
+    ns = _ns("lobatto", "pockit_amd")
+    s, p = _check_model(ns, [3, 4])
+    v = ns.constant_guess(p, 0.0)
+    with pytest.raises(NotImplementedError):
+        s.check_discontinuous([v, [2.0]])
+    v.x[0] = v.t_x
+    v.u[0] = v.t_u * 0 + 1.0
+    assert s.check([v, [0.0]]) == s.check_continuous([v, [0.0]])   # lobatto: check == check_continuous
+
+
+def test_check_and_refine_loop_like_the_hyper_sensitive_example():
+    """system.check / system.refine in the adaptive loop of examples/hyper_sensitive.py:94-116 (no solver: the
+    'solution' is a smooth guess, so each sweep must strictly reduce the number of failing intervals)."""
+    ns = _ns("radau", "pockit_amd")
+    system, phases, guess = models.brachistochrone(ns, mesh=4, num_point=3)
+    value = guess[0] if isinstance(guess, list) and len(guess) == 1 else guess
+    tol = 1e-6
+    assert not system.check(value, absolute_tolerance_continuous=tol, relative_tolerance_continuous=tol)
+    sizes = [phases[0].L]
+    for _ in range(3):
+        value = system.refine(value, absolute_tolerance_continuous=tol, relative_tolerance_continuous=tol,
+                              num_point_min=4, num_point_max=8, mesh_length_min=1e-6)
+        sizes.append(phases[0].L)
+        assert len(value.data) == phases[0].L == system.L
+        assert np.isfinite(system.objective(value.data))
+    assert sizes[1] > sizes[0]
