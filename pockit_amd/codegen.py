@@ -16,6 +16,7 @@ code object is reused across mesh refinements; it is cached by source hash (hipb
 from __future__ import annotations
 
 import hashlib
+import os
 
 import sympy as sp
 from sympy.printing.c import C99CodePrinter
@@ -311,6 +312,10 @@ class ModelSource:
         S.append(f"#define PK_NPHASE {nP}")
         S.append(f"#define PK_NS {max(plan.n_s, 1)}")
         S.append(f"#define PK_NSYS {max(plan.n_sys, 1)}")
+        if os.environ.get("POCKIT_AMD_TRACE", "0") == "1":   # developer tracing of the wave timeline (tools/wave_trace.py)
+            S.append("#define PK_TRACE 1")
+        if os.environ.get("POCKIT_AMD_NT", "0") == "1":      # A/B switch: streaming (nt) output stores, measured slower
+            S.append("#define PK_NT_STORES 1")
         S.append('#include "pk_kernels.hip.h"')
         S.append("namespace pkgen {")
         for k in range(nP):
@@ -334,7 +339,9 @@ class ModelSource:
         # LDS doubles per wave for the staged per-node values
         self.lds_g = 64 * max([1] + [pp.nx for pp in plan.phase_plans])
         self.lds_j = 64 * max([1] + [sum(1 for sg in plan.jac.segs[k] if sg.kind == "I") for k in range(nP)])
-        self.lds_h = 64 * max([1] + [sum(1 for sg in plan.hess.segs[k] if sg.kind == "I") for k in range(nP)])
+        # Hessian: staged segment values + the tile's defect multipliers [state][row]
+        self.lds_h = 64 * max([1] + [pp.nx + sum(1 for sg in plan.hess.segs[k] if sg.kind == "I")
+                                     for k, pp in enumerate(plan.phase_plans)])
         self.lds_x = 64 * max([1] + [pp.nx + sum(1 for sg in plan.jac.segs[k] if sg.kind == "I")
                                      for k, pp in enumerate(plan.phase_plans)])
         self.lds_e = 64 * max([1] + [2 * pp.nx + pp.nu for pp in plan.phase_plans])

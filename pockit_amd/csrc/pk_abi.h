@@ -54,7 +54,13 @@ struct PkTile {
   int32_t iv_off;      // db: values of kind `kid`
   int32_t tv_off;      // db: translation values of kind `kid`
   int32_t full_off;    // db: dense R x K block of kind `kidf`
-  int32_t pad;
+  int32_t pad;         // (device: index of the tile, set by the kernel prologue)
+  // floor(p / d) = umulhi(p, magic) for p < 2^16 with magic = floor((2^32 - 1) / d) + 1: no integer division on
+  // the device for the three per-tile divisors
+  uint32_t magicI;     // d = nnzI   (entries per interval of the integration pattern)
+  uint32_t magicR;     // d = R      (defect rows per interval)
+  uint32_t magicT;     // d = nnzT   (translation entries per interval)
+  int32_t pad2;
 };
 
 // Entry tables of one interval pattern (unit width).
@@ -137,6 +143,7 @@ struct PkArgs {
   const int32_t* csr_seg; // nullptr when no (row, col) repeats: out[p] = in[perm[p]]
   const int32_t* csr_perm;
   double* csr_out;
+  unsigned long long* trace;   // developer tracing (models generated with POCKIT_AMD_TRACE=1): [tile][16] s_memtime marks
   int32_t n_tiles, n_items;
   int32_t n_phase, n;
   int32_t l_s, n_s, n_sys, m;

@@ -33,10 +33,68 @@ struct PkSys {
 
 namespace pk {
 
-__device__ __forceinline__ double wave_sum(double v) {
+// Tables that no kernel ever writes (segment bases, tile records) are read through the constant address
+// space: uniform addresses then become scalar loads (s_load, SGPR results) and -- being invariant -- the
+// compiler may hoist them above stores and barriers instead of paying a vector-memory round trip right before
+// the streaming stores that need them.
+#define PK_CONST_AS __attribute__((address_space(4)))
+typedef const int64_t PK_CONST_AS* pk_cbase_t;
+__device__ __forceinline__ pk_cbase_t const_bases(const int64_t* p) { return (pk_cbase_t)(uintptr_t)p; }
+__device__ __forceinline__ PkTile load_tile(const PkTile* p) {
+  const int32_t PK_CONST_AS* src = (const int32_t PK_CONST_AS*)(uintptr_t)p;
+  PkTile t;
+  int32_t* dst = reinterpret_cast<int32_t*>(&t);
 #pragma unroll
-  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
-  return v;
+  for (int k = 0; k < (int)(sizeof(PkTile) / sizeof(int32_t)); ++k) dst[k] = src[k];
+  return t;
+}
+
+// Developer tracing: PK_MARK(k) stores the shader clock (s_memtime) of lane 0 at checkpoint k of the wave's tile.
+#ifdef PK_TRACE
+#define PK_MARK(k)                                                                                          \
+  do {                                                                                                      \
+    if (A.trace != nullptr && lane == 0 && tl.pad >= 0) A.trace[(size_t)tl.pad * 16 + (k)] = __builtin_readcyclecounter(); \
+  } while (0)
+#else
+#define PK_MARK(k) do { } while (0)
+#endif
+
+// All output stores go through put().  Streaming (`nt`) stores were measured SLOWER than plain stores on
+// MI355X (humanoid 5000x8: pk_hess 15.7 -> 20-22 us, quadrotor pk_xall 7.7 -> 7.9 us): the L2's write
+// combining of the 512-byte runs matters more than the end-of-kernel write-back.  POCKIT_AMD_NT=1 at
+// code-generation time compiles the nt variant for A/B measurements.
+#ifndef PK_NT_STORES
+#define PK_NT_STORES 0
+#endif
+__device__ __forceinline__ void put(double* __restrict__ p, double v) {
+#if PK_NT_STORES
+  __builtin_nontemporal_store(v, p);
+#else
+  *p = v;
+#endif
+}
+
+// Sum over the 64 lanes of a wave, returned in every lane.  Data-parallel-primitive (DPP) moves keep the
+// six steps in the vector ALU (2 v_mov_dpp + 1 v_add_f64 each); the xor-butterfly on __shfl_xor goes through
+// ds_bpermute, whose LDS-path latency made every reduction a ~700-cycle serial chain (wave timeline,
+// tools/wave_trace.py).  Fixed association: pairs, quads, rows of 16, rows 0+1 / 2+3, halves.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ double dpp_take(double v) {
+  const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, ROW_MASK, 0xf, false);
+  const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, ROW_MASK, 0xf, false);
+  return __hiloint2double(hi, lo);
+}
+
+__device__ __forceinline__ double wave_sum(double v) {
+  v += dpp_take<0xb1, 0xf>(v);    // quad_perm [1,0,3,2]
+  v += dpp_take<0x4e, 0xf>(v);    // quad_perm [2,3,0,1]
+  v += dpp_take<0x114, 0xf>(v);   // row_shr:4   (lanes without a source add 0)
+  v += dpp_take<0x118, 0xf>(v);   // row_shr:8   -> lanes 12..15 of every row hold the row sum
+  v += dpp_take<0x142, 0xa>(v);   // row_bcast:15 into rows 1 and 3
+  v += dpp_take<0x143, 0xc>(v);   // row_bcast:31 into rows 2 and 3 -> lane 63 holds the total
+  const int lo = __builtin_amdgcn_readlane(__double2loint(v), 63);
+  const int hi = __builtin_amdgcn_readlane(__double2hiint(v), 63);
+  return __hiloint2double(hi, lo);
 }
 
 // ---- per-phase scalars: static parameters, t0/tf with boundary substitution ------------------
@@ -61,20 +119,23 @@ __device__ __forceinline__ double phase_dt(const PkArgs& A) {
 }
 
 // ---- middle-stage arguments of node q: [x_i(q) | u_j(q) | t(q) | s]  with FIXED/FUNC boundary
-// values substituted (the reference overwrites x in place; we never write to x) ----------------
+// values substituted (the reference overwrites x in place; we never write to x).  Every lane of a wave
+// calls it (indices are clamped), so that the loads of all lanes -- nodes, the LGR end slot one past the
+// tile's last node, idle lanes -- are issued together with the table loads of the tile ------------
 template <class P>
 __device__ __forceinline__ void load_node(const PkArgs& A, const PkPhase& ph, const double* s, double dt,
                                           double mt, int q, double* a, double& tau, double& w) {
   const double* __restrict__ xp = A.x + ph.x_off;
+  const int qs = min(q, ph.state_len - 1), qm = min(q, ph.L_m - 1);
 #pragma unroll
-  for (int i = 0; i < P::NX; ++i) a[i] = xp[i * ph.state_len + q];
+  for (int i = 0; i < P::NX; ++i) a[i] = xp[i * ph.state_len + qs];
   const double* __restrict__ up = xp + P::NX * ph.state_len;
 #pragma unroll
-  for (int i = 0; i < P::NU; ++i) a[P::NX + i] = up[i * ph.L_m + q];
+  for (int i = 0; i < P::NU; ++i) a[P::NX + i] = up[i * ph.L_m + qm];
   if (q == 0) P::fix_front(a, s);
   if (P::SCHEME == 1 && q == ph.L_m - 1) P::fix_back(a, s);
-  tau = A.db[ph.tau_off + q];
-  w = A.db[ph.w_off + q];
+  tau = A.db[ph.tau_off + qm];
+  w = A.db[ph.w_off + qm];
   a[P::NX + P::NU] = (tau - 0.5) * dt + mt;
 #pragma unroll
   for (int i = 0; i < P::NS; ++i) a[P::NX + P::NU + 1 + i] = s[i];
@@ -97,84 +158,199 @@ __device__ __forceinline__ TileGeom tile_geom(const PkTile& tl) {
 
 // ---- shared pieces of the tile kernels ---------------------------------------------------------
 
+// The tile's kind tables, copied to LDS by the wave itself while its node loads are in flight: every
+// table of a pattern with K <= 8 has at most 64 entries (one per lane).  After the barrier the defect,
+// translation and streaming phases then read LDS only -- no dependent global round trips between the
+// evaluation and the stores (measured on MI355X: each such round trip costs the latency-bound kernels
+// 0.6-0.8 us).  Larger K keeps the tables in global memory.
+struct TabRegs {
+  double iv, full, tv, wd;
+  int rc;
+};
+
+struct TileTabs {
+  bool staged;
+  const double* __restrict__ iv;    // LDS copies (valid when staged), [64] each
+  const double* __restrict__ full;
+  const double* __restrict__ tv;
+  const double* __restrict__ wd;
+  const int* __restrict__ rc;       // r | c << 16
+};
+
+__device__ __forceinline__ bool tabs_fit(const PkArgs& A, const PkTile& tl, const TileGeom& g) {
+  return tl.nnzI <= PK_WAVE && g.R * g.K <= PK_WAVE && tl.nnzT <= PK_WAVE && !(A.flags & 4096);
+}
+
+__device__ __forceinline__ TabRegs tabs_issue(const PkArgs& A, const PkPhase& ph, const PkTile& tl, const TileGeom& g,
+                                              bool fit, int lane) {
+  TabRegs t{0.0, 0.0, 0.0, 0.0, 0};
+  if (!fit) return t;
+  if (lane < tl.nnzI) {
+    t.iv = A.db[tl.iv_off + lane];
+    t.rc = A.ib[tl.irc_off + 2 * lane] | (A.ib[tl.irc_off + 2 * lane + 1] << 16);
+  }
+  if (lane < g.R * g.K) t.full = A.db[tl.full_off + lane];
+  if (lane < tl.nnzT) t.tv = A.db[tl.tv_off + lane];
+  if (lane < tl.nj) t.wd = A.db[ph.width_off + tl.j0 + lane];
+  return t;
+}
+
+__device__ __forceinline__ TileTabs tabs_commit(const TabRegs& t, bool fit, int lane) {
+  __shared__ double td[PK_WAVES_PER_BLOCK][4][PK_WAVE];
+  __shared__ int ti[PK_WAVES_PER_BLOCK][PK_WAVE];
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  if (fit) {
+    td[wave][0][lane] = t.iv;
+    td[wave][1][lane] = t.full;
+    td[wave][2][lane] = t.tv;
+    td[wave][3][lane] = t.wd;
+    ti[wave][lane] = t.rc;
+  }
+  return TileTabs{fit, td[wave][0], td[wave][1], td[wave][2], td[wave][3], ti[wave]};
+}
+
+// x at the end slot of the interval whose defect row this lane writes after the barrier: lane (jj+1)*stride of
+// the wave holds it (every lane loaded its clamped slot); only a full LGR tile (64 nodes) reaches past the wave
+template <class P>
+__device__ __forceinline__ void defect_ends(const PkArgs& A, const PkPhase& ph, const PkTile& tl, const TileGeom& g,
+                                            const double* a, double* xe, int lane) {
+  const int jj = min((int)__umulhi((uint32_t)lane, tl.magicR), max(tl.nj - 1, 0));
+  const int src = (jj + 1) * g.stride;
+#pragma unroll
+  for (int i = 0; i < P::NX; ++i) xe[i] = __shfl(a[i], src & (PK_WAVE - 1), PK_WAVE);
+  if (src >= PK_WAVE && lane < tl.nj * g.R) {
+    const double* __restrict__ xp = A.x + ph.x_off;
+#pragma unroll
+    for (int i = 0; i < P::NX; ++i) xe[i] = xp[i * ph.state_len + tl.q0 + src];
+  }
+}
+
+// one defect row: acc_i += sum_c (I_hat[r, c] * d / 2) * f_i(c), K known at compile time
+template <class P, int K>
+__device__ __forceinline__ void defect_dot(const double* __restrict__ full, const double* __restrict__ f, double width,
+                                           double* acc) {
+  double a[K];
+#pragma unroll
+  for (int c = 0; c < K; ++c) a[c] = full[c] * width * 0.5;      // (I_hat * d) / 2 as the reference scales it
+#pragma unroll
+  for (int c = 0; c < K; ++c) {
+#pragma unroll
+    for (int i = 0; i < P::NX; ++i) acc[i] += a[c] * f[i * PK_WAVE + c];
+  }
+}
+
 // collocation defects of the tile's rows:  (x_q - x_end) - dt * sum_c (I_hat[r,c] d/2) f_i(c)
 // f staged in LDS as fsv[i * 64 + lane]                  (phasebase.py:1008-1012; batched small GEMV)
 template <class P>
 __device__ __forceinline__ void write_defects(const PkArgs& A, const PkPhase& ph, const PkTile& tl,
-                                              const TileGeom& g, const double* s, double dt,
-                                              const double* __restrict__ fsv, const double* xr, int lane) {
+                                              const TileGeom& g, const TileTabs& T, const double* s, double dt,
+                                              const double* __restrict__ fsv, const double* xr, double* xe,
+                                              int lane) {
   const int nrows = tl.nj * g.R;
   if (lane >= nrows) return;
-  const int jj = lane / g.R, r = lane - jj * g.R;
-  const double* __restrict__ full = A.db + tl.full_off + r * g.K;
-  const double width = A.db[ph.width_off + tl.j0 + jj];
+  const int jj = (int)__umulhi((uint32_t)lane, tl.magicR), r = lane - jj * g.R;
   const int endslot = tl.q0 + (jj + 1) * g.stride;
   const int back_slot = P::SCHEME ? ph.L_m - 1 : ph.L_m;
-  const double* __restrict__ xp = A.x + ph.x_off;
   const double* __restrict__ f = fsv + jj * g.stride;
-  double acc[P::NX], xe[P::NX];
+  double acc[P::NX];
 #pragma unroll
-  for (int i = 0; i < P::NX; ++i) {
-    acc[i] = 0.0;
-    xe[i] = xp[i * ph.state_len + endslot];
-  }
+  for (int i = 0; i < P::NX; ++i) acc[i] = 0.0;
+  if (T.staged) {
+    const double width = T.wd[jj];
+    const double* __restrict__ full = T.full + r * g.K;
+    switch (g.K) {   // K <= 8 here: fully unrolled so that all LDS reads of a row are in flight together
+      case 1: defect_dot<P, 1>(full, f, width, acc); break;
+      case 2: defect_dot<P, 2>(full, f, width, acc); break;
+      case 3: defect_dot<P, 3>(full, f, width, acc); break;
+      case 4: defect_dot<P, 4>(full, f, width, acc); break;
+      case 5: defect_dot<P, 5>(full, f, width, acc); break;
+      case 6: defect_dot<P, 6>(full, f, width, acc); break;
+      case 7: defect_dot<P, 7>(full, f, width, acc); break;
+      default: defect_dot<P, 8>(full, f, width, acc); break;
+    }
+  } else {
+    const double* __restrict__ full = A.db + tl.full_off + r * g.K;
+    const double width = A.db[ph.width_off + tl.j0 + jj];
 #pragma unroll 4
-  for (int c = 0; c < g.K; ++c) {
-    const double a = full[c] * width * 0.5;      // (I_hat * d) / 2 as the reference scales it
+    for (int c = 0; c < g.K; ++c) {
+      const double a = full[c] * width * 0.5;      // (I_hat * d) / 2 as the reference scales it
 #pragma unroll
-    for (int i = 0; i < P::NX; ++i) acc[i] += a * f[i * PK_WAVE + c];
+      for (int i = 0; i < P::NX; ++i) acc[i] += a * f[i * PK_WAVE + c];
+    }
   }
 #pragma unroll
   for (int i = 0; i < P::NX; ++i) {
     if (endslot == back_slot) xe[i] = P::back_value(i, xe[i], s);
-    A.o_g[ph.g_off + i * ph.L_d + tl.r0 + lane] = (xr[i] - xe[i]) - acc[i] * dt;
+    put(&A.o_g[ph.g_off + i * ph.L_d + tl.r0 + lane], (xr[i] - xe[i]) - acc[i] * dt);
   }
 }
 
 // constant translation entries of every state (phasebase.py:1077)
 template <class P>
-__device__ __forceinline__ void write_translation(const PkArgs& A, const PkPhase& ph, const PkTile& tl, int lane) {
+__device__ __forceinline__ void write_translation(const PkArgs& A, const PkPhase& ph, const PkTile& tl,
+                                                  const TileTabs& T, int lane) {
   const int tot = tl.nj * tl.nnzT;
-  const double* __restrict__ tv = A.db + tl.tv_off;
-  const int64_t* __restrict__ tb = A.lb + ph.jt_off;
+  const double* __restrict__ tvg = A.db + tl.tv_off;
+  pk_cbase_t tb = const_bases(A.lb + ph.jt_off);
   for (int p = lane; p < tot; p += PK_WAVE) {
-    const double v = tv[p % tl.nnzT];
+    const int t = p - (int)__umulhi((uint32_t)p, tl.magicT) * tl.nnzT;
+    const double v = T.staged ? T.tv[t] : tvg[t];
 #pragma unroll
-    for (int i = 0; i < P::NX; ++i) A.o_jac[tb[i] + tl.offT + p] = v;
+    for (int i = 0; i < P::NX; ++i) put(&A.o_jac[tb[i] + tl.offT + p], v);
   }
 }
 
 // streaming phase: out[base_e + offI + p] = -(I_hat[t] d/2) * sv_e[col(p)] (* lambda[row(p)])
 // (phasebase.py:1120-1124 and 1280-1285 -- the gather-multiply-concatenate that dominates the reference)
-template <class P, int NI, bool HESS>
-__device__ __forceinline__ void stream_expanded(const PkArgs& A, const PkPhase& ph, const PkTile& tl,
-                                                const TileGeom& g, const double* __restrict__ sv,
-                                                const int64_t* __restrict__ segb, double* __restrict__ out,
-                                                int lane) {
-  if (NI == 0) return;
+// lam_s: the tile's multiplier rows staged in LDS as lam_s[state * 64 + row]   (Hessian only)
+template <class P, int NI, bool HESS, bool STAGED>
+__device__ __forceinline__ void stream_loop(const PkArgs& A, const PkPhase& ph, const PkTile& tl, const TileGeom& g,
+                                            const TileTabs& T, const double* __restrict__ sv,
+                                            const double* __restrict__ lam_s, pk_cbase_t segb,
+                                            double* __restrict__ out, int lane) {
   const int nnz = tl.nnzI;
   const int tot = tl.nj * nnz;
-  if (tot == 0) return;
-  const int32_t* __restrict__ rc = A.ib + tl.irc_off;
-  const double* __restrict__ iv = A.db + tl.iv_off;
-  const double* __restrict__ wd = A.db + ph.width_off + tl.j0;
-  const uint32_t magic = 0xFFFFFFFFu / (uint32_t)nnz + 1u;   // p / nnz for p < 2^16
+  const int32_t* __restrict__ rcg = A.ib + tl.irc_off;
+  const double* __restrict__ ivg = A.db + tl.iv_off;
+  const double* __restrict__ wdg = A.db + ph.width_off + tl.j0;
   for (int p = lane; p < tot; p += PK_WAVE) {
-    const int jj = (int)__umulhi((uint32_t)p, magic);
+    const int jj = (int)__umulhi((uint32_t)p, tl.magicI);   // p / nnz (p < 2^16)
     const int t = p - jj * nnz;
-    const int r = rc[2 * t], c = rc[2 * t + 1];
-    const double val = -(iv[t] * wd[jj] * 0.5);
+    int r, c;
+    double val;
+    if (STAGED) {
+      const int rc = T.rc[t];
+      r = rc & 0xFFFF;
+      c = rc >> 16;
+      val = -(T.iv[t] * T.wd[jj] * 0.5);
+    } else {
+      r = rcg[2 * t];
+      c = rcg[2 * t + 1];
+      val = -(ivg[t] * wdg[jj] * 0.5);
+    }
     const double* __restrict__ col = sv + jj * g.stride + c;
     const size_t at = (size_t)tl.offI + p;
     if (HESS) {
-      const double* __restrict__ lam = A.lam + ph.g_off + tl.r0 + jj * g.R + r;
+      const double* __restrict__ lam = lam_s + jj * g.R + r;
 #pragma unroll
-      for (int e = 0; e < NI; ++e) out[segb[e] + at] = val * lam[P::H_state(e) * ph.L_d] * col[e * PK_WAVE];
+      for (int e = 0; e < NI; ++e) put(&out[segb[e] + at], val * lam[P::H_state(e) * PK_WAVE] * col[e * PK_WAVE]);
     } else {
 #pragma unroll
-      for (int e = 0; e < NI; ++e) out[segb[e] + at] = val * col[e * PK_WAVE];
+      for (int e = 0; e < NI; ++e) put(&out[segb[e] + at], val * col[e * PK_WAVE]);
     }
   }
+}
+
+template <class P, int NI, bool HESS>
+__device__ __forceinline__ void stream_expanded(const PkArgs& A, const PkPhase& ph, const PkTile& tl,
+                                                const TileGeom& g, const TileTabs& T, const double* __restrict__ sv,
+                                                const double* __restrict__ lam_s, pk_cbase_t segb,
+                                                double* __restrict__ out, int lane) {
+  if (NI == 0 || tl.nj * tl.nnzI == 0) return;
+  if (T.staged)
+    stream_loop<P, NI, HESS, true>(A, ph, tl, g, T, sv, lam_s, segb, out, lane);
+  else
+    stream_loop<P, NI, HESS, false>(A, ph, tl, g, T, sv, lam_s, segb, out, lane);
 }
 
 // per-node gradient entries: own variable slots directly, shared slots into orr   (systembase.py:646-657)
@@ -190,9 +366,9 @@ __device__ __forceinline__ void node_gradient(const PkArgs& A, const PkPhase& ph
     P::mid_grad(a, tau, dt, w, sy, nullptr, ov, orr);
   double* __restrict__ gp = A.o_grad + ph.x_off;
 #pragma unroll
-  for (int i = 0; i < P::NX; ++i) gp[i * ph.state_len + q] = ov[i];
+  for (int i = 0; i < P::NX; ++i) put(&gp[i * ph.state_len + q], ov[i]);
 #pragma unroll
-  for (int i = 0; i < P::NU; ++i) gp[P::NX * ph.state_len + i * ph.L_m + q] = ov[P::NX + i];
+  for (int i = 0; i < P::NU; ++i) put(&gp[P::NX * ph.state_len + i * ph.L_m + q], ov[P::NX + i]);
 }
 
 // ============================================================================================
@@ -233,24 +409,27 @@ __device__ __forceinline__ void tile_g(const PkArgs& A, const PkTile& tl, double
   const TileGeom g = tile_geom<P>(tl);
   double s[PK_NS], dt, mt;
   phase_scalars<P>(A, ph, s, dt, mt);
-  double xr[P::NX];
+  const bool fit = tabs_fit(A, tl, g);
+  const TabRegs tr = tabs_issue(A, ph, tl, g, fit, lane);
+  const int q = tl.q0 + lane;
+  double a[P::NARG], tau, w, xr[P::NX], xe[P::NX];
+  load_node<P>(A, ph, s, dt, mt, q, a, tau, w);
+  const TileTabs T = tabs_commit(tr, fit, lane);
+  defect_ends<P>(A, ph, tl, g, a, xe, lane);
+#pragma unroll
+  for (int i = 0; i < P::NX; ++i) xr[i] = a[i];
   if (lane < g.nq) {
-    const int q = tl.q0 + lane;
-    double a[P::NARG], tau, w, o[P::G_NOUT];
-    load_node<P>(A, ph, s, dt, mt, q, a, tau, w);
+    double o[P::G_NOUT];
     P::mid_g(a, o);
 #pragma unroll
-    for (int i = 0; i < P::NX; ++i) {
-      sv[i * PK_WAVE + lane] = o[i];
-      xr[i] = a[i];
-    }
+    for (int i = 0; i < P::NX; ++i) sv[i * PK_WAVE + lane] = o[i];
     if (lane < g.nown) {
 #pragma unroll
-      for (int j = 0; j < P::NC; ++j) A.o_g[ph.path_off + j * ph.L_m + q] = o[P::NX + j];
+      for (int j = 0; j < P::NC; ++j) put(&A.o_g[ph.path_off + j * ph.L_m + q], o[P::NX + j]);
     }
   }
   __syncthreads();
-  write_defects<P>(A, ph, tl, g, s, dt, sv, xr, lane);
+  write_defects<P>(A, ph, tl, g, T, s, dt, sv, xr, xe, lane);
 }
 
 // ============================================================================================
@@ -291,23 +470,27 @@ __device__ __forceinline__ void tile_jac(const PkArgs& A, const PkTile& tl, doub
   double s[PK_NS], dt, mt;
   phase_scalars<P>(A, ph, s, dt, mt);
   const PkSys sy{s, A.Ibuf, A.sigma, A.lam};
-  const int64_t* __restrict__ segb = A.lb + ph.jseg_off;
+  pk_cbase_t segb = const_bases(A.lb + ph.jseg_off);
+  const bool fit = tabs_fit(A, tl, g);
+  const TabRegs tr = tabs_issue(A, ph, tl, g, fit, lane);
+  const int q = tl.q0 + lane;
+  double a[P::NARG], tau, w;
+  load_node<P>(A, ph, s, dt, mt, q, a, tau, w);
+  const TileTabs T = tabs_commit(tr, fit, lane);
   if (lane < g.nq) {
-    const int q = tl.q0 + lane;
-    double a[P::NARG], tau, w, o[P::J_NI + P::J_NN + 1];
-    load_node<P>(A, ph, s, dt, mt, q, a, tau, w);
+    double o[P::J_NI + P::J_NN + 1];
     P::mid_jac(a, tau, dt, w, sy, nullptr, o);
 #pragma unroll
     for (int e = 0; e < P::J_NI; ++e) sv[e * PK_WAVE + lane] = o[e];
     if (lane < g.nown && q >= ph.mid_lo && q < ph.mid_hi) {
 #pragma unroll
-      for (int e = 0; e < P::J_NN; ++e) A.o_jac[segb[P::J_NI + e] + (q - ph.mid_lo)] = o[P::J_NI + e];
+      for (int e = 0; e < P::J_NN; ++e) put(&A.o_jac[segb[P::J_NI + e] + (q - ph.mid_lo)], o[P::J_NI + e]);
     }
   }
   __syncthreads();
   if (tl.nj == 0) return;
-  write_translation<P>(A, ph, tl, lane);
-  stream_expanded<P, P::J_NI, false>(A, ph, tl, g, sv, segb, A.o_jac, lane);
+  write_translation<P>(A, ph, tl, T, lane);
+  stream_expanded<P, P::J_NI, false>(A, ph, tl, g, T, sv, nullptr, segb, A.o_jac, lane);
 }
 
 // ============================================================================================
@@ -321,24 +504,34 @@ __device__ __forceinline__ void tile_hess(const PkArgs& A, const PkTile& tl, dou
   double s[PK_NS], dt, mt;
   phase_scalars<P>(A, ph, s, dt, mt);
   const PkSys sy{s, A.Ibuf, A.sigma, A.lam};
-  const int64_t* __restrict__ segb = A.lb + ph.hseg_off;
-  if (lane < g.nq) {
-    const int q = tl.q0 + lane;
-    double a[P::NARG], tau, w, o[P::H_NI + P::H_NN + 1], lp[P::NC > 0 ? P::NC : 1];
-    load_node<P>(A, ph, s, dt, mt, q, a, tau, w);
+  pk_cbase_t segb = const_bases(A.lb + ph.hseg_off);
+  double* __restrict__ lam_s = sv + P::H_NI * PK_WAVE;       // the tile's defect multipliers, [state][row]
+  const bool fit = tabs_fit(A, tl, g);
+  const TabRegs tr = tabs_issue(A, ph, tl, g, fit, lane);
+  const int q = tl.q0 + lane;
+  double a[P::NARG], tau, w, lp[P::NC > 0 ? P::NC : 1], lrow[P::NX];
+  const int row = min(tl.r0 + lane, ph.L_d - 1);
 #pragma unroll
-    for (int j = 0; j < P::NC; ++j) lp[j] = A.lam[ph.path_off + j * ph.L_m + q];
+  for (int i = 0; i < P::NX; ++i) lrow[i] = A.lam[ph.g_off + i * ph.L_d + row];
+  load_node<P>(A, ph, s, dt, mt, q, a, tau, w);
+#pragma unroll
+  for (int j = 0; j < P::NC; ++j) lp[j] = A.lam[ph.path_off + j * ph.L_m + min(q, ph.L_m - 1)];
+  const TileTabs T = tabs_commit(tr, fit, lane);
+#pragma unroll
+  for (int i = 0; i < P::NX; ++i) lam_s[i * PK_WAVE + lane] = lrow[i];
+  if (lane < g.nq) {
+    double o[P::H_NI + P::H_NN + 1];
     P::mid_hess(a, tau, dt, w, sy, lp, o);
 #pragma unroll
     for (int e = 0; e < P::H_NI; ++e) sv[e * PK_WAVE + lane] = o[e];
     if (lane < g.nown && q >= ph.mid_lo && q < ph.mid_hi) {
 #pragma unroll
-      for (int e = 0; e < P::H_NN; ++e) A.o_hess[segb[P::H_NI + e] + (q - ph.mid_lo)] = o[P::H_NI + e];
+      for (int e = 0; e < P::H_NN; ++e) put(&A.o_hess[segb[P::H_NI + e] + (q - ph.mid_lo)], o[P::H_NI + e]);
     }
   }
   __syncthreads();
   if (tl.nj == 0) return;
-  stream_expanded<P, P::H_NI, true>(A, ph, tl, g, sv, segb, A.o_hess, lane);
+  stream_expanded<P, P::H_NI, true>(A, ph, tl, g, T, sv, lam_s, segb, A.o_hess, lane);
 }
 
 // ============================================================================================
@@ -351,37 +544,43 @@ __device__ __forceinline__ void tile_xall(const PkArgs& A, const PkTile& tl, dou
                                           double* __restrict__ wint, double* __restrict__ wgrad, int lane) {
   const PkPhase& ph = A.ph[P::INDEX];
   const TileGeom g = tile_geom<P>(tl);
+  PK_MARK(0);
   double s[PK_NS], dt, mt;
   phase_scalars<P>(A, ph, s, dt, mt);
   const PkSys sy{s, A.Ibuf, A.sigma, A.lam};
-  const int64_t* __restrict__ segb = A.lb + ph.jseg_off;
+  pk_cbase_t segb = const_bases(A.lb + ph.jseg_off);
   double* __restrict__ jsv = sv + P::NX * PK_WAVE;
-  double xr[P::NX];
+  const bool fit = tabs_fit(A, tl, g);
+  const TabRegs tr = tabs_issue(A, ph, tl, g, fit, lane);
+  const int q = tl.q0 + lane;
+  double a[P::NARG], tau, w, xr[P::NX], xe[P::NX];
+  load_node<P>(A, ph, s, dt, mt, q, a, tau, w);
+  const TileTabs T = tabs_commit(tr, fit, lane);
+  PK_MARK(1);
+  defect_ends<P>(A, ph, tl, g, a, xe, lane);
+#pragma unroll
+  for (int i = 0; i < P::NX; ++i) xr[i] = a[i];
   double oi[P::INT_N > 0 ? P::INT_N : 1], orr[P::GR_NR > 0 ? P::GR_NR : 1];
 #pragma unroll
   for (int r = 0; r < P::INT_N; ++r) oi[r] = 0.0;
 #pragma unroll
   for (int r = 0; r < P::GR_NR; ++r) orr[r] = 0.0;
   if (lane < g.nq && !(A.flags & 512)) {   // (bit 9: diagnostic switch, skip the evaluation phase)
-    const int q = tl.q0 + lane;
-    double a[P::NARG], tau, w;
     double og[P::G_NOUT], oj[P::J_NI + P::J_NN + 1], ov[P::NX + P::NU], ot[P::GR_NR > 0 ? P::GR_NR : 1],
         op[P::INT_N > 0 ? P::INT_N : 1];
-    load_node<P>(A, ph, s, dt, mt, q, a, tau, w);
+    PK_MARK(2);
     P::mid_xall(a, tau, dt, w, sy, og, oj, ov, ot, op);
+    PK_MARK(3);
 #pragma unroll
-    for (int i = 0; i < P::NX; ++i) {
-      sv[i * PK_WAVE + lane] = og[i];
-      xr[i] = a[i];
-    }
+    for (int i = 0; i < P::NX; ++i) sv[i * PK_WAVE + lane] = og[i];
 #pragma unroll
     for (int e = 0; e < P::J_NI; ++e) jsv[e * PK_WAVE + lane] = oj[e];
     if (lane < g.nown) {
 #pragma unroll
-      for (int j = 0; j < P::NC; ++j) A.o_g[ph.path_off + j * ph.L_m + q] = og[P::NX + j];
+      for (int j = 0; j < P::NC; ++j) put(&A.o_g[ph.path_off + j * ph.L_m + q], og[P::NX + j]);
       if (q >= ph.mid_lo && q < ph.mid_hi) {
 #pragma unroll
-        for (int e = 0; e < P::J_NN; ++e) A.o_jac[segb[P::J_NI + e] + (q - ph.mid_lo)] = oj[P::J_NI + e];
+        for (int e = 0; e < P::J_NN; ++e) put(&A.o_jac[segb[P::J_NI + e] + (q - ph.mid_lo)], oj[P::J_NI + e]);
       }
 #pragma unroll
       for (int r = 0; r < P::INT_N; ++r) oi[r] = op[r] * w;
@@ -400,12 +599,21 @@ __device__ __forceinline__ void tile_xall(const PkArgs& A, const PkTile& tl, dou
     const double v = wave_sum(orr[r]);
     if (lane == 0) wgrad[r] = v;
   }
+  PK_MARK(4);
   __syncthreads();
-  if (A.flags & 256) return;   // diagnostic build switch: skip the streaming phase
-  write_defects<P>(A, ph, tl, g, s, dt, sv, xr, lane);
+  PK_MARK(5);
+  if (A.flags & 256) return;   // diagnostic build switches: skip the phases after the barrier (all / one by one)
+  if (!(A.flags & 8192)) write_defects<P>(A, ph, tl, g, T, s, dt, sv, xr, xe, lane);
+  PK_MARK(6);
   if (tl.nj == 0) return;
-  write_translation<P>(A, ph, tl, lane);
-  stream_expanded<P, P::J_NI, false>(A, ph, tl, g, jsv, segb, A.o_jac, lane);
+  if (!(A.flags & 16384)) write_translation<P>(A, ph, tl, T, lane);
+  PK_MARK(7);
+  if (!(A.flags & 32768)) stream_expanded<P, P::J_NI, false>(A, ph, tl, g, T, jsv, nullptr, segb, A.o_jac, lane);
+  PK_MARK(8);
+#ifdef PK_TRACE
+  __builtin_amdgcn_s_waitcnt(0);      // all stores acknowledged
+  PK_MARK(9);
+#endif
 }
 
 // ============================================================================================
@@ -421,7 +629,7 @@ __device__ __forceinline__ void tile_aux(const PkArgs& A, const PkTile& tl, doub
   double s[PK_NS], dt, mt;
   phase_scalars<P>(A, ph, s, dt, mt);
   const PkSys sy{s, A.Ibuf, A.sigma, A.lam};
-  const int64_t* __restrict__ segb = A.lb + ph.aseg_off;
+  pk_cbase_t segb = const_bases(A.lb + ph.aseg_off);
   if (lane < g.nown) {
     const int q = tl.q0 + lane;
     if (q >= ph.mid_lo && q < ph.mid_hi) {
@@ -474,7 +682,7 @@ __device__ __forceinline__ void tile_hessc(const PkArgs& A, const PkTile& tl, do
   double s[PK_NS], dt, mt;
   phase_scalars<P>(A, ph, s, dt, mt);
   const PkSys sy{s, A.Ibuf, A.sigma, A.lam};
-  const int64_t* __restrict__ segb = A.lb + ph.hcseg_off;
+  pk_cbase_t segb = const_bases(A.lb + ph.hcseg_off);
   if (lane < g.nown) {
     const int q = tl.q0 + lane;
     if (q >= ph.mid_lo && q < ph.mid_hi) {
@@ -599,15 +807,19 @@ __device__ __forceinline__ double block_sum_partials(const PkArgs& A, const doub
   extern __shared__ double pk_lds[];                                                  \
   __shared__ double wint[PK_WAVES_PER_BLOCK * PK_NRED];                               \
   __shared__ double wgrad[PK_WAVES_PER_BLOCK * PK_NRED];                              \
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;                         \
+  /* wave-uniform on purpose (readfirstlane): the tile record then comes through the scalar cache into */ \
+  /* SGPRs and everything derived from it is scalar arithmetic */                      \
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63; \
   const int blk = (int)blockIdx.x - (EDGE);                                           \
   const int ti = blk * PK_WAVES_PER_BLOCK + wave;                                     \
   PkTile tl;                                                                          \
   if (ti < A.n_tiles) {                                                               \
-    tl = A.tile[ti];                                                                  \
+    tl = load_tile(A.tile + ti);                                                      \
+    tl.pad = ti;                                                                      \
   } else {                                                                            \
-    tl = A.tile[A.n_tiles > 0 ? A.n_tiles - 1 : 0];                                   \
+    tl = load_tile(A.tile + (A.n_tiles > 0 ? A.n_tiles - 1 : 0));                     \
     tl.nj = 0;                                                                        \
+    tl.pad = -1;                                                                      \
   }                                                                                   \
   if (lane < PK_NRED) {                                                               \
     wint[wave * PK_NRED + lane] = 0.0;                                                \
@@ -792,7 +1004,7 @@ __device__ __forceinline__ void interval_err(const PkArgs& A, const PkErrIv& iv,
 template <class Gen>
 __device__ __forceinline__ void kernel_err(const PkArgs& A) {
   extern __shared__ double pk_lds[];
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
   const int g = (int)blockIdx.x * PK_WAVES_PER_BLOCK + wave;
   const bool valid = g < A.n_erriv;
   // a workgroup never mixes phases (the host pads every phase to a multiple of 4 intervals with K = 0 records)
@@ -868,13 +1080,21 @@ __device__ __forceinline__ void kernel_outer(const PkArgs& A) {
 
 template <class Gen>
 __device__ __forceinline__ void kernel_xall(const PkArgs& A) {
+#ifdef PK_TRACE
+  const unsigned long long t_entry = __builtin_readcyclecounter();
+#endif
   if (A.flags & 1024) return;                                   // diagnostic switches (POCKIT_AMD_DEBUG_FLAGS)
   if (PK_IS_EDGE_BLOCK() && (A.flags & 2048)) return;
   if (PK_IS_EDGE_BLOCK()) return edge_block<Gen>(A, 0, true);
   PK_TILE_PROLOGUE(1);
+#ifdef PK_TRACE
+  if (A.trace != nullptr && lane == 0 && tl.pad >= 0) A.trace[(size_t)tl.pad * 16 + 10] = t_entry;
+#endif
+  PK_MARK(11);
   Gen::tile_xall(tl.phase, A, tl, pk_lds + wave * Gen::LDS_X, wint + wave * PK_NRED, wgrad + wave * PK_NRED, lane);
   publish_block_partials(A.partial, wint, blk);
   publish_block_partials(A.partial2, wgrad, blk);
+  PK_MARK(12);
 }
 
 // The reductions over all workgroups, by ONE workgroup (all 256 threads must call it).

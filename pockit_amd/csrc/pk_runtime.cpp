@@ -81,6 +81,7 @@ struct pk_ctx {
              sigma == o.sigma && st == o.st;
     }
   } cyc_key{};
+  unsigned long long* d_trace = nullptr;   // developer tracing buffer, [n_tiles][16]
   // triplet -> CSR maps (pk_set_csr_map): [0] Jacobian, [1] Hessian of the Lagrangian (lower triangle)
   struct CsrMap {
     int32_t *d_seg = nullptr, *d_perm = nullptr;
@@ -144,6 +145,7 @@ void free_problem(pk_ctx* c) {
   release(c->d_erriv); release(c->d_errdb); release(c->d_errT); release(c->d_errI);
   c->n_erriv = 0; c->n_err_out = 0;
   drop_cycle_graph(c);
+  release(c->d_trace);
   for (auto& m : c->csr) { release(m.d_seg); release(m.d_perm); release(m.d_vals); m.n_unique = m.n_triplets = 0; }
   release(c->d_ib); release(c->d_db); release(c->d_lb);
   release(c->d_x); release(c->d_lam); release(c->d_f); release(c->d_grad); release(c->d_g); release(c->d_J);
@@ -184,6 +186,7 @@ PkArgs base_args(pk_ctx* c, const double* d_x, const double* d_lam, double sigma
   A.l_s = c->l_s; A.n_s = c->n_s; A.n_sys = c->n_sys; A.m = c->m;
   A.gz_off = c->gz_off; A.n_gz = c->n_gz; A.flags = c->shard_flags | c->debug_flags;
   for (size_t k = 0; k < c->h_phases.size(); ++k) A.ph[k] = c->h_phases[k];
+  A.trace = c->d_trace;
   return A;
 }
 
@@ -272,7 +275,7 @@ int pk_create(pk_ctx** out, int device_id) {
   if (device_id < 0 || device_id >= ndev) return fail(nullptr, 11, "pk_create: device %d out of range [0,%d)", device_id, ndev);
   pk_ctx* c = new pk_ctx();
   c->device = device_id;
-  if (const char* dbg = getenv("POCKIT_AMD_DEBUG_FLAGS")) c->debug_flags = atoi(dbg) & (256 | 512 | 1024 | 2048);
+  if (const char* dbg = getenv("POCKIT_AMD_DEBUG_FLAGS")) c->debug_flags = atoi(dbg) & (256 | 512 | 1024 | 2048 | 4096 | 8192 | 16384 | 32768);
   if ((e = hipSetDevice(device_id)) != hipSuccess || (e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)) != hipSuccess) {
     int rc = fail(nullptr, 12, "pk_create: %s", hipGetErrorString(e));
     delete c;
@@ -824,6 +827,25 @@ int pk_profile(pk_ctx* c, int enable) {
   if (!c) return fail(nullptr, 1, "null context");
   c->profiling = enable != 0;
   c->profile_mask = (unsigned)enable;   /* bit k set: time kernel id k */
+  return 0;
+}
+
+// developer tracing (models generated with POCKIT_AMD_TRACE=1): per-tile s_memtime marks of the last launch
+int pk_trace_read(pk_ctx* c, uint64_t* out, int64_t count) {
+  int rc = ready(c);
+  if (rc) return rc;
+  const int64_t need = (int64_t)c->n_tiles * 16;
+  PK_HIP(c, hipSetDevice(c->device));
+  if (!c->d_trace) {
+    PK_HIP(c, hipStreamSynchronize(c->stream));
+    PK_HIP(c, hipMalloc((void**)&c->d_trace, sizeof(uint64_t) * (size_t)(need ? need : 1)));
+    PK_HIP(c, hipMemset(c->d_trace, 0, sizeof(uint64_t) * (size_t)(need ? need : 1)));
+    drop_cycle_graph(c);
+    return 0;          // first call only arms the buffer
+  }
+  if (!out || count < need) return fail(c, 72, "pk_trace_read: need room for %lld marks", (long long)need);
+  PK_HIP(c, hipDeviceSynchronize());
+  PK_HIP(c, hipMemcpy(out, c->d_trace, sizeof(uint64_t) * (size_t)need, hipMemcpyDeviceToHost));
   return 0;
 }
 

@@ -104,6 +104,9 @@ class Tables:
                 for f in ("nnzI", "nnzT", "irc_off", "iv_off", "tv_off"):
                     rec[f] = kinds[kind0 + kid][f]
                 rec["full_off"] = kinds[kind0 + kidf]["full_off"]
+                R = int(kinds[kind0 + kidf]["R"])
+                for field, d in (("magicI", int(rec["nnzI"])), ("magicR", R), ("magicT", int(rec["nnzT"]))):
+                    rec[field] = (0xFFFFFFFF // d + 1) & 0xFFFFFFFF if d > 0 else 0
                 tiles.append(rec)
             while len(tiles) % runtime.WAVES_PER_BLOCK:      # a workgroup never mixes phases: pad with empty tiles
                 rec = np.zeros((), dtype=runtime.TILE_DTYPE)

@@ -47,8 +47,8 @@ PHASE_FIELDS = ["scheme", "n_x", "n_u", "n_c", "L_m", "L_d", "state_len", "L", "
                 "hseg_off", "red_off", "aseg_off", "hcseg_off", "ivK_off", "ivfull_off", "ivld_off", "n_int"]
 PHASE_DTYPE = np.dtype([(n, np.int32) for n in PHASE_FIELDS])
 TILE_FIELDS = ["phase", "j0", "nj", "kid", "kidf", "q0", "r0", "offI", "offT", "K", "last",
-               "nnzI", "nnzT", "irc_off", "iv_off", "tv_off", "full_off", "pad"]
-TILE_DTYPE = np.dtype([(n, np.int32) for n in TILE_FIELDS])
+               "nnzI", "nnzT", "irc_off", "iv_off", "tv_off", "full_off", "pad", "magicI", "magicR", "magicT", "pad2"]
+TILE_DTYPE = np.dtype([(n, np.uint32 if n.startswith("magic") else np.int32) for n in TILE_FIELDS])
 KIND_FIELDS = ["K", "R", "nnzI", "nnzT", "irc_off", "iv_off", "tv_off", "full_off"]
 KIND_DTYPE = np.dtype([(n, np.int32) for n in KIND_FIELDS])
 ITEM_DTYPE = np.dtype([("pos", np.int64), ("coef", np.float64), ("eid", np.int32), ("lam", np.int32)])
@@ -68,7 +68,7 @@ EXPORTS = ["pk_create", "pk_destroy", "pk_last_error", "pk_device_count", "pk_lo
            "pk_prepare_x", "pk_fetch", "pk_eval_hess_prepared", "pk_host_buffer", "pk_eval_hessc", "pk_eval_hessc_dev",
            "pk_set_mesh_error_tables", "pk_eval_mesh_error", "pk_eval_mesh_error_dev", "pk_set_cycle_graph", "pk_profile_sampling",
            "pk_set_csr_map", "pk_gather_csr_dev", "pk_eval_jac_csr_dev", "pk_eval_hess_csr_dev", "pk_eval_jac_csr",
-           "pk_eval_hess_csr"]
+           "pk_eval_hess_csr", "pk_trace_read"]
 
 _lib = None
 
@@ -140,6 +140,7 @@ def load_library():
     lib.pk_eval_hess_csr_dev.argtypes = [vp, vp, vp, C.c_double, vp, vp]
     lib.pk_eval_jac_csr.argtypes = [vp, dp, dp]
     lib.pk_eval_hess_csr.argtypes = [vp, dp, dp, C.c_double, dp]
+    lib.pk_trace_read.argtypes = [vp, C.POINTER(C.c_uint64), C.c_int64]
     lib.pk_eval_f_dev.argtypes = [vp, vp, vp, vp]
     lib.pk_eval_grad_dev.argtypes = [vp, vp, vp, vp]
     lib.pk_eval_g_dev.argtypes = [vp, vp, vp, vp]

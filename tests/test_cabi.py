@@ -24,9 +24,9 @@ def test_library_exports_every_declared_symbol():
 
 
 def test_struct_sizes_match_the_c_abi():
-    # csrc/pk_abi.h: PkPhase 28 ints, PkTile 18 ints, PkKind 8 ints, PkItem {int64, double, int32, int32}
+    # csrc/pk_abi.h: PkPhase 28 ints, PkTile 22 ints, PkKind 8 ints, PkItem {int64, double, int32, int32}
     assert runtime.PHASE_DTYPE.itemsize == 28 * 4
-    assert runtime.TILE_DTYPE.itemsize == 18 * 4
+    assert runtime.TILE_DTYPE.itemsize == 22 * 4
     assert runtime.KIND_DTYPE.itemsize == 8 * 4
     assert runtime.ITEM_DTYPE.itemsize == 24
     assert runtime.OUTER_DTYPE.itemsize == 40
