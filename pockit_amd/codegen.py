@@ -69,6 +69,24 @@ class _Names:
         return sp.sympify(expr).xreplace(self.map)
 
 
+def _fuse_sincos(exprs):
+    """Replace sin(u) / cos(u) of the same argument by a pair of symbols filled by ONE ``sincos`` call (one
+    argument reduction instead of two).  Returns (rewritten exprs, [(u, sin symbol, cos symbol)])."""
+    sines, cosines = set(), set()
+    for e in exprs:
+        sines |= {f.args[0] for f in e.atoms(sp.sin)}
+        cosines |= {f.args[0] for f in e.atoms(sp.cos)}
+    both = sorted(sines & cosines, key=sp.default_sort_key)
+    if not both:
+        return exprs, []
+    pairs, repl = [], {}
+    for k, u in enumerate(both):
+        sn, cs = sp.Symbol(f"pk_sn{k}"), sp.Symbol(f"pk_cs{k}")
+        pairs.append((u, sn, cs))
+        repl[sp.sin(u)], repl[sp.cos(u)] = sn, cs
+    return [e.xreplace(repl) for e in exprs], pairs
+
+
 def _emit_body(outputs, base, names, indent="    "):
     """C statements computing ``outputs`` = [(lvalue, expr)], expanding placeholder symbols through
     one joint CSE of their defining expressions ``base`` (placeholder -> expr)."""
@@ -77,16 +95,22 @@ def _emit_body(outputs, base, names, indent="    "):
     for _, e in outs:
         frontier |= {s for s in e.free_symbols if s in base}
     needed = sorted(frontier, key=lambda s: s.name)
+    defs = [names.apply(base[k]) for k in needed]
+    finals = [names.apply(e) for _, e in outs]
+    fused, pairs = _fuse_sincos(defs + finals)
+    defs, finals = fused[: len(defs)], fused[len(defs):]
     lines = []
+    for u, sn, cs in pairs:
+        lines.append(f"{indent}double {sn.name}, {cs.name};")
+        lines.append(f"{indent}sincos({ccode(u)}, &{sn.name}, &{cs.name});")
     if needed:
-        repl, red = sp.cse([names.apply(base[k]) for k in needed], optimizations="basic",
-                           symbols=sp.numbered_symbols("c_"))
+        repl, red = sp.cse(defs, optimizations="basic", symbols=sp.numbered_symbols("c_"))
         for sym, e in repl:
             lines.append(f"{indent}const double {sym.name} = {ccode(e)};")
         for k, e in zip(needed, red):
             lines.append(f"{indent}const double {k.name} = {ccode(e)};")
-    for lv, e in outs:
-        lines.append(f"{indent}{lv} = {ccode(names.apply(e))};")
+    for (lv, _), e in zip(outs, finals):
+        lines.append(f"{indent}{lv} = {ccode(e)};")
     return "\n".join(lines)
 
 
