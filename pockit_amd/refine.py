@@ -43,6 +43,9 @@ def error_tables(plan):
         rows_iv = lay.K + 1 if lgr else lay.K
         row0 = np.concatenate(([0], np.cumsum(rows_iv[:-1])))
         rows = int(np.sum(rows_iv))
+        if int(np.max(lay.K)) + 1 > runtime.WAVE:
+            raise NotImplementedError("mesh error estimation maps the K + 1 augmented nodes of an interval to the "
+                                      "64 lanes of a wavefront: num_point <= 63")
         for j in range(lay.N):
             K = int(lay.K[j])
             key = (lgr, K)

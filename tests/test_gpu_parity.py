@@ -494,3 +494,56 @@ def test_check_and_refine_loop_like_the_hyper_sensitive_example():
         assert len(value.data) == phases[0].L == system.L
         assert np.isfinite(system.objective(value.data))
     assert sizes[1] > sizes[0]
+
+
+# ---------------------------------------------------------------------------------------------------------
+# the reference's finite-difference derivative tests (tests/test_radau/test_derivative_radau.py:43-144,
+# tests/test_labatto/test_derivative_lobatto.py) restated against the GPU evaluator: same model, same point
+# x = arange(L)/10 + 1, same steps and tolerances
+def _dense(rows, cols, vals, shape):
+    M = np.zeros(shape)
+    np.add.at(M, (np.asarray(rows), np.asarray(cols)), vals)
+    return M
+
+
+@pytest.mark.parametrize("scheme", ["radau", "lobatto"])
+def test_reference_finite_difference_derivative_checks(scheme):
+    s, _, _ = models.derivative_model(_ns(scheme, "pockit_amd"))
+    n = s.L
+    x = np.arange(n, dtype=np.float64) / 10 + 1
+    m = len(s.constraints(x))
+
+    def shifted(*moves):
+        y = x.copy()
+        for i, d in moves:
+            y[i] += d
+        return y
+
+    # gradient and Jacobian: central differences, eps = 1e-6, np.allclose defaults
+    eps = 1e-6
+    fd_grad = np.array([(s.objective(shifted((i, eps))) - s.objective(shifted((i, -eps)))) / (2 * eps) for i in range(n)])
+    assert np.allclose(s.gradient(x), fd_grad)
+    fd_jac = np.stack([(s.constraints(shifted((i, eps))) - s.constraints(shifted((i, -eps)))) / (2 * eps)
+                       for i in range(n)], axis=1)
+    jr, jc = s.jacobianstructure()
+    assert np.allclose(_dense(jr, jc, s.jacobian(x), (m, n)), fd_jac)
+
+    # Hessians: four-point formula, eps = 2e-3, atol = rtol = 1e-4 on the lower triangle
+    eps = 2e-3
+    fd_o = np.zeros((n, n))
+    fd_c = np.zeros((m, n, n))
+    for i in range(n):
+        for j in range(i + 1):
+            pts = [shifted((i, eps), (j, eps)), shifted((i, eps), (j, -eps)), shifted((i, -eps), (j, eps)),
+                   shifted((i, -eps), (j, -eps))]
+            f = [s.objective(p) for p in pts]
+            g = [s.constraints(p) for p in pts]
+            fd_o[i, j] = (f[0] - f[1] - f[2] + f[3]) / eps / eps / 4
+            fd_c[:, i, j] = (g[0] - g[1] - g[2] + g[3]) / eps / eps / 4
+    hr, hc = s.hessianstructure_o()
+    assert np.allclose(_dense(hr, hc, s.hessian_o(x), (n, n)), fd_o, atol=1e-4, rtol=1e-4)
+    hr, hc = s.hessianstructure()
+    for c in range(m):
+        unit = np.zeros(m)
+        unit[c] = 1.0
+        assert np.allclose(_dense(hr, hc, s.hessian(x, unit, 0.0), (n, n)), fd_c[c], atol=1e-4, rtol=1e-4), c
