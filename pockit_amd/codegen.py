@@ -338,8 +338,8 @@ class ModelSource:
         S.append(f"#define PK_NSYS {max(plan.n_sys, 1)}")
         if os.environ.get("POCKIT_AMD_TRACE", "0") == "1":   # developer tracing of the wave timeline (tools/wave_trace.py)
             S.append("#define PK_TRACE 1")
-        if os.environ.get("POCKIT_AMD_NT", "0") == "1":      # A/B switch: streaming (nt) output stores, measured slower
-            S.append("#define PK_NT_STORES 1")
+        if os.environ.get("POCKIT_AMD_NT", "0") in ("1", "2", "3"):   # A/B switch of the output store flavour
+            S.append(f"#define PK_NT_STORES {os.environ['POCKIT_AMD_NT']}")
         S.append('#include "pk_kernels.hip.h"')
         S.append("namespace pkgen {")
         for k in range(nP):

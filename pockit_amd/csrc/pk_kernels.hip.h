@@ -67,8 +67,12 @@ __device__ __forceinline__ PkTile load_tile(const PkTile* p) {
 #define PK_NT_STORES 0
 #endif
 __device__ __forceinline__ void put(double* __restrict__ p, double v) {
-#if PK_NT_STORES
+#if PK_NT_STORES == 1
   __builtin_nontemporal_store(v, p);
+#elif PK_NT_STORES == 2      // agent-scope store (sc1): written through the XCD's L2
+  __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#elif PK_NT_STORES == 3      // system-scope store (sc0 sc1)
+  __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 #else
   *p = v;
 #endif
