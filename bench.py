@@ -61,6 +61,10 @@ def algorithmic_bytes(plan):
 def build_workload(name, intervals, ns):
     import models
 
+    if name.endswith("_lgl"):                       # Lobatto variant of a workload (side line of the bench)
+        import pockit_amd.lobatto as lobatto
+
+        return build_workload(name[:-4], intervals, lobatto)
     if name == "planar_quadrotor":
         return models.planar_quadrotor(ns, intervals, 6)
     if name == "brachistochrone":
@@ -312,7 +316,7 @@ def main():
         if not args.no_extra and n_gpus == 1:
             extra = {}
             for nm, iv in (("brachistochrone", 1250), ("brachistochrone", 200), ("two_stage_rocket", 1000),
-                           ("humanoid_wbc", 5000)):
+                           ("humanoid_wbc", 5000), ("planar_quadrotor_lgl", 2000)):
                 try:
                     r = run_gpu(nm, iv, max(20, args.steps // 3), max(5, args.warmup // 3), 0, 1, None)
                     b = r["bytes"][r["dominant"][3:]]

@@ -547,3 +547,69 @@ def test_reference_finite_difference_derivative_checks(scheme):
         unit = np.zeros(m)
         unit[c] = 1.0
         assert np.allclose(_dense(hr, hc, s.hessian(x, unit, 0.0), (n, n)), fd_c[c], atol=1e-4, rtol=1e-4), c
+
+
+@pytest.mark.parametrize("seed", [0, 1, 2, 3, 4, 5])
+def test_random_hp_meshes_all_callbacks_match_oracle(seed):
+    """Randomised hp meshes (every interval its own width and K, LGR K = 1..12 / LGL K = 2..12; K > 8 takes the
+    kernels' global-table path, K <= 8 the LDS-staged one) over all example models, all five callbacks, the
+    stand-alone kernels and the fused cycle."""
+    rng = np.random.default_rng(100 + seed)
+    builder = [models.brachistochrone, models.planar_quadrotor, models.two_stage_rocket, models.humanoid_wbc,
+               models.derivative_model, models.brachistochrone][seed]
+    scheme = ["radau", "lobatto"][seed % 2]
+    n_int = int(rng.integers(5, 40))
+    lo = 1 if scheme == "radau" else 2
+    K = rng.integers(lo, 13, size=n_int).tolist()
+    mesh = np.concatenate(([0.0], np.cumsum(rng.uniform(0.05, 1.0, size=n_int)))).tolist()
+    kw = dict(mesh=mesh, num_point=K)
+    system, _, guess = builder(_ns(scheme, "pockit_amd"), **kw)
+    ref, _, _ = builder(_ns(scheme, "oracle"), **kw)
+    x, lam, sigma = models.bench_inputs(system, guess)
+    sigma = 0.3 + 0.1 * seed
+    assert np.array_equal(system.jacobianstructure()[0], ref.jacobianstructure()[0])
+    assert np.array_equal(system.jacobianstructure()[1], ref.jacobianstructure()[1])
+    assert np.array_equal(system.hessianstructure()[0], ref.hessianstructure()[0])
+    assert np.array_equal(system.hessianstructure()[1], ref.hessianstructure()[1])
+    want = dict(f=ref.objective(x), grad=ref.gradient(x), g=ref.constraints(x), J=ref.jacobian(x),
+                H=ref.hessian(x, lam, sigma))
+    ev = system.evaluator
+    close(ev.objective_direct(x), want["f"], what="f")
+    close(ev.gradient_direct(x), want["grad"], what="grad")
+    close(ev.constraints_direct(x), want["g"], what="g")
+    close(ev.jacobian_direct(x), want["J"], what="J")
+    close(ev.hessian_direct(x, lam, sigma), want["H"], what="H")
+    f, grad, g, J, H = ev.cycle(x, lam, sigma)
+    for got, key in ((f, "f"), (grad, "grad"), (g, "g"), (J, "J"), (H, "H")):
+        close(got, want[key], what="cycle " + key)
+
+
+def test_adaptive_solve_check_refine_loop_converges():
+    """The whole adaptive workflow on the GPU evaluator, as examples/hyper_sensitive.py:88-120 runs it with IPOPT:
+    solve (SciPy trust-constr here), system.check, system.refine, re-solve on the refined mesh from the adapted
+    solution -- until the mesh error check passes.  The objective must approach the Riccati optimum."""
+    from scipy.integrate import solve_ivp
+
+    from pockit_amd.optimizer import scipy as scipy_solver
+
+    ns = _ns("radau", "pockit_amd")
+    system, (phase,), _ = models.lqr(ns, 2, 3)
+    value = [ns.constant_guess(phase, 0.0), [0.0]]
+    a, b, q, r, sw = -1.0, 1.0, 1.0, 0.1, 1.0
+    ric = solve_ivp(lambda t, P: -(2 * a * P - b * b * P * P / r + q), (1.0, 0.0), [sw / 2], rtol=1e-11, atol=1e-12)
+    optimum = ric.y[0, -1]
+    tol = 1e-6
+    errors, sizes = [], []
+    for sweep in range(6):
+        value, res = scipy_solver.solve(system, value, {"maxiter": 300, "gtol": 1e-10, "xtol": 1e-12})
+        errors.append(abs(res.fun - optimum))
+        sizes.append(system.L)
+        if system.check(value, absolute_tolerance_continuous=tol, relative_tolerance_continuous=tol):
+            break
+        value = system.refine(value, absolute_tolerance_continuous=tol, relative_tolerance_continuous=tol,
+                              num_point_min=3, num_point_max=8, mesh_length_min=1e-4)
+        assert len(value[0].data) == phase.L
+    else:
+        pytest.fail(f"mesh error check never passed: errors {errors}, sizes {sizes}")
+    assert len(sizes) >= 2 and sizes[-1] > sizes[0], sizes            # the coarse mesh had to be refined
+    assert errors[-1] <= 1e-6 * max(1.0, abs(optimum)) and errors[-1] < errors[0], errors
