@@ -613,3 +613,65 @@ def test_adaptive_solve_check_refine_loop_converges():
         pytest.fail(f"mesh error check never passed: errors {errors}, sizes {sizes}")
     assert len(sizes) >= 2 and sizes[-1] > sizes[0], sizes            # the coarse mesh had to be refined
     assert errors[-1] <= 1e-6 * max(1.0, abs(optimum)) and errors[-1] < errors[0], errors
+
+
+def test_ipopt_adapter_protocol_with_a_stand_in_cyipopt(monkeypatch):
+    """cyipopt / Ipopt are not installed here, so the adapter is driven by a stand-in ``cyipopt.Problem`` that
+    does what cyipopt does with a ``problem_obj`` (cyipopt's Problem.__init__/solve contract: structure queried
+    once, every callback result copied into the solver's own arrays at once, callbacks in IPOPT's per-iteration
+    order) and checks every value it receives against the oracle.  This covers the adapter's wiring and the
+    evaluator's zero-copy mode (results handed out as views of pinned buffers that the next call reuses)."""
+    import sys
+    import types
+
+    ns = _ns("radau", "pockit_amd")
+    system, phases, guess = models.two_stage_rocket(ns, 12, 4)
+    ref, _, _ = models.two_stage_rocket(_ns("radau", "oracle"), 12, 4)
+    seen = {"iters": 0, "options": {}}
+
+    class Problem:
+        def __init__(self, n, m, problem_obj, lb, ub, cl, cu):
+            assert n == ref.L and m == len(ref.c_lb) and len(lb) == len(ub) == n and len(cl) == len(cu) == m
+            assert np.array_equal(lb, ref.v_lb) and np.array_equal(ub, ref.v_ub)
+            assert np.array_equal(cl, ref.c_lb) and np.array_equal(cu, ref.c_ub)
+            self.n, self.m, self.obj = n, m, problem_obj
+            jr, jc = problem_obj.jacobianstructure()
+            hr, hc = problem_obj.hessianstructure()
+            assert np.array_equal(jr, ref.jacobianstructure()[0]) and np.array_equal(jc, ref.jacobianstructure()[1])
+            assert np.array_equal(hr, ref.hessianstructure()[0]) and np.array_equal(hc, ref.hessianstructure()[1])
+            self.nnz_j, self.nnz_h = len(jr), len(hr)
+
+        def add_option(self, key, value):
+            seen["options"][key] = value
+
+        def solve(self, x0):
+            rng = np.random.default_rng(3)
+            x = np.array(x0, dtype=np.float64)
+            for it in range(4):
+                lam = rng.standard_normal(self.m)
+                sigma = 1.0 if it else 0.5
+                got = {}
+                got["f"] = float(self.obj.objective(x))                       # line search: f and g
+                got["g"] = np.array(self.obj.constraints(x), dtype=np.float64)
+                got["grad"] = np.array(self.obj.gradient(x), dtype=np.float64)  # accepted point: derivatives
+                got["J"] = np.array(self.obj.jacobian(x), dtype=np.float64)
+                got["H"] = np.array(self.obj.hessian(x, lam, sigma), dtype=np.float64)
+                assert got["J"].shape == (self.nnz_j,) and got["H"].shape == (self.nnz_h,)
+                close(got["f"], ref.objective(x), what="f")
+                close(got["g"], ref.constraints(x), what="g")
+                close(got["grad"], ref.gradient(x), what="grad")
+                close(got["J"], ref.jacobian(x), what="J")
+                close(got["H"], ref.hessian(x, lam, sigma), what="H")
+                x = x * (1.0 + 1e-3 * rng.uniform(-1, 1, size=len(x)))
+                seen["iters"] += 1
+            return x, {"status": 0, "status_msg": b"stand-in", "obj_val": got["f"]}
+
+    fake = types.ModuleType("cyipopt")
+    fake.Problem = Problem
+    monkeypatch.setitem(sys.modules, "cyipopt", fake)
+    from pockit_amd.optimizer import ipopt
+
+    solution, info = ipopt.solve(system, guess, {"tol": 1e-8, "print_level": 0})
+    assert seen["iters"] == 4 and seen["options"] == {"tol": 1e-8, "print_level": 0} and info["status"] == 0
+    assert len(solution) == len(phases) + 1 and all(len(v.data) == p.L for v, p in zip(solution, phases))
+    assert len(solution[-1]) == system.n_s and system.evaluator.zero_copy is False
