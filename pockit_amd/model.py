@@ -320,11 +320,18 @@ class PhaseBase:
 
     def refine_discontinuous(self, variable, static_parameter=None, tolerance_discontinuous=1e-3, num_point_min=6,
                              num_point_max=12, mesh_length_min=1e-3, mesh_length_max=1.0) -> None:
+        """Move / add mesh points to the switching times of the bang-bang constraints (reference:
+        phasebase.py:1619-1868; logic in pockit_amd/refine.py).  Call ``System.update()`` afterwards."""
+        from . import refine
+
         self._require_radau()
         if self.check_discontinuous(variable, static_parameter, tolerance_discontinuous, mesh_length_min):
             return
-        raise NotImplementedError("switch-point mesh refinement for bang-bang constraints (reference: "
-                                  "phasebase.py:1619-1868) is not part of this build; use refine_continuous")
+        g_path, s = self._path_values(variable, static_parameter)
+        f_bb = self._bang_bang_values(variable.data, s, g_path)
+        mesh, num_point = refine.switch_point_discretization(self.layout, f_bb, tolerance_discontinuous, num_point_min,
+                                                             num_point_max, mesh_length_min, mesh_length_max)
+        self.set_discretization(mesh, num_point)
 
     def refine(self, variable, static_parameter=None, absolute_tolerance_continuous=1e-8,
                relative_tolerance_continuous=1e-8, tolerance_discontinuous=1e-3, num_point_min=6, num_point_max=12,

@@ -12,6 +12,7 @@ is copied: only inputs (x, lambda, sigma) and the outputs of its NLP callbacks a
 Outputs (committed):
   tests/golden/small/<case>.npz     full callback vectors for the small cases of tests/models.py
   tests/golden/error/<case>.npz     mesh error estimation data, per-interval verdicts and refined meshes
+  tests/golden/bangbang/<case>.npz  bang-bang check data and switch-point refinement results
   tests/golden/tables.npz           xw_lgr/I_lgr/xw_lgl/I_lgl for K = 1..12
   tests/golden/full.json            sizes, structure hashes, checksums and strided samples for the
                                     BASELINE.json configs at full size   (--full; takes minutes)
@@ -123,6 +124,31 @@ def error_case(name):
     return out
 
 
+def bang_bang_case(name):
+    """Bang-bang check and switch-point refinement of the reference (phasebase.py:1368-1400,1439-1474,1619-1868) on a
+    prescribed control history: the scaled constraint values, per-interval verdicts, the refined mesh / orders and
+    the values adapted to it, for two tolerance settings."""
+    kw, profile = models.BANG_BANG_CASES[name]
+    system, (p,), guess = models.bang_bang_model(ref_radau, **kw)
+    v = guess[0]
+    for i, u in enumerate(models.bang_bang_controls(p.t_u, profile)):
+        v.u[i] = u
+    v.x[0] = np.linspace(0.0, 1.0, len(v.x[0]))
+    s = np.array([0.0])
+    out = {"data": v.data.copy(), "s": s}
+    out["f_bb"] = p._error_estimation_data_discontinuous(v.data.copy(), s.copy())
+    for tag, (dtol, kmin, kmax, lmin, lmax) in (("a", (1e-3, 4, 8, 1e-3, 1.0)), ("b", (5e-2, 3, 6, 2e-2, 0.3))):
+        out[f"ok_{tag}"] = p._error_check_interval_discontinuous(out["f_bb"], dtol, 1e-4)
+        var = ref_radau.Variable(p, v.data.copy())
+        mesh0, K0 = p._mesh.copy(), p._num_point.copy()
+        p.refine_discontinuous(var, s.copy(), dtol, num_point_min=kmin, num_point_max=kmax, mesh_length_min=lmin,
+                               mesh_length_max=lmax)
+        out[f"mesh_{tag}"], out[f"K_{tag}"] = p._mesh.copy(), p._num_point.copy()
+        out[f"adapt_{tag}"] = var.adapt(p).data.copy()
+        p.set_discretization(mesh0, K0)
+    return out
+
+
 def sha(a):
     return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
 
@@ -184,6 +210,13 @@ def main():
             continue
         np.savez_compressed(os.path.join(HERE, "error", name + ".npz"), **error_case(name))
         print("error-estimation fixture", name)
+
+    os.makedirs(os.path.join(HERE, "bangbang"), exist_ok=True)
+    for name in models.BANG_BANG_CASES:
+        if args.only and args.only not in name:
+            continue
+        np.savez_compressed(os.path.join(HERE, "bangbang", name + ".npz"), **bang_bang_case(name))
+        print("bang-bang fixture", name)
 
     tabs = {}
     for K in range(1, 13):

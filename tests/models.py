@@ -425,6 +425,54 @@ def func_times_model(ns, mesh=(0, 0.3, 0.55, 1), num_point=(2, 3, 2)):
     return s, [p1, p2], guess
 
 
+def bang_bang_model(ns, mesh=6, num_point=5, second=False):
+    """Bang-bang test problem in the style of the reference's check tests (tests/test_radau/test_check_radau.py:
+    9-16): one state driven by the controls, a bang-bang path constraint u0 + s0 in [0, 2] and, with ``second``,
+    a bang-bang bound -1 <= u1 <= 1 given as a bare symbol (it becomes a variable bound, not a path row)."""
+    s = ns.System(1)
+    p = s.new_phase(1, 2 if second else 1)
+    p.set_dynamics([p.u[0] + (0.5 * p.u[1] if second else 0)])
+    p.set_boundary_condition([0.0], [None], 0.0, 1.0)
+    cons, lo, hi = [p.u[0] + p.s[0]], [0.0], [2.0]
+    if second:
+        cons, lo, hi = cons + [p.u[1]], lo + [-1.0], hi + [1.0]
+    p.set_phase_constraint(cons, lo, hi, True)
+    p.set_discretization(mesh, num_point)
+    s.set_phase([p])
+    s.set_objective(s.s[0] ** 2)
+    return s, [p], [ns.constant_guess(p, 0.0), [0.0]]
+
+
+def bang_bang_controls(t, profile):
+    """Control histories u0(t) (and u1(t)) on node times t in [0, 1]: smooth-but-steep switching functions, so that
+    the bang-bang check fails on the intervals that contain a switch."""
+    t = np.asarray(t, dtype=np.float64)
+    step = lambda c, w: 0.5 * (1.0 + np.tanh((t - c) / w))  # noqa: E731
+    if profile == "one_switch":
+        return [2.0 * step(0.37, 0.004)]
+    if profile == "two_switches":
+        return [2.0 * (step(0.22, 0.003) - step(0.71, 0.006))]
+    if profile == "near_mesh_point":
+        return [2.0 * (1.0 - step(0.5004, 0.002))]
+    if profile == "ramp":
+        return [2.0 * np.clip((t - 0.3) / 0.25, 0.0, 1.0)]
+    if profile == "two_controls":
+        return [2.0 * step(0.41, 0.005), 2.0 * step(0.63, 0.004) - 1.0]
+    raise ValueError(profile)
+
+
+# bang-bang refinement fixtures: (model kwargs, control profile)
+BANG_BANG_CASES = {
+    "bb_one_switch_6x5": (dict(mesh=6, num_point=5), "one_switch"),
+    "bb_one_switch_hp": (dict(mesh=[0, 0.1, 0.3, 0.45, 0.8, 1.0], num_point=[3, 6, 4, 7, 5]), "one_switch"),
+    "bb_two_switches_10x4": (dict(mesh=10, num_point=4), "two_switches"),
+    "bb_near_mesh_point_8x6": (dict(mesh=8, num_point=6), "near_mesh_point"),
+    "bb_ramp_5x6": (dict(mesh=5, num_point=6), "ramp"),
+    "bb_two_controls_9x5": (dict(mesh=9, num_point=5, second=True), "two_controls"),
+    "bb_two_controls_3x8": (dict(mesh=3, num_point=8, second=True), "two_controls"),
+}
+
+
 SMALL_CASES = {
     # name: (builder, scheme, kwargs)
     "derivative_lgr": (derivative_model, "radau", {}),

@@ -675,3 +675,27 @@ def test_ipopt_adapter_protocol_with_a_stand_in_cyipopt(monkeypatch):
     assert seen["iters"] == 4 and seen["options"] == {"tol": 1e-8, "print_level": 0} and info["status"] == 0
     assert len(solution) == len(phases) + 1 and all(len(v.data) == p.L for v, p in zip(solution, phases))
     assert len(solution[-1]) == system.n_s and system.evaluator.zero_copy is False
+
+
+@pytest.mark.parametrize("name", sorted(models.BANG_BANG_CASES))
+def test_bang_bang_refinement_end_to_end_matches_reference(name):
+    """system.check_discontinuous / refine_discontinuous on the GPU-backed system against the reference's results
+    (tests/golden/bangbang): the scaled constraint values come from pk_g on the device."""
+    kw, _ = models.BANG_BANG_CASES[name]
+    gold = np.load(os.path.join(HERE, "golden", "bangbang", name + ".npz"))
+    ns = _ns("radau", "pockit_amd")
+    for tag, (dtol, kmin, kmax, lmin, lmax) in (("a", (1e-3, 4, 8, 1e-3, 1.0)), ("b", (5e-2, 3, 6, 2e-2, 0.3))):
+        system, (p,), _ = models.bang_bang_model(ns, **kw)
+        value = [ns.Variable(p, gold["data"].copy()), gold["s"].copy()]
+        assert system.check_discontinuous(value, dtol, 1e-4) == bool(np.all(gold[f"ok_{tag}"]))
+        out = system.refine_discontinuous(value, dtol, num_point_min=kmin, num_point_max=kmax, mesh_length_min=lmin,
+                                          mesh_length_max=lmax)
+        assert len(p._mesh) == len(gold[f"mesh_{tag}"]) and np.allclose(p._mesh, gold[f"mesh_{tag}"], rtol=0, atol=1e-9)
+        assert np.array_equal(p._num_point, gold[f"K_{tag}"])
+        close(out[0].data, gold[f"adapt_{tag}"], 1e-9, what="adapted values")
+        x_new = np.concatenate([out[0].data, out[1]])
+        assert len(x_new) == system.L and np.isfinite(system.objective(x_new))
+        # system.refine takes the bang-bang branch first (the check fails), as the reference does
+        system2, (p2,), _ = models.bang_bang_model(ns, **kw)
+        system2.refine([ns.Variable(p2, gold["data"].copy()), gold["s"].copy()], 1e-8, 1e-8, dtol, kmin, kmax, lmin, lmax)
+        assert len(p2._mesh) == len(gold[f"mesh_{tag}"]) and np.allclose(p2._mesh, gold[f"mesh_{tag}"], rtol=0, atol=1e-9)
