@@ -392,6 +392,56 @@ class PhaseBase:
     w_m = property(lambda self: self.layout.w)
     t_x = property(lambda self: self.layout.t_x)
     t_u = property(lambda self: self.layout.tau)
+    # per-interval windows on the state / control time axes and the one-more-point ("aug") views the refinement
+    # uses (reference: radau/discretization.py:505-521,593-613, lobatto/discretization.py:431-441)
+    l_x = property(lambda self: self.layout.lm)
+    r_x = property(lambda self: self.layout.rm + (1 if self.scheme == "lgr" else 0))
+    l_u = property(lambda self: self.layout.lm)
+    r_u = property(lambda self: self.layout.rm)
+
+    @property
+    def l_m_aug(self):
+        k = self.layout.K + 1
+        step = k if self.scheme == "lgr" else k - 1
+        return np.concatenate(([0], np.cumsum(step[:-1])))
+
+    @property
+    def r_m_aug(self):
+        return self.l_m_aug + self.layout.K + 1
+
+    @property
+    def L_m_aug(self):
+        return int(self.r_m_aug[-1])
+
+    @property
+    def t_m_aug(self):
+        """Positions in [0, 1] of the nodes with one more point per interval (LGL: shared ends listed once)."""
+        from . import collocation
+
+        lay, lgr = self.layout, self.scheme == "lgr"
+        nodes = collocation.lgr_nodes_weights if lgr else collocation.lgl_nodes_weights
+        parts = []
+        for j in range(lay.N):
+            xa = lay.mesh[j] + (nodes(int(lay.K[j]) + 1)[0] + 1.0) * 0.5 * lay.width[j]
+            parts.append(xa if lgr or j == lay.N - 1 else xa[:-1])
+        return np.concatenate(parts)
+
+    @property
+    def w_aug(self):
+        from . import collocation
+
+        nodes = collocation.lgr_nodes_weights if self.scheme == "lgr" else collocation.lgl_nodes_weights
+        return [nodes(int(k))[1] for k in self.layout.K]
+
+    @property
+    def P(self):
+        """K -> matrix turning values at the K nodes of an interval into monomial coefficients (highest power
+        first) of their interpolant on [-1, 1]."""
+        from . import collocation
+
+        nodes = collocation.lgr_nodes_weights if self.scheme == "lgr" else collocation.lgl_nodes_weights
+        return lambda K: np.linalg.inv(np.vander(nodes(int(K))[0]))
+
     L_x = property(lambda self: int(self.layout.r_v[self.n_x - 1]))
     L_xu = property(lambda self: int(self.layout.r_v[-1]))
     L = property(lambda self: self.layout.L)

@@ -104,6 +104,11 @@ def error_case(name):
         xp = x[system.l_p[k]: system.r_p[k]].copy()
         T, I = p._error_estimation_data_continuous(xp.copy(), s.copy())
         out[f"T_{k}"], out[f"I_{k}"] = T, I
+        for nm in ("l_x", "r_x", "l_u", "r_u", "l_m_aug", "r_m_aug", "t_m_aug", "t_x", "t_u"):
+            out[f"{nm}_{k}"] = np.asarray(getattr(p, nm))
+        out[f"L_m_aug_{k}"] = np.int64(p.L_m_aug)
+        out[f"w_aug_{k}"] = np.concatenate(p.w_aug)
+        out[f"P5_{k}"] = p.P(5)
         # interpolation / differentiation matrices of the Variable at sample times that include interior mesh
         # points once and twice (variablebase.py:137-317)
         v0 = NS[scheme].Variable(p, xp.copy())
