@@ -9,9 +9,13 @@
 //   phase A  lane = node: coalesced 8-byte loads of the trajectory vector (states/controls are
 //            stored node-contiguous per variable), model evaluation in registers, the per-node
 //            values that are needed by all K rows of the interval are staged in LDS ([segment][lane]);
+//            in the same memory round trip the wave copies its tile's small pattern tables (K <= 8: at most
+//            64 entries each) and, for the Hessian, its rows of the multipliers into LDS;
 //   phase B  lane = output position: every I-expanded segment of the tile is a contiguous run of
 //            nj * K^2 doubles in the output array; the wave streams them out in 512-byte coalesced
-//            stores, reading the staged values from LDS (broadcast within an interval).
+//            stores, reading staged values and tables from LDS only (no global load after the barrier).
+// The tile record is wave-uniform: it is read through the scalar cache into SGPRs (readfirstlane +
+// constant address space), as are the segment base offsets.
 // Four independent waves share a 256-thread workgroup (one __syncthreads between the phases).
 // One extra workgroup per launch handles the boundary nodes and the system-level scalars.
 // Sums over all nodes (integrals, gradient entries of t0/tf/static parameters) are reduced
