@@ -338,6 +338,8 @@ class ModelSource:
         S.append(f"#define PK_NSYS {max(plan.n_sys, 1)}")
         if os.environ.get("POCKIT_AMD_TRACE", "0") == "1":   # developer tracing of the wave timeline (tools/wave_trace.py)
             S.append("#define PK_TRACE 1")
+        if os.environ.get("POCKIT_AMD_XCD_REMAP", "1") == "0":       # A/B switch of the XCD-aware block mapping
+            S.append("#define PK_XCD_REMAP 0")
         if os.environ.get("POCKIT_AMD_NT", "0") in ("1", "2", "3"):   # A/B switch of the output store flavour
             S.append(f"#define PK_NT_STORES {os.environ['POCKIT_AMD_NT']}")
         S.append('#include "pk_kernels.hip.h"')
@@ -375,10 +377,13 @@ class ModelSource:
                  "bool valid, double* __restrict__ lds, int lane) {")
         S.append(switch("pk::interval_err<{P}>(A, iv, valid, lds, lane)"))
         S.append("  }")
-        for name in ("int", "g", "grad", "jac", "hess", "xall", "aux", "hessc"):
+        targets = [(n, f"pk::tile_{n}<{{P}}>") for n in ("int", "g", "grad", "jac", "hess", "aux", "hessc")]
+        targets += [("xall", "pk::tile_xall<{P}, 0>"), ("xall1", "pk::tile_xall<{P}, 1>"),
+                    ("xall2", "pk::tile_xall<{P}, 2>")]
+        for name, target in targets:
             S.append(f"  __device__ static __forceinline__ void tile_{name}(int phase, const PkArgs& A, const PkTile& tl, "
                      f"double* __restrict__ lds, double* __restrict__ wint, double* __restrict__ wgrad, int lane) {{")
-            S.append(switch(f"pk::tile_{name}<{{P}}>(A, tl, lds, wint, wgrad, lane)"))
+            S.append(switch(f"{target}(A, tl, lds, wint, wgrad, lane)"))
             S.append("  }")
         ncmax = max([1] + [pp.phase.n_c for pp in plan.phase_plans])
         for cbname, tag in (("jac", "J"), ("hess", "H"), ("aux", "A")):

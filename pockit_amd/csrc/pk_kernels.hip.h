@@ -53,6 +53,27 @@ __device__ __forceinline__ PkTile load_tile(const PkTile* p) {
   return t;
 }
 
+// XCD-aware workgroup -> tile-block mapping.  The hardware deals consecutive workgroup ids round-robin to the 8
+// XCDs, each with its own L2; neighbouring tiles write neighbouring pieces of the same output arrays (and of the
+// same 128-byte lines where a run does not end on a line boundary).  Giving every XCD one contiguous range of
+// tile blocks lets its L2 merge those pieces into full lines before they are written back.  `first` workgroups
+// (boundary / finalize workgroups) keep their ids; returns the tile-block index of workgroup `wg`.
+#define PK_XCDS 8
+#ifndef PK_XCD_REMAP
+#define PK_XCD_REMAP 1
+#endif
+__device__ __forceinline__ int xcd_tile_block(int wg, int first, int total) {
+  if (PK_XCD_REMAP == 0) return wg - first;
+  const int x = wg % PK_XCDS;
+  int start = 0;
+#pragma unroll
+  for (int y = 0; y < PK_XCDS; ++y) {
+    const int cnt = (y < total ? (total - 1 - y) / PK_XCDS + 1 : 0) - (y < first ? 1 : 0);   // tile blocks on XCD y
+    if (y < x) start += cnt;
+  }
+  return start + (wg - x) / PK_XCDS - (x < first ? 1 : 0);
+}
+
 // Developer tracing: PK_MARK(k) stores the shader clock (s_memtime) of lane 0 at checkpoint k of the wave's tile.
 #ifdef PK_TRACE
 #define PK_MARK(k)                                                                                          \
@@ -70,6 +91,7 @@ __device__ __forceinline__ PkTile load_tile(const PkTile* p) {
 #ifndef PK_NT_STORES
 #define PK_NT_STORES 0
 #endif
+
 __device__ __forceinline__ void put(double* __restrict__ p, double v) {
 #if PK_NT_STORES == 1
   __builtin_nontemporal_store(v, p);
@@ -547,7 +569,11 @@ __device__ __forceinline__ void tile_hess(const PkArgs& A, const PkTile& tl, dou
 // (one joint CSE over all model functions; x read once).  Used by pk_eval_cycle_dev.
 // LDS: [NX dynamics values | J_NI Jacobian segments] x 64 lanes.
 // ============================================================================================
-template <class P>
+// ROLE 0: the wave produces everything of its tile.  ROLE 1 / 2: two waves share a tile (split launch) -- 1 writes
+// the values (path constraints, defects, gradient, integrand sums), 2 the Jacobian (N segments, translation
+// entries, I-expanded segments); the role is a compile-time constant, so each wave's copy of the inlined model
+// evaluation keeps only what its outputs need and its serial chain is roughly halved.
+template <class P, int ROLE>
 __device__ __forceinline__ void tile_xall(const PkArgs& A, const PkTile& tl, double* __restrict__ sv,
                                           double* __restrict__ wint, double* __restrict__ wgrad, int lane) {
   const PkPhase& ph = A.ph[P::INDEX];
@@ -565,7 +591,7 @@ __device__ __forceinline__ void tile_xall(const PkArgs& A, const PkTile& tl, dou
   load_node<P>(A, ph, s, dt, mt, q, a, tau, w);
   const TileTabs T = tabs_commit(tr, fit, lane);
   PK_MARK(1);
-  defect_ends<P>(A, ph, tl, g, a, xe, lane);
+  if (ROLE != 2) defect_ends<P>(A, ph, tl, g, a, xe, lane);
 #pragma unroll
   for (int i = 0; i < P::NX; ++i) xr[i] = a[i];
   double oi[P::INT_N > 0 ? P::INT_N : 1], orr[P::GR_NR > 0 ? P::GR_NR : 1];
@@ -579,41 +605,51 @@ __device__ __forceinline__ void tile_xall(const PkArgs& A, const PkTile& tl, dou
     PK_MARK(2);
     P::mid_xall(a, tau, dt, w, sy, og, oj, ov, ot, op);
     PK_MARK(3);
+    if (ROLE != 2) {
 #pragma unroll
-    for (int i = 0; i < P::NX; ++i) sv[i * PK_WAVE + lane] = og[i];
+      for (int i = 0; i < P::NX; ++i) sv[i * PK_WAVE + lane] = og[i];
+    }
+    if (ROLE != 1) {
 #pragma unroll
-    for (int e = 0; e < P::J_NI; ++e) jsv[e * PK_WAVE + lane] = oj[e];
+      for (int e = 0; e < P::J_NI; ++e) jsv[e * PK_WAVE + lane] = oj[e];
+    }
     if (lane < g.nown) {
+      if (ROLE != 2) {
 #pragma unroll
-      for (int j = 0; j < P::NC; ++j) put(&A.o_g[ph.path_off + j * ph.L_m + q], og[P::NX + j]);
-      if (q >= ph.mid_lo && q < ph.mid_hi) {
+        for (int j = 0; j < P::NC; ++j) put(&A.o_g[ph.path_off + j * ph.L_m + q], og[P::NX + j]);
+      }
+      if (ROLE != 1 && q >= ph.mid_lo && q < ph.mid_hi) {
 #pragma unroll
         for (int e = 0; e < P::J_NN; ++e) put(&A.o_jac[segb[P::J_NI + e] + (q - ph.mid_lo)], oj[P::J_NI + e]);
       }
+      if (ROLE != 2) {
 #pragma unroll
-      for (int r = 0; r < P::INT_N; ++r) oi[r] = op[r] * w;
+        for (int r = 0; r < P::INT_N; ++r) oi[r] = op[r] * w;
 #pragma unroll
-      for (int r = 0; r < P::GR_NR; ++r) orr[r] = ot[r];
-      node_gradient<P>(A, ph, q, a, tau, dt, w, sy, ov, orr, true);   // boundary nodes re-evaluate their own entries
+        for (int r = 0; r < P::GR_NR; ++r) orr[r] = ot[r];
+        node_gradient<P>(A, ph, q, a, tau, dt, w, sy, ov, orr, true);   // boundary nodes re-evaluate their own entries
+      }
     }
   }
+  if (ROLE != 2) {      // (the Jacobian wave leaves the zeros of the prologue in its reduction slots)
 #pragma unroll
-  for (int r = 0; r < P::INT_N; ++r) {
-    const double v = wave_sum(oi[r]);
-    if (lane == 0) wint[r] = v;
-  }
+    for (int r = 0; r < P::INT_N; ++r) {
+      const double v = wave_sum(oi[r]);
+      if (lane == 0) wint[r] = v;
+    }
 #pragma unroll
-  for (int r = 0; r < P::GR_NR; ++r) {
-    const double v = wave_sum(orr[r]);
-    if (lane == 0) wgrad[r] = v;
+    for (int r = 0; r < P::GR_NR; ++r) {
+      const double v = wave_sum(orr[r]);
+      if (lane == 0) wgrad[r] = v;
+    }
   }
   PK_MARK(4);
   __syncthreads();
   PK_MARK(5);
   if (A.flags & 256) return;   // diagnostic build switches: skip the phases after the barrier (all / one by one)
-  if (!(A.flags & 8192)) write_defects<P>(A, ph, tl, g, T, s, dt, sv, xr, xe, lane);
+  if (ROLE != 2 && !(A.flags & 8192)) write_defects<P>(A, ph, tl, g, T, s, dt, sv, xr, xe, lane);
   PK_MARK(6);
-  if (tl.nj == 0) return;
+  if (tl.nj == 0 || ROLE == 1) return;
   if (!(A.flags & 16384)) write_translation<P>(A, ph, tl, T, lane);
   PK_MARK(7);
   if (!(A.flags & 32768)) stream_expanded<P, P::J_NI, false>(A, ph, tl, g, T, jsv, nullptr, segb, A.o_jac, lane);
@@ -793,7 +829,9 @@ __device__ __forceinline__ void publish_block_partials(double* __restrict__ part
 // tree, 4-way LDS combine)
 __device__ __forceinline__ double block_sum_partials(const PkArgs& A, const double* __restrict__ partial, int k,
                                                      int r, double* red) {
-  const int blo = A.ph[k].tile_lo / PK_WAVES_PER_BLOCK, bhi = A.ph[k].tile_hi / PK_WAVES_PER_BLOCK;
+  // (split launch, flags bit 5: two waves per tile, so twice the workgroups per phase)
+  const int per = (A.flags & 32) ? PK_WAVES_PER_BLOCK / 2 : PK_WAVES_PER_BLOCK;
+  const int blo = A.ph[k].tile_lo / per, bhi = A.ph[k].tile_hi / per;
   double v = 0.0;
   for (int b = blo + (int)threadIdx.x; b < bhi; b += PK_BLOCK) v += partial[(size_t)b * PK_NRED + r];
   v = wave_sum(v);
@@ -811,15 +849,16 @@ __device__ __forceinline__ double block_sum_partials(const PkArgs& A, const doub
 // ============================================================================================
 // EDGE = 1: workgroup 0 is the boundary/system workgroup (dispatched first: its serial chain is the
 // longest of the launch), tile workgroups follow.
-#define PK_TILE_PROLOGUE(EDGE)                                                        \
+#define PK_TILE_PROLOGUE(EDGE) PK_TILE_PROLOGUE_SPLIT(EDGE, 0)
+#define PK_TILE_PROLOGUE_SPLIT(EDGE, SHIFT)                                           \
   extern __shared__ double pk_lds[];                                                  \
   __shared__ double wint[PK_WAVES_PER_BLOCK * PK_NRED];                               \
   __shared__ double wgrad[PK_WAVES_PER_BLOCK * PK_NRED];                              \
   /* wave-uniform on purpose (readfirstlane): the tile record then comes through the scalar cache into */ \
   /* SGPRs and everything derived from it is scalar arithmetic */                      \
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63; \
-  const int blk = (int)blockIdx.x - (EDGE);                                           \
-  const int ti = blk * PK_WAVES_PER_BLOCK + wave;                                     \
+  const int blk = pk::xcd_tile_block((int)blockIdx.x, (EDGE), (int)gridDim.x);        \
+  const int ti = (blk * PK_WAVES_PER_BLOCK + wave) >> (SHIFT);                        \
   PkTile tl;                                                                          \
   if (ti < A.n_tiles) {                                                               \
     tl = load_tile(A.tile + ti);                                                      \
@@ -1094,6 +1133,16 @@ __device__ __forceinline__ void kernel_xall(const PkArgs& A) {
   if (A.flags & 1024) return;                                   // diagnostic switches (POCKIT_AMD_DEBUG_FLAGS)
   if (PK_IS_EDGE_BLOCK() && (A.flags & 2048)) return;
   if (PK_IS_EDGE_BLOCK()) return edge_block<Gen>(A, 0, true);
+  if (A.flags & 32) {   // split launch: waves 2t and 2t+1 share tile t (values / Jacobian)
+    PK_TILE_PROLOGUE_SPLIT(1, 1);
+    if (wave & 1)
+      Gen::tile_xall2(tl.phase, A, tl, pk_lds + wave * Gen::LDS_X, wint + wave * PK_NRED, wgrad + wave * PK_NRED, lane);
+    else
+      Gen::tile_xall1(tl.phase, A, tl, pk_lds + wave * Gen::LDS_X, wint + wave * PK_NRED, wgrad + wave * PK_NRED, lane);
+    publish_block_partials(A.partial, wint, blk);
+    publish_block_partials(A.partial2, wgrad, blk);
+    return;
+  }
   PK_TILE_PROLOGUE(1);
 #ifdef PK_TRACE
   if (A.trace != nullptr && lane == 0 && tl.pad >= 0) A.trace[(size_t)tl.pad * 16 + 10] = t_entry;

@@ -36,7 +36,7 @@ namespace {
 enum { K_INT = 0, K_FIN, K_G, K_GRAD, K_JAC, K_HESS, K_XALL, K_AUX, K_OUTER, K_HESSC, K_ERR, K_CSR, K_COUNT };
 const char* const kKernelNames[K_COUNT] = {"pk_int", "pk_fin", "pk_g", "pk_grad", "pk_jac", "pk_hess", "pk_xall",
                                            "pk_aux", "pk_outer", "pk_hessc", "pk_err", "pk_csr"};
-enum { F_WRITE_F = 1, F_SECONDARY = 2, F_FIN_INT = 8, F_FIN_GRAD = 16 };
+enum { F_WRITE_F = 1, F_SECONDARY = 2, F_FIN_INT = 8, F_FIN_GRAD = 16, F_SPLIT = 32 };
 
 thread_local std::string g_create_error;
 
@@ -55,6 +55,7 @@ struct pk_ctx {
   int shard_flags = 0;          // OR-ed into PkArgs.flags (bit 1: secondary shard)
   bool external_prepass = false; // sharded mode: the caller all-reduces the integrals itself
   double* ext_I = nullptr;      // caller-owned integral buffer (sharded mode)
+  bool split_xall = false;      // pk_xall with two waves per tile (values / Jacobian), see pk_set_problem
   unsigned profile_mask = 0;
   unsigned profile_period = 1;  // time every n-th launch of a selected kernel
   unsigned profile_seen[16] = {};
@@ -229,6 +230,10 @@ int prepass(pk_ctx* c, const double* d_x, const double* d_lam, double sigma, dou
   return launch(c, K_FIN, A, 1, 0, st);
 }
 
+// pk_xall's launch shape: one wave per tile, or -- split launch -- two waves per tile
+unsigned xall_blocks(const pk_ctx* c) { return (c->split_xall ? 2u : 1u) * tile_blocks(c) + 1u; }
+int xall_flags(const pk_ctx* c) { return c->split_xall ? F_SPLIT : 0; }
+
 int enqueue_fused_cycle(pk_ctx* c, const double* d_x, const double* d_lam, double sigma, double* d_f, double* d_grad,
                         double* d_g, double* d_jac, double* d_hess, hipStream_t st) {
   int rc;
@@ -238,13 +243,14 @@ int enqueue_fused_cycle(pk_ctx* c, const double* d_x, const double* d_lam, doubl
   A.n_items = c->n_items_jac;
   size_t lds = sizeof(double) * PK_WAVES_PER_BLOCK * (size_t)c->md.lds_x;
   if (lds < sizeof(double) * (size_t)c->md.ne_j) lds = sizeof(double) * (size_t)c->md.ne_j;
-  if ((rc = launch(c, K_XALL, A, tile_blocks(c) + 1, lds, st))) return rc;
+  A.flags |= xall_flags(c);
+  if ((rc = launch(c, K_XALL, A, xall_blocks(c), lds, st))) return rc;
   // pk_hess's boundary workgroup also performs pk_fin's reductions (f, shared gradient slots)
   PkArgs H = base_args(c, d_x, d_lam, sigma);
   H.o_f = d_f; H.o_grad = d_grad; H.o_hess = d_hess;
   H.items = (const PkItem*)c->d_items_hess;
   H.n_items = c->n_items_hess;
-  H.flags |= F_FIN_INT | F_WRITE_F | F_FIN_GRAD;
+  H.flags |= F_FIN_INT | F_WRITE_F | F_FIN_GRAD | xall_flags(c);
   lds = sizeof(double) * PK_WAVES_PER_BLOCK * (size_t)c->md.lds_h;
   if (lds < sizeof(double) * (size_t)c->md.ne_h) lds = sizeof(double) * (size_t)c->md.ne_h;
   return launch(c, K_HESS, H, tile_blocks(c) + 2, lds, st);
@@ -331,6 +337,12 @@ int pk_set_problem(pk_ctx* c, const pk_problem_desc* pd) {
   c->n_items_jac = pd->n_items_jac; c->n_items_hess = pd->n_items_hess; c->gz_off = pd->gz_off; c->n_gz = pd->n_gz;
   c->n_items_aux = pd->n_items_aux; c->n_outer = pd->n_outer; c->n_aux = pd->n_aux;
   c->n_items_hessc = pd->n_items_hessc; c->nnz_Hc = pd->nnz_Hc;
+  // Small meshes are bound by the serial chain of one wave, not by throughput: let two waves share a tile in
+  // pk_xall as long as that still leaves at most two waves per SIMD (POCKIT_AMD_SPLIT=0/1 overrides).
+  {
+    const char* env = getenv("POCKIT_AMD_SPLIT");
+    c->split_xall = env ? atoi(env) != 0 : (pd->n_tiles > 0 && pd->n_tiles <= 1024);
+  }
   int rc;
   if ((rc = upload(c, &c->d_phases, pd->phases, sizeof(PkPhase) * (size_t)pd->n_phase))) return rc;
   c->h_phases.assign((const PkPhase*)pd->phases, (const PkPhase*)pd->phases + pd->n_phase);
@@ -353,8 +365,8 @@ int pk_set_problem(pk_ctx* c, const pk_problem_desc* pd) {
   if ((rc = dalloc(&c->d_x, c->n)) || (rc = dalloc(&c->d_lam, c->m)) || (rc = dalloc(&c->d_f, 1)) ||
       (rc = dalloc(&c->d_grad, c->n)) || (rc = dalloc(&c->d_g, c->m)) || (rc = dalloc(&c->d_J, (size_t)c->nnz_J)) ||
       (rc = dalloc(&c->d_H, (size_t)c->nnz_H)) || (rc = dalloc(&c->d_aux, (size_t)c->n_aux)) || (rc = dalloc(&c->d_Hc, (size_t)c->nnz_Hc)) || (rc = dalloc(&c->d_I, c->md.n_I)) ||
-      (rc = dalloc(&c->d_partial, ((size_t)c->n_tiles / PK_WAVES_PER_BLOCK + 2) * (size_t)c->md.nred)) ||
-      (rc = dalloc(&c->d_partial2, ((size_t)c->n_tiles / PK_WAVES_PER_BLOCK + 2) * (size_t)c->md.nred)))
+      (rc = dalloc(&c->d_partial, (2 * (size_t)c->n_tiles / PK_WAVES_PER_BLOCK + 2) * (size_t)c->md.nred)) ||
+      (rc = dalloc(&c->d_partial2, (2 * (size_t)c->n_tiles / PK_WAVES_PER_BLOCK + 2) * (size_t)c->md.nred)))
     return rc;
   {
     const size_t cnt[5] = {1, (size_t)c->n, (size_t)c->m, (size_t)c->nnz_J, (size_t)c->nnz_H};
@@ -778,7 +790,8 @@ int pk_prepare_x(pk_ctx* c, const double* x) {
   A.n_items = c->n_items_jac;
   size_t lds = sizeof(double) * PK_WAVES_PER_BLOCK * (size_t)c->md.lds_x;
   if (lds < sizeof(double) * (size_t)c->md.ne_j) lds = sizeof(double) * (size_t)c->md.ne_j;
-  if ((rc = launch(c, K_XALL, A, tile_blocks(c) + 1, lds, c->stream))) return rc;
+  A.flags |= xall_flags(c);
+  if ((rc = launch(c, K_XALL, A, xall_blocks(c), lds, c->stream))) return rc;
   A.flags |= F_FIN_INT | F_WRITE_F | F_FIN_GRAD;
   return launch(c, K_FIN, A, 1, 0, c->stream);
 }
