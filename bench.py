@@ -38,7 +38,7 @@ for p in (ROOT, os.path.join(ROOT, "tests")):
 import numpy as np  # noqa: E402
 
 HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
-KERNEL_IDS = {"pk_int": 0, "pk_fin": 1, "pk_g": 2, "pk_grad": 3, "pk_jac": 4, "pk_hess": 5, "pk_xall": 6}
+KERNEL_IDS = {"pk_int": 0, "pk_fin": 1, "pk_g": 2, "pk_grad": 3, "pk_jac": 4, "pk_hess": 5, "pk_xall": 6, "pk_cycle": 12}
 
 
 def algorithmic_bytes(plan):
@@ -55,6 +55,8 @@ def algorithmic_bytes(plan):
     per["cycle"] = sum(per.values())
     # fused x-kernel (pk_xall): x is read once, f partials + grad + g + J written once
     per["xall"] = 8 * (n + 1 + n + m + plan.nnz_J)
+    # the same cycle when x is counted once (the single-launch pk_cycle reads it once per wave role, from L2)
+    per["cycle_x_once"] = per["cycle"] - 8 * 4 * n
     return per
 
 
@@ -146,8 +148,11 @@ def run_gpu(name, intervals, steps, warmup, rank, world, dist, time_kernel=None)
 
     B = algorithmic_bytes(plan)
     fused = world == 1 and not (plan.needs_I_grad or plan.needs_I_con or plan.jac.needs_I or plan.hess.needs_I)
-    if fused:
+    if fused and os.environ.get("POCKIT_AMD_CYCLE_MODE", "1") == "0":      # A/B: the two-launch form of the cycle
+        ev.set_cycle_mode(False)
         dominant = "pk_xall" if B["xall"] >= B["hess"] else "pk_hess"
+    elif fused:
+        dominant = "pk_cycle"           # ONE launch does the whole cycle: its algorithmic bytes are SURVEY 8(d)'s B
     else:
         dominant = "pk_jac" if B["jac"] >= B["hess"] else "pk_hess"
     for _ in range(warmup):
@@ -171,7 +176,7 @@ def run_gpu(name, intervals, steps, warmup, rank, world, dist, time_kernel=None)
     ev.profile(0)
     launches, total_ms = prof[time_kernel or dominant]
     # per-kernel event timing of every kernel, outside the timed region (diagnostic)
-    ev.profile(0x7FF)
+    ev.profile(0x1FFF)
     for _ in range(min(steps, 50)):
         step()
     torch.cuda.synchronize()
@@ -299,7 +304,10 @@ def main():
                        "inputs": "example guess*(1+1e-3 U(-1,1)) seed 0; lambda N(0,1) seed 1; sigma 1"},
             "roofline": {"bound": "hbm", "kernel": res["dominant"], "achieved": achieved, "peak": HBM_PEAK_GBPS,
                          "unit": "GB/s", "frac": (achieved / HBM_PEAK_GBPS if achieved else None), "traffic": traffic,
-                         "algorithmic_bytes_per_launch": dom_bytes, "avg_launch_us": dom_us,
+                         "algorithmic_bytes_per_launch": dom_bytes,
+                         "algorithmic_bytes_per_launch_x_counted_once": (res["bytes"]["cycle_x_once"] / n_gpus
+                                                                         if res["dominant"] == "pk_cycle" else None),
+                         "avg_launch_us": dom_us,
                          "timing": f"HIP events on the launch stream, every {EVENT_PERIOD}th launch of the timed region"},
             "kernel_us": res["kernel_us"],
             "cycle_algorithmic_bytes": res["bytes"]["cycle"],

@@ -169,13 +169,17 @@ int pk_eval_g_dev(pk_ctx* ctx, const double* d_x, double* d_g, void* stream);
 int pk_eval_jac_dev(pk_ctx* ctx, const double* d_x, double* d_vals, void* stream);
 int pk_eval_hess_dev(pk_ctx* ctx, const double* d_x, const double* d_lambda, double sigma, double* d_vals,
                      void* stream);
-/* one NLP-callback cycle f, grad f, g, J, H on the same x (IPOPT's per-iteration pattern): the x-only
- * outputs come from ONE fused launch (pk_xall: each node evaluated once) + pk_fin, then pk_hess */
+/* one NLP-callback cycle f, grad f, g, J, H on the same x (IPOPT's per-iteration pattern), as ONE launch
+ * (pk_cycle: the workgroups of the fused x-kernel -- each node evaluated once for f, grad f, g, J -- and of the
+ * Hessian kernel side by side, plus a finalize workgroup fed by the same launch).  One cycle may be in flight
+ * per context at a time (the launch owns the context's hand-off slots). */
 int pk_eval_cycle_dev(pk_ctx* ctx, const double* d_x, const double* d_lambda, double sigma, double* d_f,
                       double* d_grad, double* d_g, double* d_jac, double* d_hess, void* stream);
 /* Replay the fused cycle from a cached hipGraph while its pointers, sigma and stream do not change (a solver's
  * steady state); any change re-captures.  Off by default. */
 int pk_set_cycle_graph(pk_ctx* ctx, int enable);
+/* single_launch = 1 (default): pk_cycle; 0: the two-launch form, pk_xall then pk_hess, which also reduces */
+int pk_set_cycle_mode(pk_ctx* ctx, int single_launch);
 int pk_sync(pk_ctx* ctx, void* stream);
 
 /* Mesh-interval sharding across GPUs (one context per GPU, each holding its shard of the tiles):
@@ -189,7 +193,7 @@ int pk_eval_f_from_integrals_dev(pk_ctx* ctx, const double* d_x, double* d_f, vo
 
 /* HIP-event timing of the individual kernels on the launch stream.
  * kernel ids: 0 pk_int, 1 pk_fin, 2 pk_g, 3 pk_grad, 4 pk_jac, 5 pk_hess, 6 pk_xall, 7 pk_aux, 8 pk_outer,
- * 9 pk_hessc, 10 pk_err, 11 pk_csr.  pk_profile_sampling(n): only every n-th launch of a selected kernel is timed (a timed
+ * 9 pk_hessc, 10 pk_err, 11 pk_csr, 12 pk_cycle.  pk_profile_sampling(n): only every n-th launch of a selected kernel is timed (a timed
  * launch costs ~2-3 us more than a plain one, so timing every launch slows the loop being measured). */
 int pk_profile(pk_ctx* ctx, int kernel_mask /* bit k: time kernel k; 0 = off */);
 int pk_profile_sampling(pk_ctx* ctx, int period);

@@ -381,9 +381,11 @@ class ModelSource:
         targets += [("xall", "pk::tile_xall<{P}, 0>"), ("xall1", "pk::tile_xall<{P}, 1>"),
                     ("xall2", "pk::tile_xall<{P}, 2>")]
         for name, target in targets:
+            pub = name.startswith("xall")      # the x-kernels take the hand-off block of a pk_cycle launch (-1: none)
             S.append(f"  __device__ static __forceinline__ void tile_{name}(int phase, const PkArgs& A, const PkTile& tl, "
-                     f"double* __restrict__ lds, double* __restrict__ wint, double* __restrict__ wgrad, int lane) {{")
-            S.append(switch(f"{target}(A, tl, lds, wint, wgrad, lane)"))
+                     f"double* __restrict__ lds, double* __restrict__ wint, double* __restrict__ wgrad, int lane"
+                     f"{', int pub_blk' if pub else ''}) {{")
+            S.append(switch(f"{target}(A, tl, lds, wint, wgrad, lane{', pub_blk' if pub else ''})"))
             S.append("  }")
         ncmax = max([1] + [pp.phase.n_c for pp in plan.phase_plans])
         for cbname, tag in (("jac", "J"), ("hess", "H"), ("aux", "A")):

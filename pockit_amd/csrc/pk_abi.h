@@ -114,6 +114,10 @@ struct PkErrIv {
 
 #define PK_MAX_PHASES 8
 
+// pk_cycle's in-launch hand-off: a slot of cpart / cpart2 is either PK_EMPTY (a quiet-NaN pattern no arithmetic
+// produces) or the value a tile workgroup published during the current launch.
+#define PK_EMPTY 0x7FF8C0DEC0DEC0DEull
+
 struct PkArgs {
   const double* x;        // NLP variables (device)
   const double* lam;      // constraint multipliers (device; Hessian only)
@@ -129,12 +133,15 @@ struct PkArgs {
   const PkTile* tile;
   const PkKind* kind;
   const PkItem* items;
+  const PkItem* items2;   // pk_cycle only: the Hessian's boundary / system items (items = the Jacobian's)
   const int32_t* ib;
   const double* db;
   const int64_t* lb;
   double* Ibuf;           // integrals I_k (pre-pass result)
   double* partial;        // [workgroups][PK_NRED] per-workgroup partial sums of the integrands
   double* partial2;       // [workgroups][PK_NRED] per-workgroup partial sums of the shared gradient slots
+  unsigned long long* cpart;   // pk_cycle only: the same two arrays as 64-bit patterns, handed from the tile workgroups
+  unsigned long long* cpart2;  // to the finalize workgroup INSIDE one launch (every slot holds PK_EMPTY between launches)
   const PkErrIv* erriv;   // mesh error estimation (pk_err only)
   const double* errdb;
   double* o_errT;         // T_aug x      per phase [n_x][rows]
@@ -145,6 +152,7 @@ struct PkArgs {
   double* csr_out;
   unsigned long long* trace;   // developer tracing (models generated with POCKIT_AMD_TRACE=1): [tile][16] s_memtime marks
   int32_t n_tiles, n_items;
+  int32_t n_items2, pad0;
   int32_t n_phase, n;
   int32_t l_s, n_s, n_sys, m;
   int32_t gz_off, n_gz;   // ib: gradient slots the finalize kernel zero-fills

@@ -127,6 +127,33 @@ __device__ __forceinline__ double wave_sum(double v) {
   return __hiloint2double(hi, lo);
 }
 
+// ---- in-launch hand-off of the per-workgroup partial sums (pk_cycle) --------------------------------------
+// The tile workgroups of a pk_cycle launch publish their partial sums while the SAME launch's finalize workgroup
+// waits for them, so the sums over all nodes cost no second launch.  Protocol: every slot of cpart / cpart2 holds
+// PK_EMPTY between launches; a tile workgroup overwrites its slots with ONE agent-scope 64-bit store each (written
+// through the XCD's L2, fire and forget: no fence, no counter, no wait on the publishing side); the finalize
+// workgroup polls a slot with agent-scope loads until it is not PK_EMPTY, takes the value and puts PK_EMPTY back
+// (ordered before the next launch by the end of this one).  The data word is its own flag, so there is nothing to
+// order against it -- an arrival counter would need a release that writes back the whole dirty L2 (the variant
+// DESIGN.md section 5 measured at +6 us).  Forward progress: the publishers never wait for anything, the poller
+// occupies one workgroup slot; the poll is bounded (PK_POLL_LIMIT), after which the slot reads as NaN and the
+// launch ends with NaN in f / the gradient slots instead of hanging.
+#define PK_POLL_LIMIT (1 << 17)
+__device__ __forceinline__ void handoff_put(unsigned long long* slot, double v) {
+  unsigned long long b = (unsigned long long)__double_as_longlong(v);
+  if (b == PK_EMPTY) b = 0x7FF8000000000000ull;     // (a NaN either way)
+  __hip_atomic_store(slot, b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ double handoff_take(unsigned long long* slot) {
+  unsigned long long b = __hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  for (int tries = 0; b == PK_EMPTY && tries < PK_POLL_LIMIT; ++tries) {
+    __builtin_amdgcn_s_sleep(4);
+    b = __hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  __hip_atomic_store(slot, (unsigned long long)PK_EMPTY, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  return __longlong_as_double((long long)b);
+}
+
 // ---- per-phase scalars: static parameters, t0/tf with boundary substitution ------------------
 // (reference: phasebase.py:839-851  _value_basic)
 template <class P>
@@ -573,9 +600,12 @@ __device__ __forceinline__ void tile_hess(const PkArgs& A, const PkTile& tl, dou
 // the values (path constraints, defects, gradient, integrand sums), 2 the Jacobian (N segments, translation
 // entries, I-expanded segments); the role is a compile-time constant, so each wave's copy of the inlined model
 // evaluation keeps only what its outputs need and its serial chain is roughly halved.
+// pub_blk >= 0 (pk_cycle): the workgroup hands its partial sums to the launch's finalize workgroup right after
+// the evaluation phase (handoff_put), i.e. while its own defect / streaming phase is still to come.
 template <class P, int ROLE>
 __device__ __forceinline__ void tile_xall(const PkArgs& A, const PkTile& tl, double* __restrict__ sv,
-                                          double* __restrict__ wint, double* __restrict__ wgrad, int lane) {
+                                          double* __restrict__ wint, double* __restrict__ wgrad, int lane,
+                                          int pub_blk) {
   const PkPhase& ph = A.ph[P::INDEX];
   const TileGeom g = tile_geom<P>(tl);
   PK_MARK(0);
@@ -646,6 +676,16 @@ __device__ __forceinline__ void tile_xall(const PkArgs& A, const PkTile& tl, dou
   PK_MARK(4);
   __syncthreads();
   PK_MARK(5);
+  if (pub_blk >= 0 && (int)threadIdx.x < PK_NRED) {      // lanes of wave 0, whose wint / wgrad rows start the arrays
+    double vi = 0.0, vg = 0.0;
+#pragma unroll
+    for (int w = 0; w < PK_WAVES_PER_BLOCK; ++w) {        // same order as publish_block_partials
+      vi += wint[w * PK_NRED + threadIdx.x];
+      vg += wgrad[w * PK_NRED + threadIdx.x];
+    }
+    handoff_put(A.cpart + (size_t)pub_blk * PK_NRED + threadIdx.x, vi);
+    handoff_put(A.cpart2 + (size_t)pub_blk * PK_NRED + threadIdx.x, vg);
+  }
   if (A.flags & 256) return;   // diagnostic build switches: skip the phases after the barrier (all / one by one)
   if (ROLE != 2 && !(A.flags & 8192)) write_defects<P>(A, ph, tl, g, T, s, dt, sv, xr, xe, lane);
   PK_MARK(6);
@@ -791,21 +831,22 @@ struct ItemPref {
   double lam;
   bool ok;
 };
-__device__ __forceinline__ ItemPref prefetch_item(const PkArgs& A) {
+__device__ __forceinline__ ItemPref prefetch_item(const PkArgs& A, const PkItem* __restrict__ items, int n_items) {
   ItemPref ip;
-  ip.ok = (int)threadIdx.x < A.n_items;
+  ip.ok = (int)threadIdx.x < n_items;
   ip.lam = 1.0;
   if (ip.ok) {
-    ip.m = A.items[threadIdx.x];
+    ip.m = items[threadIdx.x];
     if (ip.m.lam >= 0) ip.lam = A.lam[ip.m.lam];
   }
   return ip;
 }
-__device__ __forceinline__ void scatter_items(const PkArgs& A, const ItemPref& ip, const double* __restrict__ E,
+__device__ __forceinline__ void scatter_items(const PkArgs& A, const PkItem* __restrict__ items, int n_items,
+                                              const ItemPref& ip, const double* __restrict__ E,
                                               double* __restrict__ out) {
   if (ip.ok) out[ip.m.pos] = ip.m.coef * E[ip.m.eid] * ip.lam;
-  for (int it = threadIdx.x + PK_BLOCK; it < A.n_items; it += PK_BLOCK) {
-    const PkItem m = A.items[it];
+  for (int it = threadIdx.x + PK_BLOCK; it < n_items; it += PK_BLOCK) {
+    const PkItem m = items[it];
     double v = m.coef * E[m.eid];
     if (m.lam >= 0) v *= A.lam[m.lam];
     out[m.pos] = v;
@@ -827,13 +868,15 @@ __device__ __forceinline__ void publish_block_partials(double* __restrict__ part
 
 // deterministic sum over the workgroups of phase k (fixed shape: strided thread sums, wave shuffle
 // tree, 4-way LDS combine)
-__device__ __forceinline__ double block_sum_partials(const PkArgs& A, const double* __restrict__ partial, int k,
-                                                     int r, double* red) {
+template <bool HANDOFF>
+__device__ __forceinline__ double block_sum_partials(const PkArgs& A, const double* __restrict__ partial,
+                                                     unsigned long long* cpart, int k, int r, double* red) {
   // (split launch, flags bit 5: two waves per tile, so twice the workgroups per phase)
   const int per = (A.flags & 32) ? PK_WAVES_PER_BLOCK / 2 : PK_WAVES_PER_BLOCK;
   const int blo = A.ph[k].tile_lo / per, bhi = A.ph[k].tile_hi / per;
   double v = 0.0;
-  for (int b = blo + (int)threadIdx.x; b < bhi; b += PK_BLOCK) v += partial[(size_t)b * PK_NRED + r];
+  for (int b = blo + (int)threadIdx.x; b < bhi; b += PK_BLOCK)
+    v += HANDOFF ? handoff_take(cpart + (size_t)b * PK_NRED + r) : partial[(size_t)b * PK_NRED + r];
   v = wave_sum(v);
   __syncthreads();
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
@@ -851,13 +894,16 @@ __device__ __forceinline__ double block_sum_partials(const PkArgs& A, const doub
 // longest of the launch), tile workgroups follow.
 #define PK_TILE_PROLOGUE(EDGE) PK_TILE_PROLOGUE_SPLIT(EDGE, 0)
 #define PK_TILE_PROLOGUE_SPLIT(EDGE, SHIFT)                                           \
+  const int blk = pk::xcd_tile_block((int)blockIdx.x, (EDGE), (int)gridDim.x);        \
+  PK_TILE_PROLOGUE_AT(SHIFT)
+// PK_TILE_PROLOGUE_AT: the caller has defined `blk`, the workgroup's tile block
+#define PK_TILE_PROLOGUE_AT(SHIFT)                                                    \
   extern __shared__ double pk_lds[];                                                  \
   __shared__ double wint[PK_WAVES_PER_BLOCK * PK_NRED];                               \
   __shared__ double wgrad[PK_WAVES_PER_BLOCK * PK_NRED];                              \
   /* wave-uniform on purpose (readfirstlane): the tile record then comes through the scalar cache into */ \
   /* SGPRs and everything derived from it is scalar arithmetic */                      \
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63; \
-  const int blk = pk::xcd_tile_block((int)blockIdx.x, (EDGE), (int)gridDim.x);        \
   const int ti = (blk * PK_WAVES_PER_BLOCK + wave) >> (SHIFT);                        \
   PkTile tl;                                                                          \
   if (ti < A.n_tiles) {                                                               \
@@ -877,12 +923,13 @@ __device__ __forceinline__ double block_sum_partials(const PkArgs& A, const doub
 
 // mode 0: Jacobian, 1: Hessian, 2: auxiliary buffer, 3: compact Hessian
 template <class Gen>
-__device__ __forceinline__ void edge_block(const PkArgs& A, int mode, bool with_g) {
+__device__ __forceinline__ void edge_block(const PkArgs& A, int mode, bool with_g, const PkItem* __restrict__ items,
+                                           int n_items) {
   extern __shared__ double pk_lds[];
   const PkSys sy{A.x + A.l_s, A.Ibuf, A.sigma, A.lam};
   if (A.flags & 2) return;   // secondary shard: boundary nodes / system level belong to the primary
   if (with_g && threadIdx.x == PK_BLOCK - 1 && A.n_sys > 0) Gen::sys_constraints(sy, A.o_g);   // systembase.py:607-611
-  const ItemPref ip = prefetch_item(A);
+  const ItemPref ip = prefetch_item(A, items, n_items);
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   for (int li = wave; li < Gen::NLISTS; li += PK_WAVES_PER_BLOCK)
     if (lane == 0) {
@@ -892,7 +939,7 @@ __device__ __forceinline__ void edge_block(const PkArgs& A, int mode, bool with_
       else Gen::edge_jac(li, A, sy, pk_lds);
     }
   __syncthreads();
-  scatter_items(A, ip, pk_lds, (mode == 1 || mode == 3) ? A.o_hess : (mode == 2 ? A.o_aux : A.o_jac));
+  scatter_items(A, items, n_items, ip, pk_lds, (mode == 1 || mode == 3) ? A.o_hess : (mode == 2 ? A.o_aux : A.o_jac));
 }
 
 
@@ -925,20 +972,20 @@ __device__ __forceinline__ void kernel_grad(const PkArgs& A) {
 
 template <class Gen>
 __device__ __forceinline__ void kernel_jac(const PkArgs& A) {
-  if (PK_IS_EDGE_BLOCK()) return edge_block<Gen>(A, 0, false);
+  if (PK_IS_EDGE_BLOCK()) return edge_block<Gen>(A, 0, false, A.items, A.n_items);
   PK_TILE_PROLOGUE(1);
   Gen::tile_jac(tl.phase, A, tl, pk_lds + wave * Gen::LDS_J, wint, wgrad, lane);
 }
 
-template <class Gen>
+template <class Gen, bool HANDOFF>
 __device__ __forceinline__ void fin_body(const PkArgs& A);
 
 template <class Gen>
 __device__ __forceinline__ void kernel_hess(const PkArgs& A) {
-  if (PK_IS_EDGE_BLOCK()) return edge_block<Gen>(A, 1, false);
+  if (PK_IS_EDGE_BLOCK()) return edge_block<Gen>(A, 1, false, A.items, A.n_items);
   if (blockIdx.x == 1) {
     // cycle mode: the reductions of the preceding pk_xall launch ride along in a workgroup of their own
-    if (A.flags & (8 | 16)) fin_body<Gen>(A);
+    if (A.flags & (8 | 16)) fin_body<Gen, false>(A);
     return;
   }
   PK_TILE_PROLOGUE(2);
@@ -947,14 +994,14 @@ __device__ __forceinline__ void kernel_hess(const PkArgs& A) {
 
 template <class Gen>
 __device__ __forceinline__ void kernel_hessc(const PkArgs& A) {
-  if (PK_IS_EDGE_BLOCK()) return edge_block<Gen>(A, 3, false);
+  if (PK_IS_EDGE_BLOCK()) return edge_block<Gen>(A, 3, false, A.items, A.n_items);
   PK_TILE_PROLOGUE(1);
   Gen::tile_hessc(tl.phase, A, tl, pk_lds, wint, wgrad, lane);
 }
 
 template <class Gen>
 __device__ __forceinline__ void kernel_aux(const PkArgs& A) {
-  if (PK_IS_EDGE_BLOCK()) return edge_block<Gen>(A, 2, false);
+  if (PK_IS_EDGE_BLOCK()) return edge_block<Gen>(A, 2, false, A.items, A.n_items);
   PK_TILE_PROLOGUE(1);
   Gen::tile_aux(tl.phase, A, tl, pk_lds, wint, wgrad, lane);
 }
@@ -1132,13 +1179,13 @@ __device__ __forceinline__ void kernel_xall(const PkArgs& A) {
 #endif
   if (A.flags & 1024) return;                                   // diagnostic switches (POCKIT_AMD_DEBUG_FLAGS)
   if (PK_IS_EDGE_BLOCK() && (A.flags & 2048)) return;
-  if (PK_IS_EDGE_BLOCK()) return edge_block<Gen>(A, 0, true);
+  if (PK_IS_EDGE_BLOCK()) return edge_block<Gen>(A, 0, true, A.items, A.n_items);
   if (A.flags & 32) {   // split launch: waves 2t and 2t+1 share tile t (values / Jacobian)
     PK_TILE_PROLOGUE_SPLIT(1, 1);
     if (wave & 1)
-      Gen::tile_xall2(tl.phase, A, tl, pk_lds + wave * Gen::LDS_X, wint + wave * PK_NRED, wgrad + wave * PK_NRED, lane);
+      Gen::tile_xall2(tl.phase, A, tl, pk_lds + wave * Gen::LDS_X, wint + wave * PK_NRED, wgrad + wave * PK_NRED, lane, -1);
     else
-      Gen::tile_xall1(tl.phase, A, tl, pk_lds + wave * Gen::LDS_X, wint + wave * PK_NRED, wgrad + wave * PK_NRED, lane);
+      Gen::tile_xall1(tl.phase, A, tl, pk_lds + wave * Gen::LDS_X, wint + wave * PK_NRED, wgrad + wave * PK_NRED, lane, -1);
     publish_block_partials(A.partial, wint, blk);
     publish_block_partials(A.partial2, wgrad, blk);
     return;
@@ -1148,16 +1195,58 @@ __device__ __forceinline__ void kernel_xall(const PkArgs& A) {
   if (A.trace != nullptr && lane == 0 && tl.pad >= 0) A.trace[(size_t)tl.pad * 16 + 10] = t_entry;
 #endif
   PK_MARK(11);
-  Gen::tile_xall(tl.phase, A, tl, pk_lds + wave * Gen::LDS_X, wint + wave * PK_NRED, wgrad + wave * PK_NRED, lane);
+  Gen::tile_xall(tl.phase, A, tl, pk_lds + wave * Gen::LDS_X, wint + wave * PK_NRED, wgrad + wave * PK_NRED, lane, -1);
   publish_block_partials(A.partial, wint, blk);
   publish_block_partials(A.partial2, wgrad, blk);
   PK_MARK(12);
 }
 
+// ============================================================================================
+// pk_cycle: the whole NLP-callback cycle (f, grad f, g, J, H on one x, lambda, sigma) in ONE launch.
+// A 12k-node cycle moves 15 MB (2 us at HBM peak) while every launch costs a fixed 2-5 us and the kernels of a
+// stream do not overlap, so the cycle is the union of pk_xall's and pk_hess's workgroups instead of their sequence:
+//   workgroup 0  boundary nodes / system level of g and J          (edge_block mode 0)
+//   workgroup 1  boundary nodes / system level of H                (edge_block mode 1)
+//   workgroup 2  the sums over all nodes (integrals, f, shared gradient slots), fed by the tile workgroups of
+//                this same launch through the hand-off slots (fin_body<HANDOFF>)
+//   the rest     tile workgroups; consecutive slots alternate [x-kernel block(s) | Hessian block] of the same tiles
+//                so that every XCD gets a contiguous range of tiles of BOTH output arrays (xcd_tile_block)
+// Every wave runs exactly what it runs in pk_xall / pk_hess (three waves per tile when the x-part is split:
+// values, Jacobian, Hessian), they just run at the same time.
+// ============================================================================================
+template <class Gen>
+__device__ __forceinline__ void kernel_cycle(const PkArgs& A) {
+  if (blockIdx.x == 0) return edge_block<Gen>(A, 0, true, A.items, A.n_items);
+  if (blockIdx.x == 1) return edge_block<Gen>(A, 1, false, A.items2, A.n_items2);
+  if (blockIdx.x == 2) return fin_body<Gen, true>(A);
+  const int slot = pk::xcd_tile_block((int)blockIdx.x, 3, (int)gridDim.x);
+  const bool split = (A.flags & 32) != 0;
+  const int grp = split ? slot / 3 : slot >> 1;
+  const int sub = slot - grp * (split ? 3 : 2);
+  if (sub == (split ? 2 : 1)) {                       // Hessian block `grp`: four tiles, one wave each
+    const int blk = grp;
+    PK_TILE_PROLOGUE_AT(0);
+    Gen::tile_hess(tl.phase, A, tl, pk_lds + wave * Gen::LDS_H, wint, wgrad, lane);
+    return;
+  }
+  if (split) {                                        // x block 2 grp + sub: two tiles, waves (values, Jacobian) each
+    const int blk = 2 * grp + sub;
+    PK_TILE_PROLOGUE_AT(1);
+    if (wave & 1)
+      Gen::tile_xall2(tl.phase, A, tl, pk_lds + wave * Gen::LDS_X, wint + wave * PK_NRED, wgrad + wave * PK_NRED, lane, blk);
+    else
+      Gen::tile_xall1(tl.phase, A, tl, pk_lds + wave * Gen::LDS_X, wint + wave * PK_NRED, wgrad + wave * PK_NRED, lane, blk);
+    return;
+  }
+  const int blk = grp;
+  PK_TILE_PROLOGUE_AT(0);
+  Gen::tile_xall(tl.phase, A, tl, pk_lds + wave * Gen::LDS_X, wint + wave * PK_NRED, wgrad + wave * PK_NRED, lane, blk);
+}
+
 // The reductions over all workgroups, by ONE workgroup (all 256 threads must call it).
 // flags bit 3: I_k = dt * sum of partials -> Ibuf; bit 0: f = F_o(I, s) -> o_f (systembase.py:592-605);
 // bit 4: the gradient slots shared by all nodes (systembase.py:654-657).
-template <class Gen>
+template <class Gen, bool HANDOFF>
 __device__ __forceinline__ void fin_body(const PkArgs& A) {
   __shared__ double red[PK_WAVES_PER_BLOCK];
   __shared__ double tot[PK_NPHASE * PK_NRED];
@@ -1168,14 +1257,14 @@ __device__ __forceinline__ void fin_body(const PkArgs& A) {
   if (A.flags & 8) {
     for (int n = 0; n < Gen::N_INT; ++n) {
       const int k = Gen::int_phase(n);
-      const double sum = block_sum_partials(A, A.partial, k, Gen::int_slot(n), red);
+      const double sum = block_sum_partials<HANDOFF>(A, A.partial, A.cpart, k, Gen::int_slot(n), red);
       if (threadIdx.x == 0) A.Ibuf[Gen::int_global(n)] = sum * dts[k];
     }
   }
   if (A.flags & 16) {
     for (int k = 0; k < PK_NPHASE; ++k)
       for (int r = 0; r < Gen::gr_nr(k); ++r) {
-        const double v = block_sum_partials(A, A.partial2, k, r, red);
+        const double v = block_sum_partials<HANDOFF>(A, A.partial2, A.cpart2, k, r, red);
         if (threadIdx.x == 0) tot[k * PK_NRED + r] = v;
       }
   }
@@ -1196,7 +1285,7 @@ __device__ __forceinline__ void fin_body(const PkArgs& A) {
 
 template <class Gen>
 __device__ __forceinline__ void kernel_fin(const PkArgs& A) {
-  fin_body<Gen>(A);
+  fin_body<Gen, false>(A);
 }
 
 }  // namespace pk
@@ -1213,4 +1302,5 @@ __device__ __forceinline__ void kernel_fin(const PkArgs& A) {
   extern "C" __global__ __launch_bounds__(PK_BLOCK) void pk_outer(PkArgs A) { pk::kernel_outer(A); }     \
   extern "C" __global__ __launch_bounds__(PK_BLOCK) void pk_hessc(PkArgs A) { pk::kernel_hessc<GEN>(A); } \
   extern "C" __global__ __launch_bounds__(PK_BLOCK) void pk_err(PkArgs A) { pk::kernel_err<GEN>(A); }     \
-  extern "C" __global__ __launch_bounds__(PK_BLOCK) void pk_csr(PkArgs A) { pk::kernel_csr(A); }
+  extern "C" __global__ __launch_bounds__(PK_BLOCK) void pk_csr(PkArgs A) { pk::kernel_csr(A); }             \
+  extern "C" __global__ __launch_bounds__(PK_BLOCK) void pk_cycle(PkArgs A) { pk::kernel_cycle<GEN>(A); }

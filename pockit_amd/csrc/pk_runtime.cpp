@@ -10,8 +10,10 @@
 //   eval_g     [pk_int, pk_fin(integrals)]?  pk_g
 //   eval_jac   [pk_int, pk_fin(integrals)]?  pk_jac
 //   eval_hess  [pk_int, pk_fin(integrals)]?  pk_hess
-//   cycle      pk_xall (f partials, grad f, g, J from one node evaluation), pk_hess (whose boundary
-//              workgroup also does pk_fin's reductions: integrals, f, shared gradient slots)
+//   cycle      pk_cycle: ONE launch holding pk_xall's workgroups (f partials, grad f, g, J from one node
+//              evaluation), pk_hess's workgroups and a finalize workgroup that receives the partial sums of
+//              the same launch through hand-off slots (integrals, f, shared gradient slots);
+//              pk_set_cycle_mode(0) selects the older two-launch form pk_xall, pk_hess(+ reductions)
 // ("?" = only when a system-level function is nonlinear in the integrals, pk_model_desc.prepass_*).
 //
 // There is no CPU evaluation path: every entry point fails with an error code when no device /
@@ -33,9 +35,9 @@
 
 namespace {
 
-enum { K_INT = 0, K_FIN, K_G, K_GRAD, K_JAC, K_HESS, K_XALL, K_AUX, K_OUTER, K_HESSC, K_ERR, K_CSR, K_COUNT };
+enum { K_INT = 0, K_FIN, K_G, K_GRAD, K_JAC, K_HESS, K_XALL, K_AUX, K_OUTER, K_HESSC, K_ERR, K_CSR, K_CYCLE, K_COUNT };
 const char* const kKernelNames[K_COUNT] = {"pk_int", "pk_fin", "pk_g", "pk_grad", "pk_jac", "pk_hess", "pk_xall",
-                                           "pk_aux", "pk_outer", "pk_hessc", "pk_err", "pk_csr"};
+                                           "pk_aux", "pk_outer", "pk_hessc", "pk_err", "pk_csr", "pk_cycle"};
 enum { F_WRITE_F = 1, F_SECONDARY = 2, F_FIN_INT = 8, F_FIN_GRAD = 16, F_SPLIT = 32 };
 
 thread_local std::string g_create_error;
@@ -56,6 +58,8 @@ struct pk_ctx {
   bool external_prepass = false; // sharded mode: the caller all-reduces the integrals itself
   double* ext_I = nullptr;      // caller-owned integral buffer (sharded mode)
   bool split_xall = false;      // pk_xall with two waves per tile (values / Jacobian), see pk_set_problem
+  int cycle_mode = 1;           // 1: single-launch pk_cycle; 0: pk_xall + pk_hess (pk_set_cycle_mode)
+  unsigned long long *d_cpart = nullptr, *d_cpart2 = nullptr;   // pk_cycle's hand-off slots (PK_EMPTY between launches)
   unsigned profile_mask = 0;
   unsigned profile_period = 1;  // time every n-th launch of a selected kernel
   unsigned profile_seen[16] = {};
@@ -151,6 +155,7 @@ void free_problem(pk_ctx* c) {
   release(c->d_ib); release(c->d_db); release(c->d_lb);
   release(c->d_x); release(c->d_lam); release(c->d_f); release(c->d_grad); release(c->d_g); release(c->d_J);
   release(c->d_H); release(c->d_I); release(c->d_partial); release(c->d_partial2);
+  release(c->d_cpart); release(c->d_cpart2);
   if (c->h_x) (void)hipHostFree(c->h_x);
   if (c->h_lam) (void)hipHostFree(c->h_lam);
   c->h_x = c->h_lam = nullptr;
@@ -182,7 +187,8 @@ PkArgs base_args(pk_ctx* c, const double* d_x, const double* d_lam, double sigma
   A.x = d_x; A.lam = d_lam; A.sigma = sigma;
   A.phase = (const PkPhase*)c->d_phases; A.tile = (const PkTile*)c->d_tiles; A.kind = (const PkKind*)c->d_kinds;
   A.items = nullptr; A.ib = c->d_ib; A.db = c->d_db; A.lb = c->d_lb;
-  A.Ibuf = c->ext_I ? c->ext_I : c->d_I; A.partial = c->d_partial; A.partial2 = c->d_partial2; A.o_aux = c->d_aux; A.outer = (const PkOuter*)c->d_outer; A.n_outer = c->n_outer;
+  A.Ibuf = c->ext_I ? c->ext_I : c->d_I; A.partial = c->d_partial; A.partial2 = c->d_partial2;
+  A.cpart = c->d_cpart; A.cpart2 = c->d_cpart2; A.o_aux = c->d_aux; A.outer = (const PkOuter*)c->d_outer; A.n_outer = c->n_outer;
   A.n_tiles = c->n_tiles; A.n_items = 0; A.n_phase = c->n_phase; A.n = c->n;
   A.l_s = c->l_s; A.n_s = c->n_s; A.n_sys = c->n_sys; A.m = c->m;
   A.gz_off = c->gz_off; A.n_gz = c->n_gz; A.flags = c->shard_flags | c->debug_flags;
@@ -234,9 +240,27 @@ int prepass(pk_ctx* c, const double* d_x, const double* d_lam, double sigma, dou
 unsigned xall_blocks(const pk_ctx* c) { return (c->split_xall ? 2u : 1u) * tile_blocks(c) + 1u; }
 int xall_flags(const pk_ctx* c) { return c->split_xall ? F_SPLIT : 0; }
 
+// the cycle as ONE launch (pk_cycle): [edge J | edge H | finalize | tile slots: x block(s) + Hessian block per group]
+int enqueue_single_launch_cycle(pk_ctx* c, const double* d_x, const double* d_lam, double sigma, double* d_f,
+                                double* d_grad, double* d_g, double* d_jac, double* d_hess, hipStream_t st) {
+  PkArgs A = base_args(c, d_x, d_lam, sigma);
+  A.o_f = d_f; A.o_grad = d_grad; A.o_g = d_g; A.o_jac = d_jac; A.o_hess = d_hess;
+  A.items = (const PkItem*)c->d_items_jac;
+  A.n_items = c->n_items_jac;
+  A.items2 = (const PkItem*)c->d_items_hess;
+  A.n_items2 = c->n_items_hess;
+  A.flags |= F_FIN_INT | F_WRITE_F | F_FIN_GRAD | xall_flags(c);
+  size_t dbl = PK_WAVES_PER_BLOCK * (size_t)(c->md.lds_x > c->md.lds_h ? c->md.lds_x : c->md.lds_h);
+  if (dbl < (size_t)c->md.ne_j) dbl = (size_t)c->md.ne_j;
+  if (dbl < (size_t)c->md.ne_h) dbl = (size_t)c->md.ne_h;
+  const unsigned per_group = c->split_xall ? 3u : 2u;
+  return launch(c, K_CYCLE, A, tile_blocks(c) * per_group + 3u, sizeof(double) * dbl, st);
+}
+
 int enqueue_fused_cycle(pk_ctx* c, const double* d_x, const double* d_lam, double sigma, double* d_f, double* d_grad,
                         double* d_g, double* d_jac, double* d_hess, hipStream_t st) {
   int rc;
+  if (c->cycle_mode == 1) return enqueue_single_launch_cycle(c, d_x, d_lam, sigma, d_f, d_grad, d_g, d_jac, d_hess, st);
   PkArgs A = base_args(c, d_x, nullptr, 0.0);
   A.o_f = d_f; A.o_grad = d_grad; A.o_g = d_g; A.o_jac = d_jac;
   A.items = (const PkItem*)c->d_items_jac;
@@ -368,6 +392,12 @@ int pk_set_problem(pk_ctx* c, const pk_problem_desc* pd) {
       (rc = dalloc(&c->d_partial, (2 * (size_t)c->n_tiles / PK_WAVES_PER_BLOCK + 2) * (size_t)c->md.nred)) ||
       (rc = dalloc(&c->d_partial2, (2 * (size_t)c->n_tiles / PK_WAVES_PER_BLOCK + 2) * (size_t)c->md.nred)))
     return rc;
+  {   // hand-off slots of pk_cycle: one per x-kernel workgroup and reduction row, PK_EMPTY between launches
+    const size_t slots = (2 * (size_t)c->n_tiles / PK_WAVES_PER_BLOCK + 2) * (size_t)c->md.nred;
+    const std::vector<unsigned long long> empty(slots, (unsigned long long)PK_EMPTY);
+    if ((rc = upload(c, (void**)&c->d_cpart, empty.data(), sizeof(unsigned long long) * slots))) return rc;
+    if ((rc = upload(c, (void**)&c->d_cpart2, empty.data(), sizeof(unsigned long long) * slots))) return rc;
+  }
   {
     const size_t cnt[5] = {1, (size_t)c->n, (size_t)c->m, (size_t)c->nnz_J, (size_t)c->nnz_H};
     PK_HIP(c, hipHostMalloc((void**)&c->h_x, sizeof(double) * (size_t)(c->n ? c->n : 1), hipHostMallocDefault));
@@ -702,6 +732,14 @@ int pk_eval_cycle_dev(pk_ctx* c, const double* d_x, const double* d_lam, double 
   if (e != hipSuccess) { c->cyc_exec = nullptr; return fail(c, 3, "pk_eval_cycle: graph instantiation failed: %s", hipGetErrorString(e)); }
   c->cyc_key = key;
   PK_HIP(c, hipGraphLaunch(c->cyc_exec, st));
+  return 0;
+}
+
+// 1 (default): the cycle is ONE launch (pk_cycle); 0: two launches (pk_xall, then pk_hess with the reductions)
+int pk_set_cycle_mode(pk_ctx* c, int single_launch) {
+  if (!c) return fail(nullptr, 1, "null context");
+  c->cycle_mode = single_launch ? 1 : 0;
+  drop_cycle_graph(c);
   return 0;
 }
 

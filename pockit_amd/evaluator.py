@@ -385,8 +385,7 @@ class Evaluator:
                                                       stream))
 
     def cycle(self, x, lagrange, obj_factor):
-        """All five outputs on the same x from the fused path (pk_xall + pk_fin + pk_hess):
-        returns (f, grad, g, J, H)."""
+        """All five outputs on the same x from the single-launch cycle (pk_cycle): returns (f, grad, g, J, H)."""
         x = self._x(x)
         lam = np.ascontiguousarray(lagrange, dtype=np.float64)
         f, grad, g = np.empty(1), np.empty(self.plan.n), np.empty(self.plan.m)
@@ -414,6 +413,10 @@ class Evaluator:
         """Replay the fused cycle from a cached hipGraph (measured slower than plain launches on MI355X /
         ROCm 7.2 -- DESIGN.md section 5 -- so it is off by default)."""
         self.ctx.check(self.ctx.lib.pk_set_cycle_graph(self.ctx.handle, int(bool(enable))))
+
+    def set_cycle_mode(self, single_launch=True):
+        """True (default): one cycle = one launch (pk_cycle).  False: pk_xall, then pk_hess with the reductions."""
+        self.ctx.check(self.ctx.lib.pk_set_cycle_mode(self.ctx.handle, int(bool(single_launch))))
 
     def profile_read(self):
         """{kernel name: (launches, total_ms)} accumulated while profiling was enabled."""

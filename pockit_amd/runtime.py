@@ -60,7 +60,8 @@ ERRIV_DTYPE = np.dtype([("phase", np.int32), ("K", np.int32), ("lm", np.int32), 
 
 WAVES_PER_BLOCK = 4  # PK_WAVES_PER_BLOCK of csrc/pk_abi.h
 WAVE = 64  # PK_WAVE
-KERNELS = ["pk_int", "pk_fin", "pk_g", "pk_grad", "pk_jac", "pk_hess", "pk_xall", "pk_aux", "pk_outer", "pk_hessc", "pk_err", "pk_csr"]
+KERNELS = ["pk_int", "pk_fin", "pk_g", "pk_grad", "pk_jac", "pk_hess", "pk_xall", "pk_aux", "pk_outer", "pk_hessc", "pk_err", "pk_csr",
+           "pk_cycle"]
 EXPORTS = ["pk_create", "pk_destroy", "pk_last_error", "pk_device_count", "pk_load_model", "pk_set_problem",
            "pk_get_structure", "pk_eval_f", "pk_eval_grad", "pk_eval_g", "pk_eval_jac", "pk_eval_hess",
            "pk_eval_f_dev", "pk_eval_grad_dev", "pk_eval_g_dev", "pk_eval_jac_dev", "pk_eval_hess_dev",
@@ -69,7 +70,7 @@ EXPORTS = ["pk_create", "pk_destroy", "pk_last_error", "pk_device_count", "pk_lo
            "pk_prepare_x", "pk_fetch", "pk_eval_hess_prepared", "pk_host_buffer", "pk_eval_hessc", "pk_eval_hessc_dev",
            "pk_set_mesh_error_tables", "pk_eval_mesh_error", "pk_eval_mesh_error_dev", "pk_set_cycle_graph", "pk_profile_sampling",
            "pk_set_csr_map", "pk_gather_csr_dev", "pk_eval_jac_csr_dev", "pk_eval_hess_csr_dev", "pk_eval_jac_csr",
-           "pk_eval_hess_csr", "pk_trace_read"]
+           "pk_eval_hess_csr", "pk_trace_read", "pk_set_cycle_mode"]
 
 _lib = None
 
@@ -134,6 +135,7 @@ def load_library():
     lib.pk_eval_mesh_error.argtypes = [vp, dp, dp, dp]
     lib.pk_eval_mesh_error_dev.argtypes = [vp, vp, vp, vp, vp]
     lib.pk_set_cycle_graph.argtypes = [vp, C.c_int]
+    lib.pk_set_cycle_mode.argtypes = [vp, C.c_int]
     lib.pk_profile_sampling.argtypes = [vp, C.c_int]
     lib.pk_set_csr_map.argtypes = [vp, C.c_int, c_int32_p, c_int32_p, C.c_int64, C.c_int64]
     lib.pk_gather_csr_dev.argtypes = [vp, C.c_int, vp, vp, vp]

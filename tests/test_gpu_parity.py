@@ -368,6 +368,82 @@ def test_cycle_graph_replay_gives_identical_results():
         ev.set_cycle_graph(False)
 
 
+@pytest.mark.parametrize("case", [("planar_quadrotor", "radau", dict(mesh=301, num_point=6)),
+                                  ("two_stage_rocket", "radau", dict(mesh=150, num_point=4)),
+                                  ("brachistochrone", "lobatto", dict(mesh=1100, num_point=5)),
+                                  ("humanoid_wbc", "radau", dict(mesh=260, num_point=8))])
+@pytest.mark.parametrize("split", ["1", "0"])
+def test_single_launch_cycle_equals_two_launch_cycle_bit_for_bit(case, split, monkeypatch):
+    """pk_cycle (x-kernel, Hessian and finalize workgroups in ONE launch, partial sums handed over inside the
+    launch) runs the same waves and the same fixed-shape reductions as pk_xall -> pk_hess(+reductions): all five
+    outputs must be bit-identical, for split (<= 1024 tiles) and unsplit launches, and equal to the oracle."""
+    import torch
+
+    monkeypatch.setenv("POCKIT_AMD_SPLIT", split)      # two waves per tile in the x-part (values / Jacobian) or one
+    bname, scheme, kw = case
+    system, _, guess = getattr(models, bname)(_ns(scheme, "pockit_amd"), **kw)
+    ref, _, _ = getattr(models, bname)(_ns(scheme, "oracle"), **kw)
+    plan, ev = system.plan, system.evaluator
+    x, lam, sigma = models.bench_inputs(system, guess)
+    dev = torch.device("cuda", 0)
+    dx, dlam = torch.from_numpy(x).to(dev), torch.from_numpy(lam).to(dev)
+    sizes = (("f", 1), ("grad", plan.n), ("g", plan.m), ("J", plan.nnz_J), ("H", plan.nnz_H))
+
+    def run():
+        o = {k: torch.full((n,), float("nan"), dtype=torch.float64, device=dev) for k, n in sizes}
+        torch.cuda.synchronize()
+        for _ in range(2):
+            ev.cycle_dev(dx.data_ptr(), dlam.data_ptr(), sigma, *[o[k].data_ptr() for k, _ in sizes])
+        ev.sync()
+        return {k: v.cpu().numpy() for k, v in o.items()}
+
+    single = run()
+    ev.set_cycle_mode(False)
+    try:
+        two = run()
+    finally:
+        ev.set_cycle_mode(True)
+    for k, _ in sizes:
+        assert np.array_equal(single[k], two[k]), k
+    close(single["f"][0], ref.objective(x), what="f")
+    close(single["grad"], ref.gradient(x), what="grad")
+    close(single["g"], ref.constraints(x), what="g")
+    close(single["J"], ref.jacobian(x), what="J")
+    close(single["H"], ref.hessian(x, lam, sigma), what="H")
+
+
+def test_single_launch_cycle_hand_off_survives_back_to_back_launches():
+    """The hand-off slots of pk_cycle are emptied by the launch that consumed them: 600 cycles enqueued back to
+    back on alternating iterates, every launch writing f and grad f to its own slot, must each reproduce the value
+    of their iterate exactly (a stale or missed partial sum would show up in f or in the t0/tf gradient slots)."""
+    import torch
+
+    system, _, guess = models.two_stage_rocket(_ns("radau", "pockit_amd"), 120, 4)
+    plan, ev = system.plan, system.evaluator
+    xa, lam, sigma = models.bench_inputs(system, guess)
+    xb = xa * (1.0 + 0.05 * np.random.default_rng(11).uniform(-1, 1, xa.shape))
+    dev = torch.device("cuda", 0)
+    dxs = [torch.from_numpy(v).to(dev) for v in (xa, xb)]
+    dlam = torch.from_numpy(lam).to(dev)
+    reps = 600
+    f = torch.full((reps,), float("nan"), dtype=torch.float64, device=dev)
+    grad = torch.full((reps, plan.n), float("nan"), dtype=torch.float64, device=dev)
+    g, J, H = (torch.zeros(n, dtype=torch.float64, device=dev) for n in (plan.m, plan.nnz_J, plan.nnz_H))
+    torch.cuda.synchronize()
+    for i in range(reps):
+        ev.cycle_dev(dxs[i % 2].data_ptr(), dlam.data_ptr(), sigma, f[i:].data_ptr(), grad[i].data_ptr(), g.data_ptr(),
+                     J.data_ptr(), H.data_ptr())
+    ev.sync()
+    f, grad = f.cpu().numpy(), grad.cpu().numpy()
+    for par in (0, 1):
+        assert np.all(f[par::2] == f[par]) and np.all(grad[par::2] == grad[par]), par
+    assert f[0] != f[1]
+    ref, _, _ = models.two_stage_rocket(_ns("radau", "oracle"), 120, 4)
+    for par, x in ((0, xa), (1, xb)):
+        close(f[par], ref.objective(x), what="f")
+        close(grad[par], ref.gradient(x), what="grad")
+
+
 @pytest.mark.parametrize("name", ["brach_lgr_3x4", "quad_lgl_4x5", "rocket_lgr_3x4", "humanoid_lgr_2x3", "worked_lgr"])
 def test_device_csr_handoff_matches_reference_matrices(name):
     """pk_csr: J and the lower triangle of H gathered into CSR on the device equal the matrices the reference's
