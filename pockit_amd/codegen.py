@@ -336,6 +336,7 @@ class ModelSource:
         S.append(f"#define PK_NPHASE {nP}")
         S.append(f"#define PK_NS {max(plan.n_s, 1)}")
         S.append(f"#define PK_NSYS {max(plan.n_sys, 1)}")
+        S.append(f"#define PK_NI {max(len(plan.I_syms), 1)}")
         if os.environ.get("POCKIT_AMD_TRACE", "0") == "1":   # developer tracing of the wave timeline (tools/wave_trace.py)
             S.append("#define PK_TRACE 1")
         if os.environ.get("POCKIT_AMD_XCD_REMAP", "1") == "0":       # A/B switch of the XCD-aware block mapping
@@ -439,6 +440,13 @@ class ModelSource:
         S.append(table_fn("int_phase", [k for _, k, _ in ints]))
         S.append(table_fn("int_slot", [r for _, _, r in ints]))
         S.append(table_fn("gr_nr", [len(v) for v in plan.grad_red_slots]))
+        # rows of pk_cycle's in-launch finalize: the needed integrands, then the shared gradient slots phase by phase
+        rows = [(0, k, r) for _, k, r in ints]
+        rows += [(1, k, r) for k, v in enumerate(plan.grad_red_slots) for r in range(len(v))]
+        S.append(f"  static constexpr int N_ROWS = {len(rows)};")
+        S.append(table_fn("row_arr", [a for a, _, _ in rows]))
+        S.append(table_fn("row_phase", [k for _, k, _ in rows]))
+        S.append(table_fn("row_slot", [r for _, _, r in rows]))
         S.append("  __device__ static __forceinline__ double phase_dt(int phase, const PkArgs& A) {")
         S.append(switch("return pk::phase_dt<{P}>(A)"))
         S.append("    return 0.0;\n  }")

@@ -132,7 +132,7 @@ __device__ __forceinline__ double wave_sum(double v) {
 // waits for them, so the sums over all nodes cost no second launch.  Protocol: every slot of cpart / cpart2 holds
 // PK_EMPTY between launches; a tile workgroup overwrites its slots with ONE agent-scope 64-bit store each (written
 // through the XCD's L2, fire and forget: no fence, no counter, no wait on the publishing side); the finalize
-// workgroup polls a slot with agent-scope loads until it is not PK_EMPTY, takes the value and puts PK_EMPTY back
+// workgroup polls its slots with agent-scope loads until none is PK_EMPTY, takes the values and puts PK_EMPTY back
 // (ordered before the next launch by the end of this one).  The data word is its own flag, so there is nothing to
 // order against it -- an arrival counter would need a release that writes back the whole dirty L2 (the variant
 // DESIGN.md section 5 measured at +6 us).  Forward progress: the publishers never wait for anything, the poller
@@ -144,14 +144,11 @@ __device__ __forceinline__ void handoff_put(unsigned long long* slot, double v) 
   if (b == PK_EMPTY) b = 0x7FF8000000000000ull;     // (a NaN either way)
   __hip_atomic_store(slot, b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
-__device__ __forceinline__ double handoff_take(unsigned long long* slot) {
-  unsigned long long b = __hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  for (int tries = 0; b == PK_EMPTY && tries < PK_POLL_LIMIT; ++tries) {
-    __builtin_amdgcn_s_sleep(4);
-    b = __hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  }
+__device__ __forceinline__ unsigned long long handoff_peek(unsigned long long* slot) {
+  return __hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void handoff_clear(unsigned long long* slot) {
   __hip_atomic_store(slot, (unsigned long long)PK_EMPTY, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  return __longlong_as_double((long long)b);
 }
 
 // ---- per-phase scalars: static parameters, t0/tf with boundary substitution ------------------
@@ -868,15 +865,13 @@ __device__ __forceinline__ void publish_block_partials(double* __restrict__ part
 
 // deterministic sum over the workgroups of phase k (fixed shape: strided thread sums, wave shuffle
 // tree, 4-way LDS combine)
-template <bool HANDOFF>
-__device__ __forceinline__ double block_sum_partials(const PkArgs& A, const double* __restrict__ partial,
-                                                     unsigned long long* cpart, int k, int r, double* red) {
+__device__ __forceinline__ double block_sum_partials(const PkArgs& A, const double* __restrict__ partial, int k,
+                                                     int r, double* red) {
   // (split launch, flags bit 5: two waves per tile, so twice the workgroups per phase)
   const int per = (A.flags & 32) ? PK_WAVES_PER_BLOCK / 2 : PK_WAVES_PER_BLOCK;
   const int blo = A.ph[k].tile_lo / per, bhi = A.ph[k].tile_hi / per;
   double v = 0.0;
-  for (int b = blo + (int)threadIdx.x; b < bhi; b += PK_BLOCK)
-    v += HANDOFF ? handoff_take(cpart + (size_t)b * PK_NRED + r) : partial[(size_t)b * PK_NRED + r];
+  for (int b = blo + (int)threadIdx.x; b < bhi; b += PK_BLOCK) v += partial[(size_t)b * PK_NRED + r];
   v = wave_sum(v);
   __syncthreads();
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
@@ -977,15 +972,17 @@ __device__ __forceinline__ void kernel_jac(const PkArgs& A) {
   Gen::tile_jac(tl.phase, A, tl, pk_lds + wave * Gen::LDS_J, wint, wgrad, lane);
 }
 
-template <class Gen, bool HANDOFF>
+template <class Gen>
 __device__ __forceinline__ void fin_body(const PkArgs& A);
+template <class Gen>
+__device__ __forceinline__ void fin_handoff(const PkArgs& A);
 
 template <class Gen>
 __device__ __forceinline__ void kernel_hess(const PkArgs& A) {
   if (PK_IS_EDGE_BLOCK()) return edge_block<Gen>(A, 1, false, A.items, A.n_items);
   if (blockIdx.x == 1) {
     // cycle mode: the reductions of the preceding pk_xall launch ride along in a workgroup of their own
-    if (A.flags & (8 | 16)) fin_body<Gen, false>(A);
+    if (A.flags & (8 | 16)) fin_body<Gen>(A);
     return;
   }
   PK_TILE_PROLOGUE(2);
@@ -1216,9 +1213,11 @@ __device__ __forceinline__ void kernel_xall(const PkArgs& A) {
 // ============================================================================================
 template <class Gen>
 __device__ __forceinline__ void kernel_cycle(const PkArgs& A) {
+  if (blockIdx.x < 2 && (A.flags & 2048)) return;     // diagnostic switches (POCKIT_AMD_DEBUG_FLAGS): no boundary work,
+  if (blockIdx.x == 2 && (A.flags & 65536)) return;   // no finalize workgroup (the hand-off slots then stay filled)
   if (blockIdx.x == 0) return edge_block<Gen>(A, 0, true, A.items, A.n_items);
   if (blockIdx.x == 1) return edge_block<Gen>(A, 1, false, A.items2, A.n_items2);
-  if (blockIdx.x == 2) return fin_body<Gen, true>(A);
+  if (blockIdx.x == 2) return fin_handoff<Gen>(A);
   const int slot = pk::xcd_tile_block((int)blockIdx.x, 3, (int)gridDim.x);
   const bool split = (A.flags & 32) != 0;
   const int grp = split ? slot / 3 : slot >> 1;
@@ -1246,7 +1245,7 @@ __device__ __forceinline__ void kernel_cycle(const PkArgs& A) {
 // The reductions over all workgroups, by ONE workgroup (all 256 threads must call it).
 // flags bit 3: I_k = dt * sum of partials -> Ibuf; bit 0: f = F_o(I, s) -> o_f (systembase.py:592-605);
 // bit 4: the gradient slots shared by all nodes (systembase.py:654-657).
-template <class Gen, bool HANDOFF>
+template <class Gen>
 __device__ __forceinline__ void fin_body(const PkArgs& A) {
   __shared__ double red[PK_WAVES_PER_BLOCK];
   __shared__ double tot[PK_NPHASE * PK_NRED];
@@ -1257,14 +1256,14 @@ __device__ __forceinline__ void fin_body(const PkArgs& A) {
   if (A.flags & 8) {
     for (int n = 0; n < Gen::N_INT; ++n) {
       const int k = Gen::int_phase(n);
-      const double sum = block_sum_partials<HANDOFF>(A, A.partial, A.cpart, k, Gen::int_slot(n), red);
+      const double sum = block_sum_partials(A, A.partial, k, Gen::int_slot(n), red);
       if (threadIdx.x == 0) A.Ibuf[Gen::int_global(n)] = sum * dts[k];
     }
   }
   if (A.flags & 16) {
     for (int k = 0; k < PK_NPHASE; ++k)
       for (int r = 0; r < Gen::gr_nr(k); ++r) {
-        const double v = block_sum_partials<HANDOFF>(A, A.partial2, A.cpart2, k, r, red);
+        const double v = block_sum_partials(A, A.partial2, k, r, red);
         if (threadIdx.x == 0) tot[k * PK_NRED + r] = v;
       }
   }
@@ -1283,9 +1282,105 @@ __device__ __forceinline__ void fin_body(const PkArgs& A) {
   }
 }
 
+// pk_cycle's finalize workgroup: the same sums, in the same fixed shape (thread t adds the partials of workgroups
+// t, t + 256, ... in ascending order, DPP wave tree, waves 0..3 in order) and the same order of additions per
+// gradient slot as fin_body -- the results are bit-identical -- but fed through the hand-off slots of the launch it
+// runs in, and arranged so that its own serial chain is ONE memory round trip after the last partial sum arrives:
+// everything independent of the sums (phase durations, slot indices) is fetched first, the slots of ALL rows are
+// polled together (a `row` = one integrand or one shared gradient slot of one phase; the rows are compile-time
+// constants of the model), sums and slot values are combined in LDS and every output is stored once (no
+// read-modify-write of global memory).
+template <class Gen>
+__device__ __forceinline__ void fin_handoff(const PkArgs& A) {
+  constexpr int NR = Gen::N_ROWS > 0 ? Gen::N_ROWS : 1;
+  static_assert(NR <= PK_BLOCK, "one thread per row");
+  __shared__ double red[NR * PK_WAVES_PER_BLOCK];
+  __shared__ double tot[NR];
+  __shared__ double Ish[PK_NI];
+  __shared__ double gsh[PK_NS];
+  __shared__ double dts[PK_NPHASE];
+  __shared__ int ridx[NR];
+  const int t = threadIdx.x, wave = t >> 6;
+  if (t < PK_NPHASE) dts[t] = Gen::phase_dt(t, A);
+  const int gz0 = t < A.n_gz ? A.ib[A.gz_off + t] : -1;
+#pragma unroll
+  for (int row = 0; row < Gen::N_ROWS; ++row)
+    if (t == row) ridx[row] = Gen::row_arr(row) ? A.ib[A.ph[Gen::row_phase(row)].red_off + Gen::row_slot(row)] : -1;
+  const int per = (A.flags & 32) ? PK_WAVES_PER_BLOCK / 2 : PK_WAVES_PER_BLOCK;
+  double acc[NR];
+  int most = 0;
+#pragma unroll
+  for (int row = 0; row < Gen::N_ROWS; ++row) {
+    acc[row] = 0.0;
+    most = max(most, (A.ph[Gen::row_phase(row)].tile_hi - A.ph[Gen::row_phase(row)].tile_lo) / per);
+  }
+  for (int j = t; j < most + t; j += PK_BLOCK) {        // (uniform trip count; j - t = 0, 256, ...)
+    unsigned long long bits[NR];
+    unsigned long long* slot[NR];
+#pragma unroll
+    for (int row = 0; row < Gen::N_ROWS; ++row) {
+      const PkPhase& ph = A.ph[Gen::row_phase(row)];
+      const int b = ph.tile_lo / per + j;
+      slot[row] = b < ph.tile_hi / per ? (Gen::row_arr(row) ? A.cpart2 : A.cpart) + (size_t)b * PK_NRED + Gen::row_slot(row)
+                                       : nullptr;
+    }
+    // one poll round = the slots of ALL rows in flight together (one memory round trip), repeated until none is empty
+    for (int tries = 0; tries < PK_POLL_LIMIT; ++tries) {
+      bool empty = false;
+#pragma unroll
+      for (int row = 0; row < Gen::N_ROWS; ++row) bits[row] = slot[row] ? handoff_peek(slot[row]) : 0ull;
+#pragma unroll
+      for (int row = 0; row < Gen::N_ROWS; ++row) empty |= bits[row] == PK_EMPTY;
+      if (!empty) break;
+      __builtin_amdgcn_s_sleep(4);
+    }
+#pragma unroll
+    for (int row = 0; row < Gen::N_ROWS; ++row)
+      if (slot[row]) {
+        handoff_clear(slot[row]);
+        acc[row] += __longlong_as_double((long long)bits[row]);      // (PK_EMPTY after a timed-out poll: a NaN)
+      }
+  }
+#pragma unroll
+  for (int row = 0; row < Gen::N_ROWS; ++row) {
+    const double v = wave_sum(acc[row]);
+    if ((t & 63) == 0) red[row * PK_WAVES_PER_BLOCK + wave] = v;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int row = 0; row < Gen::N_ROWS; ++row)
+    if (t == row) {
+      double v = 0.0;
+#pragma unroll
+      for (int w = 0; w < PK_WAVES_PER_BLOCK; ++w) v += red[row * PK_WAVES_PER_BLOCK + w];
+      tot[row] = v;
+      if (!Gen::row_arr(row)) {                           // integrand row n = row: I_k = dt * sum   (phasebase.py:997-1006)
+        const double Ik = v * dts[Gen::row_phase(row)];
+        Ish[Gen::int_global(row)] = Ik;
+        A.Ibuf[Gen::int_global(row)] = Ik;
+      }
+    }
+  __syncthreads();
+  const PkSys sy{A.x + A.l_s, Ish, A.sigma, A.lam};
+  if (t == 0) A.o_f[0] = Gen::sys_objective(sy);          // systembase.py:592-605
+  if (t == 64) Gen::sys_grad_static(sy, gsh);
+  __syncthreads();
+  // gradient slots no tile writes (end slots, t0 / tf, static parameters): 0 + the sums of the rows that land on the
+  // slot, phase by phase, + the objective's direct dependence on a static parameter   (systembase.py:654-657)
+  for (int z = t; z < A.n_gz; z += PK_BLOCK) {
+    const int idx = z == t ? gz0 : A.ib[A.gz_off + z];
+    double v = 0.0;
+#pragma unroll
+    for (int row = 0; row < Gen::N_ROWS; ++row)
+      if (Gen::row_arr(row) && ridx[row] == idx) v += tot[row];
+    if (idx >= A.l_s && idx < A.l_s + A.n_s) v += gsh[idx - A.l_s];
+    A.o_grad[idx] = v;
+  }
+}
+
 template <class Gen>
 __device__ __forceinline__ void kernel_fin(const PkArgs& A) {
-  fin_body<Gen, false>(A);
+  fin_body<Gen>(A);
 }
 
 }  // namespace pk
