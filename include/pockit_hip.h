@@ -197,8 +197,10 @@ int pk_eval_f_from_integrals_dev(pk_ctx* ctx, const double* d_x, double* d_f, vo
  * launch costs ~2-3 us more than a plain one, so timing every launch slows the loop being measured). */
 int pk_profile(pk_ctx* ctx, int kernel_mask /* bit k: time kernel k; 0 = off */);
 int pk_profile_sampling(pk_ctx* ctx, int period);
-/* Developer tracing: with a model generated under POCKIT_AMD_TRACE=1 every wave of pk_xall stores s_memtime at
- * 16 checkpoints of its tile.  The first call arms the buffer, later calls copy [n_tiles][16] marks out. */
+/* Developer tracing: with a model generated under POCKIT_AMD_TRACE=1 the waves of pk_cycle / pk_xall store the
+ * constant-rate device clock (s_memrealtime) at up to 16 checkpoints of their record.  The first call arms the
+ * buffer; later calls copy the [3 n_tiles + 3][16] marks out (records: [tile][values, Jacobian, Hessian wave], then
+ * pk_cycle's boundary-J, boundary-H and finalize workgroups) and clear the buffer. */
 int pk_trace_read(pk_ctx* ctx, uint64_t* out, int64_t count);
 int pk_profile_read(pk_ctx* ctx, int kernel_id, int64_t* launches, double* total_ms);
 const char* pk_kernel_name(int kernel_id);

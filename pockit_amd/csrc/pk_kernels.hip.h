@@ -53,6 +53,40 @@ __device__ __forceinline__ PkTile load_tile(const PkTile* p) {
   return t;
 }
 
+// Base offsets of the N output segments of a phase, held by the wave itself: lane e keeps base e in a VGPR pair
+// (ONE coalesced vector load, issued together with the node loads of phase A) and v_readlane hands base e to the
+// scalar unit where a store needs it.  Read through the constant address space instead, the scalar loads are
+// re-materialised by the register allocator right at their use AFTER the evaluation -- a scalar-cache miss of
+// 0.3-0.5 us in front of the translation, the streaming and the Hessian stores (ISA + wave timeline).
+template <int N>
+struct SegBases {
+  int lo, hi;
+  pk_cbase_t mem;
+  __device__ __forceinline__ void load(const int64_t* __restrict__ lb, int off, int lane) {
+    mem = const_bases(lb + off);
+    if (N <= PK_WAVE) {
+      const long long v = lane < N ? (long long)lb[off + lane] : 0ll;
+      lo = (int)v;
+      hi = (int)(v >> 32);
+    }
+  }
+  __device__ __forceinline__ int64_t operator[](int e) const {      // e: wave-uniform (a constant after unrolling)
+    if (N > PK_WAVE) return mem[e];
+    const unsigned l = (unsigned)__builtin_amdgcn_readlane(lo, e), h = (unsigned)__builtin_amdgcn_readlane(hi, e);
+    return (int64_t)(((unsigned long long)h << 32) | l);
+  }
+};
+
+// Phase A -> phase B of a tile wave.  A wave stages values for ITSELF only (its own LDS rows, its own copy of the
+// kind tables), LDS executes a wave's instructions in order and a wave runs in lockstep, so no workgroup barrier
+// is needed between the phases: s_barrier made the Jacobian waves wait 0.8 us for the slowest wave of the
+// workgroup (wave timeline).  Only the compiler must keep the order.
+__device__ __forceinline__ void wave_lds_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
 // XCD-aware workgroup -> tile-block mapping.  The hardware deals consecutive workgroup ids round-robin to the 8
 // XCDs, each with its own L2; neighbouring tiles write neighbouring pieces of the same output arrays (and of the
 // same 128-byte lines where a run does not end on a line boundary).  Giving every XCD one contiguous range of
@@ -62,25 +96,31 @@ __device__ __forceinline__ PkTile load_tile(const PkTile* p) {
 #ifndef PK_XCD_REMAP
 #define PK_XCD_REMAP 1
 #endif
+__device__ __forceinline__ int xcd_ids_below(int n, int y) { return (n + PK_XCDS - 1 - y) / PK_XCDS; }   // ids < n on XCD y
 __device__ __forceinline__ int xcd_tile_block(int wg, int first, int total) {
   if (PK_XCD_REMAP == 0) return wg - first;
   const int x = wg % PK_XCDS;
   int start = 0;
 #pragma unroll
-  for (int y = 0; y < PK_XCDS; ++y) {
-    const int cnt = (y < total ? (total - 1 - y) / PK_XCDS + 1 : 0) - (y < first ? 1 : 0);   // tile blocks on XCD y
-    if (y < x) start += cnt;
-  }
-  return start + (wg - x) / PK_XCDS - (x < first ? 1 : 0);
+  for (int y = 0; y < PK_XCDS; ++y)
+    if (y < x) start += xcd_ids_below(total, y) - xcd_ids_below(first, y);     // tile blocks on XCD y
+  return start + xcd_ids_below(wg, x) - xcd_ids_below(first, x);
 }
 
-// Developer tracing: PK_MARK(k) stores the shader clock (s_memtime) of lane 0 at checkpoint k of the wave's tile.
+// Developer tracing: PK_MARK(k) stores the constant-rate device clock (s_memrealtime: 100 MHz, the same on every XCD)
+// of lane 0 at checkpoint k of the wave's trace record.  Records: [tile][role 0 values / whole tile, 1 Jacobian,
+// 2 Hessian], then three for pk_cycle's boundary-J, boundary-H and finalize workgroups.
 #ifdef PK_TRACE
-#define PK_MARK(k)                                                                                          \
+#define PK_TRACE_REC(role) const int pk_trec = tl.pad >= 0 ? tl.pad * 3 + (role) : -1
+#define PK_MARK_AT(rec, k)                                                                                   \
   do {                                                                                                      \
-    if (A.trace != nullptr && lane == 0 && tl.pad >= 0) A.trace[(size_t)tl.pad * 16 + (k)] = __builtin_readcyclecounter(); \
+    if (A.trace != nullptr && (threadIdx.x & 63) == 0 && (rec) >= 0)                                        \
+      A.trace[(size_t)(rec) * 16 + (k)] = __builtin_amdgcn_s_memrealtime();                                 \
   } while (0)
+#define PK_MARK(k) PK_MARK_AT(pk_trec, k)
 #else
+#define PK_TRACE_REC(role) do { } while (0)
+#define PK_MARK_AT(rec, k) do { } while (0)
 #define PK_MARK(k) do { } while (0)
 #endif
 
@@ -342,10 +382,12 @@ __device__ __forceinline__ void write_defects(const PkArgs& A, const PkPhase& ph
 // constant translation entries of every state (phasebase.py:1077)
 template <class P>
 __device__ __forceinline__ void write_translation(const PkArgs& A, const PkPhase& ph, const PkTile& tl,
-                                                  const TileTabs& T, int lane) {
+                                                  const TileTabs& T, const SegBases<P::NX>& tbase, int lane) {
   const int tot = tl.nj * tl.nnzT;
   const double* __restrict__ tvg = A.db + tl.tv_off;
-  pk_cbase_t tb = const_bases(A.lb + ph.jt_off);
+  int64_t tb[P::NX];
+#pragma unroll
+  for (int i = 0; i < P::NX; ++i) tb[i] = tbase[i];
   for (int p = lane; p < tot; p += PK_WAVE) {
     const int t = p - (int)__umulhi((uint32_t)p, tl.magicT) * tl.nnzT;
     const double v = T.staged ? T.tv[t] : tvg[t];
@@ -357,11 +399,14 @@ __device__ __forceinline__ void write_translation(const PkArgs& A, const PkPhase
 // streaming phase: out[base_e + offI + p] = -(I_hat[t] d/2) * sv_e[col(p)] (* lambda[row(p)])
 // (phasebase.py:1120-1124 and 1280-1285 -- the gather-multiply-concatenate that dominates the reference)
 // lam_s: the tile's multiplier rows staged in LDS as lam_s[state * 64 + row]   (Hessian only)
-template <class P, int NI, bool HESS, bool STAGED>
+template <class P, int NI, bool HESS, bool STAGED, class Bases>
 __device__ __forceinline__ void stream_loop(const PkArgs& A, const PkPhase& ph, const PkTile& tl, const TileGeom& g,
                                             const TileTabs& T, const double* __restrict__ sv,
-                                            const double* __restrict__ lam_s, pk_cbase_t segb,
+                                            const double* __restrict__ lam_s, const Bases& bases,
                                             double* __restrict__ out, int lane) {
+  int64_t segb[NI > 0 ? NI : 1];
+#pragma unroll
+  for (int e = 0; e < NI; ++e) segb[e] = bases[e];
   const int nnz = tl.nnzI;
   const int tot = tl.nj * nnz;
   const int32_t* __restrict__ rcg = A.ib + tl.irc_off;
@@ -395,10 +440,10 @@ __device__ __forceinline__ void stream_loop(const PkArgs& A, const PkPhase& ph, 
   }
 }
 
-template <class P, int NI, bool HESS>
+template <class P, int NI, bool HESS, class Bases>
 __device__ __forceinline__ void stream_expanded(const PkArgs& A, const PkPhase& ph, const PkTile& tl,
                                                 const TileGeom& g, const TileTabs& T, const double* __restrict__ sv,
-                                                const double* __restrict__ lam_s, pk_cbase_t segb,
+                                                const double* __restrict__ lam_s, const Bases& segb,
                                                 double* __restrict__ out, int lane) {
   if (NI == 0 || tl.nj * tl.nnzI == 0) return;
   if (T.staged)
@@ -482,7 +527,7 @@ __device__ __forceinline__ void tile_g(const PkArgs& A, const PkTile& tl, double
       for (int j = 0; j < P::NC; ++j) put(&A.o_g[ph.path_off + j * ph.L_m + q], o[P::NX + j]);
     }
   }
-  __syncthreads();
+  wave_lds_sync();
   write_defects<P>(A, ph, tl, g, T, s, dt, sv, xr, xe, lane);
 }
 
@@ -524,7 +569,10 @@ __device__ __forceinline__ void tile_jac(const PkArgs& A, const PkTile& tl, doub
   double s[PK_NS], dt, mt;
   phase_scalars<P>(A, ph, s, dt, mt);
   const PkSys sy{s, A.Ibuf, A.sigma, A.lam};
-  pk_cbase_t segb = const_bases(A.lb + ph.jseg_off);
+  SegBases<P::J_NI + P::J_NN> segb;
+  SegBases<P::NX> tbase;
+  segb.load(A.lb, ph.jseg_off, lane);
+  tbase.load(A.lb, ph.jt_off, lane);
   const bool fit = tabs_fit(A, tl, g);
   const TabRegs tr = tabs_issue(A, ph, tl, g, fit, lane);
   const int q = tl.q0 + lane;
@@ -541,9 +589,9 @@ __device__ __forceinline__ void tile_jac(const PkArgs& A, const PkTile& tl, doub
       for (int e = 0; e < P::J_NN; ++e) put(&A.o_jac[segb[P::J_NI + e] + (q - ph.mid_lo)], o[P::J_NI + e]);
     }
   }
-  __syncthreads();
+  wave_lds_sync();
   if (tl.nj == 0) return;
-  write_translation<P>(A, ph, tl, T, lane);
+  write_translation<P>(A, ph, tl, T, tbase, lane);
   stream_expanded<P, P::J_NI, false>(A, ph, tl, g, T, sv, nullptr, segb, A.o_jac, lane);
 }
 
@@ -558,8 +606,11 @@ __device__ __forceinline__ void tile_hess(const PkArgs& A, const PkTile& tl, dou
   double s[PK_NS], dt, mt;
   phase_scalars<P>(A, ph, s, dt, mt);
   const PkSys sy{s, A.Ibuf, A.sigma, A.lam};
-  pk_cbase_t segb = const_bases(A.lb + ph.hseg_off);
+  SegBases<P::H_NI + P::H_NN> segb;
+  segb.load(A.lb, ph.hseg_off, lane);
   double* __restrict__ lam_s = sv + P::H_NI * PK_WAVE;       // the tile's defect multipliers, [state][row]
+  PK_TRACE_REC(2);
+  PK_MARK(0);
   const bool fit = tabs_fit(A, tl, g);
   const TabRegs tr = tabs_issue(A, ph, tl, g, fit, lane);
   const int q = tl.q0 + lane;
@@ -573,9 +624,12 @@ __device__ __forceinline__ void tile_hess(const PkArgs& A, const PkTile& tl, dou
   const TileTabs T = tabs_commit(tr, fit, lane);
 #pragma unroll
   for (int i = 0; i < P::NX; ++i) lam_s[i * PK_WAVE + lane] = lrow[i];
+  PK_MARK(1);
   if (lane < g.nq) {
     double o[P::H_NI + P::H_NN + 1];
+    PK_MARK(2);
     P::mid_hess(a, tau, dt, w, sy, lp, o);
+    PK_MARK(3);
 #pragma unroll
     for (int e = 0; e < P::H_NI; ++e) sv[e * PK_WAVE + lane] = o[e];
     if (lane < g.nown && q >= ph.mid_lo && q < ph.mid_hi) {
@@ -583,9 +637,16 @@ __device__ __forceinline__ void tile_hess(const PkArgs& A, const PkTile& tl, dou
       for (int e = 0; e < P::H_NN; ++e) put(&A.o_hess[segb[P::H_NI + e] + (q - ph.mid_lo)], o[P::H_NI + e]);
     }
   }
-  __syncthreads();
+  PK_MARK(4);
+  wave_lds_sync();
+  PK_MARK(5);
   if (tl.nj == 0) return;
   stream_expanded<P, P::H_NI, true>(A, ph, tl, g, T, sv, lam_s, segb, A.o_hess, lane);
+  PK_MARK(8);
+#ifdef PK_TRACE
+  __builtin_amdgcn_s_waitcnt(0);      // all stores acknowledged
+  PK_MARK(9);
+#endif
 }
 
 // ============================================================================================
@@ -593,23 +654,30 @@ __device__ __forceinline__ void tile_hess(const PkArgs& A, const PkTile& tl, dou
 // (one joint CSE over all model functions; x read once).  Used by pk_eval_cycle_dev.
 // LDS: [NX dynamics values | J_NI Jacobian segments] x 64 lanes.
 // ============================================================================================
-// ROLE 0: the wave produces everything of its tile.  ROLE 1 / 2: two waves share a tile (split launch) -- 1 writes
-// the values (path constraints, defects, gradient, integrand sums), 2 the Jacobian (N segments, translation
-// entries, I-expanded segments); the role is a compile-time constant, so each wave's copy of the inlined model
-// evaluation keeps only what its outputs need and its serial chain is roughly halved.
-// pub_blk >= 0 (pk_cycle): the workgroup hands its partial sums to the launch's finalize workgroup right after
-// the evaluation phase (handoff_put), i.e. while its own defect / streaming phase is still to come.
+// ROLE 0: the wave produces everything of its tile.  ROLE 1 / 2 (split launch): two waves of two different
+// workgroups share a tile -- 1 writes the values (integrand sums, gradient, path constraints, defects), 2 the
+// Jacobian (N segments, translation entries, I-expanded segments); the role is a compile-time constant, so each
+// wave's copy of the inlined model evaluation keeps only what its outputs need and its serial chain is roughly
+// halved.  A workgroup holds four waves of ONE role (four consecutive tiles).
+// pub_blk >= 0 (pk_cycle, roles 0 / 1): the workgroup hands its partial sums to the launch's finalize workgroup as
+// soon as they exist (handoff_put) -- before its own staging, defect and streaming work.
 template <class P, int ROLE>
 __device__ __forceinline__ void tile_xall(const PkArgs& A, const PkTile& tl, double* __restrict__ sv,
                                           double* __restrict__ wint, double* __restrict__ wgrad, int lane,
                                           int pub_blk) {
   const PkPhase& ph = A.ph[P::INDEX];
   const TileGeom g = tile_geom<P>(tl);
+  PK_TRACE_REC(ROLE == 2 ? 1 : 0);
   PK_MARK(0);
   double s[PK_NS], dt, mt;
   phase_scalars<P>(A, ph, s, dt, mt);
   const PkSys sy{s, A.Ibuf, A.sigma, A.lam};
-  pk_cbase_t segb = const_bases(A.lb + ph.jseg_off);
+  SegBases<P::J_NI + P::J_NN> segb;
+  SegBases<P::NX> tbase;
+  if (ROLE != 1) {
+    segb.load(A.lb, ph.jseg_off, lane);
+    tbase.load(A.lb, ph.jt_off, lane);
+  }
   double* __restrict__ jsv = sv + P::NX * PK_WAVE;
   const bool fit = tabs_fit(A, tl, g);
   const TabRegs tr = tabs_issue(A, ph, tl, g, fit, lane);
@@ -626,12 +694,49 @@ __device__ __forceinline__ void tile_xall(const PkArgs& A, const PkTile& tl, dou
   for (int r = 0; r < P::INT_N; ++r) oi[r] = 0.0;
 #pragma unroll
   for (int r = 0; r < P::GR_NR; ++r) orr[r] = 0.0;
-  if (lane < g.nq && !(A.flags & 512)) {   // (bit 9: diagnostic switch, skip the evaluation phase)
-    double og[P::G_NOUT], oj[P::J_NI + P::J_NN + 1], ov[P::NX + P::NU], ot[P::GR_NR > 0 ? P::GR_NR : 1],
-        op[P::INT_N > 0 ? P::INT_N : 1];
+  double og[P::G_NOUT], oj[P::J_NI + P::J_NN + 1];
+  const bool live = lane < g.nq && !(A.flags & 512);   // (bit 9: diagnostic switch, skip the evaluation phase)
+  if (live) {
+    double ov[P::NX + P::NU], ot[P::GR_NR > 0 ? P::GR_NR : 1], op[P::INT_N > 0 ? P::INT_N : 1];
     PK_MARK(2);
     P::mid_xall(a, tau, dt, w, sy, og, oj, ov, ot, op);
     PK_MARK(3);
+    if (ROLE != 2 && lane < g.nown) {
+#pragma unroll
+      for (int r = 0; r < P::INT_N; ++r) oi[r] = op[r] * w;
+#pragma unroll
+      for (int r = 0; r < P::GR_NR; ++r) orr[r] = ot[r];
+      node_gradient<P>(A, ph, q, a, tau, dt, w, sy, ov, orr, true);   // boundary nodes re-evaluate their own entries
+    }
+  }
+  if (ROLE != 2) {
+#pragma unroll
+    for (int r = 0; r < P::INT_N; ++r) {
+      const double v = wave_sum(oi[r]);
+      if (lane == 0) wint[r] = v;
+    }
+#pragma unroll
+    for (int r = 0; r < P::GR_NR; ++r) {
+      const double v = wave_sum(orr[r]);
+      if (lane == 0) wgrad[r] = v;
+    }
+    PK_MARK(10);
+    if (pub_blk >= 0) {
+      __syncthreads();                                      // (all four waves of the workgroup have this role)
+      if ((int)threadIdx.x < PK_NRED) {                     // lanes of wave 0, whose wint / wgrad rows start the arrays
+        double vi = 0.0, vg = 0.0;
+#pragma unroll
+        for (int wv = 0; wv < PK_WAVES_PER_BLOCK; ++wv) {   // same order as publish_block_partials
+          vi += wint[wv * PK_NRED + threadIdx.x];
+          vg += wgrad[wv * PK_NRED + threadIdx.x];
+        }
+        handoff_put(A.cpart + (size_t)pub_blk * PK_NRED + threadIdx.x, vi);
+        handoff_put(A.cpart2 + (size_t)pub_blk * PK_NRED + threadIdx.x, vg);
+      }
+      PK_MARK(11);
+    }
+  }
+  if (live) {
     if (ROLE != 2) {
 #pragma unroll
       for (int i = 0; i < P::NX; ++i) sv[i * PK_WAVE + lane] = og[i];
@@ -649,45 +754,16 @@ __device__ __forceinline__ void tile_xall(const PkArgs& A, const PkTile& tl, dou
 #pragma unroll
         for (int e = 0; e < P::J_NN; ++e) put(&A.o_jac[segb[P::J_NI + e] + (q - ph.mid_lo)], oj[P::J_NI + e]);
       }
-      if (ROLE != 2) {
-#pragma unroll
-        for (int r = 0; r < P::INT_N; ++r) oi[r] = op[r] * w;
-#pragma unroll
-        for (int r = 0; r < P::GR_NR; ++r) orr[r] = ot[r];
-        node_gradient<P>(A, ph, q, a, tau, dt, w, sy, ov, orr, true);   // boundary nodes re-evaluate their own entries
-      }
-    }
-  }
-  if (ROLE != 2) {      // (the Jacobian wave leaves the zeros of the prologue in its reduction slots)
-#pragma unroll
-    for (int r = 0; r < P::INT_N; ++r) {
-      const double v = wave_sum(oi[r]);
-      if (lane == 0) wint[r] = v;
-    }
-#pragma unroll
-    for (int r = 0; r < P::GR_NR; ++r) {
-      const double v = wave_sum(orr[r]);
-      if (lane == 0) wgrad[r] = v;
     }
   }
   PK_MARK(4);
-  __syncthreads();
+  wave_lds_sync();
   PK_MARK(5);
-  if (pub_blk >= 0 && (int)threadIdx.x < PK_NRED) {      // lanes of wave 0, whose wint / wgrad rows start the arrays
-    double vi = 0.0, vg = 0.0;
-#pragma unroll
-    for (int w = 0; w < PK_WAVES_PER_BLOCK; ++w) {        // same order as publish_block_partials
-      vi += wint[w * PK_NRED + threadIdx.x];
-      vg += wgrad[w * PK_NRED + threadIdx.x];
-    }
-    handoff_put(A.cpart + (size_t)pub_blk * PK_NRED + threadIdx.x, vi);
-    handoff_put(A.cpart2 + (size_t)pub_blk * PK_NRED + threadIdx.x, vg);
-  }
-  if (A.flags & 256) return;   // diagnostic build switches: skip the phases after the barrier (all / one by one)
+  if (A.flags & 256) return;   // diagnostic build switches: skip the phases after the staging (all / one by one)
   if (ROLE != 2 && !(A.flags & 8192)) write_defects<P>(A, ph, tl, g, T, s, dt, sv, xr, xe, lane);
   PK_MARK(6);
   if (tl.nj == 0 || ROLE == 1) return;
-  if (!(A.flags & 16384)) write_translation<P>(A, ph, tl, T, lane);
+  if (!(A.flags & 16384)) write_translation<P>(A, ph, tl, T, tbase, lane);
   PK_MARK(7);
   if (!(A.flags & 32768)) stream_expanded<P, P::J_NI, false>(A, ph, tl, g, T, jsv, nullptr, segb, A.o_jac, lane);
   PK_MARK(8);
@@ -867,9 +943,7 @@ __device__ __forceinline__ void publish_block_partials(double* __restrict__ part
 // tree, 4-way LDS combine)
 __device__ __forceinline__ double block_sum_partials(const PkArgs& A, const double* __restrict__ partial, int k,
                                                      int r, double* red) {
-  // (split launch, flags bit 5: two waves per tile, so twice the workgroups per phase)
-  const int per = (A.flags & 32) ? PK_WAVES_PER_BLOCK / 2 : PK_WAVES_PER_BLOCK;
-  const int blo = A.ph[k].tile_lo / per, bhi = A.ph[k].tile_hi / per;
+  const int blo = A.ph[k].tile_lo / PK_WAVES_PER_BLOCK, bhi = A.ph[k].tile_hi / PK_WAVES_PER_BLOCK;
   double v = 0.0;
   for (int b = blo + (int)threadIdx.x; b < bhi; b += PK_BLOCK) v += partial[(size_t)b * PK_NRED + r];
   v = wave_sum(v);
@@ -887,19 +961,18 @@ __device__ __forceinline__ double block_sum_partials(const PkArgs& A, const doub
 // ============================================================================================
 // EDGE = 1: workgroup 0 is the boundary/system workgroup (dispatched first: its serial chain is the
 // longest of the launch), tile workgroups follow.
-#define PK_TILE_PROLOGUE(EDGE) PK_TILE_PROLOGUE_SPLIT(EDGE, 0)
-#define PK_TILE_PROLOGUE_SPLIT(EDGE, SHIFT)                                           \
+#define PK_TILE_PROLOGUE(EDGE)                                                        \
   const int blk = pk::xcd_tile_block((int)blockIdx.x, (EDGE), (int)gridDim.x);        \
-  PK_TILE_PROLOGUE_AT(SHIFT)
-// PK_TILE_PROLOGUE_AT: the caller has defined `blk`, the workgroup's tile block
-#define PK_TILE_PROLOGUE_AT(SHIFT)                                                    \
+  PK_TILE_PROLOGUE_AT()
+// PK_TILE_PROLOGUE_AT: the caller has defined `blk`, the workgroup's tile block (four consecutive tiles)
+#define PK_TILE_PROLOGUE_AT()                                                    \
   extern __shared__ double pk_lds[];                                                  \
   __shared__ double wint[PK_WAVES_PER_BLOCK * PK_NRED];                               \
   __shared__ double wgrad[PK_WAVES_PER_BLOCK * PK_NRED];                              \
   /* wave-uniform on purpose (readfirstlane): the tile record then comes through the scalar cache into */ \
   /* SGPRs and everything derived from it is scalar arithmetic */                      \
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63; \
-  const int ti = (blk * PK_WAVES_PER_BLOCK + wave) >> (SHIFT);                        \
+  const int ti = blk * PK_WAVES_PER_BLOCK + wave;                                     \
   PkTile tl;                                                                          \
   if (ti < A.n_tiles) {                                                               \
     tl = load_tile(A.tile + ti);                                                      \
@@ -1171,31 +1244,26 @@ __device__ __forceinline__ void kernel_outer(const PkArgs& A) {
 
 template <class Gen>
 __device__ __forceinline__ void kernel_xall(const PkArgs& A) {
-#ifdef PK_TRACE
-  const unsigned long long t_entry = __builtin_readcyclecounter();
-#endif
   if (A.flags & 1024) return;                                   // diagnostic switches (POCKIT_AMD_DEBUG_FLAGS)
   if (PK_IS_EDGE_BLOCK() && (A.flags & 2048)) return;
   if (PK_IS_EDGE_BLOCK()) return edge_block<Gen>(A, 0, true, A.items, A.n_items);
-  if (A.flags & 32) {   // split launch: waves 2t and 2t+1 share tile t (values / Jacobian)
-    PK_TILE_PROLOGUE_SPLIT(1, 1);
-    if (wave & 1)
+  if (A.flags & 32) {   // split launch: workgroups 2b (Jacobian) and 2b + 1 (values) share tile block b
+    const int slot = pk::xcd_tile_block((int)blockIdx.x, 1, (int)gridDim.x);
+    const int blk = slot >> 1;
+    PK_TILE_PROLOGUE_AT();
+    if (!(slot & 1)) {
       Gen::tile_xall2(tl.phase, A, tl, pk_lds + wave * Gen::LDS_X, wint + wave * PK_NRED, wgrad + wave * PK_NRED, lane, -1);
-    else
-      Gen::tile_xall1(tl.phase, A, tl, pk_lds + wave * Gen::LDS_X, wint + wave * PK_NRED, wgrad + wave * PK_NRED, lane, -1);
+      return;
+    }
+    Gen::tile_xall1(tl.phase, A, tl, pk_lds + wave * Gen::LDS_X, wint + wave * PK_NRED, wgrad + wave * PK_NRED, lane, -1);
     publish_block_partials(A.partial, wint, blk);
     publish_block_partials(A.partial2, wgrad, blk);
     return;
   }
   PK_TILE_PROLOGUE(1);
-#ifdef PK_TRACE
-  if (A.trace != nullptr && lane == 0 && tl.pad >= 0) A.trace[(size_t)tl.pad * 16 + 10] = t_entry;
-#endif
-  PK_MARK(11);
   Gen::tile_xall(tl.phase, A, tl, pk_lds + wave * Gen::LDS_X, wint + wave * PK_NRED, wgrad + wave * PK_NRED, lane, -1);
   publish_block_partials(A.partial, wint, blk);
   publish_block_partials(A.partial2, wgrad, blk);
-  PK_MARK(12);
 }
 
 // ============================================================================================
@@ -1206,40 +1274,41 @@ __device__ __forceinline__ void kernel_xall(const PkArgs& A) {
 //   workgroup 1  boundary nodes / system level of H                (edge_block mode 1)
 //   workgroup 2  the sums over all nodes (integrals, f, shared gradient slots), fed by the tile workgroups of
 //                this same launch through the hand-off slots (fin_body<HANDOFF>)
-//   the rest     tile workgroups; consecutive slots alternate [x-kernel block(s) | Hessian block] of the same tiles
-//                so that every XCD gets a contiguous range of tiles of BOTH output arrays (xcd_tile_block)
-// Every wave runs exactly what it runs in pk_xall / pk_hess (three waves per tile when the x-part is split:
-// values, Jacobian, Hessian), they just run at the same time.
+//   the rest     tile workgroups of four waves = four consecutive tiles, ONE role per workgroup; the workgroups of a
+//                tile block follow each other ([Jacobian, values, Hessian], or [x-part, Hessian] when the x-part is
+//                not split) so that every XCD gets a contiguous range of tiles of every output array
+// Every wave runs exactly what it runs in pk_xall / pk_hess, they just run at the same time.
 // ============================================================================================
 template <class Gen>
 __device__ __forceinline__ void kernel_cycle(const PkArgs& A) {
   if (blockIdx.x < 2 && (A.flags & 2048)) return;     // diagnostic switches (POCKIT_AMD_DEBUG_FLAGS): no boundary work,
   if (blockIdx.x == 2 && (A.flags & 65536)) return;   // no finalize workgroup (the hand-off slots then stay filled)
-  if (blockIdx.x == 0) return edge_block<Gen>(A, 0, true, A.items, A.n_items);
-  if (blockIdx.x == 1) return edge_block<Gen>(A, 1, false, A.items2, A.n_items2);
-  if (blockIdx.x == 2) return fin_handoff<Gen>(A);
+  if (blockIdx.x < 3) {
+    const int rec = A.n_tiles * 3 + (int)blockIdx.x;
+    (void)rec;
+    PK_MARK_AT(rec, 0);
+    if (blockIdx.x == 0) edge_block<Gen>(A, 0, true, A.items, A.n_items);
+    else if (blockIdx.x == 1) edge_block<Gen>(A, 1, false, A.items2, A.n_items2);
+    else fin_handoff<Gen>(A);
+#ifdef PK_TRACE
+    __builtin_amdgcn_s_waitcnt(0);
+#endif
+    PK_MARK_AT(rec, 9);
+    return;
+  }
   const int slot = pk::xcd_tile_block((int)blockIdx.x, 3, (int)gridDim.x);
   const bool split = (A.flags & 32) != 0;
-  const int grp = split ? slot / 3 : slot >> 1;
-  const int sub = slot - grp * (split ? 3 : 2);
-  if (sub == (split ? 2 : 1)) {                       // Hessian block `grp`: four tiles, one wave each
-    const int blk = grp;
-    PK_TILE_PROLOGUE_AT(0);
+  const int blk = split ? slot / 3 : slot >> 1;       // the tile block; its workgroups follow each other in dispatch order
+  const int sub = slot - blk * (split ? 3 : 2);       // split: 0 Jacobian, 1 values, 2 Hessian; else 0 x-part, 1 Hessian
+  PK_TILE_PROLOGUE_AT();
+  if (sub == (split ? 2 : 1))
     Gen::tile_hess(tl.phase, A, tl, pk_lds + wave * Gen::LDS_H, wint, wgrad, lane);
-    return;
-  }
-  if (split) {                                        // x block 2 grp + sub: two tiles, waves (values, Jacobian) each
-    const int blk = 2 * grp + sub;
-    PK_TILE_PROLOGUE_AT(1);
-    if (wave & 1)
-      Gen::tile_xall2(tl.phase, A, tl, pk_lds + wave * Gen::LDS_X, wint + wave * PK_NRED, wgrad + wave * PK_NRED, lane, blk);
-    else
-      Gen::tile_xall1(tl.phase, A, tl, pk_lds + wave * Gen::LDS_X, wint + wave * PK_NRED, wgrad + wave * PK_NRED, lane, blk);
-    return;
-  }
-  const int blk = grp;
-  PK_TILE_PROLOGUE_AT(0);
-  Gen::tile_xall(tl.phase, A, tl, pk_lds + wave * Gen::LDS_X, wint + wave * PK_NRED, wgrad + wave * PK_NRED, lane, blk);
+  else if (!split)
+    Gen::tile_xall(tl.phase, A, tl, pk_lds + wave * Gen::LDS_X, wint + wave * PK_NRED, wgrad + wave * PK_NRED, lane, blk);
+  else if (sub == 0)
+    Gen::tile_xall2(tl.phase, A, tl, pk_lds + wave * Gen::LDS_X, wint + wave * PK_NRED, wgrad + wave * PK_NRED, lane, -1);
+  else
+    Gen::tile_xall1(tl.phase, A, tl, pk_lds + wave * Gen::LDS_X, wint + wave * PK_NRED, wgrad + wave * PK_NRED, lane, blk);
 }
 
 // The reductions over all workgroups, by ONE workgroup (all 256 threads must call it).
@@ -1306,7 +1375,7 @@ __device__ __forceinline__ void fin_handoff(const PkArgs& A) {
 #pragma unroll
   for (int row = 0; row < Gen::N_ROWS; ++row)
     if (t == row) ridx[row] = Gen::row_arr(row) ? A.ib[A.ph[Gen::row_phase(row)].red_off + Gen::row_slot(row)] : -1;
-  const int per = (A.flags & 32) ? PK_WAVES_PER_BLOCK / 2 : PK_WAVES_PER_BLOCK;
+  constexpr int per = PK_WAVES_PER_BLOCK;              // a partial sum per tile block (four tiles)
   double acc[NR];
   int most = 0;
 #pragma unroll
@@ -1314,6 +1383,7 @@ __device__ __forceinline__ void fin_handoff(const PkArgs& A) {
     acc[row] = 0.0;
     most = max(most, (A.ph[Gen::row_phase(row)].tile_hi - A.ph[Gen::row_phase(row)].tile_lo) / per);
   }
+  PK_MARK_AT(A.n_tiles * 3 + 2, 1);
   for (int j = t; j < most + t; j += PK_BLOCK) {        // (uniform trip count; j - t = 0, 256, ...)
     unsigned long long bits[NR];
     unsigned long long* slot[NR];
@@ -1341,6 +1411,7 @@ __device__ __forceinline__ void fin_handoff(const PkArgs& A) {
         acc[row] += __longlong_as_double((long long)bits[row]);      // (PK_EMPTY after a timed-out poll: a NaN)
       }
   }
+  PK_MARK_AT(A.n_tiles * 3 + 2, 2);
 #pragma unroll
   for (int row = 0; row < Gen::N_ROWS; ++row) {
     const double v = wave_sum(acc[row]);

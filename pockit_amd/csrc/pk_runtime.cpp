@@ -236,7 +236,7 @@ int prepass(pk_ctx* c, const double* d_x, const double* d_lam, double sigma, dou
   return launch(c, K_FIN, A, 1, 0, st);
 }
 
-// pk_xall's launch shape: one wave per tile, or -- split launch -- two waves per tile
+// pk_xall's launch shape: one wave per tile, or -- split launch -- two waves (of two workgroups) per tile
 unsigned xall_blocks(const pk_ctx* c) { return (c->split_xall ? 2u : 1u) * tile_blocks(c) + 1u; }
 int xall_flags(const pk_ctx* c) { return c->split_xall ? F_SPLIT : 0; }
 
@@ -885,7 +885,7 @@ int pk_profile(pk_ctx* c, int enable) {
 int pk_trace_read(pk_ctx* c, uint64_t* out, int64_t count) {
   int rc = ready(c);
   if (rc) return rc;
-  const int64_t need = (int64_t)c->n_tiles * 16;
+  const int64_t need = ((int64_t)c->n_tiles * 3 + 3) * 16;   // [tile][role] records + pk_cycle's three special workgroups
   PK_HIP(c, hipSetDevice(c->device));
   if (!c->d_trace) {
     PK_HIP(c, hipStreamSynchronize(c->stream));
@@ -897,6 +897,7 @@ int pk_trace_read(pk_ctx* c, uint64_t* out, int64_t count) {
   if (!out || count < need) return fail(c, 72, "pk_trace_read: need room for %lld marks", (long long)need);
   PK_HIP(c, hipDeviceSynchronize());
   PK_HIP(c, hipMemcpy(out, c->d_trace, sizeof(uint64_t) * (size_t)need, hipMemcpyDeviceToHost));
+  PK_HIP(c, hipMemset(c->d_trace, 0, sizeof(uint64_t) * (size_t)need));
   return 0;
 }
 

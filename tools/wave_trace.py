@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
-"""Developer helper: timeline of pk_xall's waves from s_memtime marks (POCKIT_AMD_TRACE=1 must be set so that the
-model is generated with PK_TRACE).  Prints, per checkpoint, the median / p10 / p90 offset from the earliest mark
-of the launch, in shader-clock ticks and microseconds (tick rate estimated from the kernel's event duration)."""
+"""Developer helper: timeline of one pk_cycle launch from s_memrealtime marks (the model is generated with PK_TRACE
+because this script sets POCKIT_AMD_TRACE=1).  The clock is the constant-rate device clock (100 MHz, common to all
+XCDs), so marks of different waves are comparable: everything is printed in microseconds since the earliest mark of
+the launch.  Usage: wave_trace.py [workload] [intervals]   (default planar_quadrotor 2000)"""
 import ctypes as C
 import os
 import sys
@@ -11,34 +12,45 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "tests")]
 import numpy as np  # noqa: E402
 
+import bench  # noqa: E402
 import models  # noqa: E402
 import pockit_amd.radau as radau  # noqa: E402
 
-NAMES = ["entry", "x+tables loaded", "eval start", "eval end", "before barrier", "after barrier", "defects issued",
-         "translation issued", "stream issued", "stores acked"]
-system, _, guess = models.planar_quadrotor(radau, mesh=2000, num_point=6)
+TICK_US = 0.01
+MARKS = {0: "wave entry (tile record in SGPRs)", 1: "x + tables loaded", 2: "evaluation starts", 3: "evaluation done",
+         4: "before the barrier", 5: "after the barrier", 6: "defects issued", 7: "translation issued",
+         8: "streaming issued", 9: "stores acknowledged"}
+ROLES = ["values wave", "Jacobian wave", "Hessian wave"]
+name = sys.argv[1] if len(sys.argv) > 1 else "planar_quadrotor"
+intervals = int(sys.argv[2]) if len(sys.argv) > 2 else 2000
+system, _, guess = bench.build_workload(name, intervals, radau)
 x, lam, sigma = models.bench_inputs(system, guess)
 ev = system.evaluator
 lib, h = ev.ctx.lib, ev.ctx.handle
 ev.ctx.check(lib.pk_trace_read(h, None, 0))                      # arm
 n = len(ev.tables.tiles)
-buf = np.zeros(n * 16, dtype=np.uint64)
+buf = np.zeros((3 * n + 3) * 16, dtype=np.uint64)
 for rep in range(4):
-    ev.cycle(x, lam, sigma)
+    for _ in range(3):                                           # the last of three back-to-back cycles is read
+        ev.cycle(x, lam, sigma)
     ev.ctx.check(lib.pk_trace_read(h, buf.ctypes.data_as(C.POINTER(C.c_uint64)), len(buf)))
-    m = buf.reshape(n, 16).astype(np.int64)
-    live = m[:, 0] > 0
-    m = m[live]
-    t0 = m[:, 0].min()
-    print(f"rep {rep}: {live.sum()} waves; span of the launch {m[:, :10].max() - t0} ticks")
-    # the counters of different XCDs are not aligned: only differences inside one wave are meaningful
-    order = [10, 11] + list(range(10)) + [12]
-    names = {10: "kernel entry", 11: "tile record loaded", 12: "partials published"}
-    names.update({k: nm for k, nm in enumerate(NAMES)})
-    prev = order[0]
-    for k in order:
-        d = m[:, k] - m[:, prev]
-        tot = m[:, k] - m[:, 10]
-        print(f"  {names[k]:20s} since previous mark: median {np.median(d):7.0f} p10 {np.percentile(d, 10):7.0f} "
-              f"p90 {np.percentile(d, 90):7.0f}   since kernel entry: median {np.median(tot):7.0f}")
-        prev = k
+    m = buf.reshape(3 * n + 3, 16).astype(np.int64)
+    t0 = m[m > 0].min()
+    us = np.where(m > 0, (m - t0) * TICK_US, np.nan)
+    print(f"rep {rep}: launch spans {np.nanmax(us):.2f} us from its first to its last mark")
+    if rep < 3:
+        continue
+    for role in range(3):
+        r = us[role:3 * n:3]
+        r = r[~np.isnan(r[:, 0])]
+        if not len(r):
+            continue
+        print(f"  {ROLES[role]} ({len(r)} waves)")
+        for k, label in MARKS.items():
+            col = r[:, k][~np.isnan(r[:, k])]
+            if len(col):
+                print(f"    {label:36s} median {np.median(col):6.2f}  p10 {np.percentile(col, 10):6.2f}  "
+                      f"p90 {np.percentile(col, 90):6.2f}  max {col.max():6.2f}")
+    for i, label in enumerate(("boundary workgroup (g, J)", "boundary workgroup (H)", "finalize workgroup")):
+        row = us[3 * n + i]
+        print(f"  {label}: " + "  ".join(f"[{k}] {row[k]:.2f}" for k in range(16) if not np.isnan(row[k])))
