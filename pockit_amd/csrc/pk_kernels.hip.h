@@ -70,6 +70,12 @@ struct SegBases {
       hi = (int)(v >> 32);
     }
   }
+  // The load has to be WAITED FOR in phase A, where only loads are in flight: vmcnt counts loads and stores
+  // together and they return out of order with respect to each other, so a first use in phase B would make the
+  // compiler wait for every store issued before it (s_waitcnt vmcnt(0), a write round trip).
+  __device__ __forceinline__ void settle() {
+    if (N <= PK_WAVE) asm volatile("" : "+v"(lo), "+v"(hi));
+  }
   __device__ __forceinline__ int64_t operator[](int e) const {      // e: wave-uniform (a constant after unrolling)
     if (N > PK_WAVE) return mem[e];
     const unsigned l = (unsigned)__builtin_amdgcn_readlane(lo, e), h = (unsigned)__builtin_amdgcn_readlane(hi, e);
@@ -81,6 +87,18 @@ struct SegBases {
 // kind tables), LDS executes a wave's instructions in order and a wave runs in lockstep, so no workgroup barrier
 // is needed between the phases: s_barrier made the Jacobian waves wait 0.8 us for the slowest wave of the
 // workgroup (wave timeline).  Only the compiler must keep the order.
+// values loaded in phase A for use in phase B are pinned (waited for) before the first store goes out, see SegBases
+template <int N>
+__device__ __forceinline__ void settle(double (&v)[N]) {
+#pragma unroll
+  for (int i = 0; i < N; ++i) asm volatile("" : "+v"(v[i]));
+}
+
+// End of the load part of phase A: every vector load of the wave has returned (s_waitcnt vmcnt(0), explicit so that
+// it holds on EVERY control-flow path -- the compiler's own waits sit inside the `lane < nodes` branch, and the
+// pending-load state that leaks around that branch turns into a vmcnt(0) behind the first stores of phase B).
+__device__ __forceinline__ void loads_done() { __builtin_amdgcn_s_waitcnt(0x0F70); }
+
 __device__ __forceinline__ void wave_lds_sync() {
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
   __builtin_amdgcn_wave_barrier();
@@ -118,7 +136,11 @@ __device__ __forceinline__ int xcd_tile_block(int wg, int first, int total) {
       A.trace[(size_t)(rec) * 16 + (k)] = __builtin_amdgcn_s_memrealtime();                                 \
   } while (0)
 #define PK_MARK(k) PK_MARK_AT(pk_trec, k)
+#define PK_TRACE_PARAM , int pk_trec
+#define PK_TRACE_ARG , pk_trec
 #else
+#define PK_TRACE_PARAM
+#define PK_TRACE_ARG
 #define PK_TRACE_REC(role) do { } while (0)
 #define PK_MARK_AT(rec, k) do { } while (0)
 #define PK_MARK(k) do { } while (0)
@@ -335,7 +357,7 @@ __device__ __forceinline__ void defect_dot(const double* __restrict__ full, cons
 
 // collocation defects of the tile's rows:  (x_q - x_end) - dt * sum_c (I_hat[r,c] d/2) f_i(c)
 // f staged in LDS as fsv[i * 64 + lane]                  (phasebase.py:1008-1012; batched small GEMV)
-template <class P>
+template <class P, bool STAGED>
 __device__ __forceinline__ void write_defects(const PkArgs& A, const PkPhase& ph, const PkTile& tl,
                                               const TileGeom& g, const TileTabs& T, const double* s, double dt,
                                               const double* __restrict__ fsv, const double* xr, double* xe,
@@ -349,7 +371,7 @@ __device__ __forceinline__ void write_defects(const PkArgs& A, const PkPhase& ph
   double acc[P::NX];
 #pragma unroll
   for (int i = 0; i < P::NX; ++i) acc[i] = 0.0;
-  if (T.staged) {
+  if (STAGED) {
     const double width = T.wd[jj];
     const double* __restrict__ full = T.full + r * g.K;
     switch (g.K) {   // K <= 8 here: fully unrolled so that all LDS reads of a row are in flight together
@@ -380,19 +402,21 @@ __device__ __forceinline__ void write_defects(const PkArgs& A, const PkPhase& ph
 }
 
 // constant translation entries of every state (phasebase.py:1077)
-template <class P>
+template <class P, bool STAGED>
 __device__ __forceinline__ void write_translation(const PkArgs& A, const PkPhase& ph, const PkTile& tl,
                                                   const TileTabs& T, const SegBases<P::NX>& tbase, int lane) {
   const int tot = tl.nj * tl.nnzT;
   const double* __restrict__ tvg = A.db + tl.tv_off;
-  int64_t tb[P::NX];
+  // wave-uniform run starts (SGPR pairs) + ONE 32-bit lane offset shared by all states: the stores take the
+  // `saddr + voffset` form and no 64-bit address is computed per store
+  double* __restrict__ run[P::NX];
 #pragma unroll
-  for (int i = 0; i < P::NX; ++i) tb[i] = tbase[i];
-  for (int p = lane; p < tot; p += PK_WAVE) {
-    const int t = p - (int)__umulhi((uint32_t)p, tl.magicT) * tl.nnzT;
-    const double v = T.staged ? T.tv[t] : tvg[t];
+  for (int i = 0; i < P::NX; ++i) run[i] = A.o_jac + (tbase[i] + tl.offT);
+  for (uint32_t p = lane; p < (uint32_t)tot; p += PK_WAVE) {
+    const int t = (int)p - (int)__umulhi(p, tl.magicT) * tl.nnzT;
+    const double v = STAGED ? T.tv[t] : tvg[t];
 #pragma unroll
-    for (int i = 0; i < P::NX; ++i) put(&A.o_jac[tb[i] + tl.offT + p], v);
+    for (int i = 0; i < P::NX; ++i) put(&run[i][p], v);
   }
 }
 
@@ -404,17 +428,21 @@ __device__ __forceinline__ void stream_loop(const PkArgs& A, const PkPhase& ph, 
                                             const TileTabs& T, const double* __restrict__ sv,
                                             const double* __restrict__ lam_s, const Bases& bases,
                                             double* __restrict__ out, int lane) {
-  int64_t segb[NI > 0 ? NI : 1];
+  // the tile's run in every segment: a wave-uniform pointer (SGPR pair); with the 32-bit position p as the only
+  // per-lane part the stores take the `saddr + voffset` form (no 64-bit address arithmetic per store)
+  double* __restrict__ run[NI > 0 ? NI : 1];
 #pragma unroll
-  for (int e = 0; e < NI; ++e) segb[e] = bases[e];
+  for (int e = 0; e < NI; ++e) run[e] = out + (bases[e] + tl.offI);
   const int nnz = tl.nnzI;
   const int tot = tl.nj * nnz;
   const int32_t* __restrict__ rcg = A.ib + tl.irc_off;
   const double* __restrict__ ivg = A.db + tl.iv_off;
   const double* __restrict__ wdg = A.db + ph.width_off + tl.j0;
-  for (int p = lane; p < tot; p += PK_WAVE) {
-    const int jj = (int)__umulhi((uint32_t)p, tl.magicI);   // p / nnz (p < 2^16)
-    const int t = p - jj * nnz;
+  // (segment-major order -- each segment's stores of 256 positions back to back -- was measured slower: 2.1 vs 1.6 us)
+#pragma unroll 2
+  for (uint32_t p = lane; p < (uint32_t)tot; p += PK_WAVE) {
+    const int jj = (int)__umulhi(p, tl.magicI);   // p / nnz (p < 2^16)
+    const int t = (int)p - jj * nnz;
     int r, c;
     double val;
     if (STAGED) {
@@ -428,29 +456,50 @@ __device__ __forceinline__ void stream_loop(const PkArgs& A, const PkPhase& ph, 
       val = -(ivg[t] * wdg[jj] * 0.5);
     }
     const double* __restrict__ col = sv + jj * g.stride + c;
-    const size_t at = (size_t)tl.offI + p;
+#ifdef PK_TRACE
+    if (A.flags & 131072) {      // tracing builds only: the loop without its stores (lookups and products kept alive)
+      double acc = 0.0;
+#pragma unroll
+      for (int e = 0; e < NI; ++e) acc += val * col[e * PK_WAVE] * (HESS ? lam_s[P::H_state(e) * PK_WAVE + jj * g.R + r] : 1.0);
+      asm volatile("" ::"v"(acc));
+      continue;
+    }
+#endif
     if (HESS) {
       const double* __restrict__ lam = lam_s + jj * g.R + r;
 #pragma unroll
-      for (int e = 0; e < NI; ++e) put(&out[segb[e] + at], val * lam[P::H_state(e) * PK_WAVE] * col[e * PK_WAVE]);
+      for (int e = 0; e < NI; ++e) put(&run[e][p], val * lam[P::H_state(e) * PK_WAVE] * col[e * PK_WAVE]);
     } else {
 #pragma unroll
-      for (int e = 0; e < NI; ++e) put(&out[segb[e] + at], val * col[e * PK_WAVE]);
+      for (int e = 0; e < NI; ++e) put(&run[e][p], val * col[e * PK_WAVE]);
     }
   }
 }
 
-template <class P, int NI, bool HESS, class Bases>
+template <class P, int NI, bool HESS, bool STAGED, class Bases>
 __device__ __forceinline__ void stream_expanded(const PkArgs& A, const PkPhase& ph, const PkTile& tl,
                                                 const TileGeom& g, const TileTabs& T, const double* __restrict__ sv,
                                                 const double* __restrict__ lam_s, const Bases& segb,
                                                 double* __restrict__ out, int lane) {
   if (NI == 0 || tl.nj * tl.nnzI == 0) return;
-  if (T.staged)
-    stream_loop<P, NI, HESS, true>(A, ph, tl, g, T, sv, lam_s, segb, out, lane);
-  else
-    stream_loop<P, NI, HESS, false>(A, ph, tl, g, T, sv, lam_s, segb, out, lane);
+  stream_loop<P, NI, HESS, STAGED>(A, ph, tl, g, T, sv, lam_s, segb, out, lane);
 }
+
+// Phase B is compiled twice -- tables staged in LDS (K <= 8) or read from global memory -- and the wave branches
+// ONCE: on gfx9-class hardware loads and stores share one counter (vmcnt) and return out of order with respect to
+// each other, so a single global load in a loop of phase B makes the compiler wait for ALL outstanding stores
+// (s_waitcnt vmcnt(0): a full write round trip of 0.4-0.8 us per loop iteration, found in the ISA of the
+// translation loop and in front of the streaming loop).  The staged variant contains no global load at all.
+#define PK_PHASE_B(T, CALL)       \
+  do {                            \
+    if ((T).staged) {             \
+      constexpr bool STAGED = true;  \
+      CALL;                       \
+    } else {                      \
+      constexpr bool STAGED = false; \
+      CALL;                       \
+    }                             \
+  } while (0)
 
 // per-node gradient entries: own variable slots directly, shared slots into orr   (systembase.py:646-657)
 template <class P>
@@ -515,6 +564,8 @@ __device__ __forceinline__ void tile_g(const PkArgs& A, const PkTile& tl, double
   load_node<P>(A, ph, s, dt, mt, q, a, tau, w);
   const TileTabs T = tabs_commit(tr, fit, lane);
   defect_ends<P>(A, ph, tl, g, a, xe, lane);
+  settle(xe);
+  loads_done();
 #pragma unroll
   for (int i = 0; i < P::NX; ++i) xr[i] = a[i];
   if (lane < g.nq) {
@@ -528,7 +579,7 @@ __device__ __forceinline__ void tile_g(const PkArgs& A, const PkTile& tl, double
     }
   }
   wave_lds_sync();
-  write_defects<P>(A, ph, tl, g, T, s, dt, sv, xr, xe, lane);
+  PK_PHASE_B(T, (write_defects<P, STAGED>(A, ph, tl, g, T, s, dt, sv, xr, xe, lane)));
 }
 
 // ============================================================================================
@@ -579,6 +630,9 @@ __device__ __forceinline__ void tile_jac(const PkArgs& A, const PkTile& tl, doub
   double a[P::NARG], tau, w;
   load_node<P>(A, ph, s, dt, mt, q, a, tau, w);
   const TileTabs T = tabs_commit(tr, fit, lane);
+  segb.settle();
+  tbase.settle();
+  loads_done();
   if (lane < g.nq) {
     double o[P::J_NI + P::J_NN + 1];
     P::mid_jac(a, tau, dt, w, sy, nullptr, o);
@@ -591,8 +645,8 @@ __device__ __forceinline__ void tile_jac(const PkArgs& A, const PkTile& tl, doub
   }
   wave_lds_sync();
   if (tl.nj == 0) return;
-  write_translation<P>(A, ph, tl, T, tbase, lane);
-  stream_expanded<P, P::J_NI, false>(A, ph, tl, g, T, sv, nullptr, segb, A.o_jac, lane);
+  PK_PHASE_B(T, (write_translation<P, STAGED>(A, ph, tl, T, tbase, lane),
+                 stream_expanded<P, P::J_NI, false, STAGED>(A, ph, tl, g, T, sv, nullptr, segb, A.o_jac, lane)));
 }
 
 // ============================================================================================
@@ -624,6 +678,8 @@ __device__ __forceinline__ void tile_hess(const PkArgs& A, const PkTile& tl, dou
   const TileTabs T = tabs_commit(tr, fit, lane);
 #pragma unroll
   for (int i = 0; i < P::NX; ++i) lam_s[i * PK_WAVE + lane] = lrow[i];
+  segb.settle();
+  loads_done();
   PK_MARK(1);
   if (lane < g.nq) {
     double o[P::H_NI + P::H_NN + 1];
@@ -641,7 +697,7 @@ __device__ __forceinline__ void tile_hess(const PkArgs& A, const PkTile& tl, dou
   wave_lds_sync();
   PK_MARK(5);
   if (tl.nj == 0) return;
-  stream_expanded<P, P::H_NI, true>(A, ph, tl, g, T, sv, lam_s, segb, A.o_hess, lane);
+  PK_PHASE_B(T, (stream_expanded<P, P::H_NI, true, STAGED>(A, ph, tl, g, T, sv, lam_s, segb, A.o_hess, lane)));
   PK_MARK(8);
 #ifdef PK_TRACE
   __builtin_amdgcn_s_waitcnt(0);      // all stores acknowledged
@@ -654,6 +710,22 @@ __device__ __forceinline__ void tile_hess(const PkArgs& A, const PkTile& tl, dou
 // (one joint CSE over all model functions; x read once).  Used by pk_eval_cycle_dev.
 // LDS: [NX dynamics values | J_NI Jacobian segments] x 64 lanes.
 // ============================================================================================
+template <class P, int ROLE, bool STAGED>
+__device__ __forceinline__ void xall_phase_b(const PkArgs& A, const PkPhase& ph, const PkTile& tl, const TileGeom& g,
+                                             const TileTabs& T, const double* s, double dt,
+                                             const double* __restrict__ sv, const double* __restrict__ jsv,
+                                             const double* xr, double* xe,
+                                             const SegBases<P::J_NI + P::J_NN>& segb, const SegBases<P::NX>& tbase,
+                                             int lane PK_TRACE_PARAM) {
+  if (ROLE != 2 && !(A.flags & 8192)) write_defects<P, STAGED>(A, ph, tl, g, T, s, dt, sv, xr, xe, lane);
+  PK_MARK(6);
+  if (tl.nj == 0 || ROLE == 1) return;
+  if (!(A.flags & 16384)) write_translation<P, STAGED>(A, ph, tl, T, tbase, lane);
+  PK_MARK(7);
+  if (!(A.flags & 32768))
+    stream_expanded<P, P::J_NI, false, STAGED>(A, ph, tl, g, T, jsv, nullptr, segb, A.o_jac, lane);
+}
+
 // ROLE 0: the wave produces everything of its tile.  ROLE 1 / 2 (split launch): two waves of two different
 // workgroups share a tile -- 1 writes the values (integrand sums, gradient, path constraints, defects), 2 the
 // Jacobian (N segments, translation entries, I-expanded segments); the role is a compile-time constant, so each
@@ -685,8 +757,16 @@ __device__ __forceinline__ void tile_xall(const PkArgs& A, const PkTile& tl, dou
   double a[P::NARG], tau, w, xr[P::NX], xe[P::NX];
   load_node<P>(A, ph, s, dt, mt, q, a, tau, w);
   const TileTabs T = tabs_commit(tr, fit, lane);
+  if (ROLE != 1) {
+    segb.settle();
+    tbase.settle();
+  }
   PK_MARK(1);
-  if (ROLE != 2) defect_ends<P>(A, ph, tl, g, a, xe, lane);
+  if (ROLE != 2) {
+    defect_ends<P>(A, ph, tl, g, a, xe, lane);
+    settle(xe);
+  }
+  loads_done();
 #pragma unroll
   for (int i = 0; i < P::NX; ++i) xr[i] = a[i];
   double oi[P::INT_N > 0 ? P::INT_N : 1], orr[P::GR_NR > 0 ? P::GR_NR : 1];
@@ -760,12 +840,7 @@ __device__ __forceinline__ void tile_xall(const PkArgs& A, const PkTile& tl, dou
   wave_lds_sync();
   PK_MARK(5);
   if (A.flags & 256) return;   // diagnostic build switches: skip the phases after the staging (all / one by one)
-  if (ROLE != 2 && !(A.flags & 8192)) write_defects<P>(A, ph, tl, g, T, s, dt, sv, xr, xe, lane);
-  PK_MARK(6);
-  if (tl.nj == 0 || ROLE == 1) return;
-  if (!(A.flags & 16384)) write_translation<P>(A, ph, tl, T, tbase, lane);
-  PK_MARK(7);
-  if (!(A.flags & 32768)) stream_expanded<P, P::J_NI, false>(A, ph, tl, g, T, jsv, nullptr, segb, A.o_jac, lane);
+  PK_PHASE_B(T, (xall_phase_b<P, ROLE, STAGED>(A, ph, tl, g, T, s, dt, sv, jsv, xr, xe, segb, tbase, lane PK_TRACE_ARG)));
   PK_MARK(8);
 #ifdef PK_TRACE
   __builtin_amdgcn_s_waitcnt(0);      // all stores acknowledged
@@ -1287,6 +1362,9 @@ __device__ __forceinline__ void kernel_cycle(const PkArgs& A) {
     const int rec = A.n_tiles * 3 + (int)blockIdx.x;
     (void)rec;
     PK_MARK_AT(rec, 0);
+#ifdef PK_TRACE
+    if (A.trace != nullptr && threadIdx.x == 0) A.trace[(size_t)rec * 16 + 14] = __builtin_readcyclecounter();
+#endif
     if (blockIdx.x == 0) edge_block<Gen>(A, 0, true, A.items, A.n_items);
     else if (blockIdx.x == 1) edge_block<Gen>(A, 1, false, A.items2, A.n_items2);
     else fin_handoff<Gen>(A);
@@ -1294,6 +1372,9 @@ __device__ __forceinline__ void kernel_cycle(const PkArgs& A) {
     __builtin_amdgcn_s_waitcnt(0);
 #endif
     PK_MARK_AT(rec, 9);
+#ifdef PK_TRACE
+    if (A.trace != nullptr && threadIdx.x == 0) A.trace[(size_t)rec * 16 + 15] = __builtin_readcyclecounter();
+#endif
     return;
   }
   const int slot = pk::xcd_tile_block((int)blockIdx.x, 3, (int)gridDim.x);

@@ -305,7 +305,7 @@ int pk_create(pk_ctx** out, int device_id) {
   if (device_id < 0 || device_id >= ndev) return fail(nullptr, 11, "pk_create: device %d out of range [0,%d)", device_id, ndev);
   pk_ctx* c = new pk_ctx();
   c->device = device_id;
-  if (const char* dbg = getenv("POCKIT_AMD_DEBUG_FLAGS")) c->debug_flags = atoi(dbg) & (256 | 512 | 1024 | 2048 | 4096 | 8192 | 16384 | 32768 | 65536);
+  if (const char* dbg = getenv("POCKIT_AMD_DEBUG_FLAGS")) c->debug_flags = atoi(dbg) & (256 | 512 | 1024 | 2048 | 4096 | 8192 | 16384 | 32768 | 65536 | 131072);
   if ((e = hipSetDevice(device_id)) != hipSuccess || (e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)) != hipSuccess) {
     int rc = fail(nullptr, 12, "pk_create: %s", hipGetErrorString(e));
     delete c;

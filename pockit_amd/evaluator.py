@@ -20,13 +20,16 @@ from . import hipbuild, runtime
 from .codegen import ModelSource
 from .transcription import SystemPlan
 
-TARGET_TILES = int(os.environ.get("POCKIT_AMD_TARGET_TILES", "1024"))
+TARGET_TILES = int(os.environ.get("POCKIT_AMD_TARGET_TILES", "384"))
 
 
 def _intervals_per_wave(plan, override=None):
-    """Intervals per wavefront: as few as keeps ~TARGET_TILES waves in flight, so that small
-    meshes still fill the 256 CUs (1 interval per wave below ~2k intervals) while large meshes
-    use more lanes per wave for the model evaluation."""
+    """Intervals per wavefront: as few as keeps ~TARGET_TILES tiles (x 3 wave roles in the single-launch
+    cycle) in flight, up to 64 nodes per wave (Layout.tiles caps it).  Measured on MI355X with pk_cycle
+    (tools/ipw_sweep.sh): at 12k nodes the cycle is bound by the number of vector-memory
+    instructions a CU has to issue and by the time the dispatcher needs to start the waves, so fuller waves
+    (18-42 nodes: 126-133k cycles/s) beat many small ones (12 nodes: 114k, 6 nodes: 81k) as long as every CU
+    still gets work; the 40k-node humanoid runs best with full 64-node waves."""
     if override:
         return int(override)
     env = os.environ.get("POCKIT_AMD_IPW")

@@ -18,8 +18,9 @@ import pockit_amd.radau as radau  # noqa: E402
 
 TICK_US = 0.01
 MARKS = {0: "wave entry (tile record in SGPRs)", 1: "x + tables loaded", 2: "evaluation starts", 3: "evaluation done",
-         4: "before the barrier", 5: "after the barrier", 6: "defects issued", 7: "translation issued",
-         8: "streaming issued", 9: "stores acknowledged"}
+         10: "gradient stores, wave sums done", 11: "partial sums handed off", 4: "values staged in LDS",
+         5: "phase B starts", 6: "defects issued", 7: "translation issued", 8: "streaming issued",
+         9: "stores acknowledged"}
 ROLES = ["values wave", "Jacobian wave", "Hessian wave"]
 name = sys.argv[1] if len(sys.argv) > 1 else "planar_quadrotor"
 intervals = int(sys.argv[2]) if len(sys.argv) > 2 else 2000
@@ -35,6 +36,8 @@ for rep in range(4):
         ev.cycle(x, lam, sigma)
     ev.ctx.check(lib.pk_trace_read(h, buf.ctypes.data_as(C.POINTER(C.c_uint64)), len(buf)))
     m = buf.reshape(3 * n + 3, 16).astype(np.int64)
+    clk = m[:, 14:].copy()                                        # (marks 14 / 15 hold s_memtime, not the device clock)
+    m[:, 14:] = 0
     t0 = m[m > 0].min()
     us = np.where(m > 0, (m - t0) * TICK_US, np.nan)
     print(f"rep {rep}: launch spans {np.nanmax(us):.2f} us from its first to its last mark")
@@ -53,4 +56,9 @@ for rep in range(4):
                       f"p90 {np.percentile(col, 90):6.2f}  max {col.max():6.2f}")
     for i, label in enumerate(("boundary workgroup (g, J)", "boundary workgroup (H)", "finalize workgroup")):
         row = us[3 * n + i]
-        print(f"  {label}: " + "  ".join(f"[{k}] {row[k]:.2f}" for k in range(16) if not np.isnan(row[k])))
+        print(f"  {label}: " + "  ".join(f"[{k}] {row[k]:.2f}" for k in range(14) if not np.isnan(row[k])))
+    raw = m[3 * n + 2]                                            # finalize workgroup: s_memtime at marks 0 and 9
+    ck = clk[3 * n + 2]
+    if ck[1] > ck[0] and raw[9] > raw[0]:
+        print(f"  shader clock over the finalize workgroup's life: {(ck[1] - ck[0]) / ((raw[9] - raw[0]) * TICK_US):.0f} "
+              f"s_memtime ticks per us")
