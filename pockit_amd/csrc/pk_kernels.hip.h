@@ -1298,7 +1298,12 @@ __device__ __forceinline__ void kernel_outer(const PkArgs& A) {
       __syncthreads();
       if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
       __syncthreads();
-      if (threadIdx.x == 0) sums[which] = red[0] + red[1] + red[2] + red[3];
+      if (threadIdx.x == 0) {
+        double tot = 0.0;
+#pragma unroll
+        for (int w = 0; w < PK_WAVES_PER_BLOCK; ++w) tot += red[w];
+        sums[which] = tot;
+      }
     }
     __syncthreads();
     const int n = (d.flags & 2) ? 1 : d.lenA;

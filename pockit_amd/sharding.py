@@ -172,13 +172,26 @@ class ShardedEvaluator:
         self.I = self.small[:n_I]
         lib, h = self.ev.ctx.lib, self.ev.ctx.handle
         self.ev.ctx.check(lib.pk_set_shard(h, int(rank != 0), 1, C.c_void_p(self.I.data_ptr())))
+        self.stream = torch.cuda.Stream(device=dev)
 
     def cycle(self, x, lam, sigma, dist=None):
         """One f, grad f, g, J, H cycle on device tensors; results (reference order, complete on
-        every rank) are left in ``self.out``.  Enqueues on torch's current stream."""
+        every rank) are left in ``self.out``.  Ordered after / before the work of torch's current stream."""
+        torch = self.torch
+        # Kernels and collectives are ordered on ONE stream of our own (torch's default stream has the null handle,
+        # which the C ABI reads as "the context's stream" -- a stream torch's operations are not ordered with); the
+        # caller's current stream is joined before and after.
+        caller = torch.cuda.current_stream()
+        self.stream.wait_stream(caller)
+        with torch.cuda.stream(self.stream):
+            self._cycle_on_stream(x, lam, sigma, dist)
+        caller.wait_stream(self.stream)
+        return self.out
+
+    def _cycle_on_stream(self, x, lam, sigma, dist):
         torch = self.torch
         lib, h, chk = self.ev.ctx.lib, self.ev.ctx.handle, self.ev.ctx.check
-        st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+        st = C.c_void_p(self.stream.cuda_stream)
         o = self.out
         sharded = dist is not None and self.world > 1
         px = C.c_void_p(x.data_ptr())
