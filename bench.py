@@ -106,7 +106,7 @@ def cpu_baseline(name, intervals, budget_s=12.0, max_cycles=5000):
                       f"NumPy oracle, 1 thread of {os.cpu_count()} host CPUs"}
 
 
-EVENT_PERIOD = 8
+EVENT_PERIOD = 64
 
 
 def run_gpu(name, intervals, steps, warmup, rank, world, dist, time_kernel=None):
@@ -163,7 +163,7 @@ def run_gpu(name, intervals, steps, warmup, rank, world, dist, time_kernel=None)
     if dist is not None and world > 1:
         dist.barrier()
     torch.cuda.synchronize()
-    # HIP-event timing of the dominant kernel inside the timed region, on every 8th launch: a timed launch
+    # HIP-event timing of the dominant kernel inside the timed region, on every 64th launch: a timed launch
     # (hipExtModuleLaunchKernel + event pair) costs the loop ~3 us, timing all of them would slow it by a third
     ev.profile(1 << KERNEL_IDS[time_kernel or dominant], period=EVENT_PERIOD)
     # ... and one HIP event pair around the whole timed region, recorded on the launch stream
@@ -251,8 +251,8 @@ def run_gpu(name, intervals, steps, warmup, rank, world, dist, time_kernel=None)
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=300)
-    ap.add_argument("--warmup", type=int, default=30)
+    ap.add_argument("--steps", type=int, default=20000)      # ~0.15 s of GPU time: a 300-step region (2 ms) sits inside
+    ap.add_argument("--warmup", type=int, default=2000)      # one clock-management interval and varies +-7 % run to run
     ap.add_argument("--workload", default="planar_quadrotor")
     ap.add_argument("--intervals", type=int, default=2000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -289,7 +289,7 @@ def main():
         sampled_us = res["dominant_us"]
         # A cycle that is ONE launch (pk_cycle): the event pair around the timed region / steps is the average
         # launch duration plus the gap to the next launch -- an upper bound of the kernel's own duration that costs
-        # the loop nothing.  (The per-dispatch events of every 8th launch go through hipExtModuleLaunchKernel, whose
+        # the loop nothing.  (The per-dispatch events of every 64th launch go through hipExtModuleLaunchKernel, whose
         # own overhead shows up inside the pair: they read ~1 us more than rocprofv3 for the same kernel.)
         dom_us = res["region_us_per_step"] if res["dominant"] == "pk_cycle" else sampled_us
         achieved = dom_bytes / (dom_us * 1e-6) / 1e9 if dom_us else None

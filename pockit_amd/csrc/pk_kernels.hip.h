@@ -146,12 +146,15 @@ __device__ __forceinline__ int xcd_tile_block(int wg, int first, int total) {
 #define PK_MARK(k) do { } while (0)
 #endif
 
-// All output stores go through put().  Streaming (`nt`) stores were measured SLOWER than plain stores on
-// MI355X (humanoid 5000x8: pk_hess 15.7 -> 20-22 us, quadrotor pk_xall 7.7 -> 7.9 us): the L2's write
-// combining of the 512-byte runs matters more than the end-of-kernel write-back.  POCKIT_AMD_NT=1 at
-// code-generation time compiles the nt variant for A/B measurements.
+// All output stores go through put().  Default: agent-scope stores (`sc1`, written through the XCD's L2).  With plain
+// stores the 10-140 MB a launch writes stay dirty in the L2s until the end-of-kernel release writes them back -- after
+// the last wave, with nothing to overlap: write-through spreads that over the kernel's life (MI355X, pk_cycle:
+// quadrotor 2000x6 134k -> 161k cycles/s, brachistochrone 1250x8 135k -> 154k, humanoid 5000x8 38.5k -> 39.6k; system
+// scope `sc0 sc1` measures the same).  Streaming (`nt`) stores are SLOWER than plain ones (humanoid 38.5k -> 22.5k):
+// they lose the L2's merging of the partial lines neighbouring tiles share.  POCKIT_AMD_NT=0|1|2|3 at
+// code-generation time compiles the plain / nt / agent / system variant for A/B measurements (tools/nt_sweep.sh).
 #ifndef PK_NT_STORES
-#define PK_NT_STORES 0
+#define PK_NT_STORES 2
 #endif
 
 __device__ __forceinline__ void put(double* __restrict__ p, double v) {
