@@ -1523,7 +1523,11 @@ __device__ __forceinline__ void fin_handoff(const PkArgs& A) {
   __syncthreads();
   const PkSys sy{A.x + A.l_s, Ish, A.sigma, A.lam};
   if (t == 0) A.o_f[0] = Gen::sys_objective(sy);          // systembase.py:592-605
-  if (t == 64) Gen::sys_grad_static(sy, gsh);
+  if (t == 64) {
+#pragma unroll
+    for (int i = 0; i < PK_NS; ++i) gsh[i] = 0.0;
+    if (!(A.flags & 2)) Gen::sys_grad_static(sy, gsh);      // (sharded: the primary shard adds the direct dependence)
+  }
   __syncthreads();
   // gradient slots no tile writes (end slots, t0 / tf, static parameters): 0 + the sums of the rows that land on the
   // slot, phase by phase, + the objective's direct dependence on a static parameter   (systembase.py:654-657)

@@ -701,7 +701,10 @@ int pk_eval_cycle_dev(pk_ctx* c, const double* d_x, const double* d_lam, double 
   if (!d_lam) return fail(c, 50, "pk_eval_cycle: lambda is required");
   hipStream_t st = pick(c, stream);
   const bool needs_I = c->md.prepass_grad || c->md.prepass_g || c->md.prepass_jac || c->md.prepass_hess;
-  if (needs_I || c->external_prepass || c->shard_flags) {   // general path: the five callbacks one after the other
+  // general path: the five callbacks one after the other.  A shard (pk_set_shard) may take the single launch too: its
+  // finalize workgroup then leaves THIS shard's share of the integrals and of the shared gradient slots for the
+  // caller's all-reduce, and f is the caller's to recompute (pk_eval_f_from_integrals_dev).
+  if (needs_I || ((c->external_prepass || c->shard_flags) && c->cycle_mode != 1)) {
     if (!c->external_prepass && (rc = pk_eval_f_dev(c, d_x, d_f, stream))) return rc;
     if ((rc = pk_eval_grad_dev(c, d_x, d_grad, stream))) return rc;
     if ((rc = pk_eval_g_dev(c, d_x, d_g, stream))) return rc;

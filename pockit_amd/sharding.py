@@ -195,13 +195,20 @@ class ShardedEvaluator:
         o = self.out
         sharded = dist is not None and self.world > 1
         px = C.c_void_p(x.data_ptr())
-        chk(lib.pk_eval_integrals_dev(h, px, st))                      # this shard's share of every integral
-        if sharded and self.early_I:
-            dist.all_reduce(self.I)
-        chk(lib.pk_eval_grad_dev(h, px, C.c_void_p(o["grad"].data_ptr()), st))
-        chk(lib.pk_eval_g_dev(h, px, C.c_void_p(o["g"].data_ptr()), st))
-        chk(lib.pk_eval_jac_dev(h, px, C.c_void_p(o["J"].data_ptr()), st))
-        chk(lib.pk_eval_hess_dev(h, px, C.c_void_p(lam.data_ptr()), float(sigma), C.c_void_p(o["H"].data_ptr()), st))
+        ptr = lambda t: C.c_void_p(t.data_ptr())  # noqa: E731
+        if not self.early_I:
+            # ONE launch per rank (pk_cycle): this shard's tiles of all five outputs, its share of the integrals (-> self.I)
+            # and of the shared gradient slots; f is recomputed from the reduced integrals below
+            chk(lib.pk_eval_cycle_dev(h, px, ptr(lam), float(sigma), ptr(o["f"]), ptr(o["grad"]), ptr(o["g"]), ptr(o["J"]),
+                                      ptr(o["H"]), st))
+        else:
+            chk(lib.pk_eval_integrals_dev(h, px, st))                  # this shard's share of every integral
+            if sharded:
+                dist.all_reduce(self.I)
+            chk(lib.pk_eval_grad_dev(h, px, ptr(o["grad"]), st))
+            chk(lib.pk_eval_g_dev(h, px, ptr(o["g"]), st))
+            chk(lib.pk_eval_jac_dev(h, px, ptr(o["J"]), st))
+            chk(lib.pk_eval_hess_dev(h, px, ptr(lam), float(sigma), ptr(o["H"]), st))
         if sharded:
             if self.early_I:           # integrals are already global: keep them out of the second reduction
                 keep = self.I.clone()
