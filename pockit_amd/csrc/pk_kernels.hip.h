@@ -722,16 +722,19 @@ __device__ __forceinline__ void xall_phase_b(const PkArgs& A, const PkPhase& ph,
                                              int lane PK_TRACE_PARAM) {
   if (ROLE != 2 && !(A.flags & 8192)) write_defects<P, STAGED>(A, ph, tl, g, T, s, dt, sv, xr, xe, lane);
   PK_MARK(6);
-  if (tl.nj == 0 || ROLE == 1) return;
-  if (!(A.flags & 16384)) write_translation<P, STAGED>(A, ph, tl, T, tbase, lane);
+  if (tl.nj == 0) return;
+  // the constant translation entries of J go out with the VALUES wave: the Jacobian wave's streaming is the longest
+  // chain of the launch (wave timeline), the values wave has ~1 us of slack after its defect rows
+  if (ROLE != 2 && !(A.flags & 16384)) write_translation<P, STAGED>(A, ph, tl, T, tbase, lane);
   PK_MARK(7);
+  if (ROLE == 1) return;
   if (!(A.flags & 32768))
     stream_expanded<P, P::J_NI, false, STAGED>(A, ph, tl, g, T, jsv, nullptr, segb, A.o_jac, lane);
 }
 
 // ROLE 0: the wave produces everything of its tile.  ROLE 1 / 2 (split launch): two waves of two different
-// workgroups share a tile -- 1 writes the values (integrand sums, gradient, path constraints, defects), 2 the
-// Jacobian (N segments, translation entries, I-expanded segments); the role is a compile-time constant, so each
+// workgroups share a tile -- 1 writes the values (integrand sums, gradient, path constraints, defects) and the
+// constant translation entries of J, 2 the evaluated part of the Jacobian (N segments, I-expanded segments); the role is a compile-time constant, so each
 // wave's copy of the inlined model evaluation keeps only what its outputs need and its serial chain is roughly
 // halved.  A workgroup holds four waves of ONE role (four consecutive tiles).
 // pub_blk >= 0 (pk_cycle, roles 0 / 1): the workgroup hands its partial sums to the launch's finalize workgroup as
@@ -749,10 +752,8 @@ __device__ __forceinline__ void tile_xall(const PkArgs& A, const PkTile& tl, dou
   const PkSys sy{s, A.Ibuf, A.sigma, A.lam};
   SegBases<P::J_NI + P::J_NN> segb;
   SegBases<P::NX> tbase;
-  if (ROLE != 1) {
-    segb.load(A.lb, ph.jseg_off, lane);
-    tbase.load(A.lb, ph.jt_off, lane);
-  }
+  if (ROLE != 1) segb.load(A.lb, ph.jseg_off, lane);
+  if (ROLE != 2) tbase.load(A.lb, ph.jt_off, lane);
   double* __restrict__ jsv = sv + P::NX * PK_WAVE;
   const bool fit = tabs_fit(A, tl, g);
   const TabRegs tr = tabs_issue(A, ph, tl, g, fit, lane);
@@ -760,10 +761,8 @@ __device__ __forceinline__ void tile_xall(const PkArgs& A, const PkTile& tl, dou
   double a[P::NARG], tau, w, xr[P::NX], xe[P::NX];
   load_node<P>(A, ph, s, dt, mt, q, a, tau, w);
   const TileTabs T = tabs_commit(tr, fit, lane);
-  if (ROLE != 1) {
-    segb.settle();
-    tbase.settle();
-  }
+  if (ROLE != 1) segb.settle();
+  if (ROLE != 2) tbase.settle();
   PK_MARK(1);
   if (ROLE != 2) {
     defect_ends<P>(A, ph, tl, g, a, xe, lane);

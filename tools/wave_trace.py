@@ -31,9 +31,23 @@ lib, h = ev.ctx.lib, ev.ctx.handle
 ev.ctx.check(lib.pk_trace_read(h, None, 0))                      # arm
 n = len(ev.tables.tiles)
 buf = np.zeros((3 * n + 3) * 16, dtype=np.uint64)
+b2b = os.environ.get("POCKIT_AMD_TRACE_B2B") == "1"
+if b2b:
+    import torch
+
+    dev = torch.device("cuda", 0)
+    dx, dlam = torch.from_numpy(x).to(dev), torch.from_numpy(lam).to(dev)
+    plan = system.plan
+    outs = [torch.zeros(k, dtype=torch.float64, device=dev) for k in (1, plan.n, plan.m, plan.nnz_J, plan.nnz_H)]
+    torch.cuda.synchronize()
 for rep in range(4):
-    for _ in range(3):                                           # the last of three back-to-back cycles is read
-        ev.cycle(x, lam, sigma)
+    if b2b:
+        for _ in range(6):
+            ev.cycle_dev(dx.data_ptr(), dlam.data_ptr(), sigma, *[o.data_ptr() for o in outs])
+        ev.sync()
+    for _ in range(0 if b2b else 3):                             # the last of three cycles is read
+        ev.cycle(x, lam, sigma)                                  # (ev.cycle synchronizes: every launch starts on an idle GPU;
+                                                                 #  POCKIT_AMD_TRACE_B2B=1 traces the last of 3 queued launches)
     ev.ctx.check(lib.pk_trace_read(h, buf.ctypes.data_as(C.POINTER(C.c_uint64)), len(buf)))
     m = buf.reshape(3 * n + 3, 16).astype(np.int64)
     clk = m[:, 14:].copy()                                        # (marks 14 / 15 hold s_memtime, not the device clock)
@@ -54,6 +68,11 @@ for rep in range(4):
             if len(col):
                 print(f"    {label:36s} median {np.median(col):6.2f}  p10 {np.percentile(col, 10):6.2f}  "
                       f"p90 {np.percentile(col, 90):6.2f}  max {col.max():6.2f}")
+    # tiles are dealt to the XCDs in contiguous ranges (xcd_tile_block): entry / end per eighth of the tile list
+    jw = us[1:3 * n:3] if not np.all(np.isnan(us[1:3 * n:3, 0])) else us[0:3 * n:3]
+    parts = np.array_split(np.arange(len(jw)), 8)
+    print("  Jacobian waves by eighth of the tile list (~XCD): first entry / median entry / last store acknowledged")
+    print("   " + "  ".join(f"{np.nanmin(jw[ix, 0]):.2f}/{np.nanmedian(jw[ix, 0]):.2f}/{np.nanmax(jw[ix, 9]):.2f}" for ix in parts))
     for i, label in enumerate(("boundary workgroup (g, J)", "boundary workgroup (H)", "finalize workgroup")):
         row = us[3 * n + i]
         print(f"  {label}: " + "  ".join(f"[{k}] {row[k]:.2f}" for k in range(14) if not np.isnan(row[k])))
