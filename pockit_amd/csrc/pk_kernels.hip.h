@@ -5,23 +5,29 @@
 // that dispatches on the phase id.  Everything about *how* the work is mapped to the GPU lives here.
 //
 // Work decomposition: a *tile* is a run of consecutive mesh intervals of
-// one pattern with at most 64 collocation nodes; one 64-lane wavefront owns one tile:
+// one pattern with at most 64 collocation nodes; one 64-lane wavefront owns one tile (and one role, below):
 //   phase A  lane = node: coalesced 8-byte loads of the trajectory vector (states/controls are
 //            stored node-contiguous per variable), model evaluation in registers, the per-node
 //            values that are needed by all K rows of the interval are staged in LDS ([segment][lane]);
 //            in the same memory round trip the wave copies its tile's small pattern tables (K <= 8: at most
-//            64 entries each) and, for the Hessian, its rows of the multipliers into LDS;
+//            64 entries each), the base offsets of its output segments (kept in a VGPR pair, lane e = segment e)
+//            and, for the Hessian, its rows of the multipliers;
 //   phase B  lane = output position: every I-expanded segment of the tile is a contiguous run of
 //            nj * K^2 doubles in the output array; the wave streams them out in 512-byte coalesced
-//            stores, reading staged values and tables from LDS only (no global load after the barrier).
+//            stores, reading staged values and tables from LDS only.  Phase B contains NO vector load (loads and
+//            stores share vmcnt and return out of order: one load would make every wait a wait for all stores)
+//            and needs no workgroup barrier (a wave stages for itself only).
 // The tile record is wave-uniform: it is read through the scalar cache into SGPRs (readfirstlane +
-// constant address space), as are the segment base offsets.
-// Four independent waves share a 256-thread workgroup (one __syncthreads between the phases).
-// One extra workgroup per launch handles the boundary nodes and the system-level scalars.
+// constant address space).
+// Four waves of ONE role on four consecutive tiles share a 256-thread workgroup.  Roles: the whole tile (pk_g,
+// pk_jac, pk_hess, unsplit pk_xall), or -- split x-part -- values (g, grad f, integrand sums, constant entries of J)
+// and Jacobian (evaluated entries of J), next to the Hessian role in the single-launch cycle pk_cycle.
+// Extra workgroups handle the boundary nodes / system-level scalars and the sums over all nodes.
 // Sums over all nodes (integrals, gradient entries of t0/tf/static parameters) are reduced
-// wave -> workgroup in the tile kernels and workgroup -> total by the single-workgroup pk_fin, in a
-// fixed order (bit-reproducible).  (An in-launch "last workgroup finalizes" variant was measured
-// slower: the agent-scope hand-off costs 5-6 dependent memory round trips)
+// wave -> workgroup in the tile kernels and workgroup -> total by ONE workgroup in a fixed order
+// (bit-reproducible): pk_fin in a launch of its own, or -- pk_cycle -- a workgroup of the same launch that receives
+// the partial sums through self-flagging hand-off slots (handoff_put / fin_handoff).
+// Output stores are agent-scope (written through L2), see put().
 //
 // Reference semantics restated by each kernel are cited at the kernel.
 #pragma once
@@ -506,20 +512,31 @@ __device__ __forceinline__ void stream_expanded(const PkArgs& A, const PkPhase& 
 
 // per-node gradient entries: own variable slots directly, shared slots into orr   (systembase.py:646-657)
 template <class P>
-__device__ __forceinline__ void node_gradient(const PkArgs& A, const PkPhase& ph, int q, const double* a,
-                                              double tau, double dt, double w, const PkSys& sy, double* ov,
-                                              double* orr, bool have_mid) {
+__device__ __forceinline__ void node_gradient_eval(const PkPhase& ph, int q, const double* a, double tau, double dt,
+                                                   double w, const PkSys& sy, double* ov, double* orr, bool have_mid) {
   if (q == 0)
     P::front_grad(a, tau, dt, w, sy, nullptr, ov, orr);
   else if (P::SCHEME == 1 && q == ph.L_m - 1)
     P::back_grad(a, tau, dt, w, sy, nullptr, ov, orr);
   else if (!have_mid)
     P::mid_grad(a, tau, dt, w, sy, nullptr, ov, orr);
+}
+
+template <class P>
+__device__ __forceinline__ void node_gradient_store(const PkArgs& A, const PkPhase& ph, int q, const double* ov) {
   double* __restrict__ gp = A.o_grad + ph.x_off;
 #pragma unroll
   for (int i = 0; i < P::NX; ++i) put(&gp[i * ph.state_len + q], ov[i]);
 #pragma unroll
   for (int i = 0; i < P::NU; ++i) put(&gp[P::NX * ph.state_len + i * ph.L_m + q], ov[P::NX + i]);
+}
+
+template <class P>
+__device__ __forceinline__ void node_gradient(const PkArgs& A, const PkPhase& ph, int q, const double* a,
+                                              double tau, double dt, double w, const PkSys& sy, double* ov,
+                                              double* orr, bool have_mid) {
+  node_gradient_eval<P>(ph, q, a, tau, dt, w, sy, ov, orr, have_mid);
+  node_gradient_store<P>(A, ph, q, ov);
 }
 
 // ============================================================================================
@@ -776,10 +793,10 @@ __device__ __forceinline__ void tile_xall(const PkArgs& A, const PkTile& tl, dou
   for (int r = 0; r < P::INT_N; ++r) oi[r] = 0.0;
 #pragma unroll
   for (int r = 0; r < P::GR_NR; ++r) orr[r] = 0.0;
-  double og[P::G_NOUT], oj[P::J_NI + P::J_NN + 1];
+  double og[P::G_NOUT], oj[P::J_NI + P::J_NN + 1], ov[P::NX + P::NU];
   const bool live = lane < g.nq && !(A.flags & 512);   // (bit 9: diagnostic switch, skip the evaluation phase)
   if (live) {
-    double ov[P::NX + P::NU], ot[P::GR_NR > 0 ? P::GR_NR : 1], op[P::INT_N > 0 ? P::INT_N : 1];
+    double ot[P::GR_NR > 0 ? P::GR_NR : 1], op[P::INT_N > 0 ? P::INT_N : 1];
     PK_MARK(2);
     P::mid_xall(a, tau, dt, w, sy, og, oj, ov, ot, op);
     PK_MARK(3);
@@ -788,7 +805,7 @@ __device__ __forceinline__ void tile_xall(const PkArgs& A, const PkTile& tl, dou
       for (int r = 0; r < P::INT_N; ++r) oi[r] = op[r] * w;
 #pragma unroll
       for (int r = 0; r < P::GR_NR; ++r) orr[r] = ot[r];
-      node_gradient<P>(A, ph, q, a, tau, dt, w, sy, ov, orr, true);   // boundary nodes re-evaluate their own entries
+      node_gradient_eval<P>(ph, q, a, tau, dt, w, sy, ov, orr, true);   // boundary nodes re-evaluate their own entries
     }
   }
   if (ROLE != 2) {
@@ -820,6 +837,7 @@ __device__ __forceinline__ void tile_xall(const PkArgs& A, const PkTile& tl, dou
   }
   if (live) {
     if (ROLE != 2) {
+      if (lane < g.nown) node_gradient_store<P>(A, ph, q, ov);      // (after the sums went out: they feed the finalize chain)
 #pragma unroll
       for (int i = 0; i < P::NX; ++i) sv[i * PK_WAVE + lane] = og[i];
     }
@@ -1456,9 +1474,11 @@ __device__ __forceinline__ void fin_handoff(const PkArgs& A) {
   __shared__ double Ish[PK_NI];
   __shared__ double gsh[PK_NS];
   __shared__ double dts[PK_NPHASE];
+  __shared__ double ssh[PK_NS];                     // static parameters, fetched before the wait (F_o(I, s) reads them)
   __shared__ int ridx[NR];
   const int t = threadIdx.x, wave = t >> 6;
   if (t < PK_NPHASE) dts[t] = Gen::phase_dt(t, A);
+  if (t >= 128 && t - 128 < A.n_s && t - 128 < PK_NS) ssh[t - 128] = A.x[A.l_s + t - 128];
   const int gz0 = t < A.n_gz ? A.ib[A.gz_off + t] : -1;
 #pragma unroll
   for (int row = 0; row < Gen::N_ROWS; ++row)
@@ -1520,7 +1540,7 @@ __device__ __forceinline__ void fin_handoff(const PkArgs& A) {
       }
     }
   __syncthreads();
-  const PkSys sy{A.x + A.l_s, Ish, A.sigma, A.lam};
+  const PkSys sy{ssh, Ish, A.sigma, A.lam};
   if (t == 0) A.o_f[0] = Gen::sys_objective(sy);          // systembase.py:592-605
   if (t == 64) {
 #pragma unroll
