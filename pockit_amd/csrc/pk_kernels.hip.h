@@ -1060,7 +1060,9 @@ __device__ __forceinline__ double block_sum_partials(const PkArgs& A, const doub
   const int blk = pk::xcd_tile_block((int)blockIdx.x, (EDGE), (int)gridDim.x);        \
   PK_TILE_PROLOGUE_AT()
 // PK_TILE_PROLOGUE_AT: the caller has defined `blk`, the workgroup's tile block (four consecutive tiles)
-#define PK_TILE_PROLOGUE_AT()                                                    \
+#define PK_TILE_PROLOGUE_AT() PK_TILE_PROLOGUE_FROM(A.tile, A.n_tiles)
+// (TILES, NTILES: where the tile list comes from -- the PkArgs in the kernarg segment, or pk_cycle's preloaded copies)
+#define PK_TILE_PROLOGUE_FROM(TILES, NTILES)                                          \
   extern __shared__ double pk_lds[];                                                  \
   __shared__ double wint[PK_WAVES_PER_BLOCK * PK_NRED];                               \
   __shared__ double wgrad[PK_WAVES_PER_BLOCK * PK_NRED];                              \
@@ -1069,11 +1071,11 @@ __device__ __forceinline__ double block_sum_partials(const PkArgs& A, const doub
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63; \
   const int ti = blk * PK_WAVES_PER_BLOCK + wave;                                     \
   PkTile tl;                                                                          \
-  if (ti < A.n_tiles) {                                                               \
-    tl = load_tile(A.tile + ti);                                                      \
+  if (ti < (NTILES)) {                                                                \
+    tl = load_tile((TILES) + ti);                                                     \
     tl.pad = ti;                                                                      \
   } else {                                                                            \
-    tl = load_tile(A.tile + (A.n_tiles > 0 ? A.n_tiles - 1 : 0));                     \
+    tl = load_tile((TILES) + ((NTILES) > 0 ? (NTILES)-1 : 0));                        \
     tl.nj = 0;                                                                        \
     tl.pad = -1;                                                                      \
   }                                                                                   \
@@ -1379,8 +1381,13 @@ __device__ __forceinline__ void kernel_xall(const PkArgs& A) {
 //                not split) so that every XCD gets a contiguous range of tiles of every output array
 // Every wave runs exactly what it runs in pk_xall / pk_hess, they just run at the same time.
 // ============================================================================================
+// pre: the four values a tile wave needs before it can ask for its tile record (tile list, its length, the launch flags,
+// the grid size), passed as leading scalar kernel arguments: with kernarg preloading (gfx940+,
+// -amdgpu-kernarg-preload-count) they arrive in SGPRs with the wave, so the record load is not queued behind a first
+// round trip to the kernarg segment.
 template <class Gen>
-__device__ __forceinline__ void kernel_cycle(const PkArgs& A) {
+__device__ __forceinline__ void kernel_cycle(const PkTile* pre_tile, int pre_n_tiles, int pre_flags, int pre_grid,
+                                             const PkArgs& A) {
   if (blockIdx.x < 2 && (A.flags & 2048)) return;     // diagnostic switches (POCKIT_AMD_DEBUG_FLAGS): no boundary work,
   if (blockIdx.x == 2 && (A.flags & 65536)) return;   // no finalize workgroup (the hand-off slots then stay filled)
   if (blockIdx.x < 3) {
@@ -1402,11 +1409,11 @@ __device__ __forceinline__ void kernel_cycle(const PkArgs& A) {
 #endif
     return;
   }
-  const int slot = pk::xcd_tile_block((int)blockIdx.x, 3, (int)gridDim.x);
-  const bool split = (A.flags & 32) != 0;
+  const int slot = pk::xcd_tile_block((int)blockIdx.x, 3, pre_grid);
+  const bool split = (pre_flags & 32) != 0;
   const int blk = split ? slot / 3 : slot >> 1;       // the tile block; its workgroups follow each other in dispatch order
   const int sub = slot - blk * (split ? 3 : 2);       // split: 0 Jacobian, 1 values, 2 Hessian; else 0 x-part, 1 Hessian
-  PK_TILE_PROLOGUE_AT();
+  PK_TILE_PROLOGUE_FROM(pre_tile, pre_n_tiles);
   if (sub == (split ? 2 : 1))
     Gen::tile_hess(tl.phase, A, tl, pk_lds + wave * Gen::LDS_H, wint, wgrad, lane);
   else if (!split)
@@ -1581,4 +1588,7 @@ __device__ __forceinline__ void kernel_fin(const PkArgs& A) {
   extern "C" __global__ __launch_bounds__(PK_BLOCK) void pk_hessc(PkArgs A) { pk::kernel_hessc<GEN>(A); } \
   extern "C" __global__ __launch_bounds__(PK_BLOCK) void pk_err(PkArgs A) { pk::kernel_err<GEN>(A); }     \
   extern "C" __global__ __launch_bounds__(PK_BLOCK) void pk_csr(PkArgs A) { pk::kernel_csr(A); }             \
-  extern "C" __global__ __launch_bounds__(PK_BLOCK) void pk_cycle(PkArgs A) { pk::kernel_cycle<GEN>(A); }
+  extern "C" __global__ __launch_bounds__(PK_BLOCK) void pk_cycle(const PkTile* pre_tile, int32_t pre_n_tiles,  \
+                                                                  int32_t pre_flags, int32_t pre_grid, PkArgs A) { \
+    pk::kernel_cycle<GEN>(pre_tile, pre_n_tiles, pre_flags, pre_grid, A);                                        \
+  }

@@ -22,6 +22,7 @@
 #include <hip/hip_ext.h>
 
 #include <climits>
+#include <cstddef>
 #include <cstdarg>
 #include <cstdint>
 #include <cstdio>
@@ -197,9 +198,8 @@ PkArgs base_args(pk_ctx* c, const double* d_x, const double* d_lam, double sigma
   return A;
 }
 
-int launch(pk_ctx* c, int k, PkArgs& A, unsigned grid, size_t lds_bytes, hipStream_t st) {
-  size_t sz = sizeof(PkArgs);
-  void* config[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &A, HIP_LAUNCH_PARAM_BUFFER_SIZE, &sz, HIP_LAUNCH_PARAM_END};
+int launch_raw(pk_ctx* c, int k, void* args, size_t sz, unsigned grid, size_t lds_bytes, hipStream_t st) {
+  void* config[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, args, HIP_LAUNCH_PARAM_BUFFER_SIZE, &sz, HIP_LAUNCH_PARAM_END};
   EventPair ev{};
   if (grid == 0) return 0;
   // every `profile_period`-th launch of a selected kernel is timed (the timed launch path costs ~2-3 us of host
@@ -223,6 +223,10 @@ int launch(pk_ctx* c, int k, PkArgs& A, unsigned grid, size_t lds_bytes, hipStre
   }
   PK_HIP(c, hipModuleLaunchKernel(c->fn[k], grid, 1, 1, PK_BLOCK, 1, 1, (unsigned)lds_bytes, st, nullptr, config));
   return 0;
+}
+
+int launch(pk_ctx* c, int k, PkArgs& A, unsigned grid, size_t lds_bytes, hipStream_t st) {
+  return launch_raw(c, k, &A, sizeof(PkArgs), grid, lds_bytes, st);
 }
 
 unsigned tile_blocks(const pk_ctx* c) { return (unsigned)((c->n_tiles + PK_WAVES_PER_BLOCK - 1) / PK_WAVES_PER_BLOCK); }
@@ -254,7 +258,17 @@ int enqueue_single_launch_cycle(pk_ctx* c, const double* d_x, const double* d_la
   if (dbl < (size_t)c->md.ne_j) dbl = (size_t)c->md.ne_j;
   if (dbl < (size_t)c->md.ne_h) dbl = (size_t)c->md.ne_h;
   const unsigned per_group = c->split_xall ? 3u : 2u;
-  return launch(c, K_CYCLE, A, tile_blocks(c) * per_group + 3u, sizeof(double) * dbl, st);
+  const unsigned grid = tile_blocks(c) * per_group + 3u;
+  // pk_cycle's kernarg segment: the scalars a tile wave needs first (preloaded into SGPRs), then the PkArgs
+  struct CycleArgs {
+    const PkTile* tile;
+    int32_t n_tiles, flags, grid, pad;
+    PkArgs A;
+  } K;
+  static_assert(offsetof(CycleArgs, A) == 24, "layout of pk_cycle's kernel arguments");
+  K.tile = A.tile; K.n_tiles = A.n_tiles; K.flags = A.flags; K.grid = (int32_t)grid; K.pad = 0;
+  K.A = A;
+  return launch_raw(c, K_CYCLE, &K, sizeof K, grid, sizeof(double) * dbl, st);
 }
 
 int enqueue_fused_cycle(pk_ctx* c, const double* d_x, const double* d_lam, double sigma, double* d_f, double* d_grad,

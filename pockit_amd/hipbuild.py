@@ -56,6 +56,10 @@ def build_runtime(force=False):
 EXTRA_FLAGS = os.environ.get("POCKIT_AMD_HIPCC_FLAGS", "").split()
 
 
+# leading scalar kernel arguments (pk_cycle's tile list, counts, flags) arrive in SGPRs with the wave
+PRELOAD_FLAGS = [] if os.environ.get("POCKIT_AMD_KERNARG_PRELOAD", "1") == "0" else ["-mllvm", "-amdgpu-kernarg-preload-count=4"]
+
+
 def _kernel_header_hash():
     h = hashlib.sha256()
     for name in ("pk_kernels.hip.h", "pk_abi.h"):
@@ -66,7 +70,7 @@ def _kernel_header_hash():
 
 def compile_model(source: str, fastmath: bool = False, keep_source: bool = True) -> bytes:
     """Return the gfx950 code object of a generated model source (compiling on a cache miss)."""
-    key = hashlib.sha256((source + _kernel_header_hash() + str(bool(fastmath)) + " ".join(EXTRA_FLAGS)).encode()
+    key = hashlib.sha256((source + _kernel_header_hash() + str(bool(fastmath)) + " ".join(PRELOAD_FLAGS + EXTRA_FLAGS)).encode()
                          ).hexdigest()[:32]
     os.makedirs(CACHE_DIR, exist_ok=True)
     path = os.path.join(CACHE_DIR, key + ".hsaco")
@@ -76,7 +80,7 @@ def compile_model(source: str, fastmath: bool = False, keep_source: bool = True)
             with open(src, "w") as fh:
                 fh.write(source)
             cmd = [_hipcc(), f"--offload-arch={ARCH}", "-O3", "-std=c++17", "--genco", f"-I{CSRC}", src, "-o",
-                   os.path.join(tmp, "model.hsaco")] + EXTRA_FLAGS
+                   os.path.join(tmp, "model.hsaco")] + PRELOAD_FLAGS + EXTRA_FLAGS
             if fastmath:  # reassociation subset of fast-math (reference: numba fastmath=True, fastfunc.py:24,35)
                 cmd += ["-fassociative-math", "-freciprocal-math", "-fno-signed-zeros", "-fno-trapping-math"]
             _run(cmd)
