@@ -12,8 +12,8 @@ Workload (BASELINE.json metric: "at 10k LGR nodes"): planar_quadrotor re-meshed 
 intervals x 6 points = 12 000 nodes (configs[2], the ~10k-node headline of BASELINE.md), x =
 example guess * (1 + 1e-3 U), lambda ~ N(0,1), sigma = 1, all seeded.  For N > 1 the mesh is
 2000*N intervals of the same model, sharded by mesh interval over the N GPUs (weak scaling: 2000
-intervals per GPU) with RCCL all-gather reassembly of grad/g/J/H on every rank; ``value`` is then reported in
-12k-node-equivalent cycles/s (= N * steps / time).
+intervals per GPU) with RCCL gather reassembly of grad/g/J/H on rank 0 (where the host-side solver runs); ``value`` is
+then reported in 12k-node-equivalent cycles/s (= N * steps / time).
 
 One JSON line is printed by rank 0 (see the repository prompt for the contract), carrying
 ``roofline`` for the dominant kernel (HIP-event timed on the launch stream inside the timed
@@ -146,7 +146,7 @@ def run_gpu(name, intervals, steps, warmup, rank, world, dist, time_kernel=None)
         ev.ctx.check(lib.pk_set_shard(h, 0, 0, None))
     else:
         def step():
-            sev.cycle(dx, dlam, sigma, dist)
+            sev.cycle(dx, dlam, sigma, dist, root=0)      # triplets reassembled on rank 0, where the NLP solver runs
 
     B = algorithmic_bytes(plan)
     fused = world == 1 and not (plan.needs_I_grad or plan.needs_I_con or plan.jac.needs_I or plan.hess.needs_I)
@@ -311,8 +311,9 @@ def main():
                                    f"{6 if args.workload == 'planar_quadrotor' else 8 if args.workload != 'two_stage_rocket' else 4}"
                                    f" points ({res['nodes']} nodes; n={res['n']}, m={res['m']}, nnz_J={res['nnz_J']}, "
                                    f"nnz_H={res['nnz_H']})",
-                       "sharding": "single GPU" if n_gpus == 1 else f"mesh intervals over {n_gpus} GPUs, RCCL all-gather "
-                                                                    f"of the owned runs of grad/g/J/H + tiny all-reduce",
+                       "sharding": "single GPU" if n_gpus == 1 else f"mesh intervals over {n_gpus} GPUs, one pk_cycle launch per "
+                                                                    f"rank, RCCL gather of the owned runs of grad/g/J/H "
+                                                                    f"to rank 0 (the solver's rank) + tiny all-reduce",
                        "tiles": res["tiles"], "intervals_per_wave": res["ipw"],
                        "inputs": "example guess*(1+1e-3 U(-1,1)) seed 0; lambda N(0,1) seed 1; sigma 1"},
             "roofline": {"bound": "hbm", "kernel": res["dominant"], "achieved": achieved, "peak": HBM_PEAK_GBPS,

@@ -120,17 +120,27 @@ class Reassembler:
         self.shared_idx = torch.from_numpy(shared).to(device)
         self.recv = torch.empty(self.pad * world, dtype=torch.float64, device=device)
 
-    def exchange(self, full, small, dist):
+    def exchange(self, full, small, dist, root=None):
         """``full``: packed buffer of length total + 1 (last element is scratch); ``small``: the small
         reduction buffer [integrals | shared gradient slots] (already filled with this rank's partials).
-        One tiny all-reduce + one all-gather; afterwards ``full`` is complete on every rank."""
+        One tiny all-reduce + one all-gather; afterwards ``full`` is complete on every rank.
+
+        ``root = r``: gather to rank r instead -- the triplets are reassembled where the (host-side) NLP solver runs,
+        every other rank keeps its own slices (+ the reduced sums).  Rank r then receives (N - 1) packs over its N - 1
+        direct xGMI links at once, whereas the all-gather moves N (N - 1) packs through the same links."""
         n_sh = self.shared_idx.numel()
         if n_sh:
             small[-n_sh:] = full.index_select(0, self.shared_idx)
         dist.all_reduce(small)
         send = full.index_select(0, self.own_idx)
-        dist.all_gather_into_tensor(self.recv, send)
-        full.index_copy_(0, self.all_idx, self.recv)
+        if root is None:
+            dist.all_gather_into_tensor(self.recv, send)
+            full.index_copy_(0, self.all_idx, self.recv)
+        elif self.rank == root:
+            dist.gather(send, [self.recv[r * self.pad: (r + 1) * self.pad] for r in range(self.world)], dst=root)
+            full.index_copy_(0, self.all_idx, self.recv)
+        else:
+            dist.gather(send, None, dst=root)
         if n_sh:
             full.index_copy_(0, self.shared_idx, small[-n_sh:])
 
@@ -174,9 +184,10 @@ class ShardedEvaluator:
         self.ev.ctx.check(lib.pk_set_shard(h, int(rank != 0), 1, C.c_void_p(self.I.data_ptr())))
         self.stream = torch.cuda.Stream(device=dev)
 
-    def cycle(self, x, lam, sigma, dist=None):
+    def cycle(self, x, lam, sigma, dist=None, root=None):
         """One f, grad f, g, J, H cycle on device tensors; results (reference order, complete on
-        every rank) are left in ``self.out``.  Ordered after / before the work of torch's current stream."""
+        every rank, or -- ``root = r`` -- on rank r only) are left in ``self.out``.  Ordered after / before the
+        work of torch's current stream."""
         torch = self.torch
         # Kernels and collectives are ordered on ONE stream of our own (torch's default stream has the null handle,
         # which the C ABI reads as "the context's stream" -- a stream torch's operations are not ordered with); the
@@ -184,11 +195,11 @@ class ShardedEvaluator:
         caller = torch.cuda.current_stream()
         self.stream.wait_stream(caller)
         with torch.cuda.stream(self.stream):
-            self._cycle_on_stream(x, lam, sigma, dist)
+            self._cycle_on_stream(x, lam, sigma, dist, root)
         caller.wait_stream(self.stream)
         return self.out
 
-    def _cycle_on_stream(self, x, lam, sigma, dist):
+    def _cycle_on_stream(self, x, lam, sigma, dist, root):
         torch = self.torch
         lib, h, chk = self.ev.ctx.lib, self.ev.ctx.handle, self.ev.ctx.check
         st = C.c_void_p(self.stream.cuda_stream)
@@ -212,9 +223,9 @@ class ShardedEvaluator:
         if sharded:
             if self.early_I:           # integrals are already global: keep them out of the second reduction
                 keep = self.I.clone()
-                self.re.exchange(self.full, self.small, dist)
+                self.re.exchange(self.full, self.small, dist, root)
                 self.I.copy_(keep)
             else:
-                self.re.exchange(self.full, self.small, dist)
+                self.re.exchange(self.full, self.small, dist, root)
         chk(lib.pk_eval_f_from_integrals_dev(h, px, C.c_void_p(o["f"].data_ptr()), st))
         return o

@@ -28,6 +28,13 @@ class HostStagedDist:
         self.dist.all_gather_into_tensor(ho, hi)
         out.copy_(ho)
 
+    def gather(self, inp, gather_list, dst):
+        hl = [t.cpu() for t in gather_list] if gather_list is not None else None
+        self.dist.gather(inp.cpu(), hl, dst=dst)
+        if gather_list is not None:
+            for t, h in zip(gather_list, hl):
+                t.copy_(h)
+
     def barrier(self):
         self.dist.barrier()
 
@@ -63,6 +70,17 @@ def _worker(rank, world, port, case, ret):
                               ("H", ref.hessian(x, lam, sigma)), ("f", np.array([ref.objective(x)]))):
                 got = o[key].cpu().numpy()
                 err = max(err, float(np.max(np.abs(got - want)) / max(1.0, np.max(np.abs(want)))))
+        # gather mode (what bench.py --gpus N times): the complete outputs on rank 0 only
+        sev.full.zero_()
+        torch.cuda.synchronize()
+        o = sev.cycle(dx, dlam, sigma, hd, root=0)
+        torch.cuda.synchronize()
+        keys = ("grad", "g", "J", "H", "f") if rank == 0 else ("f",)
+        want = dict(grad=ref.gradient(x), g=ref.constraints(x), J=ref.jacobian(x), H=ref.hessian(x, lam, sigma),
+                    f=np.array([ref.objective(x)]))
+        for key in keys:
+            got = o[key].cpu().numpy()
+            err = max(err, float(np.max(np.abs(got - want[key])) / max(1.0, np.max(np.abs(want[key])))))
         flag = torch.tensor([err])
         dist.all_reduce(flag, op=dist.ReduceOp.MAX)
         if rank == 0:

@@ -10,6 +10,7 @@ import os
 import socket
 
 import numpy as np
+import pytest
 import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
@@ -17,7 +18,7 @@ import torch.multiprocessing as mp
 import models
 
 
-def _worker(rank, world, port, ret):
+def _worker(rank, world, port, ret, root=None):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -45,8 +46,15 @@ def _worker(rank, world, port, ret):
     full = torch.from_numpy(mine.copy())
     small = torch.zeros(1 + len(shared), dtype=torch.float64)
     small[0] = 1.0 + rank                           # stands for a partial integral
-    re.exchange(full, small, dist)
+    re.exchange(full, small, dist, root)
     got = full.numpy()[:-1]
+    if root is not None and rank != root:            # gather mode: the other ranks keep their own slices + the sums
+        keep = np.zeros(len(truth), dtype=bool)
+        for a, b in runs[rank]:
+            keep[a:b] = True
+        keep[shared] = True
+        assert np.all(np.isnan(got[~keep]))
+        got, truth = got[keep], truth[keep]
     ok = bool(np.array_equal(got, truth) or np.allclose(got, truth, rtol=0, atol=1e-15 * np.abs(truth).max()))
     ok &= bool(abs(float(small[0]) - 3.0) < 1e-15)  # integrals summed over the two ranks
     flag = torch.tensor([1.0 if ok else 0.0])
@@ -56,13 +64,15 @@ def _worker(rank, world, port, ret):
     dist.destroy_process_group()
 
 
-def test_two_rank_sharding_reassembles_exactly():
+@pytest.mark.parametrize("root", [None, 0, 1])
+def test_two_rank_sharding_reassembles_exactly(root):
+    """root None: all-gather, every rank complete; root r: gather to rank r (what bench.py --gpus N times)."""
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
     ctx = mp.get_context("spawn")
     ret = ctx.SimpleQueue()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, ret)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, ret, root)) for r in range(2)]
     for p in procs:
         p.start()
     for p in procs:
