@@ -109,6 +109,33 @@ def cpu_baseline(name, intervals, budget_s=12.0, max_cycles=5000):
 EVENT_PERIOD = 64
 
 
+class HostStagedDist:
+    """The collectives of the sharded cycle on CUDA tensors through a CPU (gloo) process group: lets the N > 1 code path
+    of this script be rehearsed with several ranks on ONE GPU (RCCL refuses two ranks on one device)."""
+
+    def __init__(self, dist):
+        self.dist = dist
+
+    def all_reduce(self, t, op=None):
+        h = t.cpu()
+        self.dist.all_reduce(h) if op is None else self.dist.all_reduce(h, op=op)
+        t.copy_(h)
+
+    def all_gather_into_tensor(self, out, inp):
+        ho = out.cpu()
+        self.dist.all_gather_into_tensor(ho, inp.cpu())
+        out.copy_(ho)
+
+    def gather(self, inp, gather_list, dst):
+        hl = [t.cpu() for t in gather_list] if gather_list is not None else None
+        self.dist.gather(inp.cpu(), hl, dst=dst)
+        for t, h in zip(gather_list or [], hl or []):
+            t.copy_(h)
+
+    def __getattr__(self, name):          # barrier, ReduceOp, destroy_process_group, ...
+        return getattr(self.dist, name)
+
+
 def run_gpu(name, intervals, steps, warmup, rank, world, dist, time_kernel=None):
     """Returns dict(ms_per_step, kernel timings, plan facts) for one workload on this rank."""
     import torch
@@ -149,8 +176,8 @@ def run_gpu(name, intervals, steps, warmup, rank, world, dist, time_kernel=None)
             sev.cycle(dx, dlam, sigma, dist, root=0)      # triplets reassembled on rank 0, where the NLP solver runs
 
     B = algorithmic_bytes(plan)
-    fused = world == 1 and not (plan.needs_I_grad or plan.needs_I_con or plan.jac.needs_I or plan.hess.needs_I)
-    if fused and os.environ.get("POCKIT_AMD_CYCLE_MODE", "1") == "0":      # A/B: the two-launch form of the cycle
+    fused = not (plan.needs_I_grad or plan.needs_I_con or plan.jac.needs_I or plan.hess.needs_I)
+    if fused and world == 1 and os.environ.get("POCKIT_AMD_CYCLE_MODE", "1") == "0":   # A/B: the two-launch form
         ev.set_cycle_mode(False)
         dominant = "pk_xall" if B["xall"] >= B["hess"] else "pk_hess"
     elif fused:
@@ -266,13 +293,16 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU path in pockit_amd)")
-    torch.cuda.set_device(local_rank)
+    torch.cuda.set_device(local_rank % torch.cuda.device_count())
     dist = None
     if world > 1:
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world)
+        backend = os.environ.get("POCKIT_AMD_BENCH_BACKEND", "nccl")
+        dist.init_process_group(backend, rank=rank, world_size=world)
+        if backend != "nccl":       # rehearsal of the N > 1 path on a box with fewer GPUs than ranks (not a measurement)
+            dist = HostStagedDist(dist)
     n_gpus = world
 
     intervals = args.intervals * n_gpus          # weak scaling: per-GPU share stays args.intervals
@@ -291,7 +321,8 @@ def main():
         # launch duration plus the gap to the next launch -- an upper bound of the kernel's own duration that costs
         # the loop nothing.  (The per-dispatch events of every 64th launch go through hipExtModuleLaunchKernel, whose
         # own overhead shows up inside the pair: they read ~1 us more than rocprofv3 for the same kernel.)
-        dom_us = res["region_us_per_step"] if res["dominant"] == "pk_cycle" else sampled_us
+        # (N > 1: the region also holds the exchange, so the kernel's own figure is the sampled one)
+        dom_us = res["region_us_per_step"] if res["dominant"] == "pk_cycle" and n_gpus == 1 else sampled_us
         achieved = dom_bytes / (dom_us * 1e-6) / 1e9 if dom_us else None
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
@@ -320,13 +351,13 @@ def main():
                          "unit": "GB/s", "frac": (achieved / HBM_PEAK_GBPS if achieved else None), "traffic": traffic,
                          "algorithmic_bytes_per_launch": dom_bytes,
                          "algorithmic_bytes_per_launch_x_counted_once": (res["bytes"]["cycle_x_once"] / n_gpus
-                                                                         if res["dominant"] == "pk_cycle" else None),
+                                                                         if res["dominant"] == "pk_cycle" and n_gpus == 1 else None),
                          "avg_launch_us": dom_us,
                          "sampled_dispatch_us": sampled_us,
                          "timing": ("one HIP event pair on the launch stream around the timed region / steps "
                                     "(launch duration + gap to the next launch); sampled_dispatch_us: per-dispatch "
                                     f"events on every {EVENT_PERIOD}th launch of the same region"
-                                    if res["dominant"] == "pk_cycle" else
+                                    if res["dominant"] == "pk_cycle" and n_gpus == 1 else
                                     f"HIP events on the launch stream, every {EVENT_PERIOD}th launch of the timed region")},
             "kernel_us": res["kernel_us"],
             "cycle_algorithmic_bytes": res["bytes"]["cycle"],

@@ -23,7 +23,7 @@ from .transcription import SystemPlan
 TARGET_TILES = int(os.environ.get("POCKIT_AMD_TARGET_TILES", "384"))
 
 
-def _intervals_per_wave(plan, override=None):
+def _intervals_per_wave(plan, override=None, shards=1):
     """Intervals per wavefront: as few as keeps ~TARGET_TILES tiles (x 3 wave roles in the single-launch
     cycle) in flight, up to 64 nodes per wave (Layout.tiles caps it).  Measured on MI355X with pk_cycle
     (tools/ipw_sweep.sh): at 12k nodes the cycle is bound by the number of vector-memory
@@ -36,7 +36,7 @@ def _intervals_per_wave(plan, override=None):
     if env:
         return int(env)
     n_int = sum(pp.layout.N for pp in plan.phase_plans)
-    return max(1, math.ceil(n_int / TARGET_TILES))
+    return max(1, math.ceil(n_int / (TARGET_TILES * max(1, int(shards)))))      # (a shard holds 1 / shards of the tiles)
 
 
 class Tables:

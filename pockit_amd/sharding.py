@@ -152,12 +152,14 @@ class ShardedEvaluator:
         import torch
 
         from .codegen import ModelSource
-        from .evaluator import Evaluator, Tables
+        from .evaluator import Evaluator, Tables, _intervals_per_wave
 
         self.torch, self.rank, self.world, self.plan = torch, rank, world, plan
         if world > 1 and plan.outer:
             raise NotImplementedError("objectives / system constraints nonlinear in the integrals (outer-product "
                                       "Hessian blocks) are evaluated on one GPU only; they are O(n^2) and small")
+        if intervals_per_wave is None:          # the tiling is sized for ONE shard's share of the mesh
+            intervals_per_wave = _intervals_per_wave(plan, shards=world)
         self.ev = Evaluator(plan, device=device, intervals_per_wave=intervals_per_wave,
                             tile_filter=tile_filter(rank, world) if world > 1 else None)
         dev = torch.device("cuda", device)
