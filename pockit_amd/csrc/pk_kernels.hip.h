@@ -1485,7 +1485,7 @@ __device__ __forceinline__ void fin_handoff(const PkArgs& A) {
   __shared__ int ridx[NR];
   const int t = threadIdx.x, wave = t >> 6;
   if (t < PK_NPHASE) dts[t] = Gen::phase_dt(t, A);
-  if (t >= 128 && t - 128 < A.n_s && t - 128 < PK_NS) ssh[t - 128] = A.x[A.l_s + t - 128];
+  for (int i = t; i < A.n_s && i < PK_NS; i += PK_BLOCK) ssh[i] = A.x[A.l_s + i];
   const int gz0 = t < A.n_gz ? A.ib[A.gz_off + t] : -1;
 #pragma unroll
   for (int row = 0; row < Gen::N_ROWS; ++row)
