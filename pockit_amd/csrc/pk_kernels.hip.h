@@ -209,7 +209,7 @@ __device__ __forceinline__ double wave_sum(double v) {
 // DESIGN.md section 5 measured at +6 us).  Forward progress: the publishers never wait for anything, the poller
 // occupies one workgroup slot; the poll is bounded (PK_POLL_LIMIT), after which the slot reads as NaN and the
 // launch ends with NaN in f / the gradient slots instead of hanging.
-#define PK_POLL_LIMIT (1 << 17)
+#define PK_POLL_LIMIT (1 << 24)     // poll rounds of >= 0.5 us each: several seconds, far beyond any launch's duration
 __device__ __forceinline__ void handoff_put(unsigned long long* slot, double v) {
   unsigned long long b = (unsigned long long)__double_as_longlong(v);
   if (b == PK_EMPTY) b = 0x7FF8000000000000ull;     // (a NaN either way)

@@ -412,6 +412,45 @@ def test_single_launch_cycle_equals_two_launch_cycle_bit_for_bit(case, split, mo
     close(single["H"], ref.hessian(x, lam, sigma), what="H")
 
 
+def test_single_launch_cycle_on_a_mesh_with_more_workgroups_than_the_chip_holds():
+    """360k nodes: ~5000 workgroups, more than are resident at once -- the finalize workgroup of pk_cycle polls
+    while tile workgroups are still waiting to be dispatched.  Must equal the two-launch cycle bit for bit and the
+    oracle within tolerance."""
+    import torch
+
+    kw = dict(mesh=60000, num_point=6)
+    system, _, guess = models.planar_quadrotor(_ns("radau", "pockit_amd"), **kw)
+    plan, ev = system.plan, system.evaluator
+    assert len(ev.tables.tiles) > 4096
+    x, lam, sigma = models.bench_inputs(system, guess)
+    dev = torch.device("cuda", 0)
+    dx, dlam = torch.from_numpy(x).to(dev), torch.from_numpy(lam).to(dev)
+    sizes = (("f", 1), ("grad", plan.n), ("g", plan.m), ("J", plan.nnz_J), ("H", plan.nnz_H))
+
+    def run():
+        o = {k: torch.full((n,), float("nan"), dtype=torch.float64, device=dev) for k, n in sizes}
+        torch.cuda.synchronize()
+        for _ in range(2):
+            ev.cycle_dev(dx.data_ptr(), dlam.data_ptr(), sigma, *[o[k].data_ptr() for k, _ in sizes])
+        ev.sync()
+        return {k: v.cpu().numpy() for k, v in o.items()}
+
+    single = run()
+    ev.set_cycle_mode(False)
+    try:
+        two = run()
+    finally:
+        ev.set_cycle_mode(True)
+    for k, _ in sizes:
+        assert np.array_equal(single[k], two[k]), k
+    ref, _, _ = models.planar_quadrotor(_ns("radau", "oracle"), **kw)
+    close(single["f"][0], ref.objective(x), what="f")
+    close(single["grad"], ref.gradient(x), what="grad")
+    close(single["g"], ref.constraints(x), what="g")
+    close(single["J"], ref.jacobian(x), what="J")
+    system._invalidate()
+
+
 def test_single_launch_cycle_hand_off_survives_back_to_back_launches():
     """The hand-off slots of pk_cycle are emptied by the launch that consumed them: 600 cycles enqueued back to
     back on alternating iterates, every launch writing f and grad f to its own slot, must each reproduce the value
