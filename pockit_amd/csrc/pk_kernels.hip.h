@@ -1180,7 +1180,7 @@ __device__ __forceinline__ void kernel_aux(const PkArgs& A) {
 // dynamics are evaluated there, and the two sides of the integral-form collocation equation on the
 // augmented rule are written out:  T_aug x  and  dt (I_aug d/2) f.  The host compares them per
 // interval (np.allclose semantics) and runs the hp-refinement logic (pockit_amd/refine.py).
-// LDS per wave: (2 NX + NU) x 64 doubles.  Barriers are unconditional; loads/stores are predicated.
+// LDS per wave: (2 NX + NU) x 64 doubles, private to the wave (no workgroup barrier between the three steps).
 template <class P>
 __device__ __forceinline__ void interval_err(const PkArgs& A, const PkErrIv& iv, bool valid,
                                              double* __restrict__ lds, int lane) {
@@ -1213,7 +1213,7 @@ __device__ __forceinline__ void interval_err(const PkArgs& A, const PkErrIv& iv,
 #pragma unroll
     for (int i = 0; i < P::NU; ++i) us[i * PK_WAVE + lane] = up[i * ph.L_m + iv.lm + lane];
   }
-  __syncthreads();
+  wave_lds_sync();       // (a wave stages for itself only)
   if (valid && lane < na) {
     double a[P::NARG], o[P::G_NOUT];
 #pragma unroll
@@ -1238,7 +1238,7 @@ __device__ __forceinline__ void interval_err(const PkArgs& A, const PkErrIv& iv,
 #pragma unroll
     for (int i = 0; i < P::NX; ++i) fs[i * PK_WAVE + lane] = o[i];
   }
-  __syncthreads();
+  wave_lds_sync();       // (a wave stages for itself only)
   if (valid && lane < nr) {
     double tx[P::NX], itf[P::NX];
 #pragma unroll
@@ -1256,8 +1256,8 @@ __device__ __forceinline__ void interval_err(const PkArgs& A, const PkErrIv& iv,
 #pragma unroll
     for (int i = 0; i < P::NX; ++i) {
       const int64_t pos = iv.out_off + (int64_t)i * iv.rows + iv.row0 + lane;
-      A.o_errT[pos] = tx[i];
-      A.o_errI[pos] = itf[i] * dt;
+      put(&A.o_errT[pos], tx[i]);
+      put(&A.o_errI[pos], itf[i] * dt);
     }
   }
 }
