@@ -209,6 +209,19 @@ def run_gpu(name, intervals, steps, warmup, rank, world, dist, time_kernel=None)
     prof = ev.profile_read()
     ev.profile(0)
     launches, total_ms = prof[time_kernel or dominant]
+    # N > 1: the same loop without the exchange (every rank keeps its slices), to separate the kernels from the collectives
+    no_exchange_elapsed = None
+    if world > 1 and fused:
+        cargs = (h, ptr(dx), ptr(dlam), C.c_double(float(sigma)), ptr(o["f"]), ptr(o["grad"]), ptr(o["g"]), ptr(o["J"]),
+                 ptr(o["H"]), st)
+        torch.cuda.synchronize()
+        dist.barrier()
+        t1 = time.perf_counter()
+        for _ in range(steps):
+            lib.pk_eval_cycle_dev(*cargs)
+        stream.synchronize()
+        dist.barrier()
+        no_exchange_elapsed = time.perf_counter() - t1
     # per-kernel event timing of every kernel, outside the timed region (diagnostic)
     ev.profile(0x1FFF)
     for _ in range(min(steps, 50)):
@@ -268,7 +281,7 @@ def run_gpu(name, intervals, steps, warmup, rank, world, dist, time_kernel=None)
                n=plan.n, m=plan.m, nnz_J=plan.nnz_J, nnz_H=plan.nnz_H, elapsed=elapsed, steps=steps,
                ms_per_step=elapsed / steps * 1e3, setup_s=setup_s, bytes=B, dominant=dominant,
                dominant_us=(total_ms / launches * 1e3 if launches else None), kernel_us=allk, finite=finite,
-               region_us_per_step=region_us / steps,
+               region_us_per_step=region_us / steps, no_exchange_elapsed=no_exchange_elapsed,
                tiles=int(len(ev.tables.tiles)), ipw=int(ev.tables.intervals_per_wave), compact=compact,
                mesh_err=mesh_err, csr=csr)
     ev.close()
@@ -359,6 +372,10 @@ def main():
                                     f"events on every {EVENT_PERIOD}th launch of the same region"
                                     if res["dominant"] == "pk_cycle" and n_gpus == 1 else
                                     f"HIP events on the launch stream, every {EVENT_PERIOD}th launch of the timed region")},
+            "kernels_only_without_exchange": (None if res["no_exchange_elapsed"] is None else {
+                "value": n_gpus * args.steps / res["no_exchange_elapsed"], "unit": "12k-node-equivalent cycles/s",
+                "note": "rank 0's clock around the same number of per-rank pk_cycle launches with no collective "
+                        "(every rank keeps its own slices of grad/g/J/H)"}),
             "kernel_us": res["kernel_us"],
             "cycle_algorithmic_bytes": res["bytes"]["cycle"],
             "setup_s": res["setup_s"],
