@@ -341,7 +341,7 @@ class ModelSource:
             S.append("#define PK_TRACE 1")
         if os.environ.get("POCKIT_AMD_XCD_REMAP", "1") == "0":       # A/B switch of the XCD-aware block mapping
             S.append("#define PK_XCD_REMAP 0")
-        if os.environ.get("POCKIT_AMD_NT", "") in ("0", "1", "2", "3"):   # A/B switch of the output store flavour
+        if os.environ.get("POCKIT_AMD_NT", "") in ("0", "1", "2", "3", "4"):   # A/B switch of the output store flavour
             S.append(f"#define PK_NT_STORES {os.environ['POCKIT_AMD_NT']}")
         S.append('#include "pk_kernels.hip.h"')
         S.append("namespace pkgen {")

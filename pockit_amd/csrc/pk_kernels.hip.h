@@ -170,6 +170,8 @@ __device__ __forceinline__ void put(double* __restrict__ p, double v) {
   __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 #elif PK_NT_STORES == 3      // system-scope store (sc0 sc1)
   __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+#elif PK_NT_STORES == 4      // the same sc1 store instruction, but not an atomic to the compiler (no ordering of other memory ops)
+  asm volatile("global_store_dwordx2 %0, %1, off sc1" : : "v"(p), "v"(v));
 #else
   *p = v;
 #endif
@@ -444,36 +446,59 @@ __device__ __forceinline__ void stream_loop(const PkArgs& A, const PkPhase& ph, 
   for (int e = 0; e < NI; ++e) run[e] = out + (bases[e] + tl.offI);
   const int nnz = tl.nnzI;
   const int tot = tl.nj * nnz;
+  if (STAGED) {
+    // Two positions per lane and loop iteration, and ALL LDS reads of the pair before its first store: the output
+    // stores are agent-scope atomics (put), which the compiler keeps every other memory operation behind -- written
+    // store by store, each ds_read waited for its predecessor's store (8 exposed LDS latencies per iteration in the
+    // ISA).  (Segment-major order -- each segment's stores of 256 positions back to back -- was measured slower.)
+    constexpr int U = NI <= 12 ? 2 : 1;
+    for (uint32_t p0 = lane; p0 < (uint32_t)tot; p0 += U * PK_WAVE) {
+      double v[U][NI > 0 ? NI : 1];
+      bool ok[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const uint32_t p = p0 + u * PK_WAVE;
+        ok[u] = p < (uint32_t)tot;
+        const uint32_t pc = ok[u] ? p : p0;
+        const int jj = (int)__umulhi(pc, tl.magicI);   // p / nnz (p < 2^16)
+        const int t = (int)pc - jj * nnz;
+        const int rc = T.rc[t];
+        const double val = -(T.iv[t] * T.wd[jj] * 0.5);
+        const double* __restrict__ col = sv + jj * g.stride + (rc >> 16);
+        const double* __restrict__ lam = lam_s + jj * g.R + (rc & 0xFFFF);
+#pragma unroll
+        for (int e = 0; e < NI; ++e)
+          v[u][e] = HESS ? val * lam[P::H_state(e) * PK_WAVE] * col[e * PK_WAVE] : val * col[e * PK_WAVE];
+      }
+#ifdef PK_TRACE
+      if (A.flags & 131072) {    // tracing builds only: the loop without its stores (lookups and products kept alive)
+        double acc = 0.0;
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+#pragma unroll
+          for (int e = 0; e < NI; ++e) acc += v[u][e];
+        asm volatile("" ::"v"(acc));
+        continue;
+      }
+#endif
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        if (!ok[u]) continue;
+#pragma unroll
+        for (int e = 0; e < NI; ++e) put(&run[e][p0 + u * PK_WAVE], v[u][e]);
+      }
+    }
+    return;
+  }
   const int32_t* __restrict__ rcg = A.ib + tl.irc_off;
   const double* __restrict__ ivg = A.db + tl.iv_off;
   const double* __restrict__ wdg = A.db + ph.width_off + tl.j0;
-  // (segment-major order -- each segment's stores of 256 positions back to back -- was measured slower: 2.1 vs 1.6 us)
-#pragma unroll 2
   for (uint32_t p = lane; p < (uint32_t)tot; p += PK_WAVE) {
     const int jj = (int)__umulhi(p, tl.magicI);   // p / nnz (p < 2^16)
     const int t = (int)p - jj * nnz;
-    int r, c;
-    double val;
-    if (STAGED) {
-      const int rc = T.rc[t];
-      r = rc & 0xFFFF;
-      c = rc >> 16;
-      val = -(T.iv[t] * T.wd[jj] * 0.5);
-    } else {
-      r = rcg[2 * t];
-      c = rcg[2 * t + 1];
-      val = -(ivg[t] * wdg[jj] * 0.5);
-    }
+    const int r = rcg[2 * t], c = rcg[2 * t + 1];
+    const double val = -(ivg[t] * wdg[jj] * 0.5);
     const double* __restrict__ col = sv + jj * g.stride + c;
-#ifdef PK_TRACE
-    if (A.flags & 131072) {      // tracing builds only: the loop without its stores (lookups and products kept alive)
-      double acc = 0.0;
-#pragma unroll
-      for (int e = 0; e < NI; ++e) acc += val * col[e * PK_WAVE] * (HESS ? lam_s[P::H_state(e) * PK_WAVE + jj * g.R + r] : 1.0);
-      asm volatile("" ::"v"(acc));
-      continue;
-    }
-#endif
     if (HESS) {
       const double* __restrict__ lam = lam_s + jj * g.R + r;
 #pragma unroll
