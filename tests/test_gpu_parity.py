@@ -371,7 +371,9 @@ def test_cycle_graph_replay_gives_identical_results():
 @pytest.mark.parametrize("case", [("planar_quadrotor", "radau", dict(mesh=301, num_point=6)),
                                   ("two_stage_rocket", "radau", dict(mesh=150, num_point=4)),
                                   ("brachistochrone", "lobatto", dict(mesh=1100, num_point=5)),
-                                  ("humanoid_wbc", "radau", dict(mesh=260, num_point=8))])
+                                  ("humanoid_wbc", "radau", dict(mesh=260, num_point=8)),
+                                  ("lqr", "lobatto", dict(mesh=10, num_point=10)),       # objective depends on a static parameter
+                                  ("lqr", "radau", dict(mesh=7, num_point=12))])         # tables read from global memory (K > 8)
 @pytest.mark.parametrize("split", ["1", "0"])
 def test_single_launch_cycle_equals_two_launch_cycle_bit_for_bit(case, split, monkeypatch):
     """pk_cycle (x-kernel, Hessian and finalize workgroups in ONE launch, partial sums handed over inside the
