@@ -123,26 +123,47 @@ class Reassembler:
     def exchange(self, full, small, dist, root=None):
         """``full``: packed buffer of length total + 1 (last element is scratch); ``small``: the small
         reduction buffer [integrals | shared gradient slots] (already filled with this rank's partials).
-        One tiny all-reduce + one all-gather; afterwards ``full`` is complete on every rank.
+        One tiny all-reduce + one all-gather; afterwards ``full`` and ``small`` are complete on every rank.
 
-        ``root = r``: gather to rank r instead -- the triplets are reassembled where the (host-side) NLP solver runs,
-        every other rank keeps its own slices (+ the reduced sums).  Rank r then receives (N - 1) packs over its N - 1
-        direct xGMI links at once, whereas the all-gather moves N (N - 1) packs through the same links."""
+        ``root = r``: ONE gather to rank r instead -- the triplets are reassembled where the (host-side) NLP solver
+        runs.  Rank r receives (N - 1) packs over its N - 1 direct xGMI links at once, whereas the all-gather moves
+        N (N - 1) packs through the same links; the small partial sums travel at the end of every pack and are added
+        on rank r in rank order (no second, latency-bound collective).  The other ranks keep their own slices and
+        their own partial sums."""
         n_sh = self.shared_idx.numel()
         if n_sh:
             small[-n_sh:] = full.index_select(0, self.shared_idx)
-        dist.all_reduce(small)
-        send = full.index_select(0, self.own_idx)
         if root is None:
+            dist.all_reduce(small)
+            send = full.index_select(0, self.own_idx)
             dist.all_gather_into_tensor(self.recv, send)
             full.index_copy_(0, self.all_idx, self.recv)
-        elif self.rank == root:
-            dist.gather(send, [self.recv[r * self.pad: (r + 1) * self.pad] for r in range(self.world)], dst=root)
-            full.index_copy_(0, self.all_idx, self.recv)
         else:
-            dist.gather(send, None, dst=root)
+            self._gather_to(full, small, dist, root)
+            if self.rank != root:
+                return
         if n_sh:
             full.index_copy_(0, self.shared_idx, small[-n_sh:])
+
+    def _gather_to(self, full, small, dist, root):
+        torch, n_sm, row = self.torch, small.numel(), self.pad + small.numel()
+        if getattr(self, "_send", None) is None or self._send.numel() != row:
+            self._send = torch.empty(row, dtype=full.dtype, device=full.device)
+            if self.rank == root:
+                self._rows = torch.empty(self.world * row, dtype=full.dtype, device=full.device)
+                tail = torch.full((n_sm,), self.total, dtype=torch.int64, device=full.device)   # -> the scratch element
+                self._rows_idx = torch.cat([torch.cat([self.all_idx[r * self.pad: (r + 1) * self.pad], tail])
+                                            for r in range(self.world)])
+        torch.index_select(full, 0, self.own_idx, out=self._send[: self.pad])
+        self._send[self.pad:] = small
+        if self.rank != root:
+            dist.gather(self._send, None, dst=root)
+            return
+        dist.gather(self._send, [self._rows[r * row: (r + 1) * row] for r in range(self.world)], dst=root)
+        full.index_copy_(0, self._rows_idx, self._rows)
+        small.copy_(self._rows[self.pad: row])
+        for r in range(1, self.world):                       # fixed order: reproducible sums
+            small.add_(self._rows[r * row + self.pad: (r + 1) * row])
 
 
 class ShardedEvaluator:
@@ -229,5 +250,6 @@ class ShardedEvaluator:
                 self.I.copy_(keep)
             else:
                 self.re.exchange(self.full, self.small, dist, root)
-        chk(lib.pk_eval_f_from_integrals_dev(h, px, C.c_void_p(o["f"].data_ptr()), st))
+        if root is None or root == self.rank or not sharded:     # (gather mode: only the root holds the reduced integrals)
+            chk(lib.pk_eval_f_from_integrals_dev(h, px, C.c_void_p(o["f"].data_ptr()), st))
         return o

@@ -75,7 +75,7 @@ def _worker(rank, world, port, case, ret):
         torch.cuda.synchronize()
         o = sev.cycle(dx, dlam, sigma, hd, root=0)
         torch.cuda.synchronize()
-        keys = ("grad", "g", "J", "H", "f") if rank == 0 else ("f",)
+        keys = ("grad", "g", "J", "H", "f") if rank == 0 else ()      # (the other ranks keep slices and partial sums)
         want = dict(grad=ref.gradient(x), g=ref.constraints(x), J=ref.jacobian(x), H=ref.hessian(x, lam, sigma),
                     f=np.array([ref.objective(x)]))
         for key in keys:

@@ -48,15 +48,18 @@ def _worker(rank, world, port, ret, root=None):
     small[0] = 1.0 + rank                           # stands for a partial integral
     re.exchange(full, small, dist, root)
     got = full.numpy()[:-1]
-    if root is not None and rank != root:            # gather mode: the other ranks keep their own slices + the sums
+    if root is not None and rank != root:            # gather mode: the other ranks keep their own slices and partial sums
         keep = np.zeros(len(truth), dtype=bool)
         for a, b in runs[rank]:
             keep[a:b] = True
-        keep[shared] = True
-        assert np.all(np.isnan(got[~keep]))
+        rest = ~keep
+        rest[shared] = False
+        assert np.all(np.isnan(got[rest]))
+        assert np.array_equal(got[shared], truth[shared] * share)
         got, truth = got[keep], truth[keep]
     ok = bool(np.array_equal(got, truth) or np.allclose(got, truth, rtol=0, atol=1e-15 * np.abs(truth).max()))
-    ok &= bool(abs(float(small[0]) - 3.0) < 1e-15)  # integrals summed over the two ranks
+    if root is None or rank == root:
+        ok &= bool(abs(float(small[0]) - 3.0) < 1e-15)  # integrals summed over the two ranks
     flag = torch.tensor([1.0 if ok else 0.0])
     dist.all_reduce(flag, op=dist.ReduceOp.MIN)
     if rank == 0:
