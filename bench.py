@@ -172,8 +172,18 @@ def run_gpu(name, intervals, steps, warmup, rank, world, dist, time_kernel=None)
                 ev.ctx.check(rc)
         ev.ctx.check(lib.pk_set_shard(h, 0, 0, None))
     else:
+        exchange = {"root": None if os.environ.get("POCKIT_AMD_BENCH_EXCHANGE") == "allgather" else 0}
+
         def step():
-            sev.cycle(dx, dlam, sigma, dist, root=0)      # triplets reassembled on rank 0, where the NLP solver runs
+            sev.cycle(dx, dlam, sigma, dist, root=exchange["root"])   # root 0: triplets reassembled where the solver runs
+
+        if exchange["root"] is not None:
+            try:                                       # one untimed cycle: a backend without gather falls back to all-gather
+                step()
+                torch.cuda.synchronize()
+            except (RuntimeError, NotImplementedError) as exc:
+                print(f"[bench] gather-to-root exchange not available ({exc!r}); using the all-gather form", file=sys.stderr)
+                exchange["root"] = None
 
     B = algorithmic_bytes(plan)
     fused = not (plan.needs_I_grad or plan.needs_I_con or plan.jac.needs_I or plan.hess.needs_I)
@@ -282,6 +292,7 @@ def run_gpu(name, intervals, steps, warmup, rank, world, dist, time_kernel=None)
                ms_per_step=elapsed / steps * 1e3, setup_s=setup_s, bytes=B, dominant=dominant,
                dominant_us=(total_ms / launches * 1e3 if launches else None), kernel_us=allk, finite=finite,
                region_us_per_step=region_us / steps, no_exchange_elapsed=no_exchange_elapsed,
+               exchange=("single GPU" if world == 1 else "gather to rank 0" if exchange["root"] == 0 else "all-gather"),
                tiles=int(len(ev.tables.tiles)), ipw=int(ev.tables.intervals_per_wave), compact=compact,
                mesh_err=mesh_err, csr=csr)
     ev.close()
@@ -356,8 +367,8 @@ def main():
                                    f" points ({res['nodes']} nodes; n={res['n']}, m={res['m']}, nnz_J={res['nnz_J']}, "
                                    f"nnz_H={res['nnz_H']})",
                        "sharding": "single GPU" if n_gpus == 1 else f"mesh intervals over {n_gpus} GPUs, one pk_cycle launch per "
-                                                                    f"rank, RCCL gather of the owned runs of grad/g/J/H "
-                                                                    f"to rank 0 (the solver's rank) + tiny all-reduce",
+                                                                    f"rank, RCCL {res['exchange']} of the owned runs of grad/g/J/H "
+                                                                    f"(+ the partial sums)",
                        "tiles": res["tiles"], "intervals_per_wave": res["ipw"],
                        "inputs": "example guess*(1+1e-3 U(-1,1)) seed 0; lambda N(0,1) seed 1; sigma 1"},
             "roofline": {"bound": "hbm", "kernel": res["dominant"], "achieved": achieved, "peak": HBM_PEAK_GBPS,
