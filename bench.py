@@ -109,33 +109,6 @@ def cpu_baseline(name, intervals, budget_s=12.0, max_cycles=5000):
 EVENT_PERIOD = 64
 
 
-class HostStagedDist:
-    """The collectives of the sharded cycle on CUDA tensors through a CPU (gloo) process group: lets the N > 1 code path
-    of this script be rehearsed with several ranks on ONE GPU (RCCL refuses two ranks on one device)."""
-
-    def __init__(self, dist):
-        self.dist = dist
-
-    def all_reduce(self, t, op=None):
-        h = t.cpu()
-        self.dist.all_reduce(h) if op is None else self.dist.all_reduce(h, op=op)
-        t.copy_(h)
-
-    def all_gather_into_tensor(self, out, inp):
-        ho = out.cpu()
-        self.dist.all_gather_into_tensor(ho, inp.cpu())
-        out.copy_(ho)
-
-    def gather(self, inp, gather_list, dst):
-        hl = [t.cpu() for t in gather_list] if gather_list is not None else None
-        self.dist.gather(inp.cpu(), hl, dst=dst)
-        for t, h in zip(gather_list or [], hl or []):
-            t.copy_(h)
-
-    def __getattr__(self, name):          # barrier, ReduceOp, destroy_process_group, ...
-        return getattr(self.dist, name)
-
-
 def run_gpu(name, intervals, steps, warmup, rank, world, dist, time_kernel=None):
     """Returns dict(ms_per_step, kernel timings, plan facts) for one workload on this rank."""
     import torch
@@ -326,7 +299,9 @@ def main():
         backend = os.environ.get("POCKIT_AMD_BENCH_BACKEND", "nccl")
         dist.init_process_group(backend, rank=rank, world_size=world)
         if backend != "nccl":       # rehearsal of the N > 1 path on a box with fewer GPUs than ranks (not a measurement)
-            dist = HostStagedDist(dist)
+            from pockit_amd.sharding import HostStagedCollectives
+
+            dist = HostStagedCollectives(dist)
     n_gpus = world
 
     intervals = args.intervals * n_gpus          # weak scaling: per-GPU share stays args.intervals

@@ -166,6 +166,34 @@ class Reassembler:
             small.add_(self._rows[r * row + self.pad: (r + 1) * row])
 
 
+class HostStagedCollectives:
+    """The collectives of the sharded cycle on CUDA tensors through a CPU (gloo) process group.  RCCL refuses two ranks
+    on one device; this adapter lets the N > 1 code path run with several ranks on ONE GPU (tests, rehearsals of
+    ``bench.py --gpus N``) -- it is not a measurement path."""
+
+    def __init__(self, dist):
+        self.dist = dist
+
+    def all_reduce(self, t, op=None):
+        h = t.cpu()
+        self.dist.all_reduce(h) if op is None else self.dist.all_reduce(h, op=op)
+        t.copy_(h)
+
+    def all_gather_into_tensor(self, out, inp):
+        ho = out.cpu()
+        self.dist.all_gather_into_tensor(ho, inp.cpu())
+        out.copy_(ho)
+
+    def gather(self, inp, gather_list, dst):
+        hl = [t.cpu() for t in gather_list] if gather_list is not None else None
+        self.dist.gather(inp.cpu(), hl, dst=dst)
+        for t, h in zip(gather_list or [], hl or []):
+            t.copy_(h)
+
+    def __getattr__(self, name):          # barrier, ReduceOp, destroy_process_group, ...
+        return getattr(self.dist, name)
+
+
 class ShardedEvaluator:
     """Rank-local evaluator + collectives.  ``dist`` is an initialised torch.distributed module."""
 

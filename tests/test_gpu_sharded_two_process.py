@@ -1,6 +1,6 @@
 """Two real processes run pockit_amd.sharding.ShardedEvaluator.cycle -- the exact code `bench.py --gpus N` runs
 per rank -- on one MI355X (both ranks on GPU 0; RCCL refuses two ranks on one device, so the two collectives go
-through gloo with a host-staged adapter).  Every rank must end up with the complete, oracle-equal outputs."""
+through gloo with the host-staged adapter of pockit_amd.sharding).  Every rank must end up with the complete, oracle-equal outputs."""
 import os
 import socket
 
@@ -10,33 +10,6 @@ import pytest
 import models
 
 pytestmark = pytest.mark.gpu
-
-
-class HostStagedDist:
-    """The two collectives the sharded cycle uses, on CUDA tensors through a gloo (CPU) process group."""
-
-    def __init__(self, dist):
-        self.dist = dist
-
-    def all_reduce(self, t):
-        h = t.cpu()
-        self.dist.all_reduce(h)
-        t.copy_(h)
-
-    def all_gather_into_tensor(self, out, inp):
-        ho, hi = out.cpu(), inp.cpu()
-        self.dist.all_gather_into_tensor(ho, hi)
-        out.copy_(ho)
-
-    def gather(self, inp, gather_list, dst):
-        hl = [t.cpu() for t in gather_list] if gather_list is not None else None
-        self.dist.gather(inp.cpu(), hl, dst=dst)
-        if gather_list is not None:
-            for t, h in zip(gather_list, hl):
-                t.copy_(h)
-
-    def barrier(self):
-        self.dist.barrier()
 
 
 def _worker(rank, world, port, case, ret):
@@ -49,7 +22,7 @@ def _worker(rank, world, port, case, ret):
     try:
         import importlib
 
-        from pockit_amd.sharding import ShardedEvaluator
+        from pockit_amd.sharding import HostStagedCollectives, ShardedEvaluator
 
         name, scheme, kw = case
         builder = getattr(models, name)
@@ -60,7 +33,7 @@ def _worker(rank, world, port, case, ret):
         torch.cuda.set_device(dev)
         sev = ShardedEvaluator(system.plan, rank, world, device=0, intervals_per_wave=2)
         dx, dlam = torch.from_numpy(x).to(dev), torch.from_numpy(lam).to(dev)
-        hd = HostStagedDist(dist)
+        hd = HostStagedCollectives(dist)
         err = 0.0
         for rep in range(2):                       # twice: buffers are reused between cycles
             torch.cuda.synchronize()
