@@ -162,6 +162,9 @@ __device__ __forceinline__ int xcd_tile_block(int wg, int first, int total) {
 #ifndef PK_NT_STORES
 #define PK_NT_STORES 2
 #endif
+#ifndef PK_WIDE_STORES
+#define PK_WIDE_STORES 1      // streaming loop: two consecutive positions per lane, one 16-byte store per segment
+#endif
 
 __device__ __forceinline__ void put(double* __restrict__ p, double v) {
 #if PK_NT_STORES == 1
@@ -446,6 +449,42 @@ __device__ __forceinline__ void stream_loop(const PkArgs& A, const PkPhase& ph, 
   for (int e = 0; e < NI; ++e) run[e] = out + (bases[e] + tl.offI);
   const int nnz = tl.nnzI;
   const int tot = tl.nj * nnz;
+#if PK_WIDE_STORES
+  if (STAGED) {
+    // A lane takes two CONSECUTIVE positions and writes them with one 16-byte store per segment (the same sc1
+    // flavour as put()): half the store instructions of the 8-byte variant below -- humanoid 5000x8 +2.3 %,
+    // brachistochrone 1250x8 +3 %, quadrotor 2000x6 +0..8 % (POCKIT_AMD_WIDE_STORES=0 compiles the variant below).
+    // All LDS reads of the pair come before its first store (stores are ordered against every other memory operation).
+    typedef double pk_d2 __attribute__((ext_vector_type(2)));
+    for (uint32_t p0 = 2 * lane; p0 < (uint32_t)tot; p0 += 2 * PK_WAVE) {
+      double v[2][NI > 0 ? NI : 1];
+      const bool pair = p0 + 1 < (uint32_t)tot;
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const uint32_t pc = (u == 0 || pair) ? p0 + u : p0;
+        const int jj = (int)__umulhi(pc, tl.magicI);
+        const int t = (int)pc - jj * nnz;
+        const int rc = T.rc[t];
+        const double val = -(T.iv[t] * T.wd[jj] * 0.5);
+        const double* __restrict__ col = sv + jj * g.stride + (rc >> 16);
+        const double* __restrict__ lam = lam_s + jj * g.R + (rc & 0xFFFF);
+#pragma unroll
+        for (int e = 0; e < NI; ++e)
+          v[u][e] = HESS ? val * lam[P::H_state(e) * PK_WAVE] * col[e * PK_WAVE] : val * col[e * PK_WAVE];
+      }
+#pragma unroll
+      for (int e = 0; e < NI; ++e) {
+        if (pair) {
+          const pk_d2 w = {v[0][e], v[1][e]};
+          asm volatile("global_store_dwordx4 %0, %1, off sc1" : : "v"(&run[e][p0]), "v"(w));
+        } else {
+          put(&run[e][p0], v[0][e]);
+        }
+      }
+    }
+    return;
+  }
+#endif
   if (STAGED) {
     // Two positions per lane and loop iteration, and ALL LDS reads of the pair before its first store: the output
     // stores are agent-scope atomics (put), which the compiler keeps every other memory operation behind -- written
