@@ -13,8 +13,8 @@
 //            64 entries each), the base offsets of its output segments (kept in a VGPR pair, lane e = segment e)
 //            and, for the Hessian, its rows of the multipliers;
 //   phase B  lane = output position: every I-expanded segment of the tile is a contiguous run of
-//            nj * K^2 doubles in the output array; the wave streams them out in 512-byte coalesced
-//            stores, reading staged values and tables from LDS only.  Phase B contains NO vector load (loads and
+//            nj * K^2 doubles in the output array; the wave streams them out in coalesced stores of 16 bytes
+//            per lane (two consecutive positions), reading staged values and tables from LDS only.  Phase B contains NO vector load (loads and
 //            stores share vmcnt and return out of order: one load would make every wait a wait for all stores)
 //            and needs no workgroup barrier (a wave stages for itself only).
 // The tile record is wave-uniform: it is read through the scalar cache into SGPRs (readfirstlane +
