@@ -373,6 +373,8 @@ class ModelSource:
             S.append("#define PK_TRACE 1")
         if os.environ.get("POCKIT_AMD_XCD_REMAP", "1") == "0":       # A/B switch of the XCD-aware block mapping
             S.append("#define PK_XCD_REMAP 0")
+        if os.environ.get("POCKIT_AMD_POLL_SLEEP"):                  # A/B switch: pause between the finalize workgroup's polls
+            S.append(f"#define PK_POLL_SLEEP {int(os.environ['POCKIT_AMD_POLL_SLEEP'])}")
         if os.environ.get("POCKIT_AMD_WIDE_STORES", "1") == "0":     # A/B switch: 8-byte stores in the streaming loop
             S.append("#define PK_WIDE_STORES 0")
         if os.environ.get("POCKIT_AMD_NT", "") in ("0", "1", "2", "3", "4"):   # A/B switch of the output store flavour

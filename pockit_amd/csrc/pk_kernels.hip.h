@@ -214,6 +214,9 @@ __device__ __forceinline__ double wave_sum(double v) {
 // DESIGN.md section 5 measured at +6 us).  Forward progress: the publishers never wait for anything, the poller
 // occupies one workgroup slot; the poll is bounded (PK_POLL_LIMIT), after which the slot reads as NaN and the
 // launch ends with NaN in f / the gradient slots instead of hanging.
+#ifndef PK_POLL_SLEEP
+#define PK_POLL_SLEEP 4       // s_sleep between two poll rounds (x 64 cycles)
+#endif
 #define PK_POLL_LIMIT (1 << 24)     // poll rounds of >= 0.5 us each: several seconds, far beyond any launch's duration
 __device__ __forceinline__ void handoff_put(unsigned long long* slot, double v) {
   unsigned long long b = (unsigned long long)__double_as_longlong(v);
@@ -1581,7 +1584,7 @@ __device__ __forceinline__ void fin_handoff(const PkArgs& A) {
 #pragma unroll
       for (int row = 0; row < Gen::N_ROWS; ++row) empty |= bits[row] == PK_EMPTY;
       if (!empty) break;
-      __builtin_amdgcn_s_sleep(4);
+      __builtin_amdgcn_s_sleep(PK_POLL_SLEEP);
     }
 #pragma unroll
     for (int row = 0; row < Gen::N_ROWS; ++row)
