@@ -114,16 +114,36 @@ int pk_eval_hess(pk_ctx* ctx, const double* x, const double* lambda, double sigm
 int pk_eval_cycle(pk_ctx* ctx, const double* x, const double* lambda, double sigma, double* f, double* grad,
                   double* g, double* jac, double* hess);
 
-/* "new x" protocol for host shims (IPOPT calls f, grad f, g, J separately but on the same iterate):
- * pk_prepare_x uploads x once and runs the fused x-kernel; pk_fetch copies one result out
- * (what: 0 f, 1 grad[n], 2 g[m], 3 jac[nnz_J]); pk_eval_hess_prepared reuses the uploaded x. */
+/* "new x" protocol for host shims.  cyipopt calls objective / gradient / constraints / jacobian separately but on the
+ * same iterate, then hessian with fresh multipliers (the five methods ipopt.py:41-53 hands over as ``problem_obj``).
+ *   pk_same_x      1 if ``x`` equals the x of the last pk_prepare_x bit for bit (its results are still held)
+ *   pk_prepare_x   stages x in pinned memory, uploads it, runs the fused x-kernel (every node evaluated once for f,
+ *                  grad f, g, J) and queues the copies of the results into pinned host memory right behind it, in the
+ *                  order a solver asks for them -- nothing waits; x and lambda staging is double-buffered
+ *   pk_fetch       waits for ONE result (what: 0 f, 1 grad[n], 2 g[m], 3 jac[nnz_J]); out == NULL leaves it where it
+ *                  landed (pk_result_location), otherwise it is copied on to ``out``
+ *   pk_eval_hess_prepared   Hessian of the Lagrangian on the prepared x (x is not uploaded again)
+ *   pk_set_result_targets   where the results of the NEXT prepare / Hessian land: pinned memory of the caller
+ *                  (pk_host_alloc; a solver-side array that outlives the call), NULL = the context's own buffers
+ *   pk_set_host_mode        prefetch 1 (default): all four x-results are copied out behind the kernel; 0: f and g
+ *                  always, grad f and J on first request (a line search's rejected trial points never ask);
+ *                  host_direct 1: the kernels store into the pinned host targets themselves (no DMA; A/B switch)
+ *   pk_invalidate_x         forget the prepared x (the context's buffers were used by another entry point) */
+int pk_same_x(pk_ctx* ctx, const double* x);
 int pk_prepare_x(pk_ctx* ctx, const double* x);
 int pk_fetch(pk_ctx* ctx, int what, double* out);
 int pk_eval_hess_prepared(pk_ctx* ctx, const double* lambda, double sigma, double* vals);
-/* Pinned (page-locked) result buffers owned by the context: what = 0 f, 1 grad, 2 g, 3 jac, 4 hess.  Passing
- * out == NULL / vals == NULL to pk_fetch / pk_eval_hess_prepared leaves the result there: one DMA at full PCIe
- * rate and no second host copy.  The buffers are reused by the next call for the same output. */
+int pk_set_result_targets(pk_ctx* ctx, double* f, double* grad, double* g, double* jac, double* hess);
+int pk_result_location(pk_ctx* ctx, int what /* 0..4 */, double** ptr);
+int pk_set_host_mode(pk_ctx* ctx, int prefetch, int host_direct);
+int pk_invalidate_x(pk_ctx* ctx);
+/* Pinned (page-locked) result buffers owned by the context: what = 0 f, 1 grad, 2 g, 3 jac, 4 hess.  The default
+ * landing place of the results; reused by the next iterate. */
 int pk_host_buffer(pk_ctx* ctx, int what, double** ptr, int64_t* count);
+/* Pinned, device-visible host memory that is NOT tied to a context (result arrays handed to a solver may outlive the
+ * evaluator): DMA targets at full PCIe rate.  pk_last_error(NULL) holds the message of a failure. */
+int pk_host_alloc(size_t bytes, void** out);
+int pk_host_free(void* p);
 
 /* Compact Hessian of the Lagrangian: the reference repeats every dynamics entry for
  * each nonzero of the integration matrix (phasebase.py:923-928,1280-1285; 10-20x duplication); here lambda is

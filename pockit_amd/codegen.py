@@ -120,9 +120,10 @@ def _emit_body(outputs, base, names, indent="    "):
     _EMIT_MEMO[key] = text
     try:
         os.makedirs(_EMIT_DIR, exist_ok=True)
-        with open(path + ".tmp", "w") as fh:
+        staged = f"{path}.{os.getpid()}.part"     # (ranks that start cold together write the same bodies)
+        with open(staged, "w") as fh:
             fh.write(text)
-        os.replace(path + ".tmp", path)
+        os.replace(staged, path)
     except OSError:
         pass                                 # (read-only install: the in-memory memo still serves this process)
     return text

@@ -116,6 +116,9 @@ __device__ __forceinline__ void wave_lds_sync() {
 // same 128-byte lines where a run does not end on a line boundary).  Giving every XCD one contiguous range of
 // tile blocks lets its L2 merge those pieces into full lines before they are written back.  `first` workgroups
 // (boundary / finalize workgroups) keep their ids; returns the tile-block index of workgroup `wg`.
+// array extent for "one entry per phase": a system without phases (static parameters only,
+// tests/test_base/test_system_base.py:10-20 of the reference) still needs a non-empty array type
+#define PK_NPHASE_DIM (PK_NPHASE > 0 ? PK_NPHASE : 1)
 #define PK_XCDS 8
 #ifndef PK_XCD_REMAP
 #define PK_XCD_REMAP 1
@@ -134,6 +137,14 @@ __device__ __forceinline__ int xcd_tile_block(int wg, int first, int total) {
 // Developer tracing: PK_MARK(k) stores the constant-rate device clock (s_memrealtime: 100 MHz, the same on every XCD)
 // of lane 0 at checkpoint k of the wave's trace record.  Records: [tile][role 0 values / whole tile, 1 Jacobian,
 // 2 Hessian], then three for pk_cycle's boundary-J, boundary-H and finalize workgroups.
+// Diagnostic launch switches (POCKIT_AMD_DEBUG_FLAGS, tools/cycle_flags.sh: parts of a launch switched off to time the
+// rest) exist in developer builds only (models generated with POCKIT_AMD_TRACE=1): PK_DIAG is a compile-time false in
+// production code objects, so no kernel carries the tests.
+#ifdef PK_TRACE
+#define PK_DIAG(bits) ((A.flags & (bits)) != 0)
+#else
+#define PK_DIAG(bits) false
+#endif
 #ifdef PK_TRACE
 #define PK_TRACE_REC(role) const int pk_trec = tl.pad >= 0 ? tl.pad * 3 + (role) : -1
 #define PK_MARK_AT(rec, k)                                                                                   \
@@ -274,6 +285,15 @@ __device__ __forceinline__ void load_node(const PkArgs& A, const PkPhase& ph, co
   for (int i = 0; i < P::NS; ++i) a[P::NX + P::NU + 1 + i] = s[i];
 }
 
+// floor(p / d) for p < 2^16 from the host-computed magic number of d (PkTile.magic*): umulhi(p, ceil(2^32 / d)).
+// d == 1 has no 32-bit magic (2^32): the host stores 0 for it and the quotient is p itself -- one wave-uniform select
+// (scalar) and one v_and_or per division.  (Without it the tables of LGR K = 1 / LGL K = 2 tiles holding more than
+// one interval were indexed with jj = 0 for every position.)
+__device__ __forceinline__ int magic_div(uint32_t p, uint32_t magic) {
+  const uint32_t all = magic == 0u ? 0xFFFFFFFFu : 0u;
+  return (int)(__umulhi(p, magic) | (p & all));
+}
+
 struct TileGeom {
   int K, stride, R, nq, nown;
 };
@@ -311,7 +331,7 @@ struct TileTabs {
 };
 
 __device__ __forceinline__ bool tabs_fit(const PkArgs& A, const PkTile& tl, const TileGeom& g) {
-  return tl.nnzI <= PK_WAVE && g.R * g.K <= PK_WAVE && tl.nnzT <= PK_WAVE && !(A.flags & 4096);
+  return tl.nnzI <= PK_WAVE && g.R * g.K <= PK_WAVE && tl.nnzT <= PK_WAVE && !PK_DIAG(4096);
 }
 
 __device__ __forceinline__ TabRegs tabs_issue(const PkArgs& A, const PkPhase& ph, const PkTile& tl, const TileGeom& g,
@@ -347,7 +367,7 @@ __device__ __forceinline__ TileTabs tabs_commit(const TabRegs& t, bool fit, int 
 template <class P>
 __device__ __forceinline__ void defect_ends(const PkArgs& A, const PkPhase& ph, const PkTile& tl, const TileGeom& g,
                                             const double* a, double* xe, int lane) {
-  const int jj = min((int)__umulhi((uint32_t)lane, tl.magicR), max(tl.nj - 1, 0));
+  const int jj = min(magic_div((uint32_t)lane, tl.magicR), max(tl.nj - 1, 0));
   const int src = (jj + 1) * g.stride;
 #pragma unroll
   for (int i = 0; i < P::NX; ++i) xe[i] = __shfl(a[i], src & (PK_WAVE - 1), PK_WAVE);
@@ -381,7 +401,7 @@ __device__ __forceinline__ void write_defects(const PkArgs& A, const PkPhase& ph
                                               int lane) {
   const int nrows = tl.nj * g.R;
   if (lane >= nrows) return;
-  const int jj = (int)__umulhi((uint32_t)lane, tl.magicR), r = lane - jj * g.R;
+  const int jj = magic_div((uint32_t)lane, tl.magicR), r = lane - jj * g.R;
   const int endslot = tl.q0 + (jj + 1) * g.stride;
   const int back_slot = P::SCHEME ? ph.L_m - 1 : ph.L_m;
   const double* __restrict__ f = fsv + jj * g.stride;
@@ -430,7 +450,7 @@ __device__ __forceinline__ void write_translation(const PkArgs& A, const PkPhase
 #pragma unroll
   for (int i = 0; i < P::NX; ++i) run[i] = A.o_jac + (tbase[i] + tl.offT);
   for (uint32_t p = lane; p < (uint32_t)tot; p += PK_WAVE) {
-    const int t = (int)p - (int)__umulhi(p, tl.magicT) * tl.nnzT;
+    const int t = (int)p - magic_div(p, tl.magicT) * tl.nnzT;
     const double v = STAGED ? T.tv[t] : tvg[t];
 #pragma unroll
     for (int i = 0; i < P::NX; ++i) put(&run[i][p], v);
@@ -465,7 +485,7 @@ __device__ __forceinline__ void stream_loop(const PkArgs& A, const PkPhase& ph, 
 #pragma unroll
       for (int u = 0; u < 2; ++u) {
         const uint32_t pc = (u == 0 || pair) ? p0 + u : p0;
-        const int jj = (int)__umulhi(pc, tl.magicI);
+        const int jj = magic_div(pc, tl.magicI);
         const int t = (int)pc - jj * nnz;
         const int rc = T.rc[t];
         const double val = -(T.iv[t] * T.wd[jj] * 0.5);
@@ -502,7 +522,7 @@ __device__ __forceinline__ void stream_loop(const PkArgs& A, const PkPhase& ph, 
         const uint32_t p = p0 + u * PK_WAVE;
         ok[u] = p < (uint32_t)tot;
         const uint32_t pc = ok[u] ? p : p0;
-        const int jj = (int)__umulhi(pc, tl.magicI);   // p / nnz (p < 2^16)
+        const int jj = magic_div(pc, tl.magicI);   // p / nnz (p < 2^16)
         const int t = (int)pc - jj * nnz;
         const int rc = T.rc[t];
         const double val = -(T.iv[t] * T.wd[jj] * 0.5);
@@ -513,7 +533,7 @@ __device__ __forceinline__ void stream_loop(const PkArgs& A, const PkPhase& ph, 
           v[u][e] = HESS ? val * lam[P::H_state(e) * PK_WAVE] * col[e * PK_WAVE] : val * col[e * PK_WAVE];
       }
 #ifdef PK_TRACE
-      if (A.flags & 131072) {    // tracing builds only: the loop without its stores (lookups and products kept alive)
+      if (PK_DIAG(131072)) {    // tracing builds only: the loop without its stores (lookups and products kept alive)
         double acc = 0.0;
 #pragma unroll
         for (int u = 0; u < U; ++u)
@@ -536,7 +556,7 @@ __device__ __forceinline__ void stream_loop(const PkArgs& A, const PkPhase& ph, 
   const double* __restrict__ ivg = A.db + tl.iv_off;
   const double* __restrict__ wdg = A.db + ph.width_off + tl.j0;
   for (uint32_t p = lane; p < (uint32_t)tot; p += PK_WAVE) {
-    const int jj = (int)__umulhi(p, tl.magicI);   // p / nnz (p < 2^16)
+    const int jj = magic_div(p, tl.magicI);   // p / nnz (p < 2^16)
     const int t = (int)p - jj * nnz;
     const int r = rcg[2 * t], c = rcg[2 * t + 1];
     const double val = -(ivg[t] * wdg[jj] * 0.5);
@@ -804,15 +824,15 @@ __device__ __forceinline__ void xall_phase_b(const PkArgs& A, const PkPhase& ph,
                                              const double* xr, double* xe,
                                              const SegBases<P::J_NI + P::J_NN>& segb, const SegBases<P::NX>& tbase,
                                              int lane PK_TRACE_PARAM) {
-  if (ROLE != 2 && !(A.flags & 8192)) write_defects<P, STAGED>(A, ph, tl, g, T, s, dt, sv, xr, xe, lane);
+  if (ROLE != 2 && !PK_DIAG(8192)) write_defects<P, STAGED>(A, ph, tl, g, T, s, dt, sv, xr, xe, lane);
   PK_MARK(6);
   if (tl.nj == 0) return;
   // the constant translation entries of J go out with the VALUES wave: the Jacobian wave's streaming is the longest
   // chain of the launch (wave timeline), the values wave has ~1 us of slack after its defect rows
-  if (ROLE != 2 && !(A.flags & 16384)) write_translation<P, STAGED>(A, ph, tl, T, tbase, lane);
+  if (ROLE != 2 && !PK_DIAG(16384)) write_translation<P, STAGED>(A, ph, tl, T, tbase, lane);
   PK_MARK(7);
   if (ROLE == 1) return;
-  if (!(A.flags & 32768))
+  if (!PK_DIAG(32768))
     stream_expanded<P, P::J_NI, false, STAGED>(A, ph, tl, g, T, jsv, nullptr, segb, A.o_jac, lane);
 }
 
@@ -861,7 +881,7 @@ __device__ __forceinline__ void tile_xall(const PkArgs& A, const PkTile& tl, dou
 #pragma unroll
   for (int r = 0; r < P::GR_NR; ++r) orr[r] = 0.0;
   double og[P::G_NOUT], oj[P::J_NI + P::J_NN + 1], ov[P::NX + P::NU];
-  const bool live = lane < g.nq && !(A.flags & 512);   // (bit 9: diagnostic switch, skip the evaluation phase)
+  const bool live = lane < g.nq && !PK_DIAG(512);   // (bit 9: diagnostic switch, skip the evaluation phase)
   if (live) {
     double ot[P::GR_NR > 0 ? P::GR_NR : 1], op[P::INT_N > 0 ? P::INT_N : 1];
     PK_MARK(2);
@@ -926,7 +946,7 @@ __device__ __forceinline__ void tile_xall(const PkArgs& A, const PkTile& tl, dou
   PK_MARK(4);
   wave_lds_sync();
   PK_MARK(5);
-  if (A.flags & 256) return;   // diagnostic build switches: skip the phases after the staging (all / one by one)
+  if (PK_DIAG(256)) return;   // diagnostic build switches: skip the phases after the staging (all / one by one)
   PK_PHASE_B(T, (xall_phase_b<P, ROLE, STAGED>(A, ph, tl, g, T, s, dt, sv, jsv, xr, xe, segb, tbase, lane PK_TRACE_ARG)));
   PK_MARK(8);
 #ifdef PK_TRACE
@@ -1413,8 +1433,8 @@ __device__ __forceinline__ void kernel_outer(const PkArgs& A) {
 
 template <class Gen>
 __device__ __forceinline__ void kernel_xall(const PkArgs& A) {
-  if (A.flags & 1024) return;                                   // diagnostic switches (POCKIT_AMD_DEBUG_FLAGS)
-  if (PK_IS_EDGE_BLOCK() && (A.flags & 2048)) return;
+  if (PK_DIAG(1024)) return;                                   // diagnostic switches (POCKIT_AMD_DEBUG_FLAGS)
+  if (PK_IS_EDGE_BLOCK() && PK_DIAG(2048)) return;
   if (PK_IS_EDGE_BLOCK()) return edge_block<Gen>(A, 0, true, A.items, A.n_items);
   if (A.flags & 32) {   // split launch: workgroups 2b (Jacobian) and 2b + 1 (values) share tile block b
     const int slot = pk::xcd_tile_block((int)blockIdx.x, 1, (int)gridDim.x);
@@ -1455,8 +1475,8 @@ __device__ __forceinline__ void kernel_xall(const PkArgs& A) {
 template <class Gen>
 __device__ __forceinline__ void kernel_cycle(const PkTile* pre_tile, int pre_n_tiles, int pre_flags, int pre_grid,
                                              const PkArgs& A) {
-  if (blockIdx.x < 2 && (A.flags & 2048)) return;     // diagnostic switches (POCKIT_AMD_DEBUG_FLAGS): no boundary work,
-  if (blockIdx.x == 2 && (A.flags & 65536)) return;   // no finalize workgroup (the hand-off slots then stay filled)
+  if (blockIdx.x < 2 && PK_DIAG(2048)) return;     // diagnostic switches (POCKIT_AMD_DEBUG_FLAGS): no boundary work,
+  if (blockIdx.x == 2 && PK_DIAG(65536)) return;   // no finalize workgroup (the hand-off slots then stay filled)
   if (blockIdx.x < 3) {
     const int rec = A.n_tiles * 3 + (int)blockIdx.x;
     (void)rec;
@@ -1497,8 +1517,8 @@ __device__ __forceinline__ void kernel_cycle(const PkTile* pre_tile, int pre_n_t
 template <class Gen>
 __device__ __forceinline__ void fin_body(const PkArgs& A) {
   __shared__ double red[PK_WAVES_PER_BLOCK];
-  __shared__ double tot[PK_NPHASE * PK_NRED];
-  __shared__ double dts[PK_NPHASE];
+  __shared__ double tot[PK_NPHASE_DIM * PK_NRED];
+  __shared__ double dts[PK_NPHASE_DIM];
   if ((int)threadIdx.x < PK_NPHASE) dts[threadIdx.x] = Gen::phase_dt(threadIdx.x, A);   // one phase per thread
   if (A.flags & 16)                                                                       // dead / shared slots start at 0
     for (int z = threadIdx.x; z < A.n_gz; z += PK_BLOCK) A.o_grad[A.ib[A.gz_off + z]] = 0.0;
@@ -1547,7 +1567,7 @@ __device__ __forceinline__ void fin_handoff(const PkArgs& A) {
   __shared__ double tot[NR];
   __shared__ double Ish[PK_NI];
   __shared__ double gsh[PK_NS];
-  __shared__ double dts[PK_NPHASE];
+  __shared__ double dts[PK_NPHASE_DIM];
   __shared__ double ssh[PK_NS];                     // static parameters, fetched before the wait (F_o(I, s) reads them)
   __shared__ int ridx[NR];
   const int t = threadIdx.x, wave = t >> 6;

@@ -108,8 +108,20 @@ struct pk_ctx {
   std::vector<PkPhase> h_phases;
   std::vector<EventPair> free_events;
   std::vector<int32_t> jac_row, jac_col, hess_row, hess_col;
-  // pinned host staging (zero-copy results for host shims): x, lambda, f, grad, g, J, H
-  double *h_x = nullptr, *h_lam = nullptr, *h_out[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+  // pinned host staging of the host shim: x and lambda are double-buffered (the upload of iterate k + 1 does not wait
+  // for anything of iterate k), results land in h_out (f, grad, g, J, H) or in caller-supplied pinned targets
+  double *h_xs[2] = {nullptr, nullptr}, *h_lams[2] = {nullptr, nullptr};
+  hipEvent_t ev_xs[2] = {nullptr, nullptr}, ev_lams[2] = {nullptr, nullptr};   // upload k of the buffer has left it
+  int xbuf = 0, lambuf = 0;
+  double* h_x = nullptr;                   // the staging buffer holding the x of the last pk_prepare_x (pk_same_x)
+  bool x_valid = false;
+  double* h_out[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+  double* target[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};   // pk_set_result_targets (NULL: h_out[k])
+  double* landed[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};   // where result k of the current iterate went
+  hipEvent_t ev_out[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+  bool enq[5] = {false, false, false, false, false};                   // copy of result k is enqueued / done
+  int prefetch = 1;            // 1: every x-only result is copied out right behind the kernel; 0: on first request
+  int host_direct = 0;         // 1: the kernels store into the (pinned, device-visible) host targets themselves
   // profiling
   bool profiling = false;
   std::vector<EventPair> pending[K_COUNT];
@@ -157,12 +169,22 @@ void free_problem(pk_ctx* c) {
   release(c->d_x); release(c->d_lam); release(c->d_f); release(c->d_grad); release(c->d_g); release(c->d_J);
   release(c->d_H); release(c->d_I); release(c->d_partial); release(c->d_partial2);
   release(c->d_cpart); release(c->d_cpart2);
-  if (c->h_x) (void)hipHostFree(c->h_x);
-  if (c->h_lam) (void)hipHostFree(c->h_lam);
-  c->h_x = c->h_lam = nullptr;
-  for (auto& p : c->h_out) {
-    if (p) (void)hipHostFree(p);
-    p = nullptr;
+  for (int b = 0; b < 2; ++b) {
+    if (c->h_xs[b]) (void)hipHostFree(c->h_xs[b]);
+    if (c->h_lams[b]) (void)hipHostFree(c->h_lams[b]);
+    if (c->ev_xs[b]) (void)hipEventDestroy(c->ev_xs[b]);
+    if (c->ev_lams[b]) (void)hipEventDestroy(c->ev_lams[b]);
+    c->h_xs[b] = c->h_lams[b] = nullptr;
+    c->ev_xs[b] = c->ev_lams[b] = nullptr;
+  }
+  c->h_x = nullptr;
+  c->x_valid = false;
+  for (int k = 0; k < 5; ++k) {
+    if (c->h_out[k]) (void)hipHostFree(c->h_out[k]);
+    if (c->ev_out[k]) (void)hipEventDestroy(c->ev_out[k]);
+    c->h_out[k] = c->target[k] = c->landed[k] = nullptr;
+    c->ev_out[k] = nullptr;
+    c->enq[k] = false;
   }
   c->have_problem = false;
 }
@@ -298,6 +320,44 @@ hipStream_t pick(pk_ctx* c, void* stream) { return stream ? (hipStream_t)stream 
 
 }  // namespace
 
+// ---- helpers of the host shim (the "new x" protocol further down)
+namespace {
+
+size_t result_count(const pk_ctx* c, int what) {
+  const size_t cnt[5] = {1, (size_t)c->n, (size_t)c->m, (size_t)c->nnz_J, (size_t)c->nnz_H};
+  return cnt[what];
+}
+
+double* device_result(pk_ctx* c, int what) {
+  double* src[5] = {c->d_f, c->d_grad, c->d_g, c->d_J, c->d_H};
+  return src[what];
+}
+
+// queue the copy of result `what` of the current iterate (no-op when the kernels stored it into host memory themselves)
+int enqueue_result_copy(pk_ctx* c, int what) {
+  if (c->enq[what]) return 0;
+  if (!c->host_direct)
+    PK_HIP(c, hipMemcpyAsync(c->landed[what], device_result(c, what), sizeof(double) * result_count(c, what),
+                             hipMemcpyDeviceToHost, c->stream));
+  PK_HIP(c, hipEventRecord(c->ev_out[what], c->stream));
+  c->enq[what] = true;
+  return 0;
+}
+
+// stage `count` doubles in the next staging buffer of a double-buffered pair and queue their upload
+int stage_upload(pk_ctx* c, double* const bufs[2], hipEvent_t const evs[2], int& cur, const double* src, double* dst,
+                 size_t count, double** staged) {
+  cur ^= 1;
+  PK_HIP(c, hipEventSynchronize(evs[cur]));        // (the upload that used this buffer two iterates ago; long done)
+  std::memcpy(bufs[cur], src, sizeof(double) * count);
+  PK_HIP(c, hipMemcpyAsync(dst, bufs[cur], sizeof(double) * count, hipMemcpyHostToDevice, c->stream));
+  PK_HIP(c, hipEventRecord(evs[cur], c->stream));
+  if (staged) *staged = bufs[cur];
+  return 0;
+}
+
+}  // namespace
+
 extern "C" {
 
 int pk_device_count(void) {
@@ -414,10 +474,17 @@ int pk_set_problem(pk_ctx* c, const pk_problem_desc* pd) {
   }
   {
     const size_t cnt[5] = {1, (size_t)c->n, (size_t)c->m, (size_t)c->nnz_J, (size_t)c->nnz_H};
-    PK_HIP(c, hipHostMalloc((void**)&c->h_x, sizeof(double) * (size_t)(c->n ? c->n : 1), hipHostMallocDefault));
-    PK_HIP(c, hipHostMalloc((void**)&c->h_lam, sizeof(double) * (size_t)(c->m ? c->m : 1), hipHostMallocDefault));
-    for (int k = 0; k < 5; ++k)
+    for (int b = 0; b < 2; ++b) {
+      PK_HIP(c, hipHostMalloc((void**)&c->h_xs[b], sizeof(double) * (size_t)(c->n ? c->n : 1), hipHostMallocDefault));
+      PK_HIP(c, hipHostMalloc((void**)&c->h_lams[b], sizeof(double) * (size_t)(c->m ? c->m : 1), hipHostMallocDefault));
+      PK_HIP(c, hipEventCreateWithFlags(&c->ev_xs[b], hipEventDisableTiming));
+      PK_HIP(c, hipEventCreateWithFlags(&c->ev_lams[b], hipEventDisableTiming));
+    }
+    for (int k = 0; k < 5; ++k) {
       PK_HIP(c, hipHostMalloc((void**)&c->h_out[k], sizeof(double) * (cnt[k] ? cnt[k] : 1), hipHostMallocDefault));
+      PK_HIP(c, hipEventCreateWithFlags(&c->ev_out[k], hipEventDisableTiming));
+    }
+    c->xbuf = c->lambuf = 0;
   }
   auto keep = [](std::vector<int32_t>& v, const int32_t* src, int64_t cnt) {
     v.clear();
@@ -592,6 +659,7 @@ int pk_gather_csr_dev(pk_ctx* c, int which, const double* d_triplets, double* d_
 }
 
 int pk_eval_jac_csr_dev(pk_ctx* c, const double* d_x, double* d_csr, void* stream) {
+  if (c) c->x_valid = false;      // (the triplets pass through the context's J buffer)
   int rc = pk_eval_jac_dev(c, d_x, c ? c->d_J : nullptr, stream);
   return rc ? rc : pk_gather_csr_dev(c, 0, c->d_J, d_csr, stream);
 }
@@ -607,6 +675,7 @@ int pk_eval_jac_csr(pk_ctx* c, const double* x, double* vals) {
   if (!x || !vals) return fail(c, 60, "null host buffer");
   if (c->csr[0].n_unique == 0) return fail(c, 84, "pk_eval_jac_csr: call pk_set_csr_map first");
   PK_HIP(c, hipSetDevice(c->device));
+  c->x_valid = false;
   PK_HIP(c, hipMemcpyAsync(c->d_x, x, sizeof(double) * (size_t)c->n, hipMemcpyHostToDevice, c->stream));
   if ((rc = pk_eval_jac_csr_dev(c, c->d_x, c->csr[0].d_vals, nullptr))) return rc;
   PK_HIP(c, hipMemcpyAsync(vals, c->csr[0].d_vals, sizeof(double) * (size_t)c->csr[0].n_unique, hipMemcpyDeviceToHost, c->stream));
@@ -620,6 +689,7 @@ int pk_eval_hess_csr(pk_ctx* c, const double* x, const double* lambda, double si
   if (!x || !lambda || !vals) return fail(c, 60, "null host buffer");
   if (c->csr[1].n_unique == 0) return fail(c, 84, "pk_eval_hess_csr: call pk_set_csr_map first");
   PK_HIP(c, hipSetDevice(c->device));
+  c->x_valid = false;
   PK_HIP(c, hipMemcpyAsync(c->d_x, x, sizeof(double) * (size_t)c->n, hipMemcpyHostToDevice, c->stream));
   PK_HIP(c, hipMemcpyAsync(c->d_lam, lambda, sizeof(double) * (size_t)c->m, hipMemcpyHostToDevice, c->stream));
   if ((rc = pk_eval_hess_csr_dev(c, c->d_x, c->d_lam, sigma, c->csr[1].d_vals, nullptr))) return rc;
@@ -687,6 +757,7 @@ int pk_eval_mesh_error(pk_ctx* c, const double* x, double* T, double* I) {
   if (rc) return rc;
   if (!x || !T || !I) return fail(c, 60, "null host buffer");
   PK_HIP(c, hipSetDevice(c->device));
+  c->x_valid = false;
   PK_HIP(c, hipMemcpyAsync(c->d_x, x, sizeof(double) * (size_t)c->n, hipMemcpyHostToDevice, c->stream));
   if ((rc = pk_eval_mesh_error_dev(c, c->d_x, c->d_errT, c->d_errI, nullptr))) return rc;
   PK_HIP(c, hipMemcpyAsync(T, c->d_errT, sizeof(double) * (size_t)c->n_err_out, hipMemcpyDeviceToHost, c->stream));
@@ -700,6 +771,7 @@ int pk_eval_hessc(pk_ctx* c, const double* x, const double* lambda, double sigma
   if (rc) return rc;
   if (!x || !lambda || !vals) return fail(c, 60, "null host buffer");
   PK_HIP(c, hipSetDevice(c->device));
+  c->x_valid = false;
   PK_HIP(c, hipMemcpyAsync(c->d_x, x, sizeof(double) * (size_t)c->n, hipMemcpyHostToDevice, c->stream));
   PK_HIP(c, hipMemcpyAsync(c->d_lam, lambda, sizeof(double) * (size_t)c->m, hipMemcpyHostToDevice, c->stream));
   if ((rc = pk_eval_hessc_dev(c, c->d_x, c->d_lam, sigma, c->d_Hc, nullptr))) return rc;
@@ -779,6 +851,7 @@ int pk_sync(pk_ctx* c, void* stream) {
   if (rc) return rc;                                                                                        \
   if (!x || !(OUT)) return fail(c, 60, "null host buffer");                                                 \
   PK_HIP(c, hipSetDevice(c->device));                                                                       \
+  c->x_valid = false; /* the context's x and result buffers now hold another evaluation */                  \
   PK_HIP(c, hipMemcpyAsync(c->d_x, x, sizeof(double) * (size_t)c->n, hipMemcpyHostToDevice, c->stream));    \
   IN_COPY;                                                                                                  \
   if ((rc = (CALL))) return rc;                                                                             \
@@ -810,8 +883,9 @@ int pk_eval_cycle(pk_ctx* c, const double* x, const double* lambda, double sigma
   if (rc) return rc;
   if (!x || !lambda || !f || !grad || !g || !jac || !hess) return fail(c, 60, "null host buffer");
   PK_HIP(c, hipSetDevice(c->device));
-  PK_HIP(c, hipMemcpyAsync(c->d_x, x, sizeof(double) * (size_t)c->n, hipMemcpyHostToDevice, c->stream));
-  PK_HIP(c, hipMemcpyAsync(c->d_lam, lambda, sizeof(double) * (size_t)c->m, hipMemcpyHostToDevice, c->stream));
+  c->x_valid = false;
+  if ((rc = stage_upload(c, c->h_xs, c->ev_xs, c->xbuf, x, c->d_x, (size_t)c->n, nullptr))) return rc;
+  if ((rc = stage_upload(c, c->h_lams, c->ev_lams, c->lambuf, lambda, c->d_lam, (size_t)c->m, nullptr))) return rc;
   if ((rc = pk_eval_cycle_dev(c, c->d_x, c->d_lam, sigma, c->d_f, c->d_grad, c->d_g, c->d_J, c->d_H, nullptr))) return rc;
   PK_HIP(c, hipMemcpyAsync(f, c->d_f, sizeof(double), hipMemcpyDeviceToHost, c->stream));
   PK_HIP(c, hipMemcpyAsync(grad, c->d_grad, sizeof(double) * (size_t)c->n, hipMemcpyDeviceToHost, c->stream));
@@ -822,60 +896,143 @@ int pk_eval_cycle(pk_ctx* c, const double* x, const double* lambda, double sigma
   return 0;
 }
 
-// "new x" protocol of the host shim: one upload + one fused launch serves objective, gradient, constraints and
-// Jacobian of the same x (IPOPT evaluates them separately but on the same iterate); pk_fetch copies one out.
+// ---------------------------------------------------------------- host shim: the "new x" protocol
+// IPOPT evaluates f, grad f, g, J separately but on the same iterate (ipopt.py:41-53 hands the five methods of the
+// problem object to cyipopt): pk_prepare_x uploads a new x ONCE, runs the fused x-kernel and -- prefetch mode -- queues
+// the copy of every result into pinned host memory right behind it, in the order a solver asks for them; pk_fetch then
+// only waits for the event of its result.  Nothing in here synchronizes the stream: the staging buffers of x and lambda
+// are double-buffered and guarded by events, the results by one event each.
+// 1 if x equals the x of the last pk_prepare_x bit for bit (the results held for it are still valid), else 0
+int pk_same_x(pk_ctx* c, const double* x) {
+  if (!c || !c->have_problem || !x || !c->x_valid || !c->h_x) return 0;
+  return std::memcmp(c->h_x, x, sizeof(double) * (size_t)c->n) == 0 ? 1 : 0;
+}
+
+// the context's x / result buffers were used for something else (mesh error, one-shot evals, the cycle call)
+int pk_invalidate_x(pk_ctx* c) {
+  if (!c) return fail(nullptr, 1, "null context");
+  c->x_valid = false;
+  return 0;
+}
+
+// Where the results of the NEXT pk_prepare_x / pk_eval_hess_prepared land: pinned host memory of the caller (from
+// pk_host_alloc), NULL = the context's own pinned buffer of that output (pk_host_buffer).
+int pk_set_result_targets(pk_ctx* c, double* f, double* grad, double* g, double* jac, double* hess) {
+  int rc = ready(c);
+  if (rc) return rc;
+  double* t[5] = {f, grad, g, jac, hess};
+  for (int k = 0; k < 5; ++k) c->target[k] = t[k];
+  return 0;
+}
+
+// prefetch = 1 (default): every x-only result is copied to the host right behind the kernel; 0: a result is copied
+// when it is first asked for (a request for the gradient also queues the Jacobian -- a solver wants both at an accepted
+// point, and neither at a rejected trial point).  host_direct = 1: the kernels store f / grad / g / J (and H) straight
+// into the pinned host targets over PCIe, no device-side staging and no DMA (A/B switch).
+int pk_set_host_mode(pk_ctx* c, int prefetch, int host_direct) {
+  if (!c) return fail(nullptr, 1, "null context");
+  c->prefetch = prefetch ? 1 : 0;
+  c->host_direct = host_direct ? 1 : 0;
+  c->x_valid = false;
+  return 0;
+}
+
+// Pinned (page-locked, device-visible) host memory for result arrays that outlive a call: process-wide, not tied to a
+// context (a host array handed to the solver may outlive the evaluator that filled it).
+int pk_host_alloc(size_t bytes, void** out) {
+  if (!out) return fail(nullptr, 60, "null host buffer");
+  *out = nullptr;
+  hipError_t e = hipHostMalloc(out, bytes ? bytes : 8, hipHostMallocDefault);
+  if (e != hipSuccess) return fail(nullptr, 100 + (int)e, "hipHostMalloc(%zu) failed: %s", bytes, hipGetErrorString(e));
+  return 0;
+}
+
+int pk_host_free(void* p) {
+  if (!p) return 0;
+  hipError_t e = hipHostFree(p);
+  if (e != hipSuccess) return fail(nullptr, 100 + (int)e, "hipHostFree failed: %s", hipGetErrorString(e));
+  return 0;
+}
+
 int pk_prepare_x(pk_ctx* c, const double* x) {
   int rc = ready(c);
   if (rc) return rc;
   if (!x) return fail(c, 60, "null host buffer");
   PK_HIP(c, hipSetDevice(c->device));
-  PK_HIP(c, hipStreamSynchronize(c->stream));              // the previous upload must have left the staging buffer
-  std::memcpy(c->h_x, x, sizeof(double) * (size_t)c->n);
-  PK_HIP(c, hipMemcpyAsync(c->d_x, c->h_x, sizeof(double) * (size_t)c->n, hipMemcpyHostToDevice, c->stream));
+  c->x_valid = false;
+  if ((rc = stage_upload(c, c->h_xs, c->ev_xs, c->xbuf, x, c->d_x, (size_t)c->n, &c->h_x))) return rc;
+  for (int k = 0; k < 5; ++k) {
+    c->landed[k] = c->target[k] ? c->target[k] : c->h_out[k];
+    c->enq[k] = false;
+  }
+  double* o[4];
+  for (int k = 0; k < 4; ++k) o[k] = c->host_direct ? c->landed[k] : device_result(c, k);
   const bool needs_I = c->md.prepass_grad || c->md.prepass_g || c->md.prepass_jac || c->md.prepass_hess;
   if (needs_I || c->external_prepass || c->shard_flags) {
-    if ((rc = pk_eval_f_dev(c, c->d_x, c->d_f, nullptr))) return rc;
-    if ((rc = pk_eval_grad_dev(c, c->d_x, c->d_grad, nullptr))) return rc;
-    if ((rc = pk_eval_g_dev(c, c->d_x, c->d_g, nullptr))) return rc;
-    return pk_eval_jac_dev(c, c->d_x, c->d_J, nullptr);
+    if ((rc = pk_eval_f_dev(c, c->d_x, o[0], nullptr))) return rc;
+    if ((rc = pk_eval_grad_dev(c, c->d_x, o[1], nullptr))) return rc;
+    if ((rc = pk_eval_g_dev(c, c->d_x, o[2], nullptr))) return rc;
+    if ((rc = pk_eval_jac_dev(c, c->d_x, o[3], nullptr))) return rc;
+  } else {
+    PkArgs A = base_args(c, c->d_x, nullptr, 0.0);
+    A.o_f = o[0]; A.o_grad = o[1]; A.o_g = o[2]; A.o_jac = o[3];
+    A.items = (const PkItem*)c->d_items_jac;
+    A.n_items = c->n_items_jac;
+    size_t lds = sizeof(double) * PK_WAVES_PER_BLOCK * (size_t)c->md.lds_x;
+    if (lds < sizeof(double) * (size_t)c->md.ne_j) lds = sizeof(double) * (size_t)c->md.ne_j;
+    A.flags |= xall_flags(c);
+    if ((rc = launch(c, K_XALL, A, xall_blocks(c), lds, c->stream))) return rc;
+    A.flags |= F_FIN_INT | F_WRITE_F | F_FIN_GRAD;
+    if ((rc = launch(c, K_FIN, A, 1, 0, c->stream))) return rc;
   }
-  PkArgs A = base_args(c, c->d_x, nullptr, 0.0);
-  A.o_f = c->d_f; A.o_grad = c->d_grad; A.o_g = c->d_g; A.o_jac = c->d_J;
-  A.items = (const PkItem*)c->d_items_jac;
-  A.n_items = c->n_items_jac;
-  size_t lds = sizeof(double) * PK_WAVES_PER_BLOCK * (size_t)c->md.lds_x;
-  if (lds < sizeof(double) * (size_t)c->md.ne_j) lds = sizeof(double) * (size_t)c->md.ne_j;
-  A.flags |= xall_flags(c);
-  if ((rc = launch(c, K_XALL, A, xall_blocks(c), lds, c->stream))) return rc;
-  A.flags |= F_FIN_INT | F_WRITE_F | F_FIN_GRAD;
-  return launch(c, K_FIN, A, 1, 0, c->stream);
-}
-
-int pk_fetch(pk_ctx* c, int what, double* out) {
-  int rc = ready(c);
-  if (rc) return rc;
-  const double* src[4] = {c->d_f, c->d_grad, c->d_g, c->d_J};
-  const size_t cnt[4] = {1, (size_t)c->n, (size_t)c->m, (size_t)c->nnz_J};
-  if (what < 0 || what > 3) return fail(c, 61, "pk_fetch: what must be 0 (f), 1 (grad), 2 (g) or 3 (jac)");
-  // out == NULL: leave the result in the context's pinned buffer (pk_host_buffer), no second copy
-  PK_HIP(c, hipMemcpyAsync(out ? out : c->h_out[what], src[what], sizeof(double) * cnt[what], hipMemcpyDeviceToHost,
-                           c->stream));
-  PK_HIP(c, hipStreamSynchronize(c->stream));
+  // f and g are what a line search asks for at every trial point: always on their way; grad f and J in prefetch mode
+  if ((rc = enqueue_result_copy(c, 0))) return rc;
+  if (c->prefetch && (rc = enqueue_result_copy(c, 1))) return rc;
+  if ((rc = enqueue_result_copy(c, 2))) return rc;
+  if (c->prefetch && (rc = enqueue_result_copy(c, 3))) return rc;
+  c->x_valid = true;
   return 0;
 }
 
-// Hessian on the x of the last pk_prepare_x (no re-upload of x); vals == NULL: result stays in the pinned buffer
+// result `what` (0 f, 1 grad, 2 g, 3 jac) of the last pk_prepare_x: waits for its copy.  out == NULL: the result stays
+// where it landed (pk_result_location); otherwise it is copied on to `out` (a second host copy).
+int pk_fetch(pk_ctx* c, int what, double* out) {
+  int rc = ready(c);
+  if (rc) return rc;
+  if (what < 0 || what > 3) return fail(c, 61, "pk_fetch: what must be 0 (f), 1 (grad), 2 (g) or 3 (jac)");
+  if (!c->x_valid) return fail(c, 64, "pk_fetch: no prepared x (pk_prepare_x)");
+  if (!c->enq[what]) {
+    if ((rc = enqueue_result_copy(c, what))) return rc;
+    if (what == 1 && (rc = enqueue_result_copy(c, 3))) return rc;      // an accepted point: J follows grad f
+  }
+  PK_HIP(c, hipEventSynchronize(c->ev_out[what]));
+  if (out && out != c->landed[what]) std::memcpy(out, c->landed[what], sizeof(double) * result_count(c, what));
+  return 0;
+}
+
+// Hessian on the x of the last pk_prepare_x (no re-upload of x); vals == NULL: the result stays where it landed
 int pk_eval_hess_prepared(pk_ctx* c, const double* lambda, double sigma, double* vals) {
   int rc = ready(c);
   if (rc) return rc;
   if (!lambda) return fail(c, 60, "null host buffer");
-  PK_HIP(c, hipStreamSynchronize(c->stream));
-  std::memcpy(c->h_lam, lambda, sizeof(double) * (size_t)c->m);
-  PK_HIP(c, hipMemcpyAsync(c->d_lam, c->h_lam, sizeof(double) * (size_t)c->m, hipMemcpyHostToDevice, c->stream));
-  if ((rc = pk_eval_hess_dev(c, c->d_x, c->d_lam, sigma, c->d_H, nullptr))) return rc;
-  PK_HIP(c, hipMemcpyAsync(vals ? vals : c->h_out[4], c->d_H, sizeof(double) * (size_t)c->nnz_H, hipMemcpyDeviceToHost,
-                           c->stream));
-  PK_HIP(c, hipStreamSynchronize(c->stream));
+  if (!c->x_valid) return fail(c, 64, "pk_eval_hess_prepared: no prepared x (pk_prepare_x)");
+  PK_HIP(c, hipSetDevice(c->device));
+  if ((rc = stage_upload(c, c->h_lams, c->ev_lams, c->lambuf, lambda, c->d_lam, (size_t)c->m, nullptr))) return rc;
+  c->landed[4] = c->target[4] ? c->target[4] : c->h_out[4];
+  c->enq[4] = false;
+  if ((rc = pk_eval_hess_dev(c, c->d_x, c->d_lam, sigma, c->host_direct ? c->landed[4] : c->d_H, nullptr))) return rc;
+  if ((rc = enqueue_result_copy(c, 4))) return rc;
+  PK_HIP(c, hipEventSynchronize(c->ev_out[4]));
+  if (vals && vals != c->landed[4]) std::memcpy(vals, c->landed[4], sizeof(double) * (size_t)c->nnz_H);
+  return 0;
+}
+
+// where result `what` (0..4) of the current iterate landed (valid after its pk_fetch / pk_eval_hess_prepared)
+int pk_result_location(pk_ctx* c, int what, double** ptr) {
+  int rc = ready(c);
+  if (rc) return rc;
+  if (what < 0 || what > 4 || !ptr) return fail(c, 62, "pk_result_location: bad arguments");
+  *ptr = c->landed[what] ? c->landed[what] : c->h_out[what];
   return 0;
 }
 

@@ -39,6 +39,20 @@ def _intervals_per_wave(plan, override=None, shards=1):
     return max(1, math.ceil(n_int / (TARGET_TILES * max(1, int(shards)))))      # (a shard holds 1 / shards of the tiles)
 
 
+def magic_number(d: int) -> int:
+    """32-bit magic of the divisor ``d`` for the kernels' ``magic_div`` (pk_kernels.hip.h):
+    ``p // d == (p * magic) >> 32`` for ``p < 2**16`` with ``magic = ceil(2**32 / d)``.  ``d == 1`` has no 32-bit magic
+    (2**32): it is encoded as 0 and the kernel returns ``p`` itself; ``d == 0`` (nothing to divide) is 0 as well."""
+    if d <= 1:
+        return 0
+    return (0xFFFFFFFF // d + 1) & 0xFFFFFFFF
+
+
+def magic_div(p: int, magic: int) -> int:
+    """Host model of the device function of the same name (used by the tests)."""
+    return p if magic == 0 else (p * magic) >> 32
+
+
 class Tables:
     """Mesh-dependent tables of a plan in the layout of csrc/pk_abi.h (host NumPy arrays).
 
@@ -109,7 +123,7 @@ class Tables:
                 rec["full_off"] = kinds[kind0 + kidf]["full_off"]
                 R = int(kinds[kind0 + kidf]["R"])
                 for field, d in (("magicI", int(rec["nnzI"])), ("magicR", R), ("magicT", int(rec["nnzT"]))):
-                    rec[field] = (0xFFFFFFFF // d + 1) & 0xFFFFFFFF if d > 0 else 0
+                    rec[field] = magic_number(d)
                 tiles.append(rec)
             while len(tiles) % runtime.WAVES_PER_BLOCK:      # a workgroup never mixes phases: pad with empty tiles
                 rec = np.zeros((), dtype=runtime.TILE_DTYPE)
@@ -151,12 +165,12 @@ class Tables:
 class Evaluator:
     def __init__(self, plan: SystemPlan, device: int = 0, intervals_per_wave=None, tile_filter=None):
         self.plan = plan
-        if not plan.phase_plans:
-            raise NotImplementedError("systems without phases have no GPU work; not supported by the HIP evaluator")
         self.src = ModelSource(plan)
+        # (compiled before the context is created: a box without a GPU -- the build container -- can still fill the
+        # code-object cache by constructing evaluators, tools/warm_cache.sh)
+        code = hipbuild.compile_model(self.src.source, fastmath=plan.system._fastmath)
         self.ctx = runtime.Context(device)            # raises RuntimeError without a GPU
         lib, h = self.ctx.lib, self.ctx.handle
-        code = hipbuild.compile_model(self.src.source, fastmath=plan.system._fastmath)
         md = runtime.ModelDesc()
         md.n_phase, md.n_I, md.nred = self.src.nphase, max(len(plan.I_syms), 1), self.src.nred
         md.lds_g, md.lds_j, md.lds_h, md.lds_x = self.src.lds_g, self.src.lds_j, self.src.lds_h, self.src.lds_x
@@ -172,8 +186,8 @@ class Evaluator:
         md.prepass_jac = int(plan.jac.needs_I)
         md.prepass_hess = int(plan.hess.needs_I)
         self._code = code
-        self._x_cached = None
         self._views = {}
+        self._ring, self._own, self._handed = None, {}, set()
         self.zero_copy = False   # True: callbacks return views of pinned buffers (set by the IPOPT adapter)
         self.ctx.check(lib.pk_load_model(h, code, len(code), C.byref(md)))
         self.model_desc = md
@@ -182,8 +196,8 @@ class Evaluator:
     def set_tables(self, tb: Tables):
         plan, lib, h = self.plan, self.ctx.lib, self.ctx.handle
         self.tables = tb
-        self._x_cached = None
         self._views = {}
+        self._ring, self._own, self._handed = None, {}, set()
         pd = runtime.ProblemDesc()
         pd.n, pd.m, pd.n_sys, pd.n_s, pd.l_s = plan.n, plan.m, plan.n_sys, plan.n_s, plan.l_s
         pd.n_phase, pd.n_tiles, pd.n_kinds = len(tb.phases), len(tb.tiles), len(tb.kinds)
@@ -217,13 +231,49 @@ class Evaluator:
             raise ValueError(f"x must have shape ({self.plan.n},)")
         return x
 
-    # IPOPT calls objective / gradient / constraints / jacobian one after the other on the same iterate:
-    # the first call on a new x uploads it and runs the fused x-kernel, the others only copy their result.
+    # IPOPT calls objective / gradient / constraints / jacobian one after the other on the same iterate and then
+    # hessian with new multipliers (the five methods optimizer/ipopt.py hands to cyipopt; reference ipopt.py:41-53):
+    # the first call on a new x uploads it, runs the fused x-kernel and queues the copies of all four results into
+    # pinned host memory (pk_prepare_x); every callback then only waits for its own result (pk_fetch).
+    #
+    # Where results land: ``zero_copy`` (set by the IPOPT adapter: cyipopt copies a result at once) hands out views of
+    # the context's pinned buffers, valid until the next iterate.  Otherwise the callbacks return arrays the caller
+    # owns, as the reference's do -- but over pinned memory the DMA writes directly (runtime.PinnedRing): an array is
+    # recycled only when the caller no longer refers to it.
+    def _rings(self):
+        if self._ring is None:
+            p = self.plan
+            self._ring = [runtime.PinnedRing(c) for c in (1, p.n, p.m, p.nnz_J, p.nnz_H)]
+        return self._ring
+
+    def _targets(self, whats):
+        """Pinned arrays of the caller's own for the results ``whats`` of the next evaluation (None: ring exhausted)."""
+        rings = self._rings()
+        return {w: rings[w].take() for w in whats}
+
+    def _set_targets(self, arrs):
+        ptr = [runtime.as_dp(arrs[w]) if arrs.get(w) is not None else None for w in range(5)]
+        self.ctx.check(self.ctx.lib.pk_set_result_targets(self.ctx.handle, *ptr))
+
     def _prepare(self, x):
         x = self._x(x)
-        if self._x_cached is None or not np.array_equal(x, self._x_cached):
-            self.ctx.check(self.ctx.lib.pk_prepare_x(self.ctx.handle, runtime.as_dp(x)))
-            self._x_cached = x.copy()
+        lib, h = self.ctx.lib, self.ctx.handle
+        if lib.pk_same_x(h, runtime.as_dp(x)):
+            return
+        if self.zero_copy:
+            if self._own:
+                self.ctx.check(lib.pk_set_result_targets(h, None, None, None, None, None))
+            self._own = {}
+        else:
+            self._own = self._targets((0, 1, 2, 3))
+            self._set_targets(self._own)
+        self._handed = set()
+        self.ctx.check(lib.pk_prepare_x(h, runtime.as_dp(x)))
+
+    def _invalidate_x(self):
+        """The context's x / result buffers are about to be used by an entry point outside the prepared-x protocol."""
+        if self.ctx is not None:
+            self.ctx.lib.pk_invalidate_x(self.ctx.handle)
 
     def _pinned(self, what):
         """NumPy view of the context's pinned result buffer ``what`` (0 f, 1 grad, 2 g, 3 jac, 4 hess)."""
@@ -233,20 +283,28 @@ class Evaluator:
             self._views[what] = np.ctypeslib.as_array(ptr, shape=(max(cnt.value, 1),))[: cnt.value]
         return self._views[what]
 
-    def _fetch(self, what, count):
-        # DMA into pinned memory at full PCIe rate; ``zero_copy`` hands out that buffer itself (valid until
-        # the next call for the same output -- cyipopt copies it at once), otherwise a fresh array as the
-        # reference's callbacks return.
+    def _result(self, what, count):
+        """The array result ``what`` landed in (after its wait), as the callback's return value."""
+        own = self._own.get(what)
+        if own is None:                      # landed in the context's buffer: zero-copy mode, or the ring is exhausted
+            view = self._pinned(what)[:count]           # (the caller keeps many results): plain array + host copy
+            return view if self.zero_copy else view.copy()
         if self.zero_copy:
-            self.ctx.check(self.ctx.lib.pk_fetch(self.ctx.handle, what, None))
-            return self._pinned(what)
-        out = np.empty(count)
-        self.ctx.check(self.ctx.lib.pk_fetch(self.ctx.handle, what, runtime.as_dp(out)))
-        return out
+            return own
+        if what in self._handed:             # asked twice for the same iterate: the first array is the caller's
+            return own.copy()
+        self._handed.add(what)
+        return own
+
+    def _fetch(self, what, count):
+        self.ctx.check(self.ctx.lib.pk_fetch(self.ctx.handle, what, None))
+        return self._result(what, count)
 
     def objective(self, x):
         self._prepare(x)
-        return np.float64(self._fetch(0, 1)[0])
+        self.ctx.check(self.ctx.lib.pk_fetch(self.ctx.handle, 0, None))
+        own = self._own.get(0)
+        return np.float64((own if own is not None else self._pinned(0))[0])
 
     def gradient(self, x):
         self._prepare(x)
@@ -265,41 +323,51 @@ class Evaluator:
         if lam.shape != (self.plan.m,):
             raise ValueError(f"lagrange must have shape ({self.plan.m},)")
         self._prepare(x)
-        if self.zero_copy:
-            self.ctx.check(self.ctx.lib.pk_eval_hess_prepared(self.ctx.handle, runtime.as_dp(lam), float(obj_factor), None))
-            return self._pinned(4)
-        out = np.empty(self.plan.nnz_H)
-        self.ctx.check(self.ctx.lib.pk_eval_hess_prepared(self.ctx.handle, runtime.as_dp(lam), float(obj_factor),
-                                                          runtime.as_dp(out)))
-        return out
+        lib, h = self.ctx.lib, self.ctx.handle
+        self._own[4] = None if self.zero_copy else self._rings()[4].take()
+        self._set_targets(self._own)
+        self._handed.discard(4)
+        self.ctx.check(lib.pk_eval_hess_prepared(h, runtime.as_dp(lam), float(obj_factor), None))
+        return self._result(4, self.plan.nnz_H)
+
+    def set_host_mode(self, prefetch=True, host_direct=False):
+        """``prefetch`` (default True): all four x-results are copied to the host right behind the kernel; False: f and
+        g always, grad f and J when first asked for.  ``host_direct``: the kernels store into pinned host memory
+        themselves instead of device memory + DMA (A/B switch)."""
+        self.ctx.check(self.ctx.lib.pk_set_host_mode(self.ctx.handle, int(bool(prefetch)), int(bool(host_direct))))
 
     # one-shot variants without the x cache (each uploads x and runs only its own kernels)
     def objective_direct(self, x):
         x = self._x(x)
+        self._invalidate_x()        # the context's x / result buffers are about to hold another iterate
         out = np.empty(1)
         self.ctx.check(self.ctx.lib.pk_eval_f(self.ctx.handle, runtime.as_dp(x), runtime.as_dp(out)))
         return np.float64(out[0])
 
     def gradient_direct(self, x):
         x = self._x(x)
+        self._invalidate_x()        # the context's x / result buffers are about to hold another iterate
         out = np.empty(self.plan.n)
         self.ctx.check(self.ctx.lib.pk_eval_grad(self.ctx.handle, runtime.as_dp(x), runtime.as_dp(out)))
         return out
 
     def constraints_direct(self, x):
         x = self._x(x)
+        self._invalidate_x()        # the context's x / result buffers are about to hold another iterate
         out = np.empty(self.plan.m)
         self.ctx.check(self.ctx.lib.pk_eval_g(self.ctx.handle, runtime.as_dp(x), runtime.as_dp(out)))
         return out
 
     def jacobian_direct(self, x):
         x = self._x(x)
+        self._invalidate_x()        # the context's x / result buffers are about to hold another iterate
         out = np.empty(self.plan.nnz_J)
         self.ctx.check(self.ctx.lib.pk_eval_jac(self.ctx.handle, runtime.as_dp(x), runtime.as_dp(out)))
         return out
 
     def hessian_direct(self, x, lagrange, obj_factor):
         x = self._x(x)
+        self._invalidate_x()        # the context's x / result buffers are about to hold another iterate
         lam = np.ascontiguousarray(lagrange, dtype=np.float64)
         out = np.empty(self.plan.nnz_H)
         self.ctx.check(self.ctx.lib.pk_eval_hess(self.ctx.handle, runtime.as_dp(x), runtime.as_dp(lam),
@@ -311,6 +379,7 @@ class Evaluator:
         if not self.src.compact:
             raise NotImplementedError("compact Hessian layout is not available for this model")
         x = self._x(x)
+        self._invalidate_x()        # the context's x / result buffers are about to hold another iterate
         lam = np.ascontiguousarray(lagrange, dtype=np.float64)
         out = np.empty(self.plan.nnz_Hc)
         self.ctx.check(self.ctx.lib.pk_eval_hessc(self.ctx.handle, runtime.as_dp(x), runtime.as_dp(lam),
@@ -330,6 +399,7 @@ class Evaluator:
                                                         len(tables), n_out))
             self._err_views, self._err_len = views, n_out
         x = self._x(x)
+        self._invalidate_x()        # the context's x / result buffers are about to hold another iterate
         T, I = np.empty(self._err_len), np.empty(self._err_len)
         self.ctx.check(lib.pk_eval_mesh_error(h, runtime.as_dp(x), runtime.as_dp(T), runtime.as_dp(I)))
         return [(T[o: o + nx * rows].reshape(nx, rows), I[o: o + nx * rows].reshape(nx, rows))
@@ -359,6 +429,7 @@ class Evaluator:
         """CSR values of the constraint Jacobian (structure: ``csr_map("jac")``), gathered on the device."""
         m = self.csr_map("jac")
         x = self._x(x)
+        self._invalidate_x()        # the context's x / result buffers are about to hold another iterate
         out = np.empty(m.nnz)
         self.ctx.check(self.ctx.lib.pk_eval_jac_csr(self.ctx.handle, runtime.as_dp(x), runtime.as_dp(out)))
         return out
@@ -367,6 +438,7 @@ class Evaluator:
         """CSR values of the lower triangle of the Hessian of the Lagrangian (``csr_map("hess")``)."""
         m = self.csr_map("hess")
         x = self._x(x)
+        self._invalidate_x()        # the context's x / result buffers are about to hold another iterate
         lam = np.ascontiguousarray(lagrange, dtype=np.float64)
         out = np.empty(m.nnz)
         self.ctx.check(self.ctx.lib.pk_eval_hess_csr(self.ctx.handle, runtime.as_dp(x), runtime.as_dp(lam),
@@ -375,10 +447,12 @@ class Evaluator:
 
     def jacobian_csr_dev(self, d_x, d_out, stream=None):
         self.csr_map("jac")
+        self._invalidate_x()        # (the triplets pass through the context's J buffer)
         self.ctx.check(self.ctx.lib.pk_eval_jac_csr_dev(self.ctx.handle, d_x, d_out, stream))
 
     def hessian_csr_dev(self, d_x, d_lam, sigma, d_out, stream=None):
         self.csr_map("hess")
+        self._invalidate_x()
         self.ctx.check(self.ctx.lib.pk_eval_hess_csr_dev(self.ctx.handle, d_x, d_lam, float(sigma), d_out, stream))
 
     def gather_csr_dev(self, which, d_triplets, d_out, stream=None):
@@ -390,9 +464,12 @@ class Evaluator:
     def cycle(self, x, lagrange, obj_factor):
         """All five outputs on the same x from the single-launch cycle (pk_cycle): returns (f, grad, g, J, H)."""
         x = self._x(x)
+        self._invalidate_x()        # the context's x / result buffers are about to hold another iterate
         lam = np.ascontiguousarray(lagrange, dtype=np.float64)
-        f, grad, g = np.empty(1), np.empty(self.plan.n), np.empty(self.plan.m)
-        J, H = np.empty(self.plan.nnz_J), np.empty(self.plan.nnz_H)
+        self._own = {}
+        out = self._targets(range(5))        # pinned arrays of the caller's own: the five DMAs run at full PCIe rate
+        sizes = (1, self.plan.n, self.plan.m, self.plan.nnz_J, self.plan.nnz_H)
+        f, grad, g, J, H = (out[w] if out[w] is not None else np.empty(sizes[w]) for w in range(5))
         dp = runtime.as_dp
         self.ctx.check(self.ctx.lib.pk_eval_cycle(self.ctx.handle, dp(x), dp(lam), float(obj_factor), dp(f), dp(grad),
                                                   dp(g), dp(J), dp(H)))

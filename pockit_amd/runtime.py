@@ -70,7 +70,8 @@ EXPORTS = ["pk_create", "pk_destroy", "pk_last_error", "pk_device_count", "pk_lo
            "pk_prepare_x", "pk_fetch", "pk_eval_hess_prepared", "pk_host_buffer", "pk_eval_hessc", "pk_eval_hessc_dev",
            "pk_set_mesh_error_tables", "pk_eval_mesh_error", "pk_eval_mesh_error_dev", "pk_set_cycle_graph", "pk_profile_sampling",
            "pk_set_csr_map", "pk_gather_csr_dev", "pk_eval_jac_csr_dev", "pk_eval_hess_csr_dev", "pk_eval_jac_csr",
-           "pk_eval_hess_csr", "pk_trace_read", "pk_set_cycle_mode"]
+           "pk_eval_hess_csr", "pk_trace_read", "pk_set_cycle_mode", "pk_same_x", "pk_set_result_targets",
+           "pk_result_location", "pk_set_host_mode", "pk_invalidate_x", "pk_host_alloc", "pk_host_free"]
 
 _lib = None
 
@@ -129,6 +130,13 @@ def load_library():
     lib.pk_fetch.argtypes = [vp, C.c_int, dp]
     lib.pk_eval_hess_prepared.argtypes = [vp, dp, C.c_double, dp]
     lib.pk_host_buffer.argtypes = [vp, C.c_int, C.POINTER(dp), C.POINTER(C.c_int64)]
+    lib.pk_same_x.argtypes = [vp, dp]
+    lib.pk_set_result_targets.argtypes = [vp, dp, dp, dp, dp, dp]
+    lib.pk_result_location.argtypes = [vp, C.c_int, C.POINTER(dp)]
+    lib.pk_set_host_mode.argtypes = [vp, C.c_int, C.c_int]
+    lib.pk_invalidate_x.argtypes = [vp]
+    lib.pk_host_alloc.argtypes = [C.c_size_t, C.POINTER(vp)]
+    lib.pk_host_free.argtypes = [vp]
     lib.pk_eval_hessc.argtypes = [vp, dp, dp, C.c_double, dp]
     lib.pk_eval_hessc_dev.argtypes = [vp, vp, vp, C.c_double, vp, vp]
     lib.pk_set_mesh_error_tables.argtypes = [vp, vp, C.c_int32, dp, C.c_int64, C.c_int64]
@@ -195,3 +203,69 @@ class Context:
             self.close()
         except Exception:
             pass
+
+
+class _PinnedBlock:
+    """Owner of one pk_host_alloc allocation (freed with the last array over it)."""
+
+    def __init__(self, nbytes):
+        lib = load_library()
+        self._lib, self.ptr = lib, C.c_void_p()
+        rc = lib.pk_host_alloc(int(nbytes), C.byref(self.ptr))
+        if rc != 0:
+            raise RuntimeError(f"pk_host_alloc failed ({rc}): {lib.pk_last_error(None).decode()}")
+
+    def buffer(self, count):
+        buf = (C.c_double * count).from_address(self.ptr.value)
+        buf._owner = self                        # every NumPy view keeps the ctypes array, which keeps the block
+        return buf
+
+    def __del__(self):
+        try:
+            if self.ptr:
+                self._lib.pk_host_free(self.ptr)
+                self.ptr = None
+        except Exception:
+            pass
+
+
+class PinnedArray:
+    """A float64 NumPy array over pinned (page-locked, device-visible) host memory: a DMA target at full PCIe rate that
+    can be handed to the solver as a callback's result.  The memory is not tied to a context; it is released with the
+    last view.  ``free()`` tells whether nobody but this object refers to the array any more (the caller dropped the
+    result it was given, and every view of it), i.e. whether the next iterate may land in it."""
+
+    def __init__(self, count, buffer_factory=None):
+        import sys
+
+        self._getrefcount = sys.getrefcount
+        count = int(count)
+        if buffer_factory is None:
+            root = np.frombuffer(_PinnedBlock(8 * max(count, 1)).buffer(max(count, 1)), dtype=np.float64)
+        else:
+            root = buffer_factory(max(count, 1))   # (tests: plain NumPy memory)
+        self.root = root
+        self.array = root[:count]
+
+    def free(self):
+        # root: self.root + self.array.base (+ the argument of getrefcount); array: self.array (+ argument).  Views a
+        # caller derived from the result keep ``root`` (NumPy collapses view chains to the memory's owner).
+        return self._getrefcount(self.array) == 2 and self._getrefcount(self.root) == 3
+
+
+class PinnedRing:
+    """Result arrays of one output, recycled: ``take()`` returns an array nobody refers to any more, allocates a new
+    one while fewer than ``cap`` exist, and returns None beyond that (the caller then falls back to a plain array and
+    a host copy) -- a solver that keeps every iterate's Jacobian must not pin unbounded memory."""
+
+    def __init__(self, count, cap=6, buffer_factory=None):
+        self.count, self.cap, self._factory, self.items = int(count), int(cap), buffer_factory, []
+
+    def take(self):
+        for it in self.items:
+            if it.free():
+                return it.array
+        if len(self.items) < self.cap:
+            self.items.append(PinnedArray(self.count, self._factory))
+            return self.items[-1].array
+        return None

@@ -87,6 +87,64 @@ def test_tilings_match_oracle(case, ipw, monkeypatch):
     close(H, ref.hessian(x, lam, sigma), what="cycle H")
 
 
+@pytest.mark.parametrize("ipw", [1, 3, 7, 64])
+@pytest.mark.parametrize("case", [("brachistochrone", "radau", dict(mesh=83, num_point=1)),      # R = nnzI = 1
+                                  ("brachistochrone", "lobatto", dict(mesh=83, num_point=2)),    # R = 1
+                                  ("two_stage_rocket", "radau", dict(mesh=41, num_point=1)),
+                                  ("planar_quadrotor", "lobatto", dict(mesh=50, num_point=2))])
+def test_unit_divisor_tiles_match_oracle(case, ipw, monkeypatch):
+    """Tiles whose per-interval divisors (defect rows, integration / translation entries) are 1 -- LGR K = 1 and
+    LGL K = 2 -- holding several intervals: the quotient p // 1 has no 32-bit magic number (magic_div)."""
+    monkeypatch.setenv("POCKIT_AMD_IPW", str(ipw))
+    bname, scheme, kw = case
+    system, _, guess = getattr(models, bname)(_ns(scheme, "pockit_amd"), **kw)
+    ref, _, _ = getattr(models, bname)(_ns(scheme, "oracle"), **kw)
+    tiles = system.evaluator.tables.tiles
+    if ipw >= 3:
+        assert tiles["nj"].max() >= 3 and (tiles["magicR"][tiles["nj"] > 0] == 0).all()
+    x, lam, sigma = models.bench_inputs(system, guess)
+    close(system.objective(x), ref.objective(x), what="f")
+    close(system.gradient(x), ref.gradient(x), what="grad")
+    close(system.constraints(x), ref.constraints(x), what="g")
+    close(system.jacobian(x), ref.jacobian(x), what="J")
+    close(system.hessian(x, lam, sigma), ref.hessian(x, lam, sigma), what="H")
+    f, grad, g, J, H = system.evaluator.cycle(x, lam, sigma)
+    close(g, ref.constraints(x), what="cycle g")
+    close(J, ref.jacobian(x), what="cycle J")
+    close(H, ref.hessian(x, lam, sigma), what="cycle H")
+    ev = system.evaluator
+    close(ev.constraints_direct(x), ref.constraints(x), what="g direct")
+    close(ev.jacobian_direct(x), ref.jacobian(x), what="J direct")
+    close(ev.hessian_direct(x, lam, sigma), ref.hessian(x, lam, sigma), what="H direct")
+
+
+def test_prepared_x_cache_is_dropped_by_calls_that_reuse_the_context_buffers():
+    """objective / gradient / constraints / jacobian / hessian on x1 serve from ONE upload of x1; any other entry
+    point that uploads a different x (mesh error, the one-launch cycle, the *_direct and CSR calls) in between must
+    not leave them answering for that other x."""
+    system, _, guess = models.two_stage_rocket(_ns("radau", "pockit_amd"), 60, 4)
+    ref, _, _ = models.two_stage_rocket(_ns("radau", "oracle"), 60, 4)
+    x1, lam, sigma = models.bench_inputs(system, guess)
+    x2 = x1 * (1.0 + 0.05 * np.random.default_rng(11).uniform(-1, 1, x1.shape))
+    ev = system.evaluator
+    want = dict(f=ref.objective(x1), grad=ref.gradient(x1), g=ref.constraints(x1), J=ref.jacobian(x1),
+                H=ref.hessian(x1, lam, sigma))
+    others = [lambda: ev.mesh_error(x2), lambda: ev.cycle(x2, lam, sigma), lambda: ev.gradient_direct(x2),
+              lambda: ev.jacobian_direct(x2), lambda: ev.jacobian_csr(x2), lambda: ev.hessian_csr(x2, lam, sigma),
+              lambda: ev.hessian_compact(x2, lam, sigma), lambda: ev.constraints_direct(x2),
+              lambda: ev.objective_direct(x2), lambda: ev.hessian_direct(x2, lam, sigma)]
+    for other in others:
+        close(system.gradient(x1), want["grad"], what="grad before")
+        other()
+        close(system.hessian(x1, lam, sigma), want["H"], what="H after another x went through the context")
+        other()
+        close(system.jacobian(x1), want["J"], what="J after")
+        other()
+        close(system.gradient(x1), want["grad"], what="grad after")
+        close(system.constraints(x1), want["g"], what="g after")
+        close(system.objective(x1), want["f"], what="f after")
+
+
 def test_ragged_mesh_matches_oracle():
     """hp-style mesh: every interval its own width and polynomial order (K = 1 .. 9)."""
     rng = np.random.default_rng(5)
@@ -127,6 +185,13 @@ def test_full_size_configs_match_reference_summary():
         check(system.constraints(x), gold["g"], name + " g")
         check(system.jacobian(x), gold["J"], name + " J")
         check(system.hessian(x, lam, sigma), gold["H"], name + " H")
+        # the benchmarked kernel itself: all five outputs of the ONE-launch cycle (pk_cycle) at the full size
+        f1, grad1, g1, J1, H1 = system.evaluator.cycle(x, lam, sigma)
+        assert abs(f1 - gold["f"]) <= TOL * max(1.0, abs(gold["f"])), name + " cycle f"
+        check(grad1, gold["grad"], name + " cycle grad")
+        check(g1, gold["g"], name + " cycle g")
+        check(J1, gold["J"], name + " cycle J")
+        check(H1, gold["H"], name + " cycle H")
         system._invalidate()
 
 
@@ -593,6 +658,119 @@ def test_reference_check_discontinuous_lobatto_is_not_implemented():
     v.x[0] = v.t_x
     v.u[0] = v.t_u * 0 + 1.0
     assert s.check([v, [0.0]]) == s.check_continuous([v, [0.0]])   # lobatto: check == check_continuous
+
+
+# ---------------------------------------------------------------------------------------------------------
+# the three tests of the reference's tests/test_base/test_system_base.py:10-70 that were not restated yet
+@pytest.mark.parametrize("scheme", ["radau", "lobatto"])
+def test_reference_static_only_system(scheme):
+    """A system without phases (test_system_base.py:10-20): f = s^2, grad = [2 s], no constraints -- evaluated by the
+    system-level workgroups alone (no tile workgroup exists)."""
+    system = _ns(scheme, "pockit_amd").System(1)
+    system.set_objective(system.s[0] ** 2)
+    x = np.array([2.0], dtype=np.float64)
+    assert system.objective(x) == pytest.approx(4.0)
+    assert np.allclose(system.gradient(x), [4.0])
+    assert system.constraints(x).shape == (0,)
+    assert system.jacobian(x).shape == (0,)
+    ref = _ns(scheme, "oracle").System(1)
+    ref.set_objective(ref.s[0] ** 2)
+    lam = np.zeros(0)
+    hr, hc = system.hessianstructure()
+    rr, rc = ref.hessianstructure()
+    assert np.array_equal(hr, rr) and np.array_equal(hc, rc)
+    close(system.hessian(x, lam, 0.5), ref.hessian(x, lam, 0.5), what="H")
+    f, grad, g, J, H = system.evaluator.cycle(x, lam, 0.5)         # the one-launch cycle: three workgroups, no tiles
+    assert f == pytest.approx(4.0) and np.allclose(grad, [4.0]) and g.shape == (0,) and J.shape == (0,)
+    close(H, ref.hessian(x, lam, 0.5), what="cycle H")
+    x3 = np.array([-3.0])
+    assert system.objective(x3) == pytest.approx(9.0) and np.allclose(system.gradient(x3), [-6.0])
+
+
+def test_reference_static_only_system_with_system_constraints():
+    """Static parameters only, with an objective and system constraints in them: f, grad f, g, J, H against the oracle."""
+    def build(ns):
+        system = ns.System(3)
+        a, b, c = system.s
+        system.set_objective(a ** 2 * b + sp_sin(c) * a)
+        system.set_system_constraint([a * b * c, a + b ** 2], [0.0, -1.0], [1.0, 1.0])
+        return system
+
+    import sympy
+
+    sp_sin = sympy.sin
+    system, ref = build(_ns("radau", "pockit_amd")), build(_ns("radau", "oracle"))
+    x = np.array([0.7, -1.3, 0.4])
+    lam = np.array([0.3, -2.0])
+    assert np.array_equal(system.jacobianstructure()[0], ref.jacobianstructure()[0])
+    assert np.array_equal(system.jacobianstructure()[1], ref.jacobianstructure()[1])
+    assert np.array_equal(system.hessianstructure()[0], ref.hessianstructure()[0])
+    assert np.array_equal(system.hessianstructure()[1], ref.hessianstructure()[1])
+    close(system.objective(x), ref.objective(x), what="f")
+    close(system.gradient(x), ref.gradient(x), what="grad")
+    close(system.constraints(x), ref.constraints(x), what="g")
+    close(system.jacobian(x), ref.jacobian(x), what="J")
+    close(system.hessian(x, lam, 1.7), ref.hessian(x, lam, 1.7), what="H")
+
+
+def test_reference_phase_check_uses_discontinuous_tolerance():
+    """test_system_base.py:22-32: ``phase.check`` passes its discontinuous tolerance on (u = 0.9995 of a bang-bang
+    control in [0, 1] is settled at tolerance 1e-3)."""
+    ns = _ns("radau", "pockit_amd")
+    system = ns.System(0)
+    phase = system.new_phase(1, 1)
+    phase.set_dynamics([0]).set_boundary_condition([0], [0], 0, 1)
+    phase.set_phase_constraint([phase.u[0]], [0], [1], bang_bang_control=True).set_discretization(1, 3)
+    system.set_phase([phase]).set_objective(0)
+    variable = ns.constant_guess(phase, 0)
+    variable.u[0] = 0.9995
+    assert phase.check(variable, tolerance_discontinuous=1.0e-3)
+    assert not phase.check(variable, tolerance_discontinuous=1.0e-4)
+
+
+def test_reference_reconfiguring_boundary_condition_clears_old_derivatives():
+    """test_system_base.py:34-70: a FUNC boundary value replaced by a FREE and then by a FIXED one must leave no trace
+    of the static-parameter dependence -- structure equal to the oracle's after the same sequence, J against central
+    finite differences of the constraints callback (the reference's own check)."""
+    def build(ns):
+        system = ns.System(1)
+        phase = system.new_phase(1, 0)
+        phase.set_dynamics([0]).set_boundary_condition([system.s[0] ** 2], [None], 0, 1).set_discretization(1, 3)
+        phase.set_boundary_condition([None], [None], 0, 1)
+        phase.set_boundary_condition([0], [None], 0, 1)
+        system.set_phase([phase]).set_objective(0)
+        return system, phase
+
+    ns = _ns("radau", "pockit_amd")
+    system, phase = build(ns)
+    ref, _ = build(_ns("radau", "oracle"))
+    x = np.concatenate([ns.constant_guess(phase, 0).data, [2.0]])
+    row, col = system.jacobianstructure()
+    rrow, rcol = ref.jacobianstructure()
+    assert np.array_equal(row, rrow) and np.array_equal(col, rcol)
+    assert not np.any(col == system.l_s), "no Jacobian entry may depend on the static parameter any more"
+    jacobian = np.zeros((len(system.c_lb), system.L), dtype=np.float64)
+    np.add.at(jacobian, (row, col), system.jacobian(x.copy()))
+    eps = 1.0e-6
+    finite_difference = np.empty_like(jacobian)
+    for i in range(system.L):
+        delta = np.zeros(system.L, dtype=np.float64)
+        delta[i] = eps
+        finite_difference[:, i] = (system.constraints(x.copy() + delta) - system.constraints(x.copy() - delta)) / (2 * eps)
+    assert np.allclose(jacobian, finite_difference)
+    close(system.jacobian(x), ref.jacobian(x), what="J")
+    # the intermediate configurations evaluate correctly too (FUNC, then FREE)
+    for bc in ([None], "func"):
+        s2 = ns.System(1)
+        p2 = s2.new_phase(1, 0)
+        r2 = _ns("radau", "oracle").System(1)
+        q2 = r2.new_phase(1, 0)
+        for sy, ph in ((s2, p2), (r2, q2)):
+            ph.set_dynamics([0]).set_boundary_condition([0], [None], 0, 1).set_discretization(1, 3)
+            ph.set_boundary_condition([sy.s[0] ** 2] if bc == "func" else bc, [None], 0, 1)
+            sy.set_phase([ph]).set_objective(0)
+        close(s2.jacobian(x), r2.jacobian(x), what="J " + str(bc))
+        assert np.array_equal(s2.jacobianstructure()[1], r2.jacobianstructure()[1])
 
 
 def test_check_and_refine_loop_like_the_hyper_sensitive_example():

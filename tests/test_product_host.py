@@ -130,6 +130,32 @@ def test_tiles_cover_every_interval_once():
             assert nodes.max() <= 64
 
 
+def test_magic_numbers_divide_exactly_including_the_unit_divisor():
+    """The kernels replace p // d (d = defect rows, integration entries, translation entries per interval) by
+    magic_div(p, magic): exact for every p a tile can produce, d = 1 included (LGR K = 1, LGL K = 2)."""
+    from pockit_amd.evaluator import Tables, magic_div, magic_number
+    from pockit_amd.codegen import ModelSource
+
+    p = np.arange(1 << 16, dtype=np.uint64)
+    for d in list(range(1, 700)) + [1023, 1024, 4095, 4096]:
+        mg = magic_number(d)
+        assert 0 <= mg < 1 << 32
+        q = p if mg == 0 else (p * np.uint64(mg)) >> np.uint64(32)
+        assert np.array_equal(q, p // np.uint64(d)), d
+        assert magic_div(65535, mg) == 65535 // d
+    # the tables of unit-divisor meshes: several intervals per tile, magic 0, every position decodes correctly
+    for ns, K in ((radau, 1), (lobatto, 2)):
+        system, _, _ = models.brachistochrone(ns, 800, K)
+        tb = Tables(system.plan, ModelSource(system.plan))
+        live = tb.tiles[tb.tiles["nj"] > 0]
+        assert live["nj"].max() >= 3
+        for t in live[:5]:
+            for field, d in (("magicI", int(t["nnzI"])), ("magicT", int(t["nnzT"]))):
+                for pos in range(int(t["nj"]) * d):
+                    assert magic_div(pos, int(t[field])) == pos // d
+            assert int(t["magicR"]) == 0      # R = 1
+
+
 # ------------------------------------------------------------------ modeling API behaviour
 def test_variable_and_constraint_bounds_layout():
     s = radau.System(4)
