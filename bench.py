@@ -44,6 +44,18 @@ if ROOT not in sys.path:
 
 import numpy as np  # noqa: E402
 
+SHARDING_NOTE = {
+    "sums": "mesh intervals over {n} GPUs (shares balanced by output volume), one pk_cycle launch per rank on its tiles; every "
+            "rank's slices of grad/g/J/H stay in its own HBM at the reference positions; the sums over all nodes (integrals -> "
+            "f, gradient entries of t0/tf/static parameters) are exchanged through peer-mapped mailboxes inside one "
+            "one-workgroup launch per rank (pk_xchg) -- no collective in the data path",
+    "direct": "mesh intervals over {n} GPUs, one pk_cycle launch per rank; the other ranks' kernels store their slices "
+              "straight into rank 0's buffer through hipIpc peer mappings (xGMI), pk_xchg flags completion",
+    "gather": "mesh intervals over {n} GPUs, one pk_cycle launch per rank, run-copy pack + RCCL gather to rank 0 + run-copy "
+              "unpack of the owned runs of grad/g/J/H (+ the partial sums)",
+    "allgather": "mesh intervals over {n} GPUs, one pk_cycle launch per rank, run-copy pack + RCCL all-gather + run-copy "
+                 "unpack of the owned runs of grad/g/J/H, tiny all-reduce of the partial sums",
+}
 HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 KERNEL_IDS = {"pk_int": 0, "pk_fin": 1, "pk_g": 2, "pk_grad": 3, "pk_jac": 4, "pk_hess": 5, "pk_xall": 6, "pk_cycle": 12}
 MIN_REGION_S = 0.05        # the timed region lasts at least this long (R batches of `steps` cycles)
@@ -177,8 +189,9 @@ class GpuWorkload:
         self.dx = torch.from_numpy(self.x).to(dev)
         self.dlam = torch.from_numpy(self.lam).to(dev)
         self.o = o = sev.out
-        # a stream of our own: torch's default stream has the null handle, which the C ABI reads as "the context's stream"
-        self.stream = torch.cuda.Stream(device=dev)
+        # a stream of our own (the sharded evaluator's): torch's default stream has the null handle, which the C ABI reads
+        # as "the context's stream"; launches, exchange and the timing events all go to this one
+        self.stream = sev.stream
         st = C.c_void_p(self.stream.cuda_stream)
         ptr = lambda t: C.c_void_p(t.data_ptr())  # noqa: E731
         self.cycle_args = (self.h, ptr(self.dx), ptr(self.dlam), C.c_double(float(self.sigma)), ptr(o["f"]), ptr(o["grad"]),
@@ -192,19 +205,21 @@ class GpuWorkload:
                     check(rc)
             check(lib.pk_set_shard(self.h, 0, 0, None))
         else:
-            root = {"r": None if os.environ.get("POCKIT_AMD_BENCH_EXCHANGE") == "allgather" else 0}
-
-            def step():
-                sev.cycle(self.dx, self.dlam, self.sigma, dist, root=root["r"])   # root 0: reassembled where the solver runs
-
-            if root["r"] is not None:
-                try:                                       # one untimed cycle: a backend without gather falls back to all-gather
-                    step()
-                    torch.cuda.synchronize()
-                except (RuntimeError, NotImplementedError) as exc:
-                    print(f"[bench] gather-to-root exchange not available ({exc!r}); using the all-gather form", file=sys.stderr)
-                    root["r"] = None
-            self.exchange = "gather to rank 0" if root["r"] == 0 else "all-gather"
+            # N > 1.  Default form "sums": every rank leaves its slices in its own HBM, only the sums over all nodes are
+            # exchanged (peer-mapped mailboxes inside one launch, no collective) -- the weak-scaling form.  A/B forms:
+            # "direct" (reassembly on rank 0's GPU by peer stores), "gather" / "allgather" (RCCL reassembly).
+            self.mode = os.environ.get("POCKIT_AMD_BENCH_EXCHANGE", "sums")
+            self.peer_error = None
+            try:
+                if self.fused_ok(plan):
+                    sev.enable_peer_exchange(dist, root=0)
+            except Exception as exc:          # no peer access between the GPUs: the RCCL forms remain
+                self.peer_error = repr(exc)
+                print(f"[bench] peer-mapped exchange not available ({exc!r}); using the RCCL gather form", file=sys.stderr)
+            if sev.peers is None and self.mode in ("sums", "direct"):
+                self.mode = "gather"
+            step = self.make_step(self.mode)
+            self.exchange = self.mode
         self.step = step
         self.bytes = B = algorithmic_bytes(plan)
         self.fused = not (plan.needs_I_grad or plan.needs_I_con or plan.jac.needs_I or plan.hess.needs_I)
@@ -215,6 +230,43 @@ class GpuWorkload:
             self.dominant = "pk_cycle"           # ONE launch does the whole cycle: its algorithmic bytes are SURVEY 8(d)'s B
         else:
             self.dominant = "pk_jac" if B["jac"] >= B["hess"] else "pk_hess"
+
+    @staticmethod
+    def fused_ok(plan):
+        return not (plan.needs_I_grad or plan.needs_I_con or plan.jac.needs_I or plan.hess.needs_I)
+
+    def make_step(self, mode):
+        sev, dist = self.sev, self.dist
+        if mode in ("sums", "direct"):
+            return sev.fast_step(self.dx, self.dlam, self.sigma, exchange=mode)
+        root = None if mode == "allgather" else 0
+
+        def step():
+            sev.cycle(self.dx, self.dlam, self.sigma, dist, root=root)
+
+        if root is not None:
+            try:                                       # one untimed cycle: a backend without gather falls back to all-gather
+                step()
+                self.torch.cuda.synchronize()
+            except (RuntimeError, NotImplementedError) as exc:
+                print(f"[bench] gather-to-root not available ({exc!r}); using the all-gather form", file=sys.stderr)
+                return self.make_step("allgather")
+        return step
+
+    def time_mode(self, mode, steps=200):
+        """ms per cycle of another form of the exchange (short untimed warm-up, wall clock between barriers)."""
+        try:
+            step = self.make_step(mode)
+            for _ in range(10):
+                step()
+            self.sync()
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                step()
+            self.sync()
+            return (time.perf_counter() - t0) / steps * 1e3
+        except Exception as exc:  # noqa: BLE001 -- a side figure must not cost the headline
+            return repr(exc)
 
     def sync(self):
         self.torch.cuda.synchronize()
@@ -325,7 +377,7 @@ class GpuWorkload:
 
     def all_kernel_us(self, steps=50):
         ev = self.ev
-        ev.profile(0x1FFF)
+        ev.profile(0x7FFF)
         for _ in range(steps):
             self.step()
         self.torch.cuda.synchronize()
@@ -337,7 +389,7 @@ class GpuWorkload:
         return all(bool(self.torch.isfinite(self.o[k]).all()) for k in ("f", "grad", "g", "J", "H"))
 
     def close(self):
-        self.ev.close()
+        self.sev.close()
 
 
 def measure(name, intervals, steps, warmup, rank, world, dist, with_side=True, with_e2e=True):
@@ -365,9 +417,29 @@ def measure(name, intervals, steps, warmup, rank, world, dist, with_side=True, w
         w.stream.synchronize()
         res["no_exchange_ms_per_step"] = (time.perf_counter() - t1) / n * 1e3
         w.sync()
+    res["exchange_forms_ms_per_step"] = None
+    res["ranks"] = None
+    if world > 1:
+        forms = {}
+        for mode in ("sums", "direct", "gather"):
+            if mode == w.exchange:
+                forms[mode] = res["ms_per_step"]
+            elif mode in ("sums", "direct") and w.sev.peers is None:
+                forms[mode] = "peer-mapped exchange not available: " + str(w.peer_error)
+            else:
+                forms[mode] = w.time_mode(mode)
+        res["exchange_forms_ms_per_step"] = forms
+        w.step = w.make_step(w.exchange)
     iso, fl, n_iso, n_fl = w.dispatch_times(w.dominant)
     res.update(dispatch_isolated_us=iso, dispatch_in_flight_us=fl, dispatch_samples=[n_iso, n_fl])
     res["kernel_us"] = w.all_kernel_us()
+    if world > 1:       # per rank: share of the output positions, tiles, kernel times (rank 0 prints them)
+        mine = {"rank": rank, "tiles": int((w.ev.tables.tiles["nj"] > 0).sum()),
+                "owned_output_doubles": int(sum(b - a for a, b in w.sev.runs[rank])),
+                "pk_cycle_us": iso, "pk_xchg_us": res["kernel_us"].get("pk_xchg"), "setup_s": w.setup_s}
+        allr = [None] * world
+        dist.all_gather_object(allr, mine)
+        res["ranks"] = allr
     res["finite"] = w.finite()
     res["side"] = w.side_kernels() if (with_side and world == 1) else {}
     res["end_to_end"] = None
@@ -464,12 +536,31 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     ms, wall_ms = float(t[0].item()), float(t[1].item())
 
+    # N > 1: BASELINE.json's sharded configs at their full size, STRONG-scaled over the N GPUs (every rank takes part)
+    strong = {}
+    if world > 1 and not args.no_extra:
+        for nm, iv, tag in (("two_stage_rocket", 1000, "C4 two_stage_rocket 2 phases x 1000 intervals x 4 points"),
+                            ("humanoid_wbc", 5000, "C5 humanoid_wbc 5000 intervals x 8 points")):
+            try:
+                r = measure(nm, iv, args.steps, min(args.warmup, 50), rank, world, dist, with_side=False, with_e2e=False)
+                tt = torch.tensor([r["ms_per_step"]], dtype=torch.float64, device="cuda")
+                dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+                strong[f"{nm}_{iv}_strong_scaled_over_{world}"] = {
+                    "config": tag, "nodes": r["nodes"], "scaling": "strong", "cycles_per_s": 1e3 / float(tt.item()),
+                    "ms_per_step": float(tt.item()), "exchange": r["exchange"], "exchange_forms_ms_per_step": r["exchange_forms_ms_per_step"],
+                    "ranks": r["ranks"], "cycle_bytes": r["bytes"]["cycle"]}
+            except Exception as exc:  # noqa: BLE001
+                strong[f"{nm}_{iv}_strong_scaled_over_{world}"] = {"error": repr(exc)}
+
     if rank == 0:
         value = n_gpus * 1e3 / ms
         dom = res["dominant"]
         dom_bytes = res["bytes"][dom[3:]] / n_gpus
         x_once = res["bytes"]["cycle_x_once"] / n_gpus if dom == "pk_cycle" else None
-        dom_us = res["dispatch_isolated_us"]
+        # the kernel's average launch duration: HIP events over the timed region / launches when the cycle is ONE launch
+        # (launch + gap to the next launch: an upper bound of the kernel's own duration in this very run); a cycle of
+        # several launches, or N > 1 (the region holds the exchange too), uses the per-dispatch events
+        dom_us = ms * 1e3 if (dom == "pk_cycle" and n_gpus == 1) else res["dispatch_isolated_us"]
         achieved = dom_bytes / (dom_us * 1e-6) / 1e9 if dom_us else None
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
@@ -478,7 +569,6 @@ def main():
                 traffic = json.load(open(tpath)).get(f"{args.workload}_{intervals}", {}).get(dom)
             except Exception:
                 traffic = None
-        b2b_us = ms * 1e3 if n_gpus == 1 else None
         line = {
             "metric": "NLP-callback cycles/sec (f + grad f + g + J + H)",
             "value": value,
@@ -490,9 +580,7 @@ def main():
             "config": {"workload": f"{args.workload} LGR {intervals} intervals x {POINTS.get(args.workload.replace('_lgl', ''), 0)}"
                                    f" points ({res['nodes']} nodes; n={res['n']}, m={res['m']}, nnz_J={res['nnz_J']}, "
                                    f"nnz_H={res['nnz_H']})",
-                       "sharding": "single GPU" if n_gpus == 1 else f"mesh intervals over {n_gpus} GPUs, one pk_cycle launch per "
-                                                                    f"rank, RCCL {res['exchange']} of the owned runs of grad/g/J/H "
-                                                                    f"(+ the partial sums)",
+                       "sharding": "single GPU" if n_gpus == 1 else SHARDING_NOTE[res["exchange"]].format(n=n_gpus),
                        "tiles": res["tiles"], "intervals_per_wave": res["ipw"],
                        "inputs": "example guess*(1+1e-3 U(-1,1)) seed 0; lambda N(0,1) seed 1; sigma 1"},
             "timing": {"region": f"{res['batches']} back-to-back batches of exactly {args.steps} cycles (>= {MIN_REGION_S * 1e3:.0f} ms "
@@ -508,21 +596,36 @@ def main():
                          "avg_launch_us": dom_us,
                          "frac_x_once": (x_once / (dom_us * 1e-6) / 1e9 / HBM_PEAK_GBPS if (x_once and dom_us) else None),
                          "algorithmic_bytes_per_launch_x_counted_once": x_once,
-                         "back_to_back_us_per_launch": b2b_us,
-                         "frac_back_to_back": (dom_bytes / (b2b_us * 1e-6) / 1e9 / HBM_PEAK_GBPS if b2b_us and dom == "pk_cycle" else None),
+                         "dispatch_isolated_us": res["dispatch_isolated_us"],
+                         "frac_dispatch_isolated": (dom_bytes / (res["dispatch_isolated_us"] * 1e-6) / 1e9 / HBM_PEAK_GBPS
+                                                    if res["dispatch_isolated_us"] else None),
                          "dispatch_in_flight_us": res["dispatch_in_flight_us"],
                          "dispatch_samples_isolated_in_flight": res["dispatch_samples"],
-                         "timing": ("avg_launch_us: HIP start / stop events attached to the dispatch (hipExtModuleLaunchKernel) on "
-                                    "the launch stream, stream idle before each of the sampled launches -- the kernel's own "
-                                    "duration, as a kernel trace (rocprofv3 --kernel-trace) measures it; "
-                                    "back_to_back_us_per_launch: median batch / steps of the timed region (launch + gap to the "
-                                    "next launch when launches are queued back to back, where consecutive launches overlap "
-                                    "their start-up and drain); dispatch_in_flight_us: the same per-dispatch events on every "
-                                    "64th launch of a back-to-back run (includes the wait for the previous launch's tail)")},
+                         "timing": ("avg_launch_us: HIP events on the launch stream around every batch of the timed region, median "
+                                    "batch / steps -- one launch plus the gap to the next one, i.e. an upper bound of the "
+                                    "kernel's own duration in this run (the launches of a stream do not overlap); "
+                                    "dispatch_isolated_us: start / stop events attached to the dispatch "
+                                    "(hipExtModuleLaunchKernel), stream idle before each sampled launch; dispatch_in_flight_us: "
+                                    "the same per-dispatch events on every 64th launch of a back-to-back run (start is stamped "
+                                    "when the packet is taken up, before the launch ahead of it has drained).  A kernel trace "
+                                    "(rocprofv3) slows the loop it observes (profiles/README.md): its per-kernel average lies "
+                                    "between these figures"
+                                    if (dom == "pk_cycle" and n_gpus == 1) else
+                                    "avg_launch_us: start / stop events attached to the dispatch, stream idle before each "
+                                    "sampled launch")},
             "kernels_only_without_exchange": (None if res["no_exchange_ms_per_step"] is None else {
                 "value": n_gpus * 1e3 / res["no_exchange_ms_per_step"], "unit": "12k-node-equivalent cycles/s",
                 "note": "rank 0's clock around the same per-rank pk_cycle launches with no collective "
                         "(every rank keeps its own slices of grad/g/J/H)"}),
+            "exchange_forms": (None if res["exchange_forms_ms_per_step"] is None else {
+                "ms_per_step": res["exchange_forms_ms_per_step"],
+                "equivalent_cycles_per_s": {k: (n_gpus * 1e3 / v if isinstance(v, float) else v)
+                                            for k, v in res["exchange_forms_ms_per_step"].items()},
+                "note": "sums: slices stay in each GPU's HBM, only the sums over all nodes are exchanged (pk_xchg, peer "
+                        "mailboxes); direct: reassembly on rank 0's GPU by peer stores over xGMI; gather: RCCL gather of "
+                        "the packed runs to rank 0.  The reassembling forms move one shard per peer into ONE GPU every "
+                        "cycle and are bound by that GPU's xGMI links"}),
+            "ranks": res["ranks"],
             "kernel_us": res["kernel_us"],
             "cycle_algorithmic_bytes": res["bytes"]["cycle"],
             "setup_s": res["setup_s"], "compile_s_in_setup": res["compile_s_in_setup"],
@@ -545,6 +648,8 @@ def main():
                 line["speedup_basis"] = ("end_to_end.fresh_arrays (host arrays in and out, like the CPU baseline's cycle) / "
                                          "cpu_baseline")
             line["device_resident_ratio_vs_cpu_baseline"] = value / cb["value"]
+        if not args.no_extra and n_gpus > 1:
+            line["other_workloads"] = strong
         if not args.no_extra and n_gpus == 1:
             extra = {}
             for nm, iv in (("brachistochrone", 1250), ("brachistochrone", 200), ("two_stage_rocket", 1000),

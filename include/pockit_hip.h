@@ -132,7 +132,9 @@ int pk_eval_cycle(pk_ctx* ctx, const double* x, const double* lambda, double sig
 int pk_same_x(pk_ctx* ctx, const double* x);
 int pk_prepare_x(pk_ctx* ctx, const double* x);
 int pk_fetch(pk_ctx* ctx, int what, double* out);
-int pk_eval_hess_prepared(pk_ctx* ctx, const double* lambda, double sigma, double* vals);
+int pk_eval_hess_prepared(pk_ctx* ctx, const double* lambda /* NULL: staged */, double sigma, double* vals);
+/* queue the upload of the next Hessian's multipliers and return (the x check then overlaps the DMA) */
+int pk_stage_lambda(pk_ctx* ctx, const double* lambda);
 int pk_set_result_targets(pk_ctx* ctx, double* f, double* grad, double* g, double* jac, double* hess);
 int pk_result_location(pk_ctx* ctx, int what /* 0..4 */, double** ptr);
 int pk_set_host_mode(pk_ctx* ctx, int prefetch, int host_direct);
@@ -156,14 +158,16 @@ int pk_eval_hessc_dev(pk_ctx* ctx, const double* d_x, const double* d_lambda, do
 /* Mesh error estimation (reference: phasebase.py:1339-1372
  * _error_estimation_data_continuous, called by check_continuous / refine_continuous, phasebase.py:1374-1437,
  * 1522-1617): every mesh interval is re-collocated with one more point; the kernel (pk_err, one wavefront per
- * interval) interpolates states/controls to the augmented nodes, evaluates the dynamics there and returns both
+ * group of intervals) interpolates states/controls to the augmented nodes, evaluates the dynamics there and returns both
  * sides of the integral-form collocation equation,  T = T_aug x  and  I = dt (I_aug d/2) f, per phase as
  * [n_x][rows] (rows = sum_j (K_j + 1) for LGR, sum_j K_j for LGL).  The per-interval comparison and the
  * hp-refinement decision are host logic (pockit_amd/refine.py).
- * ``intervals``: array of PkErrIv (csrc/pk_abi.h), padded per phase to a multiple of 4 records with K = 0;
+ * ``intervals``: one PkErrIv (csrc/pk_abi.h) per mesh interval; ``groups``: (first record, count) pairs -- the run of
+ * consecutive intervals of one phase and one K that ONE wavefront handles (K + 1 lanes per interval), padded per phase to a
+ * multiple of 4 groups with count 0;
  * ``tables``: the interpolation / translation / integration blocks they index; ``n_out``: doubles per output. */
-int pk_set_mesh_error_tables(pk_ctx* ctx, const void* intervals, int32_t n_intervals, const double* tables,
-                             int64_t n_tables, int64_t n_out);
+int pk_set_mesh_error_tables(pk_ctx* ctx, const void* intervals, int32_t n_intervals, const int32_t* groups,
+                             int32_t n_groups, const double* tables, int64_t n_tables, int64_t n_out);
 int pk_eval_mesh_error(pk_ctx* ctx, const double* x, double* T /* n_out */, double* I /* n_out */);
 int pk_eval_mesh_error_dev(pk_ctx* ctx, const double* d_x, double* d_T, double* d_I, void* stream);
 
@@ -211,9 +215,27 @@ int pk_set_shard(pk_ctx* ctx, int secondary, int external_prepass, double* d_int
 int pk_eval_integrals_dev(pk_ctx* ctx, const double* d_x, void* stream);
 int pk_eval_f_from_integrals_dev(pk_ctx* ctx, const double* d_x, double* d_f, void* stream);
 
+/* Sharded cycles without a collective in the data path.  Every rank leaves its shard's slices of grad f / g / J / H in
+ * its own HBM (pk_eval_cycle_dev on its tiles); what couples the shards is the handful of sums over all nodes -- the
+ * integrals (-> f) and the gradient entries of t0 / tf / static parameters.  pk_exchange_sums_dev posts this rank's
+ * partial vector into every peer's mailbox (peer-mapped fine-grained device memory: pk_device_alloc + pk_ipc_export on
+ * the owner, pk_ipc_open on the peers), waits for theirs and adds them in rank order inside ONE one-workgroup launch.
+ * pk_set_shared_grad_target redirects a shard's partial sums of the shared gradient slots (used when its gradient
+ * output points at another GPU's buffer: the reassembly of the triplets on one GPU by direct peer stores).
+ * pk_copy_runs_dev is the pack / unpack pass of the RCCL gather / all-gather forms of the reassembly (A/B). */
+int pk_device_alloc(pk_ctx* ctx, size_t bytes, int finegrained, void** out);
+int pk_device_free(pk_ctx* ctx, void* p);
+int pk_ipc_export(pk_ctx* ctx, void* dptr, void* handle64 /* 64 bytes out */);
+int pk_ipc_open(pk_ctx* ctx, const void* handle64, void** out);
+int pk_ipc_close(pk_ctx* ctx, void* p);
+int pk_set_shared_grad_target(pk_ctx* ctx, double* d_grad_shared);
+int pk_set_exchange(pk_ctx* ctx, int world, int rank, const void* d_boxes, const int32_t* d_idx, int n_sh, int stride);
+int pk_exchange_sums_dev(pk_ctx* ctx, const double* d_x, double* d_grad, double* d_f, int epoch, int write_f, void* stream);
+int pk_copy_runs_dev(pk_ctx* ctx, const int64_t* d_table, int n_chunks, const double* d_src, double* d_dst, void* stream);
+
 /* HIP-event timing of the individual kernels on the launch stream.
  * kernel ids: 0 pk_int, 1 pk_fin, 2 pk_g, 3 pk_grad, 4 pk_jac, 5 pk_hess, 6 pk_xall, 7 pk_aux, 8 pk_outer,
- * 9 pk_hessc, 10 pk_err, 11 pk_csr, 12 pk_cycle.  pk_profile_sampling(n): only every n-th launch of a selected kernel is timed (a timed
+ * 9 pk_hessc, 10 pk_err, 11 pk_csr, 12 pk_cycle, 13 pk_xchg, 14 pk_runs.  pk_profile_sampling(n): only every n-th launch of a selected kernel is timed (a timed
  * launch costs ~2-3 us more than a plain one, so timing every launch slows the loop being measured). */
 int pk_profile(pk_ctx* ctx, int kernel_mask /* bit k: time kernel k; 0 = off */);
 int pk_profile_sampling(pk_ctx* ctx, int period);

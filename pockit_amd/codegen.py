@@ -411,9 +411,9 @@ class ModelSource:
         self.lds_e = 64 * max([1] + [2 * pp.nx + pp.nu for pp in plan.phase_plans])
         S.append(f"  static constexpr int LDS_G = {self.lds_g}, LDS_J = {self.lds_j}, LDS_H = {self.lds_h}, "
                  f"LDS_X = {self.lds_x}, LDS_E = {self.lds_e};")
-        S.append("  __device__ static __forceinline__ void interval_err(int phase, const PkArgs& A, const PkErrIv& iv, "
-                 "bool valid, double* __restrict__ lds, int lane) {")
-        S.append(switch("pk::interval_err<{P}>(A, iv, valid, lds, lane)"))
+        S.append("  __device__ static __forceinline__ void interval_err(int phase, const PkArgs& A, int first, int cnt, "
+                 "double* __restrict__ lds, int lane) {")
+        S.append(switch("pk::interval_err<{P}>(A, first, cnt, lds, lane)"))
         S.append("  }")
         targets = [(n, f"pk::tile_{n}<{{P}}>") for n in ("int", "g", "grad", "jac", "hess", "aux", "hessc")]
         targets += [("xall", "pk::tile_xall<{P}, 0>"), ("xall1", "pk::tile_xall<{P}, 1>"),

@@ -113,6 +113,7 @@ struct PkErrIv {
 };
 
 #define PK_MAX_PHASES 8
+#define PK_MAX_RANKS 64       // ranks of one sharded NLP (pk_xchg: one polling thread per peer)
 
 // pk_cycle's in-launch hand-off: a slot of cpart / cpart2 is either PK_EMPTY (a quiet-NaN pattern no arithmetic
 // produces) or the value a tile workgroup published during the current launch.
@@ -143,6 +144,7 @@ struct PkArgs {
   unsigned long long* cpart;   // pk_cycle only: the same two arrays as 64-bit patterns, handed from the tile workgroups
   unsigned long long* cpart2;  // to the finalize workgroup INSIDE one launch (every slot holds PK_EMPTY between launches)
   const PkErrIv* erriv;   // mesh error estimation (pk_err only)
+  const int32_t* errgrp;  // (first record, count) of the run of intervals every wavefront of pk_err handles
   const double* errdb;
   double* o_errT;         // T_aug x      per phase [n_x][rows]
   double* o_errI;         // dt I_aug f   per phase [n_x][rows]
@@ -151,6 +153,15 @@ struct PkArgs {
   const int32_t* csr_perm;
   double* csr_out;
   unsigned long long* trace;   // developer tracing (models generated with POCKIT_AMD_TRACE=1): [tile][16] s_memtime marks
+  double* o_gshared;      // where the gradient slots shared by all nodes go (NULL: o_grad) -- a shard whose o_grad is
+                          // another GPU's buffer keeps its partial sums of those slots local
+  // pk_xchg: exchange of the shard's partial sums [integrals | shared gradient slots] through peer-mapped mailboxes
+  unsigned long long* const* xc_box;   // [world] base of every rank's mailbox as mapped in this process (own entry: own)
+  const int32_t* xc_idx;  // NLP index of every shared gradient slot
+  // pk_runs: copy of contiguous runs, table of (src offset, dst offset, length) per chunk
+  const int64_t* rc_table;
+  const double* rc_src;
+  double* rc_dst;
   int32_t n_tiles, n_items;
   int32_t n_items2, pad0;
   int32_t n_phase, n;
@@ -159,7 +170,9 @@ struct PkArgs {
   int32_t flags;          // bit 0: pk_fin writes f; bit 1: secondary shard (no system-level / boundary work);
                           // bit 3: pk_fin reduces the integrals into Ibuf; bit 4: pk_fin reduces the gradient slots
   int32_t n_outer;
-  int32_t n_erriv;
+  int32_t n_erriv;        // (pk_err: number of wave groups)
   int32_t n_csr;          // CSR entries
+  int32_t xc_world, xc_rank, xc_epoch, xc_nsh;   // ranks, this rank, cycle number (>= 1), number of shared gradient slots
+  int32_t xc_stride, rc_n;                       // mailbox words per sender (multiple of 16); chunks of the run table
   PkPhase ph[PK_MAX_PHASES];   // the phases by value (kernarg segment): no dependent global load
 };

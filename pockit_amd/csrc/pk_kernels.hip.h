@@ -1262,19 +1262,23 @@ __device__ __forceinline__ void kernel_aux(const PkArgs& A) {
 
 
 // ---- mesh error estimation (reference: phasebase.py:1339-1372  _error_estimation_data_continuous) -----
-// One wavefront per mesh interval.  The interval's K (+1) state values and K control values are
-// staged in LDS, interpolated to the K + 1 nodes of the augmented rule (lane = augmented node), the
-// dynamics are evaluated there, and the two sides of the integral-form collocation equation on the
-// augmented rule are written out:  T_aug x  and  dt (I_aug d/2) f.  The host compares them per
-// interval (np.allclose semantics) and runs the hp-refinement logic (pockit_amd/refine.py).
+// One wavefront per GROUP of consecutive mesh intervals of one phase and one K: W = K + 1 lanes per interval (the
+// interval's augmented nodes), floor(64 / W) intervals per wave -- at K = 8 seven intervals share a wave instead of one
+// wave of 9 live lanes each.  Per interval: its K (+1) state values and K control values are staged in LDS, interpolated
+// to the K + 1 nodes of the augmented rule (lane = augmented node), the dynamics are evaluated there, and the two sides of
+// the integral-form collocation equation on the augmented rule are written out:  T_aug x  and  dt (I_aug d/2) f.  The
+// host compares them per interval (np.allclose semantics) and runs the hp-refinement logic (pockit_amd/refine.py).
 // LDS per wave: (2 NX + NU) x 64 doubles, private to the wave (no workgroup barrier between the three steps).
 template <class P>
-__device__ __forceinline__ void interval_err(const PkArgs& A, const PkErrIv& iv, bool valid,
-                                             double* __restrict__ lds, int lane) {
+__device__ __forceinline__ void interval_err(const PkArgs& A, int first, int cnt, double* __restrict__ lds, int lane) {
   const PkPhase& ph = A.ph[P::INDEX];
   double s[PK_NS], dt, mt;
   phase_scalars<P>(A, ph, s, dt, mt);
-  const int K = iv.K;
+  const int K = A.erriv[first].K;                       // wave-uniform (all intervals of a group share phase and K)
+  const int W = K + 1;
+  const int jj = lane / W, a = lane - jj * W;           // interval of the group, augmented node / row / slot within it
+  const bool valid = jj < cnt;
+  const PkErrIv iv = A.erriv[first + (valid ? jj : 0)];
   const int ncx = K + 1 - P::SCHEME, na = K + 1, nr = K + 1 - P::SCHEME;
   const double* __restrict__ Vx = A.errdb + iv.tab_off;
   const double* __restrict__ Vu = Vx + na * ncx;
@@ -1283,66 +1287,66 @@ __device__ __forceinline__ void interval_err(const PkArgs& A, const PkErrIv& iv,
   const double* __restrict__ xp = A.x + ph.x_off;
   const double* __restrict__ up = xp + P::NX * ph.state_len;
   const int back_slot = P::SCHEME ? ph.L_m - 1 : ph.L_m;
-  double* __restrict__ xs = lds;
-  double* __restrict__ us = lds + P::NX * PK_WAVE;
-  double* __restrict__ fs = lds + (P::NX + P::NU) * PK_WAVE;
-  if (valid && lane < ncx) {
-    const int slot = iv.lm + lane;
+  double* __restrict__ xs = lds + jj * W;               // this interval's columns of the wave's [row][64] arrays
+  double* __restrict__ us = lds + P::NX * PK_WAVE + jj * W;
+  double* __restrict__ fs = lds + (P::NX + P::NU) * PK_WAVE + jj * W;
+  if (valid && a < ncx) {
+    const int slot = iv.lm + a;
 #pragma unroll
     for (int i = 0; i < P::NX; ++i) {
       double v = xp[i * ph.state_len + slot];
       if (slot == 0) v = P::front_value(i, v, s);
       if (slot == back_slot) v = P::back_value(i, v, s);
-      xs[i * PK_WAVE + lane] = v;
+      xs[i * PK_WAVE + a] = v;
     }
   }
-  if (valid && lane < K) {
+  if (valid && a < K) {
 #pragma unroll
-    for (int i = 0; i < P::NU; ++i) us[i * PK_WAVE + lane] = up[i * ph.L_m + iv.lm + lane];
+    for (int i = 0; i < P::NU; ++i) us[i * PK_WAVE + a] = up[i * ph.L_m + iv.lm + a];
   }
   wave_lds_sync();       // (a wave stages for itself only)
-  if (valid && lane < na) {
-    double a[P::NARG], o[P::G_NOUT];
+  if (valid) {           // (a < na always)
+    double arg[P::NARG], o[P::G_NOUT];
 #pragma unroll
-    for (int i = 0; i < P::NX; ++i) a[i] = 0.0;
+    for (int i = 0; i < P::NX; ++i) arg[i] = 0.0;
 #pragma unroll
-    for (int i = 0; i < P::NU; ++i) a[P::NX + i] = 0.0;
+    for (int i = 0; i < P::NU; ++i) arg[P::NX + i] = 0.0;
     for (int c = 0; c < ncx; ++c) {
-      const double v = Vx[lane * ncx + c];
+      const double v = Vx[a * ncx + c];
 #pragma unroll
-      for (int i = 0; i < P::NX; ++i) a[i] += v * xs[i * PK_WAVE + c];
+      for (int i = 0; i < P::NX; ++i) arg[i] += v * xs[i * PK_WAVE + c];
     }
     for (int c = 0; c < K; ++c) {
-      const double v = Vu[lane * K + c];
+      const double v = Vu[a * K + c];
 #pragma unroll
-      for (int i = 0; i < P::NU; ++i) a[P::NX + i] += v * us[i * PK_WAVE + c];
+      for (int i = 0; i < P::NU; ++i) arg[P::NX + i] += v * us[i * PK_WAVE + c];
     }
-    const double tau = A.errdb[iv.tau_off + lane];
-    a[P::NX + P::NU] = (tau - 0.5) * dt + mt;
+    const double tau = A.errdb[iv.tau_off + a];
+    arg[P::NX + P::NU] = (tau - 0.5) * dt + mt;
 #pragma unroll
-    for (int i = 0; i < P::NS; ++i) a[P::NX + P::NU + 1 + i] = s[i];
-    P::mid_g(a, o);
+    for (int i = 0; i < P::NS; ++i) arg[P::NX + P::NU + 1 + i] = s[i];
+    P::mid_g(arg, o);
 #pragma unroll
-    for (int i = 0; i < P::NX; ++i) fs[i * PK_WAVE + lane] = o[i];
+    for (int i = 0; i < P::NX; ++i) fs[i * PK_WAVE + a] = o[i];
   }
   wave_lds_sync();       // (a wave stages for itself only)
-  if (valid && lane < nr) {
+  if (valid && a < nr) {
     double tx[P::NX], itf[P::NX];
 #pragma unroll
     for (int i = 0; i < P::NX; ++i) tx[i] = itf[i] = 0.0;
     for (int c = 0; c < ncx; ++c) {
-      const double v = Tm[lane * ncx + c];
+      const double v = Tm[a * ncx + c];
 #pragma unroll
       for (int i = 0; i < P::NX; ++i) tx[i] += v * xs[i * PK_WAVE + c];
     }
     for (int c = 0; c < na; ++c) {
-      const double v = Im[lane * na + c] * iv.width * 0.5;
+      const double v = Im[a * na + c] * iv.width * 0.5;
 #pragma unroll
       for (int i = 0; i < P::NX; ++i) itf[i] += v * fs[i * PK_WAVE + c];
     }
 #pragma unroll
     for (int i = 0; i < P::NX; ++i) {
-      const int64_t pos = iv.out_off + (int64_t)i * iv.rows + iv.row0 + lane;
+      const int64_t pos = iv.out_off + (int64_t)i * iv.rows + iv.row0 + a;
       put(&A.o_errT[pos], tx[i]);
       put(&A.o_errI[pos], itf[i] * dt);
     }
@@ -1354,10 +1358,11 @@ __device__ __forceinline__ void kernel_err(const PkArgs& A) {
   extern __shared__ double pk_lds[];
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
   const int g = (int)blockIdx.x * PK_WAVES_PER_BLOCK + wave;
-  const bool valid = g < A.n_erriv;
-  // a workgroup never mixes phases (the host pads every phase to a multiple of 4 intervals with K = 0 records)
-  const PkErrIv iv = A.erriv[valid ? g : (A.n_erriv > 0 ? A.n_erriv - 1 : 0)];
-  Gen::interval_err(iv.phase, A, iv, valid && iv.K > 0, pk_lds + wave * Gen::LDS_E, lane);
+  if (g >= A.n_erriv) return;
+  // a workgroup never mixes phases (the host pads every phase to a multiple of 4 groups with count 0)
+  const int first = A.errgrp[2 * g], cnt = A.errgrp[2 * g + 1];
+  if (cnt <= 0) return;
+  Gen::interval_err(A.erriv[first].phase, A, first, cnt, pk_lds + wave * Gen::LDS_E, lane);
 }
 
 // Triplet list -> CSR values on device (hand J / H to a GPU linear solver without a
@@ -1520,8 +1525,9 @@ __device__ __forceinline__ void fin_body(const PkArgs& A) {
   __shared__ double tot[PK_NPHASE_DIM * PK_NRED];
   __shared__ double dts[PK_NPHASE_DIM];
   if ((int)threadIdx.x < PK_NPHASE) dts[threadIdx.x] = Gen::phase_dt(threadIdx.x, A);   // one phase per thread
+  double* __restrict__ gsh = A.o_gshared ? A.o_gshared : A.o_grad;     // (see PkArgs.o_gshared)
   if (A.flags & 16)                                                                       // dead / shared slots start at 0
-    for (int z = threadIdx.x; z < A.n_gz; z += PK_BLOCK) A.o_grad[A.ib[A.gz_off + z]] = 0.0;
+    for (int z = threadIdx.x; z < A.n_gz; z += PK_BLOCK) gsh[A.ib[A.gz_off + z]] = 0.0;
   if (A.flags & 8) {
     for (int n = 0; n < Gen::N_INT; ++n) {
       const int k = Gen::int_phase(n);
@@ -1542,11 +1548,11 @@ __device__ __forceinline__ void fin_body(const PkArgs& A) {
   if (A.flags & 1) A.o_f[0] = Gen::sys_objective(sy);
   if (A.flags & 16) {
     for (int k = 0; k < PK_NPHASE; ++k)
-      for (int r = 0; r < Gen::gr_nr(k); ++r) A.o_grad[A.ib[A.ph[k].red_off + r]] += tot[k * PK_NRED + r];
+      for (int r = 0; r < Gen::gr_nr(k); ++r) gsh[A.ib[A.ph[k].red_off + r]] += tot[k * PK_NRED + r];
     if (!(A.flags & 2)) {
       double gs[PK_NS];
       Gen::sys_grad_static(sy, gs);
-      for (int i = 0; i < A.n_s; ++i) A.o_grad[A.l_s + i] += gs[i];
+      for (int i = 0; i < A.n_s; ++i) gsh[A.l_s + i] += gs[i];
     }
   }
 }
@@ -1651,7 +1657,82 @@ __device__ __forceinline__ void fin_handoff(const PkArgs& A) {
     for (int row = 0; row < Gen::N_ROWS; ++row)
       if (Gen::row_arr(row) && ridx[row] == idx) v += tot[row];
     if (idx >= A.l_s && idx < A.l_s + A.n_s) v += gsh[idx - A.l_s];
-    A.o_grad[idx] = v;
+    (A.o_gshared ? A.o_gshared : A.o_grad)[idx] = v;
+  }
+}
+
+// ============================================================================================
+// pk_xchg: the ONLY exchange a sharded cycle needs -- the sums over all nodes.  Every rank evaluates its share of the
+// mesh intervals into its own HBM (pk_cycle on the shard's tiles); what couples the shards is a handful of doubles:
+// the integrals (-> f) and the gradient entries of t0 / tf / static parameters.  Each rank posts its partial vector
+// [integrals | shared gradient slots] into every peer's mailbox (peer-mapped fine-grained device memory, stores over
+// xGMI), raises a flag (the cycle number), waits for the flags of all peers, and adds the vectors IN RANK ORDER
+// (every rank gets bit-identical sums) -- one workgroup, no collective library call, no host round trip.
+// Mailbox of a rank: [parity 2][sender world][xc_stride] words, word 0 of a sender's slot = flag, data from word 1.
+// Two parities: a rank that is one cycle ahead posts into the other half (it cannot be two ahead: it needs every
+// peer's flag of the cycle in between).  The poll is bounded (then the sums read NaN).
+// ============================================================================================
+__device__ __forceinline__ void sys_store(unsigned long long* p, unsigned long long v) {
+  __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+__device__ __forceinline__ unsigned long long sys_load(unsigned long long* p) {
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+template <class Gen>
+__device__ __forceinline__ void kernel_xchg(const PkArgs& A) {
+  constexpr int CAP = 512;                              // doubles of a partial vector held in LDS (host checks)
+  __shared__ double mine[CAP];
+  __shared__ double total[CAP];
+  __shared__ int late;
+  const int t = threadIdx.x, W = A.xc_world, me = A.xc_rank;
+  const int n_I = PK_NI, n_small = n_I + A.xc_nsh;
+  const size_t half = (size_t)(A.xc_epoch & 1) * W * A.xc_stride;
+  double* __restrict__ gsh = A.o_gshared ? A.o_gshared : A.o_grad;
+  if (t == 0) late = 0;
+  for (int i = t; i < n_small; i += PK_BLOCK) {
+    const double v = i < n_I ? A.Ibuf[i] : gsh[A.xc_idx[i - n_I]];
+    mine[i] = v;
+    for (int q = 0; q < W; ++q)
+      if (q != me) sys_store(A.xc_box[q] + half + (size_t)me * A.xc_stride + 1 + i, (unsigned long long)__double_as_longlong(v));
+  }
+  __threadfence_system();                               // my data before my flags, for every observer
+  __syncthreads();
+  if (t < W && t != me) sys_store(A.xc_box[t] + half + (size_t)me * A.xc_stride, (unsigned long long)A.xc_epoch);
+  if (t < W && t != me) {                               // one polling thread per peer
+    unsigned long long* flag = A.xc_box[me] + half + (size_t)t * A.xc_stride;
+    int tries = 0;
+    while (sys_load(flag) != (unsigned long long)A.xc_epoch && ++tries < PK_POLL_LIMIT) __builtin_amdgcn_s_sleep(PK_POLL_SLEEP);
+    if (tries >= PK_POLL_LIMIT) late = 1;
+  }
+  __threadfence_system();
+  __syncthreads();
+  for (int i = t; i < n_small; i += PK_BLOCK) {
+    double sum = 0.0;
+    for (int q = 0; q < W; ++q)                         // rank order: the same additions on every rank
+      sum += q == me ? mine[i]
+                     : __longlong_as_double((long long)sys_load(A.xc_box[me] + half + (size_t)q * A.xc_stride + 1 + i));
+    if (late) sum = __longlong_as_double(0x7FF8000000000000ll);
+    total[i] = sum;
+    if (i < n_I) A.Ibuf[i] = sum;
+    else gsh[A.xc_idx[i - n_I]] = sum;
+  }
+  __syncthreads();
+  if (t == 0 && (A.flags & 1)) {
+    const PkSys sy{A.x + A.l_s, total, A.sigma, A.lam};
+    A.o_f[0] = Gen::sys_objective(sy);                  // systembase.py:592-605, on the global integrals
+  }
+}
+
+// pk_runs: dst[dst_off + i] = src[src_off + i] for every chunk (src_off, dst_off, len) of the table -- the pack /
+// unpack passes of the RCCL gather / all-gather reassembly (A/B forms of the exchange): a rank's owned output positions
+// are a few dozen contiguous runs, cut into chunks of at most 16 Ki doubles by the host, one workgroup per chunk.
+__device__ __forceinline__ void kernel_runs(const PkArgs& A) {
+  for (int c = blockIdx.x; c < A.rc_n; c += gridDim.x) {
+    const int64_t so = A.rc_table[3 * c], dofs = A.rc_table[3 * c + 1], len = A.rc_table[3 * c + 2];
+    const double* __restrict__ src = A.rc_src + so;
+    double* __restrict__ dst = A.rc_dst + dofs;
+    for (int64_t i = threadIdx.x; i < len; i += PK_BLOCK) dst[i] = src[i];
   }
 }
 
@@ -1675,6 +1756,8 @@ __device__ __forceinline__ void kernel_fin(const PkArgs& A) {
   extern "C" __global__ __launch_bounds__(PK_BLOCK) void pk_hessc(PkArgs A) { pk::kernel_hessc<GEN>(A); } \
   extern "C" __global__ __launch_bounds__(PK_BLOCK) void pk_err(PkArgs A) { pk::kernel_err<GEN>(A); }     \
   extern "C" __global__ __launch_bounds__(PK_BLOCK) void pk_csr(PkArgs A) { pk::kernel_csr(A); }             \
+  extern "C" __global__ __launch_bounds__(PK_BLOCK) void pk_xchg(PkArgs A) { pk::kernel_xchg<GEN>(A); }     \
+  extern "C" __global__ __launch_bounds__(PK_BLOCK) void pk_runs(PkArgs A) { pk::kernel_runs(A); }           \
   extern "C" __global__ __launch_bounds__(PK_BLOCK) void pk_cycle(const PkTile* pre_tile, int32_t pre_n_tiles,  \
                                                                   int32_t pre_flags, int32_t pre_grid, PkArgs A) { \
     pk::kernel_cycle<GEN>(pre_tile, pre_n_tiles, pre_flags, pre_grid, A);                                        \

@@ -36,9 +36,9 @@
 
 namespace {
 
-enum { K_INT = 0, K_FIN, K_G, K_GRAD, K_JAC, K_HESS, K_XALL, K_AUX, K_OUTER, K_HESSC, K_ERR, K_CSR, K_CYCLE, K_COUNT };
+enum { K_INT = 0, K_FIN, K_G, K_GRAD, K_JAC, K_HESS, K_XALL, K_AUX, K_OUTER, K_HESSC, K_ERR, K_CSR, K_CYCLE, K_XCHG, K_RUNS, K_COUNT };
 const char* const kKernelNames[K_COUNT] = {"pk_int", "pk_fin", "pk_g", "pk_grad", "pk_jac", "pk_hess", "pk_xall",
-                                           "pk_aux", "pk_outer", "pk_hessc", "pk_err", "pk_csr", "pk_cycle"};
+                                           "pk_aux", "pk_outer", "pk_hessc", "pk_err", "pk_csr", "pk_cycle", "pk_xchg", "pk_runs"};
 enum { F_WRITE_F = 1, F_SECONDARY = 2, F_FIN_INT = 8, F_FIN_GRAD = 16, F_SPLIT = 32 };
 
 thread_local std::string g_create_error;
@@ -58,12 +58,17 @@ struct pk_ctx {
   int shard_flags = 0;          // OR-ed into PkArgs.flags (bit 1: secondary shard)
   bool external_prepass = false; // sharded mode: the caller all-reduces the integrals itself
   double* ext_I = nullptr;      // caller-owned integral buffer (sharded mode)
+  double* gshared = nullptr;    // pk_set_shared_grad_target: where the shared gradient slots go (NULL: the gradient itself)
+  // pk_set_exchange: peer-mapped mailboxes of the partial-sum exchange (pk_xchg)
+  const unsigned long long* const* xc_box = nullptr;
+  const int32_t* xc_idx = nullptr;
+  int32_t xc_world = 0, xc_rank = 0, xc_nsh = 0, xc_stride = 0;
   bool split_xall = false;      // pk_xall with two waves per tile (values / Jacobian), see pk_set_problem
   int cycle_mode = 1;           // 1: single-launch pk_cycle; 0: pk_xall + pk_hess (pk_set_cycle_mode)
   unsigned long long *d_cpart = nullptr, *d_cpart2 = nullptr;   // pk_cycle's hand-off slots (PK_EMPTY between launches)
   unsigned profile_mask = 0;
   unsigned profile_period = 1;  // time every n-th launch of a selected kernel
-  unsigned profile_seen[16] = {};
+  unsigned profile_seen[K_COUNT] = {};
   int debug_flags = 0;          // diagnostic kernel switches (POCKIT_AMD_DEBUG_FLAGS), never set in production
   pk_model_desc md{};
   // problem
@@ -96,6 +101,7 @@ struct pk_ctx {
   } csr[2];
   // mesh error estimation (pk_set_mesh_error_tables)
   void* d_erriv = nullptr;
+  int32_t* d_errgrp = nullptr;     // (first record, count) per wavefront of pk_err
   double *d_errdb = nullptr, *d_errT = nullptr, *d_errI = nullptr;
   int32_t n_erriv = 0;
   int64_t n_err_out = 0;
@@ -115,6 +121,7 @@ struct pk_ctx {
   int xbuf = 0, lambuf = 0;
   double* h_x = nullptr;                   // the staging buffer holding the x of the last pk_prepare_x (pk_same_x)
   bool x_valid = false;
+  bool lam_staged = false;                 // pk_stage_lambda ran, pk_eval_hess_prepared has not consumed it yet
   double* h_out[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
   double* target[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};   // pk_set_result_targets (NULL: h_out[k])
   double* landed[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};   // where result k of the current iterate went
@@ -160,7 +167,7 @@ void release(T*& p) {
 
 void free_problem(pk_ctx* c) {
   release(c->d_phases); release(c->d_tiles); release(c->d_kinds); release(c->d_items_jac); release(c->d_items_hess); release(c->d_items_aux); release(c->d_outer); release(c->d_aux); release(c->d_items_hessc); release(c->d_Hc);
-  release(c->d_erriv); release(c->d_errdb); release(c->d_errT); release(c->d_errI);
+  release(c->d_erriv); release(c->d_errgrp); release(c->d_errdb); release(c->d_errT); release(c->d_errI);
   c->n_erriv = 0; c->n_err_out = 0;
   drop_cycle_graph(c);
   release(c->d_trace);
@@ -217,6 +224,7 @@ PkArgs base_args(pk_ctx* c, const double* d_x, const double* d_lam, double sigma
   A.gz_off = c->gz_off; A.n_gz = c->n_gz; A.flags = c->shard_flags | c->debug_flags;
   for (size_t k = 0; k < c->h_phases.size(); ++k) A.ph[k] = c->h_phases[k];
   A.trace = c->d_trace;
+  A.o_gshared = c->gshared;
   return A;
 }
 
@@ -699,14 +707,14 @@ int pk_eval_hess_csr(pk_ctx* c, const double* x, const double* lambda, double si
 }
 
 // ---------------------------------------------------------------- mesh error estimation
-int pk_set_mesh_error_tables(pk_ctx* c, const void* intervals, int32_t n_intervals, const double* tables,
-                             int64_t n_tables, int64_t n_out) {
+int pk_set_mesh_error_tables(pk_ctx* c, const void* intervals, int32_t n_intervals, const int32_t* groups,
+                             int32_t n_groups, const double* tables, int64_t n_tables, int64_t n_out) {
   int rc = ready(c);
   if (rc) return rc;
-  if (!intervals || n_intervals <= 0 || !tables || n_tables <= 0 || n_out <= 0)
+  if (!intervals || n_intervals <= 0 || !groups || n_groups <= 0 || !tables || n_tables <= 0 || n_out <= 0)
     return fail(c, 70, "pk_set_mesh_error_tables: empty tables");
-  if (n_intervals % PK_WAVES_PER_BLOCK)
-    return fail(c, 71, "pk_set_mesh_error_tables: interval records must be padded to a multiple of %d per phase", PK_WAVES_PER_BLOCK);
+  if (n_groups % PK_WAVES_PER_BLOCK)
+    return fail(c, 71, "pk_set_mesh_error_tables: wave groups must be padded to a multiple of %d per phase", PK_WAVES_PER_BLOCK);
   if ((size_t)c->md.lds_e * PK_WAVES_PER_BLOCK * sizeof(double) > 160 * 1024)
     return fail(c, 72, "pk_set_mesh_error_tables: model needs more than 160 KiB of LDS per workgroup");
   // host-side validation of everything the kernel indexes with (a faulting kernel can take the node down)
@@ -714,7 +722,6 @@ int pk_set_mesh_error_tables(pk_ctx* c, const void* intervals, int32_t n_interva
   for (int32_t g = 0; g < n_intervals; ++g) {
     const PkErrIv& r = iv[g];
     if (r.phase < 0 || r.phase >= c->n_phase) return fail(c, 73, "pk_set_mesh_error_tables: record %d: bad phase", g);
-    if (r.K == 0) continue;   // padding
     const PkPhase& ph = c->h_phases[r.phase];
     const int na = r.K + 1, ncx = r.K + 1 - ph.scheme, nr = ncx;
     const int64_t tab = (int64_t)na * ncx + (int64_t)na * r.K + (int64_t)nr * ncx + (int64_t)nr * na;
@@ -723,17 +730,26 @@ int pk_set_mesh_error_tables(pk_ctx* c, const void* intervals, int32_t n_interva
         r.out_off < 0 || r.out_off + (int64_t)ph.n_x * r.rows > n_out)
       return fail(c, 74, "pk_set_mesh_error_tables: record %d is inconsistent with the problem", g);
   }
+  for (int32_t g = 0; g < n_groups; ++g) {     // a wave's intervals: in range, one phase, one K, K + 1 lanes each
+    const int32_t first = groups[2 * g], cnt = groups[2 * g + 1];
+    if (first < 0 || first >= n_intervals || cnt < 0 || first + cnt > n_intervals || cnt * (iv[first].K + 1) > PK_WAVE)
+      return fail(c, 76, "pk_set_mesh_error_tables: wave group %d is out of range", g);
+    for (int32_t j = 1; j < cnt; ++j)
+      if (iv[first + j].K != iv[first].K || iv[first + j].phase != iv[first].phase)
+        return fail(c, 76, "pk_set_mesh_error_tables: wave group %d mixes phases or orders", g);
+  }
   PK_HIP(c, hipSetDevice(c->device));
   PK_HIP(c, hipStreamSynchronize(c->stream));
-  release(c->d_erriv); release(c->d_errdb); release(c->d_errT); release(c->d_errI);
+  release(c->d_erriv); release(c->d_errgrp); release(c->d_errdb); release(c->d_errT); release(c->d_errI);
   c->n_erriv = 0; c->n_err_out = 0;
   if ((rc = upload(c, &c->d_erriv, intervals, sizeof(PkErrIv) * (size_t)n_intervals))) return rc;
+  if ((rc = upload(c, (void**)&c->d_errgrp, groups, sizeof(int32_t) * 2 * (size_t)n_groups))) return rc;
   if ((rc = upload(c, (void**)&c->d_errdb, tables, sizeof(double) * (size_t)n_tables))) return rc;
   PK_HIP(c, hipMalloc((void**)&c->d_errT, sizeof(double) * (size_t)n_out));
   PK_HIP(c, hipMalloc((void**)&c->d_errI, sizeof(double) * (size_t)n_out));
   PK_HIP(c, hipMemset(c->d_errT, 0, sizeof(double) * (size_t)n_out));
   PK_HIP(c, hipMemset(c->d_errI, 0, sizeof(double) * (size_t)n_out));
-  c->n_erriv = n_intervals;
+  c->n_erriv = n_groups;
   c->n_err_out = n_out;
   return 0;
 }
@@ -744,6 +760,7 @@ int pk_eval_mesh_error_dev(pk_ctx* c, const double* d_x, double* d_T, double* d_
   if (c->n_erriv <= 0) return fail(c, 75, "pk_eval_mesh_error: call pk_set_mesh_error_tables first");
   PkArgs A = base_args(c, d_x, nullptr, 0.0);
   A.erriv = (const PkErrIv*)c->d_erriv;
+  A.errgrp = c->d_errgrp;
   A.errdb = c->d_errdb;
   A.n_erriv = c->n_erriv;
   A.o_errT = d_T;
@@ -1010,14 +1027,28 @@ int pk_fetch(pk_ctx* c, int what, double* out) {
   return 0;
 }
 
-// Hessian on the x of the last pk_prepare_x (no re-upload of x); vals == NULL: the result stays where it landed
-int pk_eval_hess_prepared(pk_ctx* c, const double* lambda, double sigma, double* vals) {
+// Queue the upload of the multipliers of the next pk_eval_hess_prepared and return: the caller's check of x
+// (pk_same_x, a pass over n doubles) then runs while the DMA is in flight.
+int pk_stage_lambda(pk_ctx* c, const double* lambda) {
   int rc = ready(c);
   if (rc) return rc;
   if (!lambda) return fail(c, 60, "null host buffer");
-  if (!c->x_valid) return fail(c, 64, "pk_eval_hess_prepared: no prepared x (pk_prepare_x)");
   PK_HIP(c, hipSetDevice(c->device));
   if ((rc = stage_upload(c, c->h_lams, c->ev_lams, c->lambuf, lambda, c->d_lam, (size_t)c->m, nullptr))) return rc;
+  c->lam_staged = true;
+  return 0;
+}
+
+// Hessian on the x of the last pk_prepare_x (no re-upload of x); vals == NULL: the result stays where it landed;
+// lambda == NULL: the multipliers staged by pk_stage_lambda
+int pk_eval_hess_prepared(pk_ctx* c, const double* lambda, double sigma, double* vals) {
+  int rc = ready(c);
+  if (rc) return rc;
+  if (!lambda && !c->lam_staged) return fail(c, 60, "null host buffer (no multipliers staged either)");
+  if (!c->x_valid) return fail(c, 64, "pk_eval_hess_prepared: no prepared x (pk_prepare_x)");
+  PK_HIP(c, hipSetDevice(c->device));
+  if (lambda && (rc = stage_upload(c, c->h_lams, c->ev_lams, c->lambuf, lambda, c->d_lam, (size_t)c->m, nullptr))) return rc;
+  c->lam_staged = false;
   c->landed[4] = c->target[4] ? c->target[4] : c->h_out[4];
   c->enq[4] = false;
   if ((rc = pk_eval_hess_dev(c, c->d_x, c->d_lam, sigma, c->host_direct ? c->landed[4] : c->d_H, nullptr))) return rc;
@@ -1045,6 +1076,101 @@ int pk_host_buffer(pk_ctx* c, int what, double** ptr, int64_t* count) {
   *ptr = c->h_out[what];
   if (count) *count = cnt[what];
   return 0;
+}
+
+// ---------------------------------------------------------------- sharded cycles: peer memory + the exchange of the sums
+// Device memory of the caller's own (a mailbox, a reassembly buffer).  finegrained = 1: coherent with other GPUs and the
+// host WHILE kernels run (flags polled across devices); 0: ordinary device memory.
+int pk_device_alloc(pk_ctx* c, size_t bytes, int finegrained, void** out) {
+  if (!c) return fail(nullptr, 1, "null context");
+  if (!out) return fail(c, 60, "null output pointer");
+  PK_HIP(c, hipSetDevice(c->device));
+  if (finegrained) PK_HIP(c, hipExtMallocWithFlags(out, bytes ? bytes : 8, hipDeviceMallocFinegrained));
+  else PK_HIP(c, hipMalloc(out, bytes ? bytes : 8));
+  PK_HIP(c, hipMemset(*out, 0, bytes ? bytes : 8));
+  PK_HIP(c, hipDeviceSynchronize());
+  return 0;
+}
+
+int pk_device_free(pk_ctx* c, void* p) {
+  if (!c) return fail(nullptr, 1, "null context");
+  PK_HIP(c, hipSetDevice(c->device));
+  PK_HIP(c, hipDeviceSynchronize());
+  if (p) PK_HIP(c, hipFree(p));
+  return 0;
+}
+
+// Inter-process handle (64 bytes) of a pk_device_alloc allocation, and its mapping in another process (one per GPU).
+int pk_ipc_export(pk_ctx* c, void* dptr, void* handle64) {
+  if (!c) return fail(nullptr, 1, "null context");
+  static_assert(sizeof(hipIpcMemHandle_t) == 64, "handle size of the C ABI");
+  PK_HIP(c, hipSetDevice(c->device));
+  PK_HIP(c, hipIpcGetMemHandle((hipIpcMemHandle_t*)handle64, dptr));
+  return 0;
+}
+
+int pk_ipc_open(pk_ctx* c, const void* handle64, void** out) {
+  if (!c) return fail(nullptr, 1, "null context");
+  hipIpcMemHandle_t h;
+  std::memcpy(&h, handle64, sizeof h);
+  PK_HIP(c, hipSetDevice(c->device));
+  PK_HIP(c, hipIpcOpenMemHandle(out, h, hipIpcMemLazyEnablePeerAccess));
+  return 0;
+}
+
+int pk_ipc_close(pk_ctx* c, void* p) {
+  if (!c) return fail(nullptr, 1, "null context");
+  PK_HIP(c, hipSetDevice(c->device));
+  PK_HIP(c, hipDeviceSynchronize());
+  PK_HIP(c, hipIpcCloseMemHandle(p));
+  return 0;
+}
+
+// A shard whose gradient output is another GPU's buffer keeps the slots shared by all nodes (partial sums) local.
+int pk_set_shared_grad_target(pk_ctx* c, double* d_grad_shared) {
+  if (!c) return fail(nullptr, 1, "null context");
+  c->gshared = d_grad_shared;
+  return 0;
+}
+
+// d_boxes: device array of `world` pointers, entry r = rank r's mailbox as mapped in this process; d_idx: device array
+// of the NLP indices of the n_sh shared gradient slots; stride: words per sender slot (>= 1 + n_I + n_sh).
+int pk_set_exchange(pk_ctx* c, int world, int rank, const void* d_boxes, const int32_t* d_idx, int n_sh, int stride) {
+  int rc = ready(c);
+  if (rc) return rc;
+  if (world < 1 || world > PK_MAX_RANKS || rank < 0 || rank >= world)
+    return fail(c, 90, "pk_set_exchange: %d ranks (at most %d), rank %d", world, PK_MAX_RANKS, rank);
+  if (c->md.n_I + n_sh > 512 || stride < 1 + c->md.n_I + n_sh)
+    return fail(c, 91, "pk_set_exchange: partial vector of %d doubles (at most 512), slot of %d words", c->md.n_I + n_sh, stride);
+  c->xc_box = (const unsigned long long* const*)d_boxes;
+  c->xc_idx = d_idx;
+  c->xc_world = world; c->xc_rank = rank; c->xc_nsh = n_sh; c->xc_stride = stride;
+  return 0;
+}
+
+// After the shard's pk_eval_cycle_dev on the same stream: post this rank's partial sums to every peer, take theirs, leave
+// the global integrals, the summed shared gradient slots (in d_grad, or the shared-slot target) and -- write_f -- f.
+int pk_exchange_sums_dev(pk_ctx* c, const double* d_x, double* d_grad, double* d_f, int epoch, int write_f, void* stream) {
+  int rc = ready(c);
+  if (rc) return rc;
+  if (!c->xc_box) return fail(c, 92, "pk_exchange_sums: call pk_set_exchange first");
+  if (epoch < 1) return fail(c, 93, "pk_exchange_sums: the cycle number starts at 1");
+  PkArgs A = base_args(c, d_x, nullptr, 0.0);
+  A.o_grad = d_grad; A.o_f = d_f;
+  A.xc_box = (unsigned long long* const*)c->xc_box; A.xc_idx = c->xc_idx;
+  A.xc_world = c->xc_world; A.xc_rank = c->xc_rank; A.xc_epoch = epoch; A.xc_nsh = c->xc_nsh; A.xc_stride = c->xc_stride;
+  A.flags = (A.flags & ~F_WRITE_F) | (write_f ? F_WRITE_F : 0);
+  return launch(c, K_XCHG, A, 1, 0, pick(c, stream));
+}
+
+// dst[dst_off + i] = src[src_off + i] over a device table of n_chunks (src_off, dst_off, len) int64 triples
+int pk_copy_runs_dev(pk_ctx* c, const int64_t* d_table, int n_chunks, const double* d_src, double* d_dst, void* stream) {
+  int rc = ready(c);
+  if (rc) return rc;
+  if (n_chunks <= 0) return 0;
+  PkArgs A = base_args(c, nullptr, nullptr, 0.0);
+  A.rc_table = d_table; A.rc_n = n_chunks; A.rc_src = d_src; A.rc_dst = d_dst;
+  return launch(c, K_RUNS, A, (unsigned)(n_chunks < 8192 ? n_chunks : 8192), 0, pick(c, stream));
 }
 
 // ---------------------------------------------------------------- profiling

@@ -322,12 +322,13 @@ class Evaluator:
         lam = np.ascontiguousarray(lagrange, dtype=np.float64)
         if lam.shape != (self.plan.m,):
             raise ValueError(f"lagrange must have shape ({self.plan.m},)")
-        self._prepare(x)
         lib, h = self.ctx.lib, self.ctx.handle
+        self.ctx.check(lib.pk_stage_lambda(h, runtime.as_dp(lam)))      # the upload runs while x is compared below
+        self._prepare(x)
         self._own[4] = None if self.zero_copy else self._rings()[4].take()
         self._set_targets(self._own)
         self._handed.discard(4)
-        self.ctx.check(lib.pk_eval_hess_prepared(h, runtime.as_dp(lam), float(obj_factor), None))
+        self.ctx.check(lib.pk_eval_hess_prepared(h, None, float(obj_factor), None))
         return self._result(4, self.plan.nnz_H)
 
     def set_host_mode(self, prefetch=True, host_direct=False):
@@ -394,8 +395,9 @@ class Evaluator:
 
         lib, h = self.ctx.lib, self.ctx.handle
         if self._err_views is None:
-            recs, tables, n_out, views = refine.error_tables(self.plan)
-            self.ctx.check(lib.pk_set_mesh_error_tables(h, recs.ctypes.data, len(recs), runtime.as_dp(tables),
+            recs, tables, n_out, views, groups = refine.error_tables(self.plan)
+            self.ctx.check(lib.pk_set_mesh_error_tables(h, recs.ctypes.data, len(recs), groups.ctypes.data, len(groups),
+                                                        runtime.as_dp(tables),
                                                         len(tables), n_out))
             self._err_views, self._err_len = views, n_out
         x = self._x(x)

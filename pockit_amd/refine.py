@@ -20,10 +20,12 @@ from . import collocation, runtime
 
 
 def error_tables(plan):
-    """(records, tables, n_out, views) for ``pk_set_mesh_error_tables``.
+    """(records, tables, n_out, views, groups) for ``pk_set_mesh_error_tables``.
 
-    records: PkErrIv array, every phase padded to a multiple of 4 records with K = 0 (a workgroup of 4 waves
-    never mixes phases); tables: float64 blob; views[k] = (offset, n_x, rows) of phase k in the outputs."""
+    records: one PkErrIv per mesh interval; tables: float64 blob; views[k] = (offset, n_x, rows) of phase k in the
+    outputs; groups: int32 [n, 2] = (first record, count) -- ONE wavefront of pk_err handles a run of consecutive
+    intervals of one phase and one K, as many as fit its 64 lanes with K + 1 lanes per interval; every phase is padded
+    to a multiple of 4 groups (count 0: a workgroup of 4 waves never mixes phases)."""
     tables, blocks = [], {}
     size = 0
 
@@ -35,7 +37,7 @@ def error_tables(plan):
         size += len(arr)
         return off
 
-    records, views = [], []
+    records, views, groups = [], [], []
     out_off = 0
     for k, pp in enumerate(plan.phase_plans):
         lay = pp.layout
@@ -59,13 +61,22 @@ def error_tables(plan):
             rec["tau_off"] = put(lay.mesh[j] + (xa + 1.0) * 0.5 * lay.width[j])
             rec["rows"], rec["out_off"], rec["width"] = rows, out_off, lay.width[j]
             records.append(rec)
-        while len(records) % runtime.WAVES_PER_BLOCK:
-            rec = np.zeros((), dtype=runtime.ERRIV_DTYPE)
-            rec["phase"] = k
-            records.append(rec)
+        first = len(records) - lay.N
+        j = 0
+        while j < lay.N:
+            K = int(lay.K[j])
+            cap = max(1, runtime.WAVE // (K + 1))
+            cnt = 1
+            while j + cnt < lay.N and cnt < cap and int(lay.K[j + cnt]) == K:
+                cnt += 1
+            groups.append((first + j, cnt))
+            j += cnt
+        while len(groups) % runtime.WAVES_PER_BLOCK:
+            groups.append((first, 0))
         views.append((out_off, pp.nx, rows))
         out_off += pp.nx * rows
-    return np.array(records, dtype=runtime.ERRIV_DTYPE), np.concatenate(tables), out_off, views
+    return (np.array(records, dtype=runtime.ERRIV_DTYPE), np.concatenate(tables), out_off, views,
+            np.array(groups, dtype=np.int32).reshape(-1, 2))
 
 
 def interval_rows(layout):

@@ -61,7 +61,7 @@ ERRIV_DTYPE = np.dtype([("phase", np.int32), ("K", np.int32), ("lm", np.int32), 
 WAVES_PER_BLOCK = 4  # PK_WAVES_PER_BLOCK of csrc/pk_abi.h
 WAVE = 64  # PK_WAVE
 KERNELS = ["pk_int", "pk_fin", "pk_g", "pk_grad", "pk_jac", "pk_hess", "pk_xall", "pk_aux", "pk_outer", "pk_hessc", "pk_err", "pk_csr",
-           "pk_cycle"]
+           "pk_cycle", "pk_xchg", "pk_runs"]
 EXPORTS = ["pk_create", "pk_destroy", "pk_last_error", "pk_device_count", "pk_load_model", "pk_set_problem",
            "pk_get_structure", "pk_eval_f", "pk_eval_grad", "pk_eval_g", "pk_eval_jac", "pk_eval_hess",
            "pk_eval_f_dev", "pk_eval_grad_dev", "pk_eval_g_dev", "pk_eval_jac_dev", "pk_eval_hess_dev",
@@ -71,7 +71,9 @@ EXPORTS = ["pk_create", "pk_destroy", "pk_last_error", "pk_device_count", "pk_lo
            "pk_set_mesh_error_tables", "pk_eval_mesh_error", "pk_eval_mesh_error_dev", "pk_set_cycle_graph", "pk_profile_sampling",
            "pk_set_csr_map", "pk_gather_csr_dev", "pk_eval_jac_csr_dev", "pk_eval_hess_csr_dev", "pk_eval_jac_csr",
            "pk_eval_hess_csr", "pk_trace_read", "pk_set_cycle_mode", "pk_same_x", "pk_set_result_targets",
-           "pk_result_location", "pk_set_host_mode", "pk_invalidate_x", "pk_host_alloc", "pk_host_free"]
+           "pk_result_location", "pk_set_host_mode", "pk_stage_lambda", "pk_invalidate_x", "pk_host_alloc", "pk_host_free",
+           "pk_device_alloc", "pk_device_free", "pk_ipc_export", "pk_ipc_open", "pk_ipc_close", "pk_set_shared_grad_target",
+           "pk_set_exchange", "pk_exchange_sums_dev", "pk_copy_runs_dev"]
 
 _lib = None
 
@@ -131,15 +133,25 @@ def load_library():
     lib.pk_eval_hess_prepared.argtypes = [vp, dp, C.c_double, dp]
     lib.pk_host_buffer.argtypes = [vp, C.c_int, C.POINTER(dp), C.POINTER(C.c_int64)]
     lib.pk_same_x.argtypes = [vp, dp]
+    lib.pk_stage_lambda.argtypes = [vp, dp]
     lib.pk_set_result_targets.argtypes = [vp, dp, dp, dp, dp, dp]
     lib.pk_result_location.argtypes = [vp, C.c_int, C.POINTER(dp)]
     lib.pk_set_host_mode.argtypes = [vp, C.c_int, C.c_int]
     lib.pk_invalidate_x.argtypes = [vp]
     lib.pk_host_alloc.argtypes = [C.c_size_t, C.POINTER(vp)]
     lib.pk_host_free.argtypes = [vp]
+    lib.pk_device_alloc.argtypes = [vp, C.c_size_t, C.c_int, C.POINTER(vp)]
+    lib.pk_device_free.argtypes = [vp, vp]
+    lib.pk_ipc_export.argtypes = [vp, vp, vp]
+    lib.pk_ipc_open.argtypes = [vp, vp, C.POINTER(vp)]
+    lib.pk_ipc_close.argtypes = [vp, vp]
+    lib.pk_set_shared_grad_target.argtypes = [vp, vp]
+    lib.pk_set_exchange.argtypes = [vp, C.c_int, C.c_int, vp, vp, C.c_int, C.c_int]
+    lib.pk_exchange_sums_dev.argtypes = [vp, vp, vp, vp, C.c_int, C.c_int, vp]
+    lib.pk_copy_runs_dev.argtypes = [vp, vp, C.c_int, vp, vp, vp]
     lib.pk_eval_hessc.argtypes = [vp, dp, dp, C.c_double, dp]
     lib.pk_eval_hessc_dev.argtypes = [vp, vp, vp, C.c_double, vp, vp]
-    lib.pk_set_mesh_error_tables.argtypes = [vp, vp, C.c_int32, dp, C.c_int64, C.c_int64]
+    lib.pk_set_mesh_error_tables.argtypes = [vp, vp, C.c_int32, vp, C.c_int32, dp, C.c_int64, C.c_int64]
     lib.pk_eval_mesh_error.argtypes = [vp, dp, dp, dp]
     lib.pk_eval_mesh_error_dev.argtypes = [vp, vp, vp, vp, vp]
     lib.pk_set_cycle_graph.argtypes = [vp, C.c_int]

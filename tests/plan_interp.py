@@ -235,12 +235,19 @@ def mesh_error(plan, x):
     from pockit_amd import refine
 
     it = Interp(plan, x)
-    recs, tab, n_out, views = refine.error_tables(plan)
+    recs, tab, n_out, views, groups = refine.error_tables(plan)
     outT, outI = np.zeros(n_out), np.zeros(n_out)
-    for rec in recs:
+    seen = np.zeros(len(recs), dtype=np.int64)
+    order = []
+    for first, cnt in groups:                      # one wavefront per group: consecutive intervals of one phase and K
+        for jj in range(int(cnt)):
+            order.append(int(first) + jj)
+            seen[int(first) + jj] += 1
+            assert recs[int(first) + jj]["K"] == recs[int(first)]["K"] and recs[int(first) + jj]["phase"] == recs[int(first)]["phase"]
+        assert int(cnt) * (int(recs[int(first)]["K"]) + 1) <= 64
+    assert np.all(seen == 1), "the groups must cover every interval exactly once"
+    for rec in recs[order]:
         K = int(rec["K"])
-        if K == 0:
-            continue
         k = int(rec["phase"])
         pp, env = plan.phase_plans[k], it.ph[k]
         p, lay = pp.phase, pp.layout

@@ -66,6 +66,106 @@ def _worker(rank, world, port, case, ret):
         dist.destroy_process_group()
 
 
+def _peer_worker(rank, world, port, case, ret):
+    """The collective-free forms of the exchange: "sums" (every rank keeps its slices; the sums over all nodes go through
+    peer-mapped mailboxes inside one launch) and "direct" (the other rank's kernels store into rank 0's buffer through
+    a hipIpc mapping).  gloo only carries the 64-byte handles at set-up."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import torch
+    import torch.distributed as dist
+
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import importlib
+
+        from pockit_amd.sharding import ShardedEvaluator, shared_gradient_slots
+
+        name, scheme, kw = case
+        builder = getattr(models, name)
+        system, _, guess = builder(importlib.import_module(f"pockit_amd.{scheme}"), **kw)
+        ref, _, _ = builder(importlib.import_module(f"oracle.{scheme}"), **kw)
+        x, lam, sigma = models.bench_inputs(system, guess)
+        dev = torch.device("cuda", 0)
+        torch.cuda.set_device(dev)
+        plan = system.plan
+        sev = ShardedEvaluator(plan, rank, world, device=0, intervals_per_wave=2)
+        sev.enable_peer_exchange(dist, root=0)
+        dx, dlam = torch.from_numpy(x).to(dev), torch.from_numpy(lam).to(dev)
+        want = np.concatenate([ref.gradient(x), ref.constraints(x), ref.jacobian(x), ref.hessian(x, lam, sigma)])
+        f_want = ref.objective(x)
+        shared = shared_gradient_slots(plan)
+        scale = lambda a: max(1.0, float(np.max(np.abs(a)))) if a.size else 1.0  # noqa: E731
+        err = 0.0
+        for rep in range(3):                                      # the mailboxes alternate between their two halves
+            xk = x * (1.0 + 1e-3 * rep)
+            if rep:
+                want = np.concatenate([ref.gradient(xk), ref.constraints(xk), ref.jacobian(xk), ref.hessian(xk, lam, sigma)])
+                f_want = ref.objective(xk)
+            dx.copy_(torch.from_numpy(xk))
+            # ---- "sums": own slices + complete shared slots and f on EVERY rank
+            sev.full.fill_(float("nan"))
+            torch.cuda.synchronize()
+            dist.barrier()
+            o = sev.cycle(dx, dlam, sigma, dist, exchange="sums")
+            torch.cuda.synchronize()
+            got = sev.full.cpu().numpy()[:-1]
+            mine = np.zeros(len(want), dtype=bool)
+            for a, b in sev.runs[rank]:
+                mine[a:b] = True
+            mine[shared] = True
+            err = max(err, float(np.max(np.abs(got[mine] - want[mine])) / scale(want)))
+            rest = ~mine
+            assert np.all(np.isnan(got[rest])), "a rank wrote outside its own runs"
+            err = max(err, abs(float(o["f"].cpu()[0]) - f_want) / max(1.0, abs(f_want)))
+            dist.barrier()
+            # ---- "direct": everything reassembled in rank 0's buffer by peer stores
+            if rank == 0:
+                sev.full.fill_(float("nan"))
+            torch.cuda.synchronize()
+            dist.barrier()
+            o = sev.cycle(dx, dlam, sigma, dist, exchange="direct")
+            torch.cuda.synchronize()
+            dist.barrier()
+            if rank == 0:
+                got = sev.full.cpu().numpy()[:-1]
+                err = max(err, float(np.max(np.abs(got - want)) / scale(want)))
+                err = max(err, abs(float(o["f"].cpu()[0]) - f_want) / max(1.0, abs(f_want)))
+            dist.barrier()
+        flag = torch.tensor([err])
+        dist.all_reduce(flag, op=dist.ReduceOp.MAX)
+        sev.close()
+        if rank == 0:
+            ret.put(float(flag.item()))
+    except Exception as exc:  # noqa: BLE001 -- report instead of hanging the other rank
+        if rank == 0:
+            ret.put(repr(exc))
+        raise
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("case", [("two_stage_rocket", "radau", dict(mesh=40, num_point=4)),
+                                  ("planar_quadrotor", "lobatto", dict(mesh=33, num_point=5))])
+def test_two_process_peer_exchange_without_collectives(case):
+    import torch.multiprocessing as mp
+
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    ret = ctx.Queue()
+    procs = [ctx.Process(target=_peer_worker, args=(r, 2, port, case, ret)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(300)
+    assert all(p.exitcode == 0 for p in procs), [p.exitcode for p in procs]
+    err = ret.get(timeout=5)
+    assert isinstance(err, float), err
+    assert err <= 1e-11, err
+
+
 @pytest.mark.parametrize("case", [("two_stage_rocket", "radau", dict(mesh=40, num_point=4)),
                                   ("planar_quadrotor", "lobatto", dict(mesh=33, num_point=5)),
                                   ("brachistochrone", "radau", dict(mesh=61, num_point=6))])

@@ -32,7 +32,7 @@ def _worker(rank, world, port, ret, root=None):
     plan = system.plan
     x, lam, sigma = models.bench_inputs(system, guess)
     src = ModelSource(plan)
-    runs = [owned_runs(plan, Tables(plan, src, 2, tile_filter(r, world)), r == 0) for r in range(world)]
+    runs = [owned_runs(plan, Tables(plan, src, 2, tile_filter(r, world, plan)), r == 0) for r in range(world)]
     re = Reassembler(torch, plan, runs, rank, world, torch.device("cpu"))
     it = Interp(plan, x, lam, sigma)
     truth = np.concatenate([it.gradient(), it.constraints(), it.jacobian(), it.hessian()])
@@ -103,6 +103,60 @@ def test_owned_runs_partition_every_output_position():
         for world in (1, 2, 3, 5):
             runs = [owned_runs(plan, Tables(plan, src, 1, tile_filter(r, world)), r == 0) for r in range(world)]
             Reassembler(torch, plan, runs, 0, world, torch.device("cpu"))
+
+
+def test_shares_are_balanced_by_output_volume_on_hp_meshes():
+    """SURVEY 8(e) "Partitioning": contiguous ranges balanced by the triplets they produce.  On an hp mesh (K = 1 .. 12,
+    triplet work per interval ~ K^2) equal tile counts are off by a factor; the weighted cuts stay within 10 %, and the
+    owned runs still partition every output position."""
+    import pockit_amd.lobatto as lobatto
+    import pockit_amd.radau as radau
+    from pockit_amd.codegen import ModelSource
+    from pockit_amd.evaluator import Tables
+    from pockit_amd.sharding import Reassembler, balanced_cuts, owned_runs, tile_filter, tile_weights
+
+    rng = np.random.default_rng(3)
+    for ns, kmin in ((radau, 1), (lobatto, 2)):
+        N = 1500
+        # smooth stretches of low order next to stretches of high order, as an hp refinement leaves them
+        K = np.clip(np.round(6.5 + 5.5 * np.sin(np.linspace(0, 9, N)) + rng.integers(-1, 2, N)), kmin, 12).astype(int)
+        mesh = np.concatenate(([0.0], np.cumsum(rng.uniform(0.5, 1.5, N))))
+        system, _, _ = models.planar_quadrotor(ns, (mesh / mesh[-1]).tolist(), K.tolist())
+        plan = system.plan
+        src = ModelSource(plan)
+        for world in (2, 4, 8):
+            tabs = [Tables(plan, src, None, tile_filter(r, world, plan)) for r in range(world)]
+            runs = [owned_runs(plan, tb, r == 0) for r, tb in enumerate(tabs)]
+            Reassembler(torch, plan, runs, 0, world, torch.device("cpu"))         # raises unless a partition
+            vol = np.array([sum(b - a for a, b in rr) for rr in runs], dtype=np.float64)
+            assert vol.max() / vol.mean() <= 1.10, (world, vol / vol.mean())
+            # the same mesh dealt by tile count is far off
+            flat = [owned_runs(plan, Tables(plan, src, None, tile_filter(r, world)), r == 0) for r in range(world)]
+            fvol = np.array([sum(b - a for a, b in rr) for rr in flat], dtype=np.float64)
+            assert fvol.max() / fvol.mean() > vol.max() / vol.mean()
+    # the cut rule itself
+    w = np.array([5, 1, 1, 1, 1, 1, 5, 5], dtype=np.int64)
+    cuts = balanced_cuts(w, 2)
+    assert cuts[0] == 0 and cuts[-1] == len(w) and sum(w[:cuts[1]]) == 10
+    assert balanced_cuts(np.ones(3), 5)[-1] == 3                                   # more ranks than tiles: empty shares
+    assert len(tile_weights(plan, 0, plan.phase_plans[0].layout.tiles(None))) > 0
+
+
+def test_run_table_chunks_cover_the_runs():
+    from pockit_amd.sharding import CHUNK, RunCopier, run_table
+
+    runs = [(3, 10), (100, 100 + 2 * CHUNK + 5), (10 ** 6, 10 ** 6 + 1)]
+    tab, n = run_table(runs)
+    assert n == sum(b - a for a, b in runs) and tab[:, 2].max() <= CHUNK
+    assert np.array_equal(tab[:, 1], np.concatenate(([0], np.cumsum(tab[:-1, 2]))))
+    src = torch.arange(10 ** 6 + 2, dtype=torch.float64)
+    pack = torch.full((n,), -1.0, dtype=torch.float64)
+    RunCopier(torch, tab, torch.device("cpu"))(src, pack)
+    want = np.concatenate([np.arange(a, b) for a, b in runs]).astype(np.float64)
+    assert np.array_equal(pack.numpy(), want)
+    back = torch.zeros_like(src)
+    RunCopier(torch, tab, torch.device("cpu"), swap=True)(pack, back)
+    assert np.array_equal(back.numpy()[3:10], np.arange(3, 10))
 
 
 def test_contiguous_share_partitions():
