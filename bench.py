@@ -410,6 +410,8 @@ def measure(name, intervals, steps, warmup, rank, world, dist, with_side=True, w
     res["no_exchange_ms_per_step"] = None
     if world > 1 and w.fused:
         w.sync()
+        w.lib.pk_set_exchange_inline(w.h, 0)
+        w.lib.pk_set_shared_grad_target(w.h, None)
         t1 = time.perf_counter()
         n = max(steps, 200)
         for _ in range(n):
@@ -417,10 +419,15 @@ def measure(name, intervals, steps, warmup, rank, world, dist, with_side=True, w
         w.stream.synchronize()
         res["no_exchange_ms_per_step"] = (time.perf_counter() - t1) / n * 1e3
         w.sync()
+        w.step = w.make_step(w.exchange)
     res["exchange_forms_ms_per_step"] = None
     res["ranks"] = None
     if world > 1:
         forms = {}
+        if w.sev.peers is not None:             # "sums" with the exchange as a second launch (pk_xchg) instead of in-launch
+            w.sev.inline_exchange = False
+            forms["sums_two_launches"] = w.time_mode("sums")
+            w.sev.inline_exchange = True
         for mode in ("sums", "direct", "gather"):
             if mode == w.exchange:
                 forms[mode] = res["ms_per_step"]

@@ -230,7 +230,11 @@ int pk_ipc_open(pk_ctx* ctx, const void* handle64, void** out);
 int pk_ipc_close(pk_ctx* ctx, void* p);
 int pk_set_shared_grad_target(pk_ctx* ctx, double* d_grad_shared);
 int pk_set_exchange(pk_ctx* ctx, int world, int rank, const void* d_boxes, const int32_t* d_idx, int n_sh, int stride);
-int pk_exchange_sums_dev(pk_ctx* ctx, const double* d_x, double* d_grad, double* d_f, int epoch, int write_f, void* stream);
+int pk_exchange_sums_dev(pk_ctx* ctx, const double* d_x, double* d_grad, double* d_f, int epoch /* <= 0: the context counts */,
+                         int write_f, void* stream);
+/* 1: the finalize workgroup of pk_eval_cycle_dev's launch exchanges the partial sums itself -- a sharded cycle is ONE
+ * launch per GPU; 0 (default): pk_exchange_sums_dev is a launch of its own behind it. */
+int pk_set_exchange_inline(pk_ctx* ctx, int enable);
 int pk_copy_runs_dev(pk_ctx* ctx, const int64_t* d_table, int n_chunks, const double* d_src, double* d_dst, void* stream);
 
 /* HIP-event timing of the individual kernels on the launch stream.

@@ -316,50 +316,80 @@ __device__ __forceinline__ TileGeom tile_geom(const PkTile& tl) {
 // translation and streaming phases then read LDS only -- no dependent global round trips between the
 // evaluation and the stores (measured on MI355X: each such round trip costs the latency-bound kernels
 // 0.6-0.8 us).  Larger K keeps the tables in global memory.
+#define PK_TAB_MAX 256      // entries of the largest staged table (K <= 16: R K <= 256 entries); pk_set_problem picks 64 or 256
 struct TabRegs {
-  double iv, full, tv, wd;
-  int rc;
+  double iv[PK_TAB_MAX / PK_WAVE], full[PK_TAB_MAX / PK_WAVE], tv, wd;
+  int rc[PK_TAB_MAX / PK_WAVE];
 };
 
 struct TileTabs {
   bool staged;
-  const double* __restrict__ iv;    // LDS copies (valid when staged), [64] each
+  const double* __restrict__ iv;    // LDS copies (valid when staged): [cap], [cap], [64], [64]
   const double* __restrict__ full;
   const double* __restrict__ tv;
   const double* __restrict__ wd;
-  const int* __restrict__ rc;       // r | c << 16
+  const int* __restrict__ rc;       // r | c << 16, [cap]
 };
 
+// doubles of one wave's table block in dynamic LDS, for table capacity `cap` (64, or 256 when the mesh has K > 8)
+__device__ __forceinline__ int tab_width(int cap) { return 2 * cap + 2 * PK_WAVE + cap / 2; }
+// start of the per-wave model staging area: behind the table blocks of the workgroup's waves
+#define PK_STAGE(A) (pk_lds + PK_WAVES_PER_BLOCK * pk::tab_width((A).tab_cap))
+
 __device__ __forceinline__ bool tabs_fit(const PkArgs& A, const PkTile& tl, const TileGeom& g) {
-  return tl.nnzI <= PK_WAVE && g.R * g.K <= PK_WAVE && tl.nnzT <= PK_WAVE && !PK_DIAG(4096);
+  return tl.nnzI <= A.tab_cap && g.R * g.K <= A.tab_cap && tl.nnzT <= PK_WAVE && !PK_DIAG(4096);
 }
 
+// Entry e = lane + 64 u of a table is loaded by lane `lane` (u = 0 .. cap / 64 - 1): one round for K <= 8, up to four
+// for K <= 16; the guards on u are wave-uniform (scalar branches), so low-order tiles issue nothing extra.
 __device__ __forceinline__ TabRegs tabs_issue(const PkArgs& A, const PkPhase& ph, const PkTile& tl, const TileGeom& g,
                                               bool fit, int lane) {
-  TabRegs t{0.0, 0.0, 0.0, 0.0, 0};
+  TabRegs t;
+#pragma unroll
+  for (int u = 0; u < PK_TAB_MAX / PK_WAVE; ++u) { t.iv[u] = 0.0; t.full[u] = 0.0; t.rc[u] = 0; }
+  t.tv = 0.0; t.wd = 0.0;
   if (!fit) return t;
-  if (lane < tl.nnzI) {
-    t.iv = A.db[tl.iv_off + lane];
-    t.rc = A.ib[tl.irc_off + 2 * lane] | (A.ib[tl.irc_off + 2 * lane + 1] << 16);
+  const int nfull = g.R * g.K;
+#pragma unroll
+  for (int u = 0; u < PK_TAB_MAX / PK_WAVE; ++u) {
+    const int e = lane + PK_WAVE * u;
+    if (u == 0 || tl.nnzI > PK_WAVE * u) {
+      if (e < tl.nnzI) {
+        t.iv[u] = A.db[tl.iv_off + e];
+        t.rc[u] = A.ib[tl.irc_off + 2 * e] | (A.ib[tl.irc_off + 2 * e + 1] << 16);
+      }
+    }
+    if (u == 0 || nfull > PK_WAVE * u) {
+      if (e < nfull) t.full[u] = A.db[tl.full_off + e];
+    }
   }
-  if (lane < g.R * g.K) t.full = A.db[tl.full_off + lane];
   if (lane < tl.nnzT) t.tv = A.db[tl.tv_off + lane];
   if (lane < tl.nj) t.wd = A.db[ph.width_off + tl.j0 + lane];
   return t;
 }
 
-__device__ __forceinline__ TileTabs tabs_commit(const TabRegs& t, bool fit, int lane) {
-  __shared__ double td[PK_WAVES_PER_BLOCK][4][PK_WAVE];
-  __shared__ int ti[PK_WAVES_PER_BLOCK][PK_WAVE];
+__device__ __forceinline__ TileTabs tabs_commit(const PkArgs& A, const PkTile& tl, const TileGeom& g, const TabRegs& t,
+                                                bool fit, int lane) {
+  extern __shared__ double pk_lds[];
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int cap = A.tab_cap;
+  double* __restrict__ iv = pk_lds + wave * tab_width(cap);
+  double* __restrict__ full = iv + cap;
+  double* __restrict__ tv = full + cap;
+  double* __restrict__ wd = tv + PK_WAVE;
+  int* __restrict__ rc = reinterpret_cast<int*>(wd + PK_WAVE);
   if (fit) {
-    td[wave][0][lane] = t.iv;
-    td[wave][1][lane] = t.full;
-    td[wave][2][lane] = t.tv;
-    td[wave][3][lane] = t.wd;
-    ti[wave][lane] = t.rc;
+    const int nfull = g.R * g.K;
+#pragma unroll
+    for (int u = 0; u < PK_TAB_MAX / PK_WAVE; ++u) {
+      const int e = lane + PK_WAVE * u;
+      if (u == 0 || tl.nnzI > PK_WAVE * u) { iv[e] = t.iv[u]; rc[e] = t.rc[u]; }
+      if (u == 0 || nfull > PK_WAVE * u) full[e] = t.full[u];
+    }
+    tv[lane] = t.tv;
+    wd[lane] = t.wd;
   }
-  return TileTabs{fit, td[wave][0], td[wave][1], td[wave][2], td[wave][3], ti[wave]};
+  return TileTabs{fit, iv, full, tv, wd, rc};
 }
 
 // x at the end slot of the interval whose defect row this lane writes after the barrier: lane (jj+1)*stride of
@@ -411,7 +441,7 @@ __device__ __forceinline__ void write_defects(const PkArgs& A, const PkPhase& ph
   if (STAGED) {
     const double width = T.wd[jj];
     const double* __restrict__ full = T.full + r * g.K;
-    switch (g.K) {   // K <= 8 here: fully unrolled so that all LDS reads of a row are in flight together
+    switch (g.K) {   // K <= 8: fully unrolled so that all LDS reads of a row are in flight together
       case 1: defect_dot<P, 1>(full, f, width, acc); break;
       case 2: defect_dot<P, 2>(full, f, width, acc); break;
       case 3: defect_dot<P, 3>(full, f, width, acc); break;
@@ -419,7 +449,15 @@ __device__ __forceinline__ void write_defects(const PkArgs& A, const PkPhase& ph
       case 5: defect_dot<P, 5>(full, f, width, acc); break;
       case 6: defect_dot<P, 6>(full, f, width, acc); break;
       case 7: defect_dot<P, 7>(full, f, width, acc); break;
-      default: defect_dot<P, 8>(full, f, width, acc); break;
+      case 8: defect_dot<P, 8>(full, f, width, acc); break;
+      default:         // 9 <= K <= 16, tables staged in LDS as well
+#pragma unroll 4
+        for (int c = 0; c < g.K; ++c) {
+          const double a = full[c] * width * 0.5;
+#pragma unroll
+          for (int i = 0; i < P::NX; ++i) acc[i] += a * f[i * PK_WAVE + c];
+        }
+        break;
     }
   } else {
     const double* __restrict__ full = A.db + tl.full_off + r * g.K;
@@ -669,7 +707,7 @@ __device__ __forceinline__ void tile_g(const PkArgs& A, const PkTile& tl, double
   const int q = tl.q0 + lane;
   double a[P::NARG], tau, w, xr[P::NX], xe[P::NX];
   load_node<P>(A, ph, s, dt, mt, q, a, tau, w);
-  const TileTabs T = tabs_commit(tr, fit, lane);
+  const TileTabs T = tabs_commit(A, tl, g, tr, fit, lane);
   defect_ends<P>(A, ph, tl, g, a, xe, lane);
   settle(xe);
   loads_done();
@@ -736,7 +774,7 @@ __device__ __forceinline__ void tile_jac(const PkArgs& A, const PkTile& tl, doub
   const int q = tl.q0 + lane;
   double a[P::NARG], tau, w;
   load_node<P>(A, ph, s, dt, mt, q, a, tau, w);
-  const TileTabs T = tabs_commit(tr, fit, lane);
+  const TileTabs T = tabs_commit(A, tl, g, tr, fit, lane);
   segb.settle();
   tbase.settle();
   loads_done();
@@ -782,7 +820,7 @@ __device__ __forceinline__ void tile_hess(const PkArgs& A, const PkTile& tl, dou
   load_node<P>(A, ph, s, dt, mt, q, a, tau, w);
 #pragma unroll
   for (int j = 0; j < P::NC; ++j) lp[j] = A.lam[ph.path_off + j * ph.L_m + min(q, ph.L_m - 1)];
-  const TileTabs T = tabs_commit(tr, fit, lane);
+  const TileTabs T = tabs_commit(A, tl, g, tr, fit, lane);
 #pragma unroll
   for (int i = 0; i < P::NX; ++i) lam_s[i * PK_WAVE + lane] = lrow[i];
   segb.settle();
@@ -864,7 +902,7 @@ __device__ __forceinline__ void tile_xall(const PkArgs& A, const PkTile& tl, dou
   const int q = tl.q0 + lane;
   double a[P::NARG], tau, w, xr[P::NX], xe[P::NX];
   load_node<P>(A, ph, s, dt, mt, q, a, tau, w);
-  const TileTabs T = tabs_commit(tr, fit, lane);
+  const TileTabs T = tabs_commit(A, tl, g, tr, fit, lane);
   if (ROLE != 1) segb.settle();
   if (ROLE != 2) tbase.settle();
   PK_MARK(1);
@@ -1212,7 +1250,7 @@ __device__ __forceinline__ void kernel_g(const PkArgs& A) {
     return;
   }
   PK_TILE_PROLOGUE(1);
-  Gen::tile_g(tl.phase, A, tl, pk_lds + wave * Gen::LDS_G, wint, wgrad, lane);
+  Gen::tile_g(tl.phase, A, tl, PK_STAGE(A) + wave * Gen::LDS_G, wint, wgrad, lane);
 }
 
 template <class Gen>
@@ -1226,7 +1264,7 @@ template <class Gen>
 __device__ __forceinline__ void kernel_jac(const PkArgs& A) {
   if (PK_IS_EDGE_BLOCK()) return edge_block<Gen>(A, 0, false, A.items, A.n_items);
   PK_TILE_PROLOGUE(1);
-  Gen::tile_jac(tl.phase, A, tl, pk_lds + wave * Gen::LDS_J, wint, wgrad, lane);
+  Gen::tile_jac(tl.phase, A, tl, PK_STAGE(A) + wave * Gen::LDS_J, wint, wgrad, lane);
 }
 
 template <class Gen>
@@ -1243,7 +1281,7 @@ __device__ __forceinline__ void kernel_hess(const PkArgs& A) {
     return;
   }
   PK_TILE_PROLOGUE(2);
-  Gen::tile_hess(tl.phase, A, tl, pk_lds + wave * Gen::LDS_H, wint, wgrad, lane);
+  Gen::tile_hess(tl.phase, A, tl, PK_STAGE(A) + wave * Gen::LDS_H, wint, wgrad, lane);
 }
 
 template <class Gen>
@@ -1446,16 +1484,16 @@ __device__ __forceinline__ void kernel_xall(const PkArgs& A) {
     const int blk = slot >> 1;
     PK_TILE_PROLOGUE_AT();
     if (!(slot & 1)) {
-      Gen::tile_xall2(tl.phase, A, tl, pk_lds + wave * Gen::LDS_X, wint + wave * PK_NRED, wgrad + wave * PK_NRED, lane, -1);
+      Gen::tile_xall2(tl.phase, A, tl, PK_STAGE(A) + wave * Gen::LDS_X, wint + wave * PK_NRED, wgrad + wave * PK_NRED, lane, -1);
       return;
     }
-    Gen::tile_xall1(tl.phase, A, tl, pk_lds + wave * Gen::LDS_X, wint + wave * PK_NRED, wgrad + wave * PK_NRED, lane, -1);
+    Gen::tile_xall1(tl.phase, A, tl, PK_STAGE(A) + wave * Gen::LDS_X, wint + wave * PK_NRED, wgrad + wave * PK_NRED, lane, -1);
     publish_block_partials(A.partial, wint, blk);
     publish_block_partials(A.partial2, wgrad, blk);
     return;
   }
   PK_TILE_PROLOGUE(1);
-  Gen::tile_xall(tl.phase, A, tl, pk_lds + wave * Gen::LDS_X, wint + wave * PK_NRED, wgrad + wave * PK_NRED, lane, -1);
+  Gen::tile_xall(tl.phase, A, tl, PK_STAGE(A) + wave * Gen::LDS_X, wint + wave * PK_NRED, wgrad + wave * PK_NRED, lane, -1);
   publish_block_partials(A.partial, wint, blk);
   publish_block_partials(A.partial2, wgrad, blk);
 }
@@ -1507,13 +1545,13 @@ __device__ __forceinline__ void kernel_cycle(const PkTile* pre_tile, int pre_n_t
   const int sub = slot - blk * (split ? 3 : 2);       // split: 0 Jacobian, 1 values, 2 Hessian; else 0 x-part, 1 Hessian
   PK_TILE_PROLOGUE_FROM(pre_tile, pre_n_tiles);
   if (sub == (split ? 2 : 1))
-    Gen::tile_hess(tl.phase, A, tl, pk_lds + wave * Gen::LDS_H, wint, wgrad, lane);
+    Gen::tile_hess(tl.phase, A, tl, PK_STAGE(A) + wave * Gen::LDS_H, wint, wgrad, lane);
   else if (!split)
-    Gen::tile_xall(tl.phase, A, tl, pk_lds + wave * Gen::LDS_X, wint + wave * PK_NRED, wgrad + wave * PK_NRED, lane, blk);
+    Gen::tile_xall(tl.phase, A, tl, PK_STAGE(A) + wave * Gen::LDS_X, wint + wave * PK_NRED, wgrad + wave * PK_NRED, lane, blk);
   else if (sub == 0)
-    Gen::tile_xall2(tl.phase, A, tl, pk_lds + wave * Gen::LDS_X, wint + wave * PK_NRED, wgrad + wave * PK_NRED, lane, -1);
+    Gen::tile_xall2(tl.phase, A, tl, PK_STAGE(A) + wave * Gen::LDS_X, wint + wave * PK_NRED, wgrad + wave * PK_NRED, lane, -1);
   else
-    Gen::tile_xall1(tl.phase, A, tl, pk_lds + wave * Gen::LDS_X, wint + wave * PK_NRED, wgrad + wave * PK_NRED, lane, blk);
+    Gen::tile_xall1(tl.phase, A, tl, PK_STAGE(A) + wave * Gen::LDS_X, wint + wave * PK_NRED, wgrad + wave * PK_NRED, lane, blk);
 }
 
 // The reductions over all workgroups, by ONE workgroup (all 256 threads must call it).
@@ -1557,6 +1595,60 @@ __device__ __forceinline__ void fin_body(const PkArgs& A) {
   }
 }
 
+// ============================================================================================
+// The ONLY exchange a sharded cycle needs -- the sums over all nodes.  Every rank evaluates its share of the mesh
+// intervals into its own HBM (pk_cycle on the shard's tiles); what couples the shards is a handful of doubles: the
+// integrals (-> f) and the gradient entries of t0 / tf / static parameters.  Each rank posts its partial vector
+// [integrals | shared gradient slots] into every peer's mailbox (peer-mapped fine-grained device memory, stores over
+// xGMI), raises a flag (the cycle number), waits for the flags of all peers, and adds the vectors IN RANK ORDER (every
+// rank gets bit-identical sums) -- one workgroup, no collective library call, no host round trip.  It runs INSIDE the
+// cycle's launch (pk_cycle's finalize workgroup, flags bit 6: a sharded cycle is ONE launch per GPU) or as a launch of
+// its own behind it (pk_xchg).
+// Mailbox of a rank: [parity 2][sender world][xc_stride] words, word 0 of a sender's slot = flag, data from word 1.
+// Two parities: a rank that is one cycle ahead posts into the other half (it cannot be two ahead: it needs every
+// peer's flag of the cycle in between).  The poll is bounded (then the sums read NaN).
+// ============================================================================================
+#define PK_XC_CAP 512                                   // doubles of a partial vector (host checks)
+__device__ __forceinline__ void sys_store(unsigned long long* p, unsigned long long v) {
+  __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+__device__ __forceinline__ unsigned long long sys_load(unsigned long long* p) {
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+// mine[0 .. n_small) (LDS, this rank's partial vector, written by the calling workgroup and visible: the caller has
+// synchronized) -> total[0 .. n_small) (LDS, the sums over all ranks); all PK_BLOCK threads call it
+__device__ __forceinline__ void exchange_partials(const PkArgs& A, const double* mine, double* total, int n_small) {
+  __shared__ int late;
+  const int t = threadIdx.x, W = A.xc_world, me = A.xc_rank;
+  const size_t half = (size_t)(A.xc_epoch & 1) * W * A.xc_stride;
+  if (t == 0) late = 0;
+  for (int i = t; i < n_small; i += PK_BLOCK) {
+    const unsigned long long b = (unsigned long long)__double_as_longlong(mine[i]);
+    for (int q = 0; q < W; ++q)
+      if (q != me) sys_store(A.xc_box[q] + half + (size_t)me * A.xc_stride + 1 + i, b);
+  }
+  __threadfence_system();                               // my data before my flags, for every observer
+  __syncthreads();
+  if (t < W && t != me) sys_store(A.xc_box[t] + half + (size_t)me * A.xc_stride, (unsigned long long)A.xc_epoch);
+  if (t < W && t != me) {                               // one polling thread per peer
+    unsigned long long* flag = A.xc_box[me] + half + (size_t)t * A.xc_stride;
+    int tries = 0;
+    while (sys_load(flag) != (unsigned long long)A.xc_epoch && ++tries < PK_POLL_LIMIT) __builtin_amdgcn_s_sleep(PK_POLL_SLEEP);
+    if (tries >= PK_POLL_LIMIT) late = 1;
+  }
+  __threadfence_system();
+  __syncthreads();
+  for (int i = t; i < n_small; i += PK_BLOCK) {
+    double sum = 0.0;
+    for (int q = 0; q < W; ++q)                         // rank order: the same additions on every rank
+      sum += q == me ? mine[i]
+                     : __longlong_as_double((long long)sys_load(A.xc_box[me] + half + (size_t)q * A.xc_stride + 1 + i));
+    total[i] = late ? __longlong_as_double(0x7FF8000000000000ll) : sum;
+  }
+  __syncthreads();
+}
+
 // pk_cycle's finalize workgroup: the same sums, in the same fixed shape (thread t adds the partials of workgroups
 // t, t + 256, ... in ascending order, DPP wave tree, waves 0..3 in order) and the same order of additions per
 // gradient slot as fin_body -- the results are bit-identical -- but fed through the hand-off slots of the launch it
@@ -1578,6 +1670,7 @@ __device__ __forceinline__ void fin_handoff(const PkArgs& A) {
   __shared__ int ridx[NR];
   const int t = threadIdx.x, wave = t >> 6;
   if (t < PK_NPHASE) dts[t] = Gen::phase_dt(t, A);
+  for (int i = t; i < PK_NI; i += PK_BLOCK) Ish[i] = 0.0;      // (integrals no system function refers to stay 0)
   for (int i = t; i < A.n_s && i < PK_NS; i += PK_BLOCK) ssh[i] = A.x[A.l_s + i];
   const int gz0 = t < A.n_gz ? A.ib[A.gz_off + t] : -1;
 #pragma unroll
@@ -1641,7 +1734,8 @@ __device__ __forceinline__ void fin_handoff(const PkArgs& A) {
     }
   __syncthreads();
   const PkSys sy{ssh, Ish, A.sigma, A.lam};
-  if (t == 0) A.o_f[0] = Gen::sys_objective(sy);          // systembase.py:592-605
+  const bool xchg = (A.flags & 64) != 0;                  // sharded cycle: the sums over the RANKS, inside this launch
+  if (t == 0 && !xchg) A.o_f[0] = Gen::sys_objective(sy); // systembase.py:592-605
   if (t == 64) {
 #pragma unroll
     for (int i = 0; i < PK_NS; ++i) gsh[i] = 0.0;
@@ -1650,6 +1744,13 @@ __device__ __forceinline__ void fin_handoff(const PkArgs& A) {
   __syncthreads();
   // gradient slots no tile writes (end slots, t0 / tf, static parameters): 0 + the sums of the rows that land on the
   // slot, phase by phase, + the objective's direct dependence on a static parameter   (systembase.py:654-657)
+  // (the finalize workgroup stages no tile: the exchange's two vectors live in the launch's dynamic LDS, which the
+  // runtime sizes to at least 2 PK_XC_CAP doubles for a sharded cycle -- static arrays would cost EVERY workgroup of
+  // the launch 8 KB of LDS and the humanoid its second workgroup per CU)
+  extern __shared__ double pk_lds[];
+  double* __restrict__ xmine = pk_lds;
+  double* __restrict__ xtotal = pk_lds + PK_XC_CAP;
+  double* __restrict__ gout = A.o_gshared ? A.o_gshared : A.o_grad;
   for (int z = t; z < A.n_gz; z += PK_BLOCK) {
     const int idx = z == t ? gz0 : A.ib[A.gz_off + z];
     double v = 0.0;
@@ -1657,67 +1758,39 @@ __device__ __forceinline__ void fin_handoff(const PkArgs& A) {
     for (int row = 0; row < Gen::N_ROWS; ++row)
       if (Gen::row_arr(row) && ridx[row] == idx) v += tot[row];
     if (idx >= A.l_s && idx < A.l_s + A.n_s) v += gsh[idx - A.l_s];
-    (A.o_gshared ? A.o_gshared : A.o_grad)[idx] = v;
+    if (xchg) xmine[PK_NI + z] = v;
+    else gout[idx] = v;
+  }
+  if (!xchg) return;                                      // (wave-uniform)
+  // this shard's partial vector [integrals | the slots above, in their order]: PK_NI + n_gz <= PK_XC_CAP (host checks)
+  for (int i = t; i < PK_NI; i += PK_BLOCK) xmine[i] = Ish[i];
+  __syncthreads();
+  exchange_partials(A, xmine, xtotal, PK_NI + A.n_gz);
+  for (int i = t; i < PK_NI; i += PK_BLOCK) A.Ibuf[i] = xtotal[i];
+  for (int z = t; z < A.n_gz; z += PK_BLOCK) gout[z == t ? gz0 : A.ib[A.gz_off + z]] = xtotal[PK_NI + z];
+  if (t == 0) {
+    const PkSys syt{ssh, xtotal, A.sigma, A.lam};
+    A.o_f[0] = Gen::sys_objective(syt);                   // f on the global integrals, on every rank
   }
 }
 
-// ============================================================================================
-// pk_xchg: the ONLY exchange a sharded cycle needs -- the sums over all nodes.  Every rank evaluates its share of the
-// mesh intervals into its own HBM (pk_cycle on the shard's tiles); what couples the shards is a handful of doubles:
-// the integrals (-> f) and the gradient entries of t0 / tf / static parameters.  Each rank posts its partial vector
-// [integrals | shared gradient slots] into every peer's mailbox (peer-mapped fine-grained device memory, stores over
-// xGMI), raises a flag (the cycle number), waits for the flags of all peers, and adds the vectors IN RANK ORDER
-// (every rank gets bit-identical sums) -- one workgroup, no collective library call, no host round trip.
-// Mailbox of a rank: [parity 2][sender world][xc_stride] words, word 0 of a sender's slot = flag, data from word 1.
-// Two parities: a rank that is one cycle ahead posts into the other half (it cannot be two ahead: it needs every
-// peer's flag of the cycle in between).  The poll is bounded (then the sums read NaN).
-// ============================================================================================
-__device__ __forceinline__ void sys_store(unsigned long long* p, unsigned long long v) {
-  __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-}
-__device__ __forceinline__ unsigned long long sys_load(unsigned long long* p) {
-  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-}
-
+// pk_xchg: the exchange as a launch of its own, behind the shard's pk_cycle on the same stream (A/B form of the in-launch
+// exchange; also what a caller uses that runs the callbacks one by one).  Partial vector: [integrals | the gradient
+// slots xc_idx lists].
 template <class Gen>
 __device__ __forceinline__ void kernel_xchg(const PkArgs& A) {
-  constexpr int CAP = 512;                              // doubles of a partial vector held in LDS (host checks)
-  __shared__ double mine[CAP];
-  __shared__ double total[CAP];
-  __shared__ int late;
-  const int t = threadIdx.x, W = A.xc_world, me = A.xc_rank;
+  __shared__ double mine[PK_XC_CAP];
+  __shared__ double total[PK_XC_CAP];
+  const int t = threadIdx.x;
   const int n_I = PK_NI, n_small = n_I + A.xc_nsh;
-  const size_t half = (size_t)(A.xc_epoch & 1) * W * A.xc_stride;
   double* __restrict__ gsh = A.o_gshared ? A.o_gshared : A.o_grad;
-  if (t == 0) late = 0;
+  for (int i = t; i < n_small; i += PK_BLOCK) mine[i] = i < n_I ? A.Ibuf[i] : gsh[A.xc_idx[i - n_I]];
+  __syncthreads();
+  exchange_partials(A, mine, total, n_small);
   for (int i = t; i < n_small; i += PK_BLOCK) {
-    const double v = i < n_I ? A.Ibuf[i] : gsh[A.xc_idx[i - n_I]];
-    mine[i] = v;
-    for (int q = 0; q < W; ++q)
-      if (q != me) sys_store(A.xc_box[q] + half + (size_t)me * A.xc_stride + 1 + i, (unsigned long long)__double_as_longlong(v));
+    if (i < n_I) A.Ibuf[i] = total[i];
+    else gsh[A.xc_idx[i - n_I]] = total[i];
   }
-  __threadfence_system();                               // my data before my flags, for every observer
-  __syncthreads();
-  if (t < W && t != me) sys_store(A.xc_box[t] + half + (size_t)me * A.xc_stride, (unsigned long long)A.xc_epoch);
-  if (t < W && t != me) {                               // one polling thread per peer
-    unsigned long long* flag = A.xc_box[me] + half + (size_t)t * A.xc_stride;
-    int tries = 0;
-    while (sys_load(flag) != (unsigned long long)A.xc_epoch && ++tries < PK_POLL_LIMIT) __builtin_amdgcn_s_sleep(PK_POLL_SLEEP);
-    if (tries >= PK_POLL_LIMIT) late = 1;
-  }
-  __threadfence_system();
-  __syncthreads();
-  for (int i = t; i < n_small; i += PK_BLOCK) {
-    double sum = 0.0;
-    for (int q = 0; q < W; ++q)                         // rank order: the same additions on every rank
-      sum += q == me ? mine[i]
-                     : __longlong_as_double((long long)sys_load(A.xc_box[me] + half + (size_t)q * A.xc_stride + 1 + i));
-    if (late) sum = __longlong_as_double(0x7FF8000000000000ll);
-    total[i] = sum;
-    if (i < n_I) A.Ibuf[i] = sum;
-    else gsh[A.xc_idx[i - n_I]] = sum;
-  }
-  __syncthreads();
   if (t == 0 && (A.flags & 1)) {
     const PkSys sy{A.x + A.l_s, total, A.sigma, A.lam};
     A.o_f[0] = Gen::sys_objective(sy);                  // systembase.py:592-605, on the global integrals

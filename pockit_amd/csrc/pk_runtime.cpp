@@ -39,7 +39,7 @@ namespace {
 enum { K_INT = 0, K_FIN, K_G, K_GRAD, K_JAC, K_HESS, K_XALL, K_AUX, K_OUTER, K_HESSC, K_ERR, K_CSR, K_CYCLE, K_XCHG, K_RUNS, K_COUNT };
 const char* const kKernelNames[K_COUNT] = {"pk_int", "pk_fin", "pk_g", "pk_grad", "pk_jac", "pk_hess", "pk_xall",
                                            "pk_aux", "pk_outer", "pk_hessc", "pk_err", "pk_csr", "pk_cycle", "pk_xchg", "pk_runs"};
-enum { F_WRITE_F = 1, F_SECONDARY = 2, F_FIN_INT = 8, F_FIN_GRAD = 16, F_SPLIT = 32 };
+enum { F_WRITE_F = 1, F_SECONDARY = 2, F_FIN_INT = 8, F_FIN_GRAD = 16, F_SPLIT = 32, F_XCHG = 64 };
 
 thread_local std::string g_create_error;
 
@@ -63,8 +63,11 @@ struct pk_ctx {
   const unsigned long long* const* xc_box = nullptr;
   const int32_t* xc_idx = nullptr;
   int32_t xc_world = 0, xc_rank = 0, xc_nsh = 0, xc_stride = 0;
+  int32_t xc_epoch = 0;         // cycles exchanged so far (every rank counts the same)
+  bool xc_inline = false;       // pk_cycle's finalize workgroup exchanges the partial sums itself (pk_set_exchange_inline)
   bool split_xall = false;      // pk_xall with two waves per tile (values / Jacobian), see pk_set_problem
   int cycle_mode = 1;           // 1: single-launch pk_cycle; 0: pk_xall + pk_hess (pk_set_cycle_mode)
+  int tab_cap = 64;             // entries of a staged pattern table: 64, or 256 when the mesh has intervals with K > 8
   unsigned long long *d_cpart = nullptr, *d_cpart2 = nullptr;   // pk_cycle's hand-off slots (PK_EMPTY between launches)
   unsigned profile_mask = 0;
   unsigned profile_period = 1;  // time every n-th launch of a selected kernel
@@ -225,6 +228,7 @@ PkArgs base_args(pk_ctx* c, const double* d_x, const double* d_lam, double sigma
   for (size_t k = 0; k < c->h_phases.size(); ++k) A.ph[k] = c->h_phases[k];
   A.trace = c->d_trace;
   A.o_gshared = c->gshared;
+  A.tab_cap = c->tab_cap;
   return A;
 }
 
@@ -232,6 +236,12 @@ int launch_raw(pk_ctx* c, int k, void* args, size_t sz, unsigned grid, size_t ld
   void* config[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, args, HIP_LAUNCH_PARAM_BUFFER_SIZE, &sz, HIP_LAUNCH_PARAM_END};
   EventPair ev{};
   if (grid == 0) return 0;
+  // the tile kernels that stage their pattern tables keep one table block per wave in front of the model's staging area
+  if (k == K_G || k == K_JAC || k == K_HESS || k == K_XALL || k == K_CYCLE)
+    lds_bytes += sizeof(double) * PK_WAVES_PER_BLOCK * (size_t)(2 * c->tab_cap + 2 * PK_WAVE + c->tab_cap / 2);
+  if (k == K_CYCLE && c->xc_inline && c->xc_world > 1 && lds_bytes < sizeof(double) * 2 * 512)
+    lds_bytes = sizeof(double) * 2 * 512;      // the finalize workgroup's exchange vectors (2 x PK_XC_CAP doubles)
+  if (lds_bytes > 160 * 1024) return fail(c, 22, "%s needs %zu bytes of LDS per workgroup (> 160 KiB)", kKernelNames[k], lds_bytes);
   // every `profile_period`-th launch of a selected kernel is timed (the timed launch path costs ~2-3 us of host
   // and command-processor work, so timing all of them would slow the loop being measured)
   const bool timed = c->profiling && ((c->profile_mask >> k) & 1u) && (c->profile_seen[k]++ % c->profile_period == 0);
@@ -284,6 +294,11 @@ int enqueue_single_launch_cycle(pk_ctx* c, const double* d_x, const double* d_la
   A.items2 = (const PkItem*)c->d_items_hess;
   A.n_items2 = c->n_items_hess;
   A.flags |= F_FIN_INT | F_WRITE_F | F_FIN_GRAD | xall_flags(c);
+  if (c->xc_inline && c->xc_world > 1) {      // sharded: the sums over the ranks are exchanged inside this launch
+    A.flags |= F_XCHG;
+    A.xc_box = (unsigned long long* const*)c->xc_box; A.xc_idx = c->xc_idx;
+    A.xc_world = c->xc_world; A.xc_rank = c->xc_rank; A.xc_epoch = ++c->xc_epoch; A.xc_nsh = c->xc_nsh; A.xc_stride = c->xc_stride;
+  }
   size_t dbl = PK_WAVES_PER_BLOCK * (size_t)(c->md.lds_x > c->md.lds_h ? c->md.lds_x : c->md.lds_h);
   if (dbl < (size_t)c->md.ne_j) dbl = (size_t)c->md.ne_j;
   if (dbl < (size_t)c->md.ne_h) dbl = (size_t)c->md.ne_h;
@@ -448,6 +463,19 @@ int pk_set_problem(pk_ctx* c, const pk_problem_desc* pd) {
   {
     const char* env = getenv("POCKIT_AMD_SPLIT");
     c->split_xall = env ? atoi(env) != 0 : (pd->n_tiles > 0 && pd->n_tiles <= 1024);
+  }
+  {   // pattern tables of up to 64 entries (K <= 8) are staged one entry per lane; a mesh with higher orders (K <= 16:
+      // up to 256 entries) gets the larger table blocks, anything beyond reads its tables from global memory
+    c->tab_cap = 64;
+    const PkTile* tl = (const PkTile*)pd->tiles;
+    const PkPhase* ph = (const PkPhase*)pd->phases;
+    for (int32_t t = 0; t < pd->n_tiles; ++t) {
+      if (tl[t].nj <= 0 || tl[t].phase < 0 || tl[t].phase >= pd->n_phase) continue;
+      const int R = tl[t].K - ph[tl[t].phase].scheme;
+      const int need = tl[t].nnzI > R * tl[t].K ? tl[t].nnzI : R * tl[t].K;
+      if (need > 64 && need <= 256) c->tab_cap = 256;
+    }
+    if (const char* env = getenv("POCKIT_AMD_TAB_CAP")) c->tab_cap = atoi(env) >= 256 ? 256 : 64;   // A/B switch
   }
   int rc;
   if ((rc = upload(c, &c->d_phases, pd->phases, sizeof(PkPhase) * (size_t)pd->n_phase))) return rc;
@@ -1144,7 +1172,18 @@ int pk_set_exchange(pk_ctx* c, int world, int rank, const void* d_boxes, const i
     return fail(c, 91, "pk_set_exchange: partial vector of %d doubles (at most 512), slot of %d words", c->md.n_I + n_sh, stride);
   c->xc_box = (const unsigned long long* const*)d_boxes;
   c->xc_idx = d_idx;
+  if (n_sh != c->n_gz) return fail(c, 94, "pk_set_exchange: %d shared gradient slots, the problem has %d", n_sh, c->n_gz);
   c->xc_world = world; c->xc_rank = rank; c->xc_nsh = n_sh; c->xc_stride = stride;
+  c->xc_epoch = 0;
+  return 0;
+}
+
+// 1: pk_eval_cycle_dev's single launch exchanges the partial sums itself (its finalize workgroup posts, waits and adds:
+// a sharded cycle is ONE launch per GPU); 0: the caller runs pk_exchange_sums_dev behind it (a second launch).
+int pk_set_exchange_inline(pk_ctx* c, int enable) {
+  if (!c) return fail(nullptr, 1, "null context");
+  if (enable && !c->xc_box) return fail(c, 92, "pk_set_exchange_inline: call pk_set_exchange first");
+  c->xc_inline = enable != 0;
   return 0;
 }
 
@@ -1154,7 +1193,7 @@ int pk_exchange_sums_dev(pk_ctx* c, const double* d_x, double* d_grad, double* d
   int rc = ready(c);
   if (rc) return rc;
   if (!c->xc_box) return fail(c, 92, "pk_exchange_sums: call pk_set_exchange first");
-  if (epoch < 1) return fail(c, 93, "pk_exchange_sums: the cycle number starts at 1");
+  if (epoch <= 0) epoch = ++c->xc_epoch;      // (the context counts the cycles; every rank counts the same)
   PkArgs A = base_args(c, d_x, nullptr, 0.0);
   A.o_grad = d_grad; A.o_f = d_f;
   A.xc_box = (unsigned long long* const*)c->xc_box; A.xc_idx = c->xc_idx;

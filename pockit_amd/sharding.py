@@ -304,7 +304,6 @@ class PeerMailboxes:
         self.idx = torch.tensor(np.asarray(shared, dtype=np.int32), dtype=torch.int32, device=device)
         chk(lib.pk_set_exchange(h, world, rank, C.c_void_p(self.table.data_ptr()), C.c_void_p(self.idx.data_ptr()),
                                 len(shared), self.stride))
-        self.epoch = 0
         dist.barrier()                     # every rank has mapped every mailbox before the first flag is raised
 
     def close(self):
@@ -397,6 +396,7 @@ class ShardedEvaluator:
         self.ev.ctx.check(lib.pk_set_shard(h, int(rank != 0), 1, C.c_void_p(self.I.data_ptr())))
         self.stream = torch.cuda.Stream(device=dev)
         self.peers, self.root, self._root_alloc, self._root_map, self.target = None, None, None, None, None
+        self.inline_exchange = True      # the sums over the ranks are exchanged inside pk_cycle's launch (False: pk_xchg behind it)
 
     def _views(self, full):
         out, off = {}, 0
@@ -464,7 +464,7 @@ class ShardedEvaluator:
         torch call (bench.py: the loop is launch-bound, a cycle is two ~5 us launches)."""
         if self.peers is None or (exchange == "direct" and self.target is None):
             raise RuntimeError(f'exchange="{exchange}" needs enable_peer_exchange() first')
-        lib, h, chk, o, peers = self.ev.ctx.lib, self.ev.ctx.handle, self.ev.ctx.check, self.out, self.peers
+        lib, h, chk, o = self.ev.ctx.lib, self.ev.ctx.handle, self.ev.ctx.check, self.out
         st = C.c_void_p(self.stream.cuda_stream)
         ptr = lambda t: C.c_void_p(t.data_ptr())  # noqa: E731
         remote = exchange == "direct" and self.rank != self.root
@@ -477,12 +477,17 @@ class ShardedEvaluator:
                tg["H"], st)
         px, pgrad, pf = C.c_void_p(x.data_ptr()), (ptr(o["grad"]) if remote else tg["grad"]), ptr(o["f"])
         cycle_fn, xchg_fn = lib.pk_eval_cycle_dev, lib.pk_exchange_sums_dev
-
-        def step():
-            peers.epoch += 1
-            rc = cycle_fn(*cyc) or xchg_fn(h, px, pgrad, pf, peers.epoch, 1, st)
-            if rc:
-                chk(rc)
+        chk(lib.pk_set_exchange_inline(h, int(self.inline_exchange)))     # (stays set: the caller's loop owns the context)
+        if self.inline_exchange:
+            def step():
+                rc = cycle_fn(*cyc)
+                if rc:
+                    chk(rc)
+        else:
+            def step():
+                rc = cycle_fn(*cyc) or xchg_fn(h, px, pgrad, pf, 0, 1, st)
+                if rc:
+                    chk(rc)
 
         return step
 
@@ -513,7 +518,6 @@ class ShardedEvaluator:
         if sharded and exchange in ("sums", "direct"):
             if self.peers is None or (exchange == "direct" and self.target is None):
                 raise RuntimeError(f'exchange="{exchange}" needs enable_peer_exchange() first')
-            self.peers.epoch += 1
             remote = exchange == "direct" and self.rank != self.root
             if exchange == "direct":
                 tg = {k: C.c_void_p(v) for k, v in self.target.items()}
@@ -522,14 +526,17 @@ class ShardedEvaluator:
             else:
                 tg = {k: ptr(o[k]) for k in ("grad", "g", "J", "H")}
                 chk(lib.pk_set_shared_grad_target(h, None))
+            chk(lib.pk_set_exchange_inline(h, int(self.inline_exchange)))
             chk(lib.pk_eval_cycle_dev(h, px, ptr(lam), float(sigma), ptr(o["f"]), tg["grad"], tg["g"], tg["J"], tg["H"], st))
-            chk(lib.pk_exchange_sums_dev(h, px, tg["grad"] if not remote else ptr(o["grad"]), ptr(o["f"]),
-                                         self.peers.epoch, 1, st))
+            if not self.inline_exchange:
+                chk(lib.pk_exchange_sums_dev(h, px, tg["grad"] if not remote else ptr(o["grad"]), ptr(o["f"]), 0, 1, st))
+            chk(lib.pk_set_exchange_inline(h, 0))
             return o
         if not self.early_I:
             # ONE launch per rank (pk_cycle): this shard's tiles of all five outputs, its share of the integrals (-> self.I)
             # and of the shared gradient slots; f is recomputed from the reduced integrals below
             chk(lib.pk_set_shared_grad_target(h, None))
+            chk(lib.pk_set_exchange_inline(h, 0))
             chk(lib.pk_eval_cycle_dev(h, px, ptr(lam), float(sigma), ptr(o["f"]), ptr(o["grad"]), ptr(o["g"]), ptr(o["J"]),
                                       ptr(o["H"]), st))
         else:

@@ -118,6 +118,38 @@ def test_unit_divisor_tiles_match_oracle(case, ipw, monkeypatch):
     close(ev.hessian_direct(x, lam, sigma), ref.hessian(x, lam, sigma), what="H direct")
 
 
+@pytest.mark.parametrize("cap", ["", "64"])
+@pytest.mark.parametrize("case", [("brachistochrone", "radau", dict(mesh=13, num_point=12)),
+                                  ("brachistochrone", "lobatto", dict(mesh=9, num_point=16)),
+                                  ("planar_quadrotor", "radau", dict(mesh=21, num_point=10)),
+                                  ("humanoid_wbc", "radau", dict(mesh=7, num_point=9)),
+                                  ("two_stage_rocket", "radau", dict(mesh=5, num_point=16)),
+                                  ("brachistochrone", "radau", dict(mesh=[0, 0.2, 0.5, 0.6, 1.0], num_point=[9, 16, 20, 7])),
+                                  ("planar_quadrotor", "lobatto", dict(mesh=3, num_point=24))])
+def test_high_order_tiles_match_oracle(case, cap, monkeypatch):
+    """Patterns with 9 <= K <= 16 stage their (up to 256-entry) tables in LDS over four entries per lane; K > 16 (and
+    POCKIT_AMD_TAB_CAP=64: every K > 8) reads them from global memory in the unstaged variant of phase B."""
+    if cap:
+        monkeypatch.setenv("POCKIT_AMD_TAB_CAP", cap)
+    bname, scheme, kw = case
+    system, _, guess = getattr(models, bname)(_ns(scheme, "pockit_amd"), **kw)
+    ref, _, _ = getattr(models, bname)(_ns(scheme, "oracle"), **kw)
+    x, lam, sigma = models.bench_inputs(system, guess)
+    close(system.objective(x), ref.objective(x), what="f")
+    close(system.gradient(x), ref.gradient(x), what="grad")
+    close(system.constraints(x), ref.constraints(x), what="g")
+    close(system.jacobian(x), ref.jacobian(x), what="J")
+    close(system.hessian(x, lam, sigma), ref.hessian(x, lam, sigma), what="H")
+    f, grad, g, J, H = system.evaluator.cycle(x, lam, sigma)
+    close(g, ref.constraints(x), what="cycle g")
+    close(J, ref.jacobian(x), what="cycle J")
+    close(H, ref.hessian(x, lam, sigma), what="cycle H")
+    ev = system.evaluator
+    close(ev.constraints_direct(x), ref.constraints(x), what="g direct")
+    close(ev.jacobian_direct(x), ref.jacobian(x), what="J direct")
+    close(ev.hessian_direct(x, lam, sigma), ref.hessian(x, lam, sigma), what="H direct")
+
+
 def test_prepared_x_cache_is_dropped_by_calls_that_reuse_the_context_buffers():
     """objective / gradient / constraints / jacobian / hessian on x1 serve from ONE upload of x1; any other entry
     point that uploads a different x (mesh error, the one-launch cycle, the *_direct and CSR calls) in between must

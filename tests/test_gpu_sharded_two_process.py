@@ -97,7 +97,8 @@ def _peer_worker(rank, world, port, case, ret):
         shared = shared_gradient_slots(plan)
         scale = lambda a: max(1.0, float(np.max(np.abs(a)))) if a.size else 1.0  # noqa: E731
         err = 0.0
-        for rep in range(3):                                      # the mailboxes alternate between their two halves
+        for rep in range(4):                                      # the mailboxes alternate between their two halves
+            sev.inline_exchange = rep % 2 == 0                     # exchange inside pk_cycle's launch / as pk_xchg behind it
             xk = x * (1.0 + 1e-3 * rep)
             if rep:
                 want = np.concatenate([ref.gradient(xk), ref.constraints(xk), ref.jacobian(xk), ref.hessian(xk, lam, sigma)])

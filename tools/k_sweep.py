@@ -1,19 +1,20 @@
 #!/usr/bin/env python3
 """Developer helper: cycles/s of the single-launch cycle for several polynomial orders K at ~12k nodes
-(K > 8: the pattern tables of a tile exceed the 64-entry LDS copies)."""
+(K <= 8: pattern tables staged one entry per lane; 9 <= K <= 16: staged over four entries per lane; beyond: read from
+global memory in phase B).  POCKIT_AMD_TAB_CAP=64 forces the unstaged variant for every K > 8 (A/B)."""
 import os
 import sys
 import time
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-sys.path[:0] = [ROOT, os.path.join(ROOT, "tests")]
+sys.path[:0] = [ROOT]
 import torch  # noqa: E402
 
-import models  # noqa: E402
+from pockit_amd import benchmarks as models  # noqa: E402
 import pockit_amd.radau as radau  # noqa: E402
 
 dev = torch.device("cuda", 0)
-for K in (4, 6, 8, 9, 10, 12, 16, 20):
+for K in (4, 6, 8, 9, 10, 12, 16, 20):      # (run with and without POCKIT_AMD_TAB_CAP=64)
     n_int = 12000 // K
     system, _, guess = models.planar_quadrotor(radau, mesh=n_int, num_point=K)
     plan, ev = system.plan, system.evaluator
