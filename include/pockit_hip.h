@@ -54,6 +54,7 @@ typedef struct pk_model_desc {
   int32_t ne_a;         /* scalar expressions of the auxiliary pass (outer-product Hessian path)  */
   int32_t ne_hc;        /* scalar expressions of the compact Hessian                              */
   int32_t lds_e;        /* LDS doubles per wave of the mesh error estimation kernel (pk_err)      */
+  int32_t tab_cap;      /* PK_TAB_CAP the code object was compiled with: entries of a staged pattern table, 64 or 256 */
 } pk_model_desc;
 
 /* One (model, mesh) instance: sizes plus the table blobs built by pockit_amd/evaluator.py.

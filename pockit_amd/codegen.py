@@ -370,6 +370,15 @@ class ModelSource:
         S.append(f"#define PK_NS {max(plan.n_s, 1)}")
         S.append(f"#define PK_NSYS {max(plan.n_sys, 1)}")
         S.append(f"#define PK_NI {max(len(plan.I_syms), 1)}")
+        # Capacity of the staged pattern tables: the ONE mesh fact the code object depends on -- 64 entries (every interval
+        # has K <= 8, one entry per lane) or 256 (some interval has 9 <= K <= 16).  A refinement that first raises an
+        # order beyond 8 costs one more compile; both variants stay cached.  POCKIT_AMD_TAB_CAP=64|256 overrides (A/B).
+        need = max([1] + [max(kd.nnzI, kd.R * kd.K) for pp in plan.phase_plans for kd in pp.layout.kinds
+                          if max(kd.nnzI, kd.R * kd.K) <= 256])
+        self.tab_cap = 256 if need > 64 else 64
+        if os.environ.get("POCKIT_AMD_TAB_CAP") in ("64", "256"):
+            self.tab_cap = int(os.environ["POCKIT_AMD_TAB_CAP"])
+        S.append(f"#define PK_TAB_CAP {self.tab_cap}")
         if os.environ.get("POCKIT_AMD_TRACE", "0") == "1":   # developer tracing of the wave timeline (tools/wave_trace.py)
             S.append("#define PK_TRACE 1")
         if os.environ.get("POCKIT_AMD_XCD_REMAP", "1") == "0":       # A/B switch of the XCD-aware block mapping
@@ -378,6 +387,10 @@ class ModelSource:
             S.append(f"#define PK_POLL_SLEEP {int(os.environ['POCKIT_AMD_POLL_SLEEP'])}")
         if os.environ.get("POCKIT_AMD_WIDE_STORES", "1") == "0":     # A/B switch: 8-byte stores in the streaming loop
             S.append("#define PK_WIDE_STORES 0")
+        stream = {"sc1nt": "sc1 nt", "nt": "nt", "plain": "", "sc0sc1": "sc0 sc1", "sc0sc1nt": "sc0 sc1 nt"}.get(
+            os.environ.get("POCKIT_AMD_STREAM", ""))
+        if stream is not None:                                       # A/B switch: cache policy of the 16-byte streaming stores
+            S.append(f'#define PK_STREAM_FLAGS "{stream}"')
         if os.environ.get("POCKIT_AMD_NT", "") in ("0", "1", "2", "3", "4"):   # A/B switch of the output store flavour
             S.append(f"#define PK_NT_STORES {os.environ['POCKIT_AMD_NT']}")
         S.append('#include "pk_kernels.hip.h"')

@@ -173,6 +173,10 @@ __device__ __forceinline__ int xcd_tile_block(int wg, int first, int total) {
 #ifndef PK_NT_STORES
 #define PK_NT_STORES 2
 #endif
+// cache-policy bits of the 16-byte streaming stores (A/B: POCKIT_AMD_STREAM=sc1|sc1nt|nt|plain at code generation)
+#ifndef PK_STREAM_FLAGS
+#define PK_STREAM_FLAGS "sc1"
+#endif
 #ifndef PK_WIDE_STORES
 #define PK_WIDE_STORES 1      // streaming loop: two consecutive positions per lane, one 16-byte store per segment
 #endif
@@ -316,10 +320,17 @@ __device__ __forceinline__ TileGeom tile_geom(const PkTile& tl) {
 // translation and streaming phases then read LDS only -- no dependent global round trips between the
 // evaluation and the stores (measured on MI355X: each such round trip costs the latency-bound kernels
 // 0.6-0.8 us).  Larger K keeps the tables in global memory.
-#define PK_TAB_MAX 256      // entries of the largest staged table (K <= 16: R K <= 256 entries); pk_set_problem picks 64 or 256
+// PK_TAB_CAP: entries of the largest staged pattern table, a COMPILE-TIME constant of the code object -- 64 (every
+// interval has K <= 8: one entry per lane, the common case) or 256 (K <= 16: R K <= 256 entries, four per lane), chosen by
+// the code generator from the mesh (codegen.py).  As a run-time value it cost the 12k-node cycle 13 % (every LDS address
+// of the staging area then needs address arithmetic instead of an immediate offset: 211k -> 184k cycles/s).
+#ifndef PK_TAB_CAP
+#define PK_TAB_CAP 64
+#endif
+#define PK_TAB_ROUNDS (PK_TAB_CAP / PK_WAVE)
 struct TabRegs {
-  double iv[PK_TAB_MAX / PK_WAVE], full[PK_TAB_MAX / PK_WAVE], tv, wd;
-  int rc[PK_TAB_MAX / PK_WAVE];
+  double iv[PK_TAB_ROUNDS], full[PK_TAB_ROUNDS], tv, wd;
+  int rc[PK_TAB_ROUNDS];
 };
 
 struct TileTabs {
@@ -331,13 +342,13 @@ struct TileTabs {
   const int* __restrict__ rc;       // r | c << 16, [cap]
 };
 
-// doubles of one wave's table block in dynamic LDS, for table capacity `cap` (64, or 256 when the mesh has K > 8)
-__device__ __forceinline__ int tab_width(int cap) { return 2 * cap + 2 * PK_WAVE + cap / 2; }
+// doubles of one wave's table block in dynamic LDS
+#define PK_TAB_WIDTH (2 * PK_TAB_CAP + 2 * PK_WAVE + PK_TAB_CAP / 2)
 // start of the per-wave model staging area: behind the table blocks of the workgroup's waves
-#define PK_STAGE(A) (pk_lds + PK_WAVES_PER_BLOCK * pk::tab_width((A).tab_cap))
+#define PK_STAGE(A) (pk_lds + PK_WAVES_PER_BLOCK * PK_TAB_WIDTH)
 
 __device__ __forceinline__ bool tabs_fit(const PkArgs& A, const PkTile& tl, const TileGeom& g) {
-  return tl.nnzI <= A.tab_cap && g.R * g.K <= A.tab_cap && tl.nnzT <= PK_WAVE && !PK_DIAG(4096);
+  return tl.nnzI <= PK_TAB_CAP && g.R * g.K <= PK_TAB_CAP && tl.nnzT <= PK_WAVE && !PK_DIAG(4096);
 }
 
 // Entry e = lane + 64 u of a table is loaded by lane `lane` (u = 0 .. cap / 64 - 1): one round for K <= 8, up to four
@@ -346,12 +357,12 @@ __device__ __forceinline__ TabRegs tabs_issue(const PkArgs& A, const PkPhase& ph
                                               bool fit, int lane) {
   TabRegs t;
 #pragma unroll
-  for (int u = 0; u < PK_TAB_MAX / PK_WAVE; ++u) { t.iv[u] = 0.0; t.full[u] = 0.0; t.rc[u] = 0; }
+  for (int u = 0; u < PK_TAB_ROUNDS; ++u) { t.iv[u] = 0.0; t.full[u] = 0.0; t.rc[u] = 0; }
   t.tv = 0.0; t.wd = 0.0;
   if (!fit) return t;
   const int nfull = g.R * g.K;
 #pragma unroll
-  for (int u = 0; u < PK_TAB_MAX / PK_WAVE; ++u) {
+  for (int u = 0; u < PK_TAB_ROUNDS; ++u) {
     const int e = lane + PK_WAVE * u;
     if (u == 0 || tl.nnzI > PK_WAVE * u) {
       if (e < tl.nnzI) {
@@ -372,8 +383,8 @@ __device__ __forceinline__ TileTabs tabs_commit(const PkArgs& A, const PkTile& t
                                                 bool fit, int lane) {
   extern __shared__ double pk_lds[];
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int cap = A.tab_cap;
-  double* __restrict__ iv = pk_lds + wave * tab_width(cap);
+  constexpr int cap = PK_TAB_CAP;
+  double* __restrict__ iv = pk_lds + wave * PK_TAB_WIDTH;
   double* __restrict__ full = iv + cap;
   double* __restrict__ tv = full + cap;
   double* __restrict__ wd = tv + PK_WAVE;
@@ -381,7 +392,7 @@ __device__ __forceinline__ TileTabs tabs_commit(const PkArgs& A, const PkTile& t
   if (fit) {
     const int nfull = g.R * g.K;
 #pragma unroll
-    for (int u = 0; u < PK_TAB_MAX / PK_WAVE; ++u) {
+    for (int u = 0; u < PK_TAB_ROUNDS; ++u) {
       const int e = lane + PK_WAVE * u;
       if (u == 0 || tl.nnzI > PK_WAVE * u) { iv[e] = t.iv[u]; rc[e] = t.rc[u]; }
       if (u == 0 || nfull > PK_WAVE * u) full[e] = t.full[u];
@@ -537,7 +548,7 @@ __device__ __forceinline__ void stream_loop(const PkArgs& A, const PkPhase& ph, 
       for (int e = 0; e < NI; ++e) {
         if (pair) {
           const pk_d2 w = {v[0][e], v[1][e]};
-          asm volatile("global_store_dwordx4 %0, %1, off sc1" : : "v"(&run[e][p0]), "v"(w));
+          asm volatile("global_store_dwordx4 %0, %1, off " PK_STREAM_FLAGS : : "v"(&run[e][p0]), "v"(w));
         } else {
           put(&run[e][p0], v[0][e]);
         }

@@ -67,7 +67,6 @@ struct pk_ctx {
   bool xc_inline = false;       // pk_cycle's finalize workgroup exchanges the partial sums itself (pk_set_exchange_inline)
   bool split_xall = false;      // pk_xall with two waves per tile (values / Jacobian), see pk_set_problem
   int cycle_mode = 1;           // 1: single-launch pk_cycle; 0: pk_xall + pk_hess (pk_set_cycle_mode)
-  int tab_cap = 64;             // entries of a staged pattern table: 64, or 256 when the mesh has intervals with K > 8
   unsigned long long *d_cpart = nullptr, *d_cpart2 = nullptr;   // pk_cycle's hand-off slots (PK_EMPTY between launches)
   unsigned profile_mask = 0;
   unsigned profile_period = 1;  // time every n-th launch of a selected kernel
@@ -228,7 +227,6 @@ PkArgs base_args(pk_ctx* c, const double* d_x, const double* d_lam, double sigma
   for (size_t k = 0; k < c->h_phases.size(); ++k) A.ph[k] = c->h_phases[k];
   A.trace = c->d_trace;
   A.o_gshared = c->gshared;
-  A.tab_cap = c->tab_cap;
   return A;
 }
 
@@ -238,7 +236,7 @@ int launch_raw(pk_ctx* c, int k, void* args, size_t sz, unsigned grid, size_t ld
   if (grid == 0) return 0;
   // the tile kernels that stage their pattern tables keep one table block per wave in front of the model's staging area
   if (k == K_G || k == K_JAC || k == K_HESS || k == K_XALL || k == K_CYCLE)
-    lds_bytes += sizeof(double) * PK_WAVES_PER_BLOCK * (size_t)(2 * c->tab_cap + 2 * PK_WAVE + c->tab_cap / 2);
+    lds_bytes += sizeof(double) * PK_WAVES_PER_BLOCK * (size_t)(2 * c->md.tab_cap + 2 * PK_WAVE + c->md.tab_cap / 2);
   if (k == K_CYCLE && c->xc_inline && c->xc_world > 1 && lds_bytes < sizeof(double) * 2 * 512)
     lds_bytes = sizeof(double) * 2 * 512;      // the finalize workgroup's exchange vectors (2 x PK_XC_CAP doubles)
   if (lds_bytes > 160 * 1024) return fail(c, 22, "%s needs %zu bytes of LDS per workgroup (> 160 KiB)", kKernelNames[k], lds_bytes);
@@ -435,6 +433,7 @@ int pk_load_model(pk_ctx* c, const void* code_object, size_t len, const pk_model
   PK_HIP(c, hipModuleLoadData(&c->module, code_object));
   for (int k = 0; k < K_COUNT; ++k) PK_HIP(c, hipModuleGetFunction(&c->fn[k], c->module, kKernelNames[k]));
   c->md = *md;
+  if (md->tab_cap != 64 && md->tab_cap != 256) return fail(c, 23, "pk_load_model: table capacity %d (64 or 256)", md->tab_cap);
   const size_t lds_max = 160 * 1024;
   const size_t need[4] = {(size_t)md->lds_g, (size_t)md->lds_j, (size_t)md->lds_h, (size_t)md->lds_x};
   for (size_t v : need)
@@ -463,19 +462,6 @@ int pk_set_problem(pk_ctx* c, const pk_problem_desc* pd) {
   {
     const char* env = getenv("POCKIT_AMD_SPLIT");
     c->split_xall = env ? atoi(env) != 0 : (pd->n_tiles > 0 && pd->n_tiles <= 1024);
-  }
-  {   // pattern tables of up to 64 entries (K <= 8) are staged one entry per lane; a mesh with higher orders (K <= 16:
-      // up to 256 entries) gets the larger table blocks, anything beyond reads its tables from global memory
-    c->tab_cap = 64;
-    const PkTile* tl = (const PkTile*)pd->tiles;
-    const PkPhase* ph = (const PkPhase*)pd->phases;
-    for (int32_t t = 0; t < pd->n_tiles; ++t) {
-      if (tl[t].nj <= 0 || tl[t].phase < 0 || tl[t].phase >= pd->n_phase) continue;
-      const int R = tl[t].K - ph[tl[t].phase].scheme;
-      const int need = tl[t].nnzI > R * tl[t].K ? tl[t].nnzI : R * tl[t].K;
-      if (need > 64 && need <= 256) c->tab_cap = 256;
-    }
-    if (const char* env = getenv("POCKIT_AMD_TAB_CAP")) c->tab_cap = atoi(env) >= 256 ? 256 : 64;   // A/B switch
   }
   int rc;
   if ((rc = upload(c, &c->d_phases, pd->phases, sizeof(PkPhase) * (size_t)pd->n_phase))) return rc;

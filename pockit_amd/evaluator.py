@@ -178,6 +178,7 @@ class Evaluator:
         md.ne_a = self.src.list_off["aux"]["total"]
         md.ne_hc = self.src.list_off["hessc"]["total"] if self.src.compact else 0
         md.lds_e = self.src.lds_e
+        md.tab_cap = self.src.tab_cap
         self._err_views = None
         self._csr = {}
         md.prepass_f = 1

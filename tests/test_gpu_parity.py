@@ -118,36 +118,43 @@ def test_unit_divisor_tiles_match_oracle(case, ipw, monkeypatch):
     close(ev.hessian_direct(x, lam, sigma), ref.hessian(x, lam, sigma), what="H direct")
 
 
+# Tolerance at high orders: the ORACLE restates the reference's np.roots-based collocation tables, which lose digits with
+# K (quadrature weights against the product's Newton-polished ones: 2e-12 at K = 12, 8e-11 at K = 16, 4e-9 at K = 20,
+# 2e-7 at K = 24; the product's node residuals stay at 1e-14) -- the comparison can only be as tight as the oracle.
 @pytest.mark.parametrize("cap", ["", "64"])
-@pytest.mark.parametrize("case", [("brachistochrone", "radau", dict(mesh=13, num_point=12)),
-                                  ("brachistochrone", "lobatto", dict(mesh=9, num_point=16)),
-                                  ("planar_quadrotor", "radau", dict(mesh=21, num_point=10)),
-                                  ("humanoid_wbc", "radau", dict(mesh=7, num_point=9)),
-                                  ("two_stage_rocket", "radau", dict(mesh=5, num_point=16)),
-                                  ("brachistochrone", "radau", dict(mesh=[0, 0.2, 0.5, 0.6, 1.0], num_point=[9, 16, 20, 7])),
-                                  ("planar_quadrotor", "lobatto", dict(mesh=3, num_point=24))])
+@pytest.mark.parametrize("case", [("brachistochrone", "radau", dict(mesh=13, num_point=12), TOL),
+                                  ("brachistochrone", "lobatto", dict(mesh=9, num_point=16), 2e-9),
+                                  ("planar_quadrotor", "radau", dict(mesh=21, num_point=10), TOL),
+                                  ("humanoid_wbc", "radau", dict(mesh=7, num_point=9), TOL),
+                                  ("two_stage_rocket", "radau", dict(mesh=5, num_point=16), 2e-9),
+                                  ("brachistochrone", "radau", dict(mesh=[0, 0.2, 0.5, 0.6, 1.0], num_point=[9, 16, 20, 7]), 1e-7),
+                                  ("planar_quadrotor", "lobatto", dict(mesh=3, num_point=24), 1e-5)])
 def test_high_order_tiles_match_oracle(case, cap, monkeypatch):
     """Patterns with 9 <= K <= 16 stage their (up to 256-entry) tables in LDS over four entries per lane; K > 16 (and
     POCKIT_AMD_TAB_CAP=64: every K > 8) reads them from global memory in the unstaged variant of phase B."""
     if cap:
         monkeypatch.setenv("POCKIT_AMD_TAB_CAP", cap)
-    bname, scheme, kw = case
+    bname, scheme, kw, tol = case
+
+    def check(a, b, what=""):              # this test's tolerance
+        close(a, b, tol=tol, what=what)
+
     system, _, guess = getattr(models, bname)(_ns(scheme, "pockit_amd"), **kw)
     ref, _, _ = getattr(models, bname)(_ns(scheme, "oracle"), **kw)
     x, lam, sigma = models.bench_inputs(system, guess)
-    close(system.objective(x), ref.objective(x), what="f")
-    close(system.gradient(x), ref.gradient(x), what="grad")
-    close(system.constraints(x), ref.constraints(x), what="g")
-    close(system.jacobian(x), ref.jacobian(x), what="J")
-    close(system.hessian(x, lam, sigma), ref.hessian(x, lam, sigma), what="H")
+    check(system.objective(x), ref.objective(x), what="f")
+    check(system.gradient(x), ref.gradient(x), what="grad")
+    check(system.constraints(x), ref.constraints(x), what="g")
+    check(system.jacobian(x), ref.jacobian(x), what="J")
+    check(system.hessian(x, lam, sigma), ref.hessian(x, lam, sigma), what="H")
     f, grad, g, J, H = system.evaluator.cycle(x, lam, sigma)
-    close(g, ref.constraints(x), what="cycle g")
-    close(J, ref.jacobian(x), what="cycle J")
-    close(H, ref.hessian(x, lam, sigma), what="cycle H")
+    check(g, ref.constraints(x), what="cycle g")
+    check(J, ref.jacobian(x), what="cycle J")
+    check(H, ref.hessian(x, lam, sigma), what="cycle H")
     ev = system.evaluator
-    close(ev.constraints_direct(x), ref.constraints(x), what="g direct")
-    close(ev.jacobian_direct(x), ref.jacobian(x), what="J direct")
-    close(ev.hessian_direct(x, lam, sigma), ref.hessian(x, lam, sigma), what="H direct")
+    check(ev.constraints_direct(x), ref.constraints(x), what="g direct")
+    check(ev.jacobian_direct(x), ref.jacobian(x), what="J direct")
+    check(ev.hessian_direct(x, lam, sigma), ref.hessian(x, lam, sigma), what="H direct")
 
 
 def test_prepared_x_cache_is_dropped_by_calls_that_reuse_the_context_buffers():
