@@ -1,0 +1,9 @@
+#!/bin/bash
+for d in _ab_old _ab_x1 _ab_x2; do (cd $d && python3 -c "
+from pockit_amd import hipbuild
+hipbuild.build_runtime(force=True)"); done
+for rep in 1 2; do
+for d in _ab_old _ab_x1 _ab_x2 .; do
+  (cd $d && python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-extra --no-end-to-end --workload two_stage_rocket --intervals 1000 > /tmp/ab_out.json 2>/tmp/ab_err.txt; python3 -c "
+import json;d=json.loads(open('/tmp/ab_out.json').read().strip().splitlines()[-1]);r=d['roofline'];print('tree=$d', 'rocket cycles/s', round(d['value']), 'us/step', round(d['ms_per_step']*1e3,3), 'isolated', round(r.get('dispatch_isolated_us', r.get('avg_launch_us')),3))" || tail -3 /tmp/ab_err.txt)
+done; done

@@ -1,0 +1,575 @@
+#!/usr/bin/env python3
+"""Benchmark of the NLP-callback hot path: cycles/sec of (f, grad f, g, J, H) on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+A *step* is one NLP-callback cycle -- objective, gradient, constraints, Jacobian, Hessian of the Lagrangian on the
+same x, in IPOPT's order -- with x and lambda already resident in HBM and all outputs left
+in HBM (``value``).  The same cycle with host NumPy arrays in and out, as a solver sees it (the five callbacks of
+``System``, PCIe included), is reported beside it as ``end_to_end`` with the time of every callback; the CPU baseline
+ratio is taken on THAT figure.
+
+Workload (BASELINE.json metric: "at 10k LGR nodes"): planar_quadrotor re-meshed on LGR 2000 intervals x 6 points =
+12 000 nodes (configs[2], the ~10k-node headline of BASELINE.md), x = example guess * (1 + 1e-3 U), lambda ~ N(0,1),
+sigma = 1, all seeded.  For N > 1 the mesh is 2000*N intervals of the same model, sharded by mesh interval over the N
+GPUs (weak scaling: 2000 intervals per GPU); ``value`` is then in 12k-node-equivalent cycles/s (= N * steps / time).
+
+Timing.  A cycle is ONE 5 us launch, so a region of ``--steps 20`` would measure the launch ramp and one
+synchronization, not the kernel.  After the warm-up the timed region therefore consists of R back-to-back batches of
+EXACTLY ``steps`` cycles each (R chosen so that the region lasts >= 50 ms), separated by HIP events recorded on the
+launch stream and bracketed as a whole by a barrier + synchronize; ``ms_per_step`` is the MEDIAN batch / steps, the
+spread over the batches and the wall clock of the whole region are reported too.
+
+One JSON line is printed by rank 0 (see the repository prompt for the contract), carrying ``roofline`` for the
+dominant kernel (per-dispatch HIP events on the launch stream) and ``cpu_baseline`` (the oracle = CPU restatement of
+the reference, timed on the host).
+"""
+import os
+
+for _v in ("OMP_NUM_THREADS", "OPENBLAS_NUM_THREADS", "MKL_NUM_THREADS", "NUMEXPR_NUM_THREADS"):
+    os.environ.setdefault(_v, "1")
+
+import argparse  # noqa: E402
+import ctypes as C  # noqa: E402
+import json  # noqa: E402
+import statistics  # noqa: E402
+import subprocess  # noqa: E402
+import sys  # noqa: E402
+import time  # noqa: E402
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+
+HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+KERNEL_IDS = {"pk_int": 0, "pk_fin": 1, "pk_g": 2, "pk_grad": 3, "pk_jac": 4, "pk_hess": 5, "pk_xall": 6, "pk_cycle": 12}
+MIN_REGION_S = 0.05        # the timed region lasts at least this long (R batches of `steps` cycles)
+MIN_WARMUP = 500           # untimed launches before the timed region (single GPU), whatever --warmup says
+ISOLATED_SAMPLES = 200     # per-dispatch kernel timings on an idle stream (what a profiler's kernel trace measures)
+POINTS = {"planar_quadrotor": 6, "brachistochrone": 8, "two_stage_rocket": 4, "humanoid_wbc": 8}
+
+
+def algorithmic_bytes(plan):
+    """Per-kernel algorithmic traffic of one cycle:
+    B = 8 (5n + m + 1 + n + m + nnz_J + nnz_H): x read by each callback, lambda once, outputs once."""
+    n, m = plan.n, plan.m
+    per = {
+        "f": 8 * (n + 1),
+        "grad": 8 * (n + n),
+        "g": 8 * (n + m),
+        "jac": 8 * (n + plan.nnz_J),
+        "hess": 8 * (n + m + plan.nnz_H),
+    }
+    per["cycle"] = sum(per.values())
+    per["xall"] = 8 * (n + 1 + n + m + plan.nnz_J)      # fused x-kernel: x read once, f partials + grad + g + J written
+    per["cycle_x_once"] = per["cycle"] - 8 * 4 * n       # the single-launch cycle reads x once from HBM
+    return per
+
+
+def build_workload(name, intervals, ns):
+    from pockit_amd import benchmarks as models
+
+    if name.endswith("_lgl"):                       # Lobatto variant of a workload (side line of the bench)
+        import pockit_amd.lobatto as lobatto
+
+        return build_workload(name[:-4], intervals, lobatto)
+    return getattr(models, name)(ns, intervals, POINTS[name])
+
+
+def cpu_baseline(name, intervals, budget_s=12.0, max_cycles=5000):
+    """The oracle (NumPy restatement of the reference algorithm, single thread) on the same workload: the same five
+    callbacks with host arrays in and out."""
+    from pockit_amd import benchmarks as models
+    import oracle.radau
+
+    system, _, guess = build_workload(name, intervals, oracle.radau)
+    x, lam, sigma = models.bench_inputs(system, guess)
+
+    def cycle():
+        system.objective(x)
+        system.gradient(x)
+        system.constraints(x)
+        system.jacobian(x)
+        system.hessian(x, lam, sigma)
+
+    for _ in range(2):
+        cycle()
+    t0 = time.perf_counter()
+    n = 0
+    while n < max_cycles and time.perf_counter() - t0 < budget_s:
+        cycle()
+        n += 1
+    dt = time.perf_counter() - t0
+    return {"value": n / dt, "unit": "cycles/s", "cores": 1, "kind": "port",
+            "sample": f"{n} full cycles of the same workload ({name} LGR {intervals} intervals) in {dt:.1f} s, "
+                      f"NumPy oracle, 1 thread of {os.cpu_count()} host CPUs"}
+
+
+def end_to_end(system, guess, warm=20, timed=100):
+    """the five callbacks through ``System`` with host NumPy arrays in and out (what cyipopt
+    calls, optimizer/ipopt.py), every cycle on a NEW x (so nothing is served from the previous iterate); median over
+    ``timed`` cycles after ``warm`` warm-up cycles, and the median time of every callback."""
+    from pockit_amd import benchmarks as models
+
+    x, lam, sigma = models.bench_inputs(system, guess)
+    xs = [x * (1.0 + 1e-9 * k) for k in range(8)]
+    ev = system.evaluator
+    names = ("objective", "gradient", "constraints", "jacobian", "hessian")
+    out = {}
+    for mode in ("fresh_arrays", "zero_copy_views"):
+        ev.zero_copy = mode == "zero_copy_views"
+        rows = []
+        for k in range(warm + timed):
+            xk = xs[k % len(xs)]
+            t = [time.perf_counter()]
+            system.objective(xk)
+            t.append(time.perf_counter())
+            system.gradient(xk)
+            t.append(time.perf_counter())
+            system.constraints(xk)
+            t.append(time.perf_counter())
+            system.jacobian(xk)
+            t.append(time.perf_counter())
+            system.hessian(xk, lam, sigma)
+            t.append(time.perf_counter())
+            if k >= warm:
+                rows.append([t[i + 1] - t[i] for i in range(5)] + [t[5] - t[0]])
+        med = [statistics.median(r[i] for r in rows) for i in range(6)]
+        out[mode] = {"cycles_per_s": 1.0 / med[5], "ms_per_cycle": med[5] * 1e3,
+                     "per_callback_ms": {nm: med[i] * 1e3 for i, nm in enumerate(names)},
+                     "min_ms_per_cycle": min(r[5] for r in rows) * 1e3, "max_ms_per_cycle": max(r[5] for r in rows) * 1e3}
+    ev.zero_copy = False
+    p = system.plan
+    out["bytes_over_pcie_per_cycle"] = 8 * (p.n + p.m + 1 + p.n + p.m + p.nnz_J + p.nnz_H)
+    out["cycles"] = {"warmup": warm, "timed": timed, "statistic": "median"}
+    out["what"] = ("objective, gradient, constraints, jacobian, hessian of System on a new x per cycle, NumPy arrays in "
+                   "and out; fresh_arrays: every callback returns an array the caller owns (the reference's semantics; "
+                   "pinned memory the DMA wrote directly), zero_copy_views: views of the context's pinned buffers "
+                   "(what the IPOPT adapter enables, cyipopt copies at once)")
+    return out
+
+
+class GpuWorkload:
+    """One workload set up on this rank: plan, evaluator, device-resident inputs / outputs, the step function."""
+
+    def __init__(self, name, intervals, rank, world, dist):
+        import torch
+
+        from pockit_amd import benchmarks as models, hipbuild
+        import pockit_amd.radau as radau
+        from pockit_amd.sharding import ShardedEvaluator
+
+        self.torch, self.name, self.intervals, self.rank, self.world, self.dist = torch, name, intervals, rank, world, dist
+        t0 = time.perf_counter()
+        c0 = hipbuild.COMPILE_SECONDS["total"]
+        self.system, _, self.guess = build_workload(name, intervals, radau)
+        self.plan = plan = self.system.plan
+        self.x, self.lam, self.sigma = models.bench_inputs(self.system, self.guess)
+        self.dev = dev = torch.device("cuda", torch.cuda.current_device())
+        self.sev = sev = ShardedEvaluator(plan, rank, world, device=dev.index)
+        self.setup_s = time.perf_counter() - t0
+        self.compile_s_in_setup = hipbuild.COMPILE_SECONDS["total"] - c0
+        self.ev = ev = sev.ev
+        self.lib, self.h = ev.ctx.lib, ev.ctx.handle
+        self.dx = torch.from_numpy(self.x).to(dev)
+        self.dlam = torch.from_numpy(self.lam).to(dev)
+        self.o = o = sev.out
+        # a stream of our own: torch's default stream has the null handle, which the C ABI reads as "the context's stream"
+        self.stream = torch.cuda.Stream(device=dev)
+        st = C.c_void_p(self.stream.cuda_stream)
+        ptr = lambda t: C.c_void_p(t.data_ptr())  # noqa: E731
+        self.cycle_args = (self.h, ptr(self.dx), ptr(self.dlam), C.c_double(float(self.sigma)), ptr(o["f"]), ptr(o["grad"]),
+                           ptr(o["g"]), ptr(o["J"]), ptr(o["H"]), st)       # built once: the loop is host-launch bound
+        self.exchange = "single GPU"
+        lib, cycle_args, check = self.lib, self.cycle_args, ev.ctx.check
+        if world == 1:
+            def step():
+                rc = lib.pk_eval_cycle_dev(*cycle_args)
+                if rc:
+                    check(rc)
+            check(lib.pk_set_shard(self.h, 0, 0, None))
+        else:
+            root = {"r": None if os.environ.get("POCKIT_AMD_BENCH_EXCHANGE") == "allgather" else 0}
+
+            def step():
+                sev.cycle(self.dx, self.dlam, self.sigma, dist, root=root["r"])   # root 0: reassembled where the solver runs
+
+            if root["r"] is not None:
+                try:                                       # one untimed cycle: a backend without gather falls back to all-gather
+                    step()
+                    torch.cuda.synchronize()
+                except (RuntimeError, NotImplementedError) as exc:
+                    print(f"[bench] gather-to-root exchange not available ({exc!r}); using the all-gather form", file=sys.stderr)
+                    root["r"] = None
+            self.exchange = "gather to rank 0" if root["r"] == 0 else "all-gather"
+        self.step = step
+        self.bytes = B = algorithmic_bytes(plan)
+        self.fused = not (plan.needs_I_grad or plan.needs_I_con or plan.jac.needs_I or plan.hess.needs_I)
+        if self.fused and world == 1 and os.environ.get("POCKIT_AMD_CYCLE_MODE", "1") == "0":   # A/B: the two-launch form
+            ev.set_cycle_mode(False)
+            self.dominant = "pk_xall" if B["xall"] >= B["hess"] else "pk_hess"
+        elif self.fused:
+            self.dominant = "pk_cycle"           # ONE launch does the whole cycle: its algorithmic bytes are SURVEY 8(d)'s B
+        else:
+            self.dominant = "pk_jac" if B["jac"] >= B["hess"] else "pk_hess"
+
+    def sync(self):
+        self.torch.cuda.synchronize()
+        if self.dist is not None and self.world > 1:
+            self.dist.barrier()
+            self.torch.cuda.synchronize()
+
+    def timed_region(self, steps, warmup):
+        """Warm-up, then R back-to-back batches of exactly ``steps`` cycles (events between the batches on the launch
+        stream), bracketed by barrier + synchronize.  Returns the batch durations (ms) and the wall clock."""
+        torch, step, stream = self.torch, self.step, self.stream
+        n_warm = max(warmup, MIN_WARMUP) if self.world == 1 else max(warmup, 3)
+        for _ in range(n_warm):
+            step()
+        self.sync()
+        # size of the region: estimate the step time on a short untimed stretch
+        t0 = time.perf_counter()
+        probe = max(steps, 50 if self.world == 1 else 5)
+        for _ in range(probe):
+            step()
+        self.sync()
+        est = (time.perf_counter() - t0) / probe
+        R = int(min(4000, max(5, -(-MIN_REGION_S // (est * steps)))))
+        if self.world > 1:                                   # every rank must run the same number of batches
+            t = torch.tensor([R], dtype=torch.int64, device=self.dev)
+            self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+            R = int(t.item())
+        events = [torch.cuda.Event(enable_timing=True) for _ in range(R + 1)]
+        self.sync()
+        t0 = time.perf_counter()
+        events[0].record(stream)
+        for b in range(R):
+            for _ in range(steps):
+                step()
+            events[b + 1].record(stream)
+        self.sync()
+        wall = time.perf_counter() - t0
+        batch_ms = [events[b].elapsed_time(events[b + 1]) for b in range(R)]
+        return batch_ms, wall, n_warm + probe
+
+    def dispatch_times(self, kernel):
+        """Per-dispatch duration of ``kernel`` from HIP events attached to the dispatch itself
+        (hipExtModuleLaunchKernel start / stop events on the launch stream), two ways:
+        * ``isolated``: the stream is idle before every sampled launch -- the kernel's own start-to-end, what a kernel
+          trace (rocprofv3) measures, because a profiler keeps consecutive dispatches apart;
+        * ``in_flight``: every 64th launch of a back-to-back run -- there the stop-minus-start of a dispatch also holds
+          its wait for the tail of the launch before it."""
+        ev, step = self.ev, self.step
+        kid = KERNEL_IDS[kernel]
+        self.sync()
+        ev.profile(1 << kid, period=1)
+        n0, ms0 = ev.profile_read()[kernel]
+        for _ in range(ISOLATED_SAMPLES):
+            step()
+            self.stream.synchronize()
+        n1, ms1 = ev.profile_read()[kernel]
+        ev.profile(1 << kid, period=64)
+        for _ in range(64 * 40):
+            step()
+        self.sync()
+        n2, ms2 = ev.profile_read()[kernel]
+        ev.profile(0)
+        iso = (ms1 - ms0) / max(n1 - n0, 1) * 1e3
+        fl = (ms2 - ms1) / max(n2 - n1, 1) * 1e3
+        return iso, fl, n1 - n0, n2 - n1
+
+    def side_kernels(self):
+        """Kernel times of the optional modes (compact Hessian, mesh error estimation, CSR hand-off), 50 launches each."""
+        torch, ev, lib, h, plan, dev = self.torch, self.ev, self.lib, self.h, self.plan, self.dev
+        st = C.c_void_p(self.stream.cuda_stream)
+        ptr = lambda t: C.c_void_p(t.data_ptr())  # noqa: E731
+        out = {}
+
+        def timed(kid, name, fn):
+            ev.profile(1 << kid)
+            n0, ms0 = ev.profile_read()[name]
+            for _ in range(50):
+                fn()
+            torch.cuda.synchronize()
+            n1, ms1 = ev.profile_read()[name]
+            ev.profile(0)
+            return (ms1 - ms0) / max(n1 - n0, 1) * 1e3
+
+        if ev.src.compact:
+            hc = torch.zeros(max(plan.nnz_Hc, 1), dtype=torch.float64, device=dev)
+            hargs = (h, ptr(self.dx), ptr(self.dlam), C.c_double(float(self.sigma)), ptr(hc), st)
+            us = timed(9, "pk_hessc", lambda: lib.pk_eval_hessc_dev(*hargs))
+            out["compact_hessian_mode"] = {"nnz_H_compact": int(plan.nnz_Hc), "nnz_H_reference": int(plan.nnz_H),
+                                           "pk_hessc_us": us, "finite": bool(torch.isfinite(hc).all())}
+        ev.mesh_error(self.x)                                           # uploads the tables on first use
+        eT = torch.zeros(ev._err_len, dtype=torch.float64, device=dev)
+        eI = torch.zeros_like(eT)
+        torch.cuda.synchronize()
+        us = timed(10, "pk_err", lambda: lib.pk_eval_mesh_error_dev(h, ptr(self.dx), ptr(eT), ptr(eI), st))
+        out["mesh_error_estimation"] = {"pk_err_us": us, "rows": int(ev._err_len),
+                                        "finite": bool(torch.isfinite(eT).all() and torch.isfinite(eI).all())}
+        mj, mh = ev.csr_map("jac"), ev.csr_map("hess")
+        cj = torch.zeros(mj.nnz, dtype=torch.float64, device=dev)
+        ch = torch.zeros(mh.nnz, dtype=torch.float64, device=dev)
+        torch.cuda.synchronize()
+        csr = {"nnz_J_csr": int(mj.nnz), "nnz_H_csr": int(mh.nnz)}
+        for which, src, dst in ((0, self.o["J"], cj), (1, self.o["H"], ch)):
+            csr["pk_csr_J_us" if which == 0 else "pk_csr_H_us"] = timed(
+                11, "pk_csr", lambda: lib.pk_gather_csr_dev(h, which, ptr(src), ptr(dst), st))
+        csr["finite"] = bool(torch.isfinite(cj).all() and torch.isfinite(ch).all())
+        out["csr_handoff"] = csr
+        return out
+
+    def all_kernel_us(self, steps=50):
+        ev = self.ev
+        ev.profile(0x1FFF)
+        for _ in range(steps):
+            self.step()
+        self.torch.cuda.synchronize()
+        allk = {k: (v[1] / v[0] * 1e3 if v[0] else 0.0) for k, v in ev.profile_read().items()}
+        ev.profile(0)
+        return allk
+
+    def finite(self):
+        return all(bool(self.torch.isfinite(self.o[k]).all()) for k in ("f", "grad", "g", "J", "H"))
+
+    def close(self):
+        self.ev.close()
+
+
+def measure(name, intervals, steps, warmup, rank, world, dist, with_side=True, with_e2e=True):
+    """Everything the JSON line says about one workload on this rank."""
+    w = GpuWorkload(name, intervals, rank, world, dist)
+    batch_ms, wall, untimed = w.timed_region(steps, warmup)
+    R = len(batch_ms)
+    med = statistics.median(batch_ms)
+    q = sorted(batch_ms)
+    res = dict(name=name, intervals=intervals, nodes=int(sum(pp.layout.L_m for pp in w.plan.phase_plans)),
+               n=w.plan.n, m=w.plan.m, nnz_J=w.plan.nnz_J, nnz_H=w.plan.nnz_H, steps=steps, batches=R,
+               median_batch_ms=med, ms_per_step=med / steps,
+               batch_ms_p10=q[int(0.1 * (R - 1))], batch_ms_p90=q[int(0.9 * (R - 1))], batch_ms_min=q[0], batch_ms_max=q[-1],
+               region_wall_s=wall, wall_ms_per_step=wall / (R * steps) * 1e3, untimed_launches=untimed,
+               setup_s=w.setup_s, compile_s_in_setup=w.compile_s_in_setup, bytes=w.bytes, dominant=w.dominant,
+               exchange=w.exchange, tiles=int(len(w.ev.tables.tiles)), ipw=int(w.ev.tables.intervals_per_wave))
+    # N > 1: the same loop without the exchange (every rank keeps its slices), to separate the kernels from the collectives
+    res["no_exchange_ms_per_step"] = None
+    if world > 1 and w.fused:
+        w.sync()
+        t1 = time.perf_counter()
+        n = max(steps, 200)
+        for _ in range(n):
+            w.lib.pk_eval_cycle_dev(*w.cycle_args)
+        w.stream.synchronize()
+        res["no_exchange_ms_per_step"] = (time.perf_counter() - t1) / n * 1e3
+        w.sync()
+    iso, fl, n_iso, n_fl = w.dispatch_times(w.dominant)
+    res.update(dispatch_isolated_us=iso, dispatch_in_flight_us=fl, dispatch_samples=[n_iso, n_fl])
+    res["kernel_us"] = w.all_kernel_us()
+    res["finite"] = w.finite()
+    res["side"] = w.side_kernels() if (with_side and world == 1) else {}
+    res["end_to_end"] = None
+    w.close()
+    if with_e2e and world == 1:
+        import pockit_amd.radau as radau
+
+        system, _, guess = build_workload(name, intervals, radau)
+        res["end_to_end"] = end_to_end(system, guess)
+        system._invalidate()
+    return res
+
+
+def cold_compile_seconds(name, intervals):
+    """hipcc time of the headline model's code object with an empty cache (what a first run of a new model pays once;
+    every later run finds the object in pockit_amd/_cache by the hash of its generated source)."""
+    import tempfile
+
+    from pockit_amd import hipbuild
+    from pockit_amd.codegen import ModelSource
+    import pockit_amd.radau as radau
+
+    system, _, _ = build_workload(name, min(intervals, 50), radau)      # (the generated source is mesh-independent)
+    src = ModelSource(system.plan)
+    keep = hipbuild.CACHE_DIR
+    try:
+        with tempfile.TemporaryDirectory() as tmp:
+            hipbuild.CACHE_DIR = tmp
+            t0 = time.perf_counter()
+            hipbuild.compile_model(src.source, fastmath=system._fastmath, keep_source=False)
+            return time.perf_counter() - t0
+    finally:
+        hipbuild.CACHE_DIR = keep
+
+
+def spawn_ranks(args):
+    """``python bench.py --gpus N`` without a launcher: start N ranks under torch.distributed.run (nothing in this
+    process has touched the GPU yet) and forward their output and exit code."""
+    import socket
+
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)        # cycles per batch; the region is R batches, >= 50 ms in total
+    ap.add_argument("--warmup", type=int, default=2000)
+    ap.add_argument("--workload", default="planar_quadrotor")
+    ap.add_argument("--intervals", type=int, default=2000)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extra", action="store_true", help="skip the supplementary workloads")
+    ap.add_argument("--no-end-to-end", action="store_true")
+    args = ap.parse_args()
+
+    env_world = os.environ.get("WORLD_SIZE")
+    if env_world is None and args.gpus > 1:
+        raise SystemExit(spawn_ranks(args))
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(env_world or "1")
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: launch one rank per GPU "
+                         f"(python -m torch.distributed.run --nproc-per-node {args.gpus} bench.py --gpus {args.gpus} ...)")
+
+    import torch
+
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (no CPU path in pockit_amd)")
+    torch.cuda.set_device(local_rank % torch.cuda.device_count())
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        backend = os.environ.get("POCKIT_AMD_BENCH_BACKEND", "nccl")
+        dist.init_process_group(backend, rank=rank, world_size=world)
+        if backend != "nccl":       # rehearsal of the N > 1 path on a box with fewer GPUs than ranks (not a measurement)
+            from pockit_amd.sharding import HostStagedCollectives
+
+            dist = HostStagedCollectives(dist)
+    n_gpus = world
+
+    intervals = args.intervals * n_gpus          # weak scaling: per-GPU share stays args.intervals
+    res = measure(args.workload, intervals, args.steps, args.warmup, rank, world, dist,
+                  with_e2e=not args.no_end_to_end)
+    t = torch.tensor([res["ms_per_step"], res["wall_ms_per_step"]], dtype=torch.float64, device="cuda")
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    ms, wall_ms = float(t[0].item()), float(t[1].item())
+
+    if rank == 0:
+        value = n_gpus * 1e3 / ms
+        dom = res["dominant"]
+        dom_bytes = res["bytes"][dom[3:]] / n_gpus
+        x_once = res["bytes"]["cycle_x_once"] / n_gpus if dom == "pk_cycle" else None
+        dom_us = res["dispatch_isolated_us"]
+        achieved = dom_bytes / (dom_us * 1e-6) / 1e9 if dom_us else None
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+        if os.path.exists(tpath):
+            try:
+                traffic = json.load(open(tpath)).get(f"{args.workload}_{intervals}", {}).get(dom)
+            except Exception:
+                traffic = None
+        b2b_us = ms * 1e3 if n_gpus == 1 else None
+        line = {
+            "metric": "NLP-callback cycles/sec (f + grad f + g + J + H)",
+            "value": value,
+            "unit": "cycles/s" if n_gpus == 1 else "12k-node-equivalent cycles/s",
+            "n_gpus": n_gpus, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": ms,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f64", "data": "synthetic",
+            "config": {"workload": f"{args.workload} LGR {intervals} intervals x {POINTS.get(args.workload.replace('_lgl', ''), 0)}"
+                                   f" points ({res['nodes']} nodes; n={res['n']}, m={res['m']}, nnz_J={res['nnz_J']}, "
+                                   f"nnz_H={res['nnz_H']})",
+                       "sharding": "single GPU" if n_gpus == 1 else f"mesh intervals over {n_gpus} GPUs, one pk_cycle launch per "
+                                                                    f"rank, RCCL {res['exchange']} of the owned runs of grad/g/J/H "
+                                                                    f"(+ the partial sums)",
+                       "tiles": res["tiles"], "intervals_per_wave": res["ipw"],
+                       "inputs": "example guess*(1+1e-3 U(-1,1)) seed 0; lambda N(0,1) seed 1; sigma 1"},
+            "timing": {"region": f"{res['batches']} back-to-back batches of exactly {args.steps} cycles (>= {MIN_REGION_S * 1e3:.0f} ms "
+                                 f"in total), HIP events between the batches on the launch stream, barrier + synchronize around "
+                                 f"the region; ms_per_step = median batch / steps (max over ranks)",
+                       "batches": res["batches"], "median_batch_ms": res["median_batch_ms"],
+                       "batch_ms_min_p10_p90_max": [res["batch_ms_min"], res["batch_ms_p10"], res["batch_ms_p90"], res["batch_ms_max"]],
+                       "region_wall_s": res["region_wall_s"], "wall_ms_per_step_whole_region": wall_ms,
+                       "untimed_launches_before_the_region": res["untimed_launches"]},
+            "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBPS,
+                         "unit": "GB/s", "frac": (achieved / HBM_PEAK_GBPS if achieved else None), "traffic": traffic,
+                         "algorithmic_bytes_per_launch": dom_bytes,
+                         "avg_launch_us": dom_us,
+                         "frac_x_once": (x_once / (dom_us * 1e-6) / 1e9 / HBM_PEAK_GBPS if (x_once and dom_us) else None),
+                         "algorithmic_bytes_per_launch_x_counted_once": x_once,
+                         "back_to_back_us_per_launch": b2b_us,
+                         "frac_back_to_back": (dom_bytes / (b2b_us * 1e-6) / 1e9 / HBM_PEAK_GBPS if b2b_us and dom == "pk_cycle" else None),
+                         "dispatch_in_flight_us": res["dispatch_in_flight_us"],
+                         "dispatch_samples_isolated_in_flight": res["dispatch_samples"],
+                         "timing": ("avg_launch_us: HIP start / stop events attached to the dispatch (hipExtModuleLaunchKernel) on "
+                                    "the launch stream, stream idle before each of the sampled launches -- the kernel's own "
+                                    "duration, as a kernel trace (rocprofv3 --kernel-trace) measures it; "
+                                    "back_to_back_us_per_launch: median batch / steps of the timed region (launch + gap to the "
+                                    "next launch when launches are queued back to back, where consecutive launches overlap "
+                                    "their start-up and drain); dispatch_in_flight_us: the same per-dispatch events on every "
+                                    "64th launch of a back-to-back run (includes the wait for the previous launch's tail)")},
+            "kernels_only_without_exchange": (None if res["no_exchange_ms_per_step"] is None else {
+                "value": n_gpus * 1e3 / res["no_exchange_ms_per_step"], "unit": "12k-node-equivalent cycles/s",
+                "note": "rank 0's clock around the same per-rank pk_cycle launches with no collective "
+                        "(every rank keeps its own slices of grad/g/J/H)"}),
+            "kernel_us": res["kernel_us"],
+            "cycle_algorithmic_bytes": res["bytes"]["cycle"],
+            "setup_s": res["setup_s"], "compile_s_in_setup": res["compile_s_in_setup"],
+            "outputs_finite": res["finite"],
+        }
+        line.update(res["side"])
+        if res["end_to_end"] is not None:
+            line["end_to_end"] = res["end_to_end"]
+        if n_gpus == 1 and not args.no_extra:
+            try:
+                line["compile_s_cold"] = cold_compile_seconds(args.workload, intervals)
+            except Exception as exc:
+                line["compile_s_cold"] = repr(exc)
+        if not args.no_cpu_baseline and n_gpus == 1:
+            cb = cpu_baseline(args.workload, intervals)
+            line["cpu_baseline"] = cb
+            if res["end_to_end"] is not None:
+                e2e = res["end_to_end"]["fresh_arrays"]["cycles_per_s"]
+                line["speedup_vs_cpu_baseline"] = e2e / cb["value"]
+                line["speedup_basis"] = ("end_to_end.fresh_arrays (host arrays in and out, like the CPU baseline's cycle) / "
+                                         "cpu_baseline")
+            line["device_resident_ratio_vs_cpu_baseline"] = value / cb["value"]
+        if not args.no_extra and n_gpus == 1:
+            extra = {}
+            for nm, iv in (("brachistochrone", 1250), ("brachistochrone", 200), ("two_stage_rocket", 1000),
+                           ("humanoid_wbc", 5000), ("planar_quadrotor_lgl", 2000)):
+                try:
+                    r = measure(nm, iv, args.steps, min(args.warmup, 500), 0, 1, None,
+                                with_side=(nm == "humanoid_wbc"), with_e2e=(nm == "humanoid_wbc" and not args.no_end_to_end))
+                    b = r["bytes"][r["dominant"][3:]]
+                    e = {"nodes": r["nodes"], "cycles_per_s": 1e3 / r["ms_per_step"], "ms_per_step": r["ms_per_step"],
+                         "batches": r["batches"], "dominant": r["dominant"], "dispatch_isolated_us": r["dispatch_isolated_us"],
+                         "dominant_GBps": b / (r["dispatch_isolated_us"] * 1e-6) / 1e9 if r["dispatch_isolated_us"] else None,
+                         "dominant_GBps_back_to_back": b / (r["ms_per_step"] * 1e-3) / 1e9,
+                         "cycle_bytes": r["bytes"]["cycle"], "setup_s": r["setup_s"]}
+                    e.update(r["side"])
+                    if r["end_to_end"] is not None:
+                        e["end_to_end"] = r["end_to_end"]
+                    extra[f"{nm}_{iv}"] = e
+                except Exception as exc:  # keep the headline line even if a side workload fails
+                    extra[f"{nm}_{iv}"] = {"error": repr(exc)}
+            line["other_workloads"] = extra
+        print(json.dumps(line))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

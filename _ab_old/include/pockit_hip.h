@@ -1,0 +1,231 @@
+/* pockit_hip.h -- C ABI of the MI355X NLP-callback evaluator (libpockit_hip.so).
+ *
+ * Drop-in boundary: these entry points are what a host binding for pockit's evaluator path
+ * binds.  Each eval function replaces one method of the reference's cyipopt ``problem_obj``
+ * (class SystemBase in /root/reference/pockit/base/systembase.py):
+ *
+ *   pk_eval_f     <-  SystemBase.objective(x)                     systembase.py:602-605
+ *   pk_eval_grad  <-  SystemBase.gradient(x)                      systembase.py:646-657
+ *   pk_eval_g     <-  SystemBase.constraints(x)                   systembase.py:613-623
+ *   pk_eval_jac   <-  SystemBase.jacobian(x)                      systembase.py:676-693
+ *   pk_eval_hess  <-  SystemBase.hessian(x, lagrange, obj_factor) systembase.py:820-835
+ *   pk_get_structure <- jacobianstructure()/hessianstructure()    systembase.py:671-674,811-818
+ * and the caller they serve is cyipopt.Problem(...) built in
+ * /root/reference/pockit/optimizer/ipopt.py:41-53.
+ *
+ * Conventions: every function returns 0 on success and a non-zero code on error, with a message
+ * retrievable through pk_last_error(); the caller owns all host buffers; the library owns device
+ * memory, its stream and the loaded code object; ``x`` is never written (the reference mutates
+ * boundary slots in place, phasebase.py:840-847 -- we evaluate as if, without touching x); one
+ * context per GPU, calls on one context are serialized by the caller (as IPOPT does).
+ * No function falls back to the CPU: without a GPU / code object every eval returns an error.
+ *
+ * The *_dev variants take device pointers (e.g. torch tensors' data_ptr()) and a hipStream_t
+ * (NULL = the context's stream); they enqueue only and do not synchronize.
+ */
+#ifndef POCKIT_HIP_H
+#define POCKIT_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct pk_ctx pk_ctx;
+
+/* Compile-time facts of a generated model (pockit_amd/codegen.py) the runtime needs to launch it. */
+typedef struct pk_model_desc {
+  int32_t n_phase;
+  int32_t n_I;          /* number of integral symbols (length of the device I buffer)            */
+  int32_t nred;         /* PK_NRED the code object was compiled with                             */
+  int32_t lds_g;        /* LDS doubles per wave for eval_g / eval_jac / eval_hess                */
+  int32_t lds_j;
+  int32_t lds_h;
+  int32_t ne_j;         /* number of boundary/system scalar expressions of eval_jac / eval_hess  */
+  int32_t ne_h;
+  int32_t prepass_f;    /* 1 if the callback needs the integral pre-pass (pk_int)                 */
+  int32_t prepass_grad;
+  int32_t prepass_g;
+  int32_t prepass_jac;
+  int32_t prepass_hess;
+  int32_t lds_x;        /* LDS doubles per wave of the fused x-kernel (pk_xall)                   */
+  int32_t ne_a;         /* scalar expressions of the auxiliary pass (outer-product Hessian path)  */
+  int32_t ne_hc;        /* scalar expressions of the compact Hessian                              */
+  int32_t lds_e;        /* LDS doubles per wave of the mesh error estimation kernel (pk_err)      */
+} pk_model_desc;
+
+/* One (model, mesh) instance: sizes plus the table blobs built by pockit_amd/evaluator.py.
+ * ``phases``/``tiles``/``kinds``/``items_*`` are arrays of the PkPhase/PkTile/PkKind/PkItem
+ * structs of pockit_amd/csrc/pk_abi.h passed as raw bytes. */
+typedef struct pk_problem_desc {
+  int32_t n, m, n_sys, n_s, l_s;
+  int32_t n_phase, n_tiles, n_kinds;
+  int64_t nnz_J, nnz_H;
+  const void* phases;
+  const void* tiles;
+  const void* kinds;
+  const void* items_jac;
+  int32_t n_items_jac;
+  const void* items_hess;
+  int32_t n_items_hess;
+  const int32_t* ib;
+  int64_t n_ib;
+  const double* db;
+  int64_t n_db;
+  const int64_t* lb;
+  int64_t n_lb;
+  int32_t gz_off, n_gz;
+  /* outer-product path (objective / system constraints nonlinear in the integrals); all may be empty */
+  const void* items_aux;
+  int32_t n_items_aux;
+  const void* outer;      /* PkOuter[n_outer] */
+  int32_t n_outer;
+  int32_t n_aux;          /* length of the auxiliary buffer */
+  /* compact (coalesced) Hessian layout, optional (nnz_Hc = 0: not available) */
+  const void* items_hessc;
+  int32_t n_items_hessc;
+  int64_t nnz_Hc;
+  /* optional COO structure in the reference's order (copied; may be NULL) */
+  const int32_t* jac_row;
+  const int32_t* jac_col;
+  const int32_t* hess_row;
+  const int32_t* hess_col;
+} pk_problem_desc;
+
+int pk_create(pk_ctx** out, int device_id);
+void pk_destroy(pk_ctx* ctx);
+const char* pk_last_error(pk_ctx* ctx); /* ctx may be NULL: last error of a failed pk_create */
+int pk_device_count(void);
+
+int pk_load_model(pk_ctx* ctx, const void* code_object, size_t len, const pk_model_desc* md);
+int pk_set_problem(pk_ctx* ctx, const pk_problem_desc* pd);
+int pk_get_structure(pk_ctx* ctx, int32_t* jac_row, int32_t* jac_col, int32_t* hess_row, int32_t* hess_col);
+
+/* host-buffer API (what the cyipopt shim calls): H2D, launch, D2H, synchronize */
+int pk_eval_f(pk_ctx* ctx, const double* x, double* f);
+int pk_eval_grad(pk_ctx* ctx, const double* x, double* grad /* n */);
+int pk_eval_g(pk_ctx* ctx, const double* x, double* g /* m */);
+int pk_eval_jac(pk_ctx* ctx, const double* x, double* vals /* nnz_J */);
+int pk_eval_hess(pk_ctx* ctx, const double* x, const double* lambda, double sigma, double* vals /* nnz_H */);
+
+/* all five outputs of one cycle on the same x (fused x-kernel + Hessian), host buffers */
+int pk_eval_cycle(pk_ctx* ctx, const double* x, const double* lambda, double sigma, double* f, double* grad,
+                  double* g, double* jac, double* hess);
+
+/* "new x" protocol for host shims.  cyipopt calls objective / gradient / constraints / jacobian separately but on the
+ * same iterate, then hessian with fresh multipliers (the five methods ipopt.py:41-53 hands over as ``problem_obj``).
+ *   pk_same_x      1 if ``x`` equals the x of the last pk_prepare_x bit for bit (its results are still held)
+ *   pk_prepare_x   stages x in pinned memory, uploads it, runs the fused x-kernel (every node evaluated once for f,
+ *                  grad f, g, J) and queues the copies of the results into pinned host memory right behind it, in the
+ *                  order a solver asks for them -- nothing waits; x and lambda staging is double-buffered
+ *   pk_fetch       waits for ONE result (what: 0 f, 1 grad[n], 2 g[m], 3 jac[nnz_J]); out == NULL leaves it where it
+ *                  landed (pk_result_location), otherwise it is copied on to ``out``
+ *   pk_eval_hess_prepared   Hessian of the Lagrangian on the prepared x (x is not uploaded again)
+ *   pk_set_result_targets   where the results of the NEXT prepare / Hessian land: pinned memory of the caller
+ *                  (pk_host_alloc; a solver-side array that outlives the call), NULL = the context's own buffers
+ *   pk_set_host_mode        prefetch 1 (default): all four x-results are copied out behind the kernel; 0: f and g
+ *                  always, grad f and J on first request (a line search's rejected trial points never ask);
+ *                  host_direct 1: the kernels store into the pinned host targets themselves (no DMA; A/B switch)
+ *   pk_invalidate_x         forget the prepared x (the context's buffers were used by another entry point) */
+int pk_same_x(pk_ctx* ctx, const double* x);
+int pk_prepare_x(pk_ctx* ctx, const double* x);
+int pk_fetch(pk_ctx* ctx, int what, double* out);
+int pk_eval_hess_prepared(pk_ctx* ctx, const double* lambda, double sigma, double* vals);
+int pk_set_result_targets(pk_ctx* ctx, double* f, double* grad, double* g, double* jac, double* hess);
+int pk_result_location(pk_ctx* ctx, int what /* 0..4 */, double** ptr);
+int pk_set_host_mode(pk_ctx* ctx, int prefetch, int host_direct);
+int pk_invalidate_x(pk_ctx* ctx);
+/* Pinned (page-locked) result buffers owned by the context: what = 0 f, 1 grad, 2 g, 3 jac, 4 hess.  The default
+ * landing place of the results; reused by the next iterate. */
+int pk_host_buffer(pk_ctx* ctx, int what, double** ptr, int64_t* count);
+/* Pinned, device-visible host memory that is NOT tied to a context (result arrays handed to a solver may outlive the
+ * evaluator): DMA targets at full PCIe rate.  pk_last_error(NULL) holds the message of a failure. */
+int pk_host_alloc(size_t bytes, void** out);
+int pk_host_free(void* p);
+
+/* Compact Hessian of the Lagrangian: the reference repeats every dynamics entry for
+ * each nonzero of the integration matrix (phasebase.py:923-928,1280-1285; 10-20x duplication); here lambda is
+ * contracted first (mu = I^T lambda) and entries of a node with equal (row, col) are summed, so one value per
+ * distinct position is produced.  Layout: pockit_amd.transcription.SystemPlan.hessc_row/col. */
+int pk_eval_hessc(pk_ctx* ctx, const double* x, const double* lambda, double sigma, double* vals /* nnz_Hc */);
+int pk_eval_hessc_dev(pk_ctx* ctx, const double* d_x, const double* d_lambda, double sigma, double* d_vals,
+                      void* stream);
+
+/* Mesh error estimation (reference: phasebase.py:1339-1372
+ * _error_estimation_data_continuous, called by check_continuous / refine_continuous, phasebase.py:1374-1437,
+ * 1522-1617): every mesh interval is re-collocated with one more point; the kernel (pk_err, one wavefront per
+ * interval) interpolates states/controls to the augmented nodes, evaluates the dynamics there and returns both
+ * sides of the integral-form collocation equation,  T = T_aug x  and  I = dt (I_aug d/2) f, per phase as
+ * [n_x][rows] (rows = sum_j (K_j + 1) for LGR, sum_j K_j for LGL).  The per-interval comparison and the
+ * hp-refinement decision are host logic (pockit_amd/refine.py).
+ * ``intervals``: array of PkErrIv (csrc/pk_abi.h), padded per phase to a multiple of 4 records with K = 0;
+ * ``tables``: the interpolation / translation / integration blocks they index; ``n_out``: doubles per output. */
+int pk_set_mesh_error_tables(pk_ctx* ctx, const void* intervals, int32_t n_intervals, const double* tables,
+                             int64_t n_tables, int64_t n_out);
+int pk_eval_mesh_error(pk_ctx* ctx, const double* x, double* T /* n_out */, double* I /* n_out */);
+int pk_eval_mesh_error_dev(pk_ctx* ctx, const double* d_x, double* d_T, double* d_I, void* stream);
+
+/* Device-resident CSR hand-off (the reference hands host triplets to IPOPT,
+ * optimizer/ipopt.py:41-53).  The triplet values of J (which = 0) or H (which = 1, lower triangle) are gathered
+ * into CSR order on the device, repeated (row, col) entries summed in triplet order: the matrices can feed a
+ * GPU KKT solve without crossing PCIe.  ``perm[q]``: triplet index of the q-th entry in (row, col) order;
+ * ``seg[p] .. seg[p+1]``: the run of q belonging to CSR entry p (NULL when no entry repeats).  The CSR
+ * structure itself (indptr, indices) is host data: pockit_amd/csr.py. */
+int pk_set_csr_map(pk_ctx* ctx, int which, const int32_t* seg /* n_unique + 1 or NULL */, const int32_t* perm,
+                   int64_t n_unique, int64_t n_triplets);
+int pk_gather_csr_dev(pk_ctx* ctx, int which, const double* d_triplets, double* d_csr, void* stream);
+int pk_eval_jac_csr_dev(pk_ctx* ctx, const double* d_x, double* d_csr, void* stream);
+int pk_eval_hess_csr_dev(pk_ctx* ctx, const double* d_x, const double* d_lambda, double sigma, double* d_csr,
+                         void* stream);
+int pk_eval_jac_csr(pk_ctx* ctx, const double* x, double* vals /* n_unique */);
+int pk_eval_hess_csr(pk_ctx* ctx, const double* x, const double* lambda, double sigma, double* vals);
+
+/* device-pointer API: enqueue on ``stream`` (hipStream_t, NULL = context stream), no sync */
+int pk_eval_f_dev(pk_ctx* ctx, const double* d_x, double* d_f, void* stream);
+int pk_eval_grad_dev(pk_ctx* ctx, const double* d_x, double* d_grad, void* stream);
+int pk_eval_g_dev(pk_ctx* ctx, const double* d_x, double* d_g, void* stream);
+int pk_eval_jac_dev(pk_ctx* ctx, const double* d_x, double* d_vals, void* stream);
+int pk_eval_hess_dev(pk_ctx* ctx, const double* d_x, const double* d_lambda, double sigma, double* d_vals,
+                     void* stream);
+/* one NLP-callback cycle f, grad f, g, J, H on the same x (IPOPT's per-iteration pattern), as ONE launch
+ * (pk_cycle: the workgroups of the fused x-kernel -- each node evaluated once for f, grad f, g, J -- and of the
+ * Hessian kernel side by side, plus a finalize workgroup fed by the same launch).  One cycle may be in flight
+ * per context at a time (the launch owns the context's hand-off slots). */
+int pk_eval_cycle_dev(pk_ctx* ctx, const double* d_x, const double* d_lambda, double sigma, double* d_f,
+                      double* d_grad, double* d_g, double* d_jac, double* d_hess, void* stream);
+/* Replay the fused cycle from a cached hipGraph while its pointers, sigma and stream do not change (a solver's
+ * steady state); any change re-captures.  Off by default. */
+int pk_set_cycle_graph(pk_ctx* ctx, int enable);
+/* single_launch = 1 (default): pk_cycle; 0: the two-launch form, pk_xall then pk_hess, which also reduces */
+int pk_set_cycle_mode(pk_ctx* ctx, int single_launch);
+int pk_sync(pk_ctx* ctx, void* stream);
+
+/* Mesh-interval sharding across GPUs (one context per GPU, each holding its shard of the tiles):
+ * ``secondary`` shards skip the boundary-node / system-level work (done once, on the primary);
+ * with ``external_prepass`` the callbacks do not run the integral pre-pass themselves: the caller
+ * runs pk_eval_integrals_dev, sums ``d_integrals`` (n_I doubles, caller-owned) across shards
+ * (RCCL all-reduce) and only then calls the callbacks / pk_eval_f_from_integrals_dev. */
+int pk_set_shard(pk_ctx* ctx, int secondary, int external_prepass, double* d_integrals);
+int pk_eval_integrals_dev(pk_ctx* ctx, const double* d_x, void* stream);
+int pk_eval_f_from_integrals_dev(pk_ctx* ctx, const double* d_x, double* d_f, void* stream);
+
+/* HIP-event timing of the individual kernels on the launch stream.
+ * kernel ids: 0 pk_int, 1 pk_fin, 2 pk_g, 3 pk_grad, 4 pk_jac, 5 pk_hess, 6 pk_xall, 7 pk_aux, 8 pk_outer,
+ * 9 pk_hessc, 10 pk_err, 11 pk_csr, 12 pk_cycle.  pk_profile_sampling(n): only every n-th launch of a selected kernel is timed (a timed
+ * launch costs ~2-3 us more than a plain one, so timing every launch slows the loop being measured). */
+int pk_profile(pk_ctx* ctx, int kernel_mask /* bit k: time kernel k; 0 = off */);
+int pk_profile_sampling(pk_ctx* ctx, int period);
+/* Developer tracing: with a model generated under POCKIT_AMD_TRACE=1 the waves of pk_cycle / pk_xall store the
+ * constant-rate device clock (s_memrealtime) at up to 16 checkpoints of their record.  The first call arms the
+ * buffer; later calls copy the [3 n_tiles + 3][16] marks out (records: [tile][values, Jacobian, Hessian wave], then
+ * pk_cycle's boundary-J, boundary-H and finalize workgroups) and clear the buffer. */
+int pk_trace_read(pk_ctx* ctx, uint64_t* out, int64_t count);
+int pk_profile_read(pk_ctx* ctx, int kernel_id, int64_t* launches, double* total_ms);
+const char* pk_kernel_name(int kernel_id);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* POCKIT_HIP_H */

@@ -1,0 +1,1681 @@
+// pk_kernels.hip.h -- hand-written CDNA4 (gfx950) kernels of the NLP-callback evaluator.
+//
+// The generated model code (pockit_amd/codegen.py) supplies, per phase, a struct P with
+// straight-line fp64 functions (mid_g, mid_int, mid_jac, mid_xall, front_jac, ...) and a struct Gen
+// that dispatches on the phase id.  Everything about *how* the work is mapped to the GPU lives here.
+//
+// Work decomposition: a *tile* is a run of consecutive mesh intervals of
+// one pattern with at most 64 collocation nodes; one 64-lane wavefront owns one tile (and one role, below):
+//   phase A  lane = node: coalesced 8-byte loads of the trajectory vector (states/controls are
+//            stored node-contiguous per variable), model evaluation in registers, the per-node
+//            values that are needed by all K rows of the interval are staged in LDS ([segment][lane]);
+//            in the same memory round trip the wave copies its tile's small pattern tables (K <= 8: at most
+//            64 entries each), the base offsets of its output segments (kept in a VGPR pair, lane e = segment e)
+//            and, for the Hessian, its rows of the multipliers;
+//   phase B  lane = output position: every I-expanded segment of the tile is a contiguous run of
+//            nj * K^2 doubles in the output array; the wave streams them out in coalesced stores of 16 bytes
+//            per lane (two consecutive positions), reading staged values and tables from LDS only.  Phase B contains NO vector load (loads and
+//            stores share vmcnt and return out of order: one load would make every wait a wait for all stores)
+//            and needs no workgroup barrier (a wave stages for itself only).
+// The tile record is wave-uniform: it is read through the scalar cache into SGPRs (readfirstlane +
+// constant address space).
+// Four waves of ONE role on four consecutive tiles share a 256-thread workgroup.  Roles: the whole tile (pk_g,
+// pk_jac, pk_hess, unsplit pk_xall), or -- split x-part -- values (g, grad f, integrand sums, constant entries of J)
+// and Jacobian (evaluated entries of J), next to the Hessian role in the single-launch cycle pk_cycle.
+// Extra workgroups handle the boundary nodes / system-level scalars and the sums over all nodes.
+// Sums over all nodes (integrals, gradient entries of t0/tf/static parameters) are reduced
+// wave -> workgroup in the tile kernels and workgroup -> total by ONE workgroup in a fixed order
+// (bit-reproducible): pk_fin in a launch of its own, or -- pk_cycle -- a workgroup of the same launch that receives
+// the partial sums through self-flagging hand-off slots (handoff_put / fin_handoff).
+// Output stores are agent-scope (written through L2), see put().
+//
+// Reference semantics restated by each kernel are cited at the kernel.
+#pragma once
+#include <hip/hip_runtime.h>
+#include "pk_abi.h"
+
+struct PkSys {
+  const double* s;     // static parameters
+  const double* I;     // integrals (valid only when the pre-pass ran)
+  double sigma;
+  const double* lams;  // multipliers of the system constraints = lambda[0 .. n_sys)
+};
+
+namespace pk {
+
+// Tables that no kernel ever writes (segment bases, tile records) are read through the constant address
+// space: uniform addresses then become scalar loads (s_load, SGPR results) and -- being invariant -- the
+// compiler may hoist them above stores and barriers instead of paying a vector-memory round trip right before
+// the streaming stores that need them.
+#define PK_CONST_AS __attribute__((address_space(4)))
+typedef const int64_t PK_CONST_AS* pk_cbase_t;
+__device__ __forceinline__ pk_cbase_t const_bases(const int64_t* p) { return (pk_cbase_t)(uintptr_t)p; }
+__device__ __forceinline__ PkTile load_tile(const PkTile* p) {
+  const int32_t PK_CONST_AS* src = (const int32_t PK_CONST_AS*)(uintptr_t)p;
+  PkTile t;
+  int32_t* dst = reinterpret_cast<int32_t*>(&t);
+#pragma unroll
+  for (int k = 0; k < (int)(sizeof(PkTile) / sizeof(int32_t)); ++k) dst[k] = src[k];
+  return t;
+}
+
+// Base offsets of the N output segments of a phase, held by the wave itself: lane e keeps base e in a VGPR pair
+// (ONE coalesced vector load, issued together with the node loads of phase A) and v_readlane hands base e to the
+// scalar unit where a store needs it.  Read through the constant address space instead, the scalar loads are
+// re-materialised by the register allocator right at their use AFTER the evaluation -- a scalar-cache miss of
+// 0.3-0.5 us in front of the translation, the streaming and the Hessian stores (ISA + wave timeline).
+template <int N>
+struct SegBases {
+  int lo, hi;
+  pk_cbase_t mem;
+  __device__ __forceinline__ void load(const int64_t* __restrict__ lb, int off, int lane) {
+    mem = const_bases(lb + off);
+    if (N <= PK_WAVE) {
+      const long long v = lane < N ? (long long)lb[off + lane] : 0ll;
+      lo = (int)v;
+      hi = (int)(v >> 32);
+    }
+  }
+  // The load has to be WAITED FOR in phase A, where only loads are in flight: vmcnt counts loads and stores
+  // together and they return out of order with respect to each other, so a first use in phase B would make the
+  // compiler wait for every store issued before it (s_waitcnt vmcnt(0), a write round trip).
+  __device__ __forceinline__ void settle() {
+    if (N <= PK_WAVE) asm volatile("" : "+v"(lo), "+v"(hi));
+  }
+  __device__ __forceinline__ int64_t operator[](int e) const {      // e: wave-uniform (a constant after unrolling)
+    if (N > PK_WAVE) return mem[e];
+    const unsigned l = (unsigned)__builtin_amdgcn_readlane(lo, e), h = (unsigned)__builtin_amdgcn_readlane(hi, e);
+    return (int64_t)(((unsigned long long)h << 32) | l);
+  }
+};
+
+// Phase A -> phase B of a tile wave.  A wave stages values for ITSELF only (its own LDS rows, its own copy of the
+// kind tables), LDS executes a wave's instructions in order and a wave runs in lockstep, so no workgroup barrier
+// is needed between the phases: s_barrier made the Jacobian waves wait 0.8 us for the slowest wave of the
+// workgroup (wave timeline).  Only the compiler must keep the order.
+// values loaded in phase A for use in phase B are pinned (waited for) before the first store goes out, see SegBases
+template <int N>
+__device__ __forceinline__ void settle(double (&v)[N]) {
+#pragma unroll
+  for (int i = 0; i < N; ++i) asm volatile("" : "+v"(v[i]));
+}
+
+// End of the load part of phase A: every vector load of the wave has returned (s_waitcnt vmcnt(0), explicit so that
+// it holds on EVERY control-flow path -- the compiler's own waits sit inside the `lane < nodes` branch, and the
+// pending-load state that leaks around that branch turns into a vmcnt(0) behind the first stores of phase B).
+__device__ __forceinline__ void loads_done() { __builtin_amdgcn_s_waitcnt(0x0F70); }
+
+__device__ __forceinline__ void wave_lds_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// XCD-aware workgroup -> tile-block mapping.  The hardware deals consecutive workgroup ids round-robin to the 8
+// XCDs, each with its own L2; neighbouring tiles write neighbouring pieces of the same output arrays (and of the
+// same 128-byte lines where a run does not end on a line boundary).  Giving every XCD one contiguous range of
+// tile blocks lets its L2 merge those pieces into full lines before they are written back.  `first` workgroups
+// (boundary / finalize workgroups) keep their ids; returns the tile-block index of workgroup `wg`.
+// array extent for "one entry per phase": a system without phases (static parameters only,
+// tests/test_base/test_system_base.py:10-20 of the reference) still needs a non-empty array type
+#define PK_NPHASE_DIM (PK_NPHASE > 0 ? PK_NPHASE : 1)
+#define PK_XCDS 8
+#ifndef PK_XCD_REMAP
+#define PK_XCD_REMAP 1
+#endif
+__device__ __forceinline__ int xcd_ids_below(int n, int y) { return (n + PK_XCDS - 1 - y) / PK_XCDS; }   // ids < n on XCD y
+__device__ __forceinline__ int xcd_tile_block(int wg, int first, int total) {
+  if (PK_XCD_REMAP == 0) return wg - first;
+  const int x = wg % PK_XCDS;
+  int start = 0;
+#pragma unroll
+  for (int y = 0; y < PK_XCDS; ++y)
+    if (y < x) start += xcd_ids_below(total, y) - xcd_ids_below(first, y);     // tile blocks on XCD y
+  return start + xcd_ids_below(wg, x) - xcd_ids_below(first, x);
+}
+
+// Developer tracing: PK_MARK(k) stores the constant-rate device clock (s_memrealtime: 100 MHz, the same on every XCD)
+// of lane 0 at checkpoint k of the wave's trace record.  Records: [tile][role 0 values / whole tile, 1 Jacobian,
+// 2 Hessian], then three for pk_cycle's boundary-J, boundary-H and finalize workgroups.
+// Diagnostic launch switches (POCKIT_AMD_DEBUG_FLAGS, tools/cycle_flags.sh: parts of a launch switched off to time the
+// rest) exist in developer builds only (models generated with POCKIT_AMD_TRACE=1): PK_DIAG is a compile-time false in
+// production code objects, so no kernel carries the tests.
+#ifdef PK_TRACE
+#define PK_DIAG(bits) ((A.flags & (bits)) != 0)
+#else
+#define PK_DIAG(bits) false
+#endif
+#ifdef PK_TRACE
+#define PK_TRACE_REC(role) const int pk_trec = tl.pad >= 0 ? tl.pad * 3 + (role) : -1
+#define PK_MARK_AT(rec, k)                                                                                   \
+  do {                                                                                                      \
+    if (A.trace != nullptr && (threadIdx.x & 63) == 0 && (rec) >= 0)                                        \
+      A.trace[(size_t)(rec) * 16 + (k)] = __builtin_amdgcn_s_memrealtime();                                 \
+  } while (0)
+#define PK_MARK(k) PK_MARK_AT(pk_trec, k)
+#define PK_TRACE_PARAM , int pk_trec
+#define PK_TRACE_ARG , pk_trec
+#else
+#define PK_TRACE_PARAM
+#define PK_TRACE_ARG
+#define PK_TRACE_REC(role) do { } while (0)
+#define PK_MARK_AT(rec, k) do { } while (0)
+#define PK_MARK(k) do { } while (0)
+#endif
+
+// All output stores go through put().  Default: agent-scope stores (`sc1`, written through the XCD's L2).  With plain
+// stores the 10-140 MB a launch writes stay dirty in the L2s until the end-of-kernel release writes them back -- after
+// the last wave, with nothing to overlap: write-through spreads that over the kernel's life (MI355X, pk_cycle:
+// quadrotor 2000x6 134k -> 161k cycles/s, brachistochrone 1250x8 135k -> 154k, humanoid 5000x8 38.5k -> 39.6k; system
+// scope `sc0 sc1` measures the same).  Streaming (`nt`) stores are SLOWER than plain ones (humanoid 38.5k -> 22.5k):
+// they lose the L2's merging of the partial lines neighbouring tiles share.  POCKIT_AMD_NT=0|1|2|3 at
+// code-generation time compiles the plain / nt / agent / system variant for A/B measurements (tools/nt_sweep.sh).
+#ifndef PK_NT_STORES
+#define PK_NT_STORES 2
+#endif
+#ifndef PK_WIDE_STORES
+#define PK_WIDE_STORES 1      // streaming loop: two consecutive positions per lane, one 16-byte store per segment
+#endif
+
+__device__ __forceinline__ void put(double* __restrict__ p, double v) {
+#if PK_NT_STORES == 1
+  __builtin_nontemporal_store(v, p);
+#elif PK_NT_STORES == 2      // agent-scope store (sc1): written through the XCD's L2
+  __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#elif PK_NT_STORES == 3      // system-scope store (sc0 sc1)
+  __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+#elif PK_NT_STORES == 4      // the same sc1 store instruction, but not an atomic to the compiler (no ordering of other memory ops)
+  asm volatile("global_store_dwordx2 %0, %1, off sc1" : : "v"(p), "v"(v));
+#else
+  *p = v;
+#endif
+}
+
+// Sum over the 64 lanes of a wave, returned in every lane.  Data-parallel-primitive (DPP) moves keep the
+// six steps in the vector ALU (2 v_mov_dpp + 1 v_add_f64 each); the xor-butterfly on __shfl_xor goes through
+// ds_bpermute, whose LDS-path latency made every reduction a ~700-cycle serial chain (wave timeline,
+// tools/wave_trace.py).  Fixed association: pairs, quads, rows of 16, rows 0+1 / 2+3, halves.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ double dpp_take(double v) {
+  const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, ROW_MASK, 0xf, false);
+  const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, ROW_MASK, 0xf, false);
+  return __hiloint2double(hi, lo);
+}
+
+__device__ __forceinline__ double wave_sum(double v) {
+  v += dpp_take<0xb1, 0xf>(v);    // quad_perm [1,0,3,2]
+  v += dpp_take<0x4e, 0xf>(v);    // quad_perm [2,3,0,1]
+  v += dpp_take<0x114, 0xf>(v);   // row_shr:4   (lanes without a source add 0)
+  v += dpp_take<0x118, 0xf>(v);   // row_shr:8   -> lanes 12..15 of every row hold the row sum
+  v += dpp_take<0x142, 0xa>(v);   // row_bcast:15 into rows 1 and 3
+  v += dpp_take<0x143, 0xc>(v);   // row_bcast:31 into rows 2 and 3 -> lane 63 holds the total
+  const int lo = __builtin_amdgcn_readlane(__double2loint(v), 63);
+  const int hi = __builtin_amdgcn_readlane(__double2hiint(v), 63);
+  return __hiloint2double(hi, lo);
+}
+
+// ---- in-launch hand-off of the per-workgroup partial sums (pk_cycle) --------------------------------------
+// The tile workgroups of a pk_cycle launch publish their partial sums while the SAME launch's finalize workgroup
+// waits for them, so the sums over all nodes cost no second launch.  Protocol: every slot of cpart / cpart2 holds
+// PK_EMPTY between launches; a tile workgroup overwrites its slots with ONE agent-scope 64-bit store each (written
+// through the XCD's L2, fire and forget: no fence, no counter, no wait on the publishing side); the finalize
+// workgroup polls its slots with agent-scope loads until none is PK_EMPTY, takes the values and puts PK_EMPTY back
+// (ordered before the next launch by the end of this one).  The data word is its own flag, so there is nothing to
+// order against it -- an arrival counter would need a release that writes back the whole dirty L2 (the variant
+// DESIGN.md section 5 measured at +6 us).  Forward progress: the publishers never wait for anything, the poller
+// occupies one workgroup slot; the poll is bounded (PK_POLL_LIMIT), after which the slot reads as NaN and the
+// launch ends with NaN in f / the gradient slots instead of hanging.
+#ifndef PK_POLL_SLEEP
+#define PK_POLL_SLEEP 4       // s_sleep between two poll rounds (x 64 cycles)
+#endif
+#define PK_POLL_LIMIT (1 << 24)     // poll rounds of >= 0.5 us each: several seconds, far beyond any launch's duration
+__device__ __forceinline__ void handoff_put(unsigned long long* slot, double v) {
+  unsigned long long b = (unsigned long long)__double_as_longlong(v);
+  if (b == PK_EMPTY) b = 0x7FF8000000000000ull;     // (a NaN either way)
+  __hip_atomic_store(slot, b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ unsigned long long handoff_peek(unsigned long long* slot) {
+  return __hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void handoff_clear(unsigned long long* slot) {
+  __hip_atomic_store(slot, (unsigned long long)PK_EMPTY, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// ---- per-phase scalars: static parameters, t0/tf with boundary substitution ------------------
+// (reference: phasebase.py:839-851  _value_basic)
+template <class P>
+__device__ __forceinline__ void phase_scalars(const PkArgs& A, const PkPhase& ph, double* s, double& dt,
+                                              double& mt) {
+  const double* __restrict__ sx = A.x + A.l_s;
+#pragma unroll
+  for (int i = 0; i < P::NS; ++i) s[i] = sx[i];
+  const double* __restrict__ xp = A.x + ph.x_off;
+  const double t0 = P::t0(xp, ph.L, s), tf = P::tf(xp, ph.L, s);
+  dt = tf - t0;
+  mt = (tf + t0) / 2;
+}
+
+template <class P>
+__device__ __forceinline__ double phase_dt(const PkArgs& A) {
+  double s[PK_NS], dt, mt;
+  phase_scalars<P>(A, A.ph[P::INDEX], s, dt, mt);
+  return dt;
+}
+
+// ---- middle-stage arguments of node q: [x_i(q) | u_j(q) | t(q) | s]  with FIXED/FUNC boundary
+// values substituted (the reference overwrites x in place; we never write to x).  Every lane of a wave
+// calls it (indices are clamped), so that the loads of all lanes -- nodes, the LGR end slot one past the
+// tile's last node, idle lanes -- are issued together with the table loads of the tile ------------
+template <class P>
+__device__ __forceinline__ void load_node(const PkArgs& A, const PkPhase& ph, const double* s, double dt,
+                                          double mt, int q, double* a, double& tau, double& w) {
+  const double* __restrict__ xp = A.x + ph.x_off;
+  const int qs = min(q, ph.state_len - 1), qm = min(q, ph.L_m - 1);
+#pragma unroll
+  for (int i = 0; i < P::NX; ++i) a[i] = xp[i * ph.state_len + qs];
+  const double* __restrict__ up = xp + P::NX * ph.state_len;
+#pragma unroll
+  for (int i = 0; i < P::NU; ++i) a[P::NX + i] = up[i * ph.L_m + qm];
+  if (q == 0) P::fix_front(a, s);
+  if (P::SCHEME == 1 && q == ph.L_m - 1) P::fix_back(a, s);
+  tau = A.db[ph.tau_off + qm];
+  w = A.db[ph.w_off + qm];
+  a[P::NX + P::NU] = (tau - 0.5) * dt + mt;
+#pragma unroll
+  for (int i = 0; i < P::NS; ++i) a[P::NX + P::NU + 1 + i] = s[i];
+}
+
+// floor(p / d) for p < 2^16 from the host-computed magic number of d (PkTile.magic*): umulhi(p, ceil(2^32 / d)).
+// d == 1 has no 32-bit magic (2^32): the host stores 0 for it and the quotient is p itself -- one wave-uniform select
+// (scalar) and one v_and_or per division.  (Without it the tables of LGR K = 1 / LGL K = 2 tiles holding more than
+// one interval were indexed with jj = 0 for every position.)
+__device__ __forceinline__ int magic_div(uint32_t p, uint32_t magic) {
+  const uint32_t all = magic == 0u ? 0xFFFFFFFFu : 0u;
+  return (int)(__umulhi(p, magic) | (p & all));
+}
+
+struct TileGeom {
+  int K, stride, R, nq, nown;
+};
+
+template <class P>
+__device__ __forceinline__ TileGeom tile_geom(const PkTile& tl) {
+  TileGeom g;
+  g.K = tl.K;
+  g.stride = tl.K - P::SCHEME;           // nodes an interval adds (LGL shares its end node)
+  g.R = g.stride;                        // defect rows per interval
+  g.nq = tl.nj == 0 ? 0 : tl.nj * g.stride + P::SCHEME;
+  g.nown = (P::SCHEME && !tl.last) ? g.nq - 1 : g.nq;   // LGL: the shared end node belongs to the next tile
+  return g;
+}
+
+// ---- shared pieces of the tile kernels ---------------------------------------------------------
+
+// The tile's kind tables, copied to LDS by the wave itself while its node loads are in flight: every
+// table of a pattern with K <= 8 has at most 64 entries (one per lane).  After the barrier the defect,
+// translation and streaming phases then read LDS only -- no dependent global round trips between the
+// evaluation and the stores (measured on MI355X: each such round trip costs the latency-bound kernels
+// 0.6-0.8 us).  Larger K keeps the tables in global memory.
+struct TabRegs {
+  double iv, full, tv, wd;
+  int rc;
+};
+
+struct TileTabs {
+  bool staged;
+  const double* __restrict__ iv;    // LDS copies (valid when staged), [64] each
+  const double* __restrict__ full;
+  const double* __restrict__ tv;
+  const double* __restrict__ wd;
+  const int* __restrict__ rc;       // r | c << 16
+};
+
+__device__ __forceinline__ bool tabs_fit(const PkArgs& A, const PkTile& tl, const TileGeom& g) {
+  return tl.nnzI <= PK_WAVE && g.R * g.K <= PK_WAVE && tl.nnzT <= PK_WAVE && !PK_DIAG(4096);
+}
+
+__device__ __forceinline__ TabRegs tabs_issue(const PkArgs& A, const PkPhase& ph, const PkTile& tl, const TileGeom& g,
+                                              bool fit, int lane) {
+  TabRegs t{0.0, 0.0, 0.0, 0.0, 0};
+  if (!fit) return t;
+  if (lane < tl.nnzI) {
+    t.iv = A.db[tl.iv_off + lane];
+    t.rc = A.ib[tl.irc_off + 2 * lane] | (A.ib[tl.irc_off + 2 * lane + 1] << 16);
+  }
+  if (lane < g.R * g.K) t.full = A.db[tl.full_off + lane];
+  if (lane < tl.nnzT) t.tv = A.db[tl.tv_off + lane];
+  if (lane < tl.nj) t.wd = A.db[ph.width_off + tl.j0 + lane];
+  return t;
+}
+
+__device__ __forceinline__ TileTabs tabs_commit(const TabRegs& t, bool fit, int lane) {
+  __shared__ double td[PK_WAVES_PER_BLOCK][4][PK_WAVE];
+  __shared__ int ti[PK_WAVES_PER_BLOCK][PK_WAVE];
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  if (fit) {
+    td[wave][0][lane] = t.iv;
+    td[wave][1][lane] = t.full;
+    td[wave][2][lane] = t.tv;
+    td[wave][3][lane] = t.wd;
+    ti[wave][lane] = t.rc;
+  }
+  return TileTabs{fit, td[wave][0], td[wave][1], td[wave][2], td[wave][3], ti[wave]};
+}
+
+// x at the end slot of the interval whose defect row this lane writes after the barrier: lane (jj+1)*stride of
+// the wave holds it (every lane loaded its clamped slot); only a full LGR tile (64 nodes) reaches past the wave
+template <class P>
+__device__ __forceinline__ void defect_ends(const PkArgs& A, const PkPhase& ph, const PkTile& tl, const TileGeom& g,
+                                            const double* a, double* xe, int lane) {
+  const int jj = min(magic_div((uint32_t)lane, tl.magicR), max(tl.nj - 1, 0));
+  const int src = (jj + 1) * g.stride;
+#pragma unroll
+  for (int i = 0; i < P::NX; ++i) xe[i] = __shfl(a[i], src & (PK_WAVE - 1), PK_WAVE);
+  if (src >= PK_WAVE && lane < tl.nj * g.R) {
+    const double* __restrict__ xp = A.x + ph.x_off;
+#pragma unroll
+    for (int i = 0; i < P::NX; ++i) xe[i] = xp[i * ph.state_len + tl.q0 + src];
+  }
+}
+
+// one defect row: acc_i += sum_c (I_hat[r, c] * d / 2) * f_i(c), K known at compile time
+template <class P, int K>
+__device__ __forceinline__ void defect_dot(const double* __restrict__ full, const double* __restrict__ f, double width,
+                                           double* acc) {
+  double a[K];
+#pragma unroll
+  for (int c = 0; c < K; ++c) a[c] = full[c] * width * 0.5;      // (I_hat * d) / 2 as the reference scales it
+#pragma unroll
+  for (int c = 0; c < K; ++c) {
+#pragma unroll
+    for (int i = 0; i < P::NX; ++i) acc[i] += a[c] * f[i * PK_WAVE + c];
+  }
+}
+
+// collocation defects of the tile's rows:  (x_q - x_end) - dt * sum_c (I_hat[r,c] d/2) f_i(c)
+// f staged in LDS as fsv[i * 64 + lane]                  (phasebase.py:1008-1012; batched small GEMV)
+template <class P, bool STAGED>
+__device__ __forceinline__ void write_defects(const PkArgs& A, const PkPhase& ph, const PkTile& tl,
+                                              const TileGeom& g, const TileTabs& T, const double* s, double dt,
+                                              const double* __restrict__ fsv, const double* xr, double* xe,
+                                              int lane) {
+  const int nrows = tl.nj * g.R;
+  if (lane >= nrows) return;
+  const int jj = magic_div((uint32_t)lane, tl.magicR), r = lane - jj * g.R;
+  const int endslot = tl.q0 + (jj + 1) * g.stride;
+  const int back_slot = P::SCHEME ? ph.L_m - 1 : ph.L_m;
+  const double* __restrict__ f = fsv + jj * g.stride;
+  double acc[P::NX];
+#pragma unroll
+  for (int i = 0; i < P::NX; ++i) acc[i] = 0.0;
+  if (STAGED) {
+    const double width = T.wd[jj];
+    const double* __restrict__ full = T.full + r * g.K;
+    switch (g.K) {   // K <= 8 here: fully unrolled so that all LDS reads of a row are in flight together
+      case 1: defect_dot<P, 1>(full, f, width, acc); break;
+      case 2: defect_dot<P, 2>(full, f, width, acc); break;
+      case 3: defect_dot<P, 3>(full, f, width, acc); break;
+      case 4: defect_dot<P, 4>(full, f, width, acc); break;
+      case 5: defect_dot<P, 5>(full, f, width, acc); break;
+      case 6: defect_dot<P, 6>(full, f, width, acc); break;
+      case 7: defect_dot<P, 7>(full, f, width, acc); break;
+      default: defect_dot<P, 8>(full, f, width, acc); break;
+    }
+  } else {
+    const double* __restrict__ full = A.db + tl.full_off + r * g.K;
+    const double width = A.db[ph.width_off + tl.j0 + jj];
+#pragma unroll 4
+    for (int c = 0; c < g.K; ++c) {
+      const double a = full[c] * width * 0.5;      // (I_hat * d) / 2 as the reference scales it
+#pragma unroll
+      for (int i = 0; i < P::NX; ++i) acc[i] += a * f[i * PK_WAVE + c];
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < P::NX; ++i) {
+    if (endslot == back_slot) xe[i] = P::back_value(i, xe[i], s);
+    put(&A.o_g[ph.g_off + i * ph.L_d + tl.r0 + lane], (xr[i] - xe[i]) - acc[i] * dt);
+  }
+}
+
+// constant translation entries of every state (phasebase.py:1077)
+template <class P, bool STAGED>
+__device__ __forceinline__ void write_translation(const PkArgs& A, const PkPhase& ph, const PkTile& tl,
+                                                  const TileTabs& T, const SegBases<P::NX>& tbase, int lane) {
+  const int tot = tl.nj * tl.nnzT;
+  const double* __restrict__ tvg = A.db + tl.tv_off;
+  // wave-uniform run starts (SGPR pairs) + ONE 32-bit lane offset shared by all states: the stores take the
+  // `saddr + voffset` form and no 64-bit address is computed per store
+  double* __restrict__ run[P::NX];
+#pragma unroll
+  for (int i = 0; i < P::NX; ++i) run[i] = A.o_jac + (tbase[i] + tl.offT);
+  for (uint32_t p = lane; p < (uint32_t)tot; p += PK_WAVE) {
+    const int t = (int)p - magic_div(p, tl.magicT) * tl.nnzT;
+    const double v = STAGED ? T.tv[t] : tvg[t];
+#pragma unroll
+    for (int i = 0; i < P::NX; ++i) put(&run[i][p], v);
+  }
+}
+
+// streaming phase: out[base_e + offI + p] = -(I_hat[t] d/2) * sv_e[col(p)] (* lambda[row(p)])
+// (phasebase.py:1120-1124 and 1280-1285 -- the gather-multiply-concatenate that dominates the reference)
+// lam_s: the tile's multiplier rows staged in LDS as lam_s[state * 64 + row]   (Hessian only)
+template <class P, int NI, bool HESS, bool STAGED, class Bases>
+__device__ __forceinline__ void stream_loop(const PkArgs& A, const PkPhase& ph, const PkTile& tl, const TileGeom& g,
+                                            const TileTabs& T, const double* __restrict__ sv,
+                                            const double* __restrict__ lam_s, const Bases& bases,
+                                            double* __restrict__ out, int lane) {
+  // the tile's run in every segment: a wave-uniform pointer (SGPR pair); with the 32-bit position p as the only
+  // per-lane part the stores take the `saddr + voffset` form (no 64-bit address arithmetic per store)
+  double* __restrict__ run[NI > 0 ? NI : 1];
+#pragma unroll
+  for (int e = 0; e < NI; ++e) run[e] = out + (bases[e] + tl.offI);
+  const int nnz = tl.nnzI;
+  const int tot = tl.nj * nnz;
+#if PK_WIDE_STORES
+  if (STAGED) {
+    // A lane takes two CONSECUTIVE positions and writes them with one 16-byte store per segment (the same sc1
+    // flavour as put()): half the store instructions of the 8-byte variant below -- humanoid 5000x8 +2.3 %,
+    // brachistochrone 1250x8 +3 %, quadrotor 2000x6 +0..8 % (POCKIT_AMD_WIDE_STORES=0 compiles the variant below).
+    // All LDS reads of the pair come before its first store (stores are ordered against every other memory operation).
+    typedef double pk_d2 __attribute__((ext_vector_type(2)));
+    for (uint32_t p0 = 2 * lane; p0 < (uint32_t)tot; p0 += 2 * PK_WAVE) {
+      double v[2][NI > 0 ? NI : 1];
+      const bool pair = p0 + 1 < (uint32_t)tot;
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const uint32_t pc = (u == 0 || pair) ? p0 + u : p0;
+        const int jj = magic_div(pc, tl.magicI);
+        const int t = (int)pc - jj * nnz;
+        const int rc = T.rc[t];
+        const double val = -(T.iv[t] * T.wd[jj] * 0.5);
+        const double* __restrict__ col = sv + jj * g.stride + (rc >> 16);
+        const double* __restrict__ lam = lam_s + jj * g.R + (rc & 0xFFFF);
+#pragma unroll
+        for (int e = 0; e < NI; ++e)
+          v[u][e] = HESS ? val * lam[P::H_state(e) * PK_WAVE] * col[e * PK_WAVE] : val * col[e * PK_WAVE];
+      }
+#pragma unroll
+      for (int e = 0; e < NI; ++e) {
+        if (pair) {
+          const pk_d2 w = {v[0][e], v[1][e]};
+          asm volatile("global_store_dwordx4 %0, %1, off sc1" : : "v"(&run[e][p0]), "v"(w));
+        } else {
+          put(&run[e][p0], v[0][e]);
+        }
+      }
+    }
+    return;
+  }
+#endif
+  if (STAGED) {
+    // Two positions per lane and loop iteration, and ALL LDS reads of the pair before its first store: the output
+    // stores are agent-scope atomics (put), which the compiler keeps every other memory operation behind -- written
+    // store by store, each ds_read waited for its predecessor's store (8 exposed LDS latencies per iteration in the
+    // ISA).  (Segment-major order -- each segment's stores of 256 positions back to back -- was measured slower.)
+    constexpr int U = NI <= 12 ? 2 : 1;
+    for (uint32_t p0 = lane; p0 < (uint32_t)tot; p0 += U * PK_WAVE) {
+      double v[U][NI > 0 ? NI : 1];
+      bool ok[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const uint32_t p = p0 + u * PK_WAVE;
+        ok[u] = p < (uint32_t)tot;
+        const uint32_t pc = ok[u] ? p : p0;
+        const int jj = magic_div(pc, tl.magicI);   // p / nnz (p < 2^16)
+        const int t = (int)pc - jj * nnz;
+        const int rc = T.rc[t];
+        const double val = -(T.iv[t] * T.wd[jj] * 0.5);
+        const double* __restrict__ col = sv + jj * g.stride + (rc >> 16);
+        const double* __restrict__ lam = lam_s + jj * g.R + (rc & 0xFFFF);
+#pragma unroll
+        for (int e = 0; e < NI; ++e)
+          v[u][e] = HESS ? val * lam[P::H_state(e) * PK_WAVE] * col[e * PK_WAVE] : val * col[e * PK_WAVE];
+      }
+#ifdef PK_TRACE
+      if (PK_DIAG(131072)) {    // tracing builds only: the loop without its stores (lookups and products kept alive)
+        double acc = 0.0;
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+#pragma unroll
+          for (int e = 0; e < NI; ++e) acc += v[u][e];
+        asm volatile("" ::"v"(acc));
+        continue;
+      }
+#endif
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        if (!ok[u]) continue;
+#pragma unroll
+        for (int e = 0; e < NI; ++e) put(&run[e][p0 + u * PK_WAVE], v[u][e]);
+      }
+    }
+    return;
+  }
+  const int32_t* __restrict__ rcg = A.ib + tl.irc_off;
+  const double* __restrict__ ivg = A.db + tl.iv_off;
+  const double* __restrict__ wdg = A.db + ph.width_off + tl.j0;
+  for (uint32_t p = lane; p < (uint32_t)tot; p += PK_WAVE) {
+    const int jj = magic_div(p, tl.magicI);   // p / nnz (p < 2^16)
+    const int t = (int)p - jj * nnz;
+    const int r = rcg[2 * t], c = rcg[2 * t + 1];
+    const double val = -(ivg[t] * wdg[jj] * 0.5);
+    const double* __restrict__ col = sv + jj * g.stride + c;
+    if (HESS) {
+      const double* __restrict__ lam = lam_s + jj * g.R + r;
+#pragma unroll
+      for (int e = 0; e < NI; ++e) put(&run[e][p], val * lam[P::H_state(e) * PK_WAVE] * col[e * PK_WAVE]);
+    } else {
+#pragma unroll
+      for (int e = 0; e < NI; ++e) put(&run[e][p], val * col[e * PK_WAVE]);
+    }
+  }
+}
+
+template <class P, int NI, bool HESS, bool STAGED, class Bases>
+__device__ __forceinline__ void stream_expanded(const PkArgs& A, const PkPhase& ph, const PkTile& tl,
+                                                const TileGeom& g, const TileTabs& T, const double* __restrict__ sv,
+                                                const double* __restrict__ lam_s, const Bases& segb,
+                                                double* __restrict__ out, int lane) {
+  if (NI == 0 || tl.nj * tl.nnzI == 0) return;
+  stream_loop<P, NI, HESS, STAGED>(A, ph, tl, g, T, sv, lam_s, segb, out, lane);
+}
+
+// Phase B is compiled twice -- tables staged in LDS (K <= 8) or read from global memory -- and the wave branches
+// ONCE: on gfx9-class hardware loads and stores share one counter (vmcnt) and return out of order with respect to
+// each other, so a single global load in a loop of phase B makes the compiler wait for ALL outstanding stores
+// (s_waitcnt vmcnt(0): a full write round trip of 0.4-0.8 us per loop iteration, found in the ISA of the
+// translation loop and in front of the streaming loop).  The staged variant contains no global load at all.
+#define PK_PHASE_B(T, CALL)       \
+  do {                            \
+    if ((T).staged) {             \
+      constexpr bool STAGED = true;  \
+      CALL;                       \
+    } else {                      \
+      constexpr bool STAGED = false; \
+      CALL;                       \
+    }                             \
+  } while (0)
+
+// per-node gradient entries: own variable slots directly, shared slots into orr   (systembase.py:646-657)
+template <class P>
+__device__ __forceinline__ void node_gradient_eval(const PkPhase& ph, int q, const double* a, double tau, double dt,
+                                                   double w, const PkSys& sy, double* ov, double* orr, bool have_mid) {
+  if (q == 0)
+    P::front_grad(a, tau, dt, w, sy, nullptr, ov, orr);
+  else if (P::SCHEME == 1 && q == ph.L_m - 1)
+    P::back_grad(a, tau, dt, w, sy, nullptr, ov, orr);
+  else if (!have_mid)
+    P::mid_grad(a, tau, dt, w, sy, nullptr, ov, orr);
+}
+
+template <class P>
+__device__ __forceinline__ void node_gradient_store(const PkArgs& A, const PkPhase& ph, int q, const double* ov) {
+  double* __restrict__ gp = A.o_grad + ph.x_off;
+#pragma unroll
+  for (int i = 0; i < P::NX; ++i) put(&gp[i * ph.state_len + q], ov[i]);
+#pragma unroll
+  for (int i = 0; i < P::NU; ++i) put(&gp[P::NX * ph.state_len + i * ph.L_m + q], ov[P::NX + i]);
+}
+
+template <class P>
+__device__ __forceinline__ void node_gradient(const PkArgs& A, const PkPhase& ph, int q, const double* a,
+                                              double tau, double dt, double w, const PkSys& sy, double* ov,
+                                              double* orr, bool have_mid) {
+  node_gradient_eval<P>(ph, q, a, tau, dt, w, sy, ov, orr, have_mid);
+  node_gradient_store<P>(A, ph, q, ov);
+}
+
+// ============================================================================================
+// integrand values -> per-wave sums of w * phi      (phasebase.py:997-1006)
+// ============================================================================================
+template <class P>
+__device__ __forceinline__ void tile_int(const PkArgs& A, const PkTile& tl, double* __restrict__,
+                                         double* __restrict__ wint, double* __restrict__, int lane) {
+  if (P::INT_N == 0) return;
+  const PkPhase& ph = A.ph[P::INDEX];
+  const TileGeom g = tile_geom<P>(tl);
+  double s[PK_NS], dt, mt;
+  phase_scalars<P>(A, ph, s, dt, mt);
+  double o[P::INT_N > 0 ? P::INT_N : 1];
+#pragma unroll
+  for (int r = 0; r < P::INT_N; ++r) o[r] = 0.0;
+  if (lane < g.nown) {
+    double a[P::NARG], tau, w;
+    load_node<P>(A, ph, s, dt, mt, tl.q0 + lane, a, tau, w);
+    P::mid_int(a, o);
+#pragma unroll
+    for (int r = 0; r < P::INT_N; ++r) o[r] *= w;
+  }
+#pragma unroll
+  for (int r = 0; r < P::INT_N; ++r) {
+    const double v = wave_sum(o[r]);
+    if (lane == 0) wint[r] = v;
+  }
+}
+
+// ============================================================================================
+// constraints: collocation defects and path-constraint values      (phasebase.py:1008-1021)
+// ============================================================================================
+template <class P>
+__device__ __forceinline__ void tile_g(const PkArgs& A, const PkTile& tl, double* __restrict__ sv,
+                                       double* __restrict__, double* __restrict__, int lane) {
+  const PkPhase& ph = A.ph[P::INDEX];
+  const TileGeom g = tile_geom<P>(tl);
+  double s[PK_NS], dt, mt;
+  phase_scalars<P>(A, ph, s, dt, mt);
+  const bool fit = tabs_fit(A, tl, g);
+  const TabRegs tr = tabs_issue(A, ph, tl, g, fit, lane);
+  const int q = tl.q0 + lane;
+  double a[P::NARG], tau, w, xr[P::NX], xe[P::NX];
+  load_node<P>(A, ph, s, dt, mt, q, a, tau, w);
+  const TileTabs T = tabs_commit(tr, fit, lane);
+  defect_ends<P>(A, ph, tl, g, a, xe, lane);
+  settle(xe);
+  loads_done();
+#pragma unroll
+  for (int i = 0; i < P::NX; ++i) xr[i] = a[i];
+  if (lane < g.nq) {
+    double o[P::G_NOUT];
+    P::mid_g(a, o);
+#pragma unroll
+    for (int i = 0; i < P::NX; ++i) sv[i * PK_WAVE + lane] = o[i];
+    if (lane < g.nown) {
+#pragma unroll
+      for (int j = 0; j < P::NC; ++j) put(&A.o_g[ph.path_off + j * ph.L_m + q], o[P::NX + j]);
+    }
+  }
+  wave_lds_sync();
+  PK_PHASE_B(T, (write_defects<P, STAGED>(A, ph, tl, g, T, s, dt, sv, xr, xe, lane)));
+}
+
+// ============================================================================================
+// dense objective gradient      (phasebase.py:1036-1068, systembase.py:625-657)
+// ============================================================================================
+template <class P>
+__device__ __forceinline__ void tile_grad(const PkArgs& A, const PkTile& tl, double* __restrict__,
+                                          double* __restrict__, double* __restrict__ wgrad, int lane) {
+  const PkPhase& ph = A.ph[P::INDEX];
+  const TileGeom g = tile_geom<P>(tl);
+  double s[PK_NS], dt, mt;
+  phase_scalars<P>(A, ph, s, dt, mt);
+  const PkSys sy{s, A.Ibuf, A.sigma, A.lam};
+  double orr[P::GR_NR > 0 ? P::GR_NR : 1];
+#pragma unroll
+  for (int r = 0; r < P::GR_NR; ++r) orr[r] = 0.0;
+  if (lane < g.nown) {
+    const int q = tl.q0 + lane;
+    double a[P::NARG], tau, w, ov[P::NX + P::NU];
+    load_node<P>(A, ph, s, dt, mt, q, a, tau, w);
+    node_gradient<P>(A, ph, q, a, tau, dt, w, sy, ov, orr, false);
+  }
+#pragma unroll
+  for (int r = 0; r < P::GR_NR; ++r) {
+    const double v = wave_sum(orr[r]);
+    if (lane == 0) wgrad[r] = v;
+  }
+}
+
+// ============================================================================================
+// Jacobian      (phasebase.py:1070-1152)
+// ============================================================================================
+template <class P>
+__device__ __forceinline__ void tile_jac(const PkArgs& A, const PkTile& tl, double* __restrict__ sv,
+                                         double* __restrict__, double* __restrict__, int lane) {
+  const PkPhase& ph = A.ph[P::INDEX];
+  const TileGeom g = tile_geom<P>(tl);
+  double s[PK_NS], dt, mt;
+  phase_scalars<P>(A, ph, s, dt, mt);
+  const PkSys sy{s, A.Ibuf, A.sigma, A.lam};
+  SegBases<P::J_NI + P::J_NN> segb;
+  SegBases<P::NX> tbase;
+  segb.load(A.lb, ph.jseg_off, lane);
+  tbase.load(A.lb, ph.jt_off, lane);
+  const bool fit = tabs_fit(A, tl, g);
+  const TabRegs tr = tabs_issue(A, ph, tl, g, fit, lane);
+  const int q = tl.q0 + lane;
+  double a[P::NARG], tau, w;
+  load_node<P>(A, ph, s, dt, mt, q, a, tau, w);
+  const TileTabs T = tabs_commit(tr, fit, lane);
+  segb.settle();
+  tbase.settle();
+  loads_done();
+  if (lane < g.nq) {
+    double o[P::J_NI + P::J_NN + 1];
+    P::mid_jac(a, tau, dt, w, sy, nullptr, o);
+#pragma unroll
+    for (int e = 0; e < P::J_NI; ++e) sv[e * PK_WAVE + lane] = o[e];
+    if (lane < g.nown && q >= ph.mid_lo && q < ph.mid_hi) {
+#pragma unroll
+      for (int e = 0; e < P::J_NN; ++e) put(&A.o_jac[segb[P::J_NI + e] + (q - ph.mid_lo)], o[P::J_NI + e]);
+    }
+  }
+  wave_lds_sync();
+  if (tl.nj == 0) return;
+  PK_PHASE_B(T, (write_translation<P, STAGED>(A, ph, tl, T, tbase, lane),
+                 stream_expanded<P, P::J_NI, false, STAGED>(A, ph, tl, g, T, sv, nullptr, segb, A.o_jac, lane)));
+}
+
+// ============================================================================================
+// Hessian of the Lagrangian      (phasebase.py:1211-1337, systembase.py:735-835)
+// ============================================================================================
+template <class P>
+__device__ __forceinline__ void tile_hess(const PkArgs& A, const PkTile& tl, double* __restrict__ sv,
+                                          double* __restrict__, double* __restrict__, int lane) {
+  const PkPhase& ph = A.ph[P::INDEX];
+  const TileGeom g = tile_geom<P>(tl);
+  double s[PK_NS], dt, mt;
+  phase_scalars<P>(A, ph, s, dt, mt);
+  const PkSys sy{s, A.Ibuf, A.sigma, A.lam};
+  SegBases<P::H_NI + P::H_NN> segb;
+  segb.load(A.lb, ph.hseg_off, lane);
+  double* __restrict__ lam_s = sv + P::H_NI * PK_WAVE;       // the tile's defect multipliers, [state][row]
+  PK_TRACE_REC(2);
+  PK_MARK(0);
+  const bool fit = tabs_fit(A, tl, g);
+  const TabRegs tr = tabs_issue(A, ph, tl, g, fit, lane);
+  const int q = tl.q0 + lane;
+  double a[P::NARG], tau, w, lp[P::NC > 0 ? P::NC : 1], lrow[P::NX];
+  const int row = min(tl.r0 + lane, ph.L_d - 1);
+#pragma unroll
+  for (int i = 0; i < P::NX; ++i) lrow[i] = A.lam[ph.g_off + i * ph.L_d + row];
+  load_node<P>(A, ph, s, dt, mt, q, a, tau, w);
+#pragma unroll
+  for (int j = 0; j < P::NC; ++j) lp[j] = A.lam[ph.path_off + j * ph.L_m + min(q, ph.L_m - 1)];
+  const TileTabs T = tabs_commit(tr, fit, lane);
+#pragma unroll
+  for (int i = 0; i < P::NX; ++i) lam_s[i * PK_WAVE + lane] = lrow[i];
+  segb.settle();
+  loads_done();
+  PK_MARK(1);
+  if (lane < g.nq) {
+    double o[P::H_NI + P::H_NN + 1];
+    PK_MARK(2);
+    P::mid_hess(a, tau, dt, w, sy, lp, o);
+    PK_MARK(3);
+#pragma unroll
+    for (int e = 0; e < P::H_NI; ++e) sv[e * PK_WAVE + lane] = o[e];
+    if (lane < g.nown && q >= ph.mid_lo && q < ph.mid_hi) {
+#pragma unroll
+      for (int e = 0; e < P::H_NN; ++e) put(&A.o_hess[segb[P::H_NI + e] + (q - ph.mid_lo)], o[P::H_NI + e]);
+    }
+  }
+  PK_MARK(4);
+  wave_lds_sync();
+  PK_MARK(5);
+  if (tl.nj == 0) return;
+  PK_PHASE_B(T, (stream_expanded<P, P::H_NI, true, STAGED>(A, ph, tl, g, T, sv, lam_s, segb, A.o_hess, lane)));
+  PK_MARK(8);
+#ifdef PK_TRACE
+  __builtin_amdgcn_s_waitcnt(0);      // all stores acknowledged
+  PK_MARK(9);
+#endif
+}
+
+// ============================================================================================
+// fused x-callbacks: f (integrand sums), grad f, g and J of one tile from ONE evaluation of the node
+// (one joint CSE over all model functions; x read once).  Used by pk_eval_cycle_dev.
+// LDS: [NX dynamics values | J_NI Jacobian segments] x 64 lanes.
+// ============================================================================================
+template <class P, int ROLE, bool STAGED>
+__device__ __forceinline__ void xall_phase_b(const PkArgs& A, const PkPhase& ph, const PkTile& tl, const TileGeom& g,
+                                             const TileTabs& T, const double* s, double dt,
+                                             const double* __restrict__ sv, const double* __restrict__ jsv,
+                                             const double* xr, double* xe,
+                                             const SegBases<P::J_NI + P::J_NN>& segb, const SegBases<P::NX>& tbase,
+                                             int lane PK_TRACE_PARAM) {
+  if (ROLE != 2 && !PK_DIAG(8192)) write_defects<P, STAGED>(A, ph, tl, g, T, s, dt, sv, xr, xe, lane);
+  PK_MARK(6);
+  if (tl.nj == 0) return;
+  // the constant translation entries of J go out with the VALUES wave: the Jacobian wave's streaming is the longest
+  // chain of the launch (wave timeline), the values wave has ~1 us of slack after its defect rows
+  if (ROLE != 2 && !PK_DIAG(16384)) write_translation<P, STAGED>(A, ph, tl, T, tbase, lane);
+  PK_MARK(7);
+  if (ROLE == 1) return;
+  if (!PK_DIAG(32768))
+    stream_expanded<P, P::J_NI, false, STAGED>(A, ph, tl, g, T, jsv, nullptr, segb, A.o_jac, lane);
+}
+
+// ROLE 0: the wave produces everything of its tile.  ROLE 1 / 2 (split launch): two waves of two different
+// workgroups share a tile -- 1 writes the values (integrand sums, gradient, path constraints, defects) and the
+// constant translation entries of J, 2 the evaluated part of the Jacobian (N segments, I-expanded segments); the role is a compile-time constant, so each
+// wave's copy of the inlined model evaluation keeps only what its outputs need and its serial chain is roughly
+// halved.  A workgroup holds four waves of ONE role (four consecutive tiles).
+// pub_blk >= 0 (pk_cycle, roles 0 / 1): the workgroup hands its partial sums to the launch's finalize workgroup as
+// soon as they exist (handoff_put) -- before its own staging, defect and streaming work.
+template <class P, int ROLE>
+__device__ __forceinline__ void tile_xall(const PkArgs& A, const PkTile& tl, double* __restrict__ sv,
+                                          double* __restrict__ wint, double* __restrict__ wgrad, int lane,
+                                          int pub_blk) {
+  const PkPhase& ph = A.ph[P::INDEX];
+  const TileGeom g = tile_geom<P>(tl);
+  PK_TRACE_REC(ROLE == 2 ? 1 : 0);
+  PK_MARK(0);
+  double s[PK_NS], dt, mt;
+  phase_scalars<P>(A, ph, s, dt, mt);
+  const PkSys sy{s, A.Ibuf, A.sigma, A.lam};
+  SegBases<P::J_NI + P::J_NN> segb;
+  SegBases<P::NX> tbase;
+  if (ROLE != 1) segb.load(A.lb, ph.jseg_off, lane);
+  if (ROLE != 2) tbase.load(A.lb, ph.jt_off, lane);
+  double* __restrict__ jsv = sv + P::NX * PK_WAVE;
+  const bool fit = tabs_fit(A, tl, g);
+  const TabRegs tr = tabs_issue(A, ph, tl, g, fit, lane);
+  const int q = tl.q0 + lane;
+  double a[P::NARG], tau, w, xr[P::NX], xe[P::NX];
+  load_node<P>(A, ph, s, dt, mt, q, a, tau, w);
+  const TileTabs T = tabs_commit(tr, fit, lane);
+  if (ROLE != 1) segb.settle();
+  if (ROLE != 2) tbase.settle();
+  PK_MARK(1);
+  if (ROLE != 2) {
+    defect_ends<P>(A, ph, tl, g, a, xe, lane);
+    settle(xe);
+  }
+  loads_done();
+#pragma unroll
+  for (int i = 0; i < P::NX; ++i) xr[i] = a[i];
+  double oi[P::INT_N > 0 ? P::INT_N : 1], orr[P::GR_NR > 0 ? P::GR_NR : 1];
+#pragma unroll
+  for (int r = 0; r < P::INT_N; ++r) oi[r] = 0.0;
+#pragma unroll
+  for (int r = 0; r < P::GR_NR; ++r) orr[r] = 0.0;
+  double og[P::G_NOUT], oj[P::J_NI + P::J_NN + 1], ov[P::NX + P::NU];
+  const bool live = lane < g.nq && !PK_DIAG(512);   // (bit 9: diagnostic switch, skip the evaluation phase)
+  if (live) {
+    double ot[P::GR_NR > 0 ? P::GR_NR : 1], op[P::INT_N > 0 ? P::INT_N : 1];
+    PK_MARK(2);
+    P::mid_xall(a, tau, dt, w, sy, og, oj, ov, ot, op);
+    PK_MARK(3);
+    if (ROLE != 2 && lane < g.nown) {
+#pragma unroll
+      for (int r = 0; r < P::INT_N; ++r) oi[r] = op[r] * w;
+#pragma unroll
+      for (int r = 0; r < P::GR_NR; ++r) orr[r] = ot[r];
+      node_gradient_eval<P>(ph, q, a, tau, dt, w, sy, ov, orr, true);   // boundary nodes re-evaluate their own entries
+    }
+  }
+  if (ROLE != 2) {
+#pragma unroll
+    for (int r = 0; r < P::INT_N; ++r) {
+      const double v = wave_sum(oi[r]);
+      if (lane == 0) wint[r] = v;
+    }
+#pragma unroll
+    for (int r = 0; r < P::GR_NR; ++r) {
+      const double v = wave_sum(orr[r]);
+      if (lane == 0) wgrad[r] = v;
+    }
+    PK_MARK(10);
+    if (pub_blk >= 0) {
+      __syncthreads();                                      // (all four waves of the workgroup have this role)
+      if ((int)threadIdx.x < PK_NRED) {                     // lanes of wave 0, whose wint / wgrad rows start the arrays
+        double vi = 0.0, vg = 0.0;
+#pragma unroll
+        for (int wv = 0; wv < PK_WAVES_PER_BLOCK; ++wv) {   // same order as publish_block_partials
+          vi += wint[wv * PK_NRED + threadIdx.x];
+          vg += wgrad[wv * PK_NRED + threadIdx.x];
+        }
+        handoff_put(A.cpart + (size_t)pub_blk * PK_NRED + threadIdx.x, vi);
+        handoff_put(A.cpart2 + (size_t)pub_blk * PK_NRED + threadIdx.x, vg);
+      }
+      PK_MARK(11);
+    }
+  }
+  if (live) {
+    if (ROLE != 2) {
+      if (lane < g.nown) node_gradient_store<P>(A, ph, q, ov);      // (after the sums went out: they feed the finalize chain)
+#pragma unroll
+      for (int i = 0; i < P::NX; ++i) sv[i * PK_WAVE + lane] = og[i];
+    }
+    if (ROLE != 1) {
+#pragma unroll
+      for (int e = 0; e < P::J_NI; ++e) jsv[e * PK_WAVE + lane] = oj[e];
+    }
+    if (lane < g.nown) {
+      if (ROLE != 2) {
+#pragma unroll
+        for (int j = 0; j < P::NC; ++j) put(&A.o_g[ph.path_off + j * ph.L_m + q], og[P::NX + j]);
+      }
+      if (ROLE != 1 && q >= ph.mid_lo && q < ph.mid_hi) {
+#pragma unroll
+        for (int e = 0; e < P::J_NN; ++e) put(&A.o_jac[segb[P::J_NI + e] + (q - ph.mid_lo)], oj[P::J_NI + e]);
+      }
+    }
+  }
+  PK_MARK(4);
+  wave_lds_sync();
+  PK_MARK(5);
+  if (PK_DIAG(256)) return;   // diagnostic build switches: skip the phases after the staging (all / one by one)
+  PK_PHASE_B(T, (xall_phase_b<P, ROLE, STAGED>(A, ph, tl, g, T, s, dt, sv, jsv, xr, xe, segb, tbase, lane PK_TRACE_ARG)));
+  PK_MARK(8);
+#ifdef PK_TRACE
+  __builtin_amdgcn_s_waitcnt(0);      // all stores acknowledged
+  PK_MARK(9);
+#endif
+}
+
+// ============================================================================================
+// auxiliary pass of the outer-product path: quadrature-weighted gradient entries of the integrals
+// (one value per middle node), consumed by pk_outer       (systembase.py:625-644; easyderiv.py:393-430)
+// ============================================================================================
+template <class P>
+__device__ __forceinline__ void tile_aux(const PkArgs& A, const PkTile& tl, double* __restrict__,
+                                         double* __restrict__, double* __restrict__, int lane) {
+  if (P::A_NN == 0) return;
+  const PkPhase& ph = A.ph[P::INDEX];
+  const TileGeom g = tile_geom<P>(tl);
+  double s[PK_NS], dt, mt;
+  phase_scalars<P>(A, ph, s, dt, mt);
+  const PkSys sy{s, A.Ibuf, A.sigma, A.lam};
+  pk_cbase_t segb = const_bases(A.lb + ph.aseg_off);
+  if (lane < g.nown) {
+    const int q = tl.q0 + lane;
+    if (q >= ph.mid_lo && q < ph.mid_hi) {
+      double a[P::NARG], tau, w, o[P::A_NN + 1];
+      load_node<P>(A, ph, s, dt, mt, q, a, tau, w);
+      P::mid_aux(a, tau, dt, w, sy, nullptr, o);
+#pragma unroll
+      for (int e = 0; e < P::A_NN; ++e) A.o_aux[segb[e] + (q - ph.mid_lo)] = o[e];
+    }
+  }
+}
+
+// ============================================================================================
+// compact Hessian: the multipliers are contracted with the integration block first,
+//   mu_i(node) = sum_r (I_hat[r, c] d/2) * lambda[row r of state i]      (a K-term product per node and state)
+// and every (row, col) position of a node gets ONE value (entries summed symbolically), so the output is
+// one run of L_m - 1 doubles per distinct position class instead of N*K^2 triplets per derivative entry.
+// ============================================================================================
+template <class P>
+__device__ __forceinline__ void interval_mu(const PkArgs& A, const PkPhase& ph, int K, const double* __restrict__ full,
+                                            double width, int ld, int c, double* mu) {
+  const int R = K - P::SCHEME;
+  const double* __restrict__ lam = A.lam + ph.g_off + ld;
+  for (int r = 0; r < R; ++r) {
+    const double a = full[r * K + c] * width * 0.5;
+#pragma unroll
+    for (int i = 0; i < P::NX; ++i) mu[i] += a * lam[i * ph.L_d + r];
+  }
+}
+
+// mu of node q (phase-local), summed over the one (LGR) or two (LGL interior mesh point) intervals holding it
+template <class P>
+__device__ __forceinline__ void node_mu(const PkArgs& A, const PkPhase& ph, int j, int c, double* mu) {
+#pragma unroll
+  for (int i = 0; i < P::NX; ++i) mu[i] = 0.0;
+  const int32_t* __restrict__ ivK = A.ib + ph.ivK_off;
+  const int32_t* __restrict__ ivF = A.ib + ph.ivfull_off;
+  const int32_t* __restrict__ ivL = A.ib + ph.ivld_off;
+  interval_mu<P>(A, ph, ivK[j], A.db + ivF[j], A.db[ph.width_off + j], ivL[j], c, mu);
+  if (P::SCHEME == 1 && c == 0 && j > 0)
+    interval_mu<P>(A, ph, ivK[j - 1], A.db + ivF[j - 1], A.db[ph.width_off + j - 1], ivL[j - 1], ivK[j - 1] - 1, mu);
+}
+
+template <class P>
+__device__ __forceinline__ void tile_hessc(const PkArgs& A, const PkTile& tl, double* __restrict__,
+                                           double* __restrict__, double* __restrict__, int lane) {
+  if (P::HC_NN == 0) return;
+  const PkPhase& ph = A.ph[P::INDEX];
+  const TileGeom g = tile_geom<P>(tl);
+  double s[PK_NS], dt, mt;
+  phase_scalars<P>(A, ph, s, dt, mt);
+  const PkSys sy{s, A.Ibuf, A.sigma, A.lam};
+  pk_cbase_t segb = const_bases(A.lb + ph.hcseg_off);
+  if (lane < g.nown) {
+    const int q = tl.q0 + lane;
+    if (q >= ph.mid_lo && q < ph.mid_hi) {
+      double a[P::NARG], tau, w, o[P::HC_NN + 1], lp[P::NC > 0 ? P::NC : 1], mu[P::NX];
+      load_node<P>(A, ph, s, dt, mt, q, a, tau, w);
+#pragma unroll
+      for (int j = 0; j < P::NC; ++j) lp[j] = A.lam[ph.path_off + j * ph.L_m + q];
+      const int jj = lane / g.stride;
+      node_mu<P>(A, ph, tl.j0 + jj, lane - jj * g.stride, mu);
+      P::mid_hessc(a, tau, dt, w, sy, lp, mu, nullptr, nullptr, o);
+#pragma unroll
+      for (int e = 0; e < P::HC_NN; ++e) A.o_hess[segb[e] + (q - ph.mid_lo)] = o[e];
+    }
+  }
+}
+
+// boundary node of the compact Hessian: also the contracted multipliers of the boundary columns
+template <class P>
+__device__ __forceinline__ void load_edge_c(const PkArgs& A, int back, double* s, double* a, double& tau, double& dt,
+                                            double& w, double* lp, double* mu, double* ltf, double* ltb) {
+  const PkPhase& ph = A.ph[P::INDEX];
+  double mt;
+  phase_scalars<P>(A, ph, s, dt, mt);
+  const int q = back ? ph.L_m - 1 : 0;
+  load_node<P>(A, ph, s, dt, mt, q, a, tau, w);
+#pragma unroll
+  for (int j = 0; j < P::NC; ++j) lp[j] = A.lam[ph.path_off + j * ph.L_m + q];
+  const int N = ph.n_int;
+  const int32_t* __restrict__ ivK = A.ib + ph.ivK_off;
+  const int32_t* __restrict__ ivL = A.ib + ph.ivld_off;
+  if (back && P::SCHEME == 1) node_mu<P>(A, ph, N - 1, ivK[N - 1] - 1, mu);
+  else node_mu<P>(A, ph, 0, 0, mu);
+  const int Rl = ivK[N - 1] - P::SCHEME;
+#pragma unroll
+  for (int i = 0; i < P::NX; ++i) {
+    const double* __restrict__ lam = A.lam + ph.g_off + i * ph.L_d;
+    ltf[i] = lam[0];                                 // T_f = (row 0, +1)
+    double sum = 0.0;
+    for (int r = 0; r < Rl; ++r) sum += lam[ivL[N - 1] + r];
+    ltb[i] = -sum;                                   // T_b = (rows of the last interval, -1)
+  }
+}
+
+// ---- boundary-node evaluation for the edge workgroup -----------------------------------------
+template <class P>
+__device__ __forceinline__ void load_edge(const PkArgs& A, int back, double* s, double* a, double& tau,
+                                          double& dt, double& w, double* lp) {
+  const PkPhase& ph = A.ph[P::INDEX];
+  double mt;
+  phase_scalars<P>(A, ph, s, dt, mt);
+  const int q = back ? ph.L_m - 1 : 0;
+  load_node<P>(A, ph, s, dt, mt, q, a, tau, w);
+  if (A.lam != nullptr) {
+#pragma unroll
+    for (int j = 0; j < P::NC; ++j) lp[j] = A.lam[ph.path_off + j * ph.L_m + q];
+  }
+}
+
+// item `threadIdx.x` and its multiplier are fetched before the boundary expressions are evaluated
+struct ItemPref {
+  PkItem m;
+  double lam;
+  bool ok;
+};
+__device__ __forceinline__ ItemPref prefetch_item(const PkArgs& A, const PkItem* __restrict__ items, int n_items) {
+  ItemPref ip;
+  ip.ok = (int)threadIdx.x < n_items;
+  ip.lam = 1.0;
+  if (ip.ok) {
+    ip.m = items[threadIdx.x];
+    if (ip.m.lam >= 0) ip.lam = A.lam[ip.m.lam];
+  }
+  return ip;
+}
+__device__ __forceinline__ void scatter_items(const PkArgs& A, const PkItem* __restrict__ items, int n_items,
+                                              const ItemPref& ip, const double* __restrict__ E,
+                                              double* __restrict__ out) {
+  if (ip.ok) out[ip.m.pos] = ip.m.coef * E[ip.m.eid] * ip.lam;
+  for (int it = threadIdx.x + PK_BLOCK; it < n_items; it += PK_BLOCK) {
+    const PkItem m = items[it];
+    double v = m.coef * E[m.eid];
+    if (m.lam >= 0) v *= A.lam[m.lam];
+    out[m.pos] = v;
+  }
+}
+
+// The four wave sums of a workgroup -> one partial per workgroup.  The host pads every phase's tile
+// list to a multiple of PK_WAVES_PER_BLOCK (empty tiles), so a workgroup never mixes phases.
+__device__ __forceinline__ void publish_block_partials(double* __restrict__ partial, const double* __restrict__ wred,
+                                                       int blk) {
+  __syncthreads();
+  if ((int)threadIdx.x < PK_NRED) {
+    double v = 0.0;
+#pragma unroll
+    for (int w = 0; w < PK_WAVES_PER_BLOCK; ++w) v += wred[w * PK_NRED + threadIdx.x];
+    partial[(size_t)blk * PK_NRED + threadIdx.x] = v;
+  }
+}
+
+// deterministic sum over the workgroups of phase k (fixed shape: strided thread sums, wave shuffle
+// tree, 4-way LDS combine)
+__device__ __forceinline__ double block_sum_partials(const PkArgs& A, const double* __restrict__ partial, int k,
+                                                     int r, double* red) {
+  const int blo = A.ph[k].tile_lo / PK_WAVES_PER_BLOCK, bhi = A.ph[k].tile_hi / PK_WAVES_PER_BLOCK;
+  double v = 0.0;
+  for (int b = blo + (int)threadIdx.x; b < bhi; b += PK_BLOCK) v += partial[(size_t)b * PK_NRED + r];
+  v = wave_sum(v);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+  __syncthreads();
+  double tot = 0.0;
+#pragma unroll
+  for (int w = 0; w < PK_WAVES_PER_BLOCK; ++w) tot += red[w];
+  return tot;
+}
+
+// ============================================================================================
+// kernels
+// ============================================================================================
+// EDGE = 1: workgroup 0 is the boundary/system workgroup (dispatched first: its serial chain is the
+// longest of the launch), tile workgroups follow.
+#define PK_TILE_PROLOGUE(EDGE)                                                        \
+  const int blk = pk::xcd_tile_block((int)blockIdx.x, (EDGE), (int)gridDim.x);        \
+  PK_TILE_PROLOGUE_AT()
+// PK_TILE_PROLOGUE_AT: the caller has defined `blk`, the workgroup's tile block (four consecutive tiles)
+#define PK_TILE_PROLOGUE_AT() PK_TILE_PROLOGUE_FROM(A.tile, A.n_tiles)
+// (TILES, NTILES: where the tile list comes from -- the PkArgs in the kernarg segment, or pk_cycle's preloaded copies)
+#define PK_TILE_PROLOGUE_FROM(TILES, NTILES)                                          \
+  extern __shared__ double pk_lds[];                                                  \
+  __shared__ double wint[PK_WAVES_PER_BLOCK * PK_NRED];                               \
+  __shared__ double wgrad[PK_WAVES_PER_BLOCK * PK_NRED];                              \
+  /* wave-uniform on purpose (readfirstlane): the tile record then comes through the scalar cache into */ \
+  /* SGPRs and everything derived from it is scalar arithmetic */                      \
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63; \
+  const int ti = blk * PK_WAVES_PER_BLOCK + wave;                                     \
+  PkTile tl;                                                                          \
+  if (ti < (NTILES)) {                                                                \
+    tl = load_tile((TILES) + ti);                                                     \
+    tl.pad = ti;                                                                      \
+  } else {                                                                            \
+    tl = load_tile((TILES) + ((NTILES) > 0 ? (NTILES)-1 : 0));                        \
+    tl.nj = 0;                                                                        \
+    tl.pad = -1;                                                                      \
+  }                                                                                   \
+  if (lane < PK_NRED) {                                                               \
+    wint[wave * PK_NRED + lane] = 0.0;                                                \
+    wgrad[wave * PK_NRED + lane] = 0.0;                                               \
+  }
+
+#define PK_IS_EDGE_BLOCK() (blockIdx.x == 0)
+
+// mode 0: Jacobian, 1: Hessian, 2: auxiliary buffer, 3: compact Hessian
+template <class Gen>
+__device__ __forceinline__ void edge_block(const PkArgs& A, int mode, bool with_g, const PkItem* __restrict__ items,
+                                           int n_items) {
+  extern __shared__ double pk_lds[];
+  const PkSys sy{A.x + A.l_s, A.Ibuf, A.sigma, A.lam};
+  if (A.flags & 2) return;   // secondary shard: boundary nodes / system level belong to the primary
+  if (with_g && threadIdx.x == PK_BLOCK - 1 && A.n_sys > 0) Gen::sys_constraints(sy, A.o_g);   // systembase.py:607-611
+  const ItemPref ip = prefetch_item(A, items, n_items);
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  for (int li = wave; li < Gen::NLISTS; li += PK_WAVES_PER_BLOCK)
+    if (lane == 0) {
+      if (mode == 1) Gen::edge_hess(li, A, sy, pk_lds);
+      else if (mode == 2) Gen::edge_aux(li, A, sy, pk_lds);
+      else if (mode == 3) Gen::edge_hessc(li, A, sy, pk_lds);
+      else Gen::edge_jac(li, A, sy, pk_lds);
+    }
+  __syncthreads();
+  scatter_items(A, items, n_items, ip, pk_lds, (mode == 1 || mode == 3) ? A.o_hess : (mode == 2 ? A.o_aux : A.o_jac));
+}
+
+
+template <class Gen>
+__device__ __forceinline__ void kernel_int(const PkArgs& A) {
+  PK_TILE_PROLOGUE(0);
+  Gen::tile_int(tl.phase, A, tl, pk_lds, wint + wave * PK_NRED, wgrad + wave * PK_NRED, lane);
+  publish_block_partials(A.partial, wint, blk);
+}
+
+template <class Gen>
+__device__ __forceinline__ void kernel_g(const PkArgs& A) {
+  if (PK_IS_EDGE_BLOCK()) {
+    if (threadIdx.x == 0 && A.n_sys > 0 && !(A.flags & 2)) {
+      const PkSys sy{A.x + A.l_s, A.Ibuf, A.sigma, A.lam};
+      Gen::sys_constraints(sy, A.o_g);
+    }
+    return;
+  }
+  PK_TILE_PROLOGUE(1);
+  Gen::tile_g(tl.phase, A, tl, pk_lds + wave * Gen::LDS_G, wint, wgrad, lane);
+}
+
+template <class Gen>
+__device__ __forceinline__ void kernel_grad(const PkArgs& A) {
+  PK_TILE_PROLOGUE(0);
+  Gen::tile_grad(tl.phase, A, tl, pk_lds, wint + wave * PK_NRED, wgrad + wave * PK_NRED, lane);
+  publish_block_partials(A.partial2, wgrad, blk);
+}
+
+template <class Gen>
+__device__ __forceinline__ void kernel_jac(const PkArgs& A) {
+  if (PK_IS_EDGE_BLOCK()) return edge_block<Gen>(A, 0, false, A.items, A.n_items);
+  PK_TILE_PROLOGUE(1);
+  Gen::tile_jac(tl.phase, A, tl, pk_lds + wave * Gen::LDS_J, wint, wgrad, lane);
+}
+
+template <class Gen>
+__device__ __forceinline__ void fin_body(const PkArgs& A);
+template <class Gen>
+__device__ __forceinline__ void fin_handoff(const PkArgs& A);
+
+template <class Gen>
+__device__ __forceinline__ void kernel_hess(const PkArgs& A) {
+  if (PK_IS_EDGE_BLOCK()) return edge_block<Gen>(A, 1, false, A.items, A.n_items);
+  if (blockIdx.x == 1) {
+    // cycle mode: the reductions of the preceding pk_xall launch ride along in a workgroup of their own
+    if (A.flags & (8 | 16)) fin_body<Gen>(A);
+    return;
+  }
+  PK_TILE_PROLOGUE(2);
+  Gen::tile_hess(tl.phase, A, tl, pk_lds + wave * Gen::LDS_H, wint, wgrad, lane);
+}
+
+template <class Gen>
+__device__ __forceinline__ void kernel_hessc(const PkArgs& A) {
+  if (PK_IS_EDGE_BLOCK()) return edge_block<Gen>(A, 3, false, A.items, A.n_items);
+  PK_TILE_PROLOGUE(1);
+  Gen::tile_hessc(tl.phase, A, tl, pk_lds, wint, wgrad, lane);
+}
+
+template <class Gen>
+__device__ __forceinline__ void kernel_aux(const PkArgs& A) {
+  if (PK_IS_EDGE_BLOCK()) return edge_block<Gen>(A, 2, false, A.items, A.n_items);
+  PK_TILE_PROLOGUE(1);
+  Gen::tile_aux(tl.phase, A, tl, pk_lds, wint, wgrad, lane);
+}
+
+
+// ---- mesh error estimation (reference: phasebase.py:1339-1372  _error_estimation_data_continuous) -----
+// One wavefront per mesh interval.  The interval's K (+1) state values and K control values are
+// staged in LDS, interpolated to the K + 1 nodes of the augmented rule (lane = augmented node), the
+// dynamics are evaluated there, and the two sides of the integral-form collocation equation on the
+// augmented rule are written out:  T_aug x  and  dt (I_aug d/2) f.  The host compares them per
+// interval (np.allclose semantics) and runs the hp-refinement logic (pockit_amd/refine.py).
+// LDS per wave: (2 NX + NU) x 64 doubles, private to the wave (no workgroup barrier between the three steps).
+template <class P>
+__device__ __forceinline__ void interval_err(const PkArgs& A, const PkErrIv& iv, bool valid,
+                                             double* __restrict__ lds, int lane) {
+  const PkPhase& ph = A.ph[P::INDEX];
+  double s[PK_NS], dt, mt;
+  phase_scalars<P>(A, ph, s, dt, mt);
+  const int K = iv.K;
+  const int ncx = K + 1 - P::SCHEME, na = K + 1, nr = K + 1 - P::SCHEME;
+  const double* __restrict__ Vx = A.errdb + iv.tab_off;
+  const double* __restrict__ Vu = Vx + na * ncx;
+  const double* __restrict__ Tm = Vu + na * K;
+  const double* __restrict__ Im = Tm + nr * ncx;
+  const double* __restrict__ xp = A.x + ph.x_off;
+  const double* __restrict__ up = xp + P::NX * ph.state_len;
+  const int back_slot = P::SCHEME ? ph.L_m - 1 : ph.L_m;
+  double* __restrict__ xs = lds;
+  double* __restrict__ us = lds + P::NX * PK_WAVE;
+  double* __restrict__ fs = lds + (P::NX + P::NU) * PK_WAVE;
+  if (valid && lane < ncx) {
+    const int slot = iv.lm + lane;
+#pragma unroll
+    for (int i = 0; i < P::NX; ++i) {
+      double v = xp[i * ph.state_len + slot];
+      if (slot == 0) v = P::front_value(i, v, s);
+      if (slot == back_slot) v = P::back_value(i, v, s);
+      xs[i * PK_WAVE + lane] = v;
+    }
+  }
+  if (valid && lane < K) {
+#pragma unroll
+    for (int i = 0; i < P::NU; ++i) us[i * PK_WAVE + lane] = up[i * ph.L_m + iv.lm + lane];
+  }
+  wave_lds_sync();       // (a wave stages for itself only)
+  if (valid && lane < na) {
+    double a[P::NARG], o[P::G_NOUT];
+#pragma unroll
+    for (int i = 0; i < P::NX; ++i) a[i] = 0.0;
+#pragma unroll
+    for (int i = 0; i < P::NU; ++i) a[P::NX + i] = 0.0;
+    for (int c = 0; c < ncx; ++c) {
+      const double v = Vx[lane * ncx + c];
+#pragma unroll
+      for (int i = 0; i < P::NX; ++i) a[i] += v * xs[i * PK_WAVE + c];
+    }
+    for (int c = 0; c < K; ++c) {
+      const double v = Vu[lane * K + c];
+#pragma unroll
+      for (int i = 0; i < P::NU; ++i) a[P::NX + i] += v * us[i * PK_WAVE + c];
+    }
+    const double tau = A.errdb[iv.tau_off + lane];
+    a[P::NX + P::NU] = (tau - 0.5) * dt + mt;
+#pragma unroll
+    for (int i = 0; i < P::NS; ++i) a[P::NX + P::NU + 1 + i] = s[i];
+    P::mid_g(a, o);
+#pragma unroll
+    for (int i = 0; i < P::NX; ++i) fs[i * PK_WAVE + lane] = o[i];
+  }
+  wave_lds_sync();       // (a wave stages for itself only)
+  if (valid && lane < nr) {
+    double tx[P::NX], itf[P::NX];
+#pragma unroll
+    for (int i = 0; i < P::NX; ++i) tx[i] = itf[i] = 0.0;
+    for (int c = 0; c < ncx; ++c) {
+      const double v = Tm[lane * ncx + c];
+#pragma unroll
+      for (int i = 0; i < P::NX; ++i) tx[i] += v * xs[i * PK_WAVE + c];
+    }
+    for (int c = 0; c < na; ++c) {
+      const double v = Im[lane * na + c] * iv.width * 0.5;
+#pragma unroll
+      for (int i = 0; i < P::NX; ++i) itf[i] += v * fs[i * PK_WAVE + c];
+    }
+#pragma unroll
+    for (int i = 0; i < P::NX; ++i) {
+      const int64_t pos = iv.out_off + (int64_t)i * iv.rows + iv.row0 + lane;
+      put(&A.o_errT[pos], tx[i]);
+      put(&A.o_errI[pos], itf[i] * dt);
+    }
+  }
+}
+
+template <class Gen>
+__device__ __forceinline__ void kernel_err(const PkArgs& A) {
+  extern __shared__ double pk_lds[];
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+  const int g = (int)blockIdx.x * PK_WAVES_PER_BLOCK + wave;
+  const bool valid = g < A.n_erriv;
+  // a workgroup never mixes phases (the host pads every phase to a multiple of 4 intervals with K = 0 records)
+  const PkErrIv iv = A.erriv[valid ? g : (A.n_erriv > 0 ? A.n_erriv - 1 : 0)];
+  Gen::interval_err(iv.phase, A, iv, valid && iv.K > 0, pk_lds + wave * Gen::LDS_E, lane);
+}
+
+// Triplet list -> CSR values on device (hand J / H to a GPU linear solver without a
+// PCIe round trip).  The (row, col) sort, the duplicate runs and the permutation are computed once per mesh
+// on the host (pockit_amd/csr.py); duplicates are summed in triplet order (deterministic).
+__device__ __forceinline__ void kernel_csr(const PkArgs& A) {
+  const int stride = (int)gridDim.x * PK_BLOCK;
+  for (int p = (int)blockIdx.x * PK_BLOCK + (int)threadIdx.x; p < A.n_csr; p += stride) {
+    if (A.csr_seg == nullptr) {
+      A.csr_out[p] = A.csr_in[A.csr_perm[p]];
+      continue;
+    }
+    const int lo = A.csr_seg[p], hi = A.csr_seg[p + 1];
+    double acc = 0.0;
+    for (int q = lo; q < hi; ++q) acc += A.csr_in[A.csr_perm[q]];
+    A.csr_out[p] = acc;
+  }
+}
+
+// One workgroup per outer-product block (generic, table driven; O(n^2) outputs exist only for
+// objectives / system constraints that are nonlinear in the integrals -- small problems in practice).
+__device__ __forceinline__ void kernel_outer(const PkArgs& A) {
+  __shared__ double red[PK_WAVES_PER_BLOCK];
+  __shared__ double sums[2];
+  for (int b = blockIdx.x; b < A.n_outer; b += gridDim.x) {
+    const PkOuter d = A.outer[b];
+    const double* __restrict__ GA = A.o_aux + d.offA;
+    const double* __restrict__ GB = A.o_aux + d.offB;
+    const double m = A.o_aux[d.offM];
+    double* __restrict__ out = A.o_hess + d.pos;
+    if (!(d.flags & 1)) {
+      const int tot = d.lenA * d.lenB;
+      for (int t = threadIdx.x; t < tot; t += PK_BLOCK) {
+        const int i = t / d.lenB, j = t - i * d.lenB;
+        out[t] = GA[i] * GB[j] * m;
+      }
+      continue;
+    }
+    for (int which = 0; which < 2; ++which) {          // collapsed runs: deterministic block sums
+      const bool need = which == 0 ? (d.flags & 2) : (d.flags & 4);
+      if (!need) continue;                              // (uniform across the workgroup)
+      const double* __restrict__ G = which == 0 ? GA : GB;
+      const int len = which == 0 ? d.lenA : d.lenB;
+      double v = 0.0;
+      for (int t = threadIdx.x; t < len; t += PK_BLOCK) v += G[t];
+      v = wave_sum(v);
+      __syncthreads();
+      if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+      __syncthreads();
+      if (threadIdx.x == 0) {
+        double tot = 0.0;
+#pragma unroll
+        for (int w = 0; w < PK_WAVES_PER_BLOCK; ++w) tot += red[w];
+        sums[which] = tot;
+      }
+    }
+    __syncthreads();
+    const int n = (d.flags & 2) ? 1 : d.lenA;
+    const int ntri = n * (n + 1) / 2;
+    for (int t = threadIdx.x; t < ntri; t += PK_BLOCK) {
+      int i = (int)((sqrt(8.0 * (double)t + 1.0) - 1.0) * 0.5);
+      while ((i + 1) * (i + 2) / 2 <= t) ++i;
+      while (i * (i + 1) / 2 > t) --i;
+      const int j = t - i * (i + 1) / 2;
+      const double ai = (d.flags & 2) ? sums[0] : GA[i], aj = (d.flags & 2) ? sums[0] : GA[j];
+      const double bi = (d.flags & 4) ? sums[1] : GB[i], bj = (d.flags & 4) ? sums[1] : GB[j];
+      out[t] = ai * bj * m;
+      if (d.flags & 8) out[ntri + t] = bi * aj * m;
+    }
+    __syncthreads();
+  }
+}
+
+template <class Gen>
+__device__ __forceinline__ void kernel_xall(const PkArgs& A) {
+  if (PK_DIAG(1024)) return;                                   // diagnostic switches (POCKIT_AMD_DEBUG_FLAGS)
+  if (PK_IS_EDGE_BLOCK() && PK_DIAG(2048)) return;
+  if (PK_IS_EDGE_BLOCK()) return edge_block<Gen>(A, 0, true, A.items, A.n_items);
+  if (A.flags & 32) {   // split launch: workgroups 2b (Jacobian) and 2b + 1 (values) share tile block b
+    const int slot = pk::xcd_tile_block((int)blockIdx.x, 1, (int)gridDim.x);
+    const int blk = slot >> 1;
+    PK_TILE_PROLOGUE_AT();
+    if (!(slot & 1)) {
+      Gen::tile_xall2(tl.phase, A, tl, pk_lds + wave * Gen::LDS_X, wint + wave * PK_NRED, wgrad + wave * PK_NRED, lane, -1);
+      return;
+    }
+    Gen::tile_xall1(tl.phase, A, tl, pk_lds + wave * Gen::LDS_X, wint + wave * PK_NRED, wgrad + wave * PK_NRED, lane, -1);
+    publish_block_partials(A.partial, wint, blk);
+    publish_block_partials(A.partial2, wgrad, blk);
+    return;
+  }
+  PK_TILE_PROLOGUE(1);
+  Gen::tile_xall(tl.phase, A, tl, pk_lds + wave * Gen::LDS_X, wint + wave * PK_NRED, wgrad + wave * PK_NRED, lane, -1);
+  publish_block_partials(A.partial, wint, blk);
+  publish_block_partials(A.partial2, wgrad, blk);
+}
+
+// ============================================================================================
+// pk_cycle: the whole NLP-callback cycle (f, grad f, g, J, H on one x, lambda, sigma) in ONE launch.
+// A 12k-node cycle moves 15 MB (2 us at HBM peak) while every launch costs a fixed 2-5 us and the kernels of a
+// stream do not overlap, so the cycle is the union of pk_xall's and pk_hess's workgroups instead of their sequence:
+//   workgroup 0  boundary nodes / system level of g and J          (edge_block mode 0)
+//   workgroup 1  boundary nodes / system level of H                (edge_block mode 1)
+//   workgroup 2  the sums over all nodes (integrals, f, shared gradient slots), fed by the tile workgroups of
+//                this same launch through the hand-off slots (fin_body<HANDOFF>)
+//   the rest     tile workgroups of four waves = four consecutive tiles, ONE role per workgroup; the workgroups of a
+//                tile block follow each other ([Jacobian, values, Hessian], or [x-part, Hessian] when the x-part is
+//                not split) so that every XCD gets a contiguous range of tiles of every output array
+// Every wave runs exactly what it runs in pk_xall / pk_hess, they just run at the same time.
+// ============================================================================================
+// pre: the four values a tile wave needs before it can ask for its tile record (tile list, its length, the launch flags,
+// the grid size), passed as leading scalar kernel arguments: with kernarg preloading (gfx940+,
+// -amdgpu-kernarg-preload-count) they arrive in SGPRs with the wave, so the record load is not queued behind a first
+// round trip to the kernarg segment.
+template <class Gen>
+__device__ __forceinline__ void kernel_cycle(const PkTile* pre_tile, int pre_n_tiles, int pre_flags, int pre_grid,
+                                             const PkArgs& A) {
+  if (blockIdx.x < 2 && PK_DIAG(2048)) return;     // diagnostic switches (POCKIT_AMD_DEBUG_FLAGS): no boundary work,
+  if (blockIdx.x == 2 && PK_DIAG(65536)) return;   // no finalize workgroup (the hand-off slots then stay filled)
+  if (blockIdx.x < 3) {
+    const int rec = A.n_tiles * 3 + (int)blockIdx.x;
+    (void)rec;
+    PK_MARK_AT(rec, 0);
+#ifdef PK_TRACE
+    if (A.trace != nullptr && threadIdx.x == 0) A.trace[(size_t)rec * 16 + 14] = __builtin_readcyclecounter();
+#endif
+    if (blockIdx.x == 0) edge_block<Gen>(A, 0, true, A.items, A.n_items);
+    else if (blockIdx.x == 1) edge_block<Gen>(A, 1, false, A.items2, A.n_items2);
+    else fin_handoff<Gen>(A);
+#ifdef PK_TRACE
+    __builtin_amdgcn_s_waitcnt(0);
+#endif
+    PK_MARK_AT(rec, 9);
+#ifdef PK_TRACE
+    if (A.trace != nullptr && threadIdx.x == 0) A.trace[(size_t)rec * 16 + 15] = __builtin_readcyclecounter();
+#endif
+    return;
+  }
+  const int slot = pk::xcd_tile_block((int)blockIdx.x, 3, pre_grid);
+  const bool split = (pre_flags & 32) != 0;
+  const int blk = split ? slot / 3 : slot >> 1;       // the tile block; its workgroups follow each other in dispatch order
+  const int sub = slot - blk * (split ? 3 : 2);       // split: 0 Jacobian, 1 values, 2 Hessian; else 0 x-part, 1 Hessian
+  PK_TILE_PROLOGUE_FROM(pre_tile, pre_n_tiles);
+  if (sub == (split ? 2 : 1))
+    Gen::tile_hess(tl.phase, A, tl, pk_lds + wave * Gen::LDS_H, wint, wgrad, lane);
+  else if (!split)
+    Gen::tile_xall(tl.phase, A, tl, pk_lds + wave * Gen::LDS_X, wint + wave * PK_NRED, wgrad + wave * PK_NRED, lane, blk);
+  else if (sub == 0)
+    Gen::tile_xall2(tl.phase, A, tl, pk_lds + wave * Gen::LDS_X, wint + wave * PK_NRED, wgrad + wave * PK_NRED, lane, -1);
+  else
+    Gen::tile_xall1(tl.phase, A, tl, pk_lds + wave * Gen::LDS_X, wint + wave * PK_NRED, wgrad + wave * PK_NRED, lane, blk);
+}
+
+// The reductions over all workgroups, by ONE workgroup (all 256 threads must call it).
+// flags bit 3: I_k = dt * sum of partials -> Ibuf; bit 0: f = F_o(I, s) -> o_f (systembase.py:592-605);
+// bit 4: the gradient slots shared by all nodes (systembase.py:654-657).
+template <class Gen>
+__device__ __forceinline__ void fin_body(const PkArgs& A) {
+  __shared__ double red[PK_WAVES_PER_BLOCK];
+  __shared__ double tot[PK_NPHASE_DIM * PK_NRED];
+  __shared__ double dts[PK_NPHASE_DIM];
+  if ((int)threadIdx.x < PK_NPHASE) dts[threadIdx.x] = Gen::phase_dt(threadIdx.x, A);   // one phase per thread
+  if (A.flags & 16)                                                                       // dead / shared slots start at 0
+    for (int z = threadIdx.x; z < A.n_gz; z += PK_BLOCK) A.o_grad[A.ib[A.gz_off + z]] = 0.0;
+  if (A.flags & 8) {
+    for (int n = 0; n < Gen::N_INT; ++n) {
+      const int k = Gen::int_phase(n);
+      const double sum = block_sum_partials(A, A.partial, k, Gen::int_slot(n), red);
+      if (threadIdx.x == 0) A.Ibuf[Gen::int_global(n)] = sum * dts[k];
+    }
+  }
+  if (A.flags & 16) {
+    for (int k = 0; k < PK_NPHASE; ++k)
+      for (int r = 0; r < Gen::gr_nr(k); ++r) {
+        const double v = block_sum_partials(A, A.partial2, k, r, red);
+        if (threadIdx.x == 0) tot[k * PK_NRED + r] = v;
+      }
+  }
+  __syncthreads();
+  if (threadIdx.x != 0) return;
+  const PkSys sy{A.x + A.l_s, A.Ibuf, A.sigma, A.lam};
+  if (A.flags & 1) A.o_f[0] = Gen::sys_objective(sy);
+  if (A.flags & 16) {
+    for (int k = 0; k < PK_NPHASE; ++k)
+      for (int r = 0; r < Gen::gr_nr(k); ++r) A.o_grad[A.ib[A.ph[k].red_off + r]] += tot[k * PK_NRED + r];
+    if (!(A.flags & 2)) {
+      double gs[PK_NS];
+      Gen::sys_grad_static(sy, gs);
+      for (int i = 0; i < A.n_s; ++i) A.o_grad[A.l_s + i] += gs[i];
+    }
+  }
+}
+
+// pk_cycle's finalize workgroup: the same sums, in the same fixed shape (thread t adds the partials of workgroups
+// t, t + 256, ... in ascending order, DPP wave tree, waves 0..3 in order) and the same order of additions per
+// gradient slot as fin_body -- the results are bit-identical -- but fed through the hand-off slots of the launch it
+// runs in, and arranged so that its own serial chain is ONE memory round trip after the last partial sum arrives:
+// everything independent of the sums (phase durations, slot indices) is fetched first, the slots of ALL rows are
+// polled together (a `row` = one integrand or one shared gradient slot of one phase; the rows are compile-time
+// constants of the model), sums and slot values are combined in LDS and every output is stored once (no
+// read-modify-write of global memory).
+template <class Gen>
+__device__ __forceinline__ void fin_handoff(const PkArgs& A) {
+  constexpr int NR = Gen::N_ROWS > 0 ? Gen::N_ROWS : 1;
+  static_assert(NR <= PK_BLOCK, "one thread per row");
+  __shared__ double red[NR * PK_WAVES_PER_BLOCK];
+  __shared__ double tot[NR];
+  __shared__ double Ish[PK_NI];
+  __shared__ double gsh[PK_NS];
+  __shared__ double dts[PK_NPHASE_DIM];
+  __shared__ double ssh[PK_NS];                     // static parameters, fetched before the wait (F_o(I, s) reads them)
+  __shared__ int ridx[NR];
+  const int t = threadIdx.x, wave = t >> 6;
+  if (t < PK_NPHASE) dts[t] = Gen::phase_dt(t, A);
+  for (int i = t; i < A.n_s && i < PK_NS; i += PK_BLOCK) ssh[i] = A.x[A.l_s + i];
+  const int gz0 = t < A.n_gz ? A.ib[A.gz_off + t] : -1;
+#pragma unroll
+  for (int row = 0; row < Gen::N_ROWS; ++row)
+    if (t == row) ridx[row] = Gen::row_arr(row) ? A.ib[A.ph[Gen::row_phase(row)].red_off + Gen::row_slot(row)] : -1;
+  constexpr int per = PK_WAVES_PER_BLOCK;              // a partial sum per tile block (four tiles)
+  double acc[NR];
+  int most = 0;
+#pragma unroll
+  for (int row = 0; row < Gen::N_ROWS; ++row) {
+    acc[row] = 0.0;
+    most = max(most, (A.ph[Gen::row_phase(row)].tile_hi - A.ph[Gen::row_phase(row)].tile_lo) / per);
+  }
+  PK_MARK_AT(A.n_tiles * 3 + 2, 1);
+  for (int j = t; j < most + t; j += PK_BLOCK) {        // (uniform trip count; j - t = 0, 256, ...)
+    unsigned long long bits[NR];
+    unsigned long long* slot[NR];
+#pragma unroll
+    for (int row = 0; row < Gen::N_ROWS; ++row) {
+      const PkPhase& ph = A.ph[Gen::row_phase(row)];
+      const int b = ph.tile_lo / per + j;
+      slot[row] = b < ph.tile_hi / per ? (Gen::row_arr(row) ? A.cpart2 : A.cpart) + (size_t)b * PK_NRED + Gen::row_slot(row)
+                                       : nullptr;
+    }
+    // one poll round = the slots of ALL rows in flight together (one memory round trip), repeated until none is empty
+    for (int tries = 0; tries < PK_POLL_LIMIT; ++tries) {
+      bool empty = false;
+#pragma unroll
+      for (int row = 0; row < Gen::N_ROWS; ++row) bits[row] = slot[row] ? handoff_peek(slot[row]) : 0ull;
+#pragma unroll
+      for (int row = 0; row < Gen::N_ROWS; ++row) empty |= bits[row] == PK_EMPTY;
+      if (!empty) break;
+      __builtin_amdgcn_s_sleep(PK_POLL_SLEEP);
+    }
+#pragma unroll
+    for (int row = 0; row < Gen::N_ROWS; ++row)
+      if (slot[row]) {
+        handoff_clear(slot[row]);
+        acc[row] += __longlong_as_double((long long)bits[row]);      // (PK_EMPTY after a timed-out poll: a NaN)
+      }
+  }
+  PK_MARK_AT(A.n_tiles * 3 + 2, 2);
+#pragma unroll
+  for (int row = 0; row < Gen::N_ROWS; ++row) {
+    const double v = wave_sum(acc[row]);
+    if ((t & 63) == 0) red[row * PK_WAVES_PER_BLOCK + wave] = v;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int row = 0; row < Gen::N_ROWS; ++row)
+    if (t == row) {
+      double v = 0.0;
+#pragma unroll
+      for (int w = 0; w < PK_WAVES_PER_BLOCK; ++w) v += red[row * PK_WAVES_PER_BLOCK + w];
+      tot[row] = v;
+      if (!Gen::row_arr(row)) {                           // integrand row n = row: I_k = dt * sum   (phasebase.py:997-1006)
+        const double Ik = v * dts[Gen::row_phase(row)];
+        Ish[Gen::int_global(row)] = Ik;
+        A.Ibuf[Gen::int_global(row)] = Ik;
+      }
+    }
+  __syncthreads();
+  const PkSys sy{ssh, Ish, A.sigma, A.lam};
+  if (t == 0) A.o_f[0] = Gen::sys_objective(sy);          // systembase.py:592-605
+  if (t == 64) {
+#pragma unroll
+    for (int i = 0; i < PK_NS; ++i) gsh[i] = 0.0;
+    if (!(A.flags & 2)) Gen::sys_grad_static(sy, gsh);      // (sharded: the primary shard adds the direct dependence)
+  }
+  __syncthreads();
+  // gradient slots no tile writes (end slots, t0 / tf, static parameters): 0 + the sums of the rows that land on the
+  // slot, phase by phase, + the objective's direct dependence on a static parameter   (systembase.py:654-657)
+  for (int z = t; z < A.n_gz; z += PK_BLOCK) {
+    const int idx = z == t ? gz0 : A.ib[A.gz_off + z];
+    double v = 0.0;
+#pragma unroll
+    for (int row = 0; row < Gen::N_ROWS; ++row)
+      if (Gen::row_arr(row) && ridx[row] == idx) v += tot[row];
+    if (idx >= A.l_s && idx < A.l_s + A.n_s) v += gsh[idx - A.l_s];
+    A.o_grad[idx] = v;
+  }
+}
+
+template <class Gen>
+__device__ __forceinline__ void kernel_fin(const PkArgs& A) {
+  fin_body<Gen>(A);
+}
+
+}  // namespace pk
+
+#define PK_DEFINE_KERNELS(GEN)                                                                         \
+  extern "C" __global__ __launch_bounds__(PK_BLOCK) void pk_int(PkArgs A) { pk::kernel_int<GEN>(A); }   \
+  extern "C" __global__ __launch_bounds__(PK_BLOCK) void pk_fin(PkArgs A) { pk::kernel_fin<GEN>(A); }   \
+  extern "C" __global__ __launch_bounds__(PK_BLOCK) void pk_g(PkArgs A) { pk::kernel_g<GEN>(A); }       \
+  extern "C" __global__ __launch_bounds__(PK_BLOCK) void pk_grad(PkArgs A) { pk::kernel_grad<GEN>(A); } \
+  extern "C" __global__ __launch_bounds__(PK_BLOCK) void pk_jac(PkArgs A) { pk::kernel_jac<GEN>(A); }   \
+  extern "C" __global__ __launch_bounds__(PK_BLOCK) void pk_hess(PkArgs A) { pk::kernel_hess<GEN>(A); } \
+  extern "C" __global__ __launch_bounds__(PK_BLOCK) void pk_xall(PkArgs A) { pk::kernel_xall<GEN>(A); } \
+  extern "C" __global__ __launch_bounds__(PK_BLOCK) void pk_aux(PkArgs A) { pk::kernel_aux<GEN>(A); }   \
+  extern "C" __global__ __launch_bounds__(PK_BLOCK) void pk_outer(PkArgs A) { pk::kernel_outer(A); }     \
+  extern "C" __global__ __launch_bounds__(PK_BLOCK) void pk_hessc(PkArgs A) { pk::kernel_hessc<GEN>(A); } \
+  extern "C" __global__ __launch_bounds__(PK_BLOCK) void pk_err(PkArgs A) { pk::kernel_err<GEN>(A); }     \
+  extern "C" __global__ __launch_bounds__(PK_BLOCK) void pk_csr(PkArgs A) { pk::kernel_csr(A); }             \
+  extern "C" __global__ __launch_bounds__(PK_BLOCK) void pk_cycle(const PkTile* pre_tile, int32_t pre_n_tiles,  \
+                                                                  int32_t pre_flags, int32_t pre_grid, PkArgs A) { \
+    pk::kernel_cycle<GEN>(pre_tile, pre_n_tiles, pre_flags, pre_grid, A);                                        \
+  }

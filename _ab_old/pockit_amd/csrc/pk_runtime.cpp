@@ -1,0 +1,1103 @@
+// pk_runtime.cpp -- host runtime behind the C ABI of include/pockit_hip.h.
+//
+// Owns: the HIP context objects of one GPU (stream, loaded code object, kernel handles), the
+// device copies of the per-(model, mesh) tables, and device work buffers (x, lambda, outputs,
+// integrals, per-tile partial sums).  It launches the kernels of the generated code object
+// (pockit_amd/codegen.py + csrc/pk_kernels.hip.h) in the order each NLP callback needs:
+//
+//   eval_f     pk_int, pk_fin(integrals, f)
+//   eval_grad  [pk_int, pk_fin(integrals)]?  pk_grad, pk_fin(gradient slots)
+//   eval_g     [pk_int, pk_fin(integrals)]?  pk_g
+//   eval_jac   [pk_int, pk_fin(integrals)]?  pk_jac
+//   eval_hess  [pk_int, pk_fin(integrals)]?  pk_hess
+//   cycle      pk_cycle: ONE launch holding pk_xall's workgroups (f partials, grad f, g, J from one node
+//              evaluation), pk_hess's workgroups and a finalize workgroup that receives the partial sums of
+//              the same launch through hand-off slots (integrals, f, shared gradient slots);
+//              pk_set_cycle_mode(0) selects the older two-launch form pk_xall, pk_hess(+ reductions)
+// ("?" = only when a system-level function is nonlinear in the integrals, pk_model_desc.prepass_*).
+//
+// There is no CPU evaluation path: every entry point fails with an error code when no device /
+// code object / problem is present.
+#include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
+
+#include <climits>
+#include <cstddef>
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/pockit_hip.h"
+#include "pk_abi.h"
+
+namespace {
+
+enum { K_INT = 0, K_FIN, K_G, K_GRAD, K_JAC, K_HESS, K_XALL, K_AUX, K_OUTER, K_HESSC, K_ERR, K_CSR, K_CYCLE, K_COUNT };
+const char* const kKernelNames[K_COUNT] = {"pk_int", "pk_fin", "pk_g", "pk_grad", "pk_jac", "pk_hess", "pk_xall",
+                                           "pk_aux", "pk_outer", "pk_hessc", "pk_err", "pk_csr", "pk_cycle"};
+enum { F_WRITE_F = 1, F_SECONDARY = 2, F_FIN_INT = 8, F_FIN_GRAD = 16, F_SPLIT = 32 };
+
+thread_local std::string g_create_error;
+
+struct EventPair {
+  hipEvent_t a, b;
+};
+
+}  // namespace
+
+struct pk_ctx {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  hipModule_t module = nullptr;
+  hipFunction_t fn[K_COUNT] = {};
+  bool have_model = false, have_problem = false;
+  int shard_flags = 0;          // OR-ed into PkArgs.flags (bit 1: secondary shard)
+  bool external_prepass = false; // sharded mode: the caller all-reduces the integrals itself
+  double* ext_I = nullptr;      // caller-owned integral buffer (sharded mode)
+  bool split_xall = false;      // pk_xall with two waves per tile (values / Jacobian), see pk_set_problem
+  int cycle_mode = 1;           // 1: single-launch pk_cycle; 0: pk_xall + pk_hess (pk_set_cycle_mode)
+  unsigned long long *d_cpart = nullptr, *d_cpart2 = nullptr;   // pk_cycle's hand-off slots (PK_EMPTY between launches)
+  unsigned profile_mask = 0;
+  unsigned profile_period = 1;  // time every n-th launch of a selected kernel
+  unsigned profile_seen[16] = {};
+  int debug_flags = 0;          // diagnostic kernel switches (POCKIT_AMD_DEBUG_FLAGS), never set in production
+  pk_model_desc md{};
+  // problem
+  int32_t n = 0, m = 0, n_sys = 0, n_s = 0, l_s = 0, n_phase = 0, n_tiles = 0;
+  int64_t nnz_J = 0, nnz_H = 0;
+  int32_t n_items_jac = 0, n_items_hess = 0, n_items_aux = 0, n_outer = 0, n_aux = 0, gz_off = 0, n_gz = 0;
+  int32_t n_items_hessc = 0;
+  int64_t nnz_Hc = 0;
+  void *d_phases = nullptr, *d_tiles = nullptr, *d_kinds = nullptr, *d_items_jac = nullptr, *d_items_hess = nullptr,
+       *d_items_aux = nullptr, *d_outer = nullptr, *d_items_hessc = nullptr;
+  double *d_aux = nullptr, *d_Hc = nullptr;
+  // cached hipGraph of the fused callback cycle (pk_set_cycle_graph)
+  bool use_graph = false;
+  hipGraphExec_t cyc_exec = nullptr;
+  struct CycleKey {
+    const void *x, *lam, *f, *grad, *g, *jac, *hess;
+    double sigma;
+    hipStream_t st;
+    bool operator==(const CycleKey& o) const {
+      return x == o.x && lam == o.lam && f == o.f && grad == o.grad && g == o.g && jac == o.jac && hess == o.hess &&
+             sigma == o.sigma && st == o.st;
+    }
+  } cyc_key{};
+  unsigned long long* d_trace = nullptr;   // developer tracing buffer, [n_tiles][16]
+  // triplet -> CSR maps (pk_set_csr_map): [0] Jacobian, [1] Hessian of the Lagrangian (lower triangle)
+  struct CsrMap {
+    int32_t *d_seg = nullptr, *d_perm = nullptr;
+    double* d_vals = nullptr;
+    int64_t n_unique = 0, n_triplets = 0;
+  } csr[2];
+  // mesh error estimation (pk_set_mesh_error_tables)
+  void* d_erriv = nullptr;
+  double *d_errdb = nullptr, *d_errT = nullptr, *d_errI = nullptr;
+  int32_t n_erriv = 0;
+  int64_t n_err_out = 0;
+  int32_t* d_ib = nullptr;
+  double* d_db = nullptr;
+  int64_t* d_lb = nullptr;
+  // work buffers
+  double *d_x = nullptr, *d_lam = nullptr, *d_f = nullptr, *d_grad = nullptr, *d_g = nullptr, *d_J = nullptr,
+         *d_H = nullptr, *d_I = nullptr, *d_partial = nullptr, *d_partial2 = nullptr;
+  std::vector<PkPhase> h_phases;
+  std::vector<EventPair> free_events;
+  std::vector<int32_t> jac_row, jac_col, hess_row, hess_col;
+  // pinned host staging of the host shim: x and lambda are double-buffered (the upload of iterate k + 1 does not wait
+  // for anything of iterate k), results land in h_out (f, grad, g, J, H) or in caller-supplied pinned targets
+  double *h_xs[2] = {nullptr, nullptr}, *h_lams[2] = {nullptr, nullptr};
+  hipEvent_t ev_xs[2] = {nullptr, nullptr}, ev_lams[2] = {nullptr, nullptr};   // upload k of the buffer has left it
+  int xbuf = 0, lambuf = 0;
+  double* h_x = nullptr;                   // the staging buffer holding the x of the last pk_prepare_x (pk_same_x)
+  bool x_valid = false;
+  double* h_out[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+  double* target[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};   // pk_set_result_targets (NULL: h_out[k])
+  double* landed[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};   // where result k of the current iterate went
+  hipEvent_t ev_out[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+  bool enq[5] = {false, false, false, false, false};                   // copy of result k is enqueued / done
+  int prefetch = 1;            // 1: every x-only result is copied out right behind the kernel; 0: on first request
+  int host_direct = 0;         // 1: the kernels store into the (pinned, device-visible) host targets themselves
+  // profiling
+  bool profiling = false;
+  std::vector<EventPair> pending[K_COUNT];
+  int64_t launches[K_COUNT] = {};
+  double total_ms[K_COUNT] = {};
+  std::string error;
+};
+
+namespace {
+
+int fail(pk_ctx* c, int code, const char* fmt, ...) {
+  char buf[1024];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof buf, fmt, ap);
+  va_end(ap);
+  if (c) c->error = buf; else g_create_error = buf;
+  return code;
+}
+
+#define PK_HIP(c, call)                                                                                  \
+  do {                                                                                                   \
+    hipError_t e_ = (call);                                                                              \
+    if (e_ != hipSuccess) return fail((c), 100 + (int)e_, "%s failed: %s", #call, hipGetErrorString(e_)); \
+  } while (0)
+
+void drop_cycle_graph(pk_ctx* c) {
+  if (c->cyc_exec) { (void)hipGraphExecDestroy(c->cyc_exec); c->cyc_exec = nullptr; }
+}
+
+template <class T>
+void release(T*& p) {
+  if (p) (void)hipFree(p);
+  p = nullptr;
+}
+
+void free_problem(pk_ctx* c) {
+  release(c->d_phases); release(c->d_tiles); release(c->d_kinds); release(c->d_items_jac); release(c->d_items_hess); release(c->d_items_aux); release(c->d_outer); release(c->d_aux); release(c->d_items_hessc); release(c->d_Hc);
+  release(c->d_erriv); release(c->d_errdb); release(c->d_errT); release(c->d_errI);
+  c->n_erriv = 0; c->n_err_out = 0;
+  drop_cycle_graph(c);
+  release(c->d_trace);
+  for (auto& m : c->csr) { release(m.d_seg); release(m.d_perm); release(m.d_vals); m.n_unique = m.n_triplets = 0; }
+  release(c->d_ib); release(c->d_db); release(c->d_lb);
+  release(c->d_x); release(c->d_lam); release(c->d_f); release(c->d_grad); release(c->d_g); release(c->d_J);
+  release(c->d_H); release(c->d_I); release(c->d_partial); release(c->d_partial2);
+  release(c->d_cpart); release(c->d_cpart2);
+  for (int b = 0; b < 2; ++b) {
+    if (c->h_xs[b]) (void)hipHostFree(c->h_xs[b]);
+    if (c->h_lams[b]) (void)hipHostFree(c->h_lams[b]);
+    if (c->ev_xs[b]) (void)hipEventDestroy(c->ev_xs[b]);
+    if (c->ev_lams[b]) (void)hipEventDestroy(c->ev_lams[b]);
+    c->h_xs[b] = c->h_lams[b] = nullptr;
+    c->ev_xs[b] = c->ev_lams[b] = nullptr;
+  }
+  c->h_x = nullptr;
+  c->x_valid = false;
+  for (int k = 0; k < 5; ++k) {
+    if (c->h_out[k]) (void)hipHostFree(c->h_out[k]);
+    if (c->ev_out[k]) (void)hipEventDestroy(c->ev_out[k]);
+    c->h_out[k] = c->target[k] = c->landed[k] = nullptr;
+    c->ev_out[k] = nullptr;
+    c->enq[k] = false;
+  }
+  c->have_problem = false;
+}
+
+int upload(pk_ctx* c, void** dst, const void* src, size_t bytes) {
+  *dst = nullptr;
+  const size_t alloc = bytes ? bytes : 8;
+  PK_HIP(c, hipMalloc(dst, alloc));
+  if (bytes) PK_HIP(c, hipMemcpy(*dst, src, bytes, hipMemcpyHostToDevice));
+  return 0;
+}
+
+int ready(pk_ctx* c) {
+  if (!c) return fail(nullptr, 1, "null context");
+  if (!c->have_model) return fail(c, 2, "no model loaded (pk_load_model)");
+  if (!c->have_problem) return fail(c, 3, "no problem set (pk_set_problem)");
+  return 0;
+}
+
+PkArgs base_args(pk_ctx* c, const double* d_x, const double* d_lam, double sigma) {
+  PkArgs A;
+  std::memset(&A, 0, sizeof A);
+  A.x = d_x; A.lam = d_lam; A.sigma = sigma;
+  A.phase = (const PkPhase*)c->d_phases; A.tile = (const PkTile*)c->d_tiles; A.kind = (const PkKind*)c->d_kinds;
+  A.items = nullptr; A.ib = c->d_ib; A.db = c->d_db; A.lb = c->d_lb;
+  A.Ibuf = c->ext_I ? c->ext_I : c->d_I; A.partial = c->d_partial; A.partial2 = c->d_partial2;
+  A.cpart = c->d_cpart; A.cpart2 = c->d_cpart2; A.o_aux = c->d_aux; A.outer = (const PkOuter*)c->d_outer; A.n_outer = c->n_outer;
+  A.n_tiles = c->n_tiles; A.n_items = 0; A.n_phase = c->n_phase; A.n = c->n;
+  A.l_s = c->l_s; A.n_s = c->n_s; A.n_sys = c->n_sys; A.m = c->m;
+  A.gz_off = c->gz_off; A.n_gz = c->n_gz; A.flags = c->shard_flags | c->debug_flags;
+  for (size_t k = 0; k < c->h_phases.size(); ++k) A.ph[k] = c->h_phases[k];
+  A.trace = c->d_trace;
+  return A;
+}
+
+int launch_raw(pk_ctx* c, int k, void* args, size_t sz, unsigned grid, size_t lds_bytes, hipStream_t st) {
+  void* config[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, args, HIP_LAUNCH_PARAM_BUFFER_SIZE, &sz, HIP_LAUNCH_PARAM_END};
+  EventPair ev{};
+  if (grid == 0) return 0;
+  // every `profile_period`-th launch of a selected kernel is timed (the timed launch path costs ~2-3 us of host
+  // and command-processor work, so timing all of them would slow the loop being measured)
+  const bool timed = c->profiling && ((c->profile_mask >> k) & 1u) && (c->profile_seen[k]++ % c->profile_period == 0);
+  if (timed) {
+    // Timed launch: hipExtModuleLaunchKernel attaches the events to the dispatch packet itself, so
+    // elapsed(a, b) is the kernel's own start->end on this stream (what rocprofv3 reports), without
+    // the command-processor gaps a hipEventRecord pair around the launch would add.
+    if (!c->free_events.empty()) {
+      ev = c->free_events.back();
+      c->free_events.pop_back();
+    } else {
+      PK_HIP(c, hipEventCreate(&ev.a));
+      PK_HIP(c, hipEventCreate(&ev.b));
+    }
+    PK_HIP(c, hipExtModuleLaunchKernel(c->fn[k], grid * PK_BLOCK, 1, 1, PK_BLOCK, 1, 1, lds_bytes, st, nullptr, config,
+                                       ev.a, ev.b, 0));
+    c->pending[k].push_back(ev);
+    return 0;
+  }
+  PK_HIP(c, hipModuleLaunchKernel(c->fn[k], grid, 1, 1, PK_BLOCK, 1, 1, (unsigned)lds_bytes, st, nullptr, config));
+  return 0;
+}
+
+int launch(pk_ctx* c, int k, PkArgs& A, unsigned grid, size_t lds_bytes, hipStream_t st) {
+  return launch_raw(c, k, &A, sizeof(PkArgs), grid, lds_bytes, st);
+}
+
+unsigned tile_blocks(const pk_ctx* c) { return (unsigned)((c->n_tiles + PK_WAVES_PER_BLOCK - 1) / PK_WAVES_PER_BLOCK); }
+
+int prepass(pk_ctx* c, const double* d_x, const double* d_lam, double sigma, double* d_f, bool write_f, hipStream_t st) {
+  PkArgs A = base_args(c, d_x, d_lam, sigma);
+  A.o_f = d_f;
+  int rc = launch(c, K_INT, A, tile_blocks(c), 0, st);
+  if (rc) return rc;
+  A.flags |= F_FIN_INT | (write_f ? F_WRITE_F : 0);
+  return launch(c, K_FIN, A, 1, 0, st);
+}
+
+// pk_xall's launch shape: one wave per tile, or -- split launch -- two waves (of two workgroups) per tile
+unsigned xall_blocks(const pk_ctx* c) { return (c->split_xall ? 2u : 1u) * tile_blocks(c) + 1u; }
+int xall_flags(const pk_ctx* c) { return c->split_xall ? F_SPLIT : 0; }
+
+// the cycle as ONE launch (pk_cycle): [edge J | edge H | finalize | tile slots: x block(s) + Hessian block per group]
+int enqueue_single_launch_cycle(pk_ctx* c, const double* d_x, const double* d_lam, double sigma, double* d_f,
+                                double* d_grad, double* d_g, double* d_jac, double* d_hess, hipStream_t st) {
+  PkArgs A = base_args(c, d_x, d_lam, sigma);
+  A.o_f = d_f; A.o_grad = d_grad; A.o_g = d_g; A.o_jac = d_jac; A.o_hess = d_hess;
+  A.items = (const PkItem*)c->d_items_jac;
+  A.n_items = c->n_items_jac;
+  A.items2 = (const PkItem*)c->d_items_hess;
+  A.n_items2 = c->n_items_hess;
+  A.flags |= F_FIN_INT | F_WRITE_F | F_FIN_GRAD | xall_flags(c);
+  size_t dbl = PK_WAVES_PER_BLOCK * (size_t)(c->md.lds_x > c->md.lds_h ? c->md.lds_x : c->md.lds_h);
+  if (dbl < (size_t)c->md.ne_j) dbl = (size_t)c->md.ne_j;
+  if (dbl < (size_t)c->md.ne_h) dbl = (size_t)c->md.ne_h;
+  const unsigned per_group = c->split_xall ? 3u : 2u;
+  const unsigned grid = tile_blocks(c) * per_group + 3u;
+  // pk_cycle's kernarg segment: the scalars a tile wave needs first (preloaded into SGPRs), then the PkArgs
+  struct CycleArgs {
+    const PkTile* tile;
+    int32_t n_tiles, flags, grid, pad;
+    PkArgs A;
+  } K;
+  static_assert(offsetof(CycleArgs, A) == 24, "layout of pk_cycle's kernel arguments");
+  K.tile = A.tile; K.n_tiles = A.n_tiles; K.flags = A.flags; K.grid = (int32_t)grid; K.pad = 0;
+  K.A = A;
+  return launch_raw(c, K_CYCLE, &K, sizeof K, grid, sizeof(double) * dbl, st);
+}
+
+int enqueue_fused_cycle(pk_ctx* c, const double* d_x, const double* d_lam, double sigma, double* d_f, double* d_grad,
+                        double* d_g, double* d_jac, double* d_hess, hipStream_t st) {
+  int rc;
+  if (c->cycle_mode == 1) return enqueue_single_launch_cycle(c, d_x, d_lam, sigma, d_f, d_grad, d_g, d_jac, d_hess, st);
+  PkArgs A = base_args(c, d_x, nullptr, 0.0);
+  A.o_f = d_f; A.o_grad = d_grad; A.o_g = d_g; A.o_jac = d_jac;
+  A.items = (const PkItem*)c->d_items_jac;
+  A.n_items = c->n_items_jac;
+  size_t lds = sizeof(double) * PK_WAVES_PER_BLOCK * (size_t)c->md.lds_x;
+  if (lds < sizeof(double) * (size_t)c->md.ne_j) lds = sizeof(double) * (size_t)c->md.ne_j;
+  A.flags |= xall_flags(c);
+  if ((rc = launch(c, K_XALL, A, xall_blocks(c), lds, st))) return rc;
+  // pk_hess's boundary workgroup also performs pk_fin's reductions (f, shared gradient slots)
+  PkArgs H = base_args(c, d_x, d_lam, sigma);
+  H.o_f = d_f; H.o_grad = d_grad; H.o_hess = d_hess;
+  H.items = (const PkItem*)c->d_items_hess;
+  H.n_items = c->n_items_hess;
+  H.flags |= F_FIN_INT | F_WRITE_F | F_FIN_GRAD | xall_flags(c);
+  lds = sizeof(double) * PK_WAVES_PER_BLOCK * (size_t)c->md.lds_h;
+  if (lds < sizeof(double) * (size_t)c->md.ne_h) lds = sizeof(double) * (size_t)c->md.ne_h;
+  return launch(c, K_HESS, H, tile_blocks(c) + 2, lds, st);
+}
+
+hipStream_t pick(pk_ctx* c, void* stream) { return stream ? (hipStream_t)stream : c->stream; }
+
+}  // namespace
+
+// ---- helpers of the host shim (the "new x" protocol further down)
+namespace {
+
+size_t result_count(const pk_ctx* c, int what) {
+  const size_t cnt[5] = {1, (size_t)c->n, (size_t)c->m, (size_t)c->nnz_J, (size_t)c->nnz_H};
+  return cnt[what];
+}
+
+double* device_result(pk_ctx* c, int what) {
+  double* src[5] = {c->d_f, c->d_grad, c->d_g, c->d_J, c->d_H};
+  return src[what];
+}
+
+// queue the copy of result `what` of the current iterate (no-op when the kernels stored it into host memory themselves)
+int enqueue_result_copy(pk_ctx* c, int what) {
+  if (c->enq[what]) return 0;
+  if (!c->host_direct)
+    PK_HIP(c, hipMemcpyAsync(c->landed[what], device_result(c, what), sizeof(double) * result_count(c, what),
+                             hipMemcpyDeviceToHost, c->stream));
+  PK_HIP(c, hipEventRecord(c->ev_out[what], c->stream));
+  c->enq[what] = true;
+  return 0;
+}
+
+// stage `count` doubles in the next staging buffer of a double-buffered pair and queue their upload
+int stage_upload(pk_ctx* c, double* const bufs[2], hipEvent_t const evs[2], int& cur, const double* src, double* dst,
+                 size_t count, double** staged) {
+  cur ^= 1;
+  PK_HIP(c, hipEventSynchronize(evs[cur]));        // (the upload that used this buffer two iterates ago; long done)
+  std::memcpy(bufs[cur], src, sizeof(double) * count);
+  PK_HIP(c, hipMemcpyAsync(dst, bufs[cur], sizeof(double) * count, hipMemcpyHostToDevice, c->stream));
+  PK_HIP(c, hipEventRecord(evs[cur], c->stream));
+  if (staged) *staged = bufs[cur];
+  return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+int pk_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+  return n;
+}
+
+const char* pk_kernel_name(int k) { return (k >= 0 && k < K_COUNT) ? kKernelNames[k] : ""; }
+
+int pk_create(pk_ctx** out, int device_id) {
+  if (!out) return fail(nullptr, 1, "pk_create: null output pointer");
+  *out = nullptr;
+  int ndev = 0;
+  hipError_t e = hipGetDeviceCount(&ndev);
+  if (e != hipSuccess || ndev == 0)
+    return fail(nullptr, 10, "pk_create: no HIP device available (%s); the evaluator has no CPU path",
+                e == hipSuccess ? "device count 0" : hipGetErrorString(e));
+  if (device_id < 0 || device_id >= ndev) return fail(nullptr, 11, "pk_create: device %d out of range [0,%d)", device_id, ndev);
+  pk_ctx* c = new pk_ctx();
+  c->device = device_id;
+  if (const char* dbg = getenv("POCKIT_AMD_DEBUG_FLAGS")) c->debug_flags = atoi(dbg) & (256 | 512 | 1024 | 2048 | 4096 | 8192 | 16384 | 32768 | 65536 | 131072);
+  if ((e = hipSetDevice(device_id)) != hipSuccess || (e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)) != hipSuccess) {
+    int rc = fail(nullptr, 12, "pk_create: %s", hipGetErrorString(e));
+    delete c;
+    return rc;
+  }
+  *out = c;
+  return 0;
+}
+
+void pk_destroy(pk_ctx* c) {
+  if (!c) return;
+  (void)hipSetDevice(c->device);
+  (void)hipStreamSynchronize(c->stream);
+  for (int k = 0; k < K_COUNT; ++k)
+    for (auto& ev : c->pending[k]) { (void)hipEventDestroy(ev.a); (void)hipEventDestroy(ev.b); }
+  for (auto& ev : c->free_events) { (void)hipEventDestroy(ev.a); (void)hipEventDestroy(ev.b); }
+  free_problem(c);
+  if (c->module) (void)hipModuleUnload(c->module);
+  if (c->stream) (void)hipStreamDestroy(c->stream);
+  delete c;
+}
+
+const char* pk_last_error(pk_ctx* c) { return c ? c->error.c_str() : g_create_error.c_str(); }
+
+int pk_load_model(pk_ctx* c, const void* code_object, size_t len, const pk_model_desc* md) {
+  if (!c) return fail(nullptr, 1, "null context");
+  if (!code_object || len == 0 || !md) return fail(c, 20, "pk_load_model: empty code object or descriptor");
+  PK_HIP(c, hipSetDevice(c->device));
+  if (c->module) { (void)hipModuleUnload(c->module); c->module = nullptr; c->have_model = false; }
+  PK_HIP(c, hipModuleLoadData(&c->module, code_object));
+  for (int k = 0; k < K_COUNT; ++k) PK_HIP(c, hipModuleGetFunction(&c->fn[k], c->module, kKernelNames[k]));
+  c->md = *md;
+  const size_t lds_max = 160 * 1024;
+  const size_t need[4] = {(size_t)md->lds_g, (size_t)md->lds_j, (size_t)md->lds_h, (size_t)md->lds_x};
+  for (size_t v : need)
+    if (v * PK_WAVES_PER_BLOCK * sizeof(double) > lds_max)
+      return fail(c, 21, "pk_load_model: model needs %zu bytes of LDS per workgroup (> 160 KiB)", v * PK_WAVES_PER_BLOCK * sizeof(double));
+  c->have_model = true;
+  return 0;
+}
+
+int pk_set_problem(pk_ctx* c, const pk_problem_desc* pd) {
+  if (!c) return fail(nullptr, 1, "null context");
+  if (!c->have_model) return fail(c, 2, "pk_set_problem: load a model first");
+  if (!pd) return fail(c, 30, "pk_set_problem: null descriptor");
+  if (pd->n_phase > PK_MAX_PHASES) return fail(c, 32, "pk_set_problem: at most %d phases are supported", PK_MAX_PHASES);
+  if (pd->n_phase != c->md.n_phase) return fail(c, 31, "pk_set_problem: %d phases but the model was generated for %d", pd->n_phase, c->md.n_phase);
+  PK_HIP(c, hipSetDevice(c->device));
+  PK_HIP(c, hipStreamSynchronize(c->stream));
+  free_problem(c);
+  c->n = pd->n; c->m = pd->m; c->n_sys = pd->n_sys; c->n_s = pd->n_s; c->l_s = pd->l_s;
+  c->n_phase = pd->n_phase; c->n_tiles = pd->n_tiles; c->nnz_J = pd->nnz_J; c->nnz_H = pd->nnz_H;
+  c->n_items_jac = pd->n_items_jac; c->n_items_hess = pd->n_items_hess; c->gz_off = pd->gz_off; c->n_gz = pd->n_gz;
+  c->n_items_aux = pd->n_items_aux; c->n_outer = pd->n_outer; c->n_aux = pd->n_aux;
+  c->n_items_hessc = pd->n_items_hessc; c->nnz_Hc = pd->nnz_Hc;
+  // Small meshes are bound by the serial chain of one wave, not by throughput: let two waves share a tile in
+  // pk_xall as long as that still leaves at most two waves per SIMD (POCKIT_AMD_SPLIT=0/1 overrides).
+  {
+    const char* env = getenv("POCKIT_AMD_SPLIT");
+    c->split_xall = env ? atoi(env) != 0 : (pd->n_tiles > 0 && pd->n_tiles <= 1024);
+  }
+  int rc;
+  if ((rc = upload(c, &c->d_phases, pd->phases, sizeof(PkPhase) * (size_t)pd->n_phase))) return rc;
+  c->h_phases.assign((const PkPhase*)pd->phases, (const PkPhase*)pd->phases + pd->n_phase);
+
+  if ((rc = upload(c, &c->d_tiles, pd->tiles, sizeof(PkTile) * (size_t)pd->n_tiles))) return rc;
+  if ((rc = upload(c, &c->d_kinds, pd->kinds, sizeof(PkKind) * (size_t)pd->n_kinds))) return rc;
+  if ((rc = upload(c, &c->d_items_jac, pd->items_jac, sizeof(PkItem) * (size_t)pd->n_items_jac))) return rc;
+  if ((rc = upload(c, &c->d_items_hess, pd->items_hess, sizeof(PkItem) * (size_t)pd->n_items_hess))) return rc;
+  if ((rc = upload(c, &c->d_items_aux, pd->items_aux, sizeof(PkItem) * (size_t)pd->n_items_aux))) return rc;
+  if ((rc = upload(c, &c->d_outer, pd->outer, sizeof(PkOuter) * (size_t)pd->n_outer))) return rc;
+  if ((rc = upload(c, &c->d_items_hessc, pd->items_hessc, sizeof(PkItem) * (size_t)pd->n_items_hessc))) return rc;
+  if ((rc = upload(c, (void**)&c->d_ib, pd->ib, sizeof(int32_t) * (size_t)pd->n_ib))) return rc;
+  if ((rc = upload(c, (void**)&c->d_db, pd->db, sizeof(double) * (size_t)pd->n_db))) return rc;
+  if ((rc = upload(c, (void**)&c->d_lb, pd->lb, sizeof(int64_t) * (size_t)pd->n_lb))) return rc;
+  auto dalloc = [&](double** p, size_t count) -> int {
+    PK_HIP(c, hipMalloc((void**)p, sizeof(double) * (count ? count : 1)));
+    PK_HIP(c, hipMemset(*p, 0, sizeof(double) * (count ? count : 1)));
+    return 0;
+  };
+  if ((rc = dalloc(&c->d_x, c->n)) || (rc = dalloc(&c->d_lam, c->m)) || (rc = dalloc(&c->d_f, 1)) ||
+      (rc = dalloc(&c->d_grad, c->n)) || (rc = dalloc(&c->d_g, c->m)) || (rc = dalloc(&c->d_J, (size_t)c->nnz_J)) ||
+      (rc = dalloc(&c->d_H, (size_t)c->nnz_H)) || (rc = dalloc(&c->d_aux, (size_t)c->n_aux)) || (rc = dalloc(&c->d_Hc, (size_t)c->nnz_Hc)) || (rc = dalloc(&c->d_I, c->md.n_I)) ||
+      (rc = dalloc(&c->d_partial, (2 * (size_t)c->n_tiles / PK_WAVES_PER_BLOCK + 2) * (size_t)c->md.nred)) ||
+      (rc = dalloc(&c->d_partial2, (2 * (size_t)c->n_tiles / PK_WAVES_PER_BLOCK + 2) * (size_t)c->md.nred)))
+    return rc;
+  {   // hand-off slots of pk_cycle: one per x-kernel workgroup and reduction row, PK_EMPTY between launches
+    const size_t slots = (2 * (size_t)c->n_tiles / PK_WAVES_PER_BLOCK + 2) * (size_t)c->md.nred;
+    const std::vector<unsigned long long> empty(slots, (unsigned long long)PK_EMPTY);
+    if ((rc = upload(c, (void**)&c->d_cpart, empty.data(), sizeof(unsigned long long) * slots))) return rc;
+    if ((rc = upload(c, (void**)&c->d_cpart2, empty.data(), sizeof(unsigned long long) * slots))) return rc;
+  }
+  {
+    const size_t cnt[5] = {1, (size_t)c->n, (size_t)c->m, (size_t)c->nnz_J, (size_t)c->nnz_H};
+    for (int b = 0; b < 2; ++b) {
+      PK_HIP(c, hipHostMalloc((void**)&c->h_xs[b], sizeof(double) * (size_t)(c->n ? c->n : 1), hipHostMallocDefault));
+      PK_HIP(c, hipHostMalloc((void**)&c->h_lams[b], sizeof(double) * (size_t)(c->m ? c->m : 1), hipHostMallocDefault));
+      PK_HIP(c, hipEventCreateWithFlags(&c->ev_xs[b], hipEventDisableTiming));
+      PK_HIP(c, hipEventCreateWithFlags(&c->ev_lams[b], hipEventDisableTiming));
+    }
+    for (int k = 0; k < 5; ++k) {
+      PK_HIP(c, hipHostMalloc((void**)&c->h_out[k], sizeof(double) * (cnt[k] ? cnt[k] : 1), hipHostMallocDefault));
+      PK_HIP(c, hipEventCreateWithFlags(&c->ev_out[k], hipEventDisableTiming));
+    }
+    c->xbuf = c->lambuf = 0;
+  }
+  auto keep = [](std::vector<int32_t>& v, const int32_t* src, int64_t cnt) {
+    v.clear();
+    if (src) v.assign(src, src + cnt);
+  };
+  keep(c->jac_row, pd->jac_row, pd->nnz_J); keep(c->jac_col, pd->jac_col, pd->nnz_J);
+  keep(c->hess_row, pd->hess_row, pd->nnz_H); keep(c->hess_col, pd->hess_col, pd->nnz_H);
+  c->have_problem = true;
+  return 0;
+}
+
+int pk_get_structure(pk_ctx* c, int32_t* jr, int32_t* jc, int32_t* hr, int32_t* hc) {
+  int rc = ready(c);
+  if (rc) return rc;
+  if (c->jac_row.empty() && c->nnz_J) return fail(c, 40, "pk_get_structure: no structure was supplied to pk_set_problem");
+  if (jr) std::memcpy(jr, c->jac_row.data(), sizeof(int32_t) * c->jac_row.size());
+  if (jc) std::memcpy(jc, c->jac_col.data(), sizeof(int32_t) * c->jac_col.size());
+  if (hr) std::memcpy(hr, c->hess_row.data(), sizeof(int32_t) * c->hess_row.size());
+  if (hc) std::memcpy(hc, c->hess_col.data(), sizeof(int32_t) * c->hess_col.size());
+  return 0;
+}
+
+// ---------------------------------------------------------------- device-pointer API
+int pk_eval_f_dev(pk_ctx* c, const double* d_x, double* d_f, void* stream) {
+  int rc = ready(c);
+  if (rc) return rc;
+  return prepass(c, d_x, nullptr, 0.0, d_f, true, pick(c, stream));
+}
+
+// sharded mode, step 1: this shard's contribution to every integral -> integral buffer
+int pk_eval_integrals_dev(pk_ctx* c, const double* d_x, void* stream) {
+  int rc = ready(c);
+  if (rc) return rc;
+  return prepass(c, d_x, nullptr, 0.0, c->d_f, false, pick(c, stream));
+}
+
+// sharded mode, step 2 (after the caller all-reduced the integral buffer): f = F_o(I, s)
+int pk_eval_f_from_integrals_dev(pk_ctx* c, const double* d_x, double* d_f, void* stream) {
+  int rc = ready(c);
+  if (rc) return rc;
+  PkArgs A = base_args(c, d_x, nullptr, 0.0);
+  A.o_f = d_f;
+  A.flags |= F_WRITE_F;
+  return launch(c, K_FIN, A, 1, 0, pick(c, stream));
+}
+
+int pk_set_shard(pk_ctx* c, int secondary, int external_prepass, double* d_integrals) {
+  if (!c) return fail(nullptr, 1, "null context");
+  c->shard_flags = secondary ? F_SECONDARY : 0;
+  c->external_prepass = external_prepass != 0;
+  c->ext_I = d_integrals;
+  return 0;
+}
+
+int pk_eval_grad_dev(pk_ctx* c, const double* d_x, double* d_grad, void* stream) {
+  int rc = ready(c);
+  if (rc) return rc;
+  hipStream_t st = pick(c, stream);
+  if (c->md.prepass_grad && !c->external_prepass && (rc = prepass(c, d_x, nullptr, 0.0, c->d_f, false, st))) return rc;
+  PkArgs A = base_args(c, d_x, nullptr, 0.0);
+  A.o_grad = d_grad;
+  if ((rc = launch(c, K_GRAD, A, tile_blocks(c), 0, st))) return rc;
+  A.flags |= F_FIN_GRAD;
+  return launch(c, K_FIN, A, 1, 0, st);
+}
+
+int pk_eval_g_dev(pk_ctx* c, const double* d_x, double* d_g, void* stream) {
+  int rc = ready(c);
+  if (rc) return rc;
+  hipStream_t st = pick(c, stream);
+  if (c->md.prepass_g && !c->external_prepass && (rc = prepass(c, d_x, nullptr, 0.0, c->d_f, false, st))) return rc;
+  PkArgs A = base_args(c, d_x, nullptr, 0.0);
+  A.o_g = d_g;
+  return launch(c, K_G, A, tile_blocks(c) + 1, sizeof(double) * PK_WAVES_PER_BLOCK * (size_t)c->md.lds_g, st);
+}
+
+int pk_eval_jac_dev(pk_ctx* c, const double* d_x, double* d_vals, void* stream) {
+  int rc = ready(c);
+  if (rc) return rc;
+  hipStream_t st = pick(c, stream);
+  if (c->md.prepass_jac && !c->external_prepass && (rc = prepass(c, d_x, nullptr, 0.0, c->d_f, false, st))) return rc;
+  PkArgs A = base_args(c, d_x, nullptr, 0.0);
+  A.o_jac = d_vals;
+  A.items = (const PkItem*)c->d_items_jac;
+  A.n_items = c->n_items_jac;
+  size_t lds = sizeof(double) * PK_WAVES_PER_BLOCK * (size_t)c->md.lds_j;
+  if (lds < sizeof(double) * (size_t)c->md.ne_j) lds = sizeof(double) * (size_t)c->md.ne_j;
+  return launch(c, K_JAC, A, tile_blocks(c) + 1, lds, st);
+}
+
+int pk_eval_hess_dev(pk_ctx* c, const double* d_x, const double* d_lam, double sigma, double* d_vals, void* stream) {
+  int rc = ready(c);
+  if (rc) return rc;
+  if (!d_lam) return fail(c, 50, "pk_eval_hess: lambda is required");
+  hipStream_t st = pick(c, stream);
+  if (c->md.prepass_hess && !c->external_prepass && (rc = prepass(c, d_x, d_lam, sigma, c->d_f, false, st))) return rc;
+  PkArgs A = base_args(c, d_x, d_lam, sigma);
+  A.o_hess = d_vals;
+  A.items = (const PkItem*)c->d_items_hess;
+  A.n_items = c->n_items_hess;
+  size_t lds = sizeof(double) * PK_WAVES_PER_BLOCK * (size_t)c->md.lds_h;
+  if (lds < sizeof(double) * (size_t)c->md.ne_h) lds = sizeof(double) * (size_t)c->md.ne_h;
+  if ((rc = launch(c, K_HESS, A, tile_blocks(c) + 2, lds, st))) return rc;
+  if (c->n_outer > 0) {   // objective / system constraints nonlinear in the integrals: outer-product blocks
+    PkArgs X = base_args(c, d_x, d_lam, sigma);
+    X.o_hess = d_vals;
+    X.items = (const PkItem*)c->d_items_aux;
+    X.n_items = c->n_items_aux;
+    if ((rc = launch(c, K_AUX, X, tile_blocks(c) + 1, sizeof(double) * (size_t)(c->md.ne_a > 0 ? c->md.ne_a : 1), st))) return rc;
+    const unsigned grid = (unsigned)(c->n_outer < 4096 ? c->n_outer : 4096);
+    return launch(c, K_OUTER, X, grid, 0, st);
+  }
+  return 0;
+}
+
+// compact (coalesced) Hessian of the Lagrangian: one value per distinct (row, col) class of a node
+int pk_eval_hessc_dev(pk_ctx* c, const double* d_x, const double* d_lam, double sigma, double* d_vals, void* stream) {
+  int rc = ready(c);
+  if (rc) return rc;
+  if (!d_lam) return fail(c, 50, "pk_eval_hessc: lambda is required");
+  if (c->nnz_Hc <= 0) return fail(c, 51, "pk_eval_hessc: no compact Hessian layout was supplied to pk_set_problem");
+  hipStream_t st = pick(c, stream);
+  if (c->md.prepass_hess && !c->external_prepass && (rc = prepass(c, d_x, d_lam, sigma, c->d_f, false, st))) return rc;
+  PkArgs A = base_args(c, d_x, d_lam, sigma);
+  A.o_hess = d_vals;
+  A.items = (const PkItem*)c->d_items_hessc;
+  A.n_items = c->n_items_hessc;
+  return launch(c, K_HESSC, A, tile_blocks(c) + 1, sizeof(double) * (size_t)(c->md.ne_hc > 0 ? c->md.ne_hc : 1), st);
+}
+
+// ---------------------------------------------------------------- device-resident CSR hand-off
+int pk_set_csr_map(pk_ctx* c, int which, const int32_t* seg, const int32_t* perm, int64_t n_unique, int64_t n_triplets) {
+  int rc = ready(c);
+  if (rc) return rc;
+  if (which < 0 || which > 1) return fail(c, 80, "pk_set_csr_map: which must be 0 (Jacobian) or 1 (Hessian)");
+  const int64_t expect = which == 0 ? c->nnz_J : c->nnz_H;
+  if (!perm || n_unique <= 0 || n_unique > n_triplets || n_triplets != expect || n_triplets > INT32_MAX)
+    return fail(c, 81, "pk_set_csr_map: map does not match the problem (%lld triplets expected)", (long long)expect);
+  // validate on the host: the kernel indexes with these
+  for (int64_t q = 0; q < n_triplets; ++q)
+    if (perm[q] < 0 || perm[q] >= n_triplets) return fail(c, 82, "pk_set_csr_map: perm[%lld] out of range", (long long)q);
+  if (seg) {
+    if (seg[0] != 0 || seg[n_unique] != n_triplets) return fail(c, 83, "pk_set_csr_map: segment table does not cover the triplets");
+    for (int64_t p = 0; p < n_unique; ++p)
+      if (seg[p + 1] <= seg[p]) return fail(c, 83, "pk_set_csr_map: empty or decreasing segment %lld", (long long)p);
+  } else if (n_unique != n_triplets) {
+    return fail(c, 83, "pk_set_csr_map: a segment table is required when entries repeat");
+  }
+  PK_HIP(c, hipSetDevice(c->device));
+  PK_HIP(c, hipStreamSynchronize(c->stream));
+  auto& m = c->csr[which];
+  release(m.d_seg); release(m.d_perm); release(m.d_vals);
+  m.n_unique = m.n_triplets = 0;
+  if (seg && (rc = upload(c, (void**)&m.d_seg, seg, sizeof(int32_t) * (size_t)(n_unique + 1)))) return rc;
+  if ((rc = upload(c, (void**)&m.d_perm, perm, sizeof(int32_t) * (size_t)n_triplets))) return rc;
+  PK_HIP(c, hipMalloc((void**)&m.d_vals, sizeof(double) * (size_t)n_unique));
+  m.n_unique = n_unique;
+  m.n_triplets = n_triplets;
+  return 0;
+}
+
+int pk_gather_csr_dev(pk_ctx* c, int which, const double* d_triplets, double* d_csr, void* stream) {
+  int rc = ready(c);
+  if (rc) return rc;
+  if (which < 0 || which > 1 || c->csr[which].n_unique == 0) return fail(c, 84, "pk_gather_csr: call pk_set_csr_map first");
+  const auto& m = c->csr[which];
+  PkArgs A = base_args(c, nullptr, nullptr, 0.0);
+  A.csr_in = d_triplets; A.csr_seg = m.d_seg; A.csr_perm = m.d_perm; A.csr_out = d_csr; A.n_csr = (int32_t)m.n_unique;
+  unsigned grid = (unsigned)((m.n_unique + PK_BLOCK - 1) / PK_BLOCK);
+  if (grid > 4096) grid = 4096;
+  return launch(c, K_CSR, A, grid, 0, pick(c, stream));
+}
+
+int pk_eval_jac_csr_dev(pk_ctx* c, const double* d_x, double* d_csr, void* stream) {
+  if (c) c->x_valid = false;      // (the triplets pass through the context's J buffer)
+  int rc = pk_eval_jac_dev(c, d_x, c ? c->d_J : nullptr, stream);
+  return rc ? rc : pk_gather_csr_dev(c, 0, c->d_J, d_csr, stream);
+}
+
+int pk_eval_hess_csr_dev(pk_ctx* c, const double* d_x, const double* d_lam, double sigma, double* d_csr, void* stream) {
+  int rc = pk_eval_hess_dev(c, d_x, d_lam, sigma, c ? c->d_H : nullptr, stream);
+  return rc ? rc : pk_gather_csr_dev(c, 1, c->d_H, d_csr, stream);
+}
+
+int pk_eval_jac_csr(pk_ctx* c, const double* x, double* vals) {
+  int rc = ready(c);
+  if (rc) return rc;
+  if (!x || !vals) return fail(c, 60, "null host buffer");
+  if (c->csr[0].n_unique == 0) return fail(c, 84, "pk_eval_jac_csr: call pk_set_csr_map first");
+  PK_HIP(c, hipSetDevice(c->device));
+  c->x_valid = false;
+  PK_HIP(c, hipMemcpyAsync(c->d_x, x, sizeof(double) * (size_t)c->n, hipMemcpyHostToDevice, c->stream));
+  if ((rc = pk_eval_jac_csr_dev(c, c->d_x, c->csr[0].d_vals, nullptr))) return rc;
+  PK_HIP(c, hipMemcpyAsync(vals, c->csr[0].d_vals, sizeof(double) * (size_t)c->csr[0].n_unique, hipMemcpyDeviceToHost, c->stream));
+  PK_HIP(c, hipStreamSynchronize(c->stream));
+  return 0;
+}
+
+int pk_eval_hess_csr(pk_ctx* c, const double* x, const double* lambda, double sigma, double* vals) {
+  int rc = ready(c);
+  if (rc) return rc;
+  if (!x || !lambda || !vals) return fail(c, 60, "null host buffer");
+  if (c->csr[1].n_unique == 0) return fail(c, 84, "pk_eval_hess_csr: call pk_set_csr_map first");
+  PK_HIP(c, hipSetDevice(c->device));
+  c->x_valid = false;
+  PK_HIP(c, hipMemcpyAsync(c->d_x, x, sizeof(double) * (size_t)c->n, hipMemcpyHostToDevice, c->stream));
+  PK_HIP(c, hipMemcpyAsync(c->d_lam, lambda, sizeof(double) * (size_t)c->m, hipMemcpyHostToDevice, c->stream));
+  if ((rc = pk_eval_hess_csr_dev(c, c->d_x, c->d_lam, sigma, c->csr[1].d_vals, nullptr))) return rc;
+  PK_HIP(c, hipMemcpyAsync(vals, c->csr[1].d_vals, sizeof(double) * (size_t)c->csr[1].n_unique, hipMemcpyDeviceToHost, c->stream));
+  PK_HIP(c, hipStreamSynchronize(c->stream));
+  return 0;
+}
+
+// ---------------------------------------------------------------- mesh error estimation
+int pk_set_mesh_error_tables(pk_ctx* c, const void* intervals, int32_t n_intervals, const double* tables,
+                             int64_t n_tables, int64_t n_out) {
+  int rc = ready(c);
+  if (rc) return rc;
+  if (!intervals || n_intervals <= 0 || !tables || n_tables <= 0 || n_out <= 0)
+    return fail(c, 70, "pk_set_mesh_error_tables: empty tables");
+  if (n_intervals % PK_WAVES_PER_BLOCK)
+    return fail(c, 71, "pk_set_mesh_error_tables: interval records must be padded to a multiple of %d per phase", PK_WAVES_PER_BLOCK);
+  if ((size_t)c->md.lds_e * PK_WAVES_PER_BLOCK * sizeof(double) > 160 * 1024)
+    return fail(c, 72, "pk_set_mesh_error_tables: model needs more than 160 KiB of LDS per workgroup");
+  // host-side validation of everything the kernel indexes with (a faulting kernel can take the node down)
+  const PkErrIv* iv = (const PkErrIv*)intervals;
+  for (int32_t g = 0; g < n_intervals; ++g) {
+    const PkErrIv& r = iv[g];
+    if (r.phase < 0 || r.phase >= c->n_phase) return fail(c, 73, "pk_set_mesh_error_tables: record %d: bad phase", g);
+    if (r.K == 0) continue;   // padding
+    const PkPhase& ph = c->h_phases[r.phase];
+    const int na = r.K + 1, ncx = r.K + 1 - ph.scheme, nr = ncx;
+    const int64_t tab = (int64_t)na * ncx + (int64_t)na * r.K + (int64_t)nr * ncx + (int64_t)nr * na;
+    if (r.K < 1 || na > PK_WAVE || r.lm < 0 || r.lm + ncx > ph.state_len || r.lm + r.K > ph.L_m || r.tab_off < 0 ||
+        r.tab_off + tab > n_tables || r.tau_off < 0 || r.tau_off + na > n_tables || r.row0 < 0 || r.row0 + nr > r.rows ||
+        r.out_off < 0 || r.out_off + (int64_t)ph.n_x * r.rows > n_out)
+      return fail(c, 74, "pk_set_mesh_error_tables: record %d is inconsistent with the problem", g);
+  }
+  PK_HIP(c, hipSetDevice(c->device));
+  PK_HIP(c, hipStreamSynchronize(c->stream));
+  release(c->d_erriv); release(c->d_errdb); release(c->d_errT); release(c->d_errI);
+  c->n_erriv = 0; c->n_err_out = 0;
+  if ((rc = upload(c, &c->d_erriv, intervals, sizeof(PkErrIv) * (size_t)n_intervals))) return rc;
+  if ((rc = upload(c, (void**)&c->d_errdb, tables, sizeof(double) * (size_t)n_tables))) return rc;
+  PK_HIP(c, hipMalloc((void**)&c->d_errT, sizeof(double) * (size_t)n_out));
+  PK_HIP(c, hipMalloc((void**)&c->d_errI, sizeof(double) * (size_t)n_out));
+  PK_HIP(c, hipMemset(c->d_errT, 0, sizeof(double) * (size_t)n_out));
+  PK_HIP(c, hipMemset(c->d_errI, 0, sizeof(double) * (size_t)n_out));
+  c->n_erriv = n_intervals;
+  c->n_err_out = n_out;
+  return 0;
+}
+
+int pk_eval_mesh_error_dev(pk_ctx* c, const double* d_x, double* d_T, double* d_I, void* stream) {
+  int rc = ready(c);
+  if (rc) return rc;
+  if (c->n_erriv <= 0) return fail(c, 75, "pk_eval_mesh_error: call pk_set_mesh_error_tables first");
+  PkArgs A = base_args(c, d_x, nullptr, 0.0);
+  A.erriv = (const PkErrIv*)c->d_erriv;
+  A.errdb = c->d_errdb;
+  A.n_erriv = c->n_erriv;
+  A.o_errT = d_T;
+  A.o_errI = d_I;
+  return launch(c, K_ERR, A, (unsigned)(c->n_erriv / PK_WAVES_PER_BLOCK),
+                sizeof(double) * PK_WAVES_PER_BLOCK * (size_t)c->md.lds_e, pick(c, stream));
+}
+
+int pk_eval_mesh_error(pk_ctx* c, const double* x, double* T, double* I) {
+  int rc = ready(c);
+  if (rc) return rc;
+  if (!x || !T || !I) return fail(c, 60, "null host buffer");
+  PK_HIP(c, hipSetDevice(c->device));
+  c->x_valid = false;
+  PK_HIP(c, hipMemcpyAsync(c->d_x, x, sizeof(double) * (size_t)c->n, hipMemcpyHostToDevice, c->stream));
+  if ((rc = pk_eval_mesh_error_dev(c, c->d_x, c->d_errT, c->d_errI, nullptr))) return rc;
+  PK_HIP(c, hipMemcpyAsync(T, c->d_errT, sizeof(double) * (size_t)c->n_err_out, hipMemcpyDeviceToHost, c->stream));
+  PK_HIP(c, hipMemcpyAsync(I, c->d_errI, sizeof(double) * (size_t)c->n_err_out, hipMemcpyDeviceToHost, c->stream));
+  PK_HIP(c, hipStreamSynchronize(c->stream));
+  return 0;
+}
+
+int pk_eval_hessc(pk_ctx* c, const double* x, const double* lambda, double sigma, double* vals) {
+  int rc = ready(c);
+  if (rc) return rc;
+  if (!x || !lambda || !vals) return fail(c, 60, "null host buffer");
+  PK_HIP(c, hipSetDevice(c->device));
+  c->x_valid = false;
+  PK_HIP(c, hipMemcpyAsync(c->d_x, x, sizeof(double) * (size_t)c->n, hipMemcpyHostToDevice, c->stream));
+  PK_HIP(c, hipMemcpyAsync(c->d_lam, lambda, sizeof(double) * (size_t)c->m, hipMemcpyHostToDevice, c->stream));
+  if ((rc = pk_eval_hessc_dev(c, c->d_x, c->d_lam, sigma, c->d_Hc, nullptr))) return rc;
+  PK_HIP(c, hipMemcpyAsync(vals, c->d_Hc, sizeof(double) * (size_t)c->nnz_Hc, hipMemcpyDeviceToHost, c->stream));
+  PK_HIP(c, hipStreamSynchronize(c->stream));
+  return 0;
+}
+
+int pk_eval_cycle_dev(pk_ctx* c, const double* d_x, const double* d_lam, double sigma, double* d_f, double* d_grad,
+                      double* d_g, double* d_jac, double* d_hess, void* stream) {
+  int rc = ready(c);
+  if (rc) return rc;
+  if (!d_lam) return fail(c, 50, "pk_eval_cycle: lambda is required");
+  hipStream_t st = pick(c, stream);
+  const bool needs_I = c->md.prepass_grad || c->md.prepass_g || c->md.prepass_jac || c->md.prepass_hess;
+  // general path: the five callbacks one after the other.  A shard (pk_set_shard) may take the single launch too: its
+  // finalize workgroup then leaves THIS shard's share of the integrals and of the shared gradient slots for the
+  // caller's all-reduce, and f is the caller's to recompute (pk_eval_f_from_integrals_dev).
+  if (needs_I || ((c->external_prepass || c->shard_flags) && c->cycle_mode != 1)) {
+    if (!c->external_prepass && (rc = pk_eval_f_dev(c, d_x, d_f, stream))) return rc;
+    if ((rc = pk_eval_grad_dev(c, d_x, d_grad, stream))) return rc;
+    if ((rc = pk_eval_g_dev(c, d_x, d_g, stream))) return rc;
+    if ((rc = pk_eval_jac_dev(c, d_x, d_jac, stream))) return rc;
+    return pk_eval_hess_dev(c, d_x, d_lam, sigma, d_hess, stream);
+  }
+  // fused path: every x-only output from one evaluation of each node, then H (whose boundary workgroup also
+  // performs the reductions).  With pk_set_cycle_graph the two launches are replayed from a cached hipGraph as
+  // long as the pointers, sigma and the stream stay the same (an NLP solver's steady state).
+  const pk_ctx::CycleKey key{d_x, d_lam, d_f, d_grad, d_g, d_jac, d_hess, sigma, st};
+  const bool graph = c->use_graph && c->profile_mask == 0;
+  if (graph && c->cyc_exec && c->cyc_key == key) {
+    PK_HIP(c, hipGraphLaunch(c->cyc_exec, st));
+    return 0;
+  }
+  if (graph) {
+    drop_cycle_graph(c);
+    PK_HIP(c, hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
+  }
+  rc = enqueue_fused_cycle(c, d_x, d_lam, sigma, d_f, d_grad, d_g, d_jac, d_hess, st);
+  if (!graph) return rc;
+  hipGraph_t g = nullptr;
+  hipError_t e = hipStreamEndCapture(st, &g);
+  if (rc) { if (g) (void)hipGraphDestroy(g); return rc; }
+  if (e != hipSuccess) return fail(c, 3, "pk_eval_cycle: graph capture failed: %s", hipGetErrorString(e));
+  e = hipGraphInstantiate(&c->cyc_exec, g, nullptr, nullptr, 0);
+  (void)hipGraphDestroy(g);
+  if (e != hipSuccess) { c->cyc_exec = nullptr; return fail(c, 3, "pk_eval_cycle: graph instantiation failed: %s", hipGetErrorString(e)); }
+  c->cyc_key = key;
+  PK_HIP(c, hipGraphLaunch(c->cyc_exec, st));
+  return 0;
+}
+
+// 1 (default): the cycle is ONE launch (pk_cycle); 0: two launches (pk_xall, then pk_hess with the reductions)
+int pk_set_cycle_mode(pk_ctx* c, int single_launch) {
+  if (!c) return fail(nullptr, 1, "null context");
+  c->cycle_mode = single_launch ? 1 : 0;
+  drop_cycle_graph(c);
+  return 0;
+}
+
+int pk_set_cycle_graph(pk_ctx* c, int enable) {
+  if (!c) return fail(nullptr, 1, "null context");
+  c->use_graph = enable != 0;
+  if (!c->use_graph) drop_cycle_graph(c);
+  return 0;
+}
+
+int pk_sync(pk_ctx* c, void* stream) {
+  if (!c) return fail(nullptr, 1, "null context");
+  PK_HIP(c, hipStreamSynchronize(pick(c, stream)));
+  return 0;
+}
+
+// ---------------------------------------------------------------- host-buffer API
+#define PK_HOST_EVAL(IN_COPY, CALL, D_OUT, OUT, COUNT)                                                      \
+  int rc = ready(c);                                                                                        \
+  if (rc) return rc;                                                                                        \
+  if (!x || !(OUT)) return fail(c, 60, "null host buffer");                                                 \
+  PK_HIP(c, hipSetDevice(c->device));                                                                       \
+  c->x_valid = false; /* the context's x and result buffers now hold another evaluation */                  \
+  PK_HIP(c, hipMemcpyAsync(c->d_x, x, sizeof(double) * (size_t)c->n, hipMemcpyHostToDevice, c->stream));    \
+  IN_COPY;                                                                                                  \
+  if ((rc = (CALL))) return rc;                                                                             \
+  PK_HIP(c, hipMemcpyAsync((OUT), (D_OUT), sizeof(double) * (size_t)(COUNT), hipMemcpyDeviceToHost, c->stream)); \
+  PK_HIP(c, hipStreamSynchronize(c->stream));                                                               \
+  return 0;
+
+int pk_eval_f(pk_ctx* c, const double* x, double* f) { PK_HOST_EVAL((void)0, pk_eval_f_dev(c, c->d_x, c->d_f, nullptr), c->d_f, f, 1) }
+
+int pk_eval_grad(pk_ctx* c, const double* x, double* grad) {
+  PK_HOST_EVAL((void)0, pk_eval_grad_dev(c, c->d_x, c->d_grad, nullptr), c->d_grad, grad, c->n)
+}
+
+int pk_eval_g(pk_ctx* c, const double* x, double* g) { PK_HOST_EVAL((void)0, pk_eval_g_dev(c, c->d_x, c->d_g, nullptr), c->d_g, g, c->m) }
+
+int pk_eval_jac(pk_ctx* c, const double* x, double* vals) {
+  PK_HOST_EVAL((void)0, pk_eval_jac_dev(c, c->d_x, c->d_J, nullptr), c->d_J, vals, c->nnz_J)
+}
+
+int pk_eval_hess(pk_ctx* c, const double* x, const double* lambda, double sigma, double* vals) {
+  if (c && !lambda) return fail(c, 50, "pk_eval_hess: lambda is required");
+  PK_HOST_EVAL(PK_HIP(c, hipMemcpyAsync(c->d_lam, lambda, sizeof(double) * (size_t)c->m, hipMemcpyHostToDevice, c->stream)),
+               pk_eval_hess_dev(c, c->d_x, c->d_lam, sigma, c->d_H, nullptr), c->d_H, vals, c->nnz_H)
+}
+
+int pk_eval_cycle(pk_ctx* c, const double* x, const double* lambda, double sigma, double* f, double* grad, double* g,
+                  double* jac, double* hess) {
+  int rc = ready(c);
+  if (rc) return rc;
+  if (!x || !lambda || !f || !grad || !g || !jac || !hess) return fail(c, 60, "null host buffer");
+  PK_HIP(c, hipSetDevice(c->device));
+  c->x_valid = false;
+  if ((rc = stage_upload(c, c->h_xs, c->ev_xs, c->xbuf, x, c->d_x, (size_t)c->n, nullptr))) return rc;
+  if ((rc = stage_upload(c, c->h_lams, c->ev_lams, c->lambuf, lambda, c->d_lam, (size_t)c->m, nullptr))) return rc;
+  if ((rc = pk_eval_cycle_dev(c, c->d_x, c->d_lam, sigma, c->d_f, c->d_grad, c->d_g, c->d_J, c->d_H, nullptr))) return rc;
+  PK_HIP(c, hipMemcpyAsync(f, c->d_f, sizeof(double), hipMemcpyDeviceToHost, c->stream));
+  PK_HIP(c, hipMemcpyAsync(grad, c->d_grad, sizeof(double) * (size_t)c->n, hipMemcpyDeviceToHost, c->stream));
+  PK_HIP(c, hipMemcpyAsync(g, c->d_g, sizeof(double) * (size_t)c->m, hipMemcpyDeviceToHost, c->stream));
+  PK_HIP(c, hipMemcpyAsync(jac, c->d_J, sizeof(double) * (size_t)c->nnz_J, hipMemcpyDeviceToHost, c->stream));
+  PK_HIP(c, hipMemcpyAsync(hess, c->d_H, sizeof(double) * (size_t)c->nnz_H, hipMemcpyDeviceToHost, c->stream));
+  PK_HIP(c, hipStreamSynchronize(c->stream));
+  return 0;
+}
+
+// ---------------------------------------------------------------- host shim: the "new x" protocol
+// IPOPT evaluates f, grad f, g, J separately but on the same iterate (ipopt.py:41-53 hands the five methods of the
+// problem object to cyipopt): pk_prepare_x uploads a new x ONCE, runs the fused x-kernel and -- prefetch mode -- queues
+// the copy of every result into pinned host memory right behind it, in the order a solver asks for them; pk_fetch then
+// only waits for the event of its result.  Nothing in here synchronizes the stream: the staging buffers of x and lambda
+// are double-buffered and guarded by events, the results by one event each.
+// 1 if x equals the x of the last pk_prepare_x bit for bit (the results held for it are still valid), else 0
+int pk_same_x(pk_ctx* c, const double* x) {
+  if (!c || !c->have_problem || !x || !c->x_valid || !c->h_x) return 0;
+  return std::memcmp(c->h_x, x, sizeof(double) * (size_t)c->n) == 0 ? 1 : 0;
+}
+
+// the context's x / result buffers were used for something else (mesh error, one-shot evals, the cycle call)
+int pk_invalidate_x(pk_ctx* c) {
+  if (!c) return fail(nullptr, 1, "null context");
+  c->x_valid = false;
+  return 0;
+}
+
+// Where the results of the NEXT pk_prepare_x / pk_eval_hess_prepared land: pinned host memory of the caller (from
+// pk_host_alloc), NULL = the context's own pinned buffer of that output (pk_host_buffer).
+int pk_set_result_targets(pk_ctx* c, double* f, double* grad, double* g, double* jac, double* hess) {
+  int rc = ready(c);
+  if (rc) return rc;
+  double* t[5] = {f, grad, g, jac, hess};
+  for (int k = 0; k < 5; ++k) c->target[k] = t[k];
+  return 0;
+}
+
+// prefetch = 1 (default): every x-only result is copied to the host right behind the kernel; 0: a result is copied
+// when it is first asked for (a request for the gradient also queues the Jacobian -- a solver wants both at an accepted
+// point, and neither at a rejected trial point).  host_direct = 1: the kernels store f / grad / g / J (and H) straight
+// into the pinned host targets over PCIe, no device-side staging and no DMA (A/B switch).
+int pk_set_host_mode(pk_ctx* c, int prefetch, int host_direct) {
+  if (!c) return fail(nullptr, 1, "null context");
+  c->prefetch = prefetch ? 1 : 0;
+  c->host_direct = host_direct ? 1 : 0;
+  c->x_valid = false;
+  return 0;
+}
+
+// Pinned (page-locked, device-visible) host memory for result arrays that outlive a call: process-wide, not tied to a
+// context (a host array handed to the solver may outlive the evaluator that filled it).
+int pk_host_alloc(size_t bytes, void** out) {
+  if (!out) return fail(nullptr, 60, "null host buffer");
+  *out = nullptr;
+  hipError_t e = hipHostMalloc(out, bytes ? bytes : 8, hipHostMallocDefault);
+  if (e != hipSuccess) return fail(nullptr, 100 + (int)e, "hipHostMalloc(%zu) failed: %s", bytes, hipGetErrorString(e));
+  return 0;
+}
+
+int pk_host_free(void* p) {
+  if (!p) return 0;
+  hipError_t e = hipHostFree(p);
+  if (e != hipSuccess) return fail(nullptr, 100 + (int)e, "hipHostFree failed: %s", hipGetErrorString(e));
+  return 0;
+}
+
+int pk_prepare_x(pk_ctx* c, const double* x) {
+  int rc = ready(c);
+  if (rc) return rc;
+  if (!x) return fail(c, 60, "null host buffer");
+  PK_HIP(c, hipSetDevice(c->device));
+  c->x_valid = false;
+  if ((rc = stage_upload(c, c->h_xs, c->ev_xs, c->xbuf, x, c->d_x, (size_t)c->n, &c->h_x))) return rc;
+  for (int k = 0; k < 5; ++k) {
+    c->landed[k] = c->target[k] ? c->target[k] : c->h_out[k];
+    c->enq[k] = false;
+  }
+  double* o[4];
+  for (int k = 0; k < 4; ++k) o[k] = c->host_direct ? c->landed[k] : device_result(c, k);
+  const bool needs_I = c->md.prepass_grad || c->md.prepass_g || c->md.prepass_jac || c->md.prepass_hess;
+  if (needs_I || c->external_prepass || c->shard_flags) {
+    if ((rc = pk_eval_f_dev(c, c->d_x, o[0], nullptr))) return rc;
+    if ((rc = pk_eval_grad_dev(c, c->d_x, o[1], nullptr))) return rc;
+    if ((rc = pk_eval_g_dev(c, c->d_x, o[2], nullptr))) return rc;
+    if ((rc = pk_eval_jac_dev(c, c->d_x, o[3], nullptr))) return rc;
+  } else {
+    PkArgs A = base_args(c, c->d_x, nullptr, 0.0);
+    A.o_f = o[0]; A.o_grad = o[1]; A.o_g = o[2]; A.o_jac = o[3];
+    A.items = (const PkItem*)c->d_items_jac;
+    A.n_items = c->n_items_jac;
+    size_t lds = sizeof(double) * PK_WAVES_PER_BLOCK * (size_t)c->md.lds_x;
+    if (lds < sizeof(double) * (size_t)c->md.ne_j) lds = sizeof(double) * (size_t)c->md.ne_j;
+    A.flags |= xall_flags(c);
+    if ((rc = launch(c, K_XALL, A, xall_blocks(c), lds, c->stream))) return rc;
+    A.flags |= F_FIN_INT | F_WRITE_F | F_FIN_GRAD;
+    if ((rc = launch(c, K_FIN, A, 1, 0, c->stream))) return rc;
+  }
+  // f and g are what a line search asks for at every trial point: always on their way; grad f and J in prefetch mode
+  if ((rc = enqueue_result_copy(c, 0))) return rc;
+  if (c->prefetch && (rc = enqueue_result_copy(c, 1))) return rc;
+  if ((rc = enqueue_result_copy(c, 2))) return rc;
+  if (c->prefetch && (rc = enqueue_result_copy(c, 3))) return rc;
+  c->x_valid = true;
+  return 0;
+}
+
+// result `what` (0 f, 1 grad, 2 g, 3 jac) of the last pk_prepare_x: waits for its copy.  out == NULL: the result stays
+// where it landed (pk_result_location); otherwise it is copied on to `out` (a second host copy).
+int pk_fetch(pk_ctx* c, int what, double* out) {
+  int rc = ready(c);
+  if (rc) return rc;
+  if (what < 0 || what > 3) return fail(c, 61, "pk_fetch: what must be 0 (f), 1 (grad), 2 (g) or 3 (jac)");
+  if (!c->x_valid) return fail(c, 64, "pk_fetch: no prepared x (pk_prepare_x)");
+  if (!c->enq[what]) {
+    if ((rc = enqueue_result_copy(c, what))) return rc;
+    if (what == 1 && (rc = enqueue_result_copy(c, 3))) return rc;      // an accepted point: J follows grad f
+  }
+  PK_HIP(c, hipEventSynchronize(c->ev_out[what]));
+  if (out && out != c->landed[what]) std::memcpy(out, c->landed[what], sizeof(double) * result_count(c, what));
+  return 0;
+}
+
+// Hessian on the x of the last pk_prepare_x (no re-upload of x); vals == NULL: the result stays where it landed
+int pk_eval_hess_prepared(pk_ctx* c, const double* lambda, double sigma, double* vals) {
+  int rc = ready(c);
+  if (rc) return rc;
+  if (!lambda) return fail(c, 60, "null host buffer");
+  if (!c->x_valid) return fail(c, 64, "pk_eval_hess_prepared: no prepared x (pk_prepare_x)");
+  PK_HIP(c, hipSetDevice(c->device));
+  if ((rc = stage_upload(c, c->h_lams, c->ev_lams, c->lambuf, lambda, c->d_lam, (size_t)c->m, nullptr))) return rc;
+  c->landed[4] = c->target[4] ? c->target[4] : c->h_out[4];
+  c->enq[4] = false;
+  if ((rc = pk_eval_hess_dev(c, c->d_x, c->d_lam, sigma, c->host_direct ? c->landed[4] : c->d_H, nullptr))) return rc;
+  if ((rc = enqueue_result_copy(c, 4))) return rc;
+  PK_HIP(c, hipEventSynchronize(c->ev_out[4]));
+  if (vals && vals != c->landed[4]) std::memcpy(vals, c->landed[4], sizeof(double) * (size_t)c->nnz_H);
+  return 0;
+}
+
+// where result `what` (0..4) of the current iterate landed (valid after its pk_fetch / pk_eval_hess_prepared)
+int pk_result_location(pk_ctx* c, int what, double** ptr) {
+  int rc = ready(c);
+  if (rc) return rc;
+  if (what < 0 || what > 4 || !ptr) return fail(c, 62, "pk_result_location: bad arguments");
+  *ptr = c->landed[what] ? c->landed[what] : c->h_out[what];
+  return 0;
+}
+
+// pinned host result buffers of the context: what = 0 f, 1 grad, 2 g, 3 jac, 4 hess
+int pk_host_buffer(pk_ctx* c, int what, double** ptr, int64_t* count) {
+  int rc = ready(c);
+  if (rc) return rc;
+  if (what < 0 || what > 4 || !ptr) return fail(c, 62, "pk_host_buffer: bad arguments");
+  const int64_t cnt[5] = {1, c->n, c->m, c->nnz_J, c->nnz_H};
+  *ptr = c->h_out[what];
+  if (count) *count = cnt[what];
+  return 0;
+}
+
+// ---------------------------------------------------------------- profiling
+int pk_profile(pk_ctx* c, int enable) {
+  if (!c) return fail(nullptr, 1, "null context");
+  c->profiling = enable != 0;
+  c->profile_mask = (unsigned)enable;   /* bit k set: time kernel id k */
+  return 0;
+}
+
+// developer tracing (models generated with POCKIT_AMD_TRACE=1): per-tile s_memtime marks of the last launch
+int pk_trace_read(pk_ctx* c, uint64_t* out, int64_t count) {
+  int rc = ready(c);
+  if (rc) return rc;
+  const int64_t need = ((int64_t)c->n_tiles * 3 + 3) * 16;   // [tile][role] records + pk_cycle's three special workgroups
+  PK_HIP(c, hipSetDevice(c->device));
+  if (!c->d_trace) {
+    PK_HIP(c, hipStreamSynchronize(c->stream));
+    PK_HIP(c, hipMalloc((void**)&c->d_trace, sizeof(uint64_t) * (size_t)(need ? need : 1)));
+    PK_HIP(c, hipMemset(c->d_trace, 0, sizeof(uint64_t) * (size_t)(need ? need : 1)));
+    drop_cycle_graph(c);
+    return 0;          // first call only arms the buffer
+  }
+  if (!out || count < need) return fail(c, 72, "pk_trace_read: need room for %lld marks", (long long)need);
+  PK_HIP(c, hipDeviceSynchronize());
+  PK_HIP(c, hipMemcpy(out, c->d_trace, sizeof(uint64_t) * (size_t)need, hipMemcpyDeviceToHost));
+  PK_HIP(c, hipMemset(c->d_trace, 0, sizeof(uint64_t) * (size_t)need));
+  return 0;
+}
+
+int pk_profile_sampling(pk_ctx* c, int period) {
+  if (!c) return fail(nullptr, 1, "null context");
+  if (period < 1) return fail(c, 71, "pk_profile_sampling: period must be >= 1");
+  c->profile_period = (unsigned)period;
+  for (auto& v : c->profile_seen) v = 0;
+  return 0;
+}
+
+int pk_profile_read(pk_ctx* c, int k, int64_t* launches, double* total_ms) {
+  if (!c) return fail(nullptr, 1, "null context");
+  if (k < 0 || k >= K_COUNT) return fail(c, 70, "pk_profile_read: bad kernel id %d", k);
+  for (auto& ev : c->pending[k]) {
+    float ms = 0.f;
+    PK_HIP(c, hipEventSynchronize(ev.b));
+    PK_HIP(c, hipEventElapsedTime(&ms, ev.a, ev.b));
+    c->total_ms[k] += ms;
+    c->launches[k] += 1;
+    c->free_events.push_back(ev);
+  }
+  c->pending[k].clear();
+  if (launches) *launches = c->launches[k];
+  if (total_ms) *total_ms = c->total_ms[k];
+  return 0;
+}
+
+}  // extern "C"

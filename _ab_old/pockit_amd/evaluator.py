@@ -1,0 +1,508 @@
+"""GPU evaluator of one transcribed system: plan -> code object + device tables -> callbacks.
+
+``Evaluator(plan)`` generates the model's HIP source, compiles (or fetches from cache) its gfx950
+code object, flattens the mesh-dependent tables into the blobs of csrc/pk_abi.h, uploads
+everything through the C ABI and then serves the five NLP callbacks with host NumPy arrays
+(pk_eval_*), or with device pointers and a stream for callers that keep data resident (pk_eval_*_dev).
+
+Mirrors the callback semantics of /root/reference/pockit/base/systembase.py:602-835: callbacks
+return freshly allocated float64 arrays; ``x`` is borrowed and never written.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+import os
+
+import numpy as np
+
+from . import hipbuild, runtime
+from .codegen import ModelSource
+from .transcription import SystemPlan
+
+TARGET_TILES = int(os.environ.get("POCKIT_AMD_TARGET_TILES", "384"))
+
+
+def _intervals_per_wave(plan, override=None, shards=1):
+    """Intervals per wavefront: as few as keeps ~TARGET_TILES tiles (x 3 wave roles in the single-launch
+    cycle) in flight, up to 64 nodes per wave (Layout.tiles caps it).  Measured on MI355X with pk_cycle
+    (tools/ipw_sweep.sh): at 12k nodes the cycle is bound by the number of vector-memory
+    instructions a CU has to issue and by the time the dispatcher needs to start the waves, so fuller waves
+    (18-42 nodes: 126-133k cycles/s) beat many small ones (12 nodes: 114k, 6 nodes: 81k) as long as every CU
+    still gets work; the 40k-node humanoid runs best with full 64-node waves."""
+    if override:
+        return int(override)
+    env = os.environ.get("POCKIT_AMD_IPW")
+    if env:
+        return int(env)
+    n_int = sum(pp.layout.N for pp in plan.phase_plans)
+    return max(1, math.ceil(n_int / (TARGET_TILES * max(1, int(shards)))))      # (a shard holds 1 / shards of the tiles)
+
+
+def magic_number(d: int) -> int:
+    """32-bit magic of the divisor ``d`` for the kernels' ``magic_div`` (pk_kernels.hip.h):
+    ``p // d == (p * magic) >> 32`` for ``p < 2**16`` with ``magic = ceil(2**32 / d)``.  ``d == 1`` has no 32-bit magic
+    (2**32): it is encoded as 0 and the kernel returns ``p`` itself; ``d == 0`` (nothing to divide) is 0 as well."""
+    if d <= 1:
+        return 0
+    return (0xFFFFFFFF // d + 1) & 0xFFFFFFFF
+
+
+def magic_div(p: int, magic: int) -> int:
+    """Host model of the device function of the same name (used by the tests)."""
+    return p if magic == 0 else (p * magic) >> 32
+
+
+class Tables:
+    """Mesh-dependent tables of a plan in the layout of csrc/pk_abi.h (host NumPy arrays).
+
+    ``tile_filter(phase_index, tiles) -> tiles`` lets a rank keep only its shard of the tiles."""
+
+    def __init__(self, plan: SystemPlan, src: ModelSource, intervals_per_wave=None, tile_filter=None):
+        ib, db, lb = [], [], []
+
+        def put(store, arr, dtype):
+            arr = np.asarray(arr, dtype=dtype).ravel()
+            off = sum(len(a) for a in store)
+            store.append(arr)
+            return off
+
+        nP = len(plan.phase_plans)
+        phases = np.zeros(nP, dtype=runtime.PHASE_DTYPE)
+        kinds, tiles = [], []
+        ipw = _intervals_per_wave(plan, intervals_per_wave)
+        for k, pp in enumerate(plan.phase_plans):
+            lay = pp.layout
+            kind0 = len(kinds)
+            for kd in lay.kinds:
+                rec = np.zeros((), dtype=runtime.KIND_DTYPE)
+                rec["K"], rec["R"], rec["nnzI"], rec["nnzT"] = kd.K, kd.R, kd.nnzI, kd.nnzT
+                rec["irc_off"] = put(ib, np.stack([kd.I_r, kd.I_c], axis=1) if kd.nnzI else np.zeros((0, 2)), np.int32)
+                rec["iv_off"] = put(db, kd.I_v, np.float64)
+                rec["tv_off"] = put(db, kd.T_v, np.float64)
+                rec["full_off"] = put(db, kd.full, np.float64)
+                kinds.append(rec)
+            tl = lay.tiles(ipw)
+            if tile_filter is not None:
+                tl = tile_filter(k, tl)
+            ph = phases[k]
+            ph["scheme"] = 0 if lay.scheme == "lgr" else 1
+            ph["n_x"], ph["n_u"], ph["n_c"] = pp.nx, pp.nu, pp.phase.n_c
+            ph["L_m"], ph["L_d"], ph["state_len"], ph["L"] = lay.L_m, lay.L_d, lay.state_len, lay.L
+            ph["x_off"], ph["g_off"], ph["path_off"] = plan.l_p[k], plan.g_off[k], plan.path_off[k]
+            ph["mid_lo"], ph["mid_hi"] = lay.mid_lo, lay.mid_hi
+            ph["tile_lo"], ph["tile_hi"] = len(tiles), len(tiles) + len(tl)
+            ph["tau_off"] = put(db, lay.tau, np.float64)
+            ph["w_off"] = put(db, lay.w, np.float64)
+            ph["width_off"] = put(db, lay.width, np.float64)
+            ph["n_int"] = lay.N
+            ph["ivK_off"] = put(ib, lay.K, np.int32)
+            ph["ivld_off"] = put(ib, lay.ld, np.int32)
+            full_pos = [int(kinds[kind0 + int(kf)]["full_off"]) for kf in lay.kid_full]
+            ph["ivfull_off"] = put(ib, full_pos, np.int32)
+            cbs = [("jac", "jseg_off"), ("hess", "hseg_off"), ("aux", "aseg_off")]
+            if src.compact:
+                cbs.append(("hessc", "hcseg_off"))
+            for cbname, field in cbs:
+                segs = getattr(plan, cbname).segs[k]
+                bases = [s.base for s in segs if s.kind == "I"] + [s.base for s in segs if s.kind == "N"]
+                ph[field] = put(lb, bases, np.int64)
+            ph["jt_off"] = put(lb, plan.jac.tconst[k], np.int64)
+            red = [plan.l_p[k] + s if s >= 0 else plan.r_s + s for s in plan.grad_red_slots[k]]
+            ph["red_off"] = put(ib, red, np.int32)
+            for row in tl:
+                j0, nj, kid, kidf, q0, r0, offI, offT = (int(v) for v in row)
+                rec = np.zeros((), dtype=runtime.TILE_DTYPE)
+                rec["phase"], rec["j0"], rec["nj"] = k, j0, nj
+                rec["kid"], rec["kidf"] = kind0 + kid, kind0 + kidf
+                rec["q0"], rec["r0"], rec["offI"], rec["offT"] = q0, r0, offI, offT
+                rec["K"] = int(lay.K[j0])
+                rec["last"] = 1 if j0 + nj == lay.N else 0
+                for f in ("nnzI", "nnzT", "irc_off", "iv_off", "tv_off"):
+                    rec[f] = kinds[kind0 + kid][f]
+                rec["full_off"] = kinds[kind0 + kidf]["full_off"]
+                R = int(kinds[kind0 + kidf]["R"])
+                for field, d in (("magicI", int(rec["nnzI"])), ("magicR", R), ("magicT", int(rec["nnzT"]))):
+                    rec[field] = magic_number(d)
+                tiles.append(rec)
+            while len(tiles) % runtime.WAVES_PER_BLOCK:      # a workgroup never mixes phases: pad with empty tiles
+                rec = np.zeros((), dtype=runtime.TILE_DTYPE)
+                rec["phase"], rec["K"] = k, 1
+                tiles.append(rec)
+            ph["tile_hi"] = len(tiles)
+        # gradient slots no tile writes: state end slots (LGR), t0/tf, static parameters
+        gz = []
+        for k, pp in enumerate(plan.phase_plans):
+            lay = pp.layout
+            if lay.scheme == "lgr":
+                gz += [plan.l_p[k] + lay.l_v[i] + lay.L_m for i in range(pp.nx)]
+            gz += [plan.l_p[k] + lay.L - 2, plan.l_p[k] + lay.L - 1]
+        gz += list(range(plan.l_s, plan.r_s))
+        self.gz_off, self.n_gz = put(ib, gz, np.int32), len(gz)
+
+        def items(cbname):
+            cb = getattr(plan, cbname)
+            off = src.list_off[cbname]
+            arr = np.zeros(len(cb.items), dtype=runtime.ITEM_DTYPE)
+            for i, it in enumerate(cb.items):
+                arr[i] = (it.pos, it.coef, off[it.lst] + it.eid, it.lam)
+            return arr
+
+        self.items_jac, self.items_hess, self.items_aux = items("jac"), items("hess"), items("aux")
+        self.items_hessc = items("hessc") if src.compact else np.zeros(0, dtype=runtime.ITEM_DTYPE)
+        self.outer = np.zeros(len(plan.outer), dtype=runtime.OUTER_DTYPE)
+        for i, b in enumerate(plan.outer):
+            flags = (1 if b.tril else 0) | (2 if b.collapseA else 0) | (4 if b.collapseB else 0) | (8 if b.second else 0)
+            self.outer[i] = (b.pos, b.offA, b.lenA, b.offB, b.lenB, b.offM, flags, b.count, 0)
+        self.phases = phases
+        self.kinds = np.array(kinds, dtype=runtime.KIND_DTYPE) if kinds else np.zeros(0, runtime.KIND_DTYPE)
+        self.tiles = np.array(tiles, dtype=runtime.TILE_DTYPE) if tiles else np.zeros(0, runtime.TILE_DTYPE)
+        cat = lambda store, dt: np.concatenate(store).astype(dt) if store else np.zeros(0, dt)  # noqa: E731
+        self.ib, self.db, self.lb = cat(ib, np.int32), cat(db, np.float64), cat(lb, np.int64)
+        self.intervals_per_wave = ipw
+
+
+class Evaluator:
+    def __init__(self, plan: SystemPlan, device: int = 0, intervals_per_wave=None, tile_filter=None):
+        self.plan = plan
+        self.src = ModelSource(plan)
+        # (compiled before the context is created: a box without a GPU -- the build container -- can still fill the
+        # code-object cache by constructing evaluators, tools/warm_cache.sh)
+        code = hipbuild.compile_model(self.src.source, fastmath=plan.system._fastmath)
+        self.ctx = runtime.Context(device)            # raises RuntimeError without a GPU
+        lib, h = self.ctx.lib, self.ctx.handle
+        md = runtime.ModelDesc()
+        md.n_phase, md.n_I, md.nred = self.src.nphase, max(len(plan.I_syms), 1), self.src.nred
+        md.lds_g, md.lds_j, md.lds_h, md.lds_x = self.src.lds_g, self.src.lds_j, self.src.lds_h, self.src.lds_x
+        md.ne_j, md.ne_h = self.src.list_off["jac"]["total"], self.src.list_off["hess"]["total"]
+        md.ne_a = self.src.list_off["aux"]["total"]
+        md.ne_hc = self.src.list_off["hessc"]["total"] if self.src.compact else 0
+        md.lds_e = self.src.lds_e
+        self._err_views = None
+        self._csr = {}
+        md.prepass_f = 1
+        md.prepass_grad = int(plan.needs_I_grad)
+        md.prepass_g = int(plan.needs_I_con)
+        md.prepass_jac = int(plan.jac.needs_I)
+        md.prepass_hess = int(plan.hess.needs_I)
+        self._code = code
+        self._views = {}
+        self._ring, self._own, self._handed = None, {}, set()
+        self.zero_copy = False   # True: callbacks return views of pinned buffers (set by the IPOPT adapter)
+        self.ctx.check(lib.pk_load_model(h, code, len(code), C.byref(md)))
+        self.model_desc = md
+        self.set_tables(Tables(plan, self.src, intervals_per_wave, tile_filter))
+
+    def set_tables(self, tb: Tables):
+        plan, lib, h = self.plan, self.ctx.lib, self.ctx.handle
+        self.tables = tb
+        self._views = {}
+        self._ring, self._own, self._handed = None, {}, set()
+        pd = runtime.ProblemDesc()
+        pd.n, pd.m, pd.n_sys, pd.n_s, pd.l_s = plan.n, plan.m, plan.n_sys, plan.n_s, plan.l_s
+        pd.n_phase, pd.n_tiles, pd.n_kinds = len(tb.phases), len(tb.tiles), len(tb.kinds)
+        pd.nnz_J, pd.nnz_H = plan.nnz_J, plan.nnz_H
+        vp = lambda a: a.ctypes.data_as(C.c_void_p)  # noqa: E731
+        pd.phases, pd.tiles, pd.kinds = vp(tb.phases), vp(tb.tiles), vp(tb.kinds)
+        pd.items_jac, pd.n_items_jac = vp(tb.items_jac), len(tb.items_jac)
+        pd.items_hess, pd.n_items_hess = vp(tb.items_hess), len(tb.items_hess)
+        pd.ib, pd.n_ib = tb.ib.ctypes.data_as(runtime.c_int32_p), len(tb.ib)
+        pd.db, pd.n_db = tb.db.ctypes.data_as(runtime.c_double_p), len(tb.db)
+        pd.lb, pd.n_lb = tb.lb.ctypes.data_as(C.POINTER(C.c_int64)), len(tb.lb)
+        pd.gz_off, pd.n_gz = tb.gz_off, tb.n_gz
+        pd.items_aux, pd.n_items_aux = vp(tb.items_aux), len(tb.items_aux)
+        pd.outer, pd.n_outer, pd.n_aux = vp(tb.outer), len(tb.outer), plan.n_aux
+        pd.items_hessc, pd.n_items_hessc = vp(tb.items_hessc), len(tb.items_hessc)
+        pd.nnz_Hc = plan.nnz_Hc if self.src.compact else 0
+        self._struct = [np.ascontiguousarray(a, dtype=np.int32) for a in
+                        (plan.jac_row, plan.jac_col, plan.hess_row, plan.hess_col)]
+        pd.jac_row, pd.jac_col, pd.hess_row, pd.hess_col = (a.ctypes.data_as(runtime.c_int32_p) for a in self._struct)
+        self.ctx.check(lib.pk_set_problem(h, C.byref(pd)))
+
+    def close(self):
+        if self.ctx is not None:
+            self.ctx.close()
+            self.ctx = None
+
+    # ------------------------------------------------------------------ host-array callbacks
+    def _x(self, x):
+        x = np.ascontiguousarray(x, dtype=np.float64)
+        if x.shape != (self.plan.n,):
+            raise ValueError(f"x must have shape ({self.plan.n},)")
+        return x
+
+    # IPOPT calls objective / gradient / constraints / jacobian one after the other on the same iterate and then
+    # hessian with new multipliers (the five methods optimizer/ipopt.py hands to cyipopt; reference ipopt.py:41-53):
+    # the first call on a new x uploads it, runs the fused x-kernel and queues the copies of all four results into
+    # pinned host memory (pk_prepare_x); every callback then only waits for its own result (pk_fetch).
+    #
+    # Where results land: ``zero_copy`` (set by the IPOPT adapter: cyipopt copies a result at once) hands out views of
+    # the context's pinned buffers, valid until the next iterate.  Otherwise the callbacks return arrays the caller
+    # owns, as the reference's do -- but over pinned memory the DMA writes directly (runtime.PinnedRing): an array is
+    # recycled only when the caller no longer refers to it.
+    def _rings(self):
+        if self._ring is None:
+            p = self.plan
+            self._ring = [runtime.PinnedRing(c) for c in (1, p.n, p.m, p.nnz_J, p.nnz_H)]
+        return self._ring
+
+    def _targets(self, whats):
+        """Pinned arrays of the caller's own for the results ``whats`` of the next evaluation (None: ring exhausted)."""
+        rings = self._rings()
+        return {w: rings[w].take() for w in whats}
+
+    def _set_targets(self, arrs):
+        ptr = [runtime.as_dp(arrs[w]) if arrs.get(w) is not None else None for w in range(5)]
+        self.ctx.check(self.ctx.lib.pk_set_result_targets(self.ctx.handle, *ptr))
+
+    def _prepare(self, x):
+        x = self._x(x)
+        lib, h = self.ctx.lib, self.ctx.handle
+        if lib.pk_same_x(h, runtime.as_dp(x)):
+            return
+        if self.zero_copy:
+            if self._own:
+                self.ctx.check(lib.pk_set_result_targets(h, None, None, None, None, None))
+            self._own = {}
+        else:
+            self._own = self._targets((0, 1, 2, 3))
+            self._set_targets(self._own)
+        self._handed = set()
+        self.ctx.check(lib.pk_prepare_x(h, runtime.as_dp(x)))
+
+    def _invalidate_x(self):
+        """The context's x / result buffers are about to be used by an entry point outside the prepared-x protocol."""
+        if self.ctx is not None:
+            self.ctx.lib.pk_invalidate_x(self.ctx.handle)
+
+    def _pinned(self, what):
+        """NumPy view of the context's pinned result buffer ``what`` (0 f, 1 grad, 2 g, 3 jac, 4 hess)."""
+        if what not in self._views:
+            ptr, cnt = runtime.c_double_p(), C.c_int64()
+            self.ctx.check(self.ctx.lib.pk_host_buffer(self.ctx.handle, what, C.byref(ptr), C.byref(cnt)))
+            self._views[what] = np.ctypeslib.as_array(ptr, shape=(max(cnt.value, 1),))[: cnt.value]
+        return self._views[what]
+
+    def _result(self, what, count):
+        """The array result ``what`` landed in (after its wait), as the callback's return value."""
+        own = self._own.get(what)
+        if own is None:                      # landed in the context's buffer: zero-copy mode, or the ring is exhausted
+            view = self._pinned(what)[:count]           # (the caller keeps many results): plain array + host copy
+            return view if self.zero_copy else view.copy()
+        if self.zero_copy:
+            return own
+        if what in self._handed:             # asked twice for the same iterate: the first array is the caller's
+            return own.copy()
+        self._handed.add(what)
+        return own
+
+    def _fetch(self, what, count):
+        self.ctx.check(self.ctx.lib.pk_fetch(self.ctx.handle, what, None))
+        return self._result(what, count)
+
+    def objective(self, x):
+        self._prepare(x)
+        self.ctx.check(self.ctx.lib.pk_fetch(self.ctx.handle, 0, None))
+        own = self._own.get(0)
+        return np.float64((own if own is not None else self._pinned(0))[0])
+
+    def gradient(self, x):
+        self._prepare(x)
+        return self._fetch(1, self.plan.n)
+
+    def constraints(self, x):
+        self._prepare(x)
+        return self._fetch(2, self.plan.m)
+
+    def jacobian(self, x):
+        self._prepare(x)
+        return self._fetch(3, self.plan.nnz_J)
+
+    def hessian(self, x, lagrange, obj_factor):
+        lam = np.ascontiguousarray(lagrange, dtype=np.float64)
+        if lam.shape != (self.plan.m,):
+            raise ValueError(f"lagrange must have shape ({self.plan.m},)")
+        self._prepare(x)
+        lib, h = self.ctx.lib, self.ctx.handle
+        self._own[4] = None if self.zero_copy else self._rings()[4].take()
+        self._set_targets(self._own)
+        self._handed.discard(4)
+        self.ctx.check(lib.pk_eval_hess_prepared(h, runtime.as_dp(lam), float(obj_factor), None))
+        return self._result(4, self.plan.nnz_H)
+
+    def set_host_mode(self, prefetch=True, host_direct=False):
+        """``prefetch`` (default True): all four x-results are copied to the host right behind the kernel; False: f and
+        g always, grad f and J when first asked for.  ``host_direct``: the kernels store into pinned host memory
+        themselves instead of device memory + DMA (A/B switch)."""
+        self.ctx.check(self.ctx.lib.pk_set_host_mode(self.ctx.handle, int(bool(prefetch)), int(bool(host_direct))))
+
+    # one-shot variants without the x cache (each uploads x and runs only its own kernels)
+    def objective_direct(self, x):
+        x = self._x(x)
+        self._invalidate_x()        # the context's x / result buffers are about to hold another iterate
+        out = np.empty(1)
+        self.ctx.check(self.ctx.lib.pk_eval_f(self.ctx.handle, runtime.as_dp(x), runtime.as_dp(out)))
+        return np.float64(out[0])
+
+    def gradient_direct(self, x):
+        x = self._x(x)
+        self._invalidate_x()        # the context's x / result buffers are about to hold another iterate
+        out = np.empty(self.plan.n)
+        self.ctx.check(self.ctx.lib.pk_eval_grad(self.ctx.handle, runtime.as_dp(x), runtime.as_dp(out)))
+        return out
+
+    def constraints_direct(self, x):
+        x = self._x(x)
+        self._invalidate_x()        # the context's x / result buffers are about to hold another iterate
+        out = np.empty(self.plan.m)
+        self.ctx.check(self.ctx.lib.pk_eval_g(self.ctx.handle, runtime.as_dp(x), runtime.as_dp(out)))
+        return out
+
+    def jacobian_direct(self, x):
+        x = self._x(x)
+        self._invalidate_x()        # the context's x / result buffers are about to hold another iterate
+        out = np.empty(self.plan.nnz_J)
+        self.ctx.check(self.ctx.lib.pk_eval_jac(self.ctx.handle, runtime.as_dp(x), runtime.as_dp(out)))
+        return out
+
+    def hessian_direct(self, x, lagrange, obj_factor):
+        x = self._x(x)
+        self._invalidate_x()        # the context's x / result buffers are about to hold another iterate
+        lam = np.ascontiguousarray(lagrange, dtype=np.float64)
+        out = np.empty(self.plan.nnz_H)
+        self.ctx.check(self.ctx.lib.pk_eval_hess(self.ctx.handle, runtime.as_dp(x), runtime.as_dp(lam),
+                                                 float(obj_factor), runtime.as_dp(out)))
+        return out
+
+    def hessian_compact(self, x, lagrange, obj_factor):
+        """Values of the compact (coalesced) Hessian layout ``plan.hessc_row/col``."""
+        if not self.src.compact:
+            raise NotImplementedError("compact Hessian layout is not available for this model")
+        x = self._x(x)
+        self._invalidate_x()        # the context's x / result buffers are about to hold another iterate
+        lam = np.ascontiguousarray(lagrange, dtype=np.float64)
+        out = np.empty(self.plan.nnz_Hc)
+        self.ctx.check(self.ctx.lib.pk_eval_hessc(self.ctx.handle, runtime.as_dp(x), runtime.as_dp(lam),
+                                                  float(obj_factor), runtime.as_dp(out)))
+        return out
+
+    def mesh_error(self, x):
+        """Mesh error estimation data of every phase at the NLP point ``x`` (one pk_err launch): a list of
+        ``(T, I)`` with shape (n_x, rows) each -- the two sides of the collocation equation on every interval
+        re-collocated with one more point (reference: phasebase.py:1339-1372)."""
+        from . import refine
+
+        lib, h = self.ctx.lib, self.ctx.handle
+        if self._err_views is None:
+            recs, tables, n_out, views = refine.error_tables(self.plan)
+            self.ctx.check(lib.pk_set_mesh_error_tables(h, recs.ctypes.data, len(recs), runtime.as_dp(tables),
+                                                        len(tables), n_out))
+            self._err_views, self._err_len = views, n_out
+        x = self._x(x)
+        self._invalidate_x()        # the context's x / result buffers are about to hold another iterate
+        T, I = np.empty(self._err_len), np.empty(self._err_len)
+        self.ctx.check(lib.pk_eval_mesh_error(h, runtime.as_dp(x), runtime.as_dp(T), runtime.as_dp(I)))
+        return [(T[o: o + nx * rows].reshape(nx, rows), I[o: o + nx * rows].reshape(nx, rows))
+                for o, nx, rows in self._err_views]
+
+    # ------------------------------------------------------------------ device-resident CSR hand-off
+    def csr_map(self, which):
+        """``CsrMap`` of the Jacobian (``"jac"``) or of the lower triangle of the Hessian of the Lagrangian
+        (``"hess"``, reference layout); built and uploaded on first use."""
+        from .csr import CsrMap
+
+        if which not in ("jac", "hess"):
+            raise ValueError('which must be "jac" or "hess"')
+        if which not in self._csr:
+            plan = self.plan
+            if which == "jac":
+                m = CsrMap(plan.jac_row, plan.jac_col, (plan.m, plan.n))
+            else:
+                m = CsrMap(plan.hess_row, plan.hess_col, (plan.n, plan.n))
+            seg = None if m.seg is None else m.seg.ctypes.data_as(runtime.c_int32_p)
+            self.ctx.check(self.ctx.lib.pk_set_csr_map(self.ctx.handle, 0 if which == "jac" else 1, seg,
+                                                       m.perm.ctypes.data_as(runtime.c_int32_p), m.nnz, m.n_triplets))
+            self._csr[which] = m
+        return self._csr[which]
+
+    def jacobian_csr(self, x):
+        """CSR values of the constraint Jacobian (structure: ``csr_map("jac")``), gathered on the device."""
+        m = self.csr_map("jac")
+        x = self._x(x)
+        self._invalidate_x()        # the context's x / result buffers are about to hold another iterate
+        out = np.empty(m.nnz)
+        self.ctx.check(self.ctx.lib.pk_eval_jac_csr(self.ctx.handle, runtime.as_dp(x), runtime.as_dp(out)))
+        return out
+
+    def hessian_csr(self, x, lagrange, obj_factor):
+        """CSR values of the lower triangle of the Hessian of the Lagrangian (``csr_map("hess")``)."""
+        m = self.csr_map("hess")
+        x = self._x(x)
+        self._invalidate_x()        # the context's x / result buffers are about to hold another iterate
+        lam = np.ascontiguousarray(lagrange, dtype=np.float64)
+        out = np.empty(m.nnz)
+        self.ctx.check(self.ctx.lib.pk_eval_hess_csr(self.ctx.handle, runtime.as_dp(x), runtime.as_dp(lam),
+                                                     float(obj_factor), runtime.as_dp(out)))
+        return out
+
+    def jacobian_csr_dev(self, d_x, d_out, stream=None):
+        self.csr_map("jac")
+        self._invalidate_x()        # (the triplets pass through the context's J buffer)
+        self.ctx.check(self.ctx.lib.pk_eval_jac_csr_dev(self.ctx.handle, d_x, d_out, stream))
+
+    def hessian_csr_dev(self, d_x, d_lam, sigma, d_out, stream=None):
+        self.csr_map("hess")
+        self._invalidate_x()
+        self.ctx.check(self.ctx.lib.pk_eval_hess_csr_dev(self.ctx.handle, d_x, d_lam, float(sigma), d_out, stream))
+
+    def gather_csr_dev(self, which, d_triplets, d_out, stream=None):
+        """Triplet values already on the device (e.g. from ``cycle_dev``) -> CSR values."""
+        self.csr_map(which)
+        self.ctx.check(self.ctx.lib.pk_gather_csr_dev(self.ctx.handle, 0 if which == "jac" else 1, d_triplets, d_out,
+                                                      stream))
+
+    def cycle(self, x, lagrange, obj_factor):
+        """All five outputs on the same x from the single-launch cycle (pk_cycle): returns (f, grad, g, J, H)."""
+        x = self._x(x)
+        self._invalidate_x()        # the context's x / result buffers are about to hold another iterate
+        lam = np.ascontiguousarray(lagrange, dtype=np.float64)
+        self._own = {}
+        out = self._targets(range(5))        # pinned arrays of the caller's own: the five DMAs run at full PCIe rate
+        sizes = (1, self.plan.n, self.plan.m, self.plan.nnz_J, self.plan.nnz_H)
+        f, grad, g, J, H = (out[w] if out[w] is not None else np.empty(sizes[w]) for w in range(5))
+        dp = runtime.as_dp
+        self.ctx.check(self.ctx.lib.pk_eval_cycle(self.ctx.handle, dp(x), dp(lam), float(obj_factor), dp(f), dp(grad),
+                                                  dp(g), dp(J), dp(H)))
+        return np.float64(f[0]), grad, g, J, H
+
+    # ------------------------------------------------------------------ device-pointer API
+    def cycle_dev(self, d_x, d_lam, sigma, d_f, d_grad, d_g, d_jac, d_hess, stream=None):
+        """Enqueue one full callback cycle on device pointers (ints); no synchronization."""
+        self.ctx.check(self.ctx.lib.pk_eval_cycle_dev(self.ctx.handle, d_x, d_lam, float(sigma), d_f, d_grad, d_g,
+                                                      d_jac, d_hess, stream))
+
+    def sync(self, stream=None):
+        self.ctx.check(self.ctx.lib.pk_sync(self.ctx.handle, stream))
+
+    def profile(self, enable=True, period=1):
+        """Time the kernels whose bit is set in ``enable`` with HIP events; only every ``period``-th launch."""
+        self.ctx.check(self.ctx.lib.pk_profile_sampling(self.ctx.handle, int(period)))
+        self.ctx.check(self.ctx.lib.pk_profile(self.ctx.handle, int(enable)))
+
+    def set_cycle_graph(self, enable=True):
+        """Replay the fused cycle from a cached hipGraph (measured slower than plain launches on MI355X /
+        ROCm 7.2 -- DESIGN.md section 5 -- so it is off by default)."""
+        self.ctx.check(self.ctx.lib.pk_set_cycle_graph(self.ctx.handle, int(bool(enable))))
+
+    def set_cycle_mode(self, single_launch=True):
+        """True (default): one cycle = one launch (pk_cycle).  False: pk_xall, then pk_hess with the reductions."""
+        self.ctx.check(self.ctx.lib.pk_set_cycle_mode(self.ctx.handle, int(bool(single_launch))))
+
+    def profile_read(self):
+        """{kernel name: (launches, total_ms)} accumulated while profiling was enabled."""
+        out = {}
+        for k, name in enumerate(runtime.KERNELS):
+            n, ms = C.c_int64(), C.c_double()
+            self.ctx.check(self.ctx.lib.pk_profile_read(self.ctx.handle, k, C.byref(n), C.byref(ms)))
+            out[name] = (n.value, ms.value)
+        return out

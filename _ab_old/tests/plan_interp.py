@@ -1,0 +1,272 @@
+"""NumPy interpreter of the product's evaluation plan (TEST INFRASTRUCTURE).
+
+Executes a ``SystemPlan`` exactly the way the HIP kernels are meant to: per-node segment
+expressions, kind tables scaled by d_j/2, scalar items, lambda gathers -- but with NumPy on the
+host.  It lets the CPU test-suite validate the transcription compiler (layout *and* value
+expressions) against the oracle / golden vectors without a GPU.  Never used by the product.
+"""
+import numpy as np
+import sympy as sp
+
+from pockit_amd.model import FIXED, FREE
+from pockit_amd.transcription import DT, SIG, TAU, WQ, lam_path, lam_sys, ltb_sym, ltf_sym, mu_sym
+
+
+def _bc_value(info, cur, sdict):
+    if info.t == FREE:
+        return cur
+    if info.t == FIXED:
+        return info.v
+    return float(info.v.expr.subs(sdict))
+
+
+class Interp:
+    def __init__(self, plan, x, lam=None, sigma=1.0):
+        self.plan, self.x = plan, np.asarray(x, dtype=np.float64)
+        self.lam = np.zeros(plan.m) if lam is None else np.asarray(lam, dtype=np.float64)
+        self.sigma = sigma
+        self._mu_cache = {}
+        self.s = self.x[plan.l_s: plan.r_s]
+        self.sdict = dict(zip(plan.s_syms, self.s))
+        self.ph = [self._phase_env(k) for k in range(len(plan.phase_plans))]
+        # integrals (only needed when system functions are nonlinear in them)
+        self.Ivals = {}
+        for a, sym in enumerate(plan.I_syms):
+            k, i = plan.I_owner[a]
+            env = self.ph[k]
+            phi = self._eval_nodes(k, [plan.phase_plans[k].integ[i].F], np.arange(env["L_m"]))[0]
+            self.Ivals[sym] = float(np.dot(phi, plan.phase_plans[k].layout.w) * env["dt"])
+
+    def _phase_env(self, k):
+        plan = self.plan
+        pp = plan.phase_plans[k]
+        p, lay = pp.phase, pp.layout
+        xp = self.x[plan.l_p[k]: plan.r_p[k]].copy()
+        for i in range(p.n_x):
+            xp[lay.l_v[i]] = _bc_value(p.info_bc_0[i], xp[lay.l_v[i]], self.sdict)
+            xp[lay.r_v[i] - 1] = _bc_value(p.info_bc_f[i], xp[lay.r_v[i] - 1], self.sdict)
+        xp[-2] = _bc_value(p.info_t_0, xp[-2], self.sdict)
+        xp[-1] = _bc_value(p.info_t_f, xp[-1], self.sdict)
+        dt = xp[-1] - xp[-2]
+        tm = (xp[-1] + xp[-2]) / 2
+        return dict(xp=xp, dt=dt, t=(lay.tau - 0.5) * dt + tm, L_m=lay.L_m, base=pp.base())
+
+    def _eval_nodes(self, k, exprs, q):
+        """Evaluate expressions (with placeholders) on nodes q of phase k."""
+        if not exprs:
+            return []
+        plan = self.plan
+        pp, env = plan.phase_plans[k], self.ph[k]
+        p, lay = pp.phase, pp.layout
+        q = np.asarray(q)
+        vals = {}
+        for i, sym in enumerate(p.x):
+            vals[sym] = env["xp"][lay.l_v[i] + q]
+        for i, sym in enumerate(p.u):
+            vals[sym] = env["xp"][lay.l_v[p.n_x + i] + q]
+        vals[p.t] = env["t"][q]
+        for sym, v in self.sdict.items():
+            vals[sym] = np.full(len(q), v)
+        vals[DT] = np.full(len(q), env["dt"])
+        vals[TAU] = lay.tau[q]
+        vals[WQ] = lay.w[q]
+        vals[SIG] = np.full(len(q), self.sigma)
+        for c in range(plan.n_sys):
+            vals[lam_sys(c)] = np.full(len(q), self.lam[c])
+        for j in range(p.n_c):
+            vals[lam_path(j)] = self.lam[plan.path_off[k] + j * lay.L_m + q]
+        for sym, v in self.Ivals.items():
+            vals[sym] = np.full(len(q), v)
+        mu = self._mu(k)
+        for i in range(p.n_x):
+            vals[mu_sym(i)] = mu[i][q]
+            r0 = plan.g_off[k] + lay.l_d[i]
+            vals[ltf_sym(i)] = np.full(len(q), float(np.dot(lay.Tf_val, self.lam[r0 + lay.Tf_row])))
+            vals[ltb_sym(i)] = np.full(len(q), float(np.dot(lay.Tb_val, self.lam[r0 + lay.Tb_row])))
+        syms = list(vals)
+        full = [sp.sympify(e).subs(env["base"]) for e in exprs]
+        fn = sp.lambdify(syms, full, modules="numpy")
+        out = fn(*[vals[s_] for s_ in syms])
+        return [np.broadcast_to(np.asarray(o, dtype=np.float64), q.shape) for o in out]
+
+    def _mu(self, k):
+        """mu_i(node) = sum over the intervals holding the node of sum_r (I_hat d/2)[r, c] * lambda[row]."""
+        if k not in self._mu_cache:
+            plan = self.plan
+            pp = plan.phase_plans[k]
+            lay = pp.layout
+            mu = np.zeros((pp.nx, lay.L_m))
+            for j in range(lay.N):
+                A = lay.kinds[lay.kid_full[j]].full * lay.width[j] * 0.5
+                nodes = lay.lm[j] + np.arange(int(lay.K[j]))
+                for i in range(pp.nx):
+                    lam = self.lam[plan.g_off[k] + lay.l_d[i] + lay.ld[j] + np.arange(A.shape[0])]
+                    mu[i, nodes] += A.T @ lam
+            self._mu_cache[k] = mu
+        return self._mu_cache[k]
+
+    def _eval_sys(self, exprs):
+        vals = dict(self.sdict)
+        vals.update(self.Ivals)
+        vals[SIG] = self.sigma
+        for c in range(self.plan.n_sys):
+            vals[lam_sys(c)] = self.lam[c]
+        return [float(sp.sympify(e).subs(vals)) for e in exprs]
+
+    def _run(self, cb, nnz, with_lambda, complete=True):
+        plan = self.plan
+        out = np.full(nnz, np.nan)
+        for k, pp in enumerate(plan.phase_plans):
+            lay = pp.layout
+            if cb is plan.jac:
+                _, _, tv = lay.T_mid_structure()
+                for base in cb.tconst[k]:
+                    out[base: base + lay.nnzT_mid] = tv
+            q_all = np.arange(lay.L_m)
+            sv = self._eval_nodes(k, [s.expr for s in cb.segs[k]], q_all)
+            Ir, Ic = lay.I_mid_structure()
+            Iv = np.concatenate([lay.kinds[lay.kid[j]].I_v * lay.width[j] * 0.5 for j in range(lay.N)])
+            for seg, v in zip(cb.segs[k], sv):
+                if seg.kind == "I":
+                    val = -Iv * v[Ic]
+                    if with_lambda:
+                        val = val * self.lam[plan.g_off[k] + lay.l_d[seg.state] + Ir]
+                    out[seg.base: seg.base + lay.nnzI_mid] = val
+                else:
+                    out[seg.base: seg.base + lay.L_mid] = v[lay.mid_lo: lay.mid_hi]
+        E = {}
+        for key, exprs in cb.lists.items():
+            if key[0] == "s":
+                E[key] = self._eval_sys(exprs)
+            else:
+                k = key[1]
+                qn = 0 if key[0] == "f" else plan.phase_plans[k].layout.L_m - 1
+                E[key] = [float(v[0]) for v in self._eval_nodes(k, exprs, [qn])]
+        for it in cb.items:
+            v = it.coef * E[it.lst][it.eid]
+            if it.lam >= 0:
+                v *= self.lam[it.lam]
+            out[it.pos] = v
+        if complete:
+            assert not np.isnan(out).any(), "plan does not cover every output slot"
+        return out
+
+    def jacobian(self):
+        return self._run(self.plan.jac, self.plan.nnz_J, False)
+
+    def hessian(self):
+        plan = self.plan
+        out = self._run(plan.hess, plan.nnz_H, True, complete=not plan.outer)
+        if plan.outer:
+            gi = self._run(plan.aux, plan.n_aux, False)          # integral gradient entries x w, multipliers
+            for b in plan.outer:
+                A, B, m = gi[b.offA: b.offA + b.lenA], gi[b.offB: b.offB + b.lenB], gi[b.offM]
+                if not b.tril:
+                    vals = np.kron(A, B) * m
+                else:
+                    A2 = np.array([A.sum()]) if b.collapseA else A
+                    B2 = np.array([B.sum()]) if b.collapseB else B
+                    tr, tc = np.tril_indices(len(A2))
+                    vals = A2[tr] * B2[tc] * m
+                    if b.second:
+                        vals = np.concatenate([vals, B2[tr] * A2[tc] * m])
+                assert len(vals) == b.count
+                out[b.pos: b.pos + b.count] = vals
+            assert not np.isnan(out).any(), "plan does not cover every output slot"
+        return out
+
+    def hessian_compact(self):
+        plan = self.plan
+        cb = plan.hessc
+        return self._run(cb, plan.nnz_Hc, False)
+
+    def objective(self):
+        return self._eval_sys([self.plan.F_o.expr])[0]
+
+    def constraints(self):
+        plan = self.plan
+        g = np.empty(plan.m)
+        g[: plan.n_sys] = self._eval_sys([f.expr for f in plan.F_c])
+        for k, pp in enumerate(plan.phase_plans):
+            lay, env = pp.layout, self.ph[k]
+            q = np.arange(lay.L_m)
+            F = self._eval_nodes(k, [fr.F for fr in pp.dyn], q)
+            for i in range(pp.nx):
+                xs = env["xp"][lay.l_v[i]: lay.r_v[i]]
+                for j in range(lay.N):
+                    kd = lay.kinds[lay.kid_full[j]]
+                    A = kd.full * lay.width[j] * 0.5
+                    r0 = plan.g_off[k] + lay.l_d[i] + lay.ld[j]
+                    nodes = lay.lm[j] + np.arange(int(lay.K[j]))
+                    end = lay.lm[j] + (int(lay.K[j]) if lay.scheme == "lgr" else int(lay.K[j]) - 1)
+                    rows = np.arange(kd.R)
+                    g[r0 + rows] = (xs[lay.lm[j] + rows] - xs[end]) - (A @ F[i][nodes]) * env["dt"]
+            C = self._eval_nodes(k, [fr.F for fr in pp.path], q)
+            for j, c in enumerate(C):
+                g[plan.path_off[k] + j * lay.L_m + q] = c
+        return g
+
+    def gradient(self):
+        plan = self.plan
+        grad = np.zeros(plan.n)
+        for k, pp in enumerate(plan.phase_plans):
+            lay = pp.layout
+            nodes = {"f": np.array([0]), "m": np.arange(lay.mid_lo, lay.mid_hi), "b": np.array([lay.L_m - 1])}
+            for w in pp.where:
+                q = nodes[w]
+                if len(q) == 0:
+                    continue
+                vals = self._eval_nodes(k, plan.grad_var[k][w], q)
+                for a, v in enumerate(vals):
+                    grad[plan.l_p[k] + lay.l_v[a] + q] += v
+                slots = list(plan.grad_red[k][w])
+                vals = self._eval_nodes(k, [plan.grad_red[k][w][s_] for s_ in slots], q)
+                for s_, v in zip(slots, vals):
+                    grad[plan.l_p[k] + s_ if s_ >= 0 else plan.r_s + s_] += v.sum()
+        for i, m in plan.grad_static.items():
+            grad[plan.l_s + i] += self._eval_sys([m])[0]
+        return grad
+
+
+def mesh_error(plan, x):
+    """NumPy execution of the error-estimation tables exactly as the device kernel pk_err decodes them
+    (csrc/pk_kernels.hip.h interval_err): per interval stage x/u, interpolate to the augmented nodes, evaluate the
+    dynamics, apply the T and I blocks.  Returns [(T, I)] per phase, shape (n_x, rows)."""
+    from pockit_amd import refine
+
+    it = Interp(plan, x)
+    recs, tab, n_out, views = refine.error_tables(plan)
+    outT, outI = np.zeros(n_out), np.zeros(n_out)
+    for rec in recs:
+        K = int(rec["K"])
+        if K == 0:
+            continue
+        k = int(rec["phase"])
+        pp, env = plan.phase_plans[k], it.ph[k]
+        p, lay = pp.phase, pp.layout
+        sch = 0 if lay.scheme == "lgr" else 1
+        ncx, na, nr = K + 1 - sch, K + 1, K + 1 - sch
+        o = int(rec["tab_off"])
+        Vx = tab[o: o + na * ncx].reshape(na, ncx); o += na * ncx
+        Vu = tab[o: o + na * K].reshape(na, K); o += na * K
+        Tm = tab[o: o + nr * ncx].reshape(nr, ncx); o += nr * ncx
+        Im = tab[o: o + nr * na].reshape(nr, na)
+        tau = tab[int(rec["tau_off"]): int(rec["tau_off"]) + na]
+        lm = int(rec["lm"])
+        xs = [env["xp"][lay.l_v[i] + lm: lay.l_v[i] + lm + ncx] for i in range(p.n_x)]
+        us = [env["xp"][lay.l_v[p.n_x + i] + lm: lay.l_v[p.n_x + i] + lm + K] for i in range(p.n_u)]
+        vals = {sym: Vx @ xs[i] for i, sym in enumerate(p.x)}
+        vals.update({sym: Vu @ us[i] for i, sym in enumerate(p.u)})
+        tm = (env["xp"][-1] + env["xp"][-2]) / 2
+        vals[p.t] = (tau - 0.5) * env["dt"] + tm
+        for sym, v in it.sdict.items():
+            vals[sym] = np.full(na, v)
+        syms = list(vals)
+        fn = sp.lambdify(syms, [sp.sympify(fr.F).subs(env["base"]) for fr in pp.dyn], modules="numpy")
+        f = [np.broadcast_to(np.asarray(v, dtype=np.float64), (na,)) for v in fn(*[vals[s_] for s_ in syms])]
+        for i in range(p.n_x):
+            pos = int(rec["out_off"]) + i * int(rec["rows"]) + int(rec["row0"])
+            outT[pos: pos + nr] = Tm @ xs[i]
+            outI[pos: pos + nr] = ((Im * rec["width"] * 0.5) @ f[i]) * env["dt"]
+    return [(outT[o: o + nx * rows].reshape(nx, rows), outI[o: o + nx * rows].reshape(nx, rows))
+            for o, nx, rows in views]

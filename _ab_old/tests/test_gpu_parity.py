@@ -1,0 +1,996 @@
+"""GPU parity: the HIP evaluator (through the C ABI) against golden vectors of the reference and
+against the oracle, on identical inputs.  Tolerance: structures exact,
+values |a-b| <= 1e-11 * max(1, max|b|) per array (fp64; libm ulps, fused multiply-add,
+reduction order)."""
+import os
+
+import numpy as np
+import pytest
+
+import models
+
+pytestmark = pytest.mark.gpu
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+TOL = 1e-11
+
+
+def close(a, b, tol=TOL, what=""):
+    a, b = np.asarray(a, dtype=np.float64), np.asarray(b, dtype=np.float64)
+    assert a.shape == b.shape, what
+    if a.size:
+        err = np.max(np.abs(a - b))
+        assert err <= tol * max(1.0, np.max(np.abs(b))), f"{what}: err {err:.3e}"
+
+
+def _ns(scheme, pkg):
+    import importlib
+
+    return importlib.import_module(f"{pkg}.{scheme}")
+
+
+def _supported(name):
+    return True
+
+
+@pytest.mark.parametrize("name", sorted(n for n in models.SMALL_CASES if _supported(n)))
+def test_small_case_matches_reference_golden(name):
+    builder, scheme, kw = models.SMALL_CASES[name]
+    gold = np.load(os.path.join(HERE, "golden", "small", name + ".npz"))
+    system, _, _ = builder(_ns(scheme, "pockit_amd"), **kw)
+    x, lam, sigma = gold["x"], gold["lam"], float(gold["sigma"])
+    x_before = x.copy()
+    jr, jc = system.jacobianstructure()
+    hr, hc = system.hessianstructure()
+    assert np.array_equal(jr, gold["jr"]) and np.array_equal(jc, gold["jc"])
+    assert np.array_equal(hr, gold["hr"]) and np.array_equal(hc, gold["hc"])
+    close(system.objective(x), gold["f"], what="f")
+    close(system.gradient(x), gold["grad"], what="grad")
+    close(system.constraints(x), gold["g"], what="g")
+    close(system.jacobian(x), gold["J"], what="J")
+    close(system.hessian(x, lam, sigma), gold["H"], what="H")
+    ev = system.evaluator                      # the stand-alone kernels of each callback (no x cache, no fusion)
+    close(ev.objective_direct(x), gold["f"], what="f direct")
+    close(ev.gradient_direct(x), gold["grad"], what="grad direct")
+    close(ev.constraints_direct(x), gold["g"], what="g direct")
+    close(ev.jacobian_direct(x), gold["J"], what="J direct")
+    close(ev.hessian_direct(x, lam, sigma), gold["H"], what="H direct")
+    close(system.hessian_o(x), gold["Ho"], what="Ho")
+    close(system.hessian_c(x, lam), gold["Hc"], what="Hc")
+    assert np.array_equal(x, x_before), "x must not be written"
+
+
+@pytest.mark.parametrize("ipw", [1, 2, 3, 64])
+@pytest.mark.parametrize("case", [("brachistochrone", "radau", dict(mesh=37, num_point=5)),
+                                  ("brachistochrone", "lobatto", dict(mesh=23, num_point=6)),
+                                  ("two_stage_rocket", "radau", dict(mesh=40, num_point=3)),
+                                  ("planar_quadrotor", "lobatto", dict(mesh=19, num_point=4)),
+                                  ("humanoid_wbc", "radau", dict(mesh=9, num_point=7))])
+def test_tilings_match_oracle(case, ipw, monkeypatch):
+    """Every intervals-per-wave tiling (incl. ragged last tiles) gives the oracle's result."""
+    monkeypatch.setenv("POCKIT_AMD_IPW", str(ipw))
+    bname, scheme, kw = case
+    system, _, guess = getattr(models, bname)(_ns(scheme, "pockit_amd"), **kw)
+    ref, _, _ = getattr(models, bname)(_ns(scheme, "oracle"), **kw)
+    x, lam, sigma = models.bench_inputs(system, guess)
+    close(system.objective(x), ref.objective(x), what="f")
+    close(system.gradient(x), ref.gradient(x), what="grad")
+    close(system.constraints(x), ref.constraints(x), what="g")
+    close(system.jacobian(x), ref.jacobian(x), what="J")
+    close(system.hessian(x, lam, sigma), ref.hessian(x, lam, sigma), what="H")
+    # the fused cycle path (one node evaluation for f, grad f, g, J) must give the same five outputs
+    f, grad, g, J, H = system.evaluator.cycle(x, lam, sigma)
+    close(f, ref.objective(x), what="cycle f")
+    close(grad, ref.gradient(x), what="cycle grad")
+    close(g, ref.constraints(x), what="cycle g")
+    close(J, ref.jacobian(x), what="cycle J")
+    close(H, ref.hessian(x, lam, sigma), what="cycle H")
+
+
+@pytest.mark.parametrize("ipw", [1, 3, 7, 64])
+@pytest.mark.parametrize("case", [("brachistochrone", "radau", dict(mesh=83, num_point=1)),      # R = nnzI = 1
+                                  ("brachistochrone", "lobatto", dict(mesh=83, num_point=2)),    # R = 1
+                                  ("two_stage_rocket", "radau", dict(mesh=41, num_point=1)),
+                                  ("planar_quadrotor", "lobatto", dict(mesh=50, num_point=2))])
+def test_unit_divisor_tiles_match_oracle(case, ipw, monkeypatch):
+    """Tiles whose per-interval divisors (defect rows, integration / translation entries) are 1 -- LGR K = 1 and
+    LGL K = 2 -- holding several intervals: the quotient p // 1 has no 32-bit magic number (magic_div)."""
+    monkeypatch.setenv("POCKIT_AMD_IPW", str(ipw))
+    bname, scheme, kw = case
+    system, _, guess = getattr(models, bname)(_ns(scheme, "pockit_amd"), **kw)
+    ref, _, _ = getattr(models, bname)(_ns(scheme, "oracle"), **kw)
+    tiles = system.evaluator.tables.tiles
+    if ipw >= 3:
+        assert tiles["nj"].max() >= 3 and (tiles["magicR"][tiles["nj"] > 0] == 0).all()
+    x, lam, sigma = models.bench_inputs(system, guess)
+    close(system.objective(x), ref.objective(x), what="f")
+    close(system.gradient(x), ref.gradient(x), what="grad")
+    close(system.constraints(x), ref.constraints(x), what="g")
+    close(system.jacobian(x), ref.jacobian(x), what="J")
+    close(system.hessian(x, lam, sigma), ref.hessian(x, lam, sigma), what="H")
+    f, grad, g, J, H = system.evaluator.cycle(x, lam, sigma)
+    close(g, ref.constraints(x), what="cycle g")
+    close(J, ref.jacobian(x), what="cycle J")
+    close(H, ref.hessian(x, lam, sigma), what="cycle H")
+    ev = system.evaluator
+    close(ev.constraints_direct(x), ref.constraints(x), what="g direct")
+    close(ev.jacobian_direct(x), ref.jacobian(x), what="J direct")
+    close(ev.hessian_direct(x, lam, sigma), ref.hessian(x, lam, sigma), what="H direct")
+
+
+def test_prepared_x_cache_is_dropped_by_calls_that_reuse_the_context_buffers():
+    """objective / gradient / constraints / jacobian / hessian on x1 serve from ONE upload of x1; any other entry
+    point that uploads a different x (mesh error, the one-launch cycle, the *_direct and CSR calls) in between must
+    not leave them answering for that other x."""
+    system, _, guess = models.two_stage_rocket(_ns("radau", "pockit_amd"), 60, 4)
+    ref, _, _ = models.two_stage_rocket(_ns("radau", "oracle"), 60, 4)
+    x1, lam, sigma = models.bench_inputs(system, guess)
+    x2 = x1 * (1.0 + 0.05 * np.random.default_rng(11).uniform(-1, 1, x1.shape))
+    ev = system.evaluator
+    want = dict(f=ref.objective(x1), grad=ref.gradient(x1), g=ref.constraints(x1), J=ref.jacobian(x1),
+                H=ref.hessian(x1, lam, sigma))
+    others = [lambda: ev.mesh_error(x2), lambda: ev.cycle(x2, lam, sigma), lambda: ev.gradient_direct(x2),
+              lambda: ev.jacobian_direct(x2), lambda: ev.jacobian_csr(x2), lambda: ev.hessian_csr(x2, lam, sigma),
+              lambda: ev.hessian_compact(x2, lam, sigma), lambda: ev.constraints_direct(x2),
+              lambda: ev.objective_direct(x2), lambda: ev.hessian_direct(x2, lam, sigma)]
+    for other in others:
+        close(system.gradient(x1), want["grad"], what="grad before")
+        other()
+        close(system.hessian(x1, lam, sigma), want["H"], what="H after another x went through the context")
+        other()
+        close(system.jacobian(x1), want["J"], what="J after")
+        other()
+        close(system.gradient(x1), want["grad"], what="grad after")
+        close(system.constraints(x1), want["g"], what="g after")
+        close(system.objective(x1), want["f"], what="f after")
+
+
+def test_ragged_mesh_matches_oracle():
+    """hp-style mesh: every interval its own width and polynomial order (K = 1 .. 9)."""
+    rng = np.random.default_rng(5)
+    K = rng.integers(1, 10, size=31).tolist()
+    mesh = np.concatenate(([0.0], np.cumsum(rng.uniform(0.2, 1.0, size=31)))).tolist()
+    kw = dict(mesh=mesh, num_point=K)
+    system, _, guess = models.brachistochrone(_ns("radau", "pockit_amd"), **kw)
+    ref, _, _ = models.brachistochrone(_ns("radau", "oracle"), **kw)
+    x, lam, sigma = models.bench_inputs(system, guess)
+    close(system.constraints(x), ref.constraints(x), what="g")
+    close(system.gradient(x), ref.gradient(x), what="grad")
+    close(system.jacobian(x), ref.jacobian(x), what="J")
+    close(system.hessian(x, lam, sigma), ref.hessian(x, lam, sigma), what="H")
+
+
+def test_full_size_configs_match_reference_summary():
+    """BASELINE.json configs at full size against the reference's checksums / strided samples."""
+    import json
+
+    full = json.load(open(os.path.join(HERE, "golden", "full.json")))
+    for name in ("C2_brach_lgr_200x8", "S_brach_lgr_1250x8", "C3_quad_lgr_2000x6", "C4_rocket_lgr_2x1000x4",
+                 "C5_humanoid_lgr_5000x8"):
+        gold = full[name]
+        builder, scheme, kw = models.FULL_CASES[name]
+        system, _, guess = builder(_ns(scheme, "pockit_amd"), **kw)
+        x, lam, sigma = models.bench_inputs(system, guess)
+
+        def check(v, S, what):
+            v = np.asarray(v)
+            assert len(v) == S["len"], what
+            scale = max(1.0, S["max"])
+            assert np.max(np.abs(v[np.array(S["idx"])] - np.array(S["samples"]))) <= TOL * scale, what
+            assert abs(v.sum() - S["sum"]) <= 1e-10 * max(1.0, S["sumabs"]), what
+
+        assert (system.plan.nnz_J, system.plan.nnz_H) == (gold["nnz_J"], gold["nnz_H"])
+        assert abs(system.objective(x) - gold["f"]) <= TOL * max(1.0, abs(gold["f"]))
+        check(system.gradient(x), gold["grad"], name + " grad")
+        check(system.constraints(x), gold["g"], name + " g")
+        check(system.jacobian(x), gold["J"], name + " J")
+        check(system.hessian(x, lam, sigma), gold["H"], name + " H")
+        # the benchmarked kernel itself: all five outputs of the ONE-launch cycle (pk_cycle) at the full size
+        f1, grad1, g1, J1, H1 = system.evaluator.cycle(x, lam, sigma)
+        assert abs(f1 - gold["f"]) <= TOL * max(1.0, abs(gold["f"])), name + " cycle f"
+        check(grad1, gold["grad"], name + " cycle grad")
+        check(g1, gold["g"], name + " cycle g")
+        check(J1, gold["J"], name + " cycle J")
+        check(H1, gold["H"], name + " cycle H")
+        system._invalidate()
+
+
+def test_repeated_evaluation_with_changing_x():
+    """The in-launch finalize (per-tile partials handed to the last-arriving workgroup) must see the
+    *current* launch's partials: alternate between two points on one evaluator."""
+    system, _, guess = models.two_stage_rocket(_ns("radau", "pockit_amd"), 300, 4)
+    ref, _, _ = models.two_stage_rocket(_ns("radau", "oracle"), 300, 4)
+    x1, lam, sigma = models.bench_inputs(system, guess)
+    x2 = x1 * (1.0 + 0.05 * np.random.default_rng(7).uniform(-1, 1, x1.shape))
+    want = {id(x): (ref.objective(x), ref.gradient(x)) for x in (x1, x2)}
+    for x in (x1, x2, x1, x2, x2, x1):
+        for _ in range(3):
+            close(system.objective(x), want[id(x)][0], what="f")
+            close(system.gradient(x), want[id(x)][1], what="grad")
+        f, grad, _, _, _ = system.evaluator.cycle(x, lam, sigma)
+        close(f, want[id(x)][0], what="cycle f")
+        close(grad, want[id(x)][1], what="cycle grad")
+
+
+def test_two_shards_on_one_gpu_reassemble_to_the_oracle():
+    """The mesh-interval sharding data path on real kernels: two rank-local evaluators (each holding
+    half of every phase's tiles) run on one GPU; summing their zero-initialised outputs -- what the
+    RCCL all-reduce does across GPUs -- must reproduce the unsharded oracle result."""
+    import ctypes as C
+
+    import torch
+
+    from pockit_amd.evaluator import Evaluator
+    from pockit_amd.sharding import tile_filter
+
+    system, _, guess = models.two_stage_rocket(_ns("radau", "pockit_amd"), 90, 4)
+    ref, _, _ = models.two_stage_rocket(_ns("radau", "oracle"), 90, 4)
+    plan = system.plan
+    x, lam, sigma = models.bench_inputs(system, guess)
+    dev = torch.device("cuda", 0)
+    dx, dlam = torch.from_numpy(x).to(dev), torch.from_numpy(lam).to(dev)
+    world = 2
+    evs, Is, outs = [], [], []
+    for r in range(world):
+        ev = Evaluator(plan, intervals_per_wave=3, tile_filter=tile_filter(r, world))
+        I = torch.zeros(max(len(plan.I_syms), 1), dtype=torch.float64, device=dev)
+        ev.ctx.check(ev.ctx.lib.pk_set_shard(ev.ctx.handle, int(r != 0), 1, C.c_void_p(I.data_ptr())))
+        evs.append(ev)
+        Is.append(I)
+        outs.append({k: torch.zeros(n, dtype=torch.float64, device=dev) for k, n in
+                     (("f", 1), ("grad", plan.n), ("g", plan.m), ("J", plan.nnz_J), ("H", plan.nnz_H))})
+    p = lambda t: C.c_void_p(t.data_ptr())  # noqa: E731
+    torch.cuda.synchronize()             # torch's zero-fills run on its own stream; the contexts use theirs
+    for ev in evs:
+        ev.ctx.check(ev.ctx.lib.pk_eval_integrals_dev(ev.ctx.handle, p(dx), None))
+        ev.sync()
+    total = sum(Is)                      # the all-reduce of the integrals
+    for I in Is:
+        I.copy_(total)
+    torch.cuda.synchronize()
+    for ev, o in zip(evs, outs):
+        lib, h = ev.ctx.lib, ev.ctx.handle
+        ev.ctx.check(lib.pk_eval_f_from_integrals_dev(h, p(dx), p(o["f"]), None))
+        ev.ctx.check(lib.pk_eval_grad_dev(h, p(dx), p(o["grad"]), None))
+        ev.ctx.check(lib.pk_eval_g_dev(h, p(dx), p(o["g"]), None))
+        ev.ctx.check(lib.pk_eval_jac_dev(h, p(dx), p(o["J"]), None))
+        ev.ctx.check(lib.pk_eval_hess_dev(h, p(dx), p(dlam), float(sigma), p(o["H"]), None))
+        ev.sync()
+    close(outs[0]["f"].cpu().numpy()[0], ref.objective(x), what="f")
+    close(outs[1]["f"].cpu().numpy()[0], ref.objective(x), what="f (rank 1)")
+    for k, want in (("grad", ref.gradient(x)), ("g", ref.constraints(x)), ("J", ref.jacobian(x)),
+                    ("H", ref.hessian(x, lam, sigma))):
+        close(sum(o[k] for o in outs).cpu().numpy(), want, what=k)
+        # disjoint support: no position is written by both shards
+        both = (outs[0][k] != 0) & (outs[1][k] != 0)
+        assert int(both.sum()) <= (plan.n_s + 2 * len(plan.phase_plans) if k == "grad" else 0), k
+    for ev in evs:
+        ev.close()
+
+
+def test_scipy_trust_constr_solves_lqr_on_the_gpu_evaluator():
+    """IPOPT-free end-to-end check (cyipopt is not installed): the SciPy adapter drives the GPU callbacks
+    to the LQR optimum (README.md:95-118 model); objective compared with the Riccati solution."""
+    from scipy.integrate import solve_ivp
+
+    from pockit_amd.optimizer import scipy as scipy_solver
+
+    ns = _ns("lobatto", "pockit_amd")
+    system, (phase,), guess = models.lqr(ns, 6, 6)
+    guess = [ns.constant_guess(phase, 0.0), [0.0]]
+    (var, s), res = scipy_solver.solve(system, guess, {"maxiter": 200, "gtol": 1e-10, "xtol": 1e-12})
+    a, b, q, r, sw = -1.0, 1.0, 1.0, 0.1, 1.0
+    ric = solve_ivp(lambda t, P: -(2 * a * P - b * b * P * P / r + q), (1.0, 0.0), [sw / 2], rtol=1e-11, atol=1e-12)
+    optimum = ric.y[0, -1] * 1.0 ** 2
+    assert abs(res.fun - optimum) <= 2e-6 * max(1.0, abs(optimum))
+    assert abs(var.x[0][-1] - s[0]) < 1e-9 and abs(var.x[0][0] - 1.0) < 1e-12
+
+
+@pytest.mark.parametrize("case", [("brachistochrone", "radau", dict(mesh=37, num_point=5)),
+                                  ("brachistochrone", "lobatto", dict(mesh=23, num_point=6)),
+                                  ("brachistochrone", "radau", dict(mesh=[0, 0.1, 0.15, 0.5, 0.9, 1.0], num_point=[3, 7, 2, 5, 1])),
+                                  ("two_stage_rocket", "radau", dict(mesh=40, num_point=3)),
+                                  ("two_stage_rocket", "lobatto", dict(mesh=11, num_point=4)),
+                                  ("planar_quadrotor", "lobatto", dict(mesh=19, num_point=4)),
+                                  ("planar_quadrotor", "radau", dict(mesh=300, num_point=6)),
+                                  ("humanoid_wbc", "radau", dict(mesh=9, num_point=7)),
+                                  ("humanoid_wbc", "lobatto", dict(mesh=6, num_point=5))])
+def test_compact_hessian_equals_coalesced_oracle(case):
+    """pk_hessc: one value per distinct position; scatter-added it must equal the scatter-add of the
+    oracle's (= the reference's) duplicate-laden triplet list."""
+    import scipy.sparse as ssp
+
+    bname, scheme, kw = case
+    system, _, guess = getattr(models, bname)(_ns(scheme, "pockit_amd"), **kw)
+    ref, _, _ = getattr(models, bname)(_ns(scheme, "oracle"), **kw)
+    x, lam, sigma = models.bench_inputs(system, guess)
+    n = system.plan.n
+    hr, hc = ref.hessianstructure()
+    want = ssp.coo_array((ref.hessian(x, lam, sigma), (hr, hc)), shape=(n, n)).tocsr()
+    system.set_hessian_layout("compact")
+    cr, cc = system.hessianstructure()
+    vals = system.hessian(x, lam, sigma)
+    assert len(vals) == len(cr) < len(hr) or bname == "lqr"
+    got = ssp.coo_array((vals, (cr, cc)), shape=(n, n)).tocsr()
+    diff = abs(got - want)
+    scale = max(1.0, abs(want).max())
+    assert (diff.max() if diff.nnz else 0.0) <= TOL * scale
+    system.set_hessian_layout("reference")
+    close(system.hessian(x, lam, sigma), ref.hessian(x, lam, sigma), what="reference layout still served")
+
+
+# ---------------------------------------------------------------------------------------------------------
+# mesh error estimation on device + hp-refinement
+ERR_TOLS = {"a": (1e-3, 1e-3), "b": (1e-7, 1e-6)}
+REFINE_KW = dict(num_point_min=3, num_point_max=7, mesh_length_min=1e-3, mesh_length_max=1.0)
+
+
+def _values(system, phases, ns, x):
+    plan = system.plan
+    value = [ns.Variable(p, x[plan.l_p[k]: plan.r_p[k]].copy()) for k, p in enumerate(phases)]
+    if system.n_s:
+        value.append(x[plan.l_s: plan.r_s].copy())
+    return value
+
+
+@pytest.mark.parametrize("name", sorted(models.ERROR_CASES))
+def test_mesh_error_kernel_matches_reference_golden(name):
+    """pk_err (T_aug x, dt I_aug f per interval) against the reference's _error_estimation_data_continuous, the
+    check against its verdicts, and one refine_continuous sweep (new mesh + adapted values) end to end."""
+    builder, scheme, kw = models.ERROR_CASES[name]
+    gold = np.load(os.path.join(HERE, "golden", "error", name + ".npz"))
+    ns = _ns(scheme, "pockit_amd")
+    system, phases, _ = builder(ns, **kw)
+    x = gold["x"]
+    data = system.evaluator.mesh_error(x)
+    for k, (T, I) in enumerate(data):
+        close(T, gold[f"T_{k}"], what=f"T phase {k}")
+        close(I, gold[f"I_{k}"], what=f"I phase {k}")
+    for tag, (atol, rtol) in ERR_TOLS.items():
+        expect = all(bool(np.all(gold[f"ok_{tag}_{k}"])) for k in range(len(phases)))
+        assert system.check_continuous(_values(system, phases, ns, x), atol, rtol, 1e-4) == expect
+        for k, p in enumerate(phases):      # phase-level entry point
+            s = x[system.plan.l_s: system.plan.r_s] if system.n_s else None
+            v = ns.Variable(p, x[system.plan.l_p[k]: system.plan.r_p[k]].copy())
+            assert p.check_continuous(v, s, atol, rtol, 1e-4) == bool(np.all(gold[f"ok_{tag}_{k}"]))
+    for tag, (atol, rtol) in ERR_TOLS.items():
+        system, phases, _ = builder(ns, **kw)
+        value = _values(system, phases, ns, x)
+        out = system.refine_continuous(value if len(value) > 1 else value[0], atol, rtol, **REFINE_KW)
+        changed = any(not np.array_equal(p._num_point, gold[f"K_{tag}_{k}"]) or len(p._mesh) != len(gold[f"mesh_{tag}_{k}"])
+                      for k, p in enumerate(phases))
+        assert not changed
+        if all(bool(np.all(gold[f"ok_{tag}_{k}"])) for k in range(len(phases))):
+            continue            # nothing to refine at this tolerance: the input is returned as is
+        out = out if isinstance(out, list) else [out]
+        for k, p in enumerate(phases):
+            assert np.allclose(p._mesh, gold[f"mesh_{tag}_{k}"], rtol=0, atol=1e-15)
+            close(out[k].data, gold[f"adapt_{tag}_{k}"], 1e-10, what=f"adapt {tag} phase {k}")
+        # the system is usable on the new discretization
+        x_new = np.concatenate([v.data for v in out[: len(phases)]] + ([np.asarray(out[-1])] if system.n_s else []))
+        assert len(x_new) == system.L and np.isfinite(system.objective(x_new))
+
+
+def test_mesh_error_full_size_matches_oracle():
+    """Quadrotor 2000 x 6 (LGR) and a ragged LGL hp mesh against the oracle's per-interval restatement."""
+    from oracle import refine as oref
+
+    rng = np.random.default_rng(11)
+    K = rng.integers(2, 12, size=57).tolist()
+    mesh = np.concatenate(([0.0], np.cumsum(rng.uniform(0.2, 1.0, size=57)))).tolist()
+    for builder, scheme, kw in ((models.planar_quadrotor, "radau", dict(mesh=2000, num_point=6)),
+                                (models.brachistochrone, "lobatto", dict(mesh=mesh, num_point=K)),
+                                (models.two_stage_rocket, "radau", dict(mesh=mesh, num_point=K))):
+        system, phases, guess = builder(_ns(scheme, "pockit_amd"), **kw)
+        ref, rphases, _ = builder(_ns(scheme, "oracle"), **kw)
+        ref.prepare()
+        x, _, _ = models.bench_inputs(system, guess)
+        data = system.evaluator.mesh_error(x)
+        s = x[ref.l_s: ref.r_s]
+        for k, rp in enumerate(rphases):
+            T, I = oref.error_data(rp, x[ref.l_p[k]: ref.r_p[k]].copy(), s)
+            close(data[k][0], T, what="T")
+            close(data[k][1], I, what="I")
+            for atol, rtol in ((1e-3, 1e-3), (1e-9, 1e-9)):
+                from pockit_amd import refine as pref
+
+                assert np.array_equal(pref.interval_ok(phases[k].layout, data[k][0], data[k][1], atol, rtol, 1e-4),
+                                      oref.check_intervals(rp, T, I, atol, rtol, 1e-4))
+        system._invalidate()
+
+
+def test_cycle_graph_replay_gives_identical_results():
+    """pk_set_cycle_graph: the cached hipGraph of the fused cycle reproduces the plain launches bit for bit, and a
+    change of sigma (re-capture) is honoured."""
+    import ctypes as C
+
+    import torch
+
+    system, _, guess = models.brachistochrone(_ns("radau", "pockit_amd"), mesh=37, num_point=5)
+    plan, ev = system.plan, system.evaluator
+    x, lam, _ = models.bench_inputs(system, guess)
+    dev = torch.device("cuda", 0)
+    dx, dlam = torch.from_numpy(x).to(dev), torch.from_numpy(lam).to(dev)
+    sizes = (("f", 1), ("grad", plan.n), ("g", plan.m), ("J", plan.nnz_J), ("H", plan.nnz_H))
+    torch.cuda.synchronize()
+
+    def run(sigma):
+        o = {k: torch.zeros(n, dtype=torch.float64, device=dev) for k, n in sizes}
+        torch.cuda.synchronize()
+        for _ in range(3):
+            ev.cycle_dev(dx.data_ptr(), dlam.data_ptr(), sigma, *[o[k].data_ptr() for k, _ in sizes])
+        ev.sync()
+        return {k: v.cpu().numpy() for k, v in o.items()}, o
+
+    plain = {s: run(s)[0] for s in (1.0, 0.25)}
+    ev.set_cycle_graph(True)
+    try:
+        for s in (1.0, 0.25, 1.0):
+            got, keep = run(s)
+            for k, _ in sizes:
+                assert np.array_equal(got[k], plain[s][k]), (k, s)
+    finally:
+        ev.set_cycle_graph(False)
+
+
+@pytest.mark.parametrize("case", [("planar_quadrotor", "radau", dict(mesh=301, num_point=6)),
+                                  ("two_stage_rocket", "radau", dict(mesh=150, num_point=4)),
+                                  ("brachistochrone", "lobatto", dict(mesh=1100, num_point=5)),
+                                  ("humanoid_wbc", "radau", dict(mesh=260, num_point=8)),
+                                  ("lqr", "lobatto", dict(mesh=10, num_point=10)),       # objective depends on a static parameter
+                                  ("lqr", "radau", dict(mesh=7, num_point=12))])         # tables read from global memory (K > 8)
+@pytest.mark.parametrize("split", ["1", "0"])
+def test_single_launch_cycle_equals_two_launch_cycle_bit_for_bit(case, split, monkeypatch):
+    """pk_cycle (x-kernel, Hessian and finalize workgroups in ONE launch, partial sums handed over inside the
+    launch) runs the same waves and the same fixed-shape reductions as pk_xall -> pk_hess(+reductions): all five
+    outputs must be bit-identical, for split (<= 1024 tiles) and unsplit launches, and equal to the oracle."""
+    import torch
+
+    monkeypatch.setenv("POCKIT_AMD_SPLIT", split)      # two waves per tile in the x-part (values / Jacobian) or one
+    bname, scheme, kw = case
+    system, _, guess = getattr(models, bname)(_ns(scheme, "pockit_amd"), **kw)
+    ref, _, _ = getattr(models, bname)(_ns(scheme, "oracle"), **kw)
+    plan, ev = system.plan, system.evaluator
+    x, lam, sigma = models.bench_inputs(system, guess)
+    dev = torch.device("cuda", 0)
+    dx, dlam = torch.from_numpy(x).to(dev), torch.from_numpy(lam).to(dev)
+    sizes = (("f", 1), ("grad", plan.n), ("g", plan.m), ("J", plan.nnz_J), ("H", plan.nnz_H))
+
+    def run():
+        o = {k: torch.full((n,), float("nan"), dtype=torch.float64, device=dev) for k, n in sizes}
+        torch.cuda.synchronize()
+        for _ in range(2):
+            ev.cycle_dev(dx.data_ptr(), dlam.data_ptr(), sigma, *[o[k].data_ptr() for k, _ in sizes])
+        ev.sync()
+        return {k: v.cpu().numpy() for k, v in o.items()}
+
+    single = run()
+    ev.set_cycle_mode(False)
+    try:
+        two = run()
+    finally:
+        ev.set_cycle_mode(True)
+    for k, _ in sizes:
+        assert np.array_equal(single[k], two[k]), k
+    close(single["f"][0], ref.objective(x), what="f")
+    close(single["grad"], ref.gradient(x), what="grad")
+    close(single["g"], ref.constraints(x), what="g")
+    close(single["J"], ref.jacobian(x), what="J")
+    close(single["H"], ref.hessian(x, lam, sigma), what="H")
+
+
+def test_single_launch_cycle_on_a_mesh_with_more_workgroups_than_the_chip_holds():
+    """360k nodes: ~5000 workgroups, more than are resident at once -- the finalize workgroup of pk_cycle polls
+    while tile workgroups are still waiting to be dispatched.  Must equal the two-launch cycle bit for bit and the
+    oracle within tolerance."""
+    import torch
+
+    kw = dict(mesh=60000, num_point=6)
+    system, _, guess = models.planar_quadrotor(_ns("radau", "pockit_amd"), **kw)
+    plan, ev = system.plan, system.evaluator
+    assert len(ev.tables.tiles) > 4096
+    x, lam, sigma = models.bench_inputs(system, guess)
+    dev = torch.device("cuda", 0)
+    dx, dlam = torch.from_numpy(x).to(dev), torch.from_numpy(lam).to(dev)
+    sizes = (("f", 1), ("grad", plan.n), ("g", plan.m), ("J", plan.nnz_J), ("H", plan.nnz_H))
+
+    def run():
+        o = {k: torch.full((n,), float("nan"), dtype=torch.float64, device=dev) for k, n in sizes}
+        torch.cuda.synchronize()
+        for _ in range(2):
+            ev.cycle_dev(dx.data_ptr(), dlam.data_ptr(), sigma, *[o[k].data_ptr() for k, _ in sizes])
+        ev.sync()
+        return {k: v.cpu().numpy() for k, v in o.items()}
+
+    single = run()
+    ev.set_cycle_mode(False)
+    try:
+        two = run()
+    finally:
+        ev.set_cycle_mode(True)
+    for k, _ in sizes:
+        assert np.array_equal(single[k], two[k]), k
+    ref, _, _ = models.planar_quadrotor(_ns("radau", "oracle"), **kw)
+    close(single["f"][0], ref.objective(x), what="f")
+    close(single["grad"], ref.gradient(x), what="grad")
+    close(single["g"], ref.constraints(x), what="g")
+    close(single["J"], ref.jacobian(x), what="J")
+    system._invalidate()
+
+
+def test_single_launch_cycle_hand_off_survives_back_to_back_launches():
+    """The hand-off slots of pk_cycle are emptied by the launch that consumed them: 600 cycles enqueued back to
+    back on alternating iterates, every launch writing f and grad f to its own slot, must each reproduce the value
+    of their iterate exactly (a stale or missed partial sum would show up in f or in the t0/tf gradient slots)."""
+    import torch
+
+    system, _, guess = models.two_stage_rocket(_ns("radau", "pockit_amd"), 120, 4)
+    plan, ev = system.plan, system.evaluator
+    xa, lam, sigma = models.bench_inputs(system, guess)
+    xb = xa * (1.0 + 0.05 * np.random.default_rng(11).uniform(-1, 1, xa.shape))
+    dev = torch.device("cuda", 0)
+    dxs = [torch.from_numpy(v).to(dev) for v in (xa, xb)]
+    dlam = torch.from_numpy(lam).to(dev)
+    reps = 600
+    f = torch.full((reps,), float("nan"), dtype=torch.float64, device=dev)
+    grad = torch.full((reps, plan.n), float("nan"), dtype=torch.float64, device=dev)
+    g, J, H = (torch.zeros(n, dtype=torch.float64, device=dev) for n in (plan.m, plan.nnz_J, plan.nnz_H))
+    torch.cuda.synchronize()
+    for i in range(reps):
+        ev.cycle_dev(dxs[i % 2].data_ptr(), dlam.data_ptr(), sigma, f[i:].data_ptr(), grad[i].data_ptr(), g.data_ptr(),
+                     J.data_ptr(), H.data_ptr())
+    ev.sync()
+    f, grad = f.cpu().numpy(), grad.cpu().numpy()
+    for par in (0, 1):
+        assert np.all(f[par::2] == f[par]) and np.all(grad[par::2] == grad[par]), par
+    assert f[0] != f[1]
+    ref, _, _ = models.two_stage_rocket(_ns("radau", "oracle"), 120, 4)
+    for par, x in ((0, xa), (1, xb)):
+        close(f[par], ref.objective(x), what="f")
+        close(grad[par], ref.gradient(x), what="grad")
+
+
+@pytest.mark.parametrize("name", ["brach_lgr_3x4", "quad_lgl_4x5", "rocket_lgr_3x4", "humanoid_lgr_2x3", "worked_lgr"])
+def test_device_csr_handoff_matches_reference_matrices(name):
+    """pk_csr: J and the lower triangle of H gathered into CSR on the device equal the matrices the reference's
+    triplets assemble to (scipy COO -> CSR of the golden vectors)."""
+    import scipy.sparse
+    import torch
+
+    builder, scheme, kw = models.SMALL_CASES[name]
+    gold = np.load(os.path.join(HERE, "golden", "small", name + ".npz"))
+    system, _, _ = builder(_ns(scheme, "pockit_amd"), **kw)
+    x, lam, sigma = gold["x"], gold["lam"], float(gold["sigma"])
+    n, m = int(gold["n"]), int(gold["m"])
+    J = system.jacobian_csr(x)
+    H = system.hessian_csr(x, lam, sigma)
+    Jref = scipy.sparse.coo_array((gold["J"], (gold["jr"], gold["jc"])), shape=(m, n)).tocsr()
+    Href = scipy.sparse.coo_array((gold["H"], (gold["hr"], gold["hc"])), shape=(n, n)).tocsr()
+    for got, ref in ((J, Jref), (H, Href)):
+        ref.sum_duplicates()
+        ref.sort_indices()
+        assert np.array_equal(got.indptr, ref.indptr) and np.array_equal(got.indices, ref.indices)
+        close(got.data, ref.data, what="csr values")
+    # device-pointer route: the fused cycle's triplets gathered without leaving the GPU
+    ev, plan = system.evaluator, system.plan
+    dev = torch.device("cuda", 0)
+    dx, dlam = torch.from_numpy(x).to(dev), torch.from_numpy(lam).to(dev)
+    o = {k: torch.zeros(max(c, 1), dtype=torch.float64, device=dev) for k, c in
+         (("f", 1), ("grad", plan.n), ("g", plan.m), ("J", plan.nnz_J), ("H", plan.nnz_H))}
+    cj = torch.zeros(ev.csr_map("jac").nnz, dtype=torch.float64, device=dev)
+    ch = torch.zeros(ev.csr_map("hess").nnz, dtype=torch.float64, device=dev)
+    torch.cuda.synchronize()
+    ev.cycle_dev(dx.data_ptr(), dlam.data_ptr(), sigma, *[o[k].data_ptr() for k in ("f", "grad", "g", "J", "H")])
+    ev.gather_csr_dev("jac", o["J"].data_ptr(), cj.data_ptr())
+    ev.gather_csr_dev("hess", o["H"].data_ptr(), ch.data_ptr())
+    ev.sync()
+    close(cj.cpu().numpy(), Jref.data, what="J csr dev")
+    close(ch.cpu().numpy(), Href.data, what="H csr dev")
+
+
+def test_device_csr_full_size_matches_host_gather():
+    """Quadrotor 2000 x 6: device gather == host gather of the device triplets (bit-exact for J: no repeats)."""
+    system, _, guess = models.planar_quadrotor(_ns("radau", "pockit_amd"), mesh=2000, num_point=6)
+    x, lam, sigma = models.bench_inputs(system, guess)
+    ev = system.evaluator
+    J, H = ev.jacobian_direct(x), ev.hessian_direct(x, lam, sigma)   # the stand-alone kernels the CSR calls run
+    mj, mh = ev.csr_map("jac"), ev.csr_map("hess")
+    assert mj.seg is None and mh.seg is not None
+    assert np.array_equal(ev.jacobian_csr(x), mj.gather(J))
+    close(ev.hessian_csr(x, lam, sigma), mh.gather(H), 1e-14, what="H csr")
+
+
+# ---------------------------------------------------------------------------------------------------------
+# the reference's own check tests (tests/test_radau/test_check_radau.py, tests/test_labatto/test_check_lobatto.py)
+# restated against the GPU-backed API
+def _check_model(ns, num_point):
+    s = ns.System(1)
+    p = s.new_phase(1, 1)
+    p.set_dynamics([p.u[0]])
+    p.set_boundary_condition([None], [None], None, None)
+    p.set_phase_constraint([p.u[0] + p.s[0]], [0.0], [2.0], [True])
+    p.set_discretization([0, 0.1, 1], num_point)
+    s.set_phase([p])
+    s.set_objective(s.s[0])
+    return s, p
+
+
+def test_reference_check_discontinuous_radau():
+    ns = _ns("radau", "pockit_amd")
+    s, p = _check_model(ns, [2, 3])
+    v = ns.constant_guess(p, 0.0)
+    assert isinstance(s.check_discontinuous([v, [2.0]]), bool)
+    assert s.check_discontinuous([v, [2.0]])
+    assert s.check_discontinuous([v, [2.01]])
+    assert not s.check_discontinuous([v, [1.99]])
+    v.u[0] = np.array([-1, -1, 1, 1, 1], dtype=np.float64)
+    assert s.check_discontinuous([v, [1.0]])
+    assert not s.check_discontinuous([v, [1.01]])
+    v.u[0] = np.array([0, 0.01, 2, 2, 2], dtype=np.float64)
+    assert not s.check_discontinuous([v, [0.0]])
+    with pytest.raises(ValueError):
+        s.check_discontinuous(v)
+
+
+@pytest.mark.parametrize("scheme,num_point", [("radau", [2, 3]), ("lobatto", [3, 4])])
+def test_reference_check_continuous(scheme, num_point):
+    ns = _ns(scheme, "pockit_amd")
+    s, p = _check_model(ns, num_point)
+    v = ns.constant_guess(p, 1.0)
+    v.x[0] = v.t_x
+    assert isinstance(s.check_continuous([v, [0.0]]), bool)
+    assert s.check_continuous([v, [0.0]])
+    v.u[0] = v.t_u * 2
+    v.x[0] = v.t_x**2
+    assert s.check_continuous([v, [0.0]])
+    v.u[0][0] += 0.01
+    assert not s.check_continuous([v, [0.0]])
+    v.u[0] = v.t_u * 1.99
+    assert not s.check_continuous([v, [0.0]])
+
+
+def test_reference_check_discontinuous_lobatto_is_not_implemented():
+    ns = _ns("lobatto", "pockit_amd")
+    s, p = _check_model(ns, [3, 4])
+    v = ns.constant_guess(p, 0.0)
+    with pytest.raises(NotImplementedError):
+        s.check_discontinuous([v, [2.0]])
+    v.x[0] = v.t_x
+    v.u[0] = v.t_u * 0 + 1.0
+    assert s.check([v, [0.0]]) == s.check_continuous([v, [0.0]])   # lobatto: check == check_continuous
+
+
+# ---------------------------------------------------------------------------------------------------------
+# the three tests of the reference's tests/test_base/test_system_base.py:10-70 that were not restated yet
+@pytest.mark.parametrize("scheme", ["radau", "lobatto"])
+def test_reference_static_only_system(scheme):
+    """A system without phases (test_system_base.py:10-20): f = s^2, grad = [2 s], no constraints -- evaluated by the
+    system-level workgroups alone (no tile workgroup exists)."""
+    system = _ns(scheme, "pockit_amd").System(1)
+    system.set_objective(system.s[0] ** 2)
+    x = np.array([2.0], dtype=np.float64)
+    assert system.objective(x) == pytest.approx(4.0)
+    assert np.allclose(system.gradient(x), [4.0])
+    assert system.constraints(x).shape == (0,)
+    assert system.jacobian(x).shape == (0,)
+    ref = _ns(scheme, "oracle").System(1)
+    ref.set_objective(ref.s[0] ** 2)
+    lam = np.zeros(0)
+    hr, hc = system.hessianstructure()
+    rr, rc = ref.hessianstructure()
+    assert np.array_equal(hr, rr) and np.array_equal(hc, rc)
+    close(system.hessian(x, lam, 0.5), ref.hessian(x, lam, 0.5), what="H")
+    f, grad, g, J, H = system.evaluator.cycle(x, lam, 0.5)         # the one-launch cycle: three workgroups, no tiles
+    assert f == pytest.approx(4.0) and np.allclose(grad, [4.0]) and g.shape == (0,) and J.shape == (0,)
+    close(H, ref.hessian(x, lam, 0.5), what="cycle H")
+    x3 = np.array([-3.0])
+    assert system.objective(x3) == pytest.approx(9.0) and np.allclose(system.gradient(x3), [-6.0])
+
+
+def test_reference_static_only_system_with_system_constraints():
+    """Static parameters only, with an objective and system constraints in them: f, grad f, g, J, H against the oracle."""
+    def build(ns):
+        system = ns.System(3)
+        a, b, c = system.s
+        system.set_objective(a ** 2 * b + sp_sin(c) * a)
+        system.set_system_constraint([a * b * c, a + b ** 2], [0.0, -1.0], [1.0, 1.0])
+        return system
+
+    import sympy
+
+    sp_sin = sympy.sin
+    system, ref = build(_ns("radau", "pockit_amd")), build(_ns("radau", "oracle"))
+    x = np.array([0.7, -1.3, 0.4])
+    lam = np.array([0.3, -2.0])
+    assert np.array_equal(system.jacobianstructure()[0], ref.jacobianstructure()[0])
+    assert np.array_equal(system.jacobianstructure()[1], ref.jacobianstructure()[1])
+    assert np.array_equal(system.hessianstructure()[0], ref.hessianstructure()[0])
+    assert np.array_equal(system.hessianstructure()[1], ref.hessianstructure()[1])
+    close(system.objective(x), ref.objective(x), what="f")
+    close(system.gradient(x), ref.gradient(x), what="grad")
+    close(system.constraints(x), ref.constraints(x), what="g")
+    close(system.jacobian(x), ref.jacobian(x), what="J")
+    close(system.hessian(x, lam, 1.7), ref.hessian(x, lam, 1.7), what="H")
+
+
+def test_reference_phase_check_uses_discontinuous_tolerance():
+    """test_system_base.py:22-32: ``phase.check`` passes its discontinuous tolerance on (u = 0.9995 of a bang-bang
+    control in [0, 1] is settled at tolerance 1e-3)."""
+    ns = _ns("radau", "pockit_amd")
+    system = ns.System(0)
+    phase = system.new_phase(1, 1)
+    phase.set_dynamics([0]).set_boundary_condition([0], [0], 0, 1)
+    phase.set_phase_constraint([phase.u[0]], [0], [1], bang_bang_control=True).set_discretization(1, 3)
+    system.set_phase([phase]).set_objective(0)
+    variable = ns.constant_guess(phase, 0)
+    variable.u[0] = 0.9995
+    assert phase.check(variable, tolerance_discontinuous=1.0e-3)
+    assert not phase.check(variable, tolerance_discontinuous=1.0e-4)
+
+
+def test_reference_reconfiguring_boundary_condition_clears_old_derivatives():
+    """test_system_base.py:34-70: a FUNC boundary value replaced by a FREE and then by a FIXED one must leave no trace
+    of the static-parameter dependence -- structure equal to the oracle's after the same sequence, J against central
+    finite differences of the constraints callback (the reference's own check)."""
+    def build(ns):
+        system = ns.System(1)
+        phase = system.new_phase(1, 0)
+        phase.set_dynamics([0]).set_boundary_condition([system.s[0] ** 2], [None], 0, 1).set_discretization(1, 3)
+        phase.set_boundary_condition([None], [None], 0, 1)
+        phase.set_boundary_condition([0], [None], 0, 1)
+        system.set_phase([phase]).set_objective(0)
+        return system, phase
+
+    ns = _ns("radau", "pockit_amd")
+    system, phase = build(ns)
+    ref, _ = build(_ns("radau", "oracle"))
+    x = np.concatenate([ns.constant_guess(phase, 0).data, [2.0]])
+    row, col = system.jacobianstructure()
+    rrow, rcol = ref.jacobianstructure()
+    assert np.array_equal(row, rrow) and np.array_equal(col, rcol)
+    assert not np.any(col == system.l_s), "no Jacobian entry may depend on the static parameter any more"
+    jacobian = np.zeros((len(system.c_lb), system.L), dtype=np.float64)
+    np.add.at(jacobian, (row, col), system.jacobian(x.copy()))
+    eps = 1.0e-6
+    finite_difference = np.empty_like(jacobian)
+    for i in range(system.L):
+        delta = np.zeros(system.L, dtype=np.float64)
+        delta[i] = eps
+        finite_difference[:, i] = (system.constraints(x.copy() + delta) - system.constraints(x.copy() - delta)) / (2 * eps)
+    assert np.allclose(jacobian, finite_difference)
+    close(system.jacobian(x), ref.jacobian(x), what="J")
+    # the intermediate configurations evaluate correctly too (FUNC, then FREE)
+    for bc in ([None], "func"):
+        s2 = ns.System(1)
+        p2 = s2.new_phase(1, 0)
+        r2 = _ns("radau", "oracle").System(1)
+        q2 = r2.new_phase(1, 0)
+        for sy, ph in ((s2, p2), (r2, q2)):
+            ph.set_dynamics([0]).set_boundary_condition([0], [None], 0, 1).set_discretization(1, 3)
+            ph.set_boundary_condition([sy.s[0] ** 2] if bc == "func" else bc, [None], 0, 1)
+            sy.set_phase([ph]).set_objective(0)
+        close(s2.jacobian(x), r2.jacobian(x), what="J " + str(bc))
+        assert np.array_equal(s2.jacobianstructure()[1], r2.jacobianstructure()[1])
+
+
+def test_check_and_refine_loop_like_the_hyper_sensitive_example():
+    """system.check / system.refine in the adaptive loop of examples/hyper_sensitive.py:94-116 (no solver: the
+    'solution' is a smooth guess, so each sweep must strictly reduce the number of failing intervals)."""
+    ns = _ns("radau", "pockit_amd")
+    system, phases, guess = models.brachistochrone(ns, mesh=4, num_point=3)
+    value = guess[0] if isinstance(guess, list) and len(guess) == 1 else guess
+    tol = 1e-6
+    assert not system.check(value, absolute_tolerance_continuous=tol, relative_tolerance_continuous=tol)
+    sizes = [phases[0].L]
+    for _ in range(3):
+        value = system.refine(value, absolute_tolerance_continuous=tol, relative_tolerance_continuous=tol,
+                              num_point_min=4, num_point_max=8, mesh_length_min=1e-6)
+        sizes.append(phases[0].L)
+        assert len(value.data) == phases[0].L == system.L
+        assert np.isfinite(system.objective(value.data))
+    assert sizes[1] > sizes[0]
+
+
+# ---------------------------------------------------------------------------------------------------------
+# the reference's finite-difference derivative tests (tests/test_radau/test_derivative_radau.py:43-144,
+# tests/test_labatto/test_derivative_lobatto.py) restated against the GPU evaluator: same model, same point
+# x = arange(L)/10 + 1, same steps and tolerances
+def _dense(rows, cols, vals, shape):
+    M = np.zeros(shape)
+    np.add.at(M, (np.asarray(rows), np.asarray(cols)), vals)
+    return M
+
+
+@pytest.mark.parametrize("scheme", ["radau", "lobatto"])
+def test_reference_finite_difference_derivative_checks(scheme):
+    s, _, _ = models.derivative_model(_ns(scheme, "pockit_amd"))
+    n = s.L
+    x = np.arange(n, dtype=np.float64) / 10 + 1
+    m = len(s.constraints(x))
+
+    def shifted(*moves):
+        y = x.copy()
+        for i, d in moves:
+            y[i] += d
+        return y
+
+    # gradient and Jacobian: central differences, eps = 1e-6, np.allclose defaults
+    eps = 1e-6
+    fd_grad = np.array([(s.objective(shifted((i, eps))) - s.objective(shifted((i, -eps)))) / (2 * eps) for i in range(n)])
+    assert np.allclose(s.gradient(x), fd_grad)
+    fd_jac = np.stack([(s.constraints(shifted((i, eps))) - s.constraints(shifted((i, -eps)))) / (2 * eps)
+                       for i in range(n)], axis=1)
+    jr, jc = s.jacobianstructure()
+    assert np.allclose(_dense(jr, jc, s.jacobian(x), (m, n)), fd_jac)
+
+    # Hessians: four-point formula, eps = 2e-3, atol = rtol = 1e-4 on the lower triangle
+    eps = 2e-3
+    fd_o = np.zeros((n, n))
+    fd_c = np.zeros((m, n, n))
+    for i in range(n):
+        for j in range(i + 1):
+            pts = [shifted((i, eps), (j, eps)), shifted((i, eps), (j, -eps)), shifted((i, -eps), (j, eps)),
+                   shifted((i, -eps), (j, -eps))]
+            f = [s.objective(p) for p in pts]
+            g = [s.constraints(p) for p in pts]
+            fd_o[i, j] = (f[0] - f[1] - f[2] + f[3]) / eps / eps / 4
+            fd_c[:, i, j] = (g[0] - g[1] - g[2] + g[3]) / eps / eps / 4
+    hr, hc = s.hessianstructure_o()
+    assert np.allclose(_dense(hr, hc, s.hessian_o(x), (n, n)), fd_o, atol=1e-4, rtol=1e-4)
+    hr, hc = s.hessianstructure()
+    for c in range(m):
+        unit = np.zeros(m)
+        unit[c] = 1.0
+        assert np.allclose(_dense(hr, hc, s.hessian(x, unit, 0.0), (n, n)), fd_c[c], atol=1e-4, rtol=1e-4), c
+
+
+@pytest.mark.parametrize("seed", [0, 1, 2, 3, 4, 5])
+def test_random_hp_meshes_all_callbacks_match_oracle(seed):
+    """Randomised hp meshes (every interval its own width and K, LGR K = 1..12 / LGL K = 2..12; K > 8 takes the
+    kernels' global-table path, K <= 8 the LDS-staged one) over all example models, all five callbacks, the
+    stand-alone kernels and the fused cycle."""
+    rng = np.random.default_rng(100 + seed)
+    builder = [models.brachistochrone, models.planar_quadrotor, models.two_stage_rocket, models.humanoid_wbc,
+               models.derivative_model, models.brachistochrone][seed]
+    scheme = ["radau", "lobatto"][seed % 2]
+    n_int = int(rng.integers(5, 40))
+    lo = 1 if scheme == "radau" else 2
+    K = rng.integers(lo, 13, size=n_int).tolist()
+    mesh = np.concatenate(([0.0], np.cumsum(rng.uniform(0.05, 1.0, size=n_int)))).tolist()
+    kw = dict(mesh=mesh, num_point=K)
+    system, _, guess = builder(_ns(scheme, "pockit_amd"), **kw)
+    ref, _, _ = builder(_ns(scheme, "oracle"), **kw)
+    x, lam, sigma = models.bench_inputs(system, guess)
+    sigma = 0.3 + 0.1 * seed
+    assert np.array_equal(system.jacobianstructure()[0], ref.jacobianstructure()[0])
+    assert np.array_equal(system.jacobianstructure()[1], ref.jacobianstructure()[1])
+    assert np.array_equal(system.hessianstructure()[0], ref.hessianstructure()[0])
+    assert np.array_equal(system.hessianstructure()[1], ref.hessianstructure()[1])
+    want = dict(f=ref.objective(x), grad=ref.gradient(x), g=ref.constraints(x), J=ref.jacobian(x),
+                H=ref.hessian(x, lam, sigma))
+    ev = system.evaluator
+    close(ev.objective_direct(x), want["f"], what="f")
+    close(ev.gradient_direct(x), want["grad"], what="grad")
+    close(ev.constraints_direct(x), want["g"], what="g")
+    close(ev.jacobian_direct(x), want["J"], what="J")
+    close(ev.hessian_direct(x, lam, sigma), want["H"], what="H")
+    f, grad, g, J, H = ev.cycle(x, lam, sigma)
+    for got, key in ((f, "f"), (grad, "grad"), (g, "g"), (J, "J"), (H, "H")):
+        close(got, want[key], what="cycle " + key)
+
+
+def test_adaptive_solve_check_refine_loop_converges():
+    """The whole adaptive workflow on the GPU evaluator, as examples/hyper_sensitive.py:88-120 runs it with IPOPT:
+    solve (SciPy trust-constr here), system.check, system.refine, re-solve on the refined mesh from the adapted
+    solution -- until the mesh error check passes.  The objective must approach the Riccati optimum."""
+    from scipy.integrate import solve_ivp
+
+    from pockit_amd.optimizer import scipy as scipy_solver
+
+    ns = _ns("radau", "pockit_amd")
+    system, (phase,), _ = models.lqr(ns, 2, 3)
+    value = [ns.constant_guess(phase, 0.0), [0.0]]
+    a, b, q, r, sw = -1.0, 1.0, 1.0, 0.1, 1.0
+    ric = solve_ivp(lambda t, P: -(2 * a * P - b * b * P * P / r + q), (1.0, 0.0), [sw / 2], rtol=1e-11, atol=1e-12)
+    optimum = ric.y[0, -1]
+    tol = 1e-6
+    errors, sizes = [], []
+    for sweep in range(6):
+        value, res = scipy_solver.solve(system, value, {"maxiter": 300, "gtol": 1e-10, "xtol": 1e-12})
+        errors.append(abs(res.fun - optimum))
+        sizes.append(system.L)
+        if system.check(value, absolute_tolerance_continuous=tol, relative_tolerance_continuous=tol):
+            break
+        value = system.refine(value, absolute_tolerance_continuous=tol, relative_tolerance_continuous=tol,
+                              num_point_min=3, num_point_max=8, mesh_length_min=1e-4)
+        assert len(value[0].data) == phase.L
+    else:
+        pytest.fail(f"mesh error check never passed: errors {errors}, sizes {sizes}")
+    assert len(sizes) >= 2 and sizes[-1] > sizes[0], sizes            # the coarse mesh had to be refined
+    assert errors[-1] <= 1e-6 * max(1.0, abs(optimum)) and errors[-1] < errors[0], errors
+
+
+def test_ipopt_adapter_protocol_with_a_stand_in_cyipopt(monkeypatch):
+    """cyipopt / Ipopt are not installed here, so the adapter is driven by a stand-in ``cyipopt.Problem`` that
+    does what cyipopt does with a ``problem_obj`` (cyipopt's Problem.__init__/solve contract: structure queried
+    once, every callback result copied into the solver's own arrays at once, callbacks in IPOPT's per-iteration
+    order) and checks every value it receives against the oracle.  This covers the adapter's wiring and the
+    evaluator's zero-copy mode (results handed out as views of pinned buffers that the next call reuses)."""
+    import sys
+    import types
+
+    ns = _ns("radau", "pockit_amd")
+    system, phases, guess = models.two_stage_rocket(ns, 12, 4)
+    ref, _, _ = models.two_stage_rocket(_ns("radau", "oracle"), 12, 4)
+    seen = {"iters": 0, "options": {}}
+
+    class Problem:
+        def __init__(self, n, m, problem_obj, lb, ub, cl, cu):
+            assert n == ref.L and m == len(ref.c_lb) and len(lb) == len(ub) == n and len(cl) == len(cu) == m
+            assert np.array_equal(lb, ref.v_lb) and np.array_equal(ub, ref.v_ub)
+            assert np.array_equal(cl, ref.c_lb) and np.array_equal(cu, ref.c_ub)
+            self.n, self.m, self.obj = n, m, problem_obj
+            jr, jc = problem_obj.jacobianstructure()
+            hr, hc = problem_obj.hessianstructure()
+            assert np.array_equal(jr, ref.jacobianstructure()[0]) and np.array_equal(jc, ref.jacobianstructure()[1])
+            assert np.array_equal(hr, ref.hessianstructure()[0]) and np.array_equal(hc, ref.hessianstructure()[1])
+            self.nnz_j, self.nnz_h = len(jr), len(hr)
+
+        def add_option(self, key, value):
+            seen["options"][key] = value
+
+        def solve(self, x0):
+            rng = np.random.default_rng(3)
+            x = np.array(x0, dtype=np.float64)
+            for it in range(4):
+                lam = rng.standard_normal(self.m)
+                sigma = 1.0 if it else 0.5
+                got = {}
+                got["f"] = float(self.obj.objective(x))                       # line search: f and g
+                got["g"] = np.array(self.obj.constraints(x), dtype=np.float64)
+                got["grad"] = np.array(self.obj.gradient(x), dtype=np.float64)  # accepted point: derivatives
+                got["J"] = np.array(self.obj.jacobian(x), dtype=np.float64)
+                got["H"] = np.array(self.obj.hessian(x, lam, sigma), dtype=np.float64)
+                assert got["J"].shape == (self.nnz_j,) and got["H"].shape == (self.nnz_h,)
+                close(got["f"], ref.objective(x), what="f")
+                close(got["g"], ref.constraints(x), what="g")
+                close(got["grad"], ref.gradient(x), what="grad")
+                close(got["J"], ref.jacobian(x), what="J")
+                close(got["H"], ref.hessian(x, lam, sigma), what="H")
+                x = x * (1.0 + 1e-3 * rng.uniform(-1, 1, size=len(x)))
+                seen["iters"] += 1
+            return x, {"status": 0, "status_msg": b"stand-in", "obj_val": got["f"]}
+
+    fake = types.ModuleType("cyipopt")
+    fake.Problem = Problem
+    monkeypatch.setitem(sys.modules, "cyipopt", fake)
+    from pockit_amd.optimizer import ipopt
+
+    solution, info = ipopt.solve(system, guess, {"tol": 1e-8, "print_level": 0})
+    assert seen["iters"] == 4 and seen["options"] == {"tol": 1e-8, "print_level": 0} and info["status"] == 0
+    assert len(solution) == len(phases) + 1 and all(len(v.data) == p.L for v, p in zip(solution, phases))
+    assert len(solution[-1]) == system.n_s and system.evaluator.zero_copy is False
+
+
+@pytest.mark.parametrize("name", sorted(models.BANG_BANG_CASES))
+def test_bang_bang_refinement_end_to_end_matches_reference(name):
+    """system.check_discontinuous / refine_discontinuous on the GPU-backed system against the reference's results
+    (tests/golden/bangbang): the scaled constraint values come from pk_g on the device."""
+    kw, _ = models.BANG_BANG_CASES[name]
+    gold = np.load(os.path.join(HERE, "golden", "bangbang", name + ".npz"))
+    ns = _ns("radau", "pockit_amd")
+    for tag, (dtol, kmin, kmax, lmin, lmax) in (("a", (1e-3, 4, 8, 1e-3, 1.0)), ("b", (5e-2, 3, 6, 2e-2, 0.3))):
+        system, (p,), _ = models.bang_bang_model(ns, **kw)
+        value = [ns.Variable(p, gold["data"].copy()), gold["s"].copy()]
+        assert system.check_discontinuous(value, dtol, 1e-4) == bool(np.all(gold[f"ok_{tag}"]))
+        out = system.refine_discontinuous(value, dtol, num_point_min=kmin, num_point_max=kmax, mesh_length_min=lmin,
+                                          mesh_length_max=lmax)
+        assert len(p._mesh) == len(gold[f"mesh_{tag}"]) and np.allclose(p._mesh, gold[f"mesh_{tag}"], rtol=0, atol=1e-9)
+        assert np.array_equal(p._num_point, gold[f"K_{tag}"])
+        close(out[0].data, gold[f"adapt_{tag}"], 1e-9, what="adapted values")
+        x_new = np.concatenate([out[0].data, out[1]])
+        assert len(x_new) == system.L and np.isfinite(system.objective(x_new))
+        # system.refine takes the bang-bang branch first (the check fails), as the reference does
+        system2, (p2,), _ = models.bang_bang_model(ns, **kw)
+        system2.refine([ns.Variable(p2, gold["data"].copy()), gold["s"].copy()], 1e-8, 1e-8, dtol, kmin, kmax, lmin, lmax)
+        assert len(p2._mesh) == len(gold[f"mesh_{tag}"]) and np.allclose(p2._mesh, gold[f"mesh_{tag}"], rtol=0, atol=1e-9)

@@ -440,6 +440,18 @@ def measure(name, intervals, steps, warmup, rank, world, dist, with_side=True, w
     iso, fl, n_iso, n_fl = w.dispatch_times(w.dominant)
     res.update(dispatch_isolated_us=iso, dispatch_in_flight_us=fl, dispatch_samples=[n_iso, n_fl])
     res["kernel_us"] = w.all_kernel_us()
+    if world > 1:       # the sums every rank ends up with must be bit-identical (same additions in rank order everywhere)
+        from pockit_amd.sharding import shared_gradient_slots
+
+        w.step()
+        w.sync()
+        sh = w.torch.as_tensor(shared_gradient_slots(w.plan), device=w.dev)
+        mine_sums = (float(w.o["f"].cpu()[0]), [float(v) for v in w.o["grad"][sh].cpu()])
+        sums = [None] * world
+        dist.all_gather_object(sums, mine_sums)
+        same = all(s_ == sums[0] for s_ in sums) if w.exchange in ("sums", "allgather") else None
+        res["exchange_check"] = {"f_per_rank": [s_[0] for s_ in sums], "sums_identical_on_every_rank": same,
+                                 "finite": bool(np.isfinite(sums[0][0]))}
     if world > 1:       # per rank: share of the output positions, tiles, kernel times (rank 0 prints them)
         mine = {"rank": rank, "tiles": int((w.ev.tables.tiles["nj"] > 0).sum()),
                 "owned_output_doubles": int(sum(b - a for a, b in w.sev.runs[rank])),
@@ -633,6 +645,7 @@ def main():
                         "the packed runs to rank 0.  The reassembling forms move one shard per peer into ONE GPU every "
                         "cycle and are bound by that GPU's xGMI links"}),
             "ranks": res["ranks"],
+            "exchange_check": res.get("exchange_check"),
             "kernel_us": res["kernel_us"],
             "cycle_algorithmic_bytes": res["bytes"]["cycle"],
             "setup_s": res["setup_s"], "compile_s_in_setup": res["compile_s_in_setup"],

@@ -55,6 +55,7 @@ typedef struct pk_model_desc {
   int32_t ne_hc;        /* scalar expressions of the compact Hessian                              */
   int32_t lds_e;        /* LDS doubles per wave of the mesh error estimation kernel (pk_err)      */
   int32_t tab_cap;      /* PK_TAB_CAP the code object was compiled with: entries of a staged pattern table, 64 or 256 */
+  int32_t sharded;      /* 1 if the code object was generated with PK_SHARDED (in-launch exchange between GPUs)       */
 } pk_model_desc;
 
 /* One (model, mesh) instance: sizes plus the table blobs built by pockit_amd/evaluator.py.

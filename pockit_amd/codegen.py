@@ -151,8 +151,11 @@ class ModelSource:
     """Generates the HIP source of one SystemPlan; exposes the compile-time counts the runtime
     tables must agree with."""
 
-    def __init__(self, plan: SystemPlan):
+    def __init__(self, plan: SystemPlan, sharded: bool = False):
         self.plan = plan
+        # sharded: the finalize workgroup of pk_cycle carries the in-launch exchange of the partial sums between the GPUs.
+        # Single-GPU code objects are compiled without it (its mere presence cost the 12k-node cycle 3 %).
+        self.sharded = bool(sharded) or os.environ.get("POCKIT_AMD_SHARDED", "0") == "1"
         self.nphase = len(plan.phase_plans)
         nI = len(plan.I_syms)
         # integrals evaluated by the pre-pass: those any system-level function references
@@ -387,6 +390,10 @@ class ModelSource:
             S.append(f"#define PK_POLL_SLEEP {int(os.environ['POCKIT_AMD_POLL_SLEEP'])}")
         if os.environ.get("POCKIT_AMD_WIDE_STORES", "1") == "0":     # A/B switch: 8-byte stores in the streaming loop
             S.append("#define PK_WIDE_STORES 0")
+        if os.environ.get("POCKIT_AMD_STATIC_TABS", "0") == "1":     # A/B: table blocks in static LDS
+            S.append("#define PK_STATIC_TABS 1")
+        if self.sharded:
+            S.append("#define PK_SHARDED 1")
         stream = {"sc1nt": "sc1 nt", "nt": "nt", "plain": "", "sc0sc1": "sc0 sc1", "sc0sc1nt": "sc0 sc1 nt"}.get(
             os.environ.get("POCKIT_AMD_STREAM", ""))
         if stream is not None:                                       # A/B switch: cache policy of the 16-byte streaming stores

@@ -174,6 +174,5 @@ struct PkArgs {
   int32_t n_csr;          // CSR entries
   int32_t xc_world, xc_rank, xc_epoch, xc_nsh;   // ranks, this rank, cycle number (>= 1), number of shared gradient slots
   int32_t xc_stride, rc_n;                       // mailbox words per sender (multiple of 16); chunks of the run table
-  int32_t pad1, pad2;
   PkPhase ph[PK_MAX_PHASES];   // the phases by value (kernarg segment): no dependent global load
 };

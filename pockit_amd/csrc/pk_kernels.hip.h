@@ -345,7 +345,11 @@ struct TileTabs {
 // doubles of one wave's table block in dynamic LDS
 #define PK_TAB_WIDTH (2 * PK_TAB_CAP + 2 * PK_WAVE + PK_TAB_CAP / 2)
 // start of the per-wave model staging area: behind the table blocks of the workgroup's waves
+#ifdef PK_STATIC_TABS      // A/B: the table blocks as static LDS arrays (the round-1 layout), staging at the start of dynamic LDS
+#define PK_STAGE(A) (pk_lds)
+#else
 #define PK_STAGE(A) (pk_lds + PK_WAVES_PER_BLOCK * PK_TAB_WIDTH)
+#endif
 
 __device__ __forceinline__ bool tabs_fit(const PkArgs& A, const PkTile& tl, const TileGeom& g) {
   return tl.nnzI <= PK_TAB_CAP && g.R * g.K <= PK_TAB_CAP && tl.nnzT <= PK_WAVE && !PK_DIAG(4096);
@@ -384,7 +388,12 @@ __device__ __forceinline__ TileTabs tabs_commit(const PkArgs& A, const PkTile& t
   extern __shared__ double pk_lds[];
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   constexpr int cap = PK_TAB_CAP;
+#ifdef PK_STATIC_TABS
+  __shared__ double pk_tab_static[PK_WAVES_PER_BLOCK * PK_TAB_WIDTH];
+  double* __restrict__ iv = pk_tab_static + wave * PK_TAB_WIDTH;
+#else
   double* __restrict__ iv = pk_lds + wave * PK_TAB_WIDTH;
+#endif
   double* __restrict__ full = iv + cap;
   double* __restrict__ tv = full + cap;
   double* __restrict__ wd = tv + PK_WAVE;
@@ -1680,6 +1689,10 @@ __device__ __forceinline__ void fin_handoff(const PkArgs& A) {
   __shared__ double ssh[PK_NS];                     // static parameters, fetched before the wait (F_o(I, s) reads them)
   __shared__ int ridx[NR];
   const int t = threadIdx.x, wave = t >> 6;
+  // where the shared gradient slots go: fetched NOW (a kernel argument of its own cache line: asked for after the wait
+  // it put a scalar-cache miss on the finalize chain -- the two-phase rocket lost 7 %)
+  double* __restrict__ gout = A.o_gshared ? A.o_gshared : A.o_grad;
+  asm volatile("" : "+s"(gout));
   if (t < PK_NPHASE) dts[t] = Gen::phase_dt(t, A);
   for (int i = t; i < PK_NI; i += PK_BLOCK) Ish[i] = 0.0;      // (integrals no system function refers to stay 0)
   for (int i = t; i < A.n_s && i < PK_NS; i += PK_BLOCK) ssh[i] = A.x[A.l_s + i];
@@ -1745,7 +1758,11 @@ __device__ __forceinline__ void fin_handoff(const PkArgs& A) {
     }
   __syncthreads();
   const PkSys sy{ssh, Ish, A.sigma, A.lam};
+#ifdef PK_SHARDED
   const bool xchg = (A.flags & 64) != 0;                  // sharded cycle: the sums over the RANKS, inside this launch
+#else
+  constexpr bool xchg = false;                            // (code objects of single-GPU evaluators carry no exchange code)
+#endif
   if (t == 0 && !xchg) A.o_f[0] = Gen::sys_objective(sy); // systembase.py:592-605
   if (t == 64) {
 #pragma unroll
@@ -1761,7 +1778,6 @@ __device__ __forceinline__ void fin_handoff(const PkArgs& A) {
   extern __shared__ double pk_lds[];
   double* __restrict__ xmine = pk_lds;
   double* __restrict__ xtotal = pk_lds + PK_XC_CAP;
-  double* __restrict__ gout = A.o_gshared ? A.o_gshared : A.o_grad;
   for (int z = t; z < A.n_gz; z += PK_BLOCK) {
     const int idx = z == t ? gz0 : A.ib[A.gz_off + z];
     double v = 0.0;

@@ -67,6 +67,7 @@ struct pk_ctx {
   bool xc_inline = false;       // pk_cycle's finalize workgroup exchanges the partial sums itself (pk_set_exchange_inline)
   bool split_xall = false;      // pk_xall with two waves per tile (values / Jacobian), see pk_set_problem
   int cycle_mode = 1;           // 1: single-launch pk_cycle; 0: pk_xall + pk_hess (pk_set_cycle_mode)
+  bool static_tabs = false;     // A/B (POCKIT_AMD_STATIC_TABS=1): the code object keeps its table blocks in static LDS
   unsigned long long *d_cpart = nullptr, *d_cpart2 = nullptr;   // pk_cycle's hand-off slots (PK_EMPTY between launches)
   unsigned profile_mask = 0;
   unsigned profile_period = 1;  // time every n-th launch of a selected kernel
@@ -235,7 +236,7 @@ int launch_raw(pk_ctx* c, int k, void* args, size_t sz, unsigned grid, size_t ld
   EventPair ev{};
   if (grid == 0) return 0;
   // the tile kernels that stage their pattern tables keep one table block per wave in front of the model's staging area
-  if (k == K_G || k == K_JAC || k == K_HESS || k == K_XALL || k == K_CYCLE)
+  if ((k == K_G || k == K_JAC || k == K_HESS || k == K_XALL || k == K_CYCLE) && !c->static_tabs)
     lds_bytes += sizeof(double) * PK_WAVES_PER_BLOCK * (size_t)(2 * c->md.tab_cap + 2 * PK_WAVE + c->md.tab_cap / 2);
   if (k == K_CYCLE && c->xc_inline && c->xc_world > 1 && lds_bytes < sizeof(double) * 2 * 512)
     lds_bytes = sizeof(double) * 2 * 512;      // the finalize workgroup's exchange vectors (2 x PK_XC_CAP doubles)
@@ -400,6 +401,7 @@ int pk_create(pk_ctx** out, int device_id) {
   if (device_id < 0 || device_id >= ndev) return fail(nullptr, 11, "pk_create: device %d out of range [0,%d)", device_id, ndev);
   pk_ctx* c = new pk_ctx();
   c->device = device_id;
+  if (const char* st = getenv("POCKIT_AMD_STATIC_TABS")) c->static_tabs = atoi(st) != 0;
   if (const char* dbg = getenv("POCKIT_AMD_DEBUG_FLAGS")) c->debug_flags = atoi(dbg) & (256 | 512 | 1024 | 2048 | 4096 | 8192 | 16384 | 32768 | 65536 | 131072);
   if ((e = hipSetDevice(device_id)) != hipSuccess || (e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)) != hipSuccess) {
     int rc = fail(nullptr, 12, "pk_create: %s", hipGetErrorString(e));
@@ -1169,6 +1171,8 @@ int pk_set_exchange(pk_ctx* c, int world, int rank, const void* d_boxes, const i
 int pk_set_exchange_inline(pk_ctx* c, int enable) {
   if (!c) return fail(nullptr, 1, "null context");
   if (enable && !c->xc_box) return fail(c, 92, "pk_set_exchange_inline: call pk_set_exchange first");
+  if (enable && !c->md.sharded)
+    return fail(c, 95, "pk_set_exchange_inline: the code object was generated for a single GPU (no exchange code in pk_cycle)");
   c->xc_inline = enable != 0;
   return 0;
 }

@@ -163,9 +163,9 @@ class Tables:
 
 
 class Evaluator:
-    def __init__(self, plan: SystemPlan, device: int = 0, intervals_per_wave=None, tile_filter=None):
+    def __init__(self, plan: SystemPlan, device: int = 0, intervals_per_wave=None, tile_filter=None, sharded=False):
         self.plan = plan
-        self.src = ModelSource(plan)
+        self.src = ModelSource(plan, sharded=sharded)
         # (compiled before the context is created: a box without a GPU -- the build container -- can still fill the
         # code-object cache by constructing evaluators, tools/warm_cache.sh)
         code = hipbuild.compile_model(self.src.source, fastmath=plan.system._fastmath)
@@ -179,6 +179,7 @@ class Evaluator:
         md.ne_hc = self.src.list_off["hessc"]["total"] if self.src.compact else 0
         md.lds_e = self.src.lds_e
         md.tab_cap = self.src.tab_cap
+        md.sharded = int(self.src.sharded)
         self._err_views = None
         self._csr = {}
         md.prepass_f = 1

@@ -285,21 +285,38 @@ class PeerMailboxes:
         n_small = max(len(plan.I_syms), 1) + len(shared)
         self.stride = -(-(1 + n_small) // 16) * 16
         words = 2 * world * self.stride
-        self.own = C.c_void_p()
-        chk(lib.pk_device_alloc(h, 8 * words, 1, C.byref(self.own)))
-        handle = C.create_string_buffer(64)
-        chk(lib.pk_ipc_export(h, self.own, handle))
+        self.own, self.mapped = C.c_void_p(), []
+        # Every rank walks through ALL collective calls below whatever fails locally (a rank that raised early would
+        # leave the others waiting); the local failures are gathered and every rank takes the same decision.
+        problem, raw = None, None
+        try:
+            chk(lib.pk_device_alloc(h, 8 * words, 1, C.byref(self.own)))
+            handle = C.create_string_buffer(64)
+            chk(lib.pk_ipc_export(h, self.own, handle))
+            raw = handle.raw
+        except Exception as exc:  # noqa: BLE001
+            problem = f"rank {rank}: {exc!r}"
         got = [None] * world
-        dist.all_gather_object(got, (rank, handle.raw, os.getpid()))
-        self.mapped, ptrs = [], []
-        for r, raw, _pid in sorted(got):
-            if r == rank:
-                ptrs.append(self.own.value)
-                continue
-            p = C.c_void_p()
-            chk(lib.pk_ipc_open(h, C.create_string_buffer(raw, 64), C.byref(p)))
-            self.mapped.append(p)
-            ptrs.append(p.value)
+        dist.all_gather_object(got, (rank, raw, os.getpid(), problem))
+        ptrs = []
+        if all(g[3] is None for g in got):
+            try:
+                for r, peer_raw, _pid, _ in sorted(got):
+                    if r == rank:
+                        ptrs.append(self.own.value)
+                        continue
+                    p = C.c_void_p()
+                    chk(lib.pk_ipc_open(h, C.create_string_buffer(peer_raw, 64), C.byref(p)))
+                    self.mapped.append(p)
+                    ptrs.append(p.value)
+            except Exception as exc:  # noqa: BLE001
+                problem = f"rank {rank}: {exc!r}"
+        verdicts = [None] * world
+        dist.all_gather_object(verdicts, problem if problem else next((g[3] for g in got if g[3]), None))
+        failed = [v for v in verdicts if v]
+        if failed:
+            self.close()
+            raise RuntimeError("peer-mapped mailboxes are not available: " + "; ".join(sorted(set(failed))))
         self.table = torch.tensor(ptrs, dtype=torch.int64, device=device)
         self.idx = torch.tensor(np.asarray(shared, dtype=np.int32), dtype=torch.int32, device=device)
         chk(lib.pk_set_exchange(h, world, rank, C.c_void_p(self.table.data_ptr()), C.c_void_p(self.idx.data_ptr()),
@@ -311,8 +328,9 @@ class PeerMailboxes:
         if h:
             for p in self.mapped:
                 lib.pk_ipc_close(h, p)
-            lib.pk_device_free(h, self.own)
-        self.mapped = []
+            if self.own:
+                lib.pk_device_free(h, self.own)
+        self.mapped, self.own = [], C.c_void_p()
 
 
 class HostStagedCollectives:
@@ -373,7 +391,7 @@ class ShardedEvaluator:
         if intervals_per_wave is None:          # the tiling is sized for ONE shard's share of the mesh
             intervals_per_wave = _intervals_per_wave(plan, shards=world)
         self.ev = Evaluator(plan, device=device, intervals_per_wave=intervals_per_wave,
-                            tile_filter=tile_filter(rank, world, plan) if world > 1 else None)
+                            tile_filter=tile_filter(rank, world, plan) if world > 1 else None, sharded=world > 1)
         self.dev = dev = torch.device("cuda", device)
         n_I = max(len(plan.I_syms), 1)
         # integrals that later kernels need (models nonlinear in I) must be global *before* those kernels
@@ -421,22 +439,36 @@ class ShardedEvaluator:
             self.root = int(root)
             count = self.total + 1
             handle = C.create_string_buffer(64)
+            problem, base = None, None
             if self.rank == root:
-                # fine-grained: other GPUs write into it while this GPU's caches may hold neighbouring lines
-                self._root_alloc = C.c_void_p()
-                chk(lib.pk_device_alloc(h, 8 * count, 1, C.byref(self._root_alloc)))
-                chk(lib.pk_ipc_export(h, self._root_alloc, handle))
-                base = self._root_alloc.value
+                try:
+                    # fine-grained: other GPUs write into it while this GPU's caches may hold neighbouring lines
+                    self._root_alloc = C.c_void_p()
+                    chk(lib.pk_device_alloc(h, 8 * count, 1, C.byref(self._root_alloc)))
+                    chk(lib.pk_ipc_export(h, self._root_alloc, handle))
+                    base = self._root_alloc.value
+                except Exception as exc:  # noqa: BLE001 -- every rank still walks through the collectives below
+                    problem = f"rank {self.rank}: {exc!r}"
+            box = [(handle.raw, problem) if self.rank == root else None]
+            dist.broadcast_object_list(box, src=root)
+            if self.rank != root and box[0][1] is None:
+                try:
+                    self._root_map = C.c_void_p()
+                    chk(lib.pk_ipc_open(h, C.create_string_buffer(box[0][0], 64), C.byref(self._root_map)))
+                    base = self._root_map.value
+                except Exception as exc:  # noqa: BLE001
+                    self._root_map, problem = None, f"rank {self.rank}: {exc!r}"
+            verdicts = [None] * self.world
+            dist.all_gather_object(verdicts, problem or box[0][1])
+            failed = sorted(set(v for v in verdicts if v))
+            if failed:
+                self.root = None
+                raise RuntimeError("the peer mapping of the root's output buffer is not available: " + "; ".join(failed))
+            if self.rank == root:
                 self.full = torch.as_tensor(_DeviceArray(base, count), device=self.dev)
                 f = self.out["f"]
                 self.out = self._views(self.full)
                 self.out["f"] = f
-            box = [handle.raw if self.rank == root else None]
-            dist.broadcast_object_list(box, src=root)
-            if self.rank != root:
-                self._root_map = C.c_void_p()
-                chk(lib.pk_ipc_open(h, C.create_string_buffer(box[0], 64), C.byref(self._root_map)))
-                base = self._root_map.value
             self.target, off = {}, 0
             for name, n in self.sizes:                         # where this rank's kernels store in "direct" mode
                 self.target[name] = base + 8 * off
