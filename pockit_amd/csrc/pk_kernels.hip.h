@@ -557,7 +557,13 @@ __device__ __forceinline__ void stream_loop(const PkArgs& A, const PkPhase& ph, 
       for (int e = 0; e < NI; ++e) {
         if (pair) {
           const pk_d2 w = {v[0][e], v[1][e]};
-          asm volatile("global_store_dwordx4 %0, %1, off " PK_STREAM_FLAGS : : "v"(&run[e][p0]), "v"(w));
+          // The trailing s_nop is REQUIRED: gfx9-class hardware reads the data registers of a store wider than 64 bits
+          // over more than one cycle, and a VALU write of those registers needs a wait state behind the store.  The
+          // compiler inserts it for stores it knows; it cannot see into an asm statement, and the next iteration's
+          // first v_mul would overwrite `w` in the window.  Found at 40k nodes (humanoid, several waves per SIMD): 7 %
+          // of the pk_cycle launches had the first double of four neighbouring 16-byte stores of one segment replaced
+          // by the following product (tests/test_gpu_parity.py::test_cycle_is_bit_stable_at_forty_thousand_nodes).
+          asm volatile("global_store_dwordx4 %0, %1, off " PK_STREAM_FLAGS "\n\ts_nop 1" : : "v"(&run[e][p0]), "v"(w));
         } else {
           put(&run[e][p0], v[0][e]);
         }

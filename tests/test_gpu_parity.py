@@ -234,6 +234,29 @@ def test_full_size_configs_match_reference_summary():
         system._invalidate()
 
 
+def test_cycle_is_bit_stable_at_forty_thousand_nodes():
+    """The single-launch cycle at the humanoid's full size, 150 times on the same inputs: every launch must reproduce
+    the stand-alone Hessian kernel bit for bit.  (Regression: the 16-byte streaming store is an asm statement, so the
+    compiler did not insert the wait state gfx9-class hardware needs between a store of more than 64 bits and a VALU
+    write of its data registers; with several waves per SIMD about 7 % of the launches had 16 entries of one segment
+    replaced by the next iteration's products.  The 12k-node configurations -- one wave per SIMD -- never showed it.)"""
+    builder, scheme, kw = models.FULL_CASES["C5_humanoid_lgr_5000x8"]
+    system, _, guess = builder(_ns(scheme, "pockit_amd"), **kw)
+    x, lam, sigma = models.bench_inputs(system, guess)
+    ev = system.evaluator
+    H0 = np.array(ev.hessian_direct(x, lam, sigma))
+    f0, grad0, g0, J0, Hc = (np.array(v) for v in ev.cycle(x, lam, sigma))
+    assert np.array_equal(Hc, H0)
+    bad = []
+    for rep in range(150):
+        f1, grad1, g1, J1, H1 = ev.cycle(x, lam, sigma)
+        if not (np.array_equal(H1, H0) and np.array_equal(J1, J0) and np.array_equal(g1, g0)
+                and np.array_equal(grad1, grad0) and f1 == f0):
+            bad.append(rep)
+    assert not bad, f"launches that differ from the first: {bad}"
+    system._invalidate()
+
+
 def test_repeated_evaluation_with_changing_x():
     """The in-launch finalize (per-tile partials handed to the last-arriving workgroup) must see the
     *current* launch's partials: alternate between two points on one evaluator."""
