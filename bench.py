@@ -164,6 +164,73 @@ def end_to_end(system, guess, warm=20, timed=100):
     return out
 
 
+def host_sharded_end_to_end(name, intervals, rank, world, dist, warm=10, timed=60):
+    """N > 1: the five callbacks with host arrays, every rank landing its slices in ONE shared pinned host array over its
+    own PCIe link (pockit_amd.hostshard; SURVEY 8(e) "each GPU D2H's its own slices straight into the pinned host
+    array").  Rank 0 plays the solver, the other ranks serve.  Every rank walks through the same collectives whatever
+    fails locally."""
+    import torch
+
+    from pockit_amd import benchmarks as models
+    from pockit_amd.hostshard import HostShardedEvaluator
+    import pockit_amd.radau as radau
+
+    hs, problem = None, None
+    try:
+        system, _, guess = build_workload(name, intervals, radau)
+        hs = HostShardedEvaluator(system.plan, rank, world, dist, device=torch.cuda.current_device(), timeout_s=90.0)
+    except Exception as exc:  # noqa: BLE001
+        problem = f"rank {rank}: {exc!r}"
+    verdicts = [None] * world
+    dist.all_gather_object(verdicts, problem)
+    failed = sorted(set(v for v in verdicts if v))
+    if failed:
+        if hs is not None:
+            hs.close()
+        return {"error": "; ".join(failed)}
+    out = None
+    try:
+        if rank != 0:
+            hs.serve()
+        else:
+            x, lam, sigma = models.bench_inputs(system, guess)
+            xs = [x * (1.0 + 1e-9 * k) for k in range(8)]
+            names = ("objective", "gradient", "constraints", "jacobian", "hessian")
+            rows = []
+            for k in range(warm + timed):
+                xk = xs[k % len(xs)]
+                t = [time.perf_counter()]
+                hs.objective(xk)
+                t.append(time.perf_counter())
+                hs.gradient(xk)
+                t.append(time.perf_counter())
+                hs.constraints(xk)
+                t.append(time.perf_counter())
+                hs.jacobian(xk)
+                t.append(time.perf_counter())
+                hs.hessian(xk, lam, sigma)
+                t.append(time.perf_counter())
+                if k >= warm:
+                    rows.append([t[i + 1] - t[i] for i in range(5)] + [t[5] - t[0]])
+            med = [statistics.median(r[i] for r in rows) for i in range(6)]
+            p = system.plan
+            finite = bool(np.isfinite(hs.h_out).all() and np.isfinite(hs.h_f[0]))
+            out = {"cycles_per_s": 1.0 / med[5], "ms_per_cycle": med[5] * 1e3,
+                   "per_callback_ms": {nm: med[i] * 1e3 for i, nm in enumerate(names)},
+                   "bytes_to_host_per_cycle": 8 * (1 + p.n + p.m + p.nnz_J + p.nnz_H), "ranks": world, "finite": finite,
+                   "cycles": {"warmup": warm, "timed": timed, "statistic": "median"},
+                   "what": "objective, gradient, constraints, jacobian, hessian on a new x per cycle with NumPy arrays in and "
+                           "out; every rank evaluates its share of the mesh intervals and its run-copy kernel stores its "
+                           "own slices straight into ONE shared pinned host array over its own PCIe link; rank 0 adds the "
+                           "partial sums and evaluates f on the host (pockit_amd/hostshard.py)"}
+    except Exception as exc:  # noqa: BLE001
+        out = {"error": repr(exc)}
+    finally:
+        hs.close()
+    dist.barrier()
+    return out
+
+
 class GpuWorkload:
     """One workload set up on this rank: plan, evaluator, device-resident inputs / outputs, the step function."""
 
@@ -216,6 +283,12 @@ class GpuWorkload:
             except Exception as exc:          # no peer access between the GPUs: the RCCL forms remain
                 self.peer_error = repr(exc)
                 print(f"[bench] peer-mapped exchange not available ({exc!r}); using the RCCL gather form", file=sys.stderr)
+            if sev.peers is not None and not self.peer_exchange_works():
+                self.peer_error = "the peers' flags did not arrive (no coherent peer access between these GPUs?)"
+                print(f"[bench] peer-mapped exchange set up but not working: {self.peer_error}; using the RCCL gather form",
+                      file=sys.stderr)
+                sev.peers.close()
+                sev.peers = None
             if sev.peers is None and self.mode in ("sums", "direct"):
                 self.mode = "gather"
             step = self.make_step(self.mode)
@@ -230,6 +303,24 @@ class GpuWorkload:
             self.dominant = "pk_cycle"           # ONE launch does the whole cycle: its algorithmic bytes are SURVEY 8(d)'s B
         else:
             self.dominant = "pk_jac" if B["jac"] >= B["hess"] else "pk_hess"
+
+    def peer_exchange_works(self):
+        """One "sums" cycle behind a barrier: every rank must end up with a finite f, the same on all ranks (a peer whose
+        flag never becomes visible makes the bounded poll give up and the sums read NaN).  Every rank takes the same
+        decision."""
+        torch, dist = self.torch, self.dist
+        self.sync()
+        f = float("nan")
+        try:                                   # (local work only inside the try: the collectives below are unconditional)
+            self.sev.cycle(self.dx, self.dlam, self.sigma, dist, exchange="sums")
+            torch.cuda.synchronize()
+            f = float(self.o["f"].cpu()[0])
+        except Exception as exc:  # noqa: BLE001
+            print(f"[bench] peer exchange probe failed: {exc!r}", file=sys.stderr)
+        bad = 0.0 if np.isfinite(f) else 1.0
+        t = torch.tensor([f if bad == 0.0 else 0.0, -f if bad == 0.0 else 0.0, bad], dtype=torch.float64, device=self.dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return bool(float(t[2]) == 0.0 and float(t[0]) == -float(t[1]))      # nobody failed, max f == min f
 
     @staticmethod
     def fused_ok(plan):
@@ -469,6 +560,8 @@ def measure(name, intervals, steps, warmup, rank, world, dist, with_side=True, w
         system, _, guess = build_workload(name, intervals, radau)
         res["end_to_end"] = end_to_end(system, guess)
         system._invalidate()
+    if with_e2e and world > 1:
+        res["end_to_end_host_sharded"] = host_sharded_end_to_end(name, intervals, rank, world, dist)
     return res
 
 
@@ -561,13 +654,15 @@ def main():
         for nm, iv, tag in (("two_stage_rocket", 1000, "C4 two_stage_rocket 2 phases x 1000 intervals x 4 points"),
                             ("humanoid_wbc", 5000, "C5 humanoid_wbc 5000 intervals x 8 points")):
             try:
-                r = measure(nm, iv, args.steps, min(args.warmup, 50), rank, world, dist, with_side=False, with_e2e=False)
+                r = measure(nm, iv, args.steps, min(args.warmup, 50), rank, world, dist, with_side=False,
+                            with_e2e=(nm == "humanoid_wbc" and not args.no_end_to_end))
                 tt = torch.tensor([r["ms_per_step"]], dtype=torch.float64, device="cuda")
                 dist.all_reduce(tt, op=dist.ReduceOp.MAX)
                 strong[f"{nm}_{iv}_strong_scaled_over_{world}"] = {
                     "config": tag, "nodes": r["nodes"], "scaling": "strong", "cycles_per_s": 1e3 / float(tt.item()),
                     "ms_per_step": float(tt.item()), "exchange": r["exchange"], "exchange_forms_ms_per_step": r["exchange_forms_ms_per_step"],
-                    "ranks": r["ranks"], "cycle_bytes": r["bytes"]["cycle"]}
+                    "ranks": r["ranks"], "cycle_bytes": r["bytes"]["cycle"],
+                    "end_to_end_host_sharded": r.get("end_to_end_host_sharded")}
             except Exception as exc:  # noqa: BLE001
                 strong[f"{nm}_{iv}_strong_scaled_over_{world}"] = {"error": repr(exc)}
 
@@ -654,6 +749,8 @@ def main():
         line.update(res["side"])
         if res["end_to_end"] is not None:
             line["end_to_end"] = res["end_to_end"]
+        if res.get("end_to_end_host_sharded") is not None:
+            line["end_to_end_host_sharded"] = res["end_to_end_host_sharded"]
         if n_gpus == 1 and not args.no_extra:
             try:
                 line["compile_s_cold"] = cold_compile_seconds(args.workload, intervals)

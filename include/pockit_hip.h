@@ -231,6 +231,13 @@ int pk_ipc_export(pk_ctx* ctx, void* dptr, void* handle64 /* 64 bytes out */);
 int pk_ipc_open(pk_ctx* ctx, const void* handle64, void** out);
 int pk_ipc_close(pk_ctx* ctx, void* p);
 int pk_set_shared_grad_target(pk_ctx* ctx, double* d_grad_shared);
+/* Host-landed sharded cycle (every GPU lands its slices in ONE host array over its own PCIe link): a host
+ * region several processes map (shared memory) is page-locked and made device-visible in every process
+ * (pk_host_register), the ranks' run-copy kernels (pk_copy_runs_dev) store their owned runs straight into it;
+ * pk_copy_dev is an asynchronous copy between any two device-visible addresses. */
+int pk_host_register(pk_ctx* ctx, void* p, size_t bytes, void** dev_ptr);
+int pk_host_unregister(pk_ctx* ctx, void* p);
+int pk_copy_dev(pk_ctx* ctx, void* dst, const void* src, size_t bytes, void* stream);
 int pk_set_exchange(pk_ctx* ctx, int world, int rank, const void* d_boxes, const int32_t* d_idx, int n_sh, int stride);
 int pk_exchange_sums_dev(pk_ctx* ctx, const double* d_x, double* d_grad, double* d_f, int epoch /* <= 0: the context counts */,
                          int write_f, void* stream);

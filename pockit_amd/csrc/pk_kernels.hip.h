@@ -1635,6 +1635,9 @@ __device__ __forceinline__ void fin_body(const PkArgs& A) {
 // peer's flag of the cycle in between).  The poll is bounded (then the sums read NaN).
 // ============================================================================================
 #define PK_XC_CAP 512                                   // doubles of a partial vector (host checks)
+#ifndef PK_XC_POLL_LIMIT
+#define PK_XC_POLL_LIMIT (1 << 20)                      // poll rounds for a peer's flag: of the order of a second, then NaN
+#endif
 __device__ __forceinline__ void sys_store(unsigned long long* p, unsigned long long v) {
   __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
@@ -1660,8 +1663,8 @@ __device__ __forceinline__ void exchange_partials(const PkArgs& A, const double*
   if (t < W && t != me) {                               // one polling thread per peer
     unsigned long long* flag = A.xc_box[me] + half + (size_t)t * A.xc_stride;
     int tries = 0;
-    while (sys_load(flag) != (unsigned long long)A.xc_epoch && ++tries < PK_POLL_LIMIT) __builtin_amdgcn_s_sleep(PK_POLL_SLEEP);
-    if (tries >= PK_POLL_LIMIT) late = 1;
+    while (sys_load(flag) != (unsigned long long)A.xc_epoch && ++tries < PK_XC_POLL_LIMIT) __builtin_amdgcn_s_sleep(PK_POLL_SLEEP);
+    if (tries >= PK_XC_POLL_LIMIT) late = 1;
   }
   __threadfence_system();
   __syncthreads();

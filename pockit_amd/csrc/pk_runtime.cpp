@@ -1142,6 +1142,33 @@ int pk_ipc_close(pk_ctx* c, void* p) {
   return 0;
 }
 
+// Host memory of the caller's own (e.g. a shared-memory segment several processes map) made a DMA / kernel target:
+// page-locks [p, p + bytes) and returns the address the device sees it at.  pk_host_unregister before it is unmapped.
+int pk_host_register(pk_ctx* c, void* p, size_t bytes, void** dev_ptr) {
+  if (!c) return fail(nullptr, 1, "null context");
+  if (!p || !bytes || !dev_ptr) return fail(c, 60, "null host buffer");
+  PK_HIP(c, hipSetDevice(c->device));
+  PK_HIP(c, hipHostRegister(p, bytes, hipHostRegisterMapped | hipHostRegisterPortable));
+  PK_HIP(c, hipHostGetDevicePointer(dev_ptr, p, 0));
+  return 0;
+}
+
+int pk_host_unregister(pk_ctx* c, void* p) {
+  if (!c) return fail(nullptr, 1, "null context");
+  PK_HIP(c, hipSetDevice(c->device));
+  PK_HIP(c, hipDeviceSynchronize());
+  PK_HIP(c, hipHostUnregister(p));
+  return 0;
+}
+
+// Asynchronous copy between any two addresses the device can see (device memory, registered / pinned host memory)
+int pk_copy_dev(pk_ctx* c, void* dst, const void* src, size_t bytes, void* stream) {
+  if (!c) return fail(nullptr, 1, "null context");
+  if (!bytes) return 0;
+  PK_HIP(c, hipMemcpyAsync(dst, src, bytes, hipMemcpyDefault, pick(c, stream)));
+  return 0;
+}
+
 // A shard whose gradient output is another GPU's buffer keeps the slots shared by all nodes (partial sums) local.
 int pk_set_shared_grad_target(pk_ctx* c, double* d_grad_shared) {
   if (!c) return fail(nullptr, 1, "null context");

@@ -187,3 +187,76 @@ def test_two_process_sharded_cycle_matches_oracle(case):
     err = ret.get(timeout=5)
     assert isinstance(err, float), err
     assert err <= 1e-11, err
+
+
+def _host_worker(rank, world, port, case, ret):
+    """The host-landed sharded cycle (pockit_amd.hostshard): rank 0 serves the five callbacks from ONE shared pinned host
+    segment into which every rank's run-copy kernel stores its own slices; the other ranks ``serve()``."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import torch
+    import torch.distributed as dist
+
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import importlib
+
+        from pockit_amd.hostshard import HostShardedEvaluator
+
+        name, scheme, kw = case
+        builder = getattr(models, name)
+        system, _, guess = builder(importlib.import_module(f"pockit_amd.{scheme}"), **kw)
+        torch.cuda.set_device(0)
+        hs = HostShardedEvaluator(system.plan, rank, world, dist, device=0, intervals_per_wave=2, timeout_s=60.0)
+        err = 0.0
+        if rank != 0:
+            assert hs.serve(), "no command arrived"
+        else:
+            ref, _, _ = builder(importlib.import_module(f"oracle.{scheme}"), **kw)
+            x, lam, sigma = models.bench_inputs(system, guess)
+            scale = lambda a: max(1.0, float(np.max(np.abs(a)))) if np.size(a) else 1.0  # noqa: E731
+            for rep in range(3):
+                xk = x * (1.0 + 1e-3 * rep)
+                want = dict(f=ref.objective(xk), grad=ref.gradient(xk), g=ref.constraints(xk), J=ref.jacobian(xk),
+                            H=ref.hessian(xk, lam * (1 + rep), sigma + rep))
+                hs.h_out[:] = np.nan                                   # every position must be written by somebody
+                got = dict(f=hs.objective(xk), grad=hs.gradient(xk), g=hs.constraints(xk), J=hs.jacobian(xk))
+                got["H"] = hs.hessian(xk, lam * (1 + rep), sigma + rep)
+                for key in ("f", "grad", "g", "J", "H"):
+                    a, b = np.asarray(got[key], dtype=np.float64), np.asarray(want[key], dtype=np.float64)
+                    assert a.shape == b.shape, key
+                    err = max(err, float(np.max(np.abs(a - b)) / scale(b)) if b.size else 0.0)
+            err = float("inf") if not np.isfinite(err) else err
+        hs.close()
+        flag = torch.tensor([err])
+        dist.all_reduce(flag, op=dist.ReduceOp.MAX)
+        if rank == 0:
+            ret.put(float(flag.item()))
+    except Exception as exc:  # noqa: BLE001 -- report instead of hanging the other rank
+        if rank == 0:
+            ret.put(repr(exc))
+        raise
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+@pytest.mark.parametrize("case", [("two_stage_rocket", "radau", dict(mesh=40, num_point=4)),
+                                  ("planar_quadrotor", "lobatto", dict(mesh=33, num_point=5))])
+def test_host_landed_sharded_cycle_matches_oracle(case, world):
+    import torch.multiprocessing as mp
+
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    ret = ctx.Queue()
+    procs = [ctx.Process(target=_host_worker, args=(r, world, port, case, ret)) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(300)
+    assert all(p.exitcode == 0 for p in procs), [p.exitcode for p in procs]
+    err = ret.get(timeout=5)
+    assert isinstance(err, float), err
+    assert err <= 1e-11, err
