@@ -6,11 +6,11 @@ import sys
 import time
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-sys.path[:0] = [ROOT, os.path.join(ROOT, "tests")]
+sys.path[:0] = [ROOT]
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
-import models  # noqa: E402
+from pockit_amd import benchmarks as models  # noqa: E402
 import pockit_amd.radau as radau  # noqa: E402
 
 for name, builder, kw in (("quadrotor 2000x6", models.planar_quadrotor, dict(mesh=2000, num_point=6)),

@@ -7,12 +7,12 @@ import os
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-sys.path[:0] = [ROOT, os.path.join(ROOT, "tests")]
+sys.path[:0] = [ROOT]
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
 import bench  # noqa: E402
-import models  # noqa: E402
+from pockit_amd import benchmarks as models  # noqa: E402
 import pockit_amd.radau as radau  # noqa: E402
 
 total = int(sys.argv[1]) if len(sys.argv) > 1 else 200000

@@ -9,11 +9,11 @@ import sys
 
 os.environ["POCKIT_AMD_TRACE"] = "1"
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-sys.path[:0] = [ROOT, os.path.join(ROOT, "tests")]
+sys.path[:0] = [ROOT]
 import numpy as np  # noqa: E402
 
 import bench  # noqa: E402
-import models  # noqa: E402
+from pockit_amd import benchmarks as models  # noqa: E402
 import pockit_amd.radau as radau  # noqa: E402
 
 TICK_US = 0.01
