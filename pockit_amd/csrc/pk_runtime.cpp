@@ -176,7 +176,8 @@ void free_problem(pk_ctx* c) {
   release(c->d_trace);
   for (auto& m : c->csr) { release(m.d_seg); release(m.d_perm); release(m.d_vals); m.n_unique = m.n_triplets = 0; }
   release(c->d_ib); release(c->d_db); release(c->d_lb);
-  release(c->d_x); release(c->d_lam); release(c->d_f); release(c->d_grad); release(c->d_g); release(c->d_J);
+  c->d_g = nullptr;               // (interior pointer of the d_grad allocation)
+  release(c->d_x); release(c->d_lam); release(c->d_f); release(c->d_grad); release(c->d_J);
   release(c->d_H); release(c->d_I); release(c->d_partial); release(c->d_partial2);
   release(c->d_cpart); release(c->d_cpart2);
   for (int b = 0; b < 2; ++b) {
@@ -190,7 +191,7 @@ void free_problem(pk_ctx* c) {
   c->h_x = nullptr;
   c->x_valid = false;
   for (int k = 0; k < 5; ++k) {
-    if (c->h_out[k]) (void)hipHostFree(c->h_out[k]);
+    if (c->h_out[k] && k != 2) (void)hipHostFree(c->h_out[k]);      // (h_out[2] lives inside h_out[1]'s block)
     if (c->ev_out[k]) (void)hipEventDestroy(c->ev_out[k]);
     c->h_out[k] = c->target[k] = c->landed[k] = nullptr;
     c->ev_out[k] = nullptr;
@@ -356,9 +357,24 @@ double* device_result(pk_ctx* c, int what) {
 }
 
 // queue the copy of result `what` of the current iterate (no-op when the kernels stored it into host memory themselves)
+// f (what = 0) never needs a copy: pk_fin stores its 8 bytes straight into the pinned landing place (a DMA of 8 bytes
+// costs 16 us on this link).  grad f and g are neighbours on the device; when their landing places are neighbours too
+// (the context's own buffers, or a combined block of the caller) ONE copy serves both.
 int enqueue_result_copy(pk_ctx* c, int what) {
   if (c->enq[what]) return 0;
-  if (!c->host_direct)
+  if (what == 1 || what == 2) {
+    const bool neighbours = c->landed[2] == c->landed[1] + c->n && !c->enq[1] && !c->enq[2];
+    if (neighbours) {
+      if (!c->host_direct)
+        PK_HIP(c, hipMemcpyAsync(c->landed[1], c->d_grad, sizeof(double) * ((size_t)c->n + (size_t)c->m), hipMemcpyDeviceToHost,
+                                 c->stream));
+      PK_HIP(c, hipEventRecord(c->ev_out[1], c->stream));
+      PK_HIP(c, hipEventRecord(c->ev_out[2], c->stream));
+      c->enq[1] = c->enq[2] = true;
+      return 0;
+    }
+  }
+  if (!c->host_direct && what != 0)
     PK_HIP(c, hipMemcpyAsync(c->landed[what], device_result(c, what), sizeof(double) * result_count(c, what),
                              hipMemcpyDeviceToHost, c->stream));
   PK_HIP(c, hipEventRecord(c->ev_out[what], c->stream));
@@ -485,11 +501,12 @@ int pk_set_problem(pk_ctx* c, const pk_problem_desc* pd) {
     return 0;
   };
   if ((rc = dalloc(&c->d_x, c->n)) || (rc = dalloc(&c->d_lam, c->m)) || (rc = dalloc(&c->d_f, 1)) ||
-      (rc = dalloc(&c->d_grad, c->n)) || (rc = dalloc(&c->d_g, c->m)) || (rc = dalloc(&c->d_J, (size_t)c->nnz_J)) ||
+      (rc = dalloc(&c->d_grad, (size_t)c->n + (size_t)c->m)) || (rc = dalloc(&c->d_J, (size_t)c->nnz_J)) ||
       (rc = dalloc(&c->d_H, (size_t)c->nnz_H)) || (rc = dalloc(&c->d_aux, (size_t)c->n_aux)) || (rc = dalloc(&c->d_Hc, (size_t)c->nnz_Hc)) || (rc = dalloc(&c->d_I, c->md.n_I)) ||
       (rc = dalloc(&c->d_partial, (2 * (size_t)c->n_tiles / PK_WAVES_PER_BLOCK + 2) * (size_t)c->md.nred)) ||
       (rc = dalloc(&c->d_partial2, (2 * (size_t)c->n_tiles / PK_WAVES_PER_BLOCK + 2) * (size_t)c->md.nred)))
     return rc;
+  c->d_g = c->d_grad + c->n;      // grad f and g are neighbours (device and pinned host): ONE copy serves both (host shim)
   {   // hand-off slots of pk_cycle: one per x-kernel workgroup and reduction row, PK_EMPTY between launches
     const size_t slots = (2 * (size_t)c->n_tiles / PK_WAVES_PER_BLOCK + 2) * (size_t)c->md.nred;
     const std::vector<unsigned long long> empty(slots, (unsigned long long)PK_EMPTY);
@@ -505,7 +522,8 @@ int pk_set_problem(pk_ctx* c, const pk_problem_desc* pd) {
       PK_HIP(c, hipEventCreateWithFlags(&c->ev_lams[b], hipEventDisableTiming));
     }
     for (int k = 0; k < 5; ++k) {
-      PK_HIP(c, hipHostMalloc((void**)&c->h_out[k], sizeof(double) * (cnt[k] ? cnt[k] : 1), hipHostMallocDefault));
+      if (k == 2) c->h_out[2] = c->h_out[1] + cnt[1];        // (one block for grad f | g)
+      else PK_HIP(c, hipHostMalloc((void**)&c->h_out[k], sizeof(double) * ((k == 1 ? cnt[1] + cnt[2] : cnt[k]) + 1), hipHostMallocDefault));
       PK_HIP(c, hipEventCreateWithFlags(&c->ev_out[k], hipEventDisableTiming));
     }
     c->xbuf = c->lambuf = 0;
@@ -999,7 +1017,7 @@ int pk_prepare_x(pk_ctx* c, const double* x) {
     c->enq[k] = false;
   }
   double* o[4];
-  for (int k = 0; k < 4; ++k) o[k] = c->host_direct ? c->landed[k] : device_result(c, k);
+  for (int k = 0; k < 4; ++k) o[k] = (c->host_direct || k == 0) ? c->landed[k] : device_result(c, k);   // (f: always direct)
   const bool needs_I = c->md.prepass_grad || c->md.prepass_g || c->md.prepass_jac || c->md.prepass_hess;
   if (needs_I || c->external_prepass || c->shard_flags) {
     if ((rc = pk_eval_f_dev(c, c->d_x, o[0], nullptr))) return rc;

@@ -244,14 +244,21 @@ class Evaluator:
     # recycled only when the caller no longer refers to it.
     def _rings(self):
         if self._ring is None:
-            p = self.plan
-            self._ring = [runtime.PinnedRing(c) for c in (1, p.n, p.m, p.nnz_J, p.nnz_H)]
+            p = self.plan       # grad f and g come from ONE block (neighbours: the library then needs one copy for both)
+            self._ring = [runtime.PinnedRing(c) for c in (1, p.n + p.m, 0, p.nnz_J, p.nnz_H)]
         return self._ring
 
     def _targets(self, whats):
         """Pinned arrays of the caller's own for the results ``whats`` of the next evaluation (None: ring exhausted)."""
-        rings = self._rings()
-        return {w: rings[w].take() for w in whats}
+        rings, out, n = self._rings(), {}, self.plan.n
+        for w in whats:
+            if w in (1, 2):
+                if 1 not in out and 2 not in out:
+                    block = rings[1].take()
+                    out[1], out[2] = (None, None) if block is None else (block[:n], block[n:])
+            else:
+                out[w] = rings[w].take()
+        return {w: out[w] for w in whats}
 
     def _set_targets(self, arrs):
         ptr = [runtime.as_dp(arrs[w]) if arrs.get(w) is not None else None for w in range(5)]
