@@ -462,6 +462,10 @@ class GpuWorkload:
         for which, src, dst in ((0, self.o["J"], cj), (1, self.o["H"], ch)):
             csr["pk_csr_J_us" if which == 0 else "pk_csr_H_us"] = timed(
                 11, "pk_csr", lambda: lib.pk_gather_csr_dev(h, which, ptr(src), ptr(dst), st))
+        if "hessc" in ev._csr:      # the route pk_eval_hess_csr takes: compact evaluation (pk_hessc) + a pure permutation
+            hcv = torch.zeros(max(plan.nnz_Hc, 1), dtype=torch.float64, device=dev)
+            lib.pk_eval_hessc_dev(h, ptr(self.dx), ptr(self.dlam), C.c_double(float(self.sigma)), ptr(hcv), st)
+            csr["pk_csr_H_from_compact_us"] = timed(11, "pk_csr", lambda: lib.pk_gather_csr_dev(h, 2, ptr(hcv), ptr(ch), st))
         csr["finite"] = bool(torch.isfinite(cj).all() and torch.isfinite(ch).all())
         out["csr_handoff"] = csr
         return out

@@ -178,7 +178,9 @@ int pk_eval_mesh_error_dev(pk_ctx* ctx, const double* d_x, double* d_T, double* 
  * into CSR order on the device, repeated (row, col) entries summed in triplet order: the matrices can feed a
  * GPU KKT solve without crossing PCIe.  ``perm[q]``: triplet index of the q-th entry in (row, col) order;
  * ``seg[p] .. seg[p+1]``: the run of q belonging to CSR entry p (NULL when no entry repeats).  The CSR
- * structure itself (indptr, indices) is host data: pockit_amd/csr.py. */
+ * structure itself (indptr, indices) is host data: pockit_amd/csr.py.  which = 2 maps the COMPACT Hessian values
+ * (pk_eval_hessc, one value per distinct entry) onto the same CSR entries: when it is set, pk_eval_hess_csr(_dev) evaluate
+ * the compact form and permute instead of writing and re-adding every repeated triplet. */
 int pk_set_csr_map(pk_ctx* ctx, int which, const int32_t* seg /* n_unique + 1 or NULL */, const int32_t* perm,
                    int64_t n_unique, int64_t n_triplets);
 int pk_gather_csr_dev(pk_ctx* ctx, int which, const double* d_triplets, double* d_csr, void* stream);

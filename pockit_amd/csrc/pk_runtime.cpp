@@ -101,7 +101,7 @@ struct pk_ctx {
     int32_t *d_seg = nullptr, *d_perm = nullptr;
     double* d_vals = nullptr;
     int64_t n_unique = 0, n_triplets = 0;
-  } csr[2];
+  } csr[3];      // + [2]: compact Hessian values -> the same CSR entries (a pure permutation: one value per entry)
   // mesh error estimation (pk_set_mesh_error_tables)
   void* d_erriv = nullptr;
   int32_t* d_errgrp = nullptr;     // (first record, count) per wavefront of pk_err
@@ -661,8 +661,8 @@ int pk_eval_hessc_dev(pk_ctx* c, const double* d_x, const double* d_lam, double 
 int pk_set_csr_map(pk_ctx* c, int which, const int32_t* seg, const int32_t* perm, int64_t n_unique, int64_t n_triplets) {
   int rc = ready(c);
   if (rc) return rc;
-  if (which < 0 || which > 1) return fail(c, 80, "pk_set_csr_map: which must be 0 (Jacobian) or 1 (Hessian)");
-  const int64_t expect = which == 0 ? c->nnz_J : c->nnz_H;
+  if (which < 0 || which > 2) return fail(c, 80, "pk_set_csr_map: which must be 0 (Jacobian), 1 (Hessian) or 2 (compact Hessian)");
+  const int64_t expect = which == 0 ? c->nnz_J : which == 1 ? c->nnz_H : c->nnz_Hc;
   if (!perm || n_unique <= 0 || n_unique > n_triplets || n_triplets != expect || n_triplets > INT32_MAX)
     return fail(c, 81, "pk_set_csr_map: map does not match the problem (%lld triplets expected)", (long long)expect);
   // validate on the host: the kernel indexes with these
@@ -691,7 +691,7 @@ int pk_set_csr_map(pk_ctx* c, int which, const int32_t* seg, const int32_t* perm
 int pk_gather_csr_dev(pk_ctx* c, int which, const double* d_triplets, double* d_csr, void* stream) {
   int rc = ready(c);
   if (rc) return rc;
-  if (which < 0 || which > 1 || c->csr[which].n_unique == 0) return fail(c, 84, "pk_gather_csr: call pk_set_csr_map first");
+  if (which < 0 || which > 2 || c->csr[which].n_unique == 0) return fail(c, 84, "pk_gather_csr: call pk_set_csr_map first");
   const auto& m = c->csr[which];
   PkArgs A = base_args(c, nullptr, nullptr, 0.0);
   A.csr_in = d_triplets; A.csr_seg = m.d_seg; A.csr_perm = m.d_perm; A.csr_out = d_csr; A.n_csr = (int32_t)m.n_unique;
@@ -706,7 +706,15 @@ int pk_eval_jac_csr_dev(pk_ctx* c, const double* d_x, double* d_csr, void* strea
   return rc ? rc : pk_gather_csr_dev(c, 0, c->d_J, d_csr, stream);
 }
 
+// The CSR values of the Hessian come from the COMPACT evaluation when its map is set (which = 2): pk_hessc writes one value
+// per distinct (row, col) -- the multipliers contracted with the integration block first -- and the gather is a pure
+// permutation of nnz_Hc values; the route through the reference layout writes every repeated triplet (6.6 per entry at the
+// humanoid's size) and adds them up again (40k nodes: 17 + 52 us vs 8 + 6 us).
 int pk_eval_hess_csr_dev(pk_ctx* c, const double* d_x, const double* d_lam, double sigma, double* d_csr, void* stream) {
+  if (c && c->have_problem && c->csr[2].n_unique > 0 && c->nnz_Hc > 0) {
+    int rc = pk_eval_hessc_dev(c, d_x, d_lam, sigma, c->d_Hc, stream);
+    return rc ? rc : pk_gather_csr_dev(c, 2, c->d_Hc, d_csr, stream);
+  }
   int rc = pk_eval_hess_dev(c, d_x, d_lam, sigma, c ? c->d_H : nullptr, stream);
   return rc ? rc : pk_gather_csr_dev(c, 1, c->d_H, d_csr, stream);
 }
@@ -729,13 +737,14 @@ int pk_eval_hess_csr(pk_ctx* c, const double* x, const double* lambda, double si
   int rc = ready(c);
   if (rc) return rc;
   if (!x || !lambda || !vals) return fail(c, 60, "null host buffer");
-  if (c->csr[1].n_unique == 0) return fail(c, 84, "pk_eval_hess_csr: call pk_set_csr_map first");
+  const int hm = c->csr[2].n_unique > 0 ? 2 : 1;      // (both maps fill the same CSR entries)
+  if (c->csr[hm].n_unique == 0) return fail(c, 84, "pk_eval_hess_csr: call pk_set_csr_map first");
   PK_HIP(c, hipSetDevice(c->device));
   c->x_valid = false;
   PK_HIP(c, hipMemcpyAsync(c->d_x, x, sizeof(double) * (size_t)c->n, hipMemcpyHostToDevice, c->stream));
   PK_HIP(c, hipMemcpyAsync(c->d_lam, lambda, sizeof(double) * (size_t)c->m, hipMemcpyHostToDevice, c->stream));
-  if ((rc = pk_eval_hess_csr_dev(c, c->d_x, c->d_lam, sigma, c->csr[1].d_vals, nullptr))) return rc;
-  PK_HIP(c, hipMemcpyAsync(vals, c->csr[1].d_vals, sizeof(double) * (size_t)c->csr[1].n_unique, hipMemcpyDeviceToHost, c->stream));
+  if ((rc = pk_eval_hess_csr_dev(c, c->d_x, c->d_lam, sigma, c->csr[hm].d_vals, nullptr))) return rc;
+  PK_HIP(c, hipMemcpyAsync(vals, c->csr[hm].d_vals, sizeof(double) * (size_t)c->csr[hm].n_unique, hipMemcpyDeviceToHost, c->stream));
   PK_HIP(c, hipStreamSynchronize(c->stream));
   return 0;
 }

@@ -434,6 +434,15 @@ class Evaluator:
             self.ctx.check(self.ctx.lib.pk_set_csr_map(self.ctx.handle, 0 if which == "jac" else 1, seg,
                                                        m.perm.ctypes.data_as(runtime.c_int32_p), m.nnz, m.n_triplets))
             self._csr[which] = m
+            if which == "hess" and self.src.compact and not os.environ.get("POCKIT_AMD_CSR_FROM_TRIPLETS"):
+                # the compact Hessian has one value per distinct (row, col): if its pattern is the full pattern's set of
+                # entries, the CSR values are a permutation of it (pk_eval_hess_csr then never writes the repeats)
+                mc = CsrMap(plan.hessc_row, plan.hessc_col, (plan.n, plan.n))
+                if mc.seg is None and mc.nnz == m.nnz and np.array_equal(mc.indices, m.indices) \
+                        and np.array_equal(mc.indptr, m.indptr):
+                    self.ctx.check(self.ctx.lib.pk_set_csr_map(self.ctx.handle, 2, None,
+                                                               mc.perm.ctypes.data_as(runtime.c_int32_p), mc.nnz, mc.n_triplets))
+                    self._csr["hessc"] = mc
         return self._csr[which]
 
     def jacobian_csr(self, x):

@@ -652,6 +652,8 @@ def test_device_csr_handoff_matches_reference_matrices(name):
 
 def test_device_csr_full_size_matches_host_gather():
     """Quadrotor 2000 x 6: device gather == host gather of the device triplets (bit-exact for J: no repeats)."""
+    import torch
+
     system, _, guess = models.planar_quadrotor(_ns("radau", "pockit_amd"), mesh=2000, num_point=6)
     x, lam, sigma = models.bench_inputs(system, guess)
     ev = system.evaluator
@@ -659,7 +661,13 @@ def test_device_csr_full_size_matches_host_gather():
     mj, mh = ev.csr_map("jac"), ev.csr_map("hess")
     assert mj.seg is None and mh.seg is not None
     assert np.array_equal(ev.jacobian_csr(x), mj.gather(J))
-    close(ev.hessian_csr(x, lam, sigma), mh.gather(H), 1e-14, what="H csr")
+    assert "hessc" in ev._csr, "the compact Hessian's pattern should be the full pattern's set of entries"
+    close(ev.hessian_csr(x, lam, sigma), mh.gather(H), what="H csr (from the compact evaluation)")
+    dev = torch.device("cuda", 0)                      # the triplet route stays available for device-resident triplets
+    dH, out = torch.from_numpy(H).to(dev), torch.zeros(mh.nnz, dtype=torch.float64, device=dev)
+    ev.gather_csr_dev("hess", dH.data_ptr(), out.data_ptr())
+    ev.sync()
+    close(out.cpu().numpy(), mh.gather(H), 1e-14, what="H csr (gathered triplets)")
 
 
 # ---------------------------------------------------------------------------------------------------------
