@@ -197,6 +197,9 @@ int pk_eval_g_dev(pk_ctx* ctx, const double* d_x, double* d_g, void* stream);
 int pk_eval_jac_dev(pk_ctx* ctx, const double* d_x, double* d_vals, void* stream);
 int pk_eval_hess_dev(pk_ctx* ctx, const double* d_x, const double* d_lambda, double sigma, double* d_vals,
                      void* stream);
+/* the four x-only outputs of one iterate (what a line search's trial point needs, what the host shim runs on a new x):
+ * the fused x-kernel + the one-workgroup reduction, two launches */
+int pk_eval_xpart_dev(pk_ctx* ctx, const double* d_x, double* d_f, double* d_grad, double* d_g, double* d_jac, void* stream);
 /* one NLP-callback cycle f, grad f, g, J, H on the same x (IPOPT's per-iteration pattern), as ONE launch
  * (pk_cycle: the workgroups of the fused x-kernel -- each node evaluated once for f, grad f, g, J -- and of the
  * Hessian kernel side by side, plus a finalize workgroup fed by the same launch).  One cycle may be in flight

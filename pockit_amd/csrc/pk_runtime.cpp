@@ -884,6 +884,34 @@ int pk_eval_cycle_dev(pk_ctx* c, const double* d_x, const double* d_lam, double 
   return 0;
 }
 
+// The four x-only outputs (f, grad f, g, J) of one iterate on device pointers: the fused x-kernel (every node evaluated
+// once, one joint CSE) + the one-workgroup reduction -- what a line search's trial point needs, and what the host shim
+// runs on a new x.  A shard (pk_set_shard) leaves ITS share of the integrals in the integral buffer and its partial sums
+// in the shared gradient slots; its f is not meaningful (the caller adds the integrals over the shards first).  Models
+// whose system functions are nonlinear in the integrals run the callbacks one after the other.
+int pk_eval_xpart_dev(pk_ctx* c, const double* d_x, double* d_f, double* d_grad, double* d_g, double* d_jac, void* stream) {
+  int rc = ready(c);
+  if (rc) return rc;
+  hipStream_t st = pick(c, stream);
+  const bool needs_I = c->md.prepass_grad || c->md.prepass_g || c->md.prepass_jac || c->md.prepass_hess;
+  if (needs_I) {
+    if (!c->external_prepass && (rc = pk_eval_f_dev(c, d_x, d_f, stream))) return rc;
+    if ((rc = pk_eval_grad_dev(c, d_x, d_grad, stream))) return rc;
+    if ((rc = pk_eval_g_dev(c, d_x, d_g, stream))) return rc;
+    return pk_eval_jac_dev(c, d_x, d_jac, stream);
+  }
+  PkArgs A = base_args(c, d_x, nullptr, 0.0);
+  A.o_f = d_f; A.o_grad = d_grad; A.o_g = d_g; A.o_jac = d_jac;
+  A.items = (const PkItem*)c->d_items_jac;
+  A.n_items = c->n_items_jac;
+  size_t lds = sizeof(double) * PK_WAVES_PER_BLOCK * (size_t)c->md.lds_x;
+  if (lds < sizeof(double) * (size_t)c->md.ne_j) lds = sizeof(double) * (size_t)c->md.ne_j;
+  A.flags |= xall_flags(c);
+  if ((rc = launch(c, K_XALL, A, xall_blocks(c), lds, st))) return rc;
+  A.flags |= F_FIN_INT | F_WRITE_F | F_FIN_GRAD;
+  return launch(c, K_FIN, A, 1, 0, st);
+}
+
 // 1 (default): the cycle is ONE launch (pk_cycle); 0: two launches (pk_xall, then pk_hess with the reductions)
 int pk_set_cycle_mode(pk_ctx* c, int single_launch) {
   if (!c) return fail(nullptr, 1, "null context");
@@ -1027,24 +1055,7 @@ int pk_prepare_x(pk_ctx* c, const double* x) {
   }
   double* o[4];
   for (int k = 0; k < 4; ++k) o[k] = (c->host_direct || k == 0) ? c->landed[k] : device_result(c, k);   // (f: always direct)
-  const bool needs_I = c->md.prepass_grad || c->md.prepass_g || c->md.prepass_jac || c->md.prepass_hess;
-  if (needs_I || c->external_prepass || c->shard_flags) {
-    if ((rc = pk_eval_f_dev(c, c->d_x, o[0], nullptr))) return rc;
-    if ((rc = pk_eval_grad_dev(c, c->d_x, o[1], nullptr))) return rc;
-    if ((rc = pk_eval_g_dev(c, c->d_x, o[2], nullptr))) return rc;
-    if ((rc = pk_eval_jac_dev(c, c->d_x, o[3], nullptr))) return rc;
-  } else {
-    PkArgs A = base_args(c, c->d_x, nullptr, 0.0);
-    A.o_f = o[0]; A.o_grad = o[1]; A.o_g = o[2]; A.o_jac = o[3];
-    A.items = (const PkItem*)c->d_items_jac;
-    A.n_items = c->n_items_jac;
-    size_t lds = sizeof(double) * PK_WAVES_PER_BLOCK * (size_t)c->md.lds_x;
-    if (lds < sizeof(double) * (size_t)c->md.ne_j) lds = sizeof(double) * (size_t)c->md.ne_j;
-    A.flags |= xall_flags(c);
-    if ((rc = launch(c, K_XALL, A, xall_blocks(c), lds, c->stream))) return rc;
-    A.flags |= F_FIN_INT | F_WRITE_F | F_FIN_GRAD;
-    if ((rc = launch(c, K_FIN, A, 1, 0, c->stream))) return rc;
-  }
+  if ((rc = pk_eval_xpart_dev(c, c->d_x, o[0], o[1], o[2], o[3], nullptr))) return rc;
   // f and g are what a line search asks for at every trial point: always on their way; grad f and J in prefetch mode
   if ((rc = enqueue_result_copy(c, 0))) return rc;
   if (c->prefetch && (rc = enqueue_result_copy(c, 1))) return rc;

@@ -11,7 +11,7 @@ Mechanics.  Rank 0 is the solver's process (``HostShardedEvaluator`` with the ca
 ``serve()``.  One POSIX shared-memory segment holds a control block, x, lambda, sigma, every rank's partial sums and the
 packed outputs ``[grad | g | J | H]``; every process page-locks it for its GPU (``pk_host_register``).  A callback on a
 new x writes x, bumps the sequence number and evaluates rank 0's own shard; every other rank sees the number, uploads x
-from the segment over its link, evaluates its shard (``pk_eval_integrals_dev / grad / g / jac`` on its tiles), lets the
+from the segment over its link, evaluates its shard (``pk_eval_xpart_dev``: the fused x-kernel on its tiles), lets the
 run-copy kernel (``pk_runs``) store its owned runs into the segment and publishes its partial sums [integrals | shared
 gradient slots]; rank 0 adds them in rank order and evaluates f = F_o(I, s) (systembase.py:592-605) on the host.  The
 Hessian works the same way with lambda and sigma.  No collective, no device-to-device traffic.
@@ -152,10 +152,9 @@ class HostShardedEvaluator:
     def _do_x_part(self):
         lib, h, chk, n, m = self.lib, self.h, self.chk, self.plan.n, self.plan.m
         chk(lib.pk_copy_dev(h, self.d_x, self._dev("x"), 8 * n, None))                 # x over THIS rank's link
-        chk(lib.pk_eval_integrals_dev(h, self.d_x, None))                                # this shard's integrals
-        chk(lib.pk_eval_grad_dev(h, self.d_x, self.d_out["grad"], None))
-        chk(lib.pk_eval_g_dev(h, self.d_x, self.d_out["g"], None))
-        chk(lib.pk_eval_jac_dev(h, self.d_x, self.d_out["J"], None))
+        # the fused x-kernel on this shard's tiles: its slices of grad f / g / J, its share of the integrals (-> d_small)
+        # and its partial sums of the shared gradient slots (f is rank 0's to compute from the summed integrals)
+        chk(lib.pk_eval_xpart_dev(h, self.d_x, self.d_f, self.d_out["grad"], self.d_out["g"], self.d_out["J"], None))
         self._runs(self.tab_x, self.d_full, self._dev("out"))                            # owned runs -> the solver's arrays
         self._runs(self.tab_sh, self.d_out["grad"], self.d_small)                        # shared slots behind the integrals
         chk(lib.pk_copy_dev(h, C.c_void_p(self._dev("part").value + 8 * self.rank * self.n_small), self.d_small,

@@ -74,7 +74,7 @@ EXPORTS = ["pk_create", "pk_destroy", "pk_last_error", "pk_device_count", "pk_lo
            "pk_result_location", "pk_set_host_mode", "pk_stage_lambda", "pk_invalidate_x", "pk_host_alloc", "pk_host_free",
            "pk_device_alloc", "pk_device_free", "pk_ipc_export", "pk_ipc_open", "pk_ipc_close", "pk_set_shared_grad_target",
            "pk_set_exchange", "pk_exchange_sums_dev", "pk_copy_runs_dev", "pk_set_exchange_inline",
-           "pk_host_register", "pk_host_unregister", "pk_copy_dev"]
+           "pk_host_register", "pk_host_unregister", "pk_copy_dev", "pk_eval_xpart_dev"]
 
 _lib = None
 
@@ -154,6 +154,7 @@ def load_library():
     lib.pk_host_register.argtypes = [vp, vp, C.c_size_t, C.POINTER(vp)]
     lib.pk_host_unregister.argtypes = [vp, vp]
     lib.pk_copy_dev.argtypes = [vp, vp, vp, C.c_size_t, vp]
+    lib.pk_eval_xpart_dev.argtypes = [vp, vp, vp, vp, vp, vp, vp]
     lib.pk_eval_hessc.argtypes = [vp, dp, dp, C.c_double, dp]
     lib.pk_eval_hessc_dev.argtypes = [vp, vp, vp, C.c_double, vp, vp]
     lib.pk_set_mesh_error_tables.argtypes = [vp, vp, C.c_int32, vp, C.c_int32, dp, C.c_int64, C.c_int64]
