@@ -127,9 +127,11 @@ struct pk_ctx {
   bool lam_staged = false;                 // pk_stage_lambda ran, pk_eval_hess_prepared has not consumed it yet
   double* h_out[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
   double* target[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};   // pk_set_result_targets (NULL: h_out[k])
+  bool target_visible[5] = {true, true, true, true, true};             // the device can store into target[k] itself
   double* landed[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};   // where result k of the current iterate went
   hipEvent_t ev_out[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
   bool enq[5] = {false, false, false, false, false};                   // copy of result k is enqueued / done
+  bool stored_direct[5] = {false, false, false, false, false};         // the kernel stored result k into its landing place
   int prefetch = 1;            // 1: every x-only result is copied out right behind the kernel; 0: on first request
   int host_direct = 0;         // 1: the kernels store into the (pinned, device-visible) host targets themselves
   // profiling
@@ -364,8 +366,8 @@ int enqueue_result_copy(pk_ctx* c, int what) {
   if (c->enq[what]) return 0;
   if (what == 1 || what == 2) {
     const bool neighbours = c->landed[2] == c->landed[1] + c->n && !c->enq[1] && !c->enq[2];
-    if (neighbours) {
-      if (!c->host_direct)
+    if (neighbours && c->stored_direct[1] == c->stored_direct[2]) {
+      if (!c->stored_direct[1])
         PK_HIP(c, hipMemcpyAsync(c->landed[1], c->d_grad, sizeof(double) * ((size_t)c->n + (size_t)c->m), hipMemcpyDeviceToHost,
                                  c->stream));
       PK_HIP(c, hipEventRecord(c->ev_out[1], c->stream));
@@ -374,7 +376,7 @@ int enqueue_result_copy(pk_ctx* c, int what) {
       return 0;
     }
   }
-  if (!c->host_direct && what != 0)
+  if (!c->stored_direct[what])
     PK_HIP(c, hipMemcpyAsync(c->landed[what], device_result(c, what), sizeof(double) * result_count(c, what),
                              hipMemcpyDeviceToHost, c->stream));
   PK_HIP(c, hipEventRecord(c->ev_out[what], c->stream));
@@ -1009,7 +1011,20 @@ int pk_set_result_targets(pk_ctx* c, double* f, double* grad, double* g, double*
   int rc = ready(c);
   if (rc) return rc;
   double* t[5] = {f, grad, g, jac, hess};
-  for (int k = 0; k < 5; ++k) c->target[k] = t[k];
+  for (int k = 0; k < 5; ++k) {
+    c->target[k] = t[k];
+    // A kernel may store into a target only if the device can see it (pinned / registered host memory); a pageable
+    // target still works as the destination of a copy.
+    c->target_visible[k] = true;
+    if (t[k]) {
+      hipPointerAttribute_t attr;
+      std::memset(&attr, 0, sizeof attr);
+      const hipError_t e = hipPointerGetAttributes(&attr, t[k]);
+      if (e != hipSuccess) (void)hipGetLastError();
+      c->target_visible[k] = e == hipSuccess && (attr.type == hipMemoryTypeHost || attr.type == hipMemoryTypeDevice ||
+                                                 attr.type == hipMemoryTypeManaged);
+    }
+  }
   return 0;
 }
 
@@ -1054,7 +1069,10 @@ int pk_prepare_x(pk_ctx* c, const double* x) {
     c->enq[k] = false;
   }
   double* o[4];
-  for (int k = 0; k < 4; ++k) o[k] = (c->host_direct || k == 0) ? c->landed[k] : device_result(c, k);   // (f: always direct)
+  for (int k = 0; k < 4; ++k) {     // (f: stored by the kernel itself whenever its landing place is device-visible)
+    c->stored_direct[k] = (c->host_direct || k == 0) && (!c->target[k] || c->target_visible[k]);
+    o[k] = c->stored_direct[k] ? c->landed[k] : device_result(c, k);
+  }
   if ((rc = pk_eval_xpart_dev(c, c->d_x, o[0], o[1], o[2], o[3], nullptr))) return rc;
   // f and g are what a line search asks for at every trial point: always on their way; grad f and J in prefetch mode
   if ((rc = enqueue_result_copy(c, 0))) return rc;
@@ -1105,7 +1123,8 @@ int pk_eval_hess_prepared(pk_ctx* c, const double* lambda, double sigma, double*
   c->lam_staged = false;
   c->landed[4] = c->target[4] ? c->target[4] : c->h_out[4];
   c->enq[4] = false;
-  if ((rc = pk_eval_hess_dev(c, c->d_x, c->d_lam, sigma, c->host_direct ? c->landed[4] : c->d_H, nullptr))) return rc;
+  c->stored_direct[4] = c->host_direct && (!c->target[4] || c->target_visible[4]);
+  if ((rc = pk_eval_hess_dev(c, c->d_x, c->d_lam, sigma, c->stored_direct[4] ? c->landed[4] : c->d_H, nullptr))) return rc;
   if ((rc = enqueue_result_copy(c, 4))) return rc;
   PK_HIP(c, hipEventSynchronize(c->ev_out[4]));
   if (vals && vals != c->landed[4]) std::memcpy(vals, c->landed[4], sizeof(double) * (size_t)c->nnz_H);

@@ -184,6 +184,38 @@ def test_prepared_x_cache_is_dropped_by_calls_that_reuse_the_context_buffers():
         close(system.objective(x1), want["f"], what="f after")
 
 
+def test_pageable_result_targets_of_a_c_abi_caller():
+    """pk_set_result_targets with ordinary (pageable) host arrays, as a caller of the C ABI may pass them: the results
+    are copied there (a kernel stores only into targets the device can see: pinned memory of pk_host_alloc, or the
+    context's own buffers)."""
+    import ctypes as C
+
+    from pockit_amd import runtime
+
+    system, _, guess = models.two_stage_rocket(_ns("radau", "pockit_amd"), 30, 4)
+    ref, _, _ = models.two_stage_rocket(_ns("radau", "oracle"), 30, 4)
+    x, lam, sigma = models.bench_inputs(system, guess)
+    ev, plan = system.evaluator, system.plan
+    lib, h, dp = ev.ctx.lib, ev.ctx.handle, runtime.as_dp
+    for host_direct in (False, True):
+        ev.set_host_mode(True, host_direct)
+        out = [np.full(k, np.nan) for k in (1, plan.n, plan.m, plan.nnz_J, plan.nnz_H)]
+        ev.ctx.check(lib.pk_set_result_targets(h, *[dp(a) for a in out]))
+        ev.ctx.check(lib.pk_prepare_x(h, dp(x)))
+        for what in range(4):
+            ev.ctx.check(lib.pk_fetch(h, what, None))
+        ev.ctx.check(lib.pk_eval_hess_prepared(h, dp(lam), C.c_double(sigma), None))
+        ev.ctx.check(lib.pk_set_result_targets(h, None, None, None, None, None))
+        close(out[0][0], ref.objective(x), what="f")
+        close(out[1], ref.gradient(x), what="grad")
+        close(out[2], ref.constraints(x), what="g")
+        close(out[3], ref.jacobian(x), what="J")
+        close(out[4], ref.hessian(x, lam, sigma), what="H")
+    ev.set_host_mode(True, False)
+    ev._invalidate_x()
+    close(system.gradient(x), ref.gradient(x), what="grad afterwards")
+
+
 def test_ragged_mesh_matches_oracle():
     """hp-style mesh: every interval its own width and polynomial order (K = 1 .. 9)."""
     rng = np.random.default_rng(5)
