@@ -226,6 +226,13 @@ class HostShardedEvaluator:
         self.out["grad"][self.shared] = small[self.n_I:]
         self._x_seq = seq
 
+    # (the structures complete the cyipopt ``problem_obj`` protocol: systembase.py:671-674, 811-818)
+    def jacobianstructure(self):
+        return self.plan.jac_row, self.plan.jac_col
+
+    def hessianstructure(self):
+        return self.plan.hess_row, self.plan.hess_col
+
     def objective(self, x):
         self._prepare(x)
         return np.float64(self.h_f[0])
