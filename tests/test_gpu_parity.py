@@ -157,6 +157,38 @@ def test_high_order_tiles_match_oracle(case, cap, monkeypatch):
     check(ev.hessian_direct(x, lam, sigma), ref.hessian(x, lam, sigma), what="H direct")
 
 
+@pytest.mark.parametrize("case", [("brachistochrone", "radau", dict(mesh=[0, 0.4, 1.0], num_point=[64, 33])),
+                                  ("brachistochrone", "lobatto", dict(mesh=[0, 0.3, 0.7, 1.0], num_point=[64, 40, 64])),
+                                  ("planar_quadrotor", "radau", dict(mesh=[0, 0.5, 1.0], num_point=[64, 64])),
+                                  ("two_stage_rocket", "lobatto", dict(mesh=2, num_point=64))])
+def test_maximum_supported_order_matches_the_plan_interpreter(case):
+    """The documented limit -- 64 points per interval, one interval filling a wavefront (the LGR end slot then lies
+    beyond the wave's lanes) -- against the NumPy execution of the same plan with the product's own tables
+    (tests/plan_interp.py): the oracle's np.roots-based tables are useless at this order (weights off by more than 1e-3)."""
+    from plan_interp import Interp
+
+    bname, scheme, kw = case
+    system, _, guess = getattr(models, bname)(_ns(scheme, "pockit_amd"), **kw)
+    x, lam, sigma = models.bench_inputs(system, guess)
+    it = Interp(system.plan, x, lam, sigma)
+    want = dict(f=it.objective(), grad=it.gradient(), g=it.constraints(), J=it.jacobian(), H=it.hessian())
+    close(system.objective(x), want["f"], what="f")
+    close(system.gradient(x), want["grad"], what="grad")
+    close(system.constraints(x), want["g"], what="g")
+    close(system.jacobian(x), want["J"], what="J")
+    close(system.hessian(x, lam, sigma), want["H"], what="H")
+    f, grad, g, J, H = system.evaluator.cycle(x, lam, sigma)
+    close(g, want["g"], what="cycle g")
+    close(J, want["J"], what="cycle J")
+    close(H, want["H"], what="cycle H")
+    ev = system.evaluator
+    close(ev.constraints_direct(x), want["g"], what="g direct")
+    close(ev.jacobian_direct(x), want["J"], what="J direct")
+    close(ev.hessian_direct(x, lam, sigma), want["H"], what="H direct")
+    with pytest.raises(NotImplementedError):
+        getattr(models, bname)(_ns(scheme, "pockit_amd"), mesh=1, num_point=65).plan
+
+
 def test_prepared_x_cache_is_dropped_by_calls_that_reuse_the_context_buffers():
     """objective / gradient / constraints / jacobian / hessian on x1 serve from ONE upload of x1; any other entry
     point that uploads a different x (mesh error, the one-launch cycle, the *_direct and CSR calls) in between must
