@@ -168,7 +168,12 @@ class ModelSource:
             self.list_keys += [("f", k), ("b", k)]
         self.list_keys.append(("s",))
         self.list_off = {}
-        self.compact = not plan.outer          # compact Hessian functions exist unless outer-product blocks are needed
+        # intervals with more points than a wavefront has lanes (64 < K <= 256) are evaluated by a whole workgroup: code
+        # compiled into the object only when the mesh has such an interval (PK_BIG); no compact Hessian then
+        self.big = any(int(pp.layout.K.max()) > 64 for pp in plan.phase_plans)
+        if self.big and plan.outer:
+            raise NotImplementedError("num_point > 64 together with system functions nonlinear in the integrals")
+        self.compact = not plan.outer and not self.big
         for cbname in ("jac", "hess", "aux") + (("hessc",) if self.compact else ()):
             cb = getattr(plan, cbname)
             off, table = 0, {}
@@ -392,6 +397,8 @@ class ModelSource:
             S.append("#define PK_WIDE_STORES 0")
         if os.environ.get("POCKIT_AMD_STATIC_TABS", "0") == "1":     # A/B: table blocks in static LDS
             S.append("#define PK_STATIC_TABS 1")
+        if self.big:
+            S.append("#define PK_BIG 1")
         if self.sharded:
             S.append("#define PK_SHARDED 1")
         stream = {"sc1nt": "sc1 nt", "nt": "nt", "plain": "", "sc0sc1": "sc0 sc1", "sc0sc1nt": "sc0 sc1 nt"}.get(
@@ -426,8 +433,8 @@ class ModelSource:
         # Hessian: staged segment values + the tile's defect multipliers [state][row]
         self.lds_h = 64 * max([1] + [pp.nx + sum(1 for sg in plan.hess.segs[k] if sg.kind == "I")
                                      for k, pp in enumerate(plan.phase_plans)])
-        self.lds_x = 64 * max([1] + [pp.nx + sum(1 for sg in plan.jac.segs[k] if sg.kind == "I")
-                                     for k, pp in enumerate(plan.phase_plans)])
+        self.lds_x = 64 * max([1] + [pp.nx * (2 if self.big else 1) + sum(1 for sg in plan.jac.segs[k] if sg.kind == "I")
+                                     for k, pp in enumerate(plan.phase_plans)])      # (big: + the node values [NX][256])
         self.lds_e = 64 * max([1] + [2 * pp.nx + pp.nu for pp in plan.phase_plans])
         S.append(f"  static constexpr int LDS_G = {self.lds_g}, LDS_J = {self.lds_j}, LDS_H = {self.lds_h}, "
                  f"LDS_X = {self.lds_x}, LDS_E = {self.lds_e};")
@@ -444,6 +451,17 @@ class ModelSource:
                      f"double* __restrict__ lds, double* __restrict__ wint, double* __restrict__ wgrad, int lane"
                      f"{', int pub_blk' if pub else ''}) {{")
             S.append(switch(f"{target}(A, tl, lds, wint, wgrad, lane{', pub_blk' if pub else ''})"))
+            S.append("  }")
+        if self.big:
+            for name, target in (("bigx0", "pk::big_xall<{P}, 0>"), ("bigx1", "pk::big_xall<{P}, 1>"),
+                                 ("bigx2", "pk::big_xall<{P}, 2>")):
+                S.append(f"  __device__ static __forceinline__ void {name}(int phase, const PkArgs& A, const PkTile& tl, "
+                         f"double* __restrict__ lds, double* __restrict__ wint, double* __restrict__ wgrad, int pub_blk) {{")
+                S.append(switch(f"{target}(A, tl, lds, wint, wgrad, pub_blk)"))
+                S.append("  }")
+            S.append("  __device__ static __forceinline__ void bigh(int phase, const PkArgs& A, const PkTile& tl, "
+                     "double* __restrict__ lds) {")
+            S.append(switch("pk::big_hess<{P}>(A, tl, lds)"))
             S.append("  }")
         ncmax = max([1] + [pp.phase.n_c for pp in plan.phase_plans])
         for cbname, tag in (("jac", "J"), ("hess", "H"), ("aux", "A")):

@@ -1019,6 +1019,187 @@ __device__ __forceinline__ void tile_xall(const PkArgs& A, const PkTile& tl, dou
 #endif
 }
 
+#ifdef PK_BIG
+// ============================================================================================
+// Intervals with more points than a wavefront has lanes (64 < K <= PK_BIG_MAX): ONE WORKGROUP per interval.
+// The reference has no limit on num_point (radau/discretization.py:488-521); the wave tiles above do (lane = node).
+// Such an interval takes the first slot of a tile block (the host leaves the other three empty); its workgroup -- one
+// per role, as for ordinary tiles -- walks the nodes with all 256 threads (phase A: evaluation, per-node outputs,
+// staging of the per-node values in LDS rows of PK_BIG_MAX doubles), synchronizes, and walks the defect rows, the
+// translation entries and the K^2 entries of every I-expanded segment (phase B; tables from global memory, 8-byte
+// stores).  Same arithmetic, same operation order as the tile path.  Compiled only into code objects whose mesh has such
+// an interval (codegen.py), so ordinary meshes carry none of it.
+// ============================================================================================
+#define PK_BIG_MAX 256
+template <class P, int ROLE>
+__device__ __forceinline__ void big_xall(const PkArgs& A, const PkTile& tl, double* __restrict__ lds,
+                                         double* __restrict__ wint, double* __restrict__ wgrad, int pub_blk) {
+  const PkPhase& ph = A.ph[P::INDEX];
+  const int t = threadIdx.x, wave = t >> 6, lane = t & 63;
+  constexpr int KS = PK_BIG_MAX;
+  const int K = tl.K, stride = K - P::SCHEME, R = stride;
+  const int nq = stride + P::SCHEME;
+  const int nown = (P::SCHEME && !tl.last) ? nq - 1 : nq;
+  double s[PK_NS], dt, mt;
+  phase_scalars<P>(A, ph, s, dt, mt);
+  const PkSys sy{s, A.Ibuf, A.sigma, A.lam};
+  double* __restrict__ xs = lds;                          // [NX][KS] node values (boundary values substituted)
+  double* __restrict__ fs = lds + P::NX * KS;             // [NX][KS] dynamics values
+  double* __restrict__ js = lds + 2 * P::NX * KS;         // [J_NI][KS] Jacobian segment values
+  pk_cbase_t segb = const_bases(A.lb + ph.jseg_off);
+  pk_cbase_t tb = const_bases(A.lb + ph.jt_off);
+  double oi[P::INT_N > 0 ? P::INT_N : 1], orr[P::GR_NR > 0 ? P::GR_NR : 1];
+#pragma unroll
+  for (int r = 0; r < P::INT_N; ++r) oi[r] = 0.0;
+#pragma unroll
+  for (int r = 0; r < P::GR_NR; ++r) orr[r] = 0.0;
+  for (int c = t; c < nq; c += PK_BLOCK) {
+    const int q = tl.q0 + c;
+    double a[P::NARG], tau, w;
+    load_node<P>(A, ph, s, dt, mt, q, a, tau, w);
+    double og[P::G_NOUT], oj[P::J_NI + P::J_NN + 1], ov[P::NX + P::NU];
+    double ot[P::GR_NR > 0 ? P::GR_NR : 1], op[P::INT_N > 0 ? P::INT_N : 1];
+    if (ROLE != 2) {
+#pragma unroll
+      for (int i = 0; i < P::NX; ++i) xs[i * KS + c] = a[i];
+    }
+    P::mid_xall(a, tau, dt, w, sy, og, oj, ov, ot, op);
+    if (ROLE != 2) {
+      if (c < nown) {
+#pragma unroll
+        for (int r = 0; r < P::INT_N; ++r) oi[r] += op[r] * w;
+        node_gradient_eval<P>(ph, q, a, tau, dt, w, sy, ov, ot, true);    // boundary nodes re-evaluate their own entries
+#pragma unroll
+        for (int r = 0; r < P::GR_NR; ++r) orr[r] += ot[r];
+        node_gradient_store<P>(A, ph, q, ov);
+#pragma unroll
+        for (int j = 0; j < P::NC; ++j) put(&A.o_g[ph.path_off + j * ph.L_m + q], og[P::NX + j]);
+      }
+#pragma unroll
+      for (int i = 0; i < P::NX; ++i) fs[i * KS + c] = og[i];
+    }
+    if (ROLE != 1) {
+#pragma unroll
+      for (int e = 0; e < P::J_NI; ++e) js[e * KS + c] = oj[e];
+      if (c < nown && q >= ph.mid_lo && q < ph.mid_hi) {
+#pragma unroll
+        for (int e = 0; e < P::J_NN; ++e) put(&A.o_jac[segb[P::J_NI + e] + (q - ph.mid_lo)], oj[P::J_NI + e]);
+      }
+    }
+  }
+  if (ROLE != 2) {
+#pragma unroll
+    for (int r = 0; r < P::INT_N; ++r) {
+      const double v = wave_sum(oi[r]);
+      if (lane == 0) wint[wave * PK_NRED + r] = v;
+    }
+#pragma unroll
+    for (int r = 0; r < P::GR_NR; ++r) {
+      const double v = wave_sum(orr[r]);
+      if (lane == 0) wgrad[wave * PK_NRED + r] = v;
+    }
+  }
+  __syncthreads();                                         // the staged rows are complete, the wave sums are in place
+  if (ROLE != 2 && pub_blk >= 0 && t < PK_NRED) {          // pk_cycle: hand the block's sums to the finalize workgroup
+    double vi = 0.0, vg = 0.0;
+#pragma unroll
+    for (int wv = 0; wv < PK_WAVES_PER_BLOCK; ++wv) {
+      vi += wint[wv * PK_NRED + t];
+      vg += wgrad[wv * PK_NRED + t];
+    }
+    handoff_put(A.cpart + (size_t)pub_blk * PK_NRED + t, vi);
+    handoff_put(A.cpart2 + (size_t)pub_blk * PK_NRED + t, vg);
+  }
+  const double width = A.db[ph.width_off + tl.j0];
+  if (ROLE != 2) {
+    const double* __restrict__ full = A.db + tl.full_off;
+    const int back_slot = P::SCHEME ? ph.L_m - 1 : ph.L_m;
+    const int endslot = tl.q0 + stride;
+    for (int r = t; r < R; r += PK_BLOCK) {                // defects: (x_q - x_end) - dt * sum_c (I_hat[r,c] d/2) f_i(c)
+      double acc[P::NX];
+#pragma unroll
+      for (int i = 0; i < P::NX; ++i) acc[i] = 0.0;
+      for (int c = 0; c < K; ++c) {
+        const double ac = full[r * K + c] * width * 0.5;
+#pragma unroll
+        for (int i = 0; i < P::NX; ++i) acc[i] += ac * fs[i * KS + c];
+      }
+#pragma unroll
+      for (int i = 0; i < P::NX; ++i) {
+        double xe = P::SCHEME ? xs[i * KS + (K - 1)] : A.x[ph.x_off + i * ph.state_len + endslot];
+        if (endslot == back_slot) xe = P::back_value(i, xe, s);
+        put(&A.o_g[ph.g_off + i * ph.L_d + tl.r0 + r], (xs[i * KS + r] - xe) - acc[i] * dt);
+      }
+    }
+    const double* __restrict__ tvg = A.db + tl.tv_off;     // constant translation entries
+    for (int p = t; p < tl.nnzT; p += PK_BLOCK) {
+      const double v = tvg[p];
+#pragma unroll
+      for (int i = 0; i < P::NX; ++i) put(&A.o_jac[tb[i] + tl.offT + p], v);
+    }
+  }
+  if (ROLE != 1) {
+    const int32_t* __restrict__ rcg = A.ib + tl.irc_off;
+    const double* __restrict__ ivg = A.db + tl.iv_off;
+    for (int p = t; p < tl.nnzI; p += PK_BLOCK) {
+      const int c = rcg[2 * p + 1];
+      const double val = -(ivg[p] * width * 0.5);
+#pragma unroll
+      for (int e = 0; e < P::J_NI; ++e) put(&A.o_jac[segb[e] + tl.offI + p], val * js[e * KS + c]);
+    }
+  }
+}
+
+template <class P>
+__device__ __forceinline__ void big_hess(const PkArgs& A, const PkTile& tl, double* __restrict__ lds) {
+  const PkPhase& ph = A.ph[P::INDEX];
+  const int t = threadIdx.x;
+  constexpr int KS = PK_BIG_MAX;
+  const int K = tl.K, stride = K - P::SCHEME;
+  const int nq = stride + P::SCHEME;
+  const int nown = (P::SCHEME && !tl.last) ? nq - 1 : nq;
+  double s[PK_NS], dt, mt;
+  phase_scalars<P>(A, ph, s, dt, mt);
+  const PkSys sy{s, A.Ibuf, A.sigma, A.lam};
+  pk_cbase_t segb = const_bases(A.lb + ph.hseg_off);
+  for (int c = t; c < nq; c += PK_BLOCK) {
+    const int q = tl.q0 + c;
+    double a[P::NARG], tau, w, lp[P::NC > 0 ? P::NC : 1], o[P::H_NI + P::H_NN + 1];
+    load_node<P>(A, ph, s, dt, mt, q, a, tau, w);
+#pragma unroll
+    for (int j = 0; j < P::NC; ++j) lp[j] = A.lam[ph.path_off + j * ph.L_m + min(q, ph.L_m - 1)];
+    P::mid_hess(a, tau, dt, w, sy, lp, o);
+#pragma unroll
+    for (int e = 0; e < P::H_NI; ++e) lds[e * KS + c] = o[e];
+    if (c < nown && q >= ph.mid_lo && q < ph.mid_hi) {
+#pragma unroll
+      for (int e = 0; e < P::H_NN; ++e) put(&A.o_hess[segb[P::H_NI + e] + (q - ph.mid_lo)], o[P::H_NI + e]);
+    }
+  }
+  __syncthreads();
+  const double width = A.db[ph.width_off + tl.j0];
+  const int32_t* __restrict__ rcg = A.ib + tl.irc_off;
+  const double* __restrict__ ivg = A.db + tl.iv_off;
+  for (int p = t; p < tl.nnzI; p += PK_BLOCK) {
+    const int r = rcg[2 * p], c = rcg[2 * p + 1];
+    const double val = -(ivg[p] * width * 0.5);
+#pragma unroll
+    for (int e = 0; e < P::H_NI; ++e) {
+      const double lam = A.lam[ph.g_off + P::H_state(e) * ph.L_d + tl.r0 + r];
+      put(&A.o_hess[segb[e] + tl.offI + p], val * lam * lds[e * KS + c]);
+    }
+  }
+}
+
+// does tile block `blk` hold an interval with more points than a wave has lanes?  (wave-uniform; tl0 receives its record)
+__device__ __forceinline__ bool big_block(const PkTile* tiles, int n_tiles, int blk, PkTile& tl0) {
+  const int t0 = blk * PK_WAVES_PER_BLOCK;
+  if (t0 >= n_tiles) return false;
+  tl0 = load_tile(tiles + t0);
+  return tl0.nj > 0 && tl0.K > PK_WAVE;
+}
+#endif
+
 // ============================================================================================
 // auxiliary pass of the outer-product path: quadrature-weighted gradient entries of the integrals
 // (one value per middle node), consumed by pk_outer       (systembase.py:625-644; easyderiv.py:393-430)
@@ -1307,6 +1488,10 @@ __device__ __forceinline__ void kernel_hess(const PkArgs& A) {
     return;
   }
   PK_TILE_PROLOGUE(2);
+#ifdef PK_BIG
+  PkTile tl0;
+  if (big_block(A.tile, A.n_tiles, blk, tl0)) return Gen::bigh(tl0.phase, A, tl0, PK_STAGE(A));
+#endif
   Gen::tile_hess(tl.phase, A, tl, PK_STAGE(A) + wave * Gen::LDS_H, wint, wgrad, lane);
 }
 
@@ -1509,16 +1694,33 @@ __device__ __forceinline__ void kernel_xall(const PkArgs& A) {
     const int slot = pk::xcd_tile_block((int)blockIdx.x, 1, (int)gridDim.x);
     const int blk = slot >> 1;
     PK_TILE_PROLOGUE_AT();
+#ifdef PK_BIG
+    PkTile tl0;
+    const bool big = big_block(A.tile, A.n_tiles, blk, tl0);
+#else
+    constexpr bool big = false;
+#endif
     if (!(slot & 1)) {
+#ifdef PK_BIG
+      if (big) return Gen::bigx2(tl0.phase, A, tl0, PK_STAGE(A), wint, wgrad, -1);
+#endif
       Gen::tile_xall2(tl.phase, A, tl, PK_STAGE(A) + wave * Gen::LDS_X, wint + wave * PK_NRED, wgrad + wave * PK_NRED, lane, -1);
       return;
     }
-    Gen::tile_xall1(tl.phase, A, tl, PK_STAGE(A) + wave * Gen::LDS_X, wint + wave * PK_NRED, wgrad + wave * PK_NRED, lane, -1);
+#ifdef PK_BIG
+    if (big) Gen::bigx1(tl0.phase, A, tl0, PK_STAGE(A), wint, wgrad, -1);
+#endif
+    if (!big) Gen::tile_xall1(tl.phase, A, tl, PK_STAGE(A) + wave * Gen::LDS_X, wint + wave * PK_NRED, wgrad + wave * PK_NRED, lane, -1);
     publish_block_partials(A.partial, wint, blk);
     publish_block_partials(A.partial2, wgrad, blk);
     return;
   }
   PK_TILE_PROLOGUE(1);
+#ifdef PK_BIG
+  PkTile tl0;
+  if (big_block(A.tile, A.n_tiles, blk, tl0)) Gen::bigx0(tl0.phase, A, tl0, PK_STAGE(A), wint, wgrad, -1);
+  else
+#endif
   Gen::tile_xall(tl.phase, A, tl, PK_STAGE(A) + wave * Gen::LDS_X, wint + wave * PK_NRED, wgrad + wave * PK_NRED, lane, -1);
   publish_block_partials(A.partial, wint, blk);
   publish_block_partials(A.partial2, wgrad, blk);
@@ -1570,6 +1772,16 @@ __device__ __forceinline__ void kernel_cycle(const PkTile* pre_tile, int pre_n_t
   const int blk = split ? slot / 3 : slot >> 1;       // the tile block; its workgroups follow each other in dispatch order
   const int sub = slot - blk * (split ? 3 : 2);       // split: 0 Jacobian, 1 values, 2 Hessian; else 0 x-part, 1 Hessian
   PK_TILE_PROLOGUE_FROM(pre_tile, pre_n_tiles);
+#ifdef PK_BIG
+  PkTile tl0;
+  if (big_block(pre_tile, pre_n_tiles, blk, tl0)) {
+    if (sub == (split ? 2 : 1)) Gen::bigh(tl0.phase, A, tl0, PK_STAGE(A));
+    else if (!split) Gen::bigx0(tl0.phase, A, tl0, PK_STAGE(A), wint, wgrad, blk);
+    else if (sub == 0) Gen::bigx2(tl0.phase, A, tl0, PK_STAGE(A), wint, wgrad, -1);
+    else Gen::bigx1(tl0.phase, A, tl0, PK_STAGE(A), wint, wgrad, blk);
+    return;
+  }
+#endif
   if (sub == (split ? 2 : 1))
     Gen::tile_hess(tl.phase, A, tl, PK_STAGE(A) + wave * Gen::LDS_H, wint, wgrad, lane);
   else if (!split)

@@ -68,6 +68,7 @@ struct pk_ctx {
   bool split_xall = false;      // pk_xall with two waves per tile (values / Jacobian), see pk_set_problem
   int cycle_mode = 1;           // 1: single-launch pk_cycle; 0: pk_xall + pk_hess (pk_set_cycle_mode)
   bool static_tabs = false;     // A/B (POCKIT_AMD_STATIC_TABS=1): the code object keeps its table blocks in static LDS
+  bool has_big = false;         // the mesh has intervals with more than 64 points (one workgroup each, PK_BIG code objects)
   unsigned long long *d_cpart = nullptr, *d_cpart2 = nullptr;   // pk_cycle's hand-off slots (PK_EMPTY between launches)
   unsigned profile_mask = 0;
   unsigned profile_period = 1;  // time every n-th launch of a selected kernel
@@ -398,6 +399,19 @@ int stage_upload(pk_ctx* c, double* const bufs[2], hipEvent_t const evs[2], int&
 
 }  // namespace
 
+extern "C" int pk_eval_xpart_dev(pk_ctx* c, const double* d_x, double* d_f, double* d_grad, double* d_g, double* d_jac, void* stream);
+
+namespace {
+// Meshes with big intervals (more than 64 points) are served by the fused x-kernel only: a single callback on device
+// pointers runs it with the context's own buffers for the outputs nobody asked for.
+int eval_one_via_xpart(pk_ctx* c, const double* d_x, int which, double* d_out, void* stream) {
+  c->x_valid = false;
+  double* o[4] = {c->d_f, c->d_grad, c->d_g, c->d_J};
+  o[which] = d_out;
+  return pk_eval_xpart_dev(c, d_x, o[0], o[1], o[2], o[3], stream);
+}
+}  // namespace
+
 extern "C" {
 
 int pk_device_count(void) {
@@ -508,6 +522,21 @@ int pk_set_problem(pk_ctx* c, const pk_problem_desc* pd) {
       (rc = dalloc(&c->d_partial, (2 * (size_t)c->n_tiles / PK_WAVES_PER_BLOCK + 2) * (size_t)c->md.nred)) ||
       (rc = dalloc(&c->d_partial2, (2 * (size_t)c->n_tiles / PK_WAVES_PER_BLOCK + 2) * (size_t)c->md.nred)))
     return rc;
+  c->has_big = false;
+  {
+    const PkTile* tl = (const PkTile*)pd->tiles;
+    for (int32_t t = 0; t < pd->n_tiles; ++t)
+      if (tl[t].nj > 0 && tl[t].K > PK_WAVE) {
+        c->has_big = true;
+        if (t % PK_WAVES_PER_BLOCK || tl[t].nj != 1 || tl[t].K > 256)
+          return fail(c, 33, "pk_set_problem: tile %d: an interval with more than %d points must be alone in the first slot of a tile block (K <= 256)", t, PK_WAVE);
+        for (int32_t u = 1; u < PK_WAVES_PER_BLOCK && t + u < pd->n_tiles; ++u)
+          if (tl[t + u].nj != 0) return fail(c, 33, "pk_set_problem: tile %d shares a block with a big interval", t + u);
+      }
+    const bool needs_I = c->md.prepass_grad || c->md.prepass_g || c->md.prepass_jac || c->md.prepass_hess;
+    if (c->has_big && needs_I)
+      return fail(c, 34, "pk_set_problem: num_point > %d is not supported together with system functions nonlinear in the integrals", PK_WAVE);
+  }
   c->d_g = c->d_grad + c->n;      // grad f and g are neighbours (device and pinned host): ONE copy serves both (host shim)
   {   // hand-off slots of pk_cycle: one per x-kernel workgroup and reduction row, PK_EMPTY between launches
     const size_t slots = (2 * (size_t)c->n_tiles / PK_WAVES_PER_BLOCK + 2) * (size_t)c->md.nred;
@@ -555,6 +584,7 @@ int pk_get_structure(pk_ctx* c, int32_t* jr, int32_t* jc, int32_t* hr, int32_t* 
 int pk_eval_f_dev(pk_ctx* c, const double* d_x, double* d_f, void* stream) {
   int rc = ready(c);
   if (rc) return rc;
+  if (c->has_big) return eval_one_via_xpart(c, d_x, 0, d_f, stream);
   return prepass(c, d_x, nullptr, 0.0, d_f, true, pick(c, stream));
 }
 
@@ -586,6 +616,7 @@ int pk_set_shard(pk_ctx* c, int secondary, int external_prepass, double* d_integ
 int pk_eval_grad_dev(pk_ctx* c, const double* d_x, double* d_grad, void* stream) {
   int rc = ready(c);
   if (rc) return rc;
+  if (c->has_big) return eval_one_via_xpart(c, d_x, 1, d_grad, stream);
   hipStream_t st = pick(c, stream);
   if (c->md.prepass_grad && !c->external_prepass && (rc = prepass(c, d_x, nullptr, 0.0, c->d_f, false, st))) return rc;
   PkArgs A = base_args(c, d_x, nullptr, 0.0);
@@ -598,6 +629,7 @@ int pk_eval_grad_dev(pk_ctx* c, const double* d_x, double* d_grad, void* stream)
 int pk_eval_g_dev(pk_ctx* c, const double* d_x, double* d_g, void* stream) {
   int rc = ready(c);
   if (rc) return rc;
+  if (c->has_big) return eval_one_via_xpart(c, d_x, 2, d_g, stream);
   hipStream_t st = pick(c, stream);
   if (c->md.prepass_g && !c->external_prepass && (rc = prepass(c, d_x, nullptr, 0.0, c->d_f, false, st))) return rc;
   PkArgs A = base_args(c, d_x, nullptr, 0.0);
@@ -608,6 +640,7 @@ int pk_eval_g_dev(pk_ctx* c, const double* d_x, double* d_g, void* stream) {
 int pk_eval_jac_dev(pk_ctx* c, const double* d_x, double* d_vals, void* stream) {
   int rc = ready(c);
   if (rc) return rc;
+  if (c->has_big) return eval_one_via_xpart(c, d_x, 3, d_vals, stream);
   hipStream_t st = pick(c, stream);
   if (c->md.prepass_jac && !c->external_prepass && (rc = prepass(c, d_x, nullptr, 0.0, c->d_f, false, st))) return rc;
   PkArgs A = base_args(c, d_x, nullptr, 0.0);

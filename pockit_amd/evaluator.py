@@ -110,8 +110,16 @@ class Tables:
             ph["jt_off"] = put(lb, plan.jac.tconst[k], np.int64)
             red = [plan.l_p[k] + s if s >= 0 else plan.r_s + s for s in plan.grad_red_slots[k]]
             ph["red_off"] = put(ib, red, np.int32)
+            def empty_tile():
+                e = np.zeros((), dtype=runtime.TILE_DTYPE)
+                e["phase"], e["K"] = k, 1
+                return e
+
             for row in tl:
                 j0, nj, kid, kidf, q0, r0, offI, offT = (int(v) for v in row)
+                big = int(lay.K[j0]) > runtime.WAVE       # more points than a wave has lanes: the interval takes a whole
+                while big and len(tiles) % runtime.WAVES_PER_BLOCK:       # workgroup (first slot of a tile block)
+                    tiles.append(empty_tile())
                 rec = np.zeros((), dtype=runtime.TILE_DTYPE)
                 rec["phase"], rec["j0"], rec["nj"] = k, j0, nj
                 rec["kid"], rec["kidf"] = kind0 + kid, kind0 + kidf
@@ -125,6 +133,8 @@ class Tables:
                 for field, d in (("magicI", int(rec["nnzI"])), ("magicR", R), ("magicT", int(rec["nnzT"]))):
                     rec[field] = magic_number(d)
                 tiles.append(rec)
+                if big:
+                    tiles.extend(empty_tile() for _ in range(runtime.WAVES_PER_BLOCK - 1))
             while len(tiles) % runtime.WAVES_PER_BLOCK:      # a workgroup never mixes phases: pad with empty tiles
                 rec = np.zeros((), dtype=runtime.TILE_DTYPE)
                 rec["phase"], rec["K"] = k, 1

@@ -20,6 +20,7 @@ import numpy as np
 from . import collocation
 
 WAVE = 64
+BIG_MAX = 256      # an interval with 64 < K <= 256 points is handled by a whole workgroup (PK_BIG code objects)
 
 
 class Kind:
@@ -64,8 +65,8 @@ class MeshLayout:
         self.n_x, self.n_u = n_x, n_u
         lgr = scheme == "lgr"
         N = self.N = len(self.K)
-        if int(self.K.max()) > WAVE:
-            raise NotImplementedError("num_point > 64 per interval is not supported by the HIP kernels")
+        if int(self.K.max()) > BIG_MAX:
+            raise NotImplementedError(f"num_point > {BIG_MAX} per interval is not supported by the HIP kernels")
         self.width = np.diff(self.mesh)
         mid = (self.mesh[1:] + self.mesh[:-1]) / 2
         self.stride = self.K if lgr else self.K - 1               # nodes an interval adds
@@ -171,7 +172,7 @@ class MeshLayout:
         while j < self.N:
             K = int(self.K[j])
             st = int(self.stride[j])
-            cap = (WAVE // K) if self.scheme == "lgr" else max((WAVE - 1) // st, 1)
+            cap = max(WAVE // K, 1) if self.scheme == "lgr" else max((WAVE - 1) // st, 1)     # (K > 64: one interval, a block)
             if intervals_per_wave:
                 cap = max(1, min(cap, int(intervals_per_wave)))
             nj = 1

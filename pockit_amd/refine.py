@@ -47,7 +47,7 @@ def error_tables(plan):
         rows = int(np.sum(rows_iv))
         if int(np.max(lay.K)) + 1 > runtime.WAVE:
             raise NotImplementedError("mesh error estimation maps the K + 1 augmented nodes of an interval to the "
-                                      "64 lanes of a wavefront: num_point <= 63")
+                                      "64 lanes of a wavefront: num_point <= 63 (the NLP callbacks themselves take up to 256)")
         for j in range(lay.N):
             K = int(lay.K[j])
             key = (lgr, K)

@@ -185,8 +185,51 @@ def test_maximum_supported_order_matches_the_plan_interpreter(case):
     close(ev.constraints_direct(x), want["g"], what="g direct")
     close(ev.jacobian_direct(x), want["J"], what="J direct")
     close(ev.hessian_direct(x, lam, sigma), want["H"], what="H direct")
+
+
+@pytest.mark.parametrize("case", [("brachistochrone", "radau", dict(mesh=[0, 0.2, 0.5, 0.7, 1.0], num_point=[6, 100, 8, 65])),
+                                  ("brachistochrone", "lobatto", dict(mesh=[0, 0.3, 0.6, 1.0], num_point=[66, 5, 130])),
+                                  ("planar_quadrotor", "radau", dict(mesh=[0, 0.5, 0.6, 1.0], num_point=[128, 6, 200])),
+                                  ("planar_quadrotor", "lobatto", dict(mesh=[0, 0.5, 1.0], num_point=[256, 7])),
+                                  ("two_stage_rocket", "radau", dict(mesh=[0, 0.4, 1.0], num_point=[70, 9])),
+                                  ("humanoid_wbc", "radau", dict(mesh=[0, 0.5, 1.0], num_point=[4, 80]))])
+def test_intervals_with_more_points_than_a_wavefront_has_lanes(case):
+    """64 < num_point <= 256 (the reference has no limit, radau/discretization.py:488-521): such an interval is evaluated
+    by a whole workgroup (PK_BIG code objects), next to ordinary wave tiles.  Reference: the NumPy execution of the same
+    plan with the product's own tables (the oracle's np.roots-based tables carry no digits at these orders)."""
+    from plan_interp import Interp
+
+    bname, scheme, kw = case
+    system, _, guess = getattr(models, bname)(_ns(scheme, "pockit_amd"), **kw)
+    x, lam, sigma = models.bench_inputs(system, guess)
+    it = Interp(system.plan, x, lam, sigma)
+    want = dict(f=it.objective(), grad=it.gradient(), g=it.constraints(), J=it.jacobian(), H=it.hessian())
+    ev = system.evaluator
+    assert ev.src.big
+    f, grad, g, J, H = ev.cycle(x, lam, sigma)                       # pk_cycle: the three roles of every big block
+    close(f, want["f"], what="cycle f")
+    close(grad, want["grad"], what="cycle grad")
+    close(g, want["g"], what="cycle g")
+    close(J, want["J"], what="cycle J")
+    close(H, want["H"], what="cycle H")
+    close(system.objective(x), want["f"], what="f")                  # the host shim: pk_xall (+ pk_fin), pk_hess
+    close(system.gradient(x), want["grad"], what="grad")
+    close(system.constraints(x), want["g"], what="g")
+    close(system.jacobian(x), want["J"], what="J")
+    close(system.hessian(x, lam, sigma), want["H"], what="H")
+    close(ev.objective_direct(x), want["f"], what="f direct")        # single callbacks (served by the fused x-kernel)
+    close(ev.gradient_direct(x), want["grad"], what="grad direct")
+    close(ev.constraints_direct(x), want["g"], what="g direct")
+    close(ev.jacobian_direct(x), want["J"], what="J direct")
+    close(ev.hessian_direct(x, lam, sigma), want["H"], what="H direct")
+    ev.set_cycle_mode(False)                                         # two-launch cycle, unsplit and split x-part
+    f2, grad2, g2, J2, H2 = ev.cycle(x, lam, sigma)
+    assert np.array_equal(J2, J) and np.array_equal(H2, H) and np.array_equal(g2, g)
+    ev.set_cycle_mode(True)
     with pytest.raises(NotImplementedError):
-        getattr(models, bname)(_ns(scheme, "pockit_amd"), mesh=1, num_point=65).plan
+        getattr(models, bname)(_ns(scheme, "pockit_amd"), mesh=1, num_point=257).plan
+    with pytest.raises(NotImplementedError):
+        system.check_continuous(guess)                                # mesh error estimation: num_point <= 63
 
 
 def test_prepared_x_cache_is_dropped_by_calls_that_reuse_the_context_buffers():

@@ -12,6 +12,44 @@ import models
 pytestmark = pytest.mark.gpu
 
 
+class _PlanReference:
+    """The NumPy execution of the product's own plan (tests/plan_interp.py) behind the oracle's callback names: the
+    reference for meshes whose orders the oracle's np.roots-based tables cannot represent (num_point > 16)."""
+
+    def __init__(self, plan):
+        self.plan = plan
+
+    def _it(self, x, lam=None, sigma=1.0):
+        from plan_interp import Interp
+
+        return Interp(self.plan, x, lam, sigma)
+
+    def objective(self, x):
+        return self._it(x).objective()
+
+    def gradient(self, x):
+        return self._it(x).gradient()
+
+    def constraints(self, x):
+        return self._it(x).constraints()
+
+    def jacobian(self, x):
+        return self._it(x).jacobian()
+
+    def hessian(self, x, lam, sigma):
+        return self._it(x, lam, sigma).hessian()
+
+
+def _reference(system, builder, scheme, kw):
+    import importlib
+
+    k = kw.get("num_point", 0)
+    if np.max(k) > 16:
+        return _PlanReference(system.plan)
+    return builder(importlib.import_module(f"oracle.{scheme}"), **kw)[0]
+
+
+
 def _worker(rank, world, port, case, ret):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
@@ -84,7 +122,7 @@ def _peer_worker(rank, world, port, case, ret):
         name, scheme, kw = case
         builder = getattr(models, name)
         system, _, guess = builder(importlib.import_module(f"pockit_amd.{scheme}"), **kw)
-        ref, _, _ = builder(importlib.import_module(f"oracle.{scheme}"), **kw)
+        ref = _reference(system, builder, scheme, kw)
         x, lam, sigma = models.bench_inputs(system, guess)
         dev = torch.device("cuda", 0)
         torch.cuda.set_device(dev)
@@ -147,7 +185,8 @@ def _peer_worker(rank, world, port, case, ret):
 
 
 @pytest.mark.parametrize("case", [("two_stage_rocket", "radau", dict(mesh=40, num_point=4)),
-                                  ("planar_quadrotor", "lobatto", dict(mesh=33, num_point=5))])
+                                  ("planar_quadrotor", "lobatto", dict(mesh=33, num_point=5)),
+                                  ("brachistochrone", "radau", dict(mesh=[0, 0.2, 0.3, 0.5, 0.8, 1.0], num_point=[70, 5, 6, 66, 7]))])
 def test_two_process_peer_exchange_without_collectives(case):
     import torch.multiprocessing as mp
 
@@ -212,7 +251,7 @@ def _host_worker(rank, world, port, case, ret):
         if rank != 0:
             assert hs.serve(), "no command arrived"
         else:
-            ref, _, _ = builder(importlib.import_module(f"oracle.{scheme}"), **kw)
+            ref = _reference(system, builder, scheme, kw)
             x, lam, sigma = models.bench_inputs(system, guess)
             scale = lambda a: max(1.0, float(np.max(np.abs(a)))) if np.size(a) else 1.0  # noqa: E731
             for rep in range(3):
@@ -242,7 +281,8 @@ def _host_worker(rank, world, port, case, ret):
 
 @pytest.mark.parametrize("world", [2, 3])
 @pytest.mark.parametrize("case", [("two_stage_rocket", "radau", dict(mesh=40, num_point=4)),
-                                  ("planar_quadrotor", "lobatto", dict(mesh=33, num_point=5))])
+                                  ("planar_quadrotor", "lobatto", dict(mesh=33, num_point=5)),
+                                  ("brachistochrone", "radau", dict(mesh=[0, 0.2, 0.3, 0.5, 0.8, 1.0], num_point=[70, 5, 6, 66, 7]))])
 def test_host_landed_sharded_cycle_matches_oracle(case, world):
     import torch.multiprocessing as mp
 
