@@ -395,6 +395,8 @@ class ModelSource:
             S.append(f"#define PK_POLL_SLEEP {int(os.environ['POCKIT_AMD_POLL_SLEEP'])}")
         if os.environ.get("POCKIT_AMD_WIDE_STORES", "1") == "0":     # A/B switch: 8-byte stores in the streaming loop
             S.append("#define PK_WIDE_STORES 0")
+        if os.environ.get("POCKIT_AMD_KA_LAZY", "1") == "0":         # A/B: pk_cycle's PkArgs loaded en bloc on entry
+            S.append("#define PK_KA_LAZY 0")
         if os.environ.get("POCKIT_AMD_STATIC_TABS", "0") == "1":     # A/B: table blocks in static LDS
             S.append("#define PK_STATIC_TABS 1")
         if self.big:

@@ -113,6 +113,7 @@ struct PkErrIv {
 };
 
 #define PK_MAX_PHASES 8
+#define PK_CYCLE_ARGS_OFFSET 24   // pk_cycle: bytes of leading scalar kernel arguments in front of its PkArgs
 #define PK_MAX_RANKS 64       // ranks of one sharded NLP (pk_xchg: one polling thread per peer)
 
 // pk_cycle's in-launch hand-off: a slot of cpart / cpart2 is either PK_EMPTY (a quiet-NaN pattern no arithmetic

@@ -145,6 +145,9 @@ __device__ __forceinline__ int xcd_tile_block(int wg, int first, int total) {
 #else
 #define PK_DIAG(bits) false
 #endif
+#ifndef PK_KA_LAZY      // A/B switch (POCKIT_AMD_KA_LAZY=0): pk_cycle's PkArgs as an ordinary by-value kernel argument
+#define PK_KA_LAZY 1
+#endif
 #ifdef PK_TRACE
 #define PK_TRACE_REC(role) const int pk_trec = tl.pad >= 0 ? tl.pad * 3 + (role) : -1
 #define PK_MARK_AT(rec, k)                                                                                   \
@@ -1746,9 +1749,33 @@ __device__ __forceinline__ void kernel_xall(const PkArgs& A) {
 template <class Gen>
 __device__ __forceinline__ void kernel_cycle(const PkTile* pre_tile, int pre_n_tiles, int pre_flags, int pre_grid,
                                              const PkArgs& A) {
+#if PK_KA_LAZY
+  // The waves read their PkArgs fields where they use them (PK_DEFINE_KERNELS).  The kernarg segment is new with every
+  // launch: every 64-byte line of it is a scalar-cache miss the first time a wave of the CU asks, and read one after
+  // the other those misses would follow each other down the wave's serial chain.  One dword of every line is requested
+  // here, all at once; the requests are collected together with the tile-record load (one round trip for all of them).
+  // Without this the lazy form loses 3-6 % on the one-phase benchmarks (profiles/r02_ka_ab.txt).
+  constexpr int ka_bytes = (int)offsetof(PkArgs, ph) + PK_NPHASE_DIM * (int)sizeof(PkPhase);
+  constexpr int ka_lines = (ka_bytes + 63) / 64 + 1;     // (+1: the PkArgs do not start on a line boundary)
+  int ka_v[ka_lines];
+  {
+    const int PK_CONST_AS* ka = (const int PK_CONST_AS*)(uintptr_t)&A;
+#pragma unroll
+    for (int o = 0; o < ka_lines; ++o) ka_v[o] = ka[(o * 64 < ka_bytes - 4 ? o * 64 : ka_bytes - 4) / 4];
+  }
+#define PK_KA_COLLECT()                                                        \
+  {                                                                            \
+    int ka_acc = 0;                                                            \
+    _Pragma("unroll") for (int o = 0; o < ka_lines; ++o) ka_acc |= ka_v[o];    \
+    asm volatile("" ::"s"(ka_acc));                                            \
+  }
+#else
+#define PK_KA_COLLECT()
+#endif
   if (blockIdx.x < 2 && PK_DIAG(2048)) return;     // diagnostic switches (POCKIT_AMD_DEBUG_FLAGS): no boundary work,
   if (blockIdx.x == 2 && PK_DIAG(65536)) return;   // no finalize workgroup (the hand-off slots then stay filled)
   if (blockIdx.x < 3) {
+    PK_KA_COLLECT();
     const int rec = A.n_tiles * 3 + (int)blockIdx.x;
     (void)rec;
     PK_MARK_AT(rec, 0);
@@ -1772,6 +1799,8 @@ __device__ __forceinline__ void kernel_cycle(const PkTile* pre_tile, int pre_n_t
   const int blk = split ? slot / 3 : slot >> 1;       // the tile block; its workgroups follow each other in dispatch order
   const int sub = slot - blk * (split ? 3 : 2);       // split: 0 Jacobian, 1 values, 2 Hessian; else 0 x-part, 1 Hessian
   PK_TILE_PROLOGUE_FROM(pre_tile, pre_n_tiles);
+  PK_KA_COLLECT();
+#undef PK_KA_COLLECT
 #ifdef PK_BIG
   PkTile tl0;
   if (big_block(pre_tile, pre_n_tiles, blk, tl0)) {
@@ -2081,5 +2110,12 @@ __device__ __forceinline__ void kernel_fin(const PkArgs& A) {
   extern "C" __global__ __launch_bounds__(PK_BLOCK) void pk_runs(PkArgs A) { pk::kernel_runs(A); }           \
   extern "C" __global__ __launch_bounds__(PK_BLOCK) void pk_cycle(const PkTile* pre_tile, int32_t pre_n_tiles,  \
                                                                   int32_t pre_flags, int32_t pre_grid, PkArgs A) { \
-    pk::kernel_cycle<GEN>(pre_tile, pre_n_tiles, pre_flags, pre_grid, A);                                        \
+    /* PK_KA_LAZY: the PkArgs are read from the kernarg segment where a wave uses them, not en bloc on entry.   \
+       As a by-value argument every field any path of the kernel touches is loaded in the entry block and stays \
+       live (100 SGPRs, spills to VGPR lanes, scalar waits in front of the tile-record load); read lazily a    \
+       tile wave loads what its phase and role need (60 SGPRs).  Two-phase rocket: 158k -> 193k cycles/s.       \
+       &A of a by-value kernel argument IS its place in the kernarg segment (constant address space). */       \
+    const PkArgs PK_CONST_AS* A_ = (const PkArgs PK_CONST_AS*)(                                                  \
+        (const char PK_CONST_AS*)__builtin_amdgcn_kernarg_segment_ptr() + PK_CYCLE_ARGS_OFFSET);                 \
+    pk::kernel_cycle<GEN>(pre_tile, pre_n_tiles, pre_flags, pre_grid, PK_KA_LAZY ? *(const PkArgs*)A_ : A);     \
   }

@@ -313,7 +313,7 @@ int enqueue_single_launch_cycle(pk_ctx* c, const double* d_x, const double* d_la
     int32_t n_tiles, flags, grid, pad;
     PkArgs A;
   } K;
-  static_assert(offsetof(CycleArgs, A) == 24, "layout of pk_cycle's kernel arguments");
+  static_assert(offsetof(CycleArgs, A) == PK_CYCLE_ARGS_OFFSET, "layout of pk_cycle's kernel arguments");
   K.tile = A.tile; K.n_tiles = A.n_tiles; K.flags = A.flags; K.grid = (int32_t)grid; K.pad = 0;
   K.A = A;
   return launch_raw(c, K_CYCLE, &K, sizeof K, grid, sizeof(double) * dbl, st);
