@@ -47,8 +47,9 @@ import numpy as np  # noqa: E402
 SHARDING_NOTE = {
     "sums": "mesh intervals over {n} GPUs (shares balanced by output volume), one pk_cycle launch per rank on its tiles; every "
             "rank's slices of grad/g/J/H stay in its own HBM at the reference positions; the sums over all nodes (integrals -> "
-            "f, gradient entries of t0/tf/static parameters) are exchanged through peer-mapped mailboxes inside one "
-            "one-workgroup launch per rank (pk_xchg) -- no collective in the data path",
+            "f, gradient entries of t0/tf/static parameters) are exchanged through peer-mapped mailboxes by the launch's finalize "
+            "workgroup (or, where that is slower or unavailable, by a one-workgroup launch pk_xchg behind it: see "
+            "exchange_forms) -- no collective in the data path",
     "direct": "mesh intervals over {n} GPUs, one pk_cycle launch per rank; the other ranks' kernels store their slices "
               "straight into rank 0's buffer through hipIpc peer mappings (xGMI), pk_xchg flags completion",
     "gather": "mesh intervals over {n} GPUs, one pk_cycle launch per rank, run-copy pack + RCCL gather to rank 0 + run-copy "
@@ -292,14 +293,39 @@ class GpuWorkload:
             except Exception as exc:          # no peer access between the GPUs: the RCCL forms remain
                 self.peer_error = repr(exc)
                 print(f"[bench] peer-mapped exchange not available ({exc!r}); using the RCCL gather form", file=sys.stderr)
+            self.exchange_fallback = None
             if sev.peers is not None and not self.peer_exchange_works():
-                self.peer_error = "the peers' flags did not arrive (no coherent peer access between these GPUs?)"
-                print(f"[bench] peer-mapped exchange set up but not working: {self.peer_error}; using the RCCL gather form",
-                      file=sys.stderr)
-                sev.peers.close()
-                sev.peers = None
+                # the in-launch exchange needs every rank's launch to be running at the same time and the peers' system-scope
+                # stores to become visible to a polling workgroup; the two-launch form (pk_xchg behind pk_cycle) asks for
+                # less -- try it before giving the mailboxes up altogether
+                self.exchange_fallback = "in-launch exchange failed its probe; pk_xchg in a launch of its own"
+                print(f"[bench] {self.exchange_fallback}", file=sys.stderr)
+                sev.inline_exchange = False
+                if not self.peer_exchange_works():
+                    self.peer_error = "the peers' flags did not arrive (no coherent peer access between these GPUs?)"
+                    print(f"[bench] peer-mapped exchange set up but not working: {self.peer_error}; using the RCCL gather form",
+                          file=sys.stderr)
+                    sev.peers.close()
+                    sev.peers = None
             if sev.peers is None and self.mode in ("sums", "direct"):
                 self.mode = "gather"
+            self.sums_forms_ms = None
+            if sev.peers is not None and self.mode == "sums" and sev.inline_exchange:
+                # both forms of "sums" work: the headline takes the faster one on THIS machine (every rank decides on the
+                # same figures: the slowest rank's time of each form)
+                t = []
+                for inline in (True, False):
+                    sev.inline_exchange = inline
+                    ms = self.time_mode("sums", steps=200)
+                    t.append(ms if isinstance(ms, float) else float("inf"))
+                tt = torch.tensor(t, dtype=torch.float64, device=self.dev)
+                dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+                t = [float(v) for v in tt.cpu()]
+                self.sums_forms_ms = {"in_launch": t[0], "pk_xchg_behind_pk_cycle": t[1]}
+                sev.inline_exchange = bool(t[0] <= t[1])
+                if not sev.inline_exchange:
+                    self.exchange_fallback = "pk_xchg in a launch of its own is faster here than the in-launch exchange"
+            self.inline_default = sev.inline_exchange
             step = self.make_step(self.mode)
             self.exchange = self.mode
         self.step = step
@@ -528,10 +554,13 @@ def measure(name, intervals, steps, warmup, rank, world, dist, with_side=True, w
     res["ranks"] = None
     if world > 1:
         forms = {}
-        if w.sev.peers is not None:             # "sums" with the exchange as a second launch (pk_xchg) instead of in-launch
-            w.sev.inline_exchange = False
-            forms["sums_two_launches"] = w.time_mode("sums")
-            w.sev.inline_exchange = True
+        if w.sev.peers is not None:             # the other form of "sums": exchange in-launch / as a second launch (pk_xchg)
+            w.sev.inline_exchange = not w.inline_default
+            forms["sums_two_launches" if w.inline_default else "sums_in_launch"] = w.time_mode("sums")
+            w.sev.inline_exchange = w.inline_default
+            forms["sums_form_of_the_headline"] = "in-launch" if w.inline_default else "pk_xchg behind pk_cycle"
+            forms["sums_forms_probe_ms"] = w.sums_forms_ms
+            forms["fallback"] = w.exchange_fallback
         for mode in ("sums", "direct", "gather"):
             if mode == w.exchange:
                 forms[mode] = res["ms_per_step"]
