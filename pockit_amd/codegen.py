@@ -444,6 +444,10 @@ class ModelSource:
                  "double* __restrict__ lds, int lane) {")
         S.append(switch("pk::interval_err<{P}>(A, first, cnt, lds, lane)"))
         S.append("  }")
+        S.append("  __device__ static __forceinline__ void interval_err_big(int phase, const PkArgs& A, int first, "
+                 "double* __restrict__ lds) {")
+        S.append(switch("pk::interval_err_big<{P}>(A, first, lds)"))
+        S.append("  }")
         targets = [(n, f"pk::tile_{n}<{{P}}>") for n in ("int", "g", "grad", "jac", "hess", "aux", "hessc")]
         targets += [("xall", "pk::tile_xall<{P}, 0>"), ("xall1", "pk::tile_xall<{P}, 1>"),
                     ("xall2", "pk::tile_xall<{P}, 2>")]

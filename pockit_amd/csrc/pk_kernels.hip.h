@@ -1605,10 +1605,102 @@ __device__ __forceinline__ void interval_err(const PkArgs& A, int first, int cnt
   }
 }
 
+// The same for ONE interval with more augmented nodes than a wave has lanes (64 <= K <= 256): all 256 threads of the
+// workgroup walk the K + 1 nodes / rows; the staged rows are PK_ERR_BIG_ROW doubles long.  Same arithmetic, same
+// operation order per node as interval_err.
+#define PK_ERR_BIG_ROW 264
+template <class P>
+__device__ __forceinline__ void interval_err_big(const PkArgs& A, int first, double* __restrict__ lds) {
+  const PkPhase& ph = A.ph[P::INDEX];
+  double s[PK_NS], dt, mt;
+  phase_scalars<P>(A, ph, s, dt, mt);
+  const PkErrIv iv = A.erriv[first];
+  const int K = iv.K, t = (int)threadIdx.x;
+  const int ncx = K + 1 - P::SCHEME, na = K + 1, nr = K + 1 - P::SCHEME;
+  const double* __restrict__ Vx = A.errdb + iv.tab_off;
+  const double* __restrict__ Vu = Vx + na * ncx;
+  const double* __restrict__ Tm = Vu + na * K;
+  const double* __restrict__ Im = Tm + nr * ncx;
+  const double* __restrict__ xp = A.x + ph.x_off;
+  const double* __restrict__ up = xp + P::NX * ph.state_len;
+  const int back_slot = P::SCHEME ? ph.L_m - 1 : ph.L_m;
+  double* __restrict__ xs = lds;
+  double* __restrict__ us = lds + P::NX * PK_ERR_BIG_ROW;
+  double* __restrict__ fs = lds + (P::NX + P::NU) * PK_ERR_BIG_ROW;
+  for (int a = t; a < ncx; a += PK_BLOCK) {
+    const int slot = iv.lm + a;
+#pragma unroll
+    for (int i = 0; i < P::NX; ++i) {
+      double v = xp[i * ph.state_len + slot];
+      if (slot == 0) v = P::front_value(i, v, s);
+      if (slot == back_slot) v = P::back_value(i, v, s);
+      xs[i * PK_ERR_BIG_ROW + a] = v;
+    }
+  }
+  for (int a = t; a < K; a += PK_BLOCK) {
+#pragma unroll
+    for (int i = 0; i < P::NU; ++i) us[i * PK_ERR_BIG_ROW + a] = up[i * ph.L_m + iv.lm + a];
+  }
+  __syncthreads();
+  for (int a = t; a < na; a += PK_BLOCK) {
+    double arg[P::NARG], o[P::G_NOUT];
+#pragma unroll
+    for (int i = 0; i < P::NX; ++i) arg[i] = 0.0;
+#pragma unroll
+    for (int i = 0; i < P::NU; ++i) arg[P::NX + i] = 0.0;
+    for (int c = 0; c < ncx; ++c) {
+      const double v = Vx[a * ncx + c];
+#pragma unroll
+      for (int i = 0; i < P::NX; ++i) arg[i] += v * xs[i * PK_ERR_BIG_ROW + c];
+    }
+    for (int c = 0; c < K; ++c) {
+      const double v = Vu[a * K + c];
+#pragma unroll
+      for (int i = 0; i < P::NU; ++i) arg[P::NX + i] += v * us[i * PK_ERR_BIG_ROW + c];
+    }
+    const double tau = A.errdb[iv.tau_off + a];
+    arg[P::NX + P::NU] = (tau - 0.5) * dt + mt;
+#pragma unroll
+    for (int i = 0; i < P::NS; ++i) arg[P::NX + P::NU + 1 + i] = s[i];
+    P::mid_g(arg, o);
+#pragma unroll
+    for (int i = 0; i < P::NX; ++i) fs[i * PK_ERR_BIG_ROW + a] = o[i];
+  }
+  __syncthreads();
+  for (int a = t; a < nr; a += PK_BLOCK) {
+    double tx[P::NX], itf[P::NX];
+#pragma unroll
+    for (int i = 0; i < P::NX; ++i) tx[i] = itf[i] = 0.0;
+    for (int c = 0; c < ncx; ++c) {
+      const double v = Tm[a * ncx + c];
+#pragma unroll
+      for (int i = 0; i < P::NX; ++i) tx[i] += v * xs[i * PK_ERR_BIG_ROW + c];
+    }
+    for (int c = 0; c < na; ++c) {
+      const double v = Im[a * na + c] * iv.width * 0.5;
+#pragma unroll
+      for (int i = 0; i < P::NX; ++i) itf[i] += v * fs[i * PK_ERR_BIG_ROW + c];
+    }
+#pragma unroll
+    for (int i = 0; i < P::NX; ++i) {
+      const int64_t pos = iv.out_off + (int64_t)i * iv.rows + iv.row0 + a;
+      put(&A.o_errT[pos], tx[i]);
+      put(&A.o_errI[pos], itf[i] * dt);
+    }
+  }
+}
+
 template <class Gen>
 __device__ __forceinline__ void kernel_err(const PkArgs& A) {
   extern __shared__ double pk_lds[];
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+  {   // an interval with more augmented nodes than a wave has lanes is the first group of a block of its own
+    const int g0 = (int)blockIdx.x * PK_WAVES_PER_BLOCK;
+    if (g0 < A.n_erriv && A.errgrp[2 * g0 + 1] == 1) {
+      const int first0 = A.errgrp[2 * g0];
+      if (A.erriv[first0].K + 1 > PK_WAVE) return Gen::interval_err_big(A.erriv[first0].phase, A, first0, pk_lds);
+    }
+  }
   const int g = (int)blockIdx.x * PK_WAVES_PER_BLOCK + wave;
   if (g >= A.n_erriv) return;
   // a workgroup never mixes phases (the host pads every phase to a multiple of 4 groups with count 0)

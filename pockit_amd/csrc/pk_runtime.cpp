@@ -793,7 +793,7 @@ int pk_set_mesh_error_tables(pk_ctx* c, const void* intervals, int32_t n_interva
     return fail(c, 70, "pk_set_mesh_error_tables: empty tables");
   if (n_groups % PK_WAVES_PER_BLOCK)
     return fail(c, 71, "pk_set_mesh_error_tables: wave groups must be padded to a multiple of %d per phase", PK_WAVES_PER_BLOCK);
-  if ((size_t)c->md.lds_e * PK_WAVES_PER_BLOCK * sizeof(double) > 160 * 1024)
+  if (((size_t)c->md.lds_e / PK_WAVE) * 264 * sizeof(double) > 160 * 1024)
     return fail(c, 72, "pk_set_mesh_error_tables: model needs more than 160 KiB of LDS per workgroup");
   // host-side validation of everything the kernel indexes with (a faulting kernel can take the node down)
   const PkErrIv* iv = (const PkErrIv*)intervals;
@@ -803,14 +803,25 @@ int pk_set_mesh_error_tables(pk_ctx* c, const void* intervals, int32_t n_interva
     const PkPhase& ph = c->h_phases[r.phase];
     const int na = r.K + 1, ncx = r.K + 1 - ph.scheme, nr = ncx;
     const int64_t tab = (int64_t)na * ncx + (int64_t)na * r.K + (int64_t)nr * ncx + (int64_t)nr * na;
-    if (r.K < 1 || na > PK_WAVE || r.lm < 0 || r.lm + ncx > ph.state_len || r.lm + r.K > ph.L_m || r.tab_off < 0 ||
+    if (r.K < 1 || r.K > 256 || r.lm < 0 || r.lm + ncx > ph.state_len || r.lm + r.K > ph.L_m || r.tab_off < 0 ||
         r.tab_off + tab > n_tables || r.tau_off < 0 || r.tau_off + na > n_tables || r.row0 < 0 || r.row0 + nr > r.rows ||
         r.out_off < 0 || r.out_off + (int64_t)ph.n_x * r.rows > n_out)
       return fail(c, 74, "pk_set_mesh_error_tables: record %d is inconsistent with the problem", g);
   }
   for (int32_t g = 0; g < n_groups; ++g) {     // a wave's intervals: in range, one phase, one K, K + 1 lanes each
     const int32_t first = groups[2 * g], cnt = groups[2 * g + 1];
-    if (first < 0 || first >= n_intervals || cnt < 0 || first + cnt > n_intervals || cnt * (iv[first].K + 1) > PK_WAVE)
+    if (first < 0 || first >= n_intervals)
+      return fail(c, 76, "pk_set_mesh_error_tables: wave group %d is out of range", g);
+    if (cnt == 1 && iv[first].K + 1 > PK_WAVE) {     // K + 1 > 64: a workgroup of its own (first group of the block, count 1;
+      if (g % PK_WAVES_PER_BLOCK)                    //  the block's other groups carry count -1)
+        return fail(c, 76, "pk_set_mesh_error_tables: wave group %d: an interval with K + 1 > %d must start a block", g, PK_WAVE);
+      for (int32_t u = 1; u < PK_WAVES_PER_BLOCK; ++u)
+        if (groups[2 * (g + u) + 1] != -1)
+          return fail(c, 76, "pk_set_mesh_error_tables: wave group %d shares its block with a workgroup-wide interval", g + u);
+      g += PK_WAVES_PER_BLOCK - 1;
+      continue;
+    }
+    if (cnt < 0 || first + cnt > n_intervals || cnt * (iv[first].K + 1) > PK_WAVE)
       return fail(c, 76, "pk_set_mesh_error_tables: wave group %d is out of range", g);
     for (int32_t j = 1; j < cnt; ++j)
       if (iv[first + j].K != iv[first].K || iv[first + j].phase != iv[first].phase)
@@ -843,8 +854,9 @@ int pk_eval_mesh_error_dev(pk_ctx* c, const double* d_x, double* d_T, double* d_
   A.n_erriv = c->n_erriv;
   A.o_errT = d_T;
   A.o_errI = d_I;
+  // (lds_e = 64 (2 n_x + n_u) doubles per wave; a workgroup-wide interval stages rows of 264 doubles)
   return launch(c, K_ERR, A, (unsigned)(c->n_erriv / PK_WAVES_PER_BLOCK),
-                sizeof(double) * PK_WAVES_PER_BLOCK * (size_t)c->md.lds_e, pick(c, stream));
+                sizeof(double) * ((size_t)c->md.lds_e / PK_WAVE) * 264, pick(c, stream));
 }
 
 int pk_eval_mesh_error(pk_ctx* c, const double* x, double* T, double* I) {

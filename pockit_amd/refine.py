@@ -25,7 +25,9 @@ def error_tables(plan):
     records: one PkErrIv per mesh interval; tables: float64 blob; views[k] = (offset, n_x, rows) of phase k in the
     outputs; groups: int32 [n, 2] = (first record, count) -- ONE wavefront of pk_err handles a run of consecutive
     intervals of one phase and one K, as many as fit its 64 lanes with K + 1 lanes per interval; every phase is padded
-    to a multiple of 4 groups (count 0: a workgroup of 4 waves never mixes phases)."""
+    to a multiple of 4 groups (count 0: a workgroup of 4 waves never mixes phases).  An interval with K + 1 > 64 is the
+    first group of a block of its own (count 1, the block's other three groups carry count -1): all 256 threads of the
+    workgroup walk its augmented nodes."""
     tables, blocks = [], {}
     size = 0
 
@@ -45,9 +47,6 @@ def error_tables(plan):
         rows_iv = lay.K + 1 if lgr else lay.K
         row0 = np.concatenate(([0], np.cumsum(rows_iv[:-1])))
         rows = int(np.sum(rows_iv))
-        if int(np.max(lay.K)) + 1 > runtime.WAVE:
-            raise NotImplementedError("mesh error estimation maps the K + 1 augmented nodes of an interval to the "
-                                      "64 lanes of a wavefront: num_point <= 63 (the NLP callbacks themselves take up to 256)")
         for j in range(lay.N):
             K = int(lay.K[j])
             key = (lgr, K)
@@ -65,6 +64,13 @@ def error_tables(plan):
         j = 0
         while j < lay.N:
             K = int(lay.K[j])
+            if K + 1 > runtime.WAVE:        # more augmented nodes than a wave has lanes: the interval takes a whole
+                while len(groups) % runtime.WAVES_PER_BLOCK:      # workgroup (first group of a block, the others idle)
+                    groups.append((first, 0))
+                groups.append((first + j, 1))
+                groups.extend([(first + j, -1)] * (runtime.WAVES_PER_BLOCK - 1))
+                j += 1
+                continue
             cap = max(1, runtime.WAVE // (K + 1))
             cnt = 1
             while j + cnt < lay.N and cnt < cap and int(lay.K[j + cnt]) == K:

@@ -239,7 +239,12 @@ def mesh_error(plan, x):
     outT, outI = np.zeros(n_out), np.zeros(n_out)
     seen = np.zeros(len(recs), dtype=np.int64)
     order = []
-    for first, cnt in groups:                      # one wavefront per group: consecutive intervals of one phase and K
+    for g, (first, cnt) in enumerate(groups):      # one wavefront per group: consecutive intervals of one phase and K
+        if int(cnt) == 1 and int(recs[int(first)]["K"]) + 1 > 64:      # a workgroup of its own
+            assert g % 4 == 0 and all(int(groups[g + u][1]) == -1 for u in (1, 2, 3))
+            order.append(int(first))
+            seen[int(first)] += 1
+            continue
         for jj in range(int(cnt)):
             order.append(int(first) + jj)
             seen[int(first) + jj] += 1

@@ -188,6 +188,7 @@ def test_maximum_supported_order_matches_the_plan_interpreter(case):
 
 
 @pytest.mark.parametrize("case", [("brachistochrone", "radau", dict(mesh=[0, 0.2, 0.5, 0.7, 1.0], num_point=[6, 100, 8, 65])),
+                                  ("brachistochrone", "radau", dict(mesh=[0, 0.3, 0.5, 1.0], num_point=[63, 64, 7])),
                                   ("brachistochrone", "lobatto", dict(mesh=[0, 0.3, 0.6, 1.0], num_point=[66, 5, 130])),
                                   ("planar_quadrotor", "radau", dict(mesh=[0, 0.5, 0.6, 1.0], num_point=[128, 6, 200])),
                                   ("planar_quadrotor", "lobatto", dict(mesh=[0, 0.5, 1.0], num_point=[256, 7])),
@@ -205,7 +206,7 @@ def test_intervals_with_more_points_than_a_wavefront_has_lanes(case):
     it = Interp(system.plan, x, lam, sigma)
     want = dict(f=it.objective(), grad=it.gradient(), g=it.constraints(), J=it.jacobian(), H=it.hessian())
     ev = system.evaluator
-    assert ev.src.big
+    assert ev.src.big == (max(kw["num_point"]) > 64)
     f, grad, g, J, H = ev.cycle(x, lam, sigma)                       # pk_cycle: the three roles of every big block
     close(f, want["f"], what="cycle f")
     close(grad, want["grad"], what="cycle grad")
@@ -228,8 +229,15 @@ def test_intervals_with_more_points_than_a_wavefront_has_lanes(case):
     ev.set_cycle_mode(True)
     with pytest.raises(NotImplementedError):
         getattr(models, bname)(_ns(scheme, "pockit_amd"), mesh=1, num_point=257).plan
-    with pytest.raises(NotImplementedError):
-        system.check_continuous(guess)                                # mesh error estimation: num_point <= 63
+    # mesh error estimation: an interval with K + 1 > 64 augmented nodes is walked by a whole workgroup of pk_err
+    import plan_interp
+
+    data = ev.mesh_error(x)
+    want_e = plan_interp.mesh_error(system.plan, x)
+    for k, (T, I) in enumerate(want_e):
+        close(data[k][0], T, what=f"error T phase {k}")
+        close(data[k][1], I, what=f"error I phase {k}")
+    assert isinstance(system.check_continuous(guess), bool)
 
 
 def test_prepared_x_cache_is_dropped_by_calls_that_reuse_the_context_buffers():
