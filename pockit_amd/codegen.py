@@ -169,11 +169,11 @@ class ModelSource:
         self.list_keys.append(("s",))
         self.list_off = {}
         # intervals with more points than a wavefront has lanes (64 < K <= 256) are evaluated by a whole workgroup: code
-        # compiled into the object only when the mesh has such an interval (PK_BIG); no compact Hessian then
+        # compiled into the object only when the mesh has such an interval (PK_BIG)
         self.big = any(int(pp.layout.K.max()) > 64 for pp in plan.phase_plans)
         if self.big and plan.outer:
             raise NotImplementedError("num_point > 64 together with system functions nonlinear in the integrals")
-        self.compact = not plan.outer and not self.big
+        self.compact = not plan.outer
         for cbname in ("jac", "hess", "aux") + (("hessc",) if self.compact else ()):
             cb = getattr(plan, cbname)
             off, table = 0, {}

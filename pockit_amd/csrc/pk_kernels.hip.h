@@ -1270,15 +1270,16 @@ __device__ __forceinline__ void tile_hessc(const PkArgs& A, const PkTile& tl, do
   phase_scalars<P>(A, ph, s, dt, mt);
   const PkSys sy{s, A.Ibuf, A.sigma, A.lam};
   pk_cbase_t segb = const_bases(A.lb + ph.hcseg_off);
-  if (lane < g.nown) {
-    const int q = tl.q0 + lane;
+  // (one pass for a wave tile; an interval with more than 64 points -- alone in its tile -- is walked 64 nodes at a time)
+  for (int c = lane; c < g.nown; c += PK_WAVE) {
+    const int q = tl.q0 + c;
     if (q >= ph.mid_lo && q < ph.mid_hi) {
       double a[P::NARG], tau, w, o[P::HC_NN + 1], lp[P::NC > 0 ? P::NC : 1], mu[P::NX];
       load_node<P>(A, ph, s, dt, mt, q, a, tau, w);
 #pragma unroll
       for (int j = 0; j < P::NC; ++j) lp[j] = A.lam[ph.path_off + j * ph.L_m + q];
-      const int jj = lane / g.stride;
-      node_mu<P>(A, ph, tl.j0 + jj, lane - jj * g.stride, mu);
+      const int jj = c / g.stride;
+      node_mu<P>(A, ph, tl.j0 + jj, c - jj * g.stride, mu);
       P::mid_hessc(a, tau, dt, w, sy, lp, mu, nullptr, nullptr, o);
 #pragma unroll
       for (int e = 0; e < P::HC_NN; ++e) A.o_hess[segb[e] + (q - ph.mid_lo)] = o[e];

@@ -229,6 +229,9 @@ def test_intervals_with_more_points_than_a_wavefront_has_lanes(case):
     ev.set_cycle_mode(True)
     with pytest.raises(NotImplementedError):
         getattr(models, bname)(_ns(scheme, "pockit_amd"), mesh=1, num_point=257).plan
+    system.set_hessian_layout("compact")                             # compact layout: pk_hessc walks such an interval 64 nodes at a time
+    close(system.hessian(x, lam, sigma), it.hessian_compact(), what="compact H")
+    system.set_hessian_layout("reference")
     # mesh error estimation: an interval with K + 1 > 64 augmented nodes is walked by a whole workgroup of pk_err
     import plan_interp
 
