@@ -426,6 +426,39 @@ def func_times_model(ns, mesh=(0, 0.3, 0.55, 1), num_point=(2, 3, 2)):
     return s, [p1, p2], guess
 
 
+def elementary_functions_model(ns, mesh=(0, 0.3, 1.0), num_point=(4, 5)):
+    """Every elementary function the reference's NumPy / Numba printing handles smoothly (fastfunc.py:41-43: lambdarepr with
+    the math. prefix stripped): tan, asin, acos, atan, atan2, the hyperbolic functions and their inverses, exp, log, sqrt,
+    rational and negative powers -- in dynamics, integrands, path and system constraints, with static parameters, a FUNC
+    boundary value and a free final time."""
+    system = ns.System(["p", "q"])
+    p_, q_ = system.s
+    phase = system.new_phase(["a", "b", "c"], ["u", "v"])
+    a, b, c = phase.x
+    u, v = phase.u
+    t = phase.t
+    phase.set_dynamics([
+        sp.tan(a / 4) + sp.asin(u / 3) * sp.exp(-b) + sp.sinh(v / 2) * p_,
+        sp.acos(v / 3) * sp.log(2 + a**2) + sp.atan(b * u) + sp.cosh(c / 3),
+        sp.tanh(a * b) + sp.sqrt(1 + c**2) * sp.atan2(u + 2, v + 3) + (2 + sp.cos(t))**sp.Rational(5, 2) + q_ * (1 + u**2)**(-2),
+    ])
+    phase.set_integral([sp.sqrt((a - 0.37)**2 + 0.01) * u**2 + sp.exp(sp.sin(b)) * v**2, sp.asinh(a * b) * c + (1 + v**2)**sp.Rational(1, 3)])
+    phase.set_phase_constraint([sp.log(1 + u**2) + sp.acosh(2 + c**2) + sp.atanh(a / 3), u, v], [-1.0, -1.0, -1.0], [3.0, 1.0, 1.0])
+    phase.set_boundary_condition([0.1, 0.2, None], [None, 0.5 * p_, None], 0.0, None)
+    phase.set_discretization(mesh, num_point)
+    system.set_phase([phase])
+    system.set_objective(phase.I[0] + phase.I[1] * p_ + q_**2)
+    system.set_system_constraint([phase.I[1] + p_ * q_], [-10.0], [10.0])
+    guess = ns.linear_guess(phase, 0.3)
+    guess.t_f = 1.5
+    guess.x[0] = 0.1 + 0.3 * guess.t_x
+    guess.x[1] = 0.2 + 0.2 * np.sin(guess.t_x)
+    guess.x[2] = 0.4 * np.cos(guess.t_x)
+    guess.u[0] = 0.3 * np.sin(2 * guess.t_u)
+    guess.u[1] = -0.2 + 0.1 * guess.t_u
+    return system, [phase], [guess, np.array([0.7, -0.4])]
+
+
 def bang_bang_model(ns, mesh=6, num_point=5, second=False):
     """Bang-bang test problem in the style of the reference's check tests (tests/test_radau/test_check_radau.py:
     9-16): one state driven by the controls, a bang-bang path constraint u0 + s0 in [0, 2] and, with ``second``,

@@ -302,6 +302,29 @@ def test_pageable_result_targets_of_a_c_abi_caller():
     close(system.gradient(x), ref.gradient(x), what="grad afterwards")
 
 
+@pytest.mark.parametrize("scheme", ["radau", "lobatto"])
+def test_elementary_functions_of_a_user_model_match_oracle(scheme):
+    """A user model may use any elementary function SymPy differentiates and the reference prints (tan, asin, acos, atan,
+    atan2, sinh ... atanh, exp, log, sqrt, rational / negative powers): the generated device code must agree with the
+    oracle's NumPy execution in structure and values."""
+    system, _, guess = models.elementary_functions_model(_ns(scheme, "pockit_amd"))
+    ref, _, _ = models.elementary_functions_model(_ns(scheme, "oracle"))
+    x, lam, sigma = models.bench_inputs(system, guess)
+    jr, jc = ref.jacobianstructure()
+    hr, hc = ref.hessianstructure()
+    pjr, pjc = system.jacobianstructure()
+    phr, phc = system.hessianstructure()
+    assert np.array_equal(jr, pjr) and np.array_equal(jc, pjc) and np.array_equal(hr, phr) and np.array_equal(hc, phc)
+    close(system.objective(x), ref.objective(x.copy()), what="f")
+    close(system.gradient(x), ref.gradient(x.copy()), what="grad")
+    close(system.constraints(x), ref.constraints(x.copy()), what="g")
+    close(system.jacobian(x), ref.jacobian(x.copy()), what="J")
+    close(system.hessian(x, lam, sigma), ref.hessian(x.copy(), lam, sigma), what="H")
+    f, grad, g, J, H = system.evaluator.cycle(x, lam, sigma)
+    close(J, ref.jacobian(x.copy()), what="cycle J")
+    close(H, ref.hessian(x.copy(), lam, sigma), what="cycle H")
+
+
 def test_ragged_mesh_matches_oracle():
     """hp-style mesh: every interval its own width and polynomial order (K = 1 .. 9)."""
     rng = np.random.default_rng(5)
