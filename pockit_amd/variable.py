@@ -34,7 +34,8 @@ def lagrange_values(nodes, points):
     hit = d == 0.0
     d[hit] = 1.0
     terms = bw[None, :] / d
-    V = terms / np.sum(terms, axis=1, keepdims=True)
+    with np.errstate(divide="ignore", invalid="ignore"):      # (rows of points that coincide with a node are replaced below)
+        V = terms / np.sum(terms, axis=1, keepdims=True)
     rows = np.any(hit, axis=1)
     V[rows] = hit[rows]
     return V
