@@ -12,7 +12,8 @@ to ``pockit_amd`` -- up to its call of ``ipopt.solve``, which is intercepted, an
 
 That is the drop-in claim on the programs users actually write: same modeling API, same NLP.  Prints one JSON object.
 Run in a process of its own (the shims and the module aliases must not leak into the test process).
-Usage: check_examples.py [name-substring ...]     (POCKIT_AMD_ALL_EXAMPLES=1: also the four whose NumPy execution takes a minute)"""
+Usage: check_examples.py [name-substring ...]     (POCKIT_AMD_ALL_EXAMPLES=1: also the four whose NumPy execution takes a minute;
+POCKIT_AMD_EXAMPLES_COMPILE=1: also generate and compile every model's gfx950 code object with hipcc, no GPU needed)"""
 import importlib
 import json
 import os
@@ -134,6 +135,13 @@ def check(name):
     pjr, pjc = system.jacobianstructure()
     phr, phc = system.hessianstructure()
     out["structure"] = bool(np.array_equal(jr, pjr) and np.array_equal(jc, pjc) and np.array_equal(hr, phr) and np.array_equal(hc, phc))
+    if os.environ.get("POCKIT_AMD_EXAMPLES_COMPILE") == "1":      # also: generate the device code and compile it for gfx950
+        from pockit_amd import hipbuild
+        from pockit_amd.codegen import ModelSource
+
+        t0 = time.time()
+        hipbuild.compile_model(ModelSource(system.plan).source, fastmath=system._fastmath, keep_source=False)
+        out["hipcc_seconds"] = round(time.time() - t0, 1)
     it = Interp(system.plan, x, lam, sigma)
     out["err"] = max(rel(it.objective(), rsys.objective(x.copy())), rel(it.gradient(), rsys.gradient(x.copy())),
                      rel(it.constraints(), rsys.constraints(x.copy())), rel(it.jacobian(), rsys.jacobian(x.copy())),
