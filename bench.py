@@ -327,6 +327,22 @@ class GpuWorkload:
                     self.exchange_fallback = "pk_xchg in a launch of its own is faster here than the in-launch exchange"
             self.inline_default = sev.inline_exchange
             step = self.make_step(self.mode)
+            # guard of the headline loop: a burst of back-to-back cycles (ranks drift apart, unlike in the one-cycle probe)
+            # must leave finite sums on every rank -- else step down: in-launch -> pk_xchg behind pk_cycle -> RCCL gather
+            while self.mode in ("sums", "direct"):
+                for _ in range(50):
+                    step()
+                self.sync()
+                if self.all_finite():
+                    break
+                if self.mode == "sums" and sev.inline_exchange:
+                    self.exchange_fallback = "in-launch exchange lost sums in a back-to-back burst; pk_xchg in a launch of its own"
+                    sev.inline_exchange = self.inline_default = False
+                else:
+                    self.exchange_fallback = f"{self.mode}: sums not finite in a back-to-back burst; RCCL gather"
+                    self.mode = "gather"
+                print(f"[bench] {self.exchange_fallback}", file=sys.stderr)
+                step = self.make_step(self.mode)
             self.exchange = self.mode
         self.step = step
         self.bytes = B = algorithmic_bytes(plan)
@@ -379,6 +395,16 @@ class GpuWorkload:
                 return self.make_step("allgather")
         return step
 
+    def all_finite(self):
+        """f finite on every rank (collective)."""
+        torch = self.torch
+        ok = 1.0 if bool(torch.isfinite(self.o["f"]).all()) else 0.0
+        if self.dist is None or self.world == 1:
+            return ok == 1.0
+        t = torch.tensor([ok], dtype=torch.float64, device=self.dev)
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MIN)
+        return float(t[0]) == 1.0
+
     def time_mode(self, mode, steps=200):
         """ms per cycle of another form of the exchange (short untimed warm-up, wall clock between barriers)."""
         try:
@@ -386,6 +412,8 @@ class GpuWorkload:
             for _ in range(10):
                 step()
             self.sync()
+            if mode in ("sums", "direct") and not self.all_finite():      # (a timed-out exchange costs ~1 s per launch)
+                raise RuntimeError("sums not finite after ten back-to-back cycles")
             t0 = time.perf_counter()
             for _ in range(steps):
                 step()
