@@ -15,8 +15,8 @@ this package's modeling API, symbol by symbol:
 The transcription compiler then rebuilds layout and triplet order from scratch; that they equal the reference's is what
 the golden vectors pin (tests/test_adapter_reference.py compares converted plans with tests/golden in the build
 container; nothing of the reference ships or is imported by this module).
-Not carried over: the bang-bang flags of phase constraints (they only feed the reference's switch-point refinement,
-which works on the reference's own objects) and FastFunc cache directories.
+The bang-bang flags of phase constraints (they feed the switch-point refinement) are recovered from the SymPy source of the
+reference's scaled constraint functions.  Not carried over: FastFunc cache directories.
 """
 from __future__ import annotations
 
@@ -30,6 +30,33 @@ def _strip(name: str) -> str:
     """``speed^{(0)}`` -> ``speed`` (the phase identifier suffix is re-attached by ``new_phase``)."""
     k = name.rfind("^{(")
     return name[:k] if k >= 0 else name
+
+
+def _bang_bang_flags(rp, conv, exprs, lb, ub):
+    """Which of the rebuilt phase constraints the reference treats as bang-bang.  The reference keeps no flags, only one
+    compiled function ``(c - lb) / (ub - lb)`` per flagged constraint, in the user's order (phasebase.py:388-412); its
+    SymPy source survives in ``FastFunc._function`` with the arguments renamed (fastfunc.py:140-149).  A rebuilt
+    constraint is bang-bang when its own scaled form equals one of those sources."""
+    funcs = list(getattr(rp, "_func_bang_bang_control", []))
+    if not funcs:
+        return False
+    scaled = []
+    for f in funcs:
+        back = dict(zip(f._args, rp._symbols))
+        scaled.append(conv(sp.sympify(f._function).xreplace(back)))
+    flags = []
+    for e, lo, hi in zip(exprs, lb, ub):
+        hit = False
+        if np.isfinite(lo) and np.isfinite(hi) and hi > lo:
+            mine = (sp.sympify(e) - lo) / (hi - lo)
+            for k, g in enumerate(scaled):
+                if g is not None and (mine == g or sp.expand(mine - g) == 0 or sp.simplify(mine - g) == 0):
+                    hit, scaled[k] = True, None      # (every compiled function marks one constraint)
+                    break
+        flags.append(hit)
+    if any(g is not None for g in scaled):
+        raise ValueError("a bang-bang constraint of the reference phase could not be matched to a phase constraint")
+    return flags
 
 
 def system_from_reference(ref):
@@ -72,7 +99,7 @@ def system_from_reference(ref):
                 exprs.append(p.t); lb.append(lo); ub.append(hi)
             for i, lo, hi in rp._static_parameter_bounds_phase:
                 exprs.append(system.s[i]); lb.append(lo); ub.append(hi)
-            p.set_phase_constraint(exprs, lb, ub)
+            p.set_phase_constraint(exprs, lb, ub, _bang_bang_flags(rp, conv, exprs, lb, ub))
         p.set_boundary_condition([bc(v) for v in rp._initial_value], [bc(v) for v in rp._terminal_value],
                                  bc(rp._initial_time), bc(rp._terminal_time))
         p.set_discretization(np.asarray(rp._mesh, dtype=np.float64), np.asarray(rp._num_point, dtype=np.int64))

@@ -46,4 +46,19 @@ for name, (builder, scheme, kw) in sorted(models.SMALL_CASES.items()):
         if want.size:
             err = max(err, float(np.max(np.abs(got - want)) / max(1.0, float(np.max(np.abs(want))))))
     out[name] = {"structure": bool(ok), "err": err, "n": int(plan.n), "m": int(plan.m)}
+# bang-bang flags: the reference keeps only compiled scaled functions; the adapter must recover which constraints they mark
+import pockit_amd.lobatto as my_lobatto  # noqa: E402
+import pockit_amd.radau as my_radau  # noqa: E402
+from pockit_amd.adapter import system_from_reference  # noqa: E402
+
+MINE = {"radau": my_radau, "lobatto": my_lobatto}
+for scheme in ("radau", "lobatto"):
+    for second in (False, True):
+        ref_system, _, _ = models.bang_bang_model(NS[scheme], second=second)
+        mine, _, _ = models.bang_bang_model(MINE[scheme], second=second)
+        conv = system_from_reference(ref_system)
+        got = [(k, i) for k, i, _, _ in conv._phase[0]._bang_bang]
+        want = [(k, i) for k, i, _, _ in mine._phase[0]._bang_bang]
+        out[f"bang_bang_{scheme}_{int(second)}"] = {"structure": got == want and len(want) == (2 if second else 1), "err": 0.0,
+                                                     "n": int(conv.plan.n), "m": int(conv.plan.m)}
 print(json.dumps(out))

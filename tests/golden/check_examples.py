@@ -7,6 +7,7 @@ to ``pockit_amd`` -- up to its call of ``ipopt.solve``, which is intercepted, an
 * the solver options,
 * variable and constraint bounds, problem sizes,
 * the triplet structures of J and H (exactly),
+* the plan the adapter (pockit_amd/adapter.py) derives from the configured reference system, bang-bang flags included,
 * f, grad f, g, J, H at a perturbed guess -- the reference's own callbacks (NumPy execution of its generated functions)
   against the NumPy execution of the product's plan (tests/plan_interp.py), to 1e-11.
 
@@ -135,6 +136,17 @@ def check(name):
     pjr, pjc = system.jacobianstructure()
     phr, phc = system.hessianstructure()
     out["structure"] = bool(np.array_equal(jr, pjr) and np.array_equal(jc, pjc) and np.array_equal(hr, phr) and np.array_equal(hc, phc))
+    # the maintainer-side route: the configured REFERENCE system converted by the adapter must give
+    # the same plan as the program run against this package, bang-bang flags included
+    from pockit_amd.adapter import system_from_reference
+
+    conv = system_from_reference(rsys)
+    cjr, cjc = conv.jacobianstructure()
+    chr_, chc = conv.hessianstructure()
+    out["adapter"] = bool(np.array_equal(cjr, jr) and np.array_equal(cjc, jc) and np.array_equal(chr_, hr) and np.array_equal(chc, hc)
+                          and np.array_equal(conv.v_lb, rsys.v_lb) and np.array_equal(conv.c_ub, rsys.c_ub)
+                          and [[(k, i) for k, i, _, _ in p._bang_bang] for p in conv._phase]
+                          == [[(k, i) for k, i, _, _ in p._bang_bang] for p in system._phase])
     if os.environ.get("POCKIT_AMD_EXAMPLES_COMPILE") == "1":      # also: generate the device code and compile it for gfx950
         from pockit_amd import hipbuild
         from pockit_amd.codegen import ModelSource

@@ -27,4 +27,5 @@ def test_reference_example_programs_build_the_same_nlp_with_this_package():
         assert r["options"], name + ": solver options differ"
         assert r["bounds"], name + ": bounds or sizes differ"
         assert r["structure"], name + ": triplet structure differs from the reference's"
+        assert r["adapter"], name + ": the adapter's plan of the configured reference system differs"
         assert r["err"] <= 1e-11, (name, r["err"])
