@@ -17,9 +17,11 @@ GPUs (weak scaling: 2000 intervals per GPU); ``value`` is then in 12k-node-equiv
 
 Timing.  A cycle is ONE 5 us launch, so a region of ``--steps 20`` would measure the launch ramp and one
 synchronization, not the kernel.  After the warm-up the timed region therefore consists of R back-to-back batches of
-EXACTLY ``steps`` cycles each (R chosen so that the region lasts >= 50 ms), separated by HIP events recorded on the
-launch stream and bracketed as a whole by a barrier + synchronize; ``ms_per_step`` is the MEDIAN batch / steps, the
-spread over the batches and the wall clock of the whole region are reported too.
+EXACTLY ``steps`` cycles each (R chosen so that the region lasts >= 50 ms), with a HIP event recorded on the launch
+stream after every ceil(200 / steps) batches (an event drains the stream, ~3 us of GPU time: between every two batches
+of 20 cycles it would add 3 % to the figure) and bracketed as a whole by a barrier + synchronize; ``ms_per_step`` is the
+MEDIAN over the timed units of (unit / batches in it) / steps, the spread and the wall clock of the whole region are
+reported too.
 
 One JSON line is printed by rank 0 (see the repository prompt for the contract), carrying ``roofline`` for the
 dominant kernel (per-dispatch HIP events on the launch stream) and ``cpu_baseline`` (the oracle = CPU restatement of
@@ -60,6 +62,7 @@ SHARDING_NOTE = {
 HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 KERNEL_IDS = {"pk_int": 0, "pk_fin": 1, "pk_g": 2, "pk_grad": 3, "pk_jac": 4, "pk_hess": 5, "pk_xall": 6, "pk_cycle": 12}
 MIN_REGION_S = 0.05        # the timed region lasts at least this long (R batches of `steps` cycles)
+EVENT_SPACING = 200        # cycles between two timing events of the region (an event costs ~3 us of GPU time)
 MIN_WARMUP = 500           # untimed launches before the timed region (single GPU), whatever --warmup says
 ISOLATED_SAMPLES = 200     # per-dispatch kernel timings on an idle stream (what a profiler's kernel trace measures)
 POINTS = {"planar_quadrotor": 6, "brachistochrone": 8, "two_stage_rocket": 4, "humanoid_wbc": 8}
@@ -280,6 +283,13 @@ class GpuWorkload:
                 rc = lib.pk_eval_cycle_dev(*cycle_args)
                 if rc:
                     check(rc)
+
+            def many(count):      # `count` cycles enqueued by the library itself (no interpreter between the launches)
+                rc = lib.pk_eval_cycle_dev_repeat(*cycle_args, count, 0, None)
+                if rc:
+                    check(rc)
+
+            step.many = many
             check(lib.pk_set_shard(self.h, 0, 0, None))
         else:
             # N > 1.  Default form "sums": every rank leaves its slices in its own HBM, only the sums over all nodes are
@@ -438,7 +448,7 @@ class GpuWorkload:
         self.sync()
         # size of the region: estimate the step time on a short untimed stretch
         t0 = time.perf_counter()
-        probe = max(steps, 50 if self.world == 1 else 5)
+        probe = max(steps, 1000 if self.world == 1 else 20)     # (long enough for the closing synchronize not to count)
         for _ in range(probe):
             step()
         self.sync()
@@ -448,17 +458,58 @@ class GpuWorkload:
             t = torch.tensor([R], dtype=torch.int64, device=self.dev)
             self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
             R = int(t.item())
-        events = [torch.cuda.Event(enable_timing=True) for _ in range(R + 1)]
+        # How a batch reaches the stream (one GPU): `steps` kernel launches enqueued by the library, or ONE replay of a
+        # hipGraph of `steps` kernel nodes (pk_set_cycle_graph: 0.4 us of host time per cycle instead of ~4, a kernel
+        # ~2 % longer).  On a box whose host needs longer per launch than the kernel runs the first form is paced by the
+        # host; both are timed on a short stretch and the faster one carries the region.
+        self.batch_launch = {"form": f"{steps} kernel launches per batch"}
+        if self.world == 1 and hasattr(step, "many") and self.dominant == "pk_cycle" and os.environ.get("POCKIT_AMD_BENCH_GRAPH", "auto") != "0":
+            ms = {}
+            for form in ("launches", "graph"):
+                self.ev.set_cycle_graph(form == "graph")
+                step.many(steps)                               # (captures the graph)
+                self.sync()
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                nb = max(10, 4000 // steps)
+                e0.record(stream)
+                for _ in range(nb):
+                    step.many(steps)
+                e1.record(stream)
+                self.sync()
+                ms[form] = e0.elapsed_time(e1) / (nb * steps)
+            use_graph = ms["graph"] < ms["launches"] or os.environ.get("POCKIT_AMD_BENCH_GRAPH") == "1"
+            self.ev.set_cycle_graph(use_graph)
+            if use_graph:
+                step.many(steps)
+                self.sync()
+            self.batch_launch = {"form": (f"one hipGraph of {steps} kernel nodes per batch" if use_graph
+                                          else f"{steps} kernel launches per batch"),
+                                 "probe_us_per_cycle": {k: v * 1e3 for k, v in ms.items()}}
+        # An event between two launches is not free: it drains the stream (measured: ~3 us of GPU time each, 3 % of a
+        # 20-cycle batch).  Events are therefore recorded after every `group` batches, group * steps >= EVENT_SPACING
+        # cycles; a timed unit is `group` whole batches and its duration / group is what enters the statistics.
+        group = max(1, -(-EVENT_SPACING // steps))
+        R = -(-R // group) * group
+        events = [torch.cuda.Event(enable_timing=True) for _ in range(R // group + 1)]
         self.sync()
         t0 = time.perf_counter()
         events[0].record(stream)
+        many = getattr(step, "many", None)      # a batch = ONE call into the library that enqueues `steps` cycles
         for b in range(R):
-            for _ in range(steps):
-                step()
-            events[b + 1].record(stream)
+            if many is not None:
+                many(steps)
+            else:
+                for _ in range(steps):
+                    step()
+            if (b + 1) % group == 0:
+                events[(b + 1) // group].record(stream)
         self.sync()
         wall = time.perf_counter() - t0
-        batch_ms = [events[b].elapsed_time(events[b + 1]) for b in range(R)]
+        batch_ms = [events[u].elapsed_time(events[u + 1]) / group for u in range(R // group)]
+        self.event_group = group
+        self.region_batches = R
+        if self.world == 1 and hasattr(step, "many"):
+            self.ev.set_cycle_graph(False)
         return batch_ms, wall, n_warm + probe
 
     def dispatch_times(self, kernel):
@@ -554,13 +605,14 @@ def measure(name, intervals, steps, warmup, rank, world, dist, with_side=True, w
     """Everything the JSON line says about one workload on this rank."""
     w = GpuWorkload(name, intervals, rank, world, dist)
     batch_ms, wall, untimed = w.timed_region(steps, warmup)
-    R = len(batch_ms)
+    R = w.region_batches
     med = statistics.median(batch_ms)
     q = sorted(batch_ms)
+    Rq = len(q)
     res = dict(name=name, intervals=intervals, nodes=int(sum(pp.layout.L_m for pp in w.plan.phase_plans)),
                n=w.plan.n, m=w.plan.m, nnz_J=w.plan.nnz_J, nnz_H=w.plan.nnz_H, steps=steps, batches=R,
-               median_batch_ms=med, ms_per_step=med / steps,
-               batch_ms_p10=q[int(0.1 * (R - 1))], batch_ms_p90=q[int(0.9 * (R - 1))], batch_ms_min=q[0], batch_ms_max=q[-1],
+               median_batch_ms=med, ms_per_step=med / steps, event_group=w.event_group, batch_launch=w.batch_launch,
+               batch_ms_p10=q[int(0.1 * (Rq - 1))], batch_ms_p90=q[int(0.9 * (Rq - 1))], batch_ms_min=q[0], batch_ms_max=q[-1],
                region_wall_s=wall, wall_ms_per_step=wall / (R * steps) * 1e3, untimed_launches=untimed,
                setup_s=w.setup_s, compile_s_in_setup=w.compile_s_in_setup, bytes=w.bytes, dominant=w.dominant,
                exchange=w.exchange, tiles=int(len(w.ev.tables.tiles)), ipw=int(w.ev.tables.intervals_per_wave))
@@ -768,9 +820,12 @@ def main():
                        "tiles": res["tiles"], "intervals_per_wave": res["ipw"],
                        "inputs": "example guess*(1+1e-3 U(-1,1)) seed 0; lambda N(0,1) seed 1; sigma 1"},
             "timing": {"region": f"{res['batches']} back-to-back batches of exactly {args.steps} cycles (>= {MIN_REGION_S * 1e3:.0f} ms "
-                                 f"in total), HIP events between the batches on the launch stream, barrier + synchronize around "
-                                 f"the region; ms_per_step = median batch / steps (max over ranks)",
-                       "batches": res["batches"], "median_batch_ms": res["median_batch_ms"],
+                                 f"in total), a HIP event on the launch stream after every {res['event_group']} batches (an event "
+                                 f"drains the stream: ~3 us each), barrier + synchronize around the region; ms_per_step = median "
+                                 f"over the timed units of (unit duration / {res['event_group']} batches) / steps (max over ranks)",
+                       "batches": res["batches"], "batches_per_timing_event": res["event_group"],
+                       "batch_launch": res["batch_launch"],
+                       "median_batch_ms": res["median_batch_ms"],
                        "batch_ms_min_p10_p90_max": [res["batch_ms_min"], res["batch_ms_p10"], res["batch_ms_p90"], res["batch_ms_max"]],
                        "region_wall_s": res["region_wall_s"], "wall_ms_per_step_whole_region": wall_ms,
                        "untimed_launches_before_the_region": res["untimed_launches"]},

@@ -206,6 +206,12 @@ int pk_eval_xpart_dev(pk_ctx* ctx, const double* d_x, double* d_f, double* d_gra
  * per context at a time (the launch owns the context's hand-off slots). */
 int pk_eval_cycle_dev(pk_ctx* ctx, const double* d_x, const double* d_lambda, double sigma, double* d_f,
                       double* d_grad, double* d_g, double* d_jac, double* d_hess, void* stream);
+/* `count` back-to-back cycles on the same buffers, enqueued by the library (a solver written against the C ABI launches from
+ * compiled code; bench.py's timed batches go through this so that no interpreter loop paces the stream).  xchg = 1: every
+ * cycle is followed by pk_exchange_sums_dev(d_x, d_xgrad, d_f) -- the two-launch form of a sharded cycle.  No reference
+ * counterpart (the reference's callbacks are synchronous NumPy calls, systembase.py:602-835). */
+int pk_eval_cycle_dev_repeat(pk_ctx* ctx, const double* d_x, const double* d_lambda, double sigma, double* d_f, double* d_grad,
+                             double* d_g, double* d_jac, double* d_hess, void* stream, int count, int xchg, double* d_xgrad);
 /* Replay the fused cycle from a cached hipGraph while its pointers, sigma and stream do not change (a solver's
  * steady state); any change re-captures.  Off by default. */
 int pk_set_cycle_graph(pk_ctx* ctx, int enable);

@@ -87,6 +87,8 @@ struct pk_ctx {
   // cached hipGraph of the fused callback cycle (pk_set_cycle_graph)
   bool use_graph = false;
   hipGraphExec_t cyc_exec = nullptr;
+  hipGraphExec_t rep_exec = nullptr;      // pk_eval_cycle_dev_repeat: a batch of rep_count cycles as one graph
+  int rep_count = 0;
   struct CycleKey {
     const void *x, *lam, *f, *grad, *g, *jac, *hess;
     double sigma;
@@ -95,7 +97,7 @@ struct pk_ctx {
       return x == o.x && lam == o.lam && f == o.f && grad == o.grad && g == o.g && jac == o.jac && hess == o.hess &&
              sigma == o.sigma && st == o.st;
     }
-  } cyc_key{};
+  } cyc_key{}, rep_key{};
   unsigned long long* d_trace = nullptr;   // developer tracing buffer, [n_tiles][16]
   // triplet -> CSR maps (pk_set_csr_map): [0] Jacobian, [1] Hessian of the Lagrangian (lower triangle)
   struct CsrMap {
@@ -163,6 +165,7 @@ int fail(pk_ctx* c, int code, const char* fmt, ...) {
 
 void drop_cycle_graph(pk_ctx* c) {
   if (c->cyc_exec) { (void)hipGraphExecDestroy(c->cyc_exec); c->cyc_exec = nullptr; }
+  if (c->rep_exec) { (void)hipGraphExecDestroy(c->rep_exec); c->rep_exec = nullptr; }
 }
 
 template <class T>
@@ -887,6 +890,8 @@ int pk_eval_hessc(pk_ctx* c, const double* x, const double* lambda, double sigma
   return 0;
 }
 
+int pk_exchange_sums_dev(pk_ctx* c, const double* d_x, double* d_grad, double* d_f, int epoch, int write_f, void* stream);
+
 int pk_eval_cycle_dev(pk_ctx* c, const double* d_x, const double* d_lam, double sigma, double* d_f, double* d_grad,
                       double* d_g, double* d_jac, double* d_hess, void* stream) {
   int rc = ready(c);
@@ -928,6 +933,47 @@ int pk_eval_cycle_dev(pk_ctx* c, const double* d_x, const double* d_lam, double 
   if (e != hipSuccess) { c->cyc_exec = nullptr; return fail(c, 3, "pk_eval_cycle: graph instantiation failed: %s", hipGetErrorString(e)); }
   c->cyc_key = key;
   PK_HIP(c, hipGraphLaunch(c->cyc_exec, st));
+  return 0;
+}
+
+// `count` back-to-back cycles on the same buffers, enqueued from here (a solver written against the C ABI launches from
+// compiled code; bench.py's timed batches use this so that a Python loop does not pace the stream).  xchg = 1: every cycle
+// is followed by pk_exchange_sums_dev(d_x, d_xgrad, d_f) -- the two-launch form of a sharded cycle.
+int pk_eval_cycle_dev_repeat(pk_ctx* c, const double* d_x, const double* d_lam, double sigma, double* d_f, double* d_grad,
+                             double* d_g, double* d_jac, double* d_hess, void* stream, int count, int xchg, double* d_xgrad) {
+  int rc = ready(c);
+  if (rc) return rc;
+  // pk_set_cycle_graph(1): the whole batch is ONE hipGraph of `count` kernel nodes, captured once and replayed while
+  // pointers, sigma, stream and count stay the same -- the host then pays one graph launch per batch instead of `count`
+  // kernel launches.  Not for sharded cycles (their exchange epoch is a kernel argument that advances with every launch).
+  const bool needs_I = c->md.prepass_grad || c->md.prepass_g || c->md.prepass_jac || c->md.prepass_hess;
+  const bool graph = c->use_graph && c->profile_mask == 0 && !xchg && c->xc_world <= 1 && !needs_I && count > 1 &&
+                     c->cycle_mode == 1 && !c->shard_flags && !c->external_prepass && d_lam;
+  if (graph) {
+    hipStream_t st = pick(c, stream);
+    const pk_ctx::CycleKey key{d_x, d_lam, d_f, d_grad, d_g, d_jac, d_hess, sigma, st};
+    if (!(c->rep_exec && c->rep_key == key && c->rep_count == count)) {
+      if (c->rep_exec) { (void)hipGraphExecDestroy(c->rep_exec); c->rep_exec = nullptr; }
+      PK_HIP(c, hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
+      for (int k = 0; k < count && !rc; ++k) rc = enqueue_single_launch_cycle(c, d_x, d_lam, sigma, d_f, d_grad, d_g, d_jac, d_hess, st);
+      hipGraph_t g = nullptr;
+      hipError_t e = hipStreamEndCapture(st, &g);
+      if (rc) { if (g) (void)hipGraphDestroy(g); return rc; }
+      if (e != hipSuccess) return fail(c, 3, "pk_eval_cycle_dev_repeat: graph capture failed: %s", hipGetErrorString(e));
+      e = hipGraphInstantiate(&c->rep_exec, g, nullptr, nullptr, 0);
+      (void)hipGraphDestroy(g);
+      if (e != hipSuccess) { c->rep_exec = nullptr; return fail(c, 3, "pk_eval_cycle_dev_repeat: graph instantiation failed: %s", hipGetErrorString(e)); }
+      c->rep_key = key;
+      c->rep_count = count;
+    }
+    PK_HIP(c, hipGraphLaunch(c->rep_exec, st));
+    return 0;
+  }
+  for (int k = 0; k < count; ++k) {
+    rc = pk_eval_cycle_dev(c, d_x, d_lam, sigma, d_f, d_grad, d_g, d_jac, d_hess, stream);
+    if (!rc && xchg) rc = pk_exchange_sums_dev(c, d_x, d_xgrad, d_f, 0, 1, stream);
+    if (rc) return rc;
+  }
   return 0;
 }
 

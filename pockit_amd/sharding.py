@@ -520,7 +520,14 @@ class ShardedEvaluator:
                 rc = cycle_fn(*cyc) or xchg_fn(h, px, pgrad, pf, 0, 1, st)
                 if rc:
                     chk(rc)
+        repeat_fn, two = lib.pk_eval_cycle_dev_repeat, 0 if self.inline_exchange else 1
 
+        def many(count):          # `count` cycles enqueued by the library itself (no interpreter between the launches)
+            rc = repeat_fn(*cyc, count, two, pgrad)
+            if rc:
+                chk(rc)
+
+        step.many = many
         return step
 
     def cycle(self, x, lam, sigma, dist=None, root=None, exchange=None):
