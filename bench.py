@@ -21,7 +21,10 @@ EXACTLY ``steps`` cycles each (R chosen so that the region lasts >= 50 ms), with
 stream after every ceil(200 / steps) batches (an event drains the stream, ~3 us of GPU time: between every two batches
 of 20 cycles it would add 3 % to the figure) and bracketed as a whole by a barrier + synchronize; ``ms_per_step`` is the
 MEDIAN over the timed units of (unit / batches in it) / steps, the spread and the wall clock of the whole region are
-reported too.
+reported too.  On one GPU a batch is ONE call into the library (pk_eval_cycle_dev_repeat): it enqueues the ``steps`` launches
+from C, or replays them as one hipGraph of ``steps`` kernel nodes -- both forms are timed on a short stretch and the faster
+one on this box carries the region (``timing.batch_launch``; under a profiler that makes launches expensive it is the
+graph).
 
 One JSON line is printed by rank 0 (see the repository prompt for the contract), carrying ``roofline`` for the
 dominant kernel (per-dispatch HIP events on the launch stream) and ``cpu_baseline`` (the oracle = CPU restatement of

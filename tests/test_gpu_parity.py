@@ -636,6 +636,44 @@ def test_cycle_graph_replay_gives_identical_results():
         ev.set_cycle_graph(False)
 
 
+def test_batches_enqueued_by_the_library_equal_single_cycles():
+    """pk_eval_cycle_dev_repeat (what bench.py's timed batches call): `count` cycles enqueued from C, as plain launches and
+    -- pk_set_cycle_graph -- as one hipGraph of `count` kernel nodes replayed twice, leave exactly the outputs of a single
+    cycle (the hand-off slots are put back by every launch, so any number of launches may follow each other)."""
+    import ctypes as C
+
+    import torch
+
+    system, _, guess = models.planar_quadrotor(_ns("radau", "pockit_amd"), mesh=200, num_point=6)
+    plan, ev = system.plan, system.evaluator
+    x, lam, sigma = models.bench_inputs(system, guess)
+    want = ev.cycle(x, lam, sigma)
+    dev = torch.device("cuda", 0)
+    dx, dlam = torch.from_numpy(x).to(dev), torch.from_numpy(lam).to(dev)
+    sizes = (("f", 1), ("grad", plan.n), ("g", plan.m), ("J", plan.nnz_J), ("H", plan.nnz_H))
+    lib, h = ev.ctx.lib, ev.ctx.handle
+
+    def run(count, times):
+        o = {k: torch.full((n,), float("nan"), dtype=torch.float64, device=dev) for k, n in sizes}
+        torch.cuda.synchronize()
+        for _ in range(times):
+            ev.ctx.check(lib.pk_eval_cycle_dev_repeat(h, C.c_void_p(dx.data_ptr()), C.c_void_p(dlam.data_ptr()), C.c_double(float(sigma)),
+                                                      *[C.c_void_p(o[k].data_ptr()) for k, _ in sizes], None, count, 0, None))
+        ev.sync()
+        return [o[k].cpu().numpy() for k, _ in sizes]
+
+    for got in (run(1, 1), run(7, 1), run(20, 3)):
+        for a, b in zip(got, want):
+            assert np.array_equal(np.asarray(a).ravel(), np.asarray(b).ravel())
+    ev.set_cycle_graph(True)
+    try:
+        for got in (run(20, 2), run(5, 3), run(20, 1)):              # capture, replay, re-capture for another count
+            for a, b in zip(got, want):
+                assert np.array_equal(np.asarray(a).ravel(), np.asarray(b).ravel())
+    finally:
+        ev.set_cycle_graph(False)
+
+
 @pytest.mark.parametrize("case", [("planar_quadrotor", "radau", dict(mesh=301, num_point=6)),
                                   ("two_stage_rocket", "radau", dict(mesh=150, num_point=4)),
                                   ("brachistochrone", "lobatto", dict(mesh=1100, num_point=5)),
