@@ -943,6 +943,7 @@ int pk_eval_cycle_dev_repeat(pk_ctx* c, const double* d_x, const double* d_lam, 
                              double* d_g, double* d_jac, double* d_hess, void* stream, int count, int xchg, double* d_xgrad) {
   int rc = ready(c);
   if (rc) return rc;
+  if (count < 0 || (xchg && !d_xgrad)) return fail(c, 50, "pk_eval_cycle_dev_repeat: bad count, or xchg without the gradient buffer of the exchange");
   // pk_set_cycle_graph(1): the whole batch is ONE hipGraph of `count` kernel nodes, captured once and replayed while
   // pointers, sigma, stream and count stay the same -- the host then pays one graph launch per batch instead of `count`
   // kernel launches.  Not for sharded cycles (their exchange epoch is a kernel argument that advances with every launch).
