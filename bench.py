@@ -24,7 +24,7 @@ MEDIAN over the timed units of (unit / batches in it) / steps, the spread and th
 reported too.  On one GPU a batch is ONE call into the library (pk_eval_cycle_dev_repeat): it enqueues the ``steps`` launches
 from C, or replays them as one hipGraph of ``steps`` kernel nodes -- both forms are timed on a short stretch and the faster
 one on this box carries the region (``timing.batch_launch``; under a profiler that makes launches expensive it is the
-graph).
+graph; POCKIT_AMD_BENCH_GRAPH=0 / 1 forces plain launches / the graph).
 
 One JSON line is printed by rank 0 (see the repository prompt for the contract), carrying ``roofline`` for the
 dominant kernel (per-dispatch HIP events on the launch stream) and ``cpu_baseline`` (the oracle = CPU restatement of
