@@ -36,7 +36,13 @@ def _intervals_per_wave(plan, override=None, shards=1):
     if env:
         return int(env)
     n_int = sum(pp.layout.N for pp in plan.phase_plans)
-    return max(1, math.ceil(n_int / (TARGET_TILES * max(1, int(shards)))))      # (a shard holds 1 / shards of the tiles)
+    # ... but never fewer than ~16 nodes per wave: on small meshes (where the rule above says 1) a wave of 6-8 nodes pays
+    # its fixed work -- tile record, table staging, one streaming iteration per segment -- for a quarter of the entries.
+    # tools/ipw_small_sweep.sh: quadrotor 100 x 6 4.79 -> 4.14 us per cycle, humanoid 100 x 8 10.7 -> 8.2, rocket
+    # 2 x 100 x 4 4.95 -> 4.5, brachistochrone 200 x 8 4.30 -> 4.26 (profiles/r02_g_ipw_small.txt).
+    ks = np.concatenate([np.asarray(pp.layout.K, dtype=np.int64) for pp in plan.phase_plans]) if plan.phase_plans else np.array([16])
+    floor = max(1, math.ceil(16 / max(1, int(np.median(ks)))))
+    return max(floor, math.ceil(n_int / (TARGET_TILES * max(1, int(shards)))))   # (a shard holds 1 / shards of the tiles)
 
 
 def magic_number(d: int) -> int:
