@@ -20,12 +20,11 @@ from . import hipbuild, runtime
 from .codegen import ModelSource
 from .transcription import SystemPlan
 
-TARGET_TILES = int(os.environ.get("POCKIT_AMD_TARGET_TILES", "384"))
+N_CU = 256      # compute units of an MI355X (one workgroup of the cycle per CU is the sweet spot, see _intervals_per_wave)
 
 
 def _intervals_per_wave(plan, override=None, shards=1):
-    """Intervals per wavefront: as few as keeps ~TARGET_TILES tiles (x 3 wave roles in the single-launch
-    cycle) in flight, up to 64 nodes per wave (Layout.tiles caps it).  Measured on MI355X with pk_cycle
+    """Intervals per wavefront, up to 64 nodes per wave (Layout.tiles caps it).  Measured on MI355X with pk_cycle
     (tools/ipw_sweep.sh): at 12k nodes the cycle is bound by the number of vector-memory
     instructions a CU has to issue and by the time the dispatcher needs to start the waves, so fuller waves
     (18-42 nodes: 126-133k cycles/s) beat many small ones (12 nodes: 114k, 6 nodes: 81k) as long as every CU
@@ -35,14 +34,37 @@ def _intervals_per_wave(plan, override=None, shards=1):
     env = os.environ.get("POCKIT_AMD_IPW")
     if env:
         return int(env)
-    n_int = sum(pp.layout.N for pp in plan.phase_plans)
-    # ... but never fewer than ~16 nodes per wave: on small meshes (where the rule above says 1) a wave of 6-8 nodes pays
-    # its fixed work -- tile record, table staging, one streaming iteration per segment -- for a quarter of the entries.
-    # tools/ipw_small_sweep.sh: quadrotor 100 x 6 4.79 -> 4.14 us per cycle, humanoid 100 x 8 10.7 -> 8.2, rocket
-    # 2 x 100 x 4 4.95 -> 4.5, brachistochrone 200 x 8 4.30 -> 4.26 (profiles/r02_g_ipw_small.txt).
-    ks = np.concatenate([np.asarray(pp.layout.K, dtype=np.int64) for pp in plan.phase_plans]) if plan.phase_plans else np.array([16])
-    floor = max(1, math.ceil(16 / max(1, int(np.median(ks)))))
-    return max(floor, math.ceil(n_int / (TARGET_TILES * max(1, int(shards)))))   # (a shard holds 1 / shards of the tiles)
+    # Candidates from ~16 nodes per wave (on small meshes a wave of 6-8 nodes pays its fixed work -- tile record, table
+    # staging, one streaming iteration per segment -- for a quarter of the entries: tools/ipw_small_sweep.sh, humanoid
+    # 100 x 8 10.7 -> 8.2 us per cycle, quadrotor 100 x 6 4.79 -> 4.14) up to full waves; the choice minimizes the work of
+    # the busiest CU.  A launch is as slow as its most loaded CU: with 303 workgroups on 256 CUs 47 CUs hold two and the
+    # launch takes as long as with 504 (tools/mid_size_sweep.sh: quadrotor 3000 x 6 with 380 tiles 6.09 us, with 304 tiles
+    # 5.21 us).  Cost of a candidate = workgroups per CU x (intervals per wave [x 1.5 where one wave does the Jacobian and
+    # the values] + 4 for a workgroup's fixed work); ties go to the fuller waves.  The model reproduces the optimum of the
+    # sweeps at 100 ... 10 000 intervals (profiles/r02_g_ipw_small.txt, r02_g_mid_size.txt, r02_z2_tile_sweep.txt).
+    shards = max(1, int(shards))
+    best = None
+    caps = []
+    for pp in plan.phase_plans:
+        lay = pp.layout
+        kmed = max(1, int(np.median(np.asarray(lay.K, dtype=np.int64))))
+        nodes = kmed if lay.scheme == "lgr" else max(kmed - 1, 1)
+        caps.append((int(lay.N), max(1, (runtime.WAVE if lay.scheme == "lgr" else runtime.WAVE - 1) // nodes), kmed))
+    if not caps:
+        return 1
+    lo = max(1, math.ceil(16 / max(1, int(np.median([k for _, _, k in caps])))))
+    hi = max(lo, max(c for _, c, _ in caps))
+    for ipw in range(lo, hi + 1):
+        tiles = 0
+        for n_p, cap, _ in caps:
+            t = math.ceil(max(n_p / shards - 1, 0) / min(ipw, cap)) + 1        # (the first interval is a kind of its own)
+            tiles += -(-t // runtime.WAVES_PER_BLOCK) * runtime.WAVES_PER_BLOCK
+        roles = 3 if tiles <= 1024 else 2          # (pk_set_problem: the x-part is split into two roles up to 1024 tiles)
+        per_cu = math.ceil((roles * tiles // runtime.WAVES_PER_BLOCK + 3) / N_CU)
+        cost = per_cu * (ipw * (1.0 if roles == 3 else 1.5) + 4.0)      # (+4: a workgroup's fixed work, in intervals)
+        if best is None or cost <= best[0]:
+            best = (cost, ipw)
+    return best[1]
 
 
 def magic_number(d: int) -> int:
