@@ -1,3 +1,5 @@
+#!/bin/bash
+# GPU box: intervals per wave 1 ... 8 on small meshes (50 ... 400 intervals) of the benchmark models: us per cycle.
 for wl in "brachistochrone:200" "planar_quadrotor:100" "planar_quadrotor:400" "humanoid_wbc:100" "humanoid_wbc:200" "two_stage_rocket:100" "brachistochrone:50"; do
   IFS=: read name iv <<< "$wl"
   for ipw in 1 2 3 4 6 8; do
