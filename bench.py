@@ -138,8 +138,12 @@ def end_to_end(system, guess, warm=20, timed=100):
     ev = system.evaluator
     names = ("objective", "gradient", "constraints", "jacobian", "hessian")
     out = {}
-    for mode in ("fresh_arrays", "zero_copy_views"):
+    modes = ["fresh_arrays", "zero_copy_views"]
+    if ev.src.compact:
+        modes.append("fresh_arrays_compact_hessian")      # the same five callbacks for a solver handed the compact H structure
+    for mode in modes:
         ev.zero_copy = mode == "zero_copy_views"
+        system.set_hessian_layout("compact" if mode.endswith("compact_hessian") else "reference")
         rows = []
         for k in range(warm + timed):
             xk = xs[k % len(xs)]
@@ -161,6 +165,10 @@ def end_to_end(system, guess, warm=20, timed=100):
                      "per_callback_ms": {nm: med[i] * 1e3 for i, nm in enumerate(names)},
                      "min_ms_per_cycle": min(r[5] for r in rows) * 1e3, "max_ms_per_cycle": max(r[5] for r in rows) * 1e3}
     ev.zero_copy = False
+    system.set_hessian_layout("reference")
+    if "fresh_arrays_compact_hessian" in out:
+        out["fresh_arrays_compact_hessian"]["hessian_values"] = int(system.plan.nnz_Hc)
+        out["fresh_arrays_compact_hessian"]["hessian_values_reference_layout"] = int(system.plan.nnz_H)
     # all five outputs from ONE call when the caller has lambda at hand (Evaluator.cycle: one pk_cycle launch, five copies
     # into pinned arrays of the caller's own, one synchronization) -- not what IPOPT's call order allows, shown beside it
     rows = []
@@ -176,7 +184,9 @@ def end_to_end(system, guess, warm=20, timed=100):
     out["what"] = ("objective, gradient, constraints, jacobian, hessian of System on a new x per cycle, NumPy arrays in "
                    "and out; fresh_arrays: every callback returns an array the caller owns (the reference's semantics; "
                    "pinned memory the DMA wrote directly), zero_copy_views: views of the context's pinned buffers "
-                   "(what the IPOPT adapter enables, cyipopt copies at once)")
+                   "(what the IPOPT adapter enables, cyipopt copies at once); fresh_arrays_compact_hessian: the same with "
+                   "System.set_hessian_layout('compact') -- one Hessian value per distinct position of a node (SURVEY 8(f) rank "
+                   "1), an optional mode with fewer bytes over PCIe, not the headline")
     return out
 
 

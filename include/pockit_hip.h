@@ -131,6 +131,10 @@ int pk_eval_cycle(pk_ctx* ctx, const double* x, const double* lambda, double sig
  *                  always, grad f and J on first request (a line search's rejected trial points never ask);
  *                  host_direct 1: the kernels store into the pinned host targets themselves (no DMA; A/B switch)
  *   pk_invalidate_x         forget the prepared x (the context's buffers were used by another entry point) */
+/* the compact Hessian layout (pk_eval_hessc: one value per distinct position of a node) on the x of the last pk_prepare_x,
+ * multipliers given or staged by pk_stage_lambda; vals_pinned = 1: `vals` is pk_host_alloc memory the DMA writes directly.
+ * What SystemBase.hessian (systembase.py:820-835) becomes for a solver that was handed the compact structure. */
+int pk_eval_hessc_prepared(pk_ctx* ctx, const double* lambda, double sigma, double* vals, int vals_pinned);
 int pk_same_x(pk_ctx* ctx, const double* x);
 int pk_prepare_x(pk_ctx* ctx, const double* x);
 int pk_fetch(pk_ctx* ctx, int what, double* out);

@@ -115,6 +115,7 @@ struct pk_ctx {
   double* d_db = nullptr;
   int64_t* d_lb = nullptr;
   // work buffers
+  double* h_Hc = nullptr;      // pinned landing place of the compact Hessian (pk_eval_hessc_prepared), allocated on first use
   double *d_x = nullptr, *d_lam = nullptr, *d_f = nullptr, *d_grad = nullptr, *d_g = nullptr, *d_J = nullptr,
          *d_H = nullptr, *d_I = nullptr, *d_partial = nullptr, *d_partial2 = nullptr;
   std::vector<PkPhase> h_phases;
@@ -183,6 +184,7 @@ void free_problem(pk_ctx* c) {
   for (auto& m : c->csr) { release(m.d_seg); release(m.d_perm); release(m.d_vals); m.n_unique = m.n_triplets = 0; }
   release(c->d_ib); release(c->d_db); release(c->d_lb);
   c->d_g = nullptr;               // (interior pointer of the d_grad allocation)
+  if (c->h_Hc) { (void)hipHostFree(c->h_Hc); c->h_Hc = nullptr; }
   release(c->d_x); release(c->d_lam); release(c->d_f); release(c->d_grad); release(c->d_J);
   release(c->d_H); release(c->d_I); release(c->d_partial); release(c->d_partial2);
   release(c->d_cpart); release(c->d_cpart2);
@@ -1220,6 +1222,33 @@ int pk_eval_hess_prepared(pk_ctx* c, const double* lambda, double sigma, double*
   if ((rc = enqueue_result_copy(c, 4))) return rc;
   PK_HIP(c, hipEventSynchronize(c->ev_out[4]));
   if (vals && vals != c->landed[4]) std::memcpy(vals, c->landed[4], sizeof(double) * (size_t)c->nnz_H);
+  return 0;
+}
+
+// The compact Hessian layout on the x of the last pk_prepare_x: what a solver that was handed the compact structure calls
+// instead of pk_eval_hess_prepared -- 6 ... 10 x fewer values over PCIe.  lambda == NULL: the
+// multipliers staged by pk_stage_lambda.  vals_pinned = 1: `vals` is device-visible host memory (pk_host_alloc) and the
+// DMA writes it directly; 0: the values land in a pinned buffer of the context and are copied on.
+int pk_eval_hessc_prepared(pk_ctx* c, const double* lambda, double sigma, double* vals, int vals_pinned) {
+  int rc = ready(c);
+  if (rc) return rc;
+  if (!vals) return fail(c, 60, "null host buffer");
+  if (!lambda && !c->lam_staged) return fail(c, 60, "null host buffer (no multipliers staged either)");
+  if (!c->x_valid) return fail(c, 64, "pk_eval_hessc_prepared: no prepared x (pk_prepare_x)");
+  if (c->nnz_Hc <= 0) return fail(c, 51, "pk_eval_hessc: no compact Hessian layout was supplied to pk_set_problem");
+  PK_HIP(c, hipSetDevice(c->device));
+  if (lambda && (rc = stage_upload(c, c->h_lams, c->ev_lams, c->lambuf, lambda, c->d_lam, (size_t)c->m, nullptr))) return rc;
+  c->lam_staged = false;
+  if ((rc = pk_eval_hessc_dev(c, c->d_x, c->d_lam, sigma, c->d_Hc, nullptr))) return rc;
+  const size_t bytes = sizeof(double) * (size_t)c->nnz_Hc;
+  double* dst = vals;
+  if (!vals_pinned) {
+    if (!c->h_Hc) PK_HIP(c, hipHostMalloc((void**)&c->h_Hc, bytes, hipHostMallocDefault));
+    dst = c->h_Hc;
+  }
+  PK_HIP(c, hipMemcpyAsync(dst, c->d_Hc, bytes, hipMemcpyDeviceToHost, c->stream));
+  PK_HIP(c, hipStreamSynchronize(c->stream));       // (every earlier copy of this iterate has been waited for by its callback)
+  if (!vals_pinned) std::memcpy(vals, c->h_Hc, bytes);
   return 0;
 }
 

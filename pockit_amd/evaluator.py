@@ -227,7 +227,7 @@ class Evaluator:
         md.prepass_hess = int(plan.hess.needs_I)
         self._code = code
         self._views = {}
-        self._ring, self._own, self._handed = None, {}, set()
+        self._ring, self._ring_hc, self._own, self._handed = None, None, {}, set()
         self.zero_copy = False   # True: callbacks return views of pinned buffers (set by the IPOPT adapter)
         self.ctx.check(lib.pk_load_model(h, code, len(code), C.byref(md)))
         self.model_desc = md
@@ -237,7 +237,7 @@ class Evaluator:
         plan, lib, h = self.plan, self.ctx.lib, self.ctx.handle
         self.tables = tb
         self._views = {}
-        self._ring, self._own, self._handed = None, {}, set()
+        self._ring, self._ring_hc, self._own, self._handed = None, None, {}, set()
         pd = runtime.ProblemDesc()
         pd.n, pd.m, pd.n_sys, pd.n_s, pd.l_s = plan.n, plan.m, plan.n_sys, plan.n_s, plan.l_s
         pd.n_phase, pd.n_tiles, pd.n_kinds = len(tb.phases), len(tb.tiles), len(tb.kinds)
@@ -426,12 +426,21 @@ class Evaluator:
         """Values of the compact (coalesced) Hessian layout ``plan.hessc_row/col``."""
         if not self.src.compact:
             raise NotImplementedError("compact Hessian layout is not available for this model")
-        x = self._x(x)
-        self._invalidate_x()        # the context's x / result buffers are about to hold another iterate
         lam = np.ascontiguousarray(lagrange, dtype=np.float64)
-        out = np.empty(self.plan.nnz_Hc)
-        self.ctx.check(self.ctx.lib.pk_eval_hessc(self.ctx.handle, runtime.as_dp(x), runtime.as_dp(lam),
-                                                  float(obj_factor), runtime.as_dp(out)))
+        if lam.shape != (self.plan.m,):
+            raise ValueError(f"lagrange must have shape ({self.plan.m},)")
+        # the prepared-x protocol, like hessian(): the multipliers go up while x is compared, the x of the iterate is
+        # already on the device (objective ... jacobian ran on it), the values come back by DMA into a pinned array
+        lib, h = self.ctx.lib, self.ctx.handle
+        self.ctx.check(lib.pk_stage_lambda(h, runtime.as_dp(lam)))
+        self._prepare(x)
+        if self._ring_hc is None:
+            self._ring_hc = runtime.PinnedRing(self.plan.nnz_Hc)
+        out = None if self.zero_copy else self._ring_hc.take()
+        pinned = out is not None
+        if out is None:
+            out = np.empty(self.plan.nnz_Hc)
+        self.ctx.check(lib.pk_eval_hessc_prepared(h, None, float(obj_factor), runtime.as_dp(out), int(pinned)))
         return out
 
     def mesh_error(self, x):

@@ -65,7 +65,7 @@ KERNELS = ["pk_int", "pk_fin", "pk_g", "pk_grad", "pk_jac", "pk_hess", "pk_xall"
 EXPORTS = ["pk_create", "pk_destroy", "pk_last_error", "pk_device_count", "pk_load_model", "pk_set_problem",
            "pk_get_structure", "pk_eval_f", "pk_eval_grad", "pk_eval_g", "pk_eval_jac", "pk_eval_hess",
            "pk_eval_f_dev", "pk_eval_grad_dev", "pk_eval_g_dev", "pk_eval_jac_dev", "pk_eval_hess_dev",
-           "pk_eval_cycle_dev", "pk_eval_cycle_dev_repeat", "pk_sync", "pk_profile", "pk_profile_read", "pk_kernel_name",
+           "pk_eval_cycle_dev", "pk_eval_cycle_dev_repeat", "pk_eval_hessc_prepared", "pk_sync", "pk_profile", "pk_profile_read", "pk_kernel_name",
            "pk_set_shard", "pk_eval_integrals_dev", "pk_eval_f_from_integrals_dev", "pk_eval_cycle",
            "pk_prepare_x", "pk_fetch", "pk_eval_hess_prepared", "pk_host_buffer", "pk_eval_hessc", "pk_eval_hessc_dev",
            "pk_set_mesh_error_tables", "pk_eval_mesh_error", "pk_eval_mesh_error_dev", "pk_set_cycle_graph", "pk_profile_sampling",
@@ -176,6 +176,7 @@ def load_library():
     lib.pk_eval_jac_dev.argtypes = [vp, vp, vp, vp]
     lib.pk_eval_hess_dev.argtypes = [vp, vp, vp, C.c_double, vp, vp]
     lib.pk_eval_cycle_dev.argtypes = [vp, vp, vp, C.c_double, vp, vp, vp, vp, vp, vp]
+    lib.pk_eval_hessc_prepared.argtypes = [vp, dp, C.c_double, dp, C.c_int]
     lib.pk_eval_cycle_dev_repeat.argtypes = [vp, vp, vp, C.c_double, vp, vp, vp, vp, vp, vp, C.c_int, C.c_int, vp]
     lib.pk_sync.argtypes = [vp, vp]
     lib.pk_set_shard.argtypes = [vp, C.c_int, C.c_int, vp]

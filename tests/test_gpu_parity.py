@@ -522,6 +522,48 @@ def test_compact_hessian_equals_coalesced_oracle(case):
     close(system.hessian(x, lam, sigma), ref.hessian(x, lam, sigma), what="reference layout still served")
 
 
+def test_compact_hessian_rides_on_the_prepared_x():
+    """hessian() in the compact layout follows the prepared-x protocol (x of the iterate already on the device, multipliers
+    staged, values by DMA into a pinned array of the caller's): interleaved with the other callbacks on two iterates it
+    returns exactly what the one-shot entry point pk_eval_hessc computes, in arrays that stay valid."""
+    import ctypes as C
+
+    system, _, guess = models.planar_quadrotor(_ns("radau", "pockit_amd"), mesh=60, num_point=6)
+    x1, lam, sigma = models.bench_inputs(system, guess)
+    x2 = x1 * (1 + 1e-3)
+    ev = system.evaluator
+    lib, h = ev.ctx.lib, ev.ctx.handle
+
+    def one_shot(x, lam_, sg):
+        out = np.empty(system.plan.nnz_Hc)
+        ev.ctx.check(lib.pk_eval_hessc(h, x.ctypes.data_as(C.POINTER(C.c_double)), lam_.ctypes.data_as(C.POINTER(C.c_double)),
+                                       C.c_double(sg), out.ctypes.data_as(C.POINTER(C.c_double))))
+        ev._invalidate_x()
+        return out
+
+    want = {(k, sg): one_shot(x, lam, sg) for k, x in ((1, x1), (2, x2)) for sg in (sigma, 0.5)}
+    system.set_hessian_layout("compact")
+    try:
+        f1 = system.objective(x1)
+        a = system.hessian(x1, lam, sigma)
+        g1 = system.constraints(x1)
+        b = system.hessian(x1, lam, 0.5)
+        c = system.hessian(x2, lam, sigma)                      # a new x straight into the Hessian
+        j2 = system.jacobian(x2)
+        d = system.hessian(x2, lam, 0.5)
+        assert np.array_equal(a, want[(1, sigma)]) and np.array_equal(b, want[(1, 0.5)])
+        assert np.array_equal(c, want[(2, sigma)]) and np.array_equal(d, want[(2, 0.5)])
+        assert a is not b and not np.shares_memory(a, b)
+        ev.zero_copy = True
+        e = system.hessian(x1, lam, sigma)
+        assert np.array_equal(e, want[(1, sigma)]) and np.array_equal(a, want[(1, sigma)])
+    finally:
+        ev.zero_copy = False
+        system.set_hessian_layout("reference")
+    close(system.hessian(x1, lam, sigma), system.evaluator.hessian_direct(x1, lam, sigma), what="reference layout afterwards")
+    assert np.isfinite(f1) and np.all(np.isfinite(g1)) and np.all(np.isfinite(j2))
+
+
 # ---------------------------------------------------------------------------------------------------------
 # mesh error estimation on device + hp-refinement (SURVEY.md 8(f) ranks 2-3)
 ERR_TOLS = {"a": (1e-3, 1e-3), "b": (1e-7, 1e-6)}
