@@ -142,6 +142,28 @@ int pk_eval_hess_prepared(pk_ctx* ctx, const double* lambda /* NULL: staged */, 
 /* queue the upload of the next Hessian's multipliers and return (the x check then overlaps the DMA) */
 int pk_stage_lambda(pk_ctx* ctx, const double* lambda);
 int pk_set_result_targets(pk_ctx* ctx, double* f, double* grad, double* g, double* jac, double* hess);
+/* ONE call per callback of a host shim (what a cyipopt binding makes of the five methods it is handed, ipopt.py:41-53):
+ *   pk_callback_x     what = 0 objective (systembase.py:602), 1 gradient (:646), 2 constraints (:613), 3 jacobian (:676).
+ *                     If `x` is not the prepared iterate it becomes it (pk_prepare_x) and *fresh = 1; its results then land
+ *                     in `block`, pinned memory of the caller's laid out like the library's own buffers,
+ *                     [J (nnz_J) | grad f (n) | g (m)] (NULL: the context's buffers, pk_host_buffer) -- the pieces of J that
+ *                     change with x, grad f and g leave the device in ONE copy.  Then result `what` is waited for; f_out
+ *                     receives f for what = 0.
+ *   pk_callback_hess  SystemBase.hessian (systembase.py:820-835): stages the multipliers, prepares a new x as above, evaluates
+ *                     the Hessian of the Lagrangian into `hess` (pinned memory of the caller's or NULL = the context's
+ *                     buffer; compact = 1: the compact layout of pk_eval_hessc, `hess` required) and waits for it.
+ *   pk_set_jac_constant_runs   runs [start, stop) of the Jacobian values that do not depend on x (the +-1 translation entries
+ *                     of phasebase.py:1071-1081 and constant boundary items: 19 % of J at 12k quadrotor nodes): the copy to the
+ *                     host skips them from then on; every landing array must have been filled once with
+ *   pk_fill_jac_constants      (the context's own buffer is filled by pk_set_jac_constant_runs itself).
+ *   pk_set_host_option         A/B switches (default): "spin_wait" (1), "lambda_direct" (1), "chunk_upload" (1), "kernel_upload"
+ *                     (1), "kernel_download" (8: up to that many MiB per copy), "split_copy" (1), "speculative_hess" (1) -- see pk_runtime.cpp. */
+int pk_callback_x(pk_ctx* ctx, int what, const double* x, double* block, double* f_out, int* fresh);
+int pk_callback_hess(pk_ctx* ctx, const double* x, const double* lambda, double sigma, double* block, double* hess,
+                     int compact, int* fresh);
+int pk_set_jac_constant_runs(pk_ctx* ctx, int n_runs, const int64_t* start, const int64_t* stop);
+int pk_fill_jac_constants(pk_ctx* ctx, double* jac /* nnz_J */);
+int pk_set_host_option(pk_ctx* ctx, const char* name, int value);
 int pk_result_location(pk_ctx* ctx, int what /* 0..4 */, double** ptr);
 int pk_set_host_mode(pk_ctx* ctx, int prefetch, int host_direct);
 int pk_invalidate_x(pk_ctx* ctx);

@@ -241,6 +241,10 @@ __device__ __forceinline__ void handoff_put(unsigned long long* slot, double v) 
   if (b == PK_EMPTY) b = 0x7FF8000000000000ull;     // (a NaN either way)
   __hip_atomic_store(slot, b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
+// f may land in pinned host memory that the host polls (pk_runtime.cpp, wait_result): one system-scope store
+__device__ __forceinline__ void put_f(double* p, double v) {
+  __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
 __device__ __forceinline__ unsigned long long handoff_peek(unsigned long long* slot) {
   return __hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
@@ -1943,7 +1947,7 @@ __device__ __forceinline__ void fin_body(const PkArgs& A) {
   __syncthreads();
   if (threadIdx.x != 0) return;
   const PkSys sy{A.x + A.l_s, A.Ibuf, A.sigma, A.lam};
-  if (A.flags & 1) A.o_f[0] = Gen::sys_objective(sy);
+  if (A.flags & 1) put_f(A.o_f, Gen::sys_objective(sy));
   if (A.flags & 16) {
     for (int k = 0; k < PK_NPHASE; ++k)
       for (int r = 0; r < Gen::gr_nr(k); ++r) gsh[A.ib[A.ph[k].red_off + r]] += tot[k * PK_NRED + r];
@@ -2106,7 +2110,7 @@ __device__ __forceinline__ void fin_handoff(const PkArgs& A) {
 #else
   constexpr bool xchg = false;                            // (code objects of single-GPU evaluators carry no exchange code)
 #endif
-  if (t == 0 && !xchg) A.o_f[0] = Gen::sys_objective(sy); // systembase.py:592-605
+  if (t == 0 && !xchg) put_f(A.o_f, Gen::sys_objective(sy)); // systembase.py:592-605
   if (t == 64) {
 #pragma unroll
     for (int i = 0; i < PK_NS; ++i) gsh[i] = 0.0;
@@ -2140,7 +2144,7 @@ __device__ __forceinline__ void fin_handoff(const PkArgs& A) {
   for (int z = t; z < A.n_gz; z += PK_BLOCK) gout[z == t ? gz0 : A.ib[A.gz_off + z]] = xtotal[PK_NI + z];
   if (t == 0) {
     const PkSys syt{ssh, xtotal, A.sigma, A.lam};
-    A.o_f[0] = Gen::sys_objective(syt);                   // f on the global integrals, on every rank
+    put_f(A.o_f, Gen::sys_objective(syt));                // f on the global integrals, on every rank
   }
 }
 
@@ -2163,7 +2167,7 @@ __device__ __forceinline__ void kernel_xchg(const PkArgs& A) {
   }
   if (t == 0 && (A.flags & 1)) {
     const PkSys sy{A.x + A.l_s, total, A.sigma, A.lam};
-    A.o_f[0] = Gen::sys_objective(sy);                  // systembase.py:592-605, on the global integrals
+    put_f(A.o_f, Gen::sys_objective(sy));               // systembase.py:592-605, on the global integrals
   }
 }
 

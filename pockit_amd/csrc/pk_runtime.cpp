@@ -134,10 +134,43 @@ struct pk_ctx {
   bool target_visible[5] = {true, true, true, true, true};             // the device can store into target[k] itself
   double* landed[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};   // where result k of the current iterate went
   hipEvent_t ev_out[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
-  bool enq[5] = {false, false, false, false, false};                   // copy of result k is enqueued / done
+  bool enq[5] = {false, false, false, false, false};                   // copy of result k is enqueued
+  bool done[5] = {false, false, false, false, false};                  // ... and known to have landed
   bool stored_direct[5] = {false, false, false, false, false};         // the kernel stored result k into its landing place
   int prefetch = 1;            // 1: every x-only result is copied out right behind the kernel; 0: on first request
   int host_direct = 0;         // 1: the kernels store into the (pinned, device-visible) host targets themselves
+  // Host-shim tuning (pk_set_host_option; defaults = what measured fastest on MI355X, tools/dma_probe.cpp):
+  int spin_wait = 1;           // results are awaited by polling (the event's state / f's own pinned word), not hipEventSynchronize
+  int lambda_direct = 1;       // the Hessian kernel of the prepared protocol reads the multipliers from the pinned staging
+                               // buffer itself (one pass over PCIe inside the kernel) instead of an upload in front of it;
+                               // applied up to 2 MB of multipliers (12k nodes: -8 us; at 3.2 MB the chunk-pipelined upload
+                               // wins by 16 us: the staging memcpy then overlaps the link)
+  int chunk_upload = 1;        // staging of large inputs is pipelined with their upload in a few chunks
+  int kernel_upload = 1;       // x (and lambda) go up through a copy kernel on the compute queue instead of the DMA engine: the
+                               // kernel behind it then starts without a cross-engine hand-off (~10 us on the path to f)
+  int kernel_download = 8;     // results of up to this many MiB per piece come down through a copy kernel instead of the DMA
+                               // engine (0: never): no cross-engine hand-off behind the kernel that produced them (~10 us per
+                               // copy), but 51 instead of 56 GB/s on the link -- the DMA engine wins from ~5 MB on
+  int split_copy = 1;          // grad f | g leave in a copy of their own in front of J (+1 DMA), with an event behind it: the
+                               // gradient and constraints callbacks return while J is still on the link, and the bitwise
+                               // compares of x they and the Jacobian callback start with are hidden behind that copy
+  int speculative_hess = 1;    // pk_callback_hess launches on the prepared x BEFORE comparing x with it (the compare then runs
+                               // while the GPU works; a different x -- rare -- discards the launch and starts over)
+  bool target_pinned[5] = {false, false, false, false, false};   // target[k] is pinned memory by contract (landing blocks)
+  // reuse guard of the staging buffers without events: every enqueue takes a sequence number; an idle stream seen by the host
+  // (wait_result) retires all numbers issued so far
+  uint64_t op_seq = 0, idle_seq = 0;
+  uint64_t xs_seq[2] = {0, 0}, lams_seq[2] = {0, 0};
+  hipEvent_t ev_early = nullptr;     // behind the grad f | g copy of the current iterate (split_copy)
+  bool early_valid = false;
+  const double* lam_src = nullptr;   // where the staged multipliers are read from (d_lam, or the pinned staging buffer)
+  int ev_of[5] = {0, 1, 2, 3, 4};    // the event that covers result k of the current iterate (one event per batch of copies)
+  // Pieces [start, stop) of the Jacobian values that CHANGE with x.  Default: everything.  pk_set_jac_constant_runs takes
+  // x-independent runs (the +-1 translation entries of phasebase.py:1071-1081 are 19 % of J at 12k nodes) out of the
+  // per-iterate copy: they are put into a landing array once (pk_fill_jac_constants) and never cross PCIe again.
+  std::vector<std::pair<int64_t, int64_t>> jruns, jconst;
+  bool target_filled = false;  // the caller's J landing array (target[3]) already holds the constant runs (pk_callback_x blocks)
+  bool jac_filled = false;     // ... and so does the landing place of the CURRENT iterate: its copy skips them
   // profiling
   bool profiling = false;
   std::vector<EventPair> pending[K_COUNT];
@@ -183,9 +216,11 @@ void free_problem(pk_ctx* c) {
   release(c->d_trace);
   for (auto& m : c->csr) { release(m.d_seg); release(m.d_perm); release(m.d_vals); m.n_unique = m.n_triplets = 0; }
   release(c->d_ib); release(c->d_db); release(c->d_lb);
-  c->d_g = nullptr;               // (interior pointer of the d_grad allocation)
+  c->d_g = c->d_grad = nullptr;   // (interior pointers of the d_J allocation: one block [J | grad f | g])
+  c->jruns.clear(); c->jconst.clear();
+  c->lam_src = nullptr;
   if (c->h_Hc) { (void)hipHostFree(c->h_Hc); c->h_Hc = nullptr; }
-  release(c->d_x); release(c->d_lam); release(c->d_f); release(c->d_grad); release(c->d_J);
+  release(c->d_x); release(c->d_lam); release(c->d_f); release(c->d_J);
   release(c->d_H); release(c->d_I); release(c->d_partial); release(c->d_partial2);
   release(c->d_cpart); release(c->d_cpart2);
   for (int b = 0; b < 2; ++b) {
@@ -195,11 +230,14 @@ void free_problem(pk_ctx* c) {
     if (c->ev_lams[b]) (void)hipEventDestroy(c->ev_lams[b]);
     c->h_xs[b] = c->h_lams[b] = nullptr;
     c->ev_xs[b] = c->ev_lams[b] = nullptr;
+    c->xs_seq[b] = c->lams_seq[b] = 0;
   }
+  if (c->ev_early) { (void)hipEventDestroy(c->ev_early); c->ev_early = nullptr; }
+  c->early_valid = false;
   c->h_x = nullptr;
   c->x_valid = false;
   for (int k = 0; k < 5; ++k) {
-    if (c->h_out[k] && k != 2) (void)hipHostFree(c->h_out[k]);      // (h_out[2] lives inside h_out[1]'s block)
+    if (c->h_out[k] && k != 1 && k != 2) (void)hipHostFree(c->h_out[k]);      // (h_out[1], h_out[2] live inside h_out[3]'s block)
     if (c->ev_out[k]) (void)hipEventDestroy(c->ev_out[k]);
     c->h_out[k] = c->target[k] = c->landed[k] = nullptr;
     c->ev_out[k] = nullptr;
@@ -352,7 +390,37 @@ hipStream_t pick(pk_ctx* c, void* stream) { return stream ? (hipStream_t)stream 
 }  // namespace
 
 // ---- helpers of the host shim (the "new x" protocol further down)
+// Copy kernel of the host shim: n doubles between pinned host memory and device memory, 16 bytes per lane.  src and dst
+// are congruent modulo 16 bytes (the caller checks), so at most one leading and one trailing double go alone.
+__global__ void __launch_bounds__(256) pk_copy_kernel(const double* __restrict__ src, double* __restrict__ dst, size_t n) {
+  size_t head = ((uintptr_t)src >> 3) & 1;
+  if (head > n) head = n;
+  const size_t pairs = (n - head) >> 1;
+  const double2* __restrict__ s2 = reinterpret_cast<const double2*>(src + head);
+  double2* __restrict__ d2 = reinterpret_cast<double2*>(dst + head);
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < pairs; i += (size_t)gridDim.x * blockDim.x) d2[i] = s2[i];
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    if (head) dst[0] = src[0];
+    if (head + 2 * pairs < n) dst[n - 1] = src[n - 1];
+  }
+}
+
 namespace {
+
+// dst[0 .. n) = src[0 .. n) on the context's stream: the copy kernel when asked for and possible, else the DMA engine
+int copy_async(pk_ctx* c, double* dst, const double* src, size_t n, hipMemcpyKind kind, bool by_kernel) {
+  if (!n) return 0;
+  if (by_kernel && !(((uintptr_t)dst ^ (uintptr_t)src) & 8)) {
+    const size_t pairs = n / 2 + 1;
+    unsigned grid = (unsigned)((pairs + 255) / 256);
+    if (grid > 1024) grid = 1024;
+    hipLaunchKernelGGL(pk_copy_kernel, dim3(grid), dim3(256), 0, c->stream, src, dst, n);
+    PK_HIP(c, hipGetLastError());
+    return 0;
+  }
+  PK_HIP(c, hipMemcpyAsync(dst, src, sizeof(double) * n, kind, c->stream));
+  return 0;
+}
 
 size_t result_count(const pk_ctx* c, int what) {
   const size_t cnt[5] = {1, (size_t)c->n, (size_t)c->m, (size_t)c->nnz_J, (size_t)c->nnz_H};
@@ -364,40 +432,139 @@ double* device_result(pk_ctx* c, int what) {
   return src[what];
 }
 
-// queue the copy of result `what` of the current iterate (no-op when the kernels stored it into host memory themselves)
-// f (what = 0) never needs a copy: pk_fin stores its 8 bytes straight into the pinned landing place (a DMA of 8 bytes
-// costs 16 us on this link).  grad f and g are neighbours on the device; when their landing places are neighbours too
-// (the context's own buffers, or a combined block of the caller) ONE copy serves both.
-int enqueue_result_copy(pk_ctx* c, int what) {
-  if (c->enq[what]) return 0;
-  if (what == 1 || what == 2) {
-    const bool neighbours = c->landed[2] == c->landed[1] + c->n && !c->enq[1] && !c->enq[2];
-    if (neighbours && c->stored_direct[1] == c->stored_direct[2]) {
-      if (!c->stored_direct[1])
-        PK_HIP(c, hipMemcpyAsync(c->landed[1], c->d_grad, sizeof(double) * ((size_t)c->n + (size_t)c->m), hipMemcpyDeviceToHost,
-                                 c->stream));
-      PK_HIP(c, hipEventRecord(c->ev_out[1], c->stream));
-      PK_HIP(c, hipEventRecord(c->ev_out[2], c->stream));
-      c->enq[1] = c->enq[2] = true;
-      return 0;
+// Queue the copies of the results in `mask` (bit k: result k; 0 f, 1 grad f, 2 g, 3 J, 4 H) of the current iterate that are
+// not on their way yet, and -- unless results are awaited by polling the stream, see wait_result -- ONE event behind them.  J, grad f and g are neighbours on the device ([J | grad | g], one
+// allocation); where their landing places are neighbours in the same order (the context's own block, or one block of the
+// caller's) the pieces are merged: the changing part of J, grad f and g leave in one DMA.  The pieces of J that never
+// change (pk_set_jac_constant_runs) are not copied at all.  f needs no copy when the kernel stored it into its pinned
+// landing place itself (a DMA of 8 bytes costs as much as one of 100 KB).
+int enqueue_result_copies(pk_ctx* c, unsigned mask) {
+  struct Piece { const double* src; double* dst; size_t count; bool pinned; };
+  std::vector<Piece> pcs;
+  pcs.reserve(8);
+  int first = -1;
+  auto add = [&](const double* src, double* dst, size_t count, bool pinned) {
+    if (!count) return;
+    if (!pcs.empty() && pcs.back().src + pcs.back().count == src && pcs.back().dst + pcs.back().count == dst &&
+        pcs.back().pinned == pinned) {
+      pcs.back().count += count;
+      return;
+    }
+    pcs.push_back(Piece{src, dst, count, pinned});
+  };
+  // device order of the x-results is [J | grad f | g]: one piece when nothing is left out; split_copy sends grad f | g first
+  const int joined[5] = {0, 3, 1, 2, 4}, split[5] = {0, 1, 2, 3, 4};
+  const int* order = c->split_copy ? split : joined;
+  size_t early_pieces = 0;
+  bool early = false;
+  for (int o = 0; o < 5; ++o) {
+    const int k = order[o];
+    if (!((mask >> k) & 1u) || c->enq[k]) continue;
+    if (first < 0) first = k;
+    if (c->stored_direct[k]) continue;
+    const bool pinned = !c->target[k] || c->target_pinned[k];
+    if (k == 3 && c->jac_filled) {
+      for (const auto& r : c->jruns) add(c->d_J + r.first, c->landed[3] + r.first, (size_t)(r.second - r.first), pinned);
+    } else {
+      add(device_result(c, k), c->landed[k], result_count(c, k), pinned);
+    }
+    if (c->split_copy && (k == 1 || k == 2)) { early = true; early_pieces = pcs.size(); }
+  }
+  if (first < 0) return 0;
+  // an event behind grad f | g only when something (J) follows them in this batch: otherwise the stream's state tells
+  const bool want_early = early && c->spin_wait && ((mask >> 3) & 1u) && !c->enq[3] && !c->stored_direct[3] && pcs.size() > early_pieces;
+  int rc;
+  for (size_t i = 0; i < pcs.size(); ++i) {
+    const bool by_kernel = pcs[i].pinned && sizeof(double) * pcs[i].count <= ((size_t)c->kernel_download << 20);
+    if ((rc = copy_async(c, pcs[i].dst, pcs[i].src, pcs[i].count, hipMemcpyDeviceToHost, by_kernel))) return rc;
+    if (want_early && i + 1 == early_pieces) {
+      PK_HIP(c, hipEventRecord(c->ev_early, c->stream));
+      c->early_valid = true;
     }
   }
-  if (!c->stored_direct[what])
-    PK_HIP(c, hipMemcpyAsync(c->landed[what], device_result(c, what), sizeof(double) * result_count(c, what),
-                             hipMemcpyDeviceToHost, c->stream));
-  PK_HIP(c, hipEventRecord(c->ev_out[what], c->stream));
-  c->enq[what] = true;
+  ++c->op_seq;
+  if (!c->spin_wait) PK_HIP(c, hipEventRecord(c->ev_out[first], c->stream));      // (see wait_result)
+  for (int k = 0; k < 5; ++k)
+    if (((mask >> k) & 1u) && !c->enq[k]) { c->enq[k] = true; c->ev_of[k] = first; }
   return 0;
 }
 
-// stage `count` doubles in the next staging buffer of a double-buffered pair and queue their upload
-int stage_upload(pk_ctx* c, double* const bufs[2], hipEvent_t const evs[2], int& cur, const double* src, double* dst,
-                 size_t count, double** staged) {
+// Wait for result k of the current iterate.  Measured on MI355X (tools/dma_probe.cpp, profiles/r03_b_dma_probe.txt): a
+// hipEventRecord behind a copy plus hipEventSynchronize (or polling hipEventQuery) returns ~8 us after polling
+// hipStreamQuery alone does, and a word the kernel itself stores into pinned memory is seen ~4 us before its event.  So
+// (spin_wait, the default) no event is recorded for the results at all: f, which the finalize kernel stores into its
+// pinned landing place, is awaited on its own word (PK_EMPTY until the system-scope store lands), every copied result by
+// polling the stream -- the result copies are the last thing an iterate enqueues, and an idle stream means every result
+// enqueued so far has landed.
+int wait_result(pk_ctx* c, int k) {
+  if (c->done[k]) return 0;
+  if (k == 0 && c->stored_direct[0] && c->spin_wait) {
+    const volatile unsigned long long* word = (const volatile unsigned long long*)c->landed[0];
+    for (long spins = 1; *word == (unsigned long long)PK_EMPTY; ++spins) {
+      if ((spins & 0x3FFF) == 0) {          // now and then: has the stream finished (or failed) without storing f?
+        const uint64_t seen = c->op_seq;
+        const hipError_t e = hipStreamQuery(c->stream);
+        if (e == hipSuccess) {
+          c->idle_seq = seen;
+          if (*word == (unsigned long long)PK_EMPTY) return fail(c, 65, "the objective was not stored by its kernel");
+          break;
+        }
+        if (e != hipErrorNotReady) return fail(c, 100 + (int)e, "waiting for f: %s", hipGetErrorString(e));
+      }
+    }
+    c->done[0] = true;
+    return 0;
+  }
+  if (c->spin_wait) {
+    hipError_t e;
+    if ((k == 1 || k == 2) && c->early_valid) {       // grad f | g went ahead of J with an event of their own (split_copy)
+      while ((e = hipEventQuery(c->ev_early)) == hipErrorNotReady) { }
+      if (e != hipSuccess) return fail(c, 100 + (int)e, "hipEventQuery failed: %s", hipGetErrorString(e));
+      c->done[1] = c->done[2] = true;
+      return 0;
+    }
+    const uint64_t seen = c->op_seq;
+    while ((e = hipStreamQuery(c->stream)) == hipErrorNotReady) { }
+    if (e != hipSuccess) return fail(c, 100 + (int)e, "hipStreamQuery failed: %s", hipGetErrorString(e));
+    c->idle_seq = seen;
+    for (int j = 0; j < 5; ++j)
+      if (c->enq[j]) c->done[j] = true;
+    return 0;
+  }
+  PK_HIP(c, hipEventSynchronize(c->ev_out[c->ev_of[k]]));
+  c->done[k] = true;
+  return 0;
+}
+
+// stage `count` doubles in the next staging buffer of a double-buffered pair and queue their upload (dst == nullptr: stage
+// only -- the consumer kernel reads the pinned buffer itself).  Large inputs are staged and uploaded in a few chunks so that
+// the host's memcpy of chunk i + 1 runs while chunk i is on the link (4.8 MB: 202 -> 157 us; every extra DMA costs ~10 us,
+// so small inputs go in one piece).
+int stage_upload(pk_ctx* c, double* const bufs[2], hipEvent_t const evs[2], uint64_t seqs[2], int& cur, const double* src,
+                 double* dst, size_t count, double** staged) {
   cur ^= 1;
-  PK_HIP(c, hipEventSynchronize(evs[cur]));        // (the upload that used this buffer two iterates ago; long done)
-  std::memcpy(bufs[cur], src, sizeof(double) * count);
-  PK_HIP(c, hipMemcpyAsync(dst, bufs[cur], sizeof(double) * count, hipMemcpyHostToDevice, c->stream));
-  PK_HIP(c, hipEventRecord(evs[cur], c->stream));
+  // the buffer was last read two iterates ago -- by an upload whose completion an idle stream seen since then implies
+  // (polling waits), or whose event says so (event waits)
+  if (seqs[cur] > c->idle_seq) {
+    if (c->spin_wait) {
+      const uint64_t seen = c->op_seq;
+      PK_HIP(c, hipStreamSynchronize(c->stream));
+      c->idle_seq = seen;
+    } else {
+      PK_HIP(c, hipEventSynchronize(evs[cur]));
+    }
+  }
+  const size_t bytes = sizeof(double) * count;
+  const int chunks = (dst && c->chunk_upload && bytes >= ((size_t)2 << 20)) ? (c->kernel_upload ? 4 : 3) : 1;
+  const size_t step = ((count + chunks - 1) / chunks + 7) & ~(size_t)7;
+  int rc;
+  for (size_t lo = 0; lo < count; lo += step) {
+    const size_t len = count - lo < step ? count - lo : step;
+    std::memcpy(bufs[cur] + lo, src + lo, sizeof(double) * len);
+    if (dst && (rc = copy_async(c, dst + lo, bufs[cur] + lo, len, hipMemcpyHostToDevice, c->kernel_upload != 0))) return rc;
+  }
+  seqs[cur] = ++c->op_seq;          // (a consumer kernel reading the buffer itself is enqueued right behind: same number)
+  if (dst && !c->spin_wait) PK_HIP(c, hipEventRecord(evs[cur], c->stream));
   if (staged) *staged = bufs[cur];
   return 0;
 }
@@ -521,8 +688,10 @@ int pk_set_problem(pk_ctx* c, const pk_problem_desc* pd) {
     PK_HIP(c, hipMemset(*p, 0, sizeof(double) * (count ? count : 1)));
     return 0;
   };
+  // J, grad f and g of the host shim share ONE allocation in this order, on the device and in pinned host memory: the
+  // pieces of J that change with x, grad f and g then leave in one DMA (every extra DMA costs ~10 us on this link)
   if ((rc = dalloc(&c->d_x, c->n)) || (rc = dalloc(&c->d_lam, c->m)) || (rc = dalloc(&c->d_f, 1)) ||
-      (rc = dalloc(&c->d_grad, (size_t)c->n + (size_t)c->m)) || (rc = dalloc(&c->d_J, (size_t)c->nnz_J)) ||
+      (rc = dalloc(&c->d_J, (size_t)c->nnz_J + (size_t)c->n + (size_t)c->m)) ||
       (rc = dalloc(&c->d_H, (size_t)c->nnz_H)) || (rc = dalloc(&c->d_aux, (size_t)c->n_aux)) || (rc = dalloc(&c->d_Hc, (size_t)c->nnz_Hc)) || (rc = dalloc(&c->d_I, c->md.n_I)) ||
       (rc = dalloc(&c->d_partial, (2 * (size_t)c->n_tiles / PK_WAVES_PER_BLOCK + 2) * (size_t)c->md.nred)) ||
       (rc = dalloc(&c->d_partial2, (2 * (size_t)c->n_tiles / PK_WAVES_PER_BLOCK + 2) * (size_t)c->md.nred)))
@@ -542,7 +711,10 @@ int pk_set_problem(pk_ctx* c, const pk_problem_desc* pd) {
     if (c->has_big && needs_I)
       return fail(c, 34, "pk_set_problem: num_point > %d is not supported together with system functions nonlinear in the integrals", PK_WAVE);
   }
-  c->d_g = c->d_grad + c->n;      // grad f and g are neighbours (device and pinned host): ONE copy serves both (host shim)
+  c->d_grad = c->d_J + c->nnz_J;
+  c->d_g = c->d_grad + c->n;
+  c->jruns.assign(1, std::make_pair((int64_t)0, (int64_t)c->nnz_J));
+  c->jconst.clear();
   {   // hand-off slots of pk_cycle: one per x-kernel workgroup and reduction row, PK_EMPTY between launches
     const size_t slots = (2 * (size_t)c->n_tiles / PK_WAVES_PER_BLOCK + 2) * (size_t)c->md.nred;
     const std::vector<unsigned long long> empty(slots, (unsigned long long)PK_EMPTY);
@@ -557,11 +729,13 @@ int pk_set_problem(pk_ctx* c, const pk_problem_desc* pd) {
       PK_HIP(c, hipEventCreateWithFlags(&c->ev_xs[b], hipEventDisableTiming));
       PK_HIP(c, hipEventCreateWithFlags(&c->ev_lams[b], hipEventDisableTiming));
     }
-    for (int k = 0; k < 5; ++k) {
-      if (k == 2) c->h_out[2] = c->h_out[1] + cnt[1];        // (one block for grad f | g)
-      else PK_HIP(c, hipHostMalloc((void**)&c->h_out[k], sizeof(double) * ((k == 1 ? cnt[1] + cnt[2] : cnt[k]) + 1), hipHostMallocDefault));
-      PK_HIP(c, hipEventCreateWithFlags(&c->ev_out[k], hipEventDisableTiming));
-    }
+    PK_HIP(c, hipHostMalloc((void**)&c->h_out[0], sizeof(double) * 8, hipHostMallocDefault));
+    PK_HIP(c, hipHostMalloc((void**)&c->h_out[3], sizeof(double) * (cnt[3] + cnt[1] + cnt[2] + 1), hipHostMallocDefault));
+    PK_HIP(c, hipHostMalloc((void**)&c->h_out[4], sizeof(double) * (cnt[4] + 1), hipHostMallocDefault));
+    c->h_out[1] = c->h_out[3] + cnt[3];                      // (one block [J | grad f | g], like the device's)
+    c->h_out[2] = c->h_out[1] + cnt[1];
+    for (int k = 0; k < 5; ++k) PK_HIP(c, hipEventCreateWithFlags(&c->ev_out[k], hipEventDisableTiming));
+    PK_HIP(c, hipEventCreateWithFlags(&c->ev_early, hipEventDisableTiming));
     c->xbuf = c->lambuf = 0;
   }
   auto keep = [](std::vector<int32_t>& v, const int32_t* src, int64_t cnt) {
@@ -615,6 +789,7 @@ int pk_set_shard(pk_ctx* c, int secondary, int external_prepass, double* d_integ
   c->shard_flags = secondary ? F_SECONDARY : 0;
   c->external_prepass = external_prepass != 0;
   c->ext_I = d_integrals;
+  drop_cycle_graph(c);            // (a captured cycle holds the old flags / integral buffer)
   return 0;
 }
 
@@ -915,7 +1090,10 @@ int pk_eval_cycle_dev(pk_ctx* c, const double* d_x, const double* d_lam, double 
   // performs the reductions).  With pk_set_cycle_graph the two launches are replayed from a cached hipGraph as
   // long as the pointers, sigma and the stream stay the same (an NLP solver's steady state).
   const pk_ctx::CycleKey key{d_x, d_lam, d_f, d_grad, d_g, d_jac, d_hess, sigma, st};
-  const bool graph = c->use_graph && c->profile_mask == 0;
+  // (a sharded cycle is not replayed: its launch arguments -- exchange epoch, shard flags, shared-slot target, external
+  //  integral buffer -- change from cycle to cycle or with the pk_set_* calls below, which also drop a captured graph)
+  const bool graph = c->use_graph && c->profile_mask == 0 && !(c->xc_inline && c->xc_world > 1) && !c->shard_flags &&
+                     !c->external_prepass;
   if (graph && c->cyc_exec && c->cyc_key == key) {
     PK_HIP(c, hipGraphLaunch(c->cyc_exec, st));
     return 0;
@@ -1068,8 +1246,8 @@ int pk_eval_cycle(pk_ctx* c, const double* x, const double* lambda, double sigma
   if (!x || !lambda || !f || !grad || !g || !jac || !hess) return fail(c, 60, "null host buffer");
   PK_HIP(c, hipSetDevice(c->device));
   c->x_valid = false;
-  if ((rc = stage_upload(c, c->h_xs, c->ev_xs, c->xbuf, x, c->d_x, (size_t)c->n, nullptr))) return rc;
-  if ((rc = stage_upload(c, c->h_lams, c->ev_lams, c->lambuf, lambda, c->d_lam, (size_t)c->m, nullptr))) return rc;
+  if ((rc = stage_upload(c, c->h_xs, c->ev_xs, c->xs_seq, c->xbuf, x, c->d_x, (size_t)c->n, nullptr))) return rc;
+  if ((rc = stage_upload(c, c->h_lams, c->ev_lams, c->lams_seq, c->lambuf, lambda, c->d_lam, (size_t)c->m, nullptr))) return rc;
   if ((rc = pk_eval_cycle_dev(c, c->d_x, c->d_lam, sigma, c->d_f, c->d_grad, c->d_g, c->d_J, c->d_H, nullptr))) return rc;
   PK_HIP(c, hipMemcpyAsync(f, c->d_f, sizeof(double), hipMemcpyDeviceToHost, c->stream));
   PK_HIP(c, hipMemcpyAsync(grad, c->d_grad, sizeof(double) * (size_t)c->n, hipMemcpyDeviceToHost, c->stream));
@@ -1105,8 +1283,10 @@ int pk_set_result_targets(pk_ctx* c, double* f, double* grad, double* g, double*
   int rc = ready(c);
   if (rc) return rc;
   double* t[5] = {f, grad, g, jac, hess};
+  c->target_filled = false;       // (an arbitrary array of the caller's: the whole Jacobian is copied into it)
   for (int k = 0; k < 5; ++k) {
     c->target[k] = t[k];
+    c->target_pinned[k] = false;
     // A kernel may store into a target only if the device can see it (pinned / registered host memory); a pageable
     // target still works as the destination of a copy.
     c->target_visible[k] = true;
@@ -1151,28 +1331,52 @@ int pk_host_free(void* p) {
   return 0;
 }
 
+namespace {
+// multipliers of the next Hessian: staged in pinned memory; uploaded by DMA, or -- lambda_direct -- left there for the
+// Hessian kernel to read over PCIe itself (0.77 MB: DMA + kernel 34 us, kernel reading pinned memory 26 us)
+int stage_lambda(pk_ctx* c, const double* lambda) {
+  double* staged = nullptr;
+  const bool direct = c->lambda_direct != 0 && sizeof(double) * (size_t)c->m <= ((size_t)2 << 20);
+  int rc = stage_upload(c, c->h_lams, c->ev_lams, c->lams_seq, c->lambuf, lambda, direct ? nullptr : c->d_lam, (size_t)c->m, &staged);
+  if (rc) return rc;
+  c->lam_src = direct ? staged : c->d_lam;
+  c->lam_staged = true;
+  return 0;
+}
+
+// a landing block of the caller's for the x-results of the next new iterate: [J (nnz_J) | grad f (n) | g (m)]
+void take_block(pk_ctx* c, double* block) {
+  c->target[3] = block;
+  c->target[1] = block ? block + c->nnz_J : nullptr;
+  c->target[2] = block ? block + c->nnz_J + c->n : nullptr;
+  c->target_visible[1] = c->target_visible[2] = c->target_visible[3] = !c->host_direct;   // (copy targets; see pk_set_result_targets)
+  c->target_filled = block != nullptr;      // (the contract of pk_callback_x: blocks were filled by pk_fill_jac_constants)
+  c->target_pinned[1] = c->target_pinned[2] = c->target_pinned[3] = block != nullptr;      // (... and are pinned memory)
+}
+}  // namespace
+
 int pk_prepare_x(pk_ctx* c, const double* x) {
   int rc = ready(c);
   if (rc) return rc;
   if (!x) return fail(c, 60, "null host buffer");
   PK_HIP(c, hipSetDevice(c->device));
   c->x_valid = false;
-  if ((rc = stage_upload(c, c->h_xs, c->ev_xs, c->xbuf, x, c->d_x, (size_t)c->n, &c->h_x))) return rc;
+  if ((rc = stage_upload(c, c->h_xs, c->ev_xs, c->xs_seq, c->xbuf, x, c->d_x, (size_t)c->n, &c->h_x))) return rc;
   for (int k = 0; k < 5; ++k) {
     c->landed[k] = c->target[k] ? c->target[k] : c->h_out[k];
-    c->enq[k] = false;
+    c->enq[k] = c->done[k] = false;
   }
+  c->jac_filled = !c->jconst.empty() && (c->target[3] ? c->target_filled : true) && !c->host_direct;
+  c->early_valid = false;
   double* o[4];
   for (int k = 0; k < 4; ++k) {     // (f: stored by the kernel itself whenever its landing place is device-visible)
     c->stored_direct[k] = (c->host_direct || k == 0) && (!c->target[k] || c->target_visible[k]);
     o[k] = c->stored_direct[k] ? c->landed[k] : device_result(c, k);
   }
+  if (c->stored_direct[0]) *(volatile unsigned long long*)c->landed[0] = (unsigned long long)PK_EMPTY;     // (see wait_result)
   if ((rc = pk_eval_xpart_dev(c, c->d_x, o[0], o[1], o[2], o[3], nullptr))) return rc;
   // f and g are what a line search asks for at every trial point: always on their way; grad f and J in prefetch mode
-  if ((rc = enqueue_result_copy(c, 0))) return rc;
-  if (c->prefetch && (rc = enqueue_result_copy(c, 1))) return rc;
-  if ((rc = enqueue_result_copy(c, 2))) return rc;
-  if (c->prefetch && (rc = enqueue_result_copy(c, 3))) return rc;
+  if ((rc = enqueue_result_copies(c, c->prefetch ? 0xFu : 0x5u))) return rc;
   c->x_valid = true;
   return 0;
 }
@@ -1184,12 +1388,30 @@ int pk_fetch(pk_ctx* c, int what, double* out) {
   if (rc) return rc;
   if (what < 0 || what > 3) return fail(c, 61, "pk_fetch: what must be 0 (f), 1 (grad), 2 (g) or 3 (jac)");
   if (!c->x_valid) return fail(c, 64, "pk_fetch: no prepared x (pk_prepare_x)");
-  if (!c->enq[what]) {
-    if ((rc = enqueue_result_copy(c, what))) return rc;
-    if (what == 1 && (rc = enqueue_result_copy(c, 3))) return rc;      // an accepted point: J follows grad f
-  }
-  PK_HIP(c, hipEventSynchronize(c->ev_out[what]));
+  if (!c->enq[what] && (rc = enqueue_result_copies(c, (1u << what) | (what == 1 ? 8u : 0u)))) return rc;   // (an accepted point: J follows grad f)
+  if ((rc = wait_result(c, what))) return rc;
   if (out && out != c->landed[what]) std::memcpy(out, c->landed[what], sizeof(double) * result_count(c, what));
+  return 0;
+}
+
+// ONE call per x-callback of a host shim (objective / gradient / constraints / jacobian of the cyipopt protocol,
+// ipopt.py:41-53): if `x` is not the prepared iterate it becomes it -- its results landing in `block`, pinned memory of the
+// caller's holding [J (nnz_J) | grad f (n) | g (m)] (NULL: the context's own buffers; f always lands in the context's
+// pinned word) and *fresh = 1 -- then result `what` is waited for; f_out (may be NULL) receives f when what == 0.
+int pk_callback_x(pk_ctx* c, int what, const double* x, double* block, double* f_out, int* fresh) {
+  int rc = ready(c);
+  if (rc) return rc;
+  if (!x) return fail(c, 60, "null host buffer");
+  if (what < 0 || what > 3) return fail(c, 61, "pk_callback_x: what must be 0 (f), 1 (grad), 2 (g) or 3 (jac)");
+  const bool same = pk_same_x(c, x) != 0;
+  if (fresh) *fresh = same ? 0 : 1;
+  if (!same) {
+    c->target[0] = nullptr;
+    take_block(c, block);
+    if ((rc = pk_prepare_x(c, x))) return rc;
+  }
+  if ((rc = pk_fetch(c, what, nullptr))) return rc;
+  if (what == 0 && f_out) *f_out = c->landed[0][0];
   return 0;
 }
 
@@ -1200,9 +1422,7 @@ int pk_stage_lambda(pk_ctx* c, const double* lambda) {
   if (rc) return rc;
   if (!lambda) return fail(c, 60, "null host buffer");
   PK_HIP(c, hipSetDevice(c->device));
-  if ((rc = stage_upload(c, c->h_lams, c->ev_lams, c->lambuf, lambda, c->d_lam, (size_t)c->m, nullptr))) return rc;
-  c->lam_staged = true;
-  return 0;
+  return stage_lambda(c, lambda);
 }
 
 // Hessian on the x of the last pk_prepare_x (no re-upload of x); vals == NULL: the result stays where it landed;
@@ -1213,14 +1433,14 @@ int pk_eval_hess_prepared(pk_ctx* c, const double* lambda, double sigma, double*
   if (!lambda && !c->lam_staged) return fail(c, 60, "null host buffer (no multipliers staged either)");
   if (!c->x_valid) return fail(c, 64, "pk_eval_hess_prepared: no prepared x (pk_prepare_x)");
   PK_HIP(c, hipSetDevice(c->device));
-  if (lambda && (rc = stage_upload(c, c->h_lams, c->ev_lams, c->lambuf, lambda, c->d_lam, (size_t)c->m, nullptr))) return rc;
+  if (lambda && (rc = stage_lambda(c, lambda))) return rc;
   c->lam_staged = false;
   c->landed[4] = c->target[4] ? c->target[4] : c->h_out[4];
-  c->enq[4] = false;
+  c->enq[4] = c->done[4] = false;
   c->stored_direct[4] = c->host_direct && (!c->target[4] || c->target_visible[4]);
-  if ((rc = pk_eval_hess_dev(c, c->d_x, c->d_lam, sigma, c->stored_direct[4] ? c->landed[4] : c->d_H, nullptr))) return rc;
-  if ((rc = enqueue_result_copy(c, 4))) return rc;
-  PK_HIP(c, hipEventSynchronize(c->ev_out[4]));
+  if ((rc = pk_eval_hess_dev(c, c->d_x, c->lam_src, sigma, c->stored_direct[4] ? c->landed[4] : c->d_H, nullptr))) return rc;
+  if ((rc = enqueue_result_copies(c, 1u << 4))) return rc;
+  if ((rc = wait_result(c, 4))) return rc;
   if (vals && vals != c->landed[4]) std::memcpy(vals, c->landed[4], sizeof(double) * (size_t)c->nnz_H);
   return 0;
 }
@@ -1237,18 +1457,158 @@ int pk_eval_hessc_prepared(pk_ctx* c, const double* lambda, double sigma, double
   if (!c->x_valid) return fail(c, 64, "pk_eval_hessc_prepared: no prepared x (pk_prepare_x)");
   if (c->nnz_Hc <= 0) return fail(c, 51, "pk_eval_hessc: no compact Hessian layout was supplied to pk_set_problem");
   PK_HIP(c, hipSetDevice(c->device));
-  if (lambda && (rc = stage_upload(c, c->h_lams, c->ev_lams, c->lambuf, lambda, c->d_lam, (size_t)c->m, nullptr))) return rc;
+  if (lambda && (rc = stage_lambda(c, lambda))) return rc;
   c->lam_staged = false;
-  if ((rc = pk_eval_hessc_dev(c, c->d_x, c->d_lam, sigma, c->d_Hc, nullptr))) return rc;
+  if ((rc = pk_eval_hessc_dev(c, c->d_x, c->lam_src, sigma, c->d_Hc, nullptr))) return rc;
   const size_t bytes = sizeof(double) * (size_t)c->nnz_Hc;
   double* dst = vals;
   if (!vals_pinned) {
     if (!c->h_Hc) PK_HIP(c, hipHostMalloc((void**)&c->h_Hc, bytes, hipHostMallocDefault));
     dst = c->h_Hc;
   }
-  PK_HIP(c, hipMemcpyAsync(dst, c->d_Hc, bytes, hipMemcpyDeviceToHost, c->stream));
-  PK_HIP(c, hipStreamSynchronize(c->stream));       // (every earlier copy of this iterate has been waited for by its callback)
+  if ((rc = copy_async(c, dst, c->d_Hc, (size_t)c->nnz_Hc, hipMemcpyDeviceToHost, bytes <= ((size_t)c->kernel_download << 20)))) return rc;
+  ++c->op_seq;
+  if (c->spin_wait) {      // (every earlier copy of this iterate has been waited for by its callback)
+    hipError_t e;
+    while ((e = hipStreamQuery(c->stream)) == hipErrorNotReady) { }
+    if (e != hipSuccess) return fail(c, 100 + (int)e, "hipStreamQuery failed: %s", hipGetErrorString(e));
+  } else {
+    PK_HIP(c, hipStreamSynchronize(c->stream));
+  }
   if (!vals_pinned) std::memcpy(vals, c->h_Hc, bytes);
+  return 0;
+}
+
+// ONE call for the Hessian callback of a host shim (SystemBase.hessian, systembase.py:820-835): the multipliers are staged
+// first (their upload, if any, runs while x is compared), a new x is prepared like in pk_callback_x (landing block
+// `block`), then the Hessian of the Lagrangian is evaluated on the prepared x and waited for.  compact = 0: reference
+// layout, `hess` = pinned landing place of nnz_H values (NULL: the context's buffer); compact = 1: the compact layout
+// (pk_eval_hessc), `hess` = pinned landing place of nnz_Hc values (required).
+int pk_callback_hess(pk_ctx* c, const double* x, const double* lambda, double sigma, double* block, double* hess, int compact,
+                     int* fresh) {
+  int rc = ready(c);
+  if (rc) return rc;
+  if (!x || !lambda) return fail(c, 60, "null host buffer");
+  if (compact && !hess) return fail(c, 60, "pk_callback_hess: the compact layout needs a landing array");
+  PK_HIP(c, hipSetDevice(c->device));
+  if ((rc = stage_lambda(c, lambda))) return rc;
+  if (!compact) {
+    c->target[4] = hess;
+    c->target_visible[4] = !c->host_direct;
+    c->target_pinned[4] = hess != nullptr;
+  }
+  if (fresh) *fresh = 0;
+  // The solver's Hessian callback comes on the iterate the x-callbacks just ran on: launch on the prepared x at once and
+  // compare x with it WHILE the GPU works (the compare is a pass over n doubles: 10 us at 12k nodes, 90 us at 40k).  A
+  // different x discards the launch (its values are overwritten below) and takes the ordinary route.
+  if (c->speculative_hess && c->x_valid && c->h_x) {
+    const size_t bytes = sizeof(double) * (size_t)c->nnz_Hc;
+    if (compact) {
+      if ((rc = pk_eval_hessc_dev(c, c->d_x, c->lam_src, sigma, c->d_Hc, nullptr))) return rc;
+      if ((rc = copy_async(c, hess, c->d_Hc, (size_t)c->nnz_Hc, hipMemcpyDeviceToHost,
+                           sizeof(double) * (size_t)c->nnz_Hc <= ((size_t)c->kernel_download << 20)))) return rc;
+      ++c->op_seq;
+    } else {
+      c->landed[4] = c->target[4] ? c->target[4] : c->h_out[4];
+      c->enq[4] = c->done[4] = false;
+      c->stored_direct[4] = c->host_direct && (!c->target[4] || c->target_visible[4]);
+      if ((rc = pk_eval_hess_dev(c, c->d_x, c->lam_src, sigma, c->stored_direct[4] ? c->landed[4] : c->d_H, nullptr))) return rc;
+      if ((rc = enqueue_result_copies(c, 1u << 4))) return rc;
+    }
+    (void)bytes;
+    const bool same = std::memcmp(c->h_x, x, sizeof(double) * (size_t)c->n) == 0;
+    const uint64_t seen = c->op_seq;
+    if (same) {
+      c->lam_staged = false;
+      if (!compact) return wait_result(c, 4);
+      hipError_t e;
+      while ((e = hipStreamQuery(c->stream)) == hipErrorNotReady) { }
+      if (e != hipSuccess) return fail(c, 100 + (int)e, "hipStreamQuery failed: %s", hipGetErrorString(e));
+      c->idle_seq = seen;
+      return 0;
+    }
+    PK_HIP(c, hipStreamSynchronize(c->stream));       // (the discarded launch must not write behind the one that follows)
+    c->idle_seq = seen;
+    c->x_valid = false;
+  }
+  const bool same = pk_same_x(c, x) != 0;
+  if (fresh) *fresh = same ? 0 : 1;
+  if (!same) {
+    c->target[0] = nullptr;
+    take_block(c, block);
+    if ((rc = pk_prepare_x(c, x))) return rc;
+  }
+  if (compact) return pk_eval_hessc_prepared(c, nullptr, sigma, hess, 1);
+  return pk_eval_hess_prepared(c, nullptr, sigma, nullptr);
+}
+
+// Runs [start[i], stop[i]) of the Jacobian values that never change with x (ascending, disjoint): the x-results' copy to the
+// host skips them from now on.  The landing arrays must hold those values already: pk_fill_jac_constants writes them into
+// an array once (the context's own landing buffer is filled here).  n_runs = 0 restores the full copy.
+// Reference: the translation part of the Jacobian, phasebase.py:1071-1081, is recomputed and returned by every call there.
+int pk_set_jac_constant_runs(pk_ctx* c, int n_runs, const int64_t* start, const int64_t* stop) {
+  int rc = ready(c);
+  if (rc) return rc;
+  if (n_runs < 0 || (n_runs > 0 && (!start || !stop))) return fail(c, 66, "pk_set_jac_constant_runs: bad arguments");
+  int64_t at = 0;
+  for (int i = 0; i < n_runs; ++i) {
+    if (start[i] < at || stop[i] <= start[i] || stop[i] > c->nnz_J)
+      return fail(c, 66, "pk_set_jac_constant_runs: run %d [%lld, %lld) is out of order or out of range", i, (long long)start[i], (long long)stop[i]);
+    at = stop[i];
+  }
+  PK_HIP(c, hipSetDevice(c->device));
+  PK_HIP(c, hipStreamSynchronize(c->stream));
+  c->x_valid = false;
+  c->jconst.clear();
+  c->jruns.clear();
+  at = 0;
+  for (int i = 0; i < n_runs; ++i) {
+    if (start[i] > at) c->jruns.emplace_back(at, start[i]);
+    c->jconst.emplace_back(start[i], stop[i]);
+    at = stop[i];
+  }
+  if (at < c->nnz_J || c->jruns.empty()) c->jruns.emplace_back(at, (int64_t)c->nnz_J);
+  if (n_runs == 0) return 0;
+  // one evaluation of J into the context's device buffer (whatever x it holds: the constant entries do not depend on it),
+  // from which the constants are taken
+  if ((rc = pk_eval_jac_dev(c, c->d_x, c->d_J, nullptr))) return rc;
+  return pk_fill_jac_constants(c, c->h_out[3]);
+}
+
+// the x-independent runs of J (pk_set_jac_constant_runs) -> jac[...]; the other entries of `jac` are not touched
+int pk_fill_jac_constants(pk_ctx* c, double* jac) {
+  int rc = ready(c);
+  if (rc) return rc;
+  if (!jac) return fail(c, 60, "null host buffer");
+  PK_HIP(c, hipSetDevice(c->device));
+  for (const auto& r : c->jconst)
+    PK_HIP(c, hipMemcpyAsync(jac + r.first, c->d_J + r.first, sizeof(double) * (size_t)(r.second - r.first), hipMemcpyDeviceToHost, c->stream));
+  PK_HIP(c, hipStreamSynchronize(c->stream));
+  return 0;
+}
+
+// A/B switches of the host shim (defaults: what measured fastest): "spin_wait" (1: results are awaited
+// by polling, 0: hipEventSynchronize), "lambda_direct" (1: the Hessian kernel reads the staged multipliers from pinned
+// memory itself, 0: they are uploaded first), "chunk_upload" (1: large inputs are staged and uploaded in chunks),
+// "kernel_upload" / "kernel_download" (copy kernels instead of the DMA engine), "split_copy" (grad f | g ahead of J),
+// "speculative_hess" (the Hessian is launched before x has been compared with the prepared iterate).
+int pk_set_host_option(pk_ctx* c, const char* name, int value) {
+  if (!c) return fail(nullptr, 1, "null context");
+  if (!name) return fail(c, 67, "pk_set_host_option: null name");
+  if (c->have_problem) {
+    PK_HIP(c, hipSetDevice(c->device));
+    PK_HIP(c, hipStreamSynchronize(c->stream));
+  }
+  c->x_valid = false;
+  c->lam_staged = false;
+  if (!std::strcmp(name, "spin_wait")) c->spin_wait = value != 0;
+  else if (!std::strcmp(name, "lambda_direct")) c->lambda_direct = value != 0;
+  else if (!std::strcmp(name, "chunk_upload")) c->chunk_upload = value != 0;
+  else if (!std::strcmp(name, "kernel_upload")) c->kernel_upload = value != 0;
+  else if (!std::strcmp(name, "kernel_download")) c->kernel_download = value < 0 ? 0 : (value > 4096 ? 4096 : value);
+  else if (!std::strcmp(name, "split_copy")) c->split_copy = value != 0;
+  else if (!std::strcmp(name, "speculative_hess")) c->speculative_hess = value != 0;
+  else return fail(c, 67, "pk_set_host_option: unknown option \"%s\"", name);
   return 0;
 }
 
@@ -1351,6 +1711,7 @@ int pk_copy_dev(pk_ctx* c, void* dst, const void* src, size_t bytes, void* strea
 int pk_set_shared_grad_target(pk_ctx* c, double* d_grad_shared) {
   if (!c) return fail(nullptr, 1, "null context");
   c->gshared = d_grad_shared;
+  drop_cycle_graph(c);
   return 0;
 }
 
@@ -1379,6 +1740,7 @@ int pk_set_exchange_inline(pk_ctx* c, int enable) {
   if (enable && !c->md.sharded)
     return fail(c, 95, "pk_set_exchange_inline: the code object was generated for a single GPU (no exchange code in pk_cycle)");
   c->xc_inline = enable != 0;
+  drop_cycle_graph(c);
   return 0;
 }
 

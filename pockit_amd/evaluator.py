@@ -227,7 +227,6 @@ class Evaluator:
         md.prepass_hess = int(plan.hess.needs_I)
         self._code = code
         self._views = {}
-        self._ring, self._ring_hc, self._own, self._handed = None, None, {}, set()
         self.zero_copy = False   # True: callbacks return views of pinned buffers (set by the IPOPT adapter)
         self.ctx.check(lib.pk_load_model(h, code, len(code), C.byref(md)))
         self.model_desc = md
@@ -237,7 +236,6 @@ class Evaluator:
         plan, lib, h = self.plan, self.ctx.lib, self.ctx.handle
         self.tables = tb
         self._views = {}
-        self._ring, self._ring_hc, self._own, self._handed = None, None, {}, set()
         pd = runtime.ProblemDesc()
         pd.n, pd.m, pd.n_sys, pd.n_s, pd.l_s = plan.n, plan.m, plan.n_sys, plan.n_s, plan.l_s
         pd.n_phase, pd.n_tiles, pd.n_kinds = len(tb.phases), len(tb.tiles), len(tb.kinds)
@@ -258,6 +256,7 @@ class Evaluator:
                         (plan.jac_row, plan.jac_col, plan.hess_row, plan.hess_col)]
         pd.jac_row, pd.jac_col, pd.hess_row, pd.hess_col = (a.ctypes.data_as(runtime.c_int32_p) for a in self._struct)
         self.ctx.check(lib.pk_set_problem(h, C.byref(pd)))
+        self._host_setup()
 
     def close(self):
         if self.ctx is not None:
@@ -272,50 +271,76 @@ class Evaluator:
         return x
 
     # IPOPT calls objective / gradient / constraints / jacobian one after the other on the same iterate and then
-    # hessian with new multipliers (the five methods optimizer/ipopt.py hands to cyipopt; reference ipopt.py:41-53):
-    # the first call on a new x uploads it, runs the fused x-kernel and queues the copies of all four results into
-    # pinned host memory (pk_prepare_x); every callback then only waits for its own result (pk_fetch).
+    # hessian with new multipliers (the five methods optimizer/ipopt.py hands to cyipopt; reference ipopt.py:41-53).
+    # Every callback is ONE call into the library (pk_callback_x / pk_callback_hess): a bitwise compare decides whether x is
+    # the prepared iterate; a new x is staged, uploaded, evaluated by the fused x-kernel and all of its results are on their
+    # way to pinned host memory behind it; the callback then only waits for its own result.
     #
     # Where results land: ``zero_copy`` (set by the IPOPT adapter: cyipopt copies a result at once) hands out views of
     # the context's pinned buffers, valid until the next iterate.  Otherwise the callbacks return arrays the caller
-    # owns, as the reference's do -- but over pinned memory the DMA writes directly (runtime.PinnedRing): an array is
-    # recycled only when the caller no longer refers to it.
-    def _rings(self):
-        if self._ring is None:
-            p = self.plan       # grad f and g come from ONE block (neighbours: the library then needs one copy for both)
-            self._ring = [runtime.PinnedRing(c) for c in (1, p.n + p.m, 0, p.nnz_J, p.nnz_H)]
-        return self._ring
+    # owns, as the reference's do -- but over pinned memory the DMA writes directly (runtime.PinnedRing): J, grad f and g of
+    # one iterate are three views of ONE block laid out like the device's buffer, [J | grad f | g], so that they arrive in a
+    # single DMA; the x-independent entries of J (the translation part, ``SystemPlan.jac_constant_runs``) were put into the
+    # block when it was allocated and never cross PCIe again.  A block is recycled only when the caller no longer refers
+    # to any of its arrays.
+    HEAD_RUN_MIN = 1024         # constant runs worth leaving out of the copy: at the head of J (the copy just starts later)
+    INNER_RUN_MIN = 80_000      # ... and inside it (the copy splits in two: ~10 us per extra DMA = 0.5 MB of link time)
 
-    def _targets(self, whats):
-        """Pinned arrays of the caller's own for the results ``whats`` of the next evaluation (None: ring exhausted)."""
-        rings, out, n = self._rings(), {}, self.plan.n
-        for w in whats:
-            if w in (1, 2):
-                if 1 not in out and 2 not in out:
-                    block = rings[1].take()
-                    out[1], out[2] = (None, None) if block is None else (block[:n], block[n:])
-            else:
-                out[w] = rings[w].take()
-        return {w: out[w] for w in whats}
+    def _host_setup(self):
+        p = self.plan
+        self._blocks = runtime.PinnedRing(p.nnz_J + p.n + p.m)
+        self._ring_h = runtime.PinnedRing(p.nnz_H)
+        self._ring_hc = None
+        self._next = self._cur = None
+        self._cur_views, self._handed = {}, set()
+        self._c_f, self._c_fresh = C.c_double(), C.c_int()
+        self._a_f, self._a_fresh = C.addressof(self._c_f), C.addressof(self._c_fresh)
+        runs = [(a, b) for a, b in p.jac_constant_runs()
+                if b - a >= (self.HEAD_RUN_MIN if a == 0 else self.INNER_RUN_MIN)]
+        if os.environ.get("POCKIT_AMD_JAC_CONSTANTS", "1") == "0":      # A/B: every iterate ships the whole Jacobian
+            runs = []
+        self.jac_constant_runs = runs
+        if runs:
+            lo = (C.c_int64 * len(runs))(*[a for a, _ in runs])
+            hi = (C.c_int64 * len(runs))(*[b for _, b in runs])
+            self.ctx.check(self.ctx.lib.pk_set_jac_constant_runs(self.ctx.handle, len(runs), lo, hi))
 
-    def _set_targets(self, arrs):
-        ptr = [runtime.as_dp(arrs[w]) if arrs.get(w) is not None else None for w in range(5)]
-        self.ctx.check(self.ctx.lib.pk_set_result_targets(self.ctx.handle, *ptr))
-
-    def _prepare(self, x):
-        x = self._x(x)
-        lib, h = self.ctx.lib, self.ctx.handle
-        if lib.pk_same_x(h, runtime.as_dp(x)):
-            return
+    def _next_block(self):
+        """The landing block [J | grad f | g] of the next new iterate (None: zero-copy mode, or the caller holds on to every
+        block of the ring -- the results then land in the context's buffers and are copied)."""
         if self.zero_copy:
-            if self._own:
-                self.ctx.check(lib.pk_set_result_targets(h, None, None, None, None, None))
-            self._own = {}
+            return None
+        it = self._next
+        if it is None:
+            it = self._blocks.take_item()
+            if it is None:
+                return None
+            if not it.ready:
+                if self.jac_constant_runs:
+                    self.ctx.check(self.ctx.lib.pk_fill_jac_constants(self.ctx.handle, it.address))
+                it.ready = True
+            self._next = it
+        return it
+
+    def _became_current(self, it):
+        """A new iterate was prepared; its x-results land in ``it`` (None: in the context's buffers)."""
+        self._cur, self._next, self._handed = it, None, set()
+        if it is None:
+            self._cur_views = {}
         else:
-            self._own = self._targets((0, 1, 2, 3))
-            self._set_targets(self._own)
-        self._handed = set()
-        self.ctx.check(lib.pk_prepare_x(h, runtime.as_dp(x)))
+            p, root = self.plan, it.root
+            self._cur_views = {3: root[: p.nnz_J], 1: root[p.nnz_J: p.nnz_J + p.n],
+                               2: root[p.nnz_J + p.n: p.nnz_J + p.n + p.m]}
+
+    def _callback_x(self, what, x):
+        x = self._x(x)
+        it = self._next_block()
+        rc = self.ctx.lib.pk_callback_x(self.ctx.handle, what, x.ctypes.data, it.address if it is not None else None,
+                                        self._a_f, self._a_fresh)
+        if rc:
+            self.ctx.check(rc)
+        if self._c_fresh.value:
+            self._became_current(it)
 
     def _invalidate_x(self):
         """The context's x / result buffers are about to be used by an entry point outside the prepared-x protocol."""
@@ -331,8 +356,8 @@ class Evaluator:
         return self._views[what]
 
     def _result(self, what, count):
-        """The array result ``what`` landed in (after its wait), as the callback's return value."""
-        own = self._own.get(what)
+        """The array result ``what`` of the current iterate landed in, as the callback's return value."""
+        own = self._cur_views.get(what)
         if own is None:                      # landed in the context's buffer: zero-copy mode, or the ring is exhausted
             view = self._pinned(what)[:count]           # (the caller keeps many results): plain array + host copy
             return view if self.zero_copy else view.copy()
@@ -343,40 +368,46 @@ class Evaluator:
         self._handed.add(what)
         return own
 
-    def _fetch(self, what, count):
-        self.ctx.check(self.ctx.lib.pk_fetch(self.ctx.handle, what, None))
-        return self._result(what, count)
-
     def objective(self, x):
-        self._prepare(x)
-        self.ctx.check(self.ctx.lib.pk_fetch(self.ctx.handle, 0, None))
-        own = self._own.get(0)
-        return np.float64((own if own is not None else self._pinned(0))[0])
+        self._callback_x(0, x)
+        return np.float64(self._c_f.value)
 
     def gradient(self, x):
-        self._prepare(x)
-        return self._fetch(1, self.plan.n)
+        self._callback_x(1, x)
+        return self._result(1, self.plan.n)
 
     def constraints(self, x):
-        self._prepare(x)
-        return self._fetch(2, self.plan.m)
+        self._callback_x(2, x)
+        return self._result(2, self.plan.m)
 
     def jacobian(self, x):
-        self._prepare(x)
-        return self._fetch(3, self.plan.nnz_J)
+        self._callback_x(3, x)
+        return self._result(3, self.plan.nnz_J)
 
-    def hessian(self, x, lagrange, obj_factor):
+    def _lam(self, lagrange):
         lam = np.ascontiguousarray(lagrange, dtype=np.float64)
         if lam.shape != (self.plan.m,):
             raise ValueError(f"lagrange must have shape ({self.plan.m},)")
-        lib, h = self.ctx.lib, self.ctx.handle
-        self.ctx.check(lib.pk_stage_lambda(h, runtime.as_dp(lam)))      # the upload runs while x is compared below
-        self._prepare(x)
-        self._own[4] = None if self.zero_copy else self._rings()[4].take()
-        self._set_targets(self._own)
-        self._handed.discard(4)
-        self.ctx.check(lib.pk_eval_hess_prepared(h, None, float(obj_factor), None))
-        return self._result(4, self.plan.nnz_H)
+        return lam
+
+    def _callback_hess(self, x, lam, obj_factor, target, compact):
+        x = self._x(x)
+        it = self._next_block()
+        rc = self.ctx.lib.pk_callback_hess(self.ctx.handle, x.ctypes.data, lam.ctypes.data, float(obj_factor),
+                                           it.address if it is not None else None, target, compact, self._a_fresh)
+        if rc:
+            self.ctx.check(rc)
+        if self._c_fresh.value:
+            self._became_current(it)
+
+    def hessian(self, x, lagrange, obj_factor):
+        lam = self._lam(lagrange)
+        hit = None if self.zero_copy else self._ring_h.take_item()
+        self._callback_hess(x, lam, obj_factor, hit.address if hit is not None else None, 0)
+        if hit is None:                      # the context's buffer: zero-copy mode, or the caller keeps every Hessian
+            view = self._pinned(4)[: self.plan.nnz_H]
+            return view if self.zero_copy else view.copy()
+        return hit.array
 
     def set_host_mode(self, prefetch=True, host_direct=False):
         """``prefetch`` (default True): all four x-results are copied to the host right behind the kernel; False: f and
@@ -426,21 +457,20 @@ class Evaluator:
         """Values of the compact (coalesced) Hessian layout ``plan.hessc_row/col``."""
         if not self.src.compact:
             raise NotImplementedError("compact Hessian layout is not available for this model")
-        lam = np.ascontiguousarray(lagrange, dtype=np.float64)
-        if lam.shape != (self.plan.m,):
-            raise ValueError(f"lagrange must have shape ({self.plan.m},)")
-        # the prepared-x protocol, like hessian(): the multipliers go up while x is compared, the x of the iterate is
-        # already on the device (objective ... jacobian ran on it), the values come back by DMA into a pinned array
-        lib, h = self.ctx.lib, self.ctx.handle
-        self.ctx.check(lib.pk_stage_lambda(h, runtime.as_dp(lam)))
-        self._prepare(x)
+        lam = self._lam(lagrange)
+        # the prepared-x protocol, like hessian(): the x of the iterate is already on the device (objective ... jacobian ran
+        # on it), the values come back by DMA into a pinned array of the caller's
         if self._ring_hc is None:
             self._ring_hc = runtime.PinnedRing(self.plan.nnz_Hc)
-        out = None if self.zero_copy else self._ring_hc.take()
-        pinned = out is not None
-        if out is None:
-            out = np.empty(self.plan.nnz_Hc)
-        self.ctx.check(lib.pk_eval_hessc_prepared(h, None, float(obj_factor), runtime.as_dp(out), int(pinned)))
+        hit = self._ring_hc.take_item()
+        if hit is not None:
+            self._callback_hess(x, lam, obj_factor, hit.address, 1)
+            return hit.array
+        # (the caller keeps every array of the ring: a plain array, filled through the context's pinned buffer)
+        lib, h = self.ctx.lib, self.ctx.handle
+        self._callback_x(2, x)
+        out = np.empty(self.plan.nnz_Hc)
+        self.ctx.check(lib.pk_eval_hessc_prepared(h, runtime.as_dp(lam), float(obj_factor), runtime.as_dp(out), 0))
         return out
 
     def mesh_error(self, x):
@@ -533,10 +563,18 @@ class Evaluator:
         x = self._x(x)
         self._invalidate_x()        # the context's x / result buffers are about to hold another iterate
         lam = np.ascontiguousarray(lagrange, dtype=np.float64)
-        self._own = {}
-        out = self._targets(range(5))        # pinned arrays of the caller's own: the five DMAs run at full PCIe rate
-        sizes = (1, self.plan.n, self.plan.m, self.plan.nnz_J, self.plan.nnz_H)
-        f, grad, g, J, H = (out[w] if out[w] is not None else np.empty(sizes[w]) for w in range(5))
+        p = self.plan
+        # pinned arrays of the caller's own (the block set aside for the next iterate of the callbacks, if there is one)
+        blk = self._next if self._next is not None else self._blocks.take_item()
+        self._next, hit = None, self._ring_h.take_item()
+        if blk is not None:
+            root = blk.root
+            J, grad, g = root[: p.nnz_J], root[p.nnz_J: p.nnz_J + p.n], root[p.nnz_J + p.n: p.nnz_J + p.n + p.m]
+            blk.ready = True        # (this call writes the whole Jacobian, constant entries included)
+        else:
+            J, grad, g = np.empty(p.nnz_J), np.empty(p.n), np.empty(p.m)
+        H = hit.array if hit is not None else np.empty(p.nnz_H)
+        f = np.empty(1)
         dp = runtime.as_dp
         self.ctx.check(self.ctx.lib.pk_eval_cycle(self.ctx.handle, dp(x), dp(lam), float(obj_factor), dp(f), dp(grad),
                                                   dp(g), dp(J), dp(H)))

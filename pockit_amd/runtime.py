@@ -74,7 +74,8 @@ EXPORTS = ["pk_create", "pk_destroy", "pk_last_error", "pk_device_count", "pk_lo
            "pk_result_location", "pk_set_host_mode", "pk_stage_lambda", "pk_invalidate_x", "pk_host_alloc", "pk_host_free",
            "pk_device_alloc", "pk_device_free", "pk_ipc_export", "pk_ipc_open", "pk_ipc_close", "pk_set_shared_grad_target",
            "pk_set_exchange", "pk_exchange_sums_dev", "pk_copy_runs_dev", "pk_set_exchange_inline",
-           "pk_host_register", "pk_host_unregister", "pk_copy_dev", "pk_eval_xpart_dev"]
+           "pk_host_register", "pk_host_unregister", "pk_copy_dev", "pk_eval_xpart_dev",
+           "pk_callback_x", "pk_callback_hess", "pk_set_jac_constant_runs", "pk_fill_jac_constants", "pk_set_host_option"]
 
 _lib = None
 
@@ -155,6 +156,12 @@ def load_library():
     lib.pk_host_unregister.argtypes = [vp, vp]
     lib.pk_copy_dev.argtypes = [vp, vp, vp, C.c_size_t, vp]
     lib.pk_eval_xpart_dev.argtypes = [vp, vp, vp, vp, vp, vp, vp]
+    # (raw addresses on the per-callback entry points: building a typed pointer costs more than the call)
+    lib.pk_callback_x.argtypes = [vp, C.c_int, vp, vp, vp, vp]
+    lib.pk_callback_hess.argtypes = [vp, vp, vp, C.c_double, vp, vp, C.c_int, vp]
+    lib.pk_set_jac_constant_runs.argtypes = [vp, C.c_int, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
+    lib.pk_fill_jac_constants.argtypes = [vp, vp]
+    lib.pk_set_host_option.argtypes = [vp, C.c_char_p, C.c_int]
     lib.pk_eval_hessc.argtypes = [vp, dp, dp, C.c_double, dp]
     lib.pk_eval_hessc_dev.argtypes = [vp, vp, vp, C.c_double, vp, vp]
     lib.pk_set_mesh_error_tables.argtypes = [vp, vp, C.c_int32, vp, C.c_int32, dp, C.c_int64, C.c_int64]
@@ -266,6 +273,8 @@ class PinnedArray:
             root = buffer_factory(max(count, 1))   # (tests: plain NumPy memory)
         self.root = root
         self.array = root[:count]
+        self.address = int(root.ctypes.data)
+        self.ready = False       # (evaluator: the x-independent entries have been filled in)
 
     def free(self):
         # root: self.root + self.array.base (+ the argument of getrefcount); array: self.array (+ argument).  Views a
@@ -281,11 +290,16 @@ class PinnedRing:
     def __init__(self, count, cap=6, buffer_factory=None):
         self.count, self.cap, self._factory, self.items = int(count), int(cap), buffer_factory, []
 
-    def take(self):
+    def take_item(self):
+        """The ``PinnedArray`` itself (its ``array``, ``address``, ``ready``), or None when all ``cap`` are in use."""
         for it in self.items:
             if it.free():
-                return it.array
+                return it
         if len(self.items) < self.cap:
             self.items.append(PinnedArray(self.count, self._factory))
-            return self.items[-1].array
+            return self.items[-1]
         return None
+
+    def take(self):
+        it = self.take_item()
+        return None if it is None else it.array

@@ -491,6 +491,13 @@ class ShardedEvaluator:
         self.peers = self._root_map = self._root_alloc = None
         self.ev.close()
 
+    def _inline(self, exchange):
+        """Whether the sums are exchanged inside pk_cycle's launch.  Never for ``"direct"``: the finalize workgroup would
+        raise the completion flags while the other workgroups of the same launch are still streaming their slices into the
+        root's buffer over xGMI -- the root could read J / H before they have landed.  With pk_xchg as a launch of its own
+        behind pk_cycle on the same stream, the kernel boundary orders every peer store before the flag."""
+        return bool(self.inline_exchange) and exchange != "direct"
+
     def fast_step(self, x, lam, sigma, exchange="sums"):
         """A closure running one "sums" / "direct" cycle on this evaluator's stream with pre-built ctypes arguments and no
         torch call (bench.py: the loop is launch-bound, a cycle is two ~5 us launches)."""
@@ -509,8 +516,9 @@ class ShardedEvaluator:
                tg["H"], st)
         px, pgrad, pf = C.c_void_p(x.data_ptr()), (ptr(o["grad"]) if remote else tg["grad"]), ptr(o["f"])
         cycle_fn, xchg_fn = lib.pk_eval_cycle_dev, lib.pk_exchange_sums_dev
-        chk(lib.pk_set_exchange_inline(h, int(self.inline_exchange)))     # (stays set: the caller's loop owns the context)
-        if self.inline_exchange:
+        inline = self._inline(exchange)
+        chk(lib.pk_set_exchange_inline(h, int(inline)))     # (stays set: the caller's loop owns the context)
+        if inline:
             def step():
                 rc = cycle_fn(*cyc)
                 if rc:
@@ -520,7 +528,7 @@ class ShardedEvaluator:
                 rc = cycle_fn(*cyc) or xchg_fn(h, px, pgrad, pf, 0, 1, st)
                 if rc:
                     chk(rc)
-        repeat_fn, two = lib.pk_eval_cycle_dev_repeat, 0 if self.inline_exchange else 1
+        repeat_fn, two = lib.pk_eval_cycle_dev_repeat, 0 if inline else 1
 
         def many(count):          # `count` cycles enqueued by the library itself (no interpreter between the launches)
             rc = repeat_fn(*cyc, count, two, pgrad)
@@ -565,9 +573,10 @@ class ShardedEvaluator:
             else:
                 tg = {k: ptr(o[k]) for k in ("grad", "g", "J", "H")}
                 chk(lib.pk_set_shared_grad_target(h, None))
-            chk(lib.pk_set_exchange_inline(h, int(self.inline_exchange)))
+            inline = self._inline(exchange)
+            chk(lib.pk_set_exchange_inline(h, int(inline)))
             chk(lib.pk_eval_cycle_dev(h, px, ptr(lam), float(sigma), ptr(o["f"]), tg["grad"], tg["g"], tg["J"], tg["H"], st))
-            if not self.inline_exchange:
+            if not inline:
                 chk(lib.pk_exchange_sums_dev(h, px, tg["grad"] if not remote else ptr(o["grad"]), ptr(o["f"]), 0, 1, st))
             chk(lib.pk_set_exchange_inline(h, 0))
             return o

@@ -485,6 +485,21 @@ class SystemPlan:
         self.jac_row = np.concatenate(rows) if rows else np.zeros(0, np.int64)
         self.jac_col = np.concatenate(cols) if cols else np.zeros(0, np.int64)
 
+    def jac_constant_runs(self):
+        """Runs ``[(start, stop)]`` of Jacobian positions whose value does not depend on x: the +-1 translation entries
+        (the reference recomputes them in every call, phasebase.py:1071-1081) and boundary / system items whose expression is
+        a number (a FREE boundary slot contributes ``coef * 1``).  A host shim fills them into its landing arrays once and
+        leaves them out of the per-iterate copy (``pk_set_jac_constant_runs``)."""
+        const = np.zeros(self.nnz_J + 1, dtype=np.int8)
+        for k, pp in enumerate(self.phase_plans):
+            for base in self.jac.tconst[k]:
+                const[base: base + pp.layout.nnzT_mid] = 1
+        for it in self.jac.items:
+            if it.lam < 0 and not sp.sympify(self.jac.lists[it.lst][it.eid]).free_symbols:
+                const[it.pos] = 1
+        edges = np.flatnonzero(np.diff(np.concatenate(([0], const[:-1], [0]))))
+        return [(int(a), int(b)) for a, b in zip(edges[0::2], edges[1::2])]
+
     # ------------------------------------------------------------------ Hessian of the Lagrangian
     def _plan_hessian(self):
         cb = self.hess

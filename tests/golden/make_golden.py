@@ -37,6 +37,7 @@ if not hasattr(typing, "Self"):
 sys.path.insert(0, os.path.join(HERE, "refharness"))  # stub numba first
 sys.path.insert(0, "/root/reference")
 sys.path.insert(0, os.path.join(ROOT, "tests"))
+sys.path.insert(0, ROOT)          # (tests/models.py re-exports pockit_amd.benchmarks: the repo root must be importable)
 sys.modules.setdefault("cyipopt", types.ModuleType("cyipopt"))
 
 import numpy as np  # noqa: E402

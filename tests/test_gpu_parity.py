@@ -1286,3 +1286,66 @@ def test_bang_bang_refinement_end_to_end_matches_reference(name):
         system2, (p2,), _ = models.bang_bang_model(ns, **kw)
         system2.refine([ns.Variable(p2, gold["data"].copy()), gold["s"].copy()], 1e-8, 1e-8, dtol, kmin, kmax, lmin, lmax)
         assert len(p2._mesh) == len(gold[f"mesh_{tag}"]) and np.allclose(p2._mesh, gold[f"mesh_{tag}"], rtol=0, atol=1e-9)
+
+
+def test_landing_blocks_keep_the_constant_jacobian_entries_across_recycling():
+    """J, grad f and g of an iterate are views of one pinned block [J | grad f | g] that arrives in one copy; the
+    x-independent entries of J (translation part, phasebase.py:1071-1081) are filled into a block once and left out of the
+    copy afterwards.  Over more iterates than the ring has blocks -- the caller keeping some arrays, dropping others --
+    every returned array must equal the oracle's, constant entries included, and arrays the caller still holds must not
+    change; a C-ABI caller's arbitrary target array (pk_set_result_targets) still receives the whole Jacobian."""
+    import ctypes as C
+
+    from pockit_amd import runtime
+
+    system, _, guess = models.planar_quadrotor(_ns("radau", "pockit_amd"), mesh=60, num_point=6)
+    ref, _, _ = models.planar_quadrotor(_ns("radau", "oracle"), mesh=60, num_point=6)
+    x0, lam, sigma = models.bench_inputs(system, guess)
+    ev, plan = system.evaluator, system.plan
+    runs = ev.jac_constant_runs
+    assert runs and runs[0][0] == 0 and runs[0][1] >= 1024, runs
+    rng = np.random.default_rng(5)
+    kept = []
+    for k in range(14):                      # (the ring holds 6 blocks)
+        x = x0 * (1.0 + 1e-3 * rng.uniform(-1, 1, x0.shape))
+        order = rng.permutation(4)
+        got = {}
+        for what in order:                   # any order of the x-callbacks
+            got[what] = (system.objective, system.gradient, system.constraints, system.jacobian)[what](x)
+        H = system.hessian(x, lam, sigma)
+        want = (ref.objective(x), ref.gradient(x), ref.constraints(x), ref.jacobian(x), ref.hessian(x, lam, sigma))
+        for what in range(4):
+            close(got[what], want[what], what=f"iterate {k} result {what}")
+        close(H, want[4], what=f"iterate {k} H")
+        assert np.all(np.abs(got[3][: runs[0][1]]) == 1.0)          # the head of J is the +-1 translation part
+        if k % 3 == 0:
+            kept.append((got[3], want[3].copy(), got[1], want[1].copy(), H, want[4].copy()))
+    for J, Jw, g_, gw, H, Hw in kept:        # arrays the caller kept were never recycled under it
+        close(J, Jw, what="kept J"); close(g_, gw, what="kept grad"); close(H, Hw, what="kept H")
+    # a plain array as the Jacobian target of a C-ABI caller: all of J is copied
+    lib, h, dp = ev.ctx.lib, ev.ctx.handle, runtime.as_dp
+    out = [np.full(k, np.nan) for k in (1, plan.n, plan.m, plan.nnz_J, plan.nnz_H)]
+    ev.ctx.check(lib.pk_set_result_targets(h, *[dp(a) for a in out]))
+    x = x0 * 1.001
+    ev.ctx.check(lib.pk_prepare_x(h, dp(x)))
+    for what in range(4):
+        ev.ctx.check(lib.pk_fetch(h, what, None))
+    ev.ctx.check(lib.pk_set_result_targets(h, None, None, None, None, None))
+    ev._invalidate_x()
+    close(out[3], ref.jacobian(x), what="J in a caller's plain array")
+    close(out[1], ref.gradient(x), what="grad in a caller's plain array")
+    # every switch of the shim gives the same arrays
+    base = [system.gradient(x).copy(), system.jacobian(x).copy(), system.hessian(x, lam, sigma).copy()]
+    for name, dflt in ((b"spin_wait", 1), (b"lambda_direct", 1), (b"chunk_upload", 1), (b"kernel_upload", 1),
+                       (b"kernel_download", 8), (b"split_copy", 1), (b"speculative_hess", 1)):
+        ev.ctx.check(lib.pk_set_host_option(h, name, 0 if dflt else 1))
+        now = [system.gradient(x), system.jacobian(x), system.hessian(x, lam, sigma)]
+        x_other = x * 1.0005                   # ... also when the Hessian callback is the first to see a new x
+        h_new = system.hessian(x_other, lam, sigma)
+        g_new = system.gradient(x_other)
+        ev.ctx.check(lib.pk_set_host_option(h, name, dflt))
+        for a, b in zip(base, now):
+            assert np.array_equal(a, b), name
+        close(h_new, ref.hessian(x_other, lam, sigma), what=f"H on a new x, {name}")
+        close(g_new, ref.gradient(x_other), what=f"grad on that x, {name}")
+    assert lib.pk_set_host_option(h, b"no_such_option", 1) != 0
