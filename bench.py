@@ -4,31 +4,29 @@
     python bench.py --gpus N --steps K --warmup W
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
-A *step* is one NLP-callback cycle -- objective, gradient, constraints, Jacobian, Hessian of the Lagrangian on the
-same x, in IPOPT's order -- with x and lambda already resident in HBM and all outputs left
-in HBM (``value``).  The same cycle with host NumPy arrays in and out, as a solver sees it (the five callbacks of
-``System``, PCIe included), is reported beside it as ``end_to_end`` with the time of every callback; the CPU baseline
-ratio is taken on THAT figure.
+A *step* is one NLP-callback cycle as a solver sees it (what the reference's
+``SystemBase`` returns to cyipopt, systembase.py:602-835 / optimizer/ipopt.py:41-53): objective, gradient, constraints,
+jacobian, hessian of ``System`` called in IPOPT's order on a NEW x, host NumPy arrays in, host NumPy arrays the caller owns
+out (reference triplet layout).  ``value`` = those cycles per second: x and lambda cross PCIe up, every result crosses it
+down (round 2's headline was the device-resident launch rate of the same cycle; it is kept, with its roofline, under
+``device_resident`` / ``roofline``: the kernel's quality is read there, the solver's throughput in ``value``).
 
 Workload (BASELINE.json metric: "at 10k LGR nodes"): planar_quadrotor re-meshed on LGR 2000 intervals x 6 points =
 12 000 nodes (configs[2], the ~10k-node headline of BASELINE.md), x = example guess * (1 + 1e-3 U), lambda ~ N(0,1),
 sigma = 1, all seeded.  For N > 1 the mesh is 2000*N intervals of the same model, sharded by mesh interval over the N
-GPUs (weak scaling: 2000 intervals per GPU); ``value`` is then in 12k-node-equivalent cycles/s (= N * steps / time).
+GPUs (weak scaling: 2000 intervals per GPU), every GPU landing its slices of the outputs in ONE host array over its own
+PCIe link (pockit_amd/hostshard.py); ``value`` is then in 12k-node-equivalent cycles/s (= N * cycles/s of the N-times
+larger system).
 
-Timing.  A cycle is ONE 5 us launch, so a region of ``--steps 20`` would measure the launch ramp and one
-synchronization, not the kernel.  After the warm-up the timed region therefore consists of R back-to-back batches of
-EXACTLY ``steps`` cycles each (R chosen so that the region lasts >= 50 ms), with a HIP event recorded on the launch
-stream after every ceil(200 / steps) batches (an event drains the stream, ~3 us of GPU time: between every two batches
-of 20 cycles it would add 3 % to the figure) and bracketed as a whole by a barrier + synchronize; ``ms_per_step`` is the
-MEDIAN over the timed units of (unit / batches in it) / steps, the spread and the wall clock of the whole region are
-reported too.  On one GPU a batch is ONE call into the library (pk_eval_cycle_dev_repeat): it enqueues the ``steps`` launches
-from C, or replays them as one hipGraph of ``steps`` kernel nodes -- both forms are timed on a short stretch and the faster
-one on this box carries the region (``timing.batch_launch``; under a profiler that makes launches expensive it is the
-graph; POCKIT_AMD_BENCH_GRAPH=0 / 1 forces plain launches / the graph).
+Timing of ``value``: after the warm-up cycles, R back-to-back batches of EXACTLY ``steps`` cycles (R such that the region
+lasts >= 0.2 s), each batch bracketed by the host clock -- a cycle ends with its Hessian in host memory, so the host clock
+sees all of it --, the whole region by synchronize (+ barrier); ``ms_per_step`` = median batch / steps (max over ranks).
+Timing of ``device_resident``: a cycle there is ONE 5 us launch; R batches of ``steps`` launches enqueued by the library
+(or replayed as a hipGraph, whichever is faster on the box), HIP events on the launch stream every >= 200 cycles, median.
 
 One JSON line is printed by rank 0 (see the repository prompt for the contract), carrying ``roofline`` for the
-dominant kernel (per-dispatch HIP events on the launch stream) and ``cpu_baseline`` (the oracle = CPU restatement of
-the reference, timed on the host).
+dominant kernel (HIP events on the launch stream over the device-resident region) and ``cpu_baseline`` (the oracle =
+CPU restatement of the reference, timed on the host on the same five callbacks).
 """
 import os
 
@@ -63,6 +61,8 @@ SHARDING_NOTE = {
                  "unpack of the owned runs of grad/g/J/H, tiny all-reduce of the partial sums",
 }
 HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+HBM_ACHIEVABLE_GBPS = 6300.0   # what the guide's stream-type kernels reach (MI355X_MICROARCH.md: "~6.3 TB/s achievable")
+LAUNCH_FLOOR_US = 4.3          # a pk_cycle-shaped launch before its first output byte leaves
 KERNEL_IDS = {"pk_int": 0, "pk_fin": 1, "pk_g": 2, "pk_grad": 3, "pk_jac": 4, "pk_hess": 5, "pk_xall": 6, "pk_cycle": 12}
 MIN_REGION_S = 0.05        # the timed region lasts at least this long (R batches of `steps` cycles)
 EVENT_SPACING = 200        # cycles between two timing events of the region (an event costs ~3 us of GPU time)
@@ -127,17 +127,98 @@ def cpu_baseline(name, intervals, budget_s=12.0, max_cycles=5000):
                       f"NumPy oracle, 1 thread of {os.cpu_count()} host CPUs"}
 
 
-def end_to_end(system, guess, warm=20, timed=100):
-    """the five callbacks through ``System`` with host NumPy arrays in and out (what cyipopt
-    calls, optimizer/ipopt.py), every cycle on a NEW x (so nothing is served from the previous iterate); median over
-    ``timed`` cycles after ``warm`` warm-up cycles, and the median time of every callback."""
+def solver_inputs(system, guess):
+    """x of consecutive cycles: two arrays with different values used in turn (every cycle sees a new x; a solver's iterate
+    was just written by the solver, i.e. it is warm in the host's caches -- two arrays keep that, eight 4.8 MB arrays of
+    the 40k-node system would come from DRAM every time)."""
     from pockit_amd import benchmarks as models
 
     x, lam, sigma = models.bench_inputs(system, guess)
-    xs = [x * (1.0 + 1e-9 * k) for k in range(8)]
+    return [x * (1.0 + 1e-9 * k) for k in range(2)], lam, sigma
+
+
+def pcie_floor(plan, shipped_J):
+    """The link of THIS box for the cycle's four transfers -- x up, [J (changing part) | grad f | g] down, lambda up, H down --
+    each as ONE pinned DMA + synchronize (what tools/pcie_probe.py measures), median of 30: the floor the host-landed
+    cycle is read against (``end_to_end.pcie_frac`` = floor / measured cycle)."""
+    import torch
+
+    dev = torch.device("cuda", torch.cuda.current_device())
+    sizes = {"x_up": plan.n, "xpart_down": shipped_J + plan.n + plan.m, "lambda_up": plan.m, "hess_down": plan.nnz_H}
+    out, total = {}, 0.0
+    for name, count in sizes.items():
+        d = torch.zeros(max(count, 1), dtype=torch.float64, device=dev)
+        hbuf = torch.zeros(max(count, 1), dtype=torch.float64).pin_memory()
+        src, dst = (hbuf, d) if name.endswith("_up") else (d, hbuf)
+        for _ in range(5):
+            dst.copy_(src, non_blocking=True)
+        torch.cuda.synchronize()
+        ts = []
+        for _ in range(30):
+            t0 = time.perf_counter()
+            dst.copy_(src, non_blocking=True)
+            torch.cuda.synchronize()
+            ts.append(time.perf_counter() - t0)
+        us = statistics.median(ts) * 1e6
+        out[name] = {"MB": 8 * count / 1e6, "us": us, "GBps": 8 * count / us / 1e3}
+        total += us
+    out["floor_us"] = total
+    return out
+
+
+def five_callbacks(system, xk, lam, sigma):
+    system.objective(xk)
+    system.gradient(xk)
+    system.constraints(xk)
+    system.jacobian(xk)
+    system.hessian(xk, lam, sigma)
+
+
+def timed_cycles(cycle, steps, warmup, min_region_s=0.2, max_batches=400):
+    """``warmup`` untimed cycles, then R back-to-back batches of exactly ``steps`` cycles, each batch on the host clock.
+    ``cycle(k)`` runs cycle number k.  Returns the batch durations in seconds."""
+    k = 0
+    for _ in range(max(warmup, 10)):
+        cycle(k)
+        k += 1
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        cycle(k)
+        k += 1
+    est = (time.perf_counter() - t0) / steps
+    R = int(min(max_batches, max(5, -(-min_region_s // (est * steps)))))
+    batches = []
+    for _ in range(R):
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            cycle(k)
+            k += 1
+        batches.append(time.perf_counter() - t0)
+    return batches
+
+
+def end_to_end(system, guess, steps, warmup):
+    """The headline: the five callbacks of ``System`` (what cyipopt calls, optimizer/ipopt.py) with host NumPy arrays in
+    and out, every cycle on a NEW x, every callback returning an array the caller owns (the reference's semantics), in
+    the reference's triplet layout.  Beside it: the time of every callback, the same with zero-copy views / the compact
+    Hessian layout, all five outputs from one call, and the PCIe floor of this box measured in the same run."""
+    import torch
+
+    xs, lam, sigma = solver_inputs(system, guess)
     ev = system.evaluator
     names = ("objective", "gradient", "constraints", "jacobian", "hessian")
     out = {}
+    torch.cuda.synchronize()
+    t_region = time.perf_counter()
+    batches = timed_cycles(lambda k: five_callbacks(system, xs[k & 1], lam, sigma), steps, warmup)
+    torch.cuda.synchronize()
+    wall = time.perf_counter() - t_region
+    q = sorted(batches)
+    med = statistics.median(batches)
+    out["headline"] = {"ms_per_step": med / steps * 1e3, "cycles_per_s": steps / med, "batches": len(batches), "steps": steps,
+                       "batch_ms_min_p10_p90_max": [q[0] * 1e3, q[int(0.1 * (len(q) - 1))] * 1e3, q[int(0.9 * (len(q) - 1))] * 1e3,
+                                                    q[-1] * 1e3],
+                       "region_wall_s": wall}
     modes = ["fresh_arrays", "zero_copy_views"]
     if ev.src.compact:
         modes.append("fresh_arrays_compact_hessian")      # the same five callbacks for a solver handed the compact H structure
@@ -145,8 +226,8 @@ def end_to_end(system, guess, warm=20, timed=100):
         ev.zero_copy = mode == "zero_copy_views"
         system.set_hessian_layout("compact" if mode.endswith("compact_hessian") else "reference")
         rows = []
-        for k in range(warm + timed):
-            xk = xs[k % len(xs)]
+        for k in range(15 + 100):
+            xk = xs[k & 1]
             t = [time.perf_counter()]
             system.objective(xk)
             t.append(time.perf_counter())
@@ -158,50 +239,60 @@ def end_to_end(system, guess, warm=20, timed=100):
             t.append(time.perf_counter())
             system.hessian(xk, lam, sigma)
             t.append(time.perf_counter())
-            if k >= warm:
+            if k >= 15:
                 rows.append([t[i + 1] - t[i] for i in range(5)] + [t[5] - t[0]])
-        med = [statistics.median(r[i] for r in rows) for i in range(6)]
-        out[mode] = {"cycles_per_s": 1.0 / med[5], "ms_per_cycle": med[5] * 1e3,
-                     "per_callback_ms": {nm: med[i] * 1e3 for i, nm in enumerate(names)},
+        m = [statistics.median(r[i] for r in rows) for i in range(6)]
+        out[mode] = {"cycles_per_s": 1.0 / m[5], "ms_per_cycle": m[5] * 1e3,
+                     "per_callback_ms": {nm: m[i] * 1e3 for i, nm in enumerate(names)},
                      "min_ms_per_cycle": min(r[5] for r in rows) * 1e3, "max_ms_per_cycle": max(r[5] for r in rows) * 1e3}
     ev.zero_copy = False
     system.set_hessian_layout("reference")
     if "fresh_arrays_compact_hessian" in out:
         out["fresh_arrays_compact_hessian"]["hessian_values"] = int(system.plan.nnz_Hc)
         out["fresh_arrays_compact_hessian"]["hessian_values_reference_layout"] = int(system.plan.nnz_H)
-    # all five outputs from ONE call when the caller has lambda at hand (Evaluator.cycle: one pk_cycle launch, five copies
+    # all five outputs from ONE call when the caller has lambda at hand (Evaluator.cycle: one pk_cycle launch, the copies
     # into pinned arrays of the caller's own, one synchronization) -- not what IPOPT's call order allows, shown beside it
     rows = []
-    for k in range(warm + timed):
+    for k in range(15 + 100):
         t0 = time.perf_counter()
-        ev.cycle(xs[k % len(xs)], lam, sigma)
-        if k >= warm:
+        ev.cycle(xs[k & 1], lam, sigma)
+        if k >= 15:
             rows.append(time.perf_counter() - t0)
     out["one_call_cycle"] = {"cycles_per_s": 1.0 / statistics.median(rows), "ms_per_cycle": statistics.median(rows) * 1e3}
     p = system.plan
-    out["bytes_over_pcie_per_cycle"] = 8 * (p.n + p.m + 1 + p.n + p.m + p.nnz_J + p.nnz_H)
-    out["cycles"] = {"warmup": warm, "timed": timed, "statistic": "median"}
+    kept = sum(b - a for a, b in ev.jac_constant_runs)
+    out["jacobian_values_never_shipped"] = {"count": int(kept), "of": int(p.nnz_J),
+                                            "what": "x-independent entries (translation part, phasebase.py:1071-1081): filled "
+                                                    "into every landing array once, left out of the per-iterate copy"}
+    out["bytes_over_pcie_per_cycle"] = 8 * (p.n + p.m + 1 + p.n + p.m + p.nnz_J - kept + p.nnz_H)
+    try:
+        floor = pcie_floor(p, p.nnz_J - kept)
+        out["pcie"] = floor
+        out["pcie_frac"] = floor["floor_us"] / (out["headline"]["ms_per_step"] * 1e3)
+        out["pcie_frac_note"] = ("floor = x up + [J (changing part) | grad f | g] down + lambda up + H down, each measured here as "
+                                 "ONE pinned DMA + synchronize; pcie_frac = floor / measured cycle")
+    except Exception as exc:  # noqa: BLE001
+        out["pcie"] = {"error": repr(exc)}
     out["what"] = ("objective, gradient, constraints, jacobian, hessian of System on a new x per cycle, NumPy arrays in "
-                   "and out; fresh_arrays: every callback returns an array the caller owns (the reference's semantics; "
-                   "pinned memory the DMA wrote directly), zero_copy_views: views of the context's pinned buffers "
+                   "and out; headline / fresh_arrays: every callback returns an array the caller owns (the reference's "
+                   "semantics; pinned memory the copy wrote directly), zero_copy_views: views of the context's pinned buffers "
                    "(what the IPOPT adapter enables, cyipopt copies at once); fresh_arrays_compact_hessian: the same with "
                    "System.set_hessian_layout('compact') -- one Hessian value per distinct position of a node (SURVEY 8(f) rank "
-                   "1), an optional mode with fewer bytes over PCIe, not the headline")
+                   "1), an optional mode with fewer bytes over PCIe")
     return out
 
 
-def host_sharded_end_to_end(name, intervals, rank, world, dist, warm=10, timed=60):
-    """N > 1: the five callbacks with host arrays, every rank landing its slices in ONE shared pinned host array over its
-    own PCIe link (pockit_amd.hostshard; SURVEY 8(e) "each GPU D2H's its own slices straight into the pinned host
-    array").  Rank 0 plays the solver, the other ranks serve.  Every rank walks through the same collectives whatever
-    fails locally."""
+def host_sharded_end_to_end(name, intervals, rank, world, dist, steps, warmup):
+    """N > 1, the headline: the five callbacks with host arrays, every rank landing its slices in ONE shared pinned host
+    array over its own PCIe link (pockit_amd.hostshard; SURVEY 8(e) "each GPU D2H's its own slices straight into the pinned
+    host array") -- the form that hands a host-side solver the reassembled COO triplets.  Rank 0 plays the solver, the other
+    ranks serve.  Every rank walks through the same collectives whatever fails locally."""
     import torch
 
-    from pockit_amd import benchmarks as models
     from pockit_amd.hostshard import HostShardedEvaluator
     import pockit_amd.radau as radau
 
-    hs, problem = None, None
+    hs, problem, system = None, None, None
     try:
         system, _, guess = build_workload(name, intervals, radau)
         hs = HostShardedEvaluator(system.plan, rank, world, dist, device=torch.cuda.current_device(), timeout_s=90.0)
@@ -219,12 +310,14 @@ def host_sharded_end_to_end(name, intervals, rank, world, dist, warm=10, timed=6
         if rank != 0:
             hs.serve()
         else:
-            x, lam, sigma = models.bench_inputs(system, guess)
-            xs = [x * (1.0 + 1e-9 * k) for k in range(8)]
+            xs, lam, sigma = solver_inputs(system, guess)
             names = ("objective", "gradient", "constraints", "jacobian", "hessian")
+            batches = timed_cycles(lambda k: five_callbacks(hs, xs[k & 1], lam, sigma), steps, warmup)
+            med = statistics.median(batches)
+            q = sorted(batches)
             rows = []
-            for k in range(warm + timed):
-                xk = xs[k % len(xs)]
+            for k in range(40):
+                xk = xs[k & 1]
                 t = [time.perf_counter()]
                 hs.objective(xk)
                 t.append(time.perf_counter())
@@ -236,15 +329,15 @@ def host_sharded_end_to_end(name, intervals, rank, world, dist, warm=10, timed=6
                 t.append(time.perf_counter())
                 hs.hessian(xk, lam, sigma)
                 t.append(time.perf_counter())
-                if k >= warm:
-                    rows.append([t[i + 1] - t[i] for i in range(5)] + [t[5] - t[0]])
-            med = [statistics.median(r[i] for r in rows) for i in range(6)]
+                rows.append([t[i + 1] - t[i] for i in range(5)])
+            per = [statistics.median(r[i] for r in rows) for i in range(5)]
             p = system.plan
             finite = bool(np.isfinite(hs.h_out).all() and np.isfinite(hs.h_f[0]))
-            out = {"cycles_per_s": 1.0 / med[5], "ms_per_cycle": med[5] * 1e3,
-                   "per_callback_ms": {nm: med[i] * 1e3 for i, nm in enumerate(names)},
+            out = {"cycles_per_s": steps / med, "ms_per_cycle": med / steps * 1e3, "batches": len(batches), "steps": steps,
+                   "batch_ms_min_p10_p90_max": [q[0] * 1e3, q[int(0.1 * (len(q) - 1))] * 1e3, q[int(0.9 * (len(q) - 1))] * 1e3,
+                                                q[-1] * 1e3],
+                   "per_callback_ms": {nm: per[i] * 1e3 for i, nm in enumerate(names)},
                    "bytes_to_host_per_cycle": 8 * (1 + p.n + p.m + p.nnz_J + p.nnz_H), "ranks": world, "finite": finite,
-                   "cycles": {"warmup": warm, "timed": timed, "statistic": "median"},
                    "what": "objective, gradient, constraints, jacobian, hessian on a new x per cycle with NumPy arrays in and "
                            "out; every rank evaluates its share of the mesh intervals and its run-copy kernel stores its "
                            "own slices straight into ONE shared pinned host array over its own PCIe link; rank 0 adds the "
@@ -622,7 +715,7 @@ class GpuWorkload:
         self.sev.close()
 
 
-def measure(name, intervals, steps, warmup, rank, world, dist, with_side=True, with_e2e=True):
+def measure(name, intervals, steps, warmup, rank, world, dist, with_side=True, with_e2e=True, e2e_steps=None, e2e_warmup=None):
     """Everything the JSON line says about one workload on this rank."""
     w = GpuWorkload(name, intervals, rank, world, dist)
     batch_ms, wall, untimed = w.timed_region(steps, warmup)
@@ -694,6 +787,8 @@ def measure(name, intervals, steps, warmup, rank, world, dist, with_side=True, w
         dist.all_gather_object(allr, mine)
         res["ranks"] = allr
     res["finite"] = w.finite()
+    if world > 1:
+        res["multi_gpu"] = multi_gpu_facts(w.torch, dist, rank, world, w)
     # (the supplementary figures must not cost the headline: a failure is reported in their place)
     try:
         res["side"] = w.side_kernels() if (with_side and world == 1) else {}
@@ -706,13 +801,49 @@ def measure(name, intervals, steps, warmup, rank, world, dist, with_side=True, w
 
         try:
             system, _, guess = build_workload(name, intervals, radau)
-            res["end_to_end"] = end_to_end(system, guess)
+            res["end_to_end"] = end_to_end(system, guess, e2e_steps or steps, e2e_warmup if e2e_warmup is not None else warmup)
             system._invalidate()
         except Exception as exc:  # noqa: BLE001
             res["end_to_end"] = {"error": repr(exc)}
     if with_e2e and world > 1:
-        res["end_to_end_host_sharded"] = host_sharded_end_to_end(name, intervals, rank, world, dist)
+        res["end_to_end_host_sharded"] = host_sharded_end_to_end(name, intervals, rank, world, dist, e2e_steps or steps,
+                                                                  e2e_warmup if e2e_warmup is not None else warmup)
     return res
+
+
+def multi_gpu_facts(torch, dist, rank, world, w):
+    """What the N > 1 line says about the machine it ran on: the ranks RCCL saw, every rank's device, the peer-access
+    matrix between the ranks' devices, and which device-resident exchange form carried the side figures and why (all
+    ranks take part: collectives only, no local failure changes the sequence)."""
+    try:
+        props = torch.cuda.get_device_properties(torch.cuda.current_device())
+        mine = {"rank": rank, "device": int(torch.cuda.current_device()), "name": props.name,
+                "visible_devices": int(torch.cuda.device_count())}
+    except Exception as exc:  # noqa: BLE001
+        mine = {"rank": rank, "error": repr(exc)}
+    devs = [None] * world
+    dist.all_gather_object(devs, mine)
+    row = []
+    for other in devs:
+        try:
+            a, b = mine.get("device"), other.get("device")
+            row.append(None if (a is None or b is None) else (True if a == b and other["rank"] == rank else
+                                                               bool(torch.cuda.can_device_access_peer(a, b)) if a != b else "same device"))
+        except Exception as exc:  # noqa: BLE001
+            row.append(repr(exc))
+    rows = [None] * world
+    dist.all_gather_object(rows, row)
+    try:
+        backend = str(dist.get_backend())
+    except Exception:  # noqa: BLE001
+        backend = "unknown"
+    return {"ranks_seen_by_rccl": int(dist.get_world_size()), "backend": backend + (" (= RCCL on ROCm)" if backend == "nccl" else
+                                                                                   " (rehearsal: NOT a measurement)"),
+            "devices": devs, "peer_access": rows,
+            "headline_form": "host-landed sharded cycle (every GPU lands its slices in one host array over its own PCIe link): "
+                             "the form that hands a host-side solver the reassembled COO triplets",
+            "device_resident_form": w.exchange, "device_resident_form_fallback": getattr(w, "exchange_fallback", None),
+            "peer_exchange_error": getattr(w, "peer_error", None)}
 
 
 def cold_compile_seconds(name, intervals):
@@ -816,8 +947,29 @@ def main():
             except Exception as exc:  # noqa: BLE001
                 strong[f"{nm}_{iv}_strong_scaled_over_{world}"] = {"error": repr(exc)}
 
+    # ---- the headline: the solver-visible (host-landed) cycle; the device-resident launch rate stays beside it
+    e2e = res.get("end_to_end") if world == 1 else res.get("end_to_end_host_sharded")
+    head_ms, basis = None, None
+    if rank == 0 and isinstance(e2e, dict) and "error" not in e2e:
+        if world == 1 and "headline" in e2e:
+            head_ms = e2e["headline"]["ms_per_step"]
+            basis = ("host-landed cycle: the five callbacks of System on a new x, NumPy arrays in, caller-owned NumPy arrays out, "
+                     "reference triplet layout (end_to_end.headline)")
+        elif world > 1 and "ms_per_cycle" in e2e:
+            head_ms = e2e["ms_per_cycle"]
+            basis = ("host-landed sharded cycle: the five callbacks on rank 0, every GPU landing its slices of grad f / g / J / H in "
+                     "ONE pinned host array over its own PCIe link (end_to_end_host_sharded)")
+    if world > 1:          # every rank prints / decides on rank 0's figure
+        box = [head_ms, basis]
+        dist.broadcast_object_list(box, src=0)
+        head_ms, basis = box
     if rank == 0:
-        value = n_gpus * 1e3 / ms
+        dev_value = n_gpus * 1e3 / ms
+        if head_ms is None:        # no host-landed figure (--no-end-to-end, or it failed): the device-resident rate, said so
+            head_ms = ms
+            basis = ("DEVICE-RESIDENT launch rate (x, lambda and all outputs stay in HBM): the host-landed cycle was not "
+                     "measured in this run" + (f" ({e2e.get('error')})" if isinstance(e2e, dict) and e2e.get("error") else ""))
+        value = n_gpus * 1e3 / head_ms
         dom = res["dominant"]
         dom_bytes = res["bytes"][dom[3:]] / n_gpus
         x_once = res["bytes"]["cycle_x_once"] / n_gpus if dom == "pk_cycle" else None
@@ -826,39 +978,68 @@ def main():
         # several launches, or N > 1 (the region holds the exchange too), uses the per-dispatch events
         dom_us = ms * 1e3 if (dom == "pk_cycle" and n_gpus == 1) else res["dispatch_isolated_us"]
         achieved = dom_bytes / (dom_us * 1e-6) / 1e9 if dom_us else None
-        traffic = None
+        traffic, profiled = None, None
         tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
         if os.path.exists(tpath):
             try:
-                traffic = json.load(open(tpath)).get(f"{args.workload}_{intervals}", {}).get(dom)
+                rec = json.load(open(tpath)).get(f"{args.workload}_{intervals}", {})
+                traffic = rec.get(dom)
+                profiled = rec.get(dom + "_profiled")     # {"avg_ns": ..., "calls": ..., "file": "profiles/..."} of the committed trace
             except Exception:
                 traffic = None
+        out_bytes = 8 * (1 + res["n"] + res["m"] + res["nnz_J"] + res["nnz_H"]) / n_gpus
+        regime = ("hbm" if out_bytes > 256 * 2**20 else ("latency" if (dom_us and dom_us < 2 * LAUNCH_FLOOR_US) else "mall"))
         line = {
             "metric": "NLP-callback cycles/sec (f + grad f + g + J + H)",
             "value": value,
             "unit": "cycles/s" if n_gpus == 1 else "12k-node-equivalent cycles/s",
             "n_gpus": n_gpus, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": ms,
+            "ms_per_step": head_ms,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
+            "value_basis": basis,
             "config": {"workload": f"{args.workload} LGR {intervals} intervals x {POINTS.get(args.workload.replace('_lgl', ''), 0)}"
                                    f" points ({res['nodes']} nodes; n={res['n']}, m={res['m']}, nnz_J={res['nnz_J']}, "
                                    f"nnz_H={res['nnz_H']})",
-                       "sharding": "single GPU" if n_gpus == 1 else SHARDING_NOTE[res["exchange"]].format(n=n_gpus),
+                       "sharding": ("single GPU" if n_gpus == 1 else
+                                    f"mesh intervals over {n_gpus} GPUs (shares balanced by output volume); every rank uploads x over "
+                                    f"its own PCIe link, evaluates its tiles and stores its owned runs of grad f / g / J / H straight "
+                                    f"into ONE pinned host array shared by the ranks; rank 0 adds the partial sums in rank order -- "
+                                    f"no collective in the data path (device-resident side forms: see device_resident)"),
                        "tiles": res["tiles"], "intervals_per_wave": res["ipw"],
                        "inputs": "example guess*(1+1e-3 U(-1,1)) seed 0; lambda N(0,1) seed 1; sigma 1"},
-            "timing": {"region": f"{res['batches']} back-to-back batches of exactly {args.steps} cycles (>= {MIN_REGION_S * 1e3:.0f} ms "
-                                 f"in total), a HIP event on the launch stream after every {res['event_group']} batches (an event "
-                                 f"drains the stream: ~3 us each), barrier + synchronize around the region; ms_per_step = median "
-                                 f"over the timed units of (unit duration / {res['event_group']} batches) / steps (max over ranks)",
-                       "batches": res["batches"], "batches_per_timing_event": res["event_group"],
-                       "batch_launch": res["batch_launch"],
-                       "median_batch_ms": res["median_batch_ms"],
-                       "batch_ms_min_p10_p90_max": [res["batch_ms_min"], res["batch_ms_p10"], res["batch_ms_p90"], res["batch_ms_max"]],
-                       "region_wall_s": res["region_wall_s"], "wall_ms_per_step_whole_region": wall_ms,
-                       "untimed_launches_before_the_region": res["untimed_launches"]},
+            "timing": {"region": ("R back-to-back batches of exactly `steps` host-landed cycles on the host clock (a cycle ends with "
+                                  "its Hessian in host memory), synchronize (+ barrier) around the region; ms_per_step = median "
+                                  "batch / steps; see end_to_end" + ("" if n_gpus == 1 else "_host_sharded")),
+                       "headline": (e2e.get("headline") if (isinstance(e2e, dict) and n_gpus == 1) else
+                                    ({k: e2e.get(k) for k in ("batches", "steps", "batch_ms_min_p10_p90_max")}
+                                     if isinstance(e2e, dict) else None))},
+            "device_resident": {
+                "value": dev_value, "unit": "cycles/s" if n_gpus == 1 else "12k-node-equivalent cycles/s", "ms_per_step": ms,
+                "what": ("the same cycle with x and lambda resident in HBM and all outputs left in HBM: ONE pk_cycle launch per "
+                         "cycle" + ("" if n_gpus == 1 else f" and GPU, exchange form '{res['exchange']}': "
+                                    + SHARDING_NOTE[res["exchange"]].format(n=n_gpus))),
+                "timing": {"region": f"{res['batches']} back-to-back batches of exactly {args.steps} cycles (>= {MIN_REGION_S * 1e3:.0f} ms "
+                                     f"in total), a HIP event on the launch stream after every {res['event_group']} batches (an event "
+                                     f"drains the stream: ~3 us each), barrier + synchronize around the region; ms_per_step = median "
+                                     f"over the timed units of (unit duration / {res['event_group']} batches) / steps (max over ranks)",
+                           "batches": res["batches"], "batches_per_timing_event": res["event_group"],
+                           "batch_launch": res["batch_launch"],
+                           "median_batch_ms": res["median_batch_ms"],
+                           "batch_ms_min_p10_p90_max": [res["batch_ms_min"], res["batch_ms_p10"], res["batch_ms_p90"], res["batch_ms_max"]],
+                           "region_wall_s": res["region_wall_s"], "wall_ms_per_step_whole_region": wall_ms,
+                           "untimed_launches_before_the_region": res["untimed_launches"]}},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBPS,
                          "unit": "GB/s", "frac": (achieved / HBM_PEAK_GBPS if achieved else None), "traffic": traffic,
+                         "regime": regime,
+                         "regime_note": ("latency: the launch lasts less than twice the ~4.3 us a launch of this shape costs before "
+                                         "its first byte leaves; mall: the outputs of one launch (rewritten every cycle) fit the "
+                                         "256 MiB Infinity Cache, FETCH/WRITE_SIZE count fabric requests; hbm: they do not"),
+                         "frac_of_achievable": (achieved / HBM_ACHIEVABLE_GBPS if achieved else None),
+                         "achievable_peak": HBM_ACHIEVABLE_GBPS,
+                         "frac_profiled": ((dom_bytes / (profiled["avg_ns"] * 1e-9) / 1e9 / HBM_PEAK_GBPS)
+                                           if (profiled and profiled.get("avg_ns")) else None),
+                         "profiled": profiled,
                          "algorithmic_bytes_per_launch": dom_bytes,
                          "avg_launch_us": dom_us,
                          "frac_x_once": (x_once / (dom_us * 1e-6) / 1e9 / HBM_PEAK_GBPS if (x_once and dom_us) else None),
@@ -868,7 +1049,8 @@ def main():
                                                     if res["dispatch_isolated_us"] else None),
                          "dispatch_in_flight_us": res["dispatch_in_flight_us"],
                          "dispatch_samples_isolated_in_flight": res["dispatch_samples"],
-                         "timing": ("avg_launch_us: HIP events on the launch stream around every batch of the timed region, median "
+                         "timing": ("measured on the device-resident region (device_resident.timing).  avg_launch_us: HIP events on "
+                                    "the launch stream around every batch of that region, median "
                                     "batch / steps -- one launch plus the gap to the next one, i.e. an upper bound of the "
                                     "kernel's own duration in this run (the launches of a stream do not overlap); "
                                     "dispatch_isolated_us: start / stop events attached to the dispatch "
@@ -876,7 +1058,7 @@ def main():
                                     "the same per-dispatch events on every 64th launch of a back-to-back run (start is stamped "
                                     "when the packet is taken up, before the launch ahead of it has drained).  A kernel trace "
                                     "(rocprofv3) slows the loop it observes (profiles/README.md): its per-kernel average lies "
-                                    "between these figures"
+                                    "between these figures; frac_profiled = the same bytes over the committed trace's average"
                                     if (dom == "pk_cycle" and n_gpus == 1) else
                                     "avg_launch_us: start / stop events attached to the dispatch, stream idle before each "
                                     "sampled launch")},
@@ -888,11 +1070,13 @@ def main():
                 "ms_per_step": res["exchange_forms_ms_per_step"],
                 "equivalent_cycles_per_s": {k: (n_gpus * 1e3 / v if isinstance(v, float) else v)
                                             for k, v in res["exchange_forms_ms_per_step"].items()},
-                "note": "sums: slices stay in each GPU's HBM, only the sums over all nodes are exchanged (pk_xchg, peer "
+                "note": "device-resident forms of a sharded cycle.  sums: slices stay in each GPU's HBM, only the sums over all "
+                        "nodes are exchanged (pk_xchg, peer "
                         "mailboxes); direct: reassembly on rank 0's GPU by peer stores over xGMI; gather: RCCL gather of "
                         "the packed runs to rank 0.  The reassembling forms move one shard per peer into ONE GPU every "
                         "cycle and are bound by that GPU's xGMI links"}),
             "ranks": res["ranks"],
+            "multi_gpu": res.get("multi_gpu"),
             "exchange_check": res.get("exchange_check"),
             "kernel_us": res["kernel_us"],
             "cycle_algorithmic_bytes": res["bytes"]["cycle"],
@@ -912,12 +1096,9 @@ def main():
         if not args.no_cpu_baseline and n_gpus == 1:
             cb = cpu_baseline(args.workload, intervals)      # (required by the contract: a failure here is a failure of the run)
             line["cpu_baseline"] = cb
-            if res["end_to_end"] is not None and "fresh_arrays" in res["end_to_end"]:
-                e2e = res["end_to_end"]["fresh_arrays"]["cycles_per_s"]
-                line["speedup_vs_cpu_baseline"] = e2e / cb["value"]
-                line["speedup_basis"] = ("end_to_end.fresh_arrays (host arrays in and out, like the CPU baseline's cycle) / "
-                                         "cpu_baseline")
-            line["device_resident_ratio_vs_cpu_baseline"] = value / cb["value"]
+            line["speedup_vs_cpu_baseline"] = value / cb["value"]
+            line["speedup_basis"] = "value (" + basis.split(":")[0] + ") / cpu_baseline, both host arrays in and out"
+            line["device_resident_ratio_vs_cpu_baseline"] = dev_value / cb["value"]
         if not args.no_extra and n_gpus > 1:
             line["other_workloads"] = strong
         if not args.no_extra and n_gpus == 1:
@@ -926,7 +1107,8 @@ def main():
                            ("humanoid_wbc", 5000), ("planar_quadrotor_lgl", 2000)):
                 try:
                     r = measure(nm, iv, args.steps, min(args.warmup, 500), 0, 1, None,
-                                with_side=(nm == "humanoid_wbc"), with_e2e=(nm == "humanoid_wbc" and not args.no_end_to_end))
+                                with_side=(nm == "humanoid_wbc"), with_e2e=(nm == "humanoid_wbc" and not args.no_end_to_end),
+                                e2e_steps=min(args.steps, 20), e2e_warmup=5)
                     b = r["bytes"][r["dominant"][3:]]
                     e = {"nodes": r["nodes"], "cycles_per_s": 1e3 / r["ms_per_step"], "ms_per_step": r["ms_per_step"],
                          "batches": r["batches"], "dominant": r["dominant"], "dispatch_isolated_us": r["dispatch_isolated_us"],

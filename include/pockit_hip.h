@@ -56,6 +56,8 @@ typedef struct pk_model_desc {
   int32_t lds_e;        /* LDS doubles per wave of the mesh error estimation kernel (pk_err)      */
   int32_t tab_cap;      /* PK_TAB_CAP the code object was compiled with: entries of a staged pattern table, 64 or 256 */
   int32_t sharded;      /* 1 if the code object was generated with PK_SHARDED (in-launch exchange between GPUs)       */
+  int32_t lds_jc;       /* LDS doubles per wave of the compact Jacobian kernel (pk_jacc)                                */
+  int32_t ne_jc;        /* scalar expressions of the compact Jacobian                                                   */
 } pk_model_desc;
 
 /* One (model, mesh) instance: sizes plus the table blobs built by pockit_amd/evaluator.py.
@@ -94,6 +96,10 @@ typedef struct pk_problem_desc {
   const int32_t* jac_col;
   const int32_t* hess_row;
   const int32_t* hess_col;
+  /* compact (coalesced) Jacobian layout, optional (nnz_Jc = 0: not available) */
+  const void* items_jacc;
+  int32_t n_items_jacc;
+  int64_t nnz_Jc;
 } pk_problem_desc;
 
 int pk_create(pk_ctx** out, int device_id);
@@ -180,6 +186,14 @@ int pk_host_free(void* p);
  * contracted first (mu = I^T lambda) and entries of a node with equal (row, col) are summed, so one value per
  * distinct position is produced.  Layout: pockit_amd.transcription.SystemPlan.hessc_row/col. */
 int pk_eval_hessc(pk_ctx* ctx, const double* x, const double* lambda, double sigma, double* vals /* nnz_Hc */);
+/* Compact Jacobian (the other half of SURVEY.md 8(f) rank 1): the reference repeats every derivative entry of a dynamics
+ * function for each nonzero of the integration matrix (phasebase.py:885-887,1120-1124); where the entry's column is the
+ * same on every node (t_0, t_f, a static parameter) that is K triplets on one (row, column).  pk_jacc contracts such
+ * entries with the integration block first -- one value per defect row -- and sums scalar items that meet on one
+ * position; entries with a per-node column keep the reference's form.  Layout: SystemPlan.jacc_row/col; scatter-added, the
+ * triplets give the matrix SystemBase.jacobian (systembase.py:676-693) assembles to. */
+int pk_eval_jacc(pk_ctx* ctx, const double* x, double* vals /* nnz_Jc */);
+int pk_eval_jacc_dev(pk_ctx* ctx, const double* d_x, double* d_vals, void* stream);
 int pk_eval_hessc_dev(pk_ctx* ctx, const double* d_x, const double* d_lambda, double sigma, double* d_vals,
                       void* stream);
 
@@ -285,7 +299,7 @@ int pk_copy_runs_dev(pk_ctx* ctx, const int64_t* d_table, int n_chunks, const do
 
 /* HIP-event timing of the individual kernels on the launch stream.
  * kernel ids: 0 pk_int, 1 pk_fin, 2 pk_g, 3 pk_grad, 4 pk_jac, 5 pk_hess, 6 pk_xall, 7 pk_aux, 8 pk_outer,
- * 9 pk_hessc, 10 pk_err, 11 pk_csr, 12 pk_cycle, 13 pk_xchg, 14 pk_runs.  pk_profile_sampling(n): only every n-th launch of a selected kernel is timed (a timed
+ * 9 pk_hessc, 10 pk_err, 11 pk_csr, 12 pk_cycle, 13 pk_xchg, 14 pk_runs, 15 pk_jacc.  pk_profile_sampling(n): only every n-th launch of a selected kernel is timed (a timed
  * launch costs ~2-3 us more than a plain one, so timing every launch slows the loop being measured). */
 int pk_profile(pk_ctx* ctx, int kernel_mask /* bit k: time kernel k; 0 = off */);
 int pk_profile_sampling(pk_ctx* ctx, int period);

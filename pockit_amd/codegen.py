@@ -174,7 +174,8 @@ class ModelSource:
         if self.big and plan.outer:
             raise NotImplementedError("num_point > 64 together with system functions nonlinear in the integrals")
         self.compact = not plan.outer
-        for cbname in ("jac", "hess", "aux") + (("hessc",) if self.compact else ()):
+        self.compact_j = not self.big             # (the compact Jacobian has no workgroup-per-interval path)
+        for cbname in ("jac", "hess", "aux") + (("hessc",) if self.compact else ()) + (("jacc",) if self.compact_j else ()):
             cb = getattr(plan, cbname)
             off, table = 0, {}
             for key in self.list_keys:
@@ -317,6 +318,38 @@ class ModelSource:
             S.append("  static constexpr int HC_NN = 0;")
             S.append(f"  __device__ static __forceinline__ void mid_hessc({sig_c}, double* __restrict__ o) {{}}")
 
+        # ---- compact Jacobian: expanded (per-node column), contracted (dense column) and per-node entries ----
+        if self.compact_j:
+            cb = plan.jacc
+            segs = cb.segs[k]
+            ci = [sg for sg in segs if sg.kind == "I"]
+            cd = [sg for sg in segs if sg.kind == "D"]
+            cn = [sg for sg in segs if sg.kind == "N"]
+            S.append(f"  static constexpr int JC_NI = {len(ci)}, JC_ND = {len(cd)}, JC_NN = {len(cn)};")
+            S.append(f"  __device__ static __forceinline__ void mid_jacc({sig_node}, double* __restrict__ o) {{")
+            S.append(_emit_body([(f"o[{e}]", sg.expr) for e, sg in enumerate(ci + cd + cn)], base, nm))
+            S.append("  }")
+            for wname, attr in (("front", "front"), ("back", "back")):
+                S.append(f"  __device__ static __forceinline__ void {wname}_jacc_dense({sig_node}, double* __restrict__ o) {{")
+                S.append(_emit_body([(f"o[{e}]", getattr(sg, attr)) for e, sg in enumerate(cd)], base, nm))
+                S.append("  }")
+            S.append("  __device__ static __forceinline__ void jacc_tdense(const double* __restrict__ a, "
+                     "double* __restrict__ otf, double* __restrict__ otb) {")
+            S.append(_emit_body([(f"otf[{e}]", sg.tfront) for e, sg in enumerate(cd)] +
+                                [(f"otb[{e}]", sg.tback) for e, sg in enumerate(cd)], base, nm))
+            S.append("  }")
+            for w, wname in (("f", "front"), ("b", "back")):
+                exprs = cb.lists.get((w, k), [])
+                S.append(f"  __device__ static __forceinline__ void {wname}_jacc({sig_node}, double* __restrict__ E) {{")
+                S.append(_emit_body([(f"E[{e}]", ex) for e, ex in enumerate(exprs)], base, nm))
+                S.append("  }")
+        else:
+            S.append("  static constexpr int JC_NI = 0, JC_ND = 0, JC_NN = 0;")
+            S.append(f"  __device__ static __forceinline__ void mid_jacc({sig_node}, double* __restrict__ o) {{}}")
+            S.append(f"  __device__ static __forceinline__ void front_jacc_dense({sig_node}, double* __restrict__ o) {{}}")
+            S.append(f"  __device__ static __forceinline__ void back_jacc_dense({sig_node}, double* __restrict__ o) {{}}")
+            S.append("  __device__ static __forceinline__ void jacc_tdense(const double*, double*, double*) {}")
+
         # ---- dense objective gradient ----
         slots = plan.grad_red_slots[k]
         S.append(f"  static constexpr int GR_NR = {len(slots)};")
@@ -360,7 +393,7 @@ class ModelSource:
         S.append(_emit_body([(f"gs[{i}]", plan.grad_static.get(i, sp.Integer(0))) for i in range(plan.n_s)],
                             {}, nm, "  "))
         S.append("}")
-        for cbname in ("jac", "hess", "aux") + (("hessc",) if self.compact else ()):
+        for cbname in ("jac", "hess", "aux") + (("hessc",) if self.compact else ()) + (("jacc",) if self.compact_j else ()):
             exprs = getattr(plan, cbname).lists.get(("s",), [])
             S.append(f"__device__ static __forceinline__ void sys_{cbname}(const PkSys& sy, double* __restrict__ E) {{")
             S.append(_emit_body([(f"E[{e}]", ex) for e, ex in enumerate(exprs)], {}, nm, "  "))
@@ -438,8 +471,9 @@ class ModelSource:
         self.lds_x = 64 * max([1] + [pp.nx * (2 if self.big else 1) + sum(1 for sg in plan.jac.segs[k] if sg.kind == "I")
                                      for k, pp in enumerate(plan.phase_plans)])      # (big: + the node values [NX][256])
         self.lds_e = 64 * max([1] + [2 * pp.nx + pp.nu for pp in plan.phase_plans])
+        self.lds_jc = 64 * max([1] + [sum(1 for sg in plan.jacc.segs[k] if sg.kind in "ID") for k in range(nP)]) if self.compact_j else 64
         S.append(f"  static constexpr int LDS_G = {self.lds_g}, LDS_J = {self.lds_j}, LDS_H = {self.lds_h}, "
-                 f"LDS_X = {self.lds_x}, LDS_E = {self.lds_e};")
+                 f"LDS_X = {self.lds_x}, LDS_E = {self.lds_e}, LDS_JC = {self.lds_jc};")
         S.append("  __device__ static __forceinline__ void interval_err(int phase, const PkArgs& A, int first, int cnt, "
                  "double* __restrict__ lds, int lane) {")
         S.append(switch("pk::interval_err<{P}>(A, first, cnt, lds, lane)"))
@@ -448,7 +482,7 @@ class ModelSource:
                  "double* __restrict__ lds) {")
         S.append(switch("pk::interval_err_big<{P}>(A, first, lds)"))
         S.append("  }")
-        targets = [(n, f"pk::tile_{n}<{{P}}>") for n in ("int", "g", "grad", "jac", "hess", "aux", "hessc")]
+        targets = [(n, f"pk::tile_{n}<{{P}}>") for n in ("int", "g", "grad", "jac", "hess", "aux", "hessc", "jacc")]
         targets += [("xall", "pk::tile_xall<{P}, 0>"), ("xall1", "pk::tile_xall<{P}, 1>"),
                     ("xall2", "pk::tile_xall<{P}, 2>")]
         for name, target in targets:
@@ -514,6 +548,28 @@ class ModelSource:
         else:
             S.append("  static constexpr int HC_NE = 1;")
             S.append("  __device__ static __forceinline__ void edge_hessc(int, const PkArgs&, const PkSys&, double*) {}")
+        if self.compact_j:
+            off = self.list_off["jacc"]
+            S.append(f"  static constexpr int JC_NE = {max(off['total'], 1)};")
+            S.append("  __device__ static __forceinline__ void edge_jacc(int li, const PkArgs& A, const PkSys& sy, "
+                     "double* __restrict__ E) {")
+            S.append("    switch (li) {")
+            for li, key in enumerate(self.list_keys):
+                if key[0] == "s":
+                    S.append(f"      case {li}: sys_jacc(sy, E + {off[key]}); break;")
+                    continue
+                k = key[1]
+                if not plan.jacc.lists.get(key):
+                    continue
+                wname = "front" if key[0] == "f" else "back"
+                S.append(f"      case {li}: {{ double s_[PK_NS], a[P{k}::NARG], tau, dt, w, lp[{ncmax}];")
+                S.append(f"        pk::load_edge<P{k}>(A, {1 if key[0] == 'b' else 0}, s_, a, tau, dt, w, lp);")
+                S.append(f"        const PkSys sy2{{s_, sy.I, sy.sigma, sy.lams}};")
+                S.append(f"        P{k}::{wname}_jacc(a, tau, dt, w, sy2, lp, E + {off[key]}); }} break;")
+            S.append("      default: break;\n    }\n  }")
+        else:
+            S.append("  static constexpr int JC_NE = 1;")
+            S.append("  __device__ static __forceinline__ void edge_jacc(int, const PkArgs&, const PkSys&, double*) {}")
         S.append(f"  static constexpr int NLISTS = {len(self.list_keys)};")
         ints = [(a, plan.I_owner[a][0], self.int_local[plan.I_owner[a][0]].index(a)) for a in self.int_needed]
         S.append(f"  static constexpr int N_INT = {len(ints)};")

@@ -34,6 +34,8 @@ struct PkPhase {
   int32_t ivfull_off;  // ib: db offset of the dense R x K integration block of every interval
   int32_t ivld_off;    // ib: first defect row (within a state) of every interval
   int32_t n_int;       // number of mesh intervals N
+  int32_t jcseg_off;   // lb: base offset in the compact Jacobian of every compact segment of the phase (I, then D, then N)
+  int32_t jct_off;     // lb: base offset in the compact Jacobian of the translation piece of every state
 };
 
 // A run of `nj` consecutive intervals of one kind handled by one wavefront (<= 64 nodes).

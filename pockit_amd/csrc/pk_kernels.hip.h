@@ -828,6 +828,88 @@ __device__ __forceinline__ void tile_jac(const PkArgs& A, const PkTile& tl, doub
 }
 
 // ============================================================================================
+// compact Jacobian (transcription.SystemPlan.jacc): the reference emits one triplet per nonzero of
+// the integration matrix for every derivative entry of a dynamics function (phasebase.py:885-887,1120-1124); an entry
+// whose column is the same on every node (t_0, t_f, a static parameter) thereby lands K times on one (row, column).
+// Such "dense-column" entries are contracted with the integration block here, like the defects of pk_g:
+//   out[row r] = -sum_c (I_hat[r, c] d/2) e(c)  (+ what the translation block adds for FUNC boundary values)
+// with e(c) taken from the front / back node's own expression on those nodes; entries with a per-node column keep the
+// reference's expanded form (they are unique).  LDS: [JC_NI expanded | JC_ND dense-column] x 64 lanes.
+// ============================================================================================
+template <class P, bool STAGED>
+__device__ __forceinline__ void write_dense_rows(const PkArgs& A, const PkPhase& ph, const PkTile& tl, const TileGeom& g,
+                                                 const TileTabs& T, const double* __restrict__ a,
+                                                 const double* __restrict__ dsv, const SegBases<P::JC_NI + P::JC_ND + P::JC_NN>& segb,
+                                                 int lane) {
+  constexpr int ND = P::JC_ND > 0 ? P::JC_ND : 1;
+  if (P::JC_ND == 0) return;
+  const int nrows = tl.nj * g.R;
+  if (lane >= nrows) return;
+  const int jj = magic_div((uint32_t)lane, tl.magicR), r = lane - jj * g.R;
+  const double* __restrict__ f = dsv + jj * g.stride;
+  const double* __restrict__ full = STAGED ? T.full + r * g.K : A.db + tl.full_off + r * g.K;
+  const double width = STAGED ? T.wd[jj] : A.db[ph.width_off + tl.j0 + jj];
+  double acc[ND], tf[ND], tb[ND];
+#pragma unroll
+  for (int e = 0; e < P::JC_ND; ++e) acc[e] = 0.0;
+#pragma unroll 4
+  for (int c = 0; c < g.K; ++c) {
+    const double w = full[c] * width * 0.5;      // (I_hat * d) / 2 as the reference scales it
+#pragma unroll
+    for (int e = 0; e < P::JC_ND; ++e) acc[e] += w * f[e * PK_WAVE + c];
+  }
+  P::jacc_tdense(a, tf, tb);                     // (functions of the static parameters: the same on every lane)
+  const bool first = tl.r0 + lane == 0, last_iv = tl.j0 + jj == ph.n_int - 1;
+#pragma unroll
+  for (int e = 0; e < P::JC_ND; ++e)
+    put(&A.o_jac[segb[P::JC_NI + e] + tl.r0 + lane], (first ? tf[e] : 0.0) + (last_iv ? tb[e] : 0.0) - acc[e]);
+}
+
+template <class P>
+__device__ __forceinline__ void tile_jacc(const PkArgs& A, const PkTile& tl, double* __restrict__ sv,
+                                          double* __restrict__, double* __restrict__, int lane) {
+  const PkPhase& ph = A.ph[P::INDEX];
+  const TileGeom g = tile_geom<P>(tl);
+  double s[PK_NS], dt, mt;
+  phase_scalars<P>(A, ph, s, dt, mt);
+  const PkSys sy{s, A.Ibuf, A.sigma, A.lam};
+  SegBases<P::JC_NI + P::JC_ND + P::JC_NN> segb;
+  SegBases<P::NX> tbase;
+  segb.load(A.lb, ph.jcseg_off, lane);
+  tbase.load(A.lb, ph.jct_off, lane);
+  double* __restrict__ dsv = sv + P::JC_NI * PK_WAVE;
+  const bool fit = tabs_fit(A, tl, g);
+  const TabRegs tr = tabs_issue(A, ph, tl, g, fit, lane);
+  const int q = tl.q0 + lane;
+  double a[P::NARG], tau, w;
+  load_node<P>(A, ph, s, dt, mt, q, a, tau, w);
+  const TileTabs T = tabs_commit(A, tl, g, tr, fit, lane);
+  segb.settle();
+  tbase.settle();
+  loads_done();
+  if (lane < g.nq) {
+    double o[P::JC_NI + P::JC_ND + P::JC_NN + 1];
+    P::mid_jacc(a, tau, dt, w, sy, nullptr, o);
+    if (P::JC_ND > 0) {              // the boundary nodes carry their own expressions of the dense-column entries
+      if (q == 0) P::front_jacc_dense(a, tau, dt, w, sy, nullptr, o + P::JC_NI);
+      else if (P::SCHEME == 1 && q == ph.L_m - 1) P::back_jacc_dense(a, tau, dt, w, sy, nullptr, o + P::JC_NI);
+    }
+#pragma unroll
+    for (int e = 0; e < P::JC_NI + P::JC_ND; ++e) sv[e * PK_WAVE + lane] = o[e];
+    if (lane < g.nown && q >= ph.mid_lo && q < ph.mid_hi) {
+#pragma unroll
+      for (int e = 0; e < P::JC_NN; ++e)
+        put(&A.o_jac[segb[P::JC_NI + P::JC_ND + e] + (q - ph.mid_lo)], o[P::JC_NI + P::JC_ND + e]);
+    }
+  }
+  wave_lds_sync();
+  if (tl.nj == 0) return;
+  PK_PHASE_B(T, (write_translation<P, STAGED>(A, ph, tl, T, tbase, lane),
+                 write_dense_rows<P, STAGED>(A, ph, tl, g, T, a, dsv, segb, lane),
+                 stream_expanded<P, P::JC_NI, false, STAGED>(A, ph, tl, g, T, sv, nullptr, segb, A.o_jac, lane)));
+}
+
+// ============================================================================================
 // Hessian of the Lagrangian      (phasebase.py:1211-1337, systembase.py:735-835)
 // ============================================================================================
 template <class P>
@@ -1426,7 +1508,7 @@ __device__ __forceinline__ double block_sum_partials(const PkArgs& A, const doub
 
 #define PK_IS_EDGE_BLOCK() (blockIdx.x == 0)
 
-// mode 0: Jacobian, 1: Hessian, 2: auxiliary buffer, 3: compact Hessian
+// mode 0: Jacobian, 1: Hessian, 2: auxiliary buffer, 3: compact Hessian, 4: compact Jacobian
 template <class Gen>
 __device__ __forceinline__ void edge_block(const PkArgs& A, int mode, bool with_g, const PkItem* __restrict__ items,
                                            int n_items) {
@@ -1441,6 +1523,7 @@ __device__ __forceinline__ void edge_block(const PkArgs& A, int mode, bool with_
       if (mode == 1) Gen::edge_hess(li, A, sy, pk_lds);
       else if (mode == 2) Gen::edge_aux(li, A, sy, pk_lds);
       else if (mode == 3) Gen::edge_hessc(li, A, sy, pk_lds);
+      else if (mode == 4) Gen::edge_jacc(li, A, sy, pk_lds);
       else Gen::edge_jac(li, A, sy, pk_lds);
     }
   __syncthreads();
@@ -1508,6 +1591,13 @@ __device__ __forceinline__ void kernel_hessc(const PkArgs& A) {
   if (PK_IS_EDGE_BLOCK()) return edge_block<Gen>(A, 3, false, A.items, A.n_items);
   PK_TILE_PROLOGUE(1);
   Gen::tile_hessc(tl.phase, A, tl, pk_lds, wint, wgrad, lane);
+}
+
+template <class Gen>
+__device__ __forceinline__ void kernel_jacc(const PkArgs& A) {
+  if (PK_IS_EDGE_BLOCK()) return edge_block<Gen>(A, 4, false, A.items, A.n_items);
+  PK_TILE_PROLOGUE(1);
+  Gen::tile_jacc(tl.phase, A, tl, PK_STAGE(A) + wave * Gen::LDS_JC, wint, wgrad, lane);
 }
 
 template <class Gen>
@@ -2201,6 +2291,7 @@ __device__ __forceinline__ void kernel_fin(const PkArgs& A) {
   extern "C" __global__ __launch_bounds__(PK_BLOCK) void pk_aux(PkArgs A) { pk::kernel_aux<GEN>(A); }   \
   extern "C" __global__ __launch_bounds__(PK_BLOCK) void pk_outer(PkArgs A) { pk::kernel_outer(A); }     \
   extern "C" __global__ __launch_bounds__(PK_BLOCK) void pk_hessc(PkArgs A) { pk::kernel_hessc<GEN>(A); } \
+  extern "C" __global__ __launch_bounds__(PK_BLOCK) void pk_jacc(PkArgs A) { pk::kernel_jacc<GEN>(A); }   \
   extern "C" __global__ __launch_bounds__(PK_BLOCK) void pk_err(PkArgs A) { pk::kernel_err<GEN>(A); }     \
   extern "C" __global__ __launch_bounds__(PK_BLOCK) void pk_csr(PkArgs A) { pk::kernel_csr(A); }             \
   extern "C" __global__ __launch_bounds__(PK_BLOCK) void pk_xchg(PkArgs A) { pk::kernel_xchg<GEN>(A); }     \

@@ -36,9 +36,10 @@
 
 namespace {
 
-enum { K_INT = 0, K_FIN, K_G, K_GRAD, K_JAC, K_HESS, K_XALL, K_AUX, K_OUTER, K_HESSC, K_ERR, K_CSR, K_CYCLE, K_XCHG, K_RUNS, K_COUNT };
+enum { K_INT = 0, K_FIN, K_G, K_GRAD, K_JAC, K_HESS, K_XALL, K_AUX, K_OUTER, K_HESSC, K_ERR, K_CSR, K_CYCLE, K_XCHG, K_RUNS, K_JACC, K_COUNT };
 const char* const kKernelNames[K_COUNT] = {"pk_int", "pk_fin", "pk_g", "pk_grad", "pk_jac", "pk_hess", "pk_xall",
-                                           "pk_aux", "pk_outer", "pk_hessc", "pk_err", "pk_csr", "pk_cycle", "pk_xchg", "pk_runs"};
+                                           "pk_aux", "pk_outer", "pk_hessc", "pk_err", "pk_csr", "pk_cycle", "pk_xchg", "pk_runs",
+                                           "pk_jacc"};
 enum { F_WRITE_F = 1, F_SECONDARY = 2, F_FIN_INT = 8, F_FIN_GRAD = 16, F_SPLIT = 32, F_XCHG = 64 };
 
 thread_local std::string g_create_error;
@@ -79,8 +80,10 @@ struct pk_ctx {
   int32_t n = 0, m = 0, n_sys = 0, n_s = 0, l_s = 0, n_phase = 0, n_tiles = 0;
   int64_t nnz_J = 0, nnz_H = 0;
   int32_t n_items_jac = 0, n_items_hess = 0, n_items_aux = 0, n_outer = 0, n_aux = 0, gz_off = 0, n_gz = 0;
-  int32_t n_items_hessc = 0;
-  int64_t nnz_Hc = 0;
+  int32_t n_items_hessc = 0, n_items_jacc = 0;
+  int64_t nnz_Hc = 0, nnz_Jc = 0;
+  void* d_items_jacc = nullptr;
+  double* d_Jc = nullptr;
   void *d_phases = nullptr, *d_tiles = nullptr, *d_kinds = nullptr, *d_items_jac = nullptr, *d_items_hess = nullptr,
        *d_items_aux = nullptr, *d_outer = nullptr, *d_items_hessc = nullptr;
   double *d_aux = nullptr, *d_Hc = nullptr;
@@ -209,6 +212,7 @@ void release(T*& p) {
 }
 
 void free_problem(pk_ctx* c) {
+  release(c->d_items_jacc); release(c->d_Jc);
   release(c->d_phases); release(c->d_tiles); release(c->d_kinds); release(c->d_items_jac); release(c->d_items_hess); release(c->d_items_aux); release(c->d_outer); release(c->d_aux); release(c->d_items_hessc); release(c->d_Hc);
   release(c->d_erriv); release(c->d_errgrp); release(c->d_errdb); release(c->d_errT); release(c->d_errI);
   c->n_erriv = 0; c->n_err_out = 0;
@@ -283,7 +287,7 @@ int launch_raw(pk_ctx* c, int k, void* args, size_t sz, unsigned grid, size_t ld
   EventPair ev{};
   if (grid == 0) return 0;
   // the tile kernels that stage their pattern tables keep one table block per wave in front of the model's staging area
-  if ((k == K_G || k == K_JAC || k == K_HESS || k == K_XALL || k == K_CYCLE) && !c->static_tabs)
+  if ((k == K_G || k == K_JAC || k == K_HESS || k == K_XALL || k == K_CYCLE || k == K_JACC) && !c->static_tabs)
     lds_bytes += sizeof(double) * PK_WAVES_PER_BLOCK * (size_t)(2 * c->md.tab_cap + 2 * PK_WAVE + c->md.tab_cap / 2);
   if (k == K_CYCLE && c->xc_inline && c->xc_world > 1 && lds_bytes < sizeof(double) * 2 * 512)
     lds_bytes = sizeof(double) * 2 * 512;      // the finalize workgroup's exchange vectors (2 x PK_XC_CAP doubles)
@@ -411,9 +415,12 @@ namespace {
 int copy_async(pk_ctx* c, double* dst, const double* src, size_t n, hipMemcpyKind kind, bool by_kernel) {
   if (!n) return 0;
   if (by_kernel && !(((uintptr_t)dst ^ (uintptr_t)src) & 8)) {
+    // (tools/copy_kernel_probe.cpp: device -> host does not care about the grid, 49-50 GB/s from 32 to 2048 workgroups;
+    //  host -> device prefers FEW workgroups: 0.77 MB 28 us with 64, 32 us with 1024; 4.8 MB 101 vs 123 us)
     const size_t pairs = n / 2 + 1;
     unsigned grid = (unsigned)((pairs + 255) / 256);
-    if (grid > 1024) grid = 1024;
+    const unsigned cap = kind == hipMemcpyHostToDevice ? 64u : 512u;
+    if (grid > cap) grid = cap;
     hipLaunchKernelGGL(pk_copy_kernel, dim3(grid), dim3(256), 0, c->stream, src, dst, n);
     PK_HIP(c, hipGetLastError());
     return 0;
@@ -663,6 +670,7 @@ int pk_set_problem(pk_ctx* c, const pk_problem_desc* pd) {
   c->n_items_jac = pd->n_items_jac; c->n_items_hess = pd->n_items_hess; c->gz_off = pd->gz_off; c->n_gz = pd->n_gz;
   c->n_items_aux = pd->n_items_aux; c->n_outer = pd->n_outer; c->n_aux = pd->n_aux;
   c->n_items_hessc = pd->n_items_hessc; c->nnz_Hc = pd->nnz_Hc;
+  c->n_items_jacc = pd->n_items_jacc; c->nnz_Jc = pd->nnz_Jc;
   // Small meshes are bound by the serial chain of one wave, not by throughput: let two waves share a tile in
   // pk_xall as long as that still leaves at most two waves per SIMD (POCKIT_AMD_SPLIT=0/1 overrides).
   {
@@ -680,6 +688,7 @@ int pk_set_problem(pk_ctx* c, const pk_problem_desc* pd) {
   if ((rc = upload(c, &c->d_items_aux, pd->items_aux, sizeof(PkItem) * (size_t)pd->n_items_aux))) return rc;
   if ((rc = upload(c, &c->d_outer, pd->outer, sizeof(PkOuter) * (size_t)pd->n_outer))) return rc;
   if ((rc = upload(c, &c->d_items_hessc, pd->items_hessc, sizeof(PkItem) * (size_t)pd->n_items_hessc))) return rc;
+  if ((rc = upload(c, &c->d_items_jacc, pd->items_jacc, sizeof(PkItem) * (size_t)pd->n_items_jacc))) return rc;
   if ((rc = upload(c, (void**)&c->d_ib, pd->ib, sizeof(int32_t) * (size_t)pd->n_ib))) return rc;
   if ((rc = upload(c, (void**)&c->d_db, pd->db, sizeof(double) * (size_t)pd->n_db))) return rc;
   if ((rc = upload(c, (void**)&c->d_lb, pd->lb, sizeof(int64_t) * (size_t)pd->n_lb))) return rc;
@@ -692,7 +701,7 @@ int pk_set_problem(pk_ctx* c, const pk_problem_desc* pd) {
   // pieces of J that change with x, grad f and g then leave in one DMA (every extra DMA costs ~10 us on this link)
   if ((rc = dalloc(&c->d_x, c->n)) || (rc = dalloc(&c->d_lam, c->m)) || (rc = dalloc(&c->d_f, 1)) ||
       (rc = dalloc(&c->d_J, (size_t)c->nnz_J + (size_t)c->n + (size_t)c->m)) ||
-      (rc = dalloc(&c->d_H, (size_t)c->nnz_H)) || (rc = dalloc(&c->d_aux, (size_t)c->n_aux)) || (rc = dalloc(&c->d_Hc, (size_t)c->nnz_Hc)) || (rc = dalloc(&c->d_I, c->md.n_I)) ||
+      (rc = dalloc(&c->d_H, (size_t)c->nnz_H)) || (rc = dalloc(&c->d_aux, (size_t)c->n_aux)) || (rc = dalloc(&c->d_Hc, (size_t)c->nnz_Hc)) || (rc = dalloc(&c->d_Jc, (size_t)c->nnz_Jc)) || (rc = dalloc(&c->d_I, c->md.n_I)) ||
       (rc = dalloc(&c->d_partial, (2 * (size_t)c->n_tiles / PK_WAVES_PER_BLOCK + 2) * (size_t)c->md.nred)) ||
       (rc = dalloc(&c->d_partial2, (2 * (size_t)c->n_tiles / PK_WAVES_PER_BLOCK + 2) * (size_t)c->md.nred)))
     return rc;
@@ -870,6 +879,35 @@ int pk_eval_hessc_dev(pk_ctx* c, const double* d_x, const double* d_lam, double 
   A.items = (const PkItem*)c->d_items_hessc;
   A.n_items = c->n_items_hessc;
   return launch(c, K_HESSC, A, tile_blocks(c) + 1, sizeof(double) * (size_t)(c->md.ne_hc > 0 ? c->md.ne_hc : 1), st);
+}
+
+// compact (coalesced) Jacobian: dense-column entries of the dynamics contracted with the integration block first
+int pk_eval_jacc_dev(pk_ctx* c, const double* d_x, double* d_vals, void* stream) {
+  int rc = ready(c);
+  if (rc) return rc;
+  if (c->nnz_Jc <= 0) return fail(c, 52, "pk_eval_jacc: no compact Jacobian layout was supplied to pk_set_problem");
+  hipStream_t st = pick(c, stream);
+  if (c->md.prepass_jac && !c->external_prepass && (rc = prepass(c, d_x, nullptr, 0.0, c->d_f, false, st))) return rc;
+  PkArgs A = base_args(c, d_x, nullptr, 0.0);
+  A.o_jac = d_vals;
+  A.items = (const PkItem*)c->d_items_jacc;
+  A.n_items = c->n_items_jacc;
+  size_t lds = sizeof(double) * PK_WAVES_PER_BLOCK * (size_t)c->md.lds_jc;
+  if (lds < sizeof(double) * (size_t)c->md.ne_jc) lds = sizeof(double) * (size_t)c->md.ne_jc;
+  return launch(c, K_JACC, A, tile_blocks(c) + 1, lds, st);
+}
+
+int pk_eval_jacc(pk_ctx* c, const double* x, double* vals) {
+  int rc = ready(c);
+  if (rc) return rc;
+  if (!x || !vals) return fail(c, 60, "null host buffer");
+  PK_HIP(c, hipSetDevice(c->device));
+  c->x_valid = false;
+  PK_HIP(c, hipMemcpyAsync(c->d_x, x, sizeof(double) * (size_t)c->n, hipMemcpyHostToDevice, c->stream));
+  if ((rc = pk_eval_jacc_dev(c, c->d_x, c->d_Jc, nullptr))) return rc;
+  PK_HIP(c, hipMemcpyAsync(vals, c->d_Jc, sizeof(double) * (size_t)c->nnz_Jc, hipMemcpyDeviceToHost, c->stream));
+  PK_HIP(c, hipStreamSynchronize(c->stream));
+  return 0;
 }
 
 // ---------------------------------------------------------------- device-resident CSR hand-off

@@ -131,11 +131,16 @@ class Tables:
             cbs = [("jac", "jseg_off"), ("hess", "hseg_off"), ("aux", "aseg_off")]
             if src.compact:
                 cbs.append(("hessc", "hcseg_off"))
+            if src.compact_j:
+                cbs.append(("jacc", "jcseg_off"))
             for cbname, field in cbs:
                 segs = getattr(plan, cbname).segs[k]
-                bases = [s.base for s in segs if s.kind == "I"] + [s.base for s in segs if s.kind == "N"]
+                bases = [s.base for s in segs if s.kind == "I"] + [s.base for s in segs if s.kind == "D"] + \
+                        [s.base for s in segs if s.kind == "N"]
                 ph[field] = put(lb, bases, np.int64)
             ph["jt_off"] = put(lb, plan.jac.tconst[k], np.int64)
+            if src.compact_j:
+                ph["jct_off"] = put(lb, plan.jacc.tconst[k], np.int64)
             red = [plan.l_p[k] + s if s >= 0 else plan.r_s + s for s in plan.grad_red_slots[k]]
             ph["red_off"] = put(ib, red, np.int32)
             def empty_tile():
@@ -188,6 +193,7 @@ class Tables:
 
         self.items_jac, self.items_hess, self.items_aux = items("jac"), items("hess"), items("aux")
         self.items_hessc = items("hessc") if src.compact else np.zeros(0, dtype=runtime.ITEM_DTYPE)
+        self.items_jacc = items("jacc") if src.compact_j else np.zeros(0, dtype=runtime.ITEM_DTYPE)
         self.outer = np.zeros(len(plan.outer), dtype=runtime.OUTER_DTYPE)
         for i, b in enumerate(plan.outer):
             flags = (1 if b.tril else 0) | (2 if b.collapseA else 0) | (4 if b.collapseB else 0) | (8 if b.second else 0)
@@ -216,6 +222,8 @@ class Evaluator:
         md.ne_a = self.src.list_off["aux"]["total"]
         md.ne_hc = self.src.list_off["hessc"]["total"] if self.src.compact else 0
         md.lds_e = self.src.lds_e
+        md.lds_jc = self.src.lds_jc
+        md.ne_jc = self.src.list_off["jacc"]["total"] if self.src.compact_j else 0
         md.tab_cap = self.src.tab_cap
         md.sharded = int(self.src.sharded)
         self._err_views = None
@@ -252,6 +260,8 @@ class Evaluator:
         pd.outer, pd.n_outer, pd.n_aux = vp(tb.outer), len(tb.outer), plan.n_aux
         pd.items_hessc, pd.n_items_hessc = vp(tb.items_hessc), len(tb.items_hessc)
         pd.nnz_Hc = plan.nnz_Hc if self.src.compact else 0
+        pd.items_jacc, pd.n_items_jacc = vp(tb.items_jacc), len(tb.items_jacc)
+        pd.nnz_Jc = plan.nnz_Jc if self.src.compact_j else 0
         self._struct = [np.ascontiguousarray(a, dtype=np.int32) for a in
                         (plan.jac_row, plan.jac_col, plan.hess_row, plan.hess_col)]
         pd.jac_row, pd.jac_col, pd.hess_row, pd.hess_col = (a.ctypes.data_as(runtime.c_int32_p) for a in self._struct)
@@ -471,6 +481,16 @@ class Evaluator:
         self._callback_x(2, x)
         out = np.empty(self.plan.nnz_Hc)
         self.ctx.check(lib.pk_eval_hessc_prepared(h, runtime.as_dp(lam), float(obj_factor), runtime.as_dp(out), 0))
+        return out
+
+    def jacobian_compact(self, x):
+        """Values of the compact (coalesced) Jacobian layout ``plan.jacc_row/col`` (one pk_jacc launch)."""
+        if not self.src.compact_j:
+            raise NotImplementedError("the compact Jacobian layout is not available for intervals with more than 64 points")
+        x = self._x(x)
+        self._invalidate_x()        # the context's x buffer is about to hold another iterate
+        out = np.empty(self.plan.nnz_Jc)
+        self.ctx.check(self.ctx.lib.pk_eval_jacc(self.ctx.handle, runtime.as_dp(x), runtime.as_dp(out)))
         return out
 
     def mesh_error(self, x):

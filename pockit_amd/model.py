@@ -500,6 +500,7 @@ class SystemBase:
         self._evaluator = None
         self._built_for = None
         self._hessian_layout = "reference"
+        self._jacobian_layout = "reference"
         self.set_phase([])
         self.set_system_constraint([], np.array([]), np.array([]))
 
@@ -543,6 +544,17 @@ class SystemBase:
         if layout not in ("reference", "compact"):
             raise ValueError('layout must be "reference" or "compact"')
         self._hessian_layout = layout
+        return self
+
+    def set_jacobian_layout(self, layout: str):
+        """``"reference"`` (default): the reference's triplet list (drop-in).  ``"compact"``: derivative entries of the
+        dynamics whose column is the same on every node (t_0, t_f, static parameters) are contracted with the
+        integration block -- one value per defect row instead of one per nonzero of the integration matrix
+        (phasebase.py:885-887,1120-1124 emit K per row); ``jacobianstructure()`` / ``jacobian()`` switch together, the
+        matrices are equal."""
+        if layout not in ("reference", "compact"):
+            raise ValueError('layout must be "reference" or "compact"')
+        self._jacobian_layout = layout
         return self
 
     def update(self) -> None:
@@ -612,9 +624,14 @@ class SystemBase:
         return self.evaluator.constraints(x)
 
     def jacobianstructure(self):
+        if self._jacobian_layout == "compact":
+            self.plan.jacc  # noqa: B018  (builds the compact plan)
+            return self.plan.jacc_row, self.plan.jacc_col
         return self.plan.jac_row, self.plan.jac_col
 
     def jacobian(self, x):
+        if self._jacobian_layout == "compact":
+            return self.evaluator.jacobian_compact(x)
         return self.evaluator.jacobian(x)
 
     def hessianstructure(self):

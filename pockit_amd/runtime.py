@@ -19,7 +19,8 @@ c_int32_p = C.POINTER(C.c_int32)
 class ModelDesc(C.Structure):
     _fields_ = [(n, C.c_int32) for n in
                 ("n_phase", "n_I", "nred", "lds_g", "lds_j", "lds_h", "ne_j", "ne_h", "prepass_f", "prepass_grad",
-                 "prepass_g", "prepass_jac", "prepass_hess", "lds_x", "ne_a", "ne_hc", "lds_e", "tab_cap", "sharded")]
+                 "prepass_g", "prepass_jac", "prepass_hess", "lds_x", "ne_a", "ne_hc", "lds_e", "tab_cap", "sharded",
+                 "lds_jc", "ne_jc")]
 
 
 class ProblemDesc(C.Structure):
@@ -38,13 +39,14 @@ class ProblemDesc(C.Structure):
         ("outer", C.c_void_p), ("n_outer", C.c_int32), ("n_aux", C.c_int32),
         ("items_hessc", C.c_void_p), ("n_items_hessc", C.c_int32), ("nnz_Hc", C.c_int64),
         ("jac_row", c_int32_p), ("jac_col", c_int32_p), ("hess_row", c_int32_p), ("hess_col", c_int32_p),
+        ("items_jacc", C.c_void_p), ("n_items_jacc", C.c_int32), ("nnz_Jc", C.c_int64),
     ]
 
 
 # numpy mirrors of csrc/pk_abi.h
 PHASE_FIELDS = ["scheme", "n_x", "n_u", "n_c", "L_m", "L_d", "state_len", "L", "x_off", "g_off", "path_off",
                 "mid_lo", "mid_hi", "tile_lo", "tile_hi", "tau_off", "w_off", "width_off", "jseg_off", "jt_off",
-                "hseg_off", "red_off", "aseg_off", "hcseg_off", "ivK_off", "ivfull_off", "ivld_off", "n_int"]
+                "hseg_off", "red_off", "aseg_off", "hcseg_off", "ivK_off", "ivfull_off", "ivld_off", "n_int", "jcseg_off", "jct_off"]
 PHASE_DTYPE = np.dtype([(n, np.int32) for n in PHASE_FIELDS])
 TILE_FIELDS = ["phase", "j0", "nj", "kid", "kidf", "q0", "r0", "offI", "offT", "K", "last",
                "nnzI", "nnzT", "irc_off", "iv_off", "tv_off", "full_off", "pad", "magicI", "magicR", "magicT", "pad2"]
@@ -61,7 +63,7 @@ ERRIV_DTYPE = np.dtype([("phase", np.int32), ("K", np.int32), ("lm", np.int32), 
 WAVES_PER_BLOCK = 4  # PK_WAVES_PER_BLOCK of csrc/pk_abi.h
 WAVE = 64  # PK_WAVE
 KERNELS = ["pk_int", "pk_fin", "pk_g", "pk_grad", "pk_jac", "pk_hess", "pk_xall", "pk_aux", "pk_outer", "pk_hessc", "pk_err", "pk_csr",
-           "pk_cycle", "pk_xchg", "pk_runs"]
+           "pk_cycle", "pk_xchg", "pk_runs", "pk_jacc"]
 EXPORTS = ["pk_create", "pk_destroy", "pk_last_error", "pk_device_count", "pk_load_model", "pk_set_problem",
            "pk_get_structure", "pk_eval_f", "pk_eval_grad", "pk_eval_g", "pk_eval_jac", "pk_eval_hess",
            "pk_eval_f_dev", "pk_eval_grad_dev", "pk_eval_g_dev", "pk_eval_jac_dev", "pk_eval_hess_dev",
@@ -75,7 +77,7 @@ EXPORTS = ["pk_create", "pk_destroy", "pk_last_error", "pk_device_count", "pk_lo
            "pk_device_alloc", "pk_device_free", "pk_ipc_export", "pk_ipc_open", "pk_ipc_close", "pk_set_shared_grad_target",
            "pk_set_exchange", "pk_exchange_sums_dev", "pk_copy_runs_dev", "pk_set_exchange_inline",
            "pk_host_register", "pk_host_unregister", "pk_copy_dev", "pk_eval_xpart_dev",
-           "pk_callback_x", "pk_callback_hess", "pk_set_jac_constant_runs", "pk_fill_jac_constants", "pk_set_host_option"]
+           "pk_eval_jacc", "pk_eval_jacc_dev", "pk_callback_x", "pk_callback_hess", "pk_set_jac_constant_runs", "pk_fill_jac_constants", "pk_set_host_option"]
 
 _lib = None
 
@@ -163,6 +165,8 @@ def load_library():
     lib.pk_fill_jac_constants.argtypes = [vp, vp]
     lib.pk_set_host_option.argtypes = [vp, C.c_char_p, C.c_int]
     lib.pk_eval_hessc.argtypes = [vp, dp, dp, C.c_double, dp]
+    lib.pk_eval_jacc.argtypes = [vp, dp, dp]
+    lib.pk_eval_jacc_dev.argtypes = [vp, vp, vp, vp]
     lib.pk_eval_hessc_dev.argtypes = [vp, vp, vp, C.c_double, vp, vp]
     lib.pk_set_mesh_error_tables.argtypes = [vp, vp, C.c_int32, vp, C.c_int32, dp, C.c_int64, C.c_int64]
     lib.pk_eval_mesh_error.argtypes = [vp, dp, dp, dp]

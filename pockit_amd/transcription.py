@@ -213,9 +213,16 @@ class PhasePlan:
 class Seg:
     """A per-node output of a phase in one callback."""
     expr: sp.Expr
-    kind: str          # 'I' expanded over the integration matrix, 'N' one value per middle node
+    kind: str          # 'I' expanded over the integration matrix, 'N' one value per middle node, 'D' (compact Jacobian)
+                       # contracted with the integration matrix: one value per defect row of the state
     base: int          # offset of the piece in the output array
-    state: int = -1    # kind 'I': the state whose defect rows (and multipliers) the piece belongs to
+    state: int = -1    # kind 'I' / 'D': the state whose defect rows (and multipliers) the piece belongs to
+    # kind 'D' only: the entry's expression at the front node / the back node (LGL), and what the translation block adds
+    # to the first row / to every row of the last interval (FUNC boundary values; functions of the static parameters)
+    front: sp.Expr = None
+    back: sp.Expr = None
+    tfront: sp.Expr = None
+    tback: sp.Expr = None
 
 
 @dataclass
@@ -499,6 +506,166 @@ class SystemPlan:
                 const[it.pos] = 1
         edges = np.flatnonzero(np.diff(np.concatenate(([0], const[:-1], [0]))))
         return [(int(a), int(b)) for a, b in zip(edges[0::2], edges[1::2])]
+
+    # ------------------------------------------------------------------ compact Jacobian
+    @property
+    def jacc(self):
+        """Compact (coalesced) Jacobian plan, built on first use.  The reference emits one triplet per nonzero of the
+        integration matrix for EVERY derivative entry of a dynamics function (phasebase.py:885-887,1120-1124); for an
+        entry whose column is the same on every node -- t_0, t_f, a static parameter -- that is K triplets per defect
+        row on one (row, column).  Here such an entry is contracted with the integration block first,
+        ``value(row r) = -sum_c (I_hat[r, c] d/2) e(c)`` (the I.F product of the constraints, applied to a derivative
+        column), the front / back node's share and the translation block's FUNC-boundary share included, and scalar
+        items that meet on one position are summed symbolically: one value per distinct (row, column) of the defect
+        rows' dense columns.  Entries with a per-node column are unique already and keep the reference's form.  (What
+        stays repeated: a state's own translation entry where d f_i / d x_i is not zero, and the rows of system
+        constraints that depend on integrals.)  Scatter-added, the triplets give the reference's matrix."""
+        if getattr(self, "_jacc", None) is None:
+            self._plan_jacobian_compact()
+        return self._jacc
+
+    def _plan_jacobian_compact(self):
+        nP = len(self.phase_plans)
+        cb = CallbackPlan(nP)
+        rows, cols, pos = [], [], 0
+        nI = len(self.I_syms)
+        if any(int(pp.layout.K.max()) > 64 for pp in self.phase_plans):
+            raise NotImplementedError("the compact Jacobian layout is not available for intervals with more than 64 points")
+
+        def scalar(row, colv, coef, key, expr):
+            nonlocal pos
+            rows.append(np.array([row], dtype=np.int64))
+            cols.append(np.array([colv], dtype=np.int64))
+            cb.items.append(Item(pos, coef, key, cb.entry(key, expr)))
+            pos += 1
+
+        # 1. system constraints: the reference's entries (systembase.py:472-479,659-669)
+        for c, fc in enumerate(self.F_c):
+            for a, m in zip(fc.G_index.tolist(), fc.grad):
+                cb.needs_I |= self._uses_I(m)
+                if a >= nI:
+                    scalar(c, self.l_s + (a - nI), 1.0, ("s",), m)
+                    continue
+                k, i = self.I_owner[a]
+                pp = self.phase_plans[k]
+                lay = pp.layout
+                nodes = pp.int_nodes[i]
+                for idx, e in nodes["f"].G:
+                    scalar(c, self.col(k, idx, 0), 1.0, ("f", k), m * WQ * e)
+                q = np.arange(lay.mid_lo, lay.mid_hi)
+                for idx, e in nodes["m"].G:
+                    cb.segs[k].append(Seg(m * WQ * e, "N", pos))
+                    rows.append(np.full(lay.L_mid, c, dtype=np.int64))
+                    cols.append(np.broadcast_to(self.col(k, idx, q), (lay.L_mid,)).astype(np.int64))
+                    pos += lay.L_mid
+                if lay.has_back:
+                    for idx, e in nodes["b"].G:
+                        scalar(c, self.col(k, idx, lay.L_m - 1), 1.0, ("b", k), m * WQ * e)
+
+        # 2. phases
+        self.jacc_dense = []        # per phase: number of contracted (dense-column) entries
+        for k, pp in enumerate(self.phase_plans):
+            lay, g0 = pp.layout, self.g_off[k]
+            Ir, Ic = lay.I_mid_structure()
+            Tr, Tc, _ = lay.T_mid_structure()
+            dense = lambda idx, lay=lay: idx[0] == "c" and (idx[1] < 0 or idx[1] >= lay.L - 2)  # noqa: E731
+            merged = {}             # (row, col, list key) -> summed expression of the scalar items that meet there
+
+            def item(row, colv, key, expr, merged=merged):
+                tag = (int(row), int(colv), key)
+                merged[tag] = merged.get(tag, sp.Integer(0)) + expr
+
+            tdf = [dict() for _ in range(pp.nx)]      # state -> {dense idx: translation share of the first row}
+            tdb = [dict() for _ in range(pp.nx)]      # ... of every row of the last interval
+            for i in range(pp.nx):                                   # translation part
+                r0 = g0 + lay.l_d[i]
+                for t_row, t_val in zip(lay.Tf_row, lay.Tf_val):
+                    for idx, e in pp.x_f[i].G:
+                        if dense(idx):
+                            tdf[i][idx] = tdf[i].get(idx, sp.Integer(0)) + float(t_val) * e
+                        else:
+                            item(r0 + t_row, self.col(k, idx, 0), ("f", k), float(t_val) * e)
+                cb.tconst[k].append(pos)
+                rows.append(r0 + Tr)
+                cols.append(self.l_p[k] + lay.l_v[i] + Tc)
+                pos += lay.nnzT_mid
+                for idx, e in pp.x_b[i].G:
+                    if dense(idx):                                    # (T_b: -1 on every row of the last interval)
+                        tdb[i][idx] = tdb[i].get(idx, sp.Integer(0)) + float(lay.Tb_val[0]) * e
+                    else:
+                        for t_row, t_val in zip(lay.Tb_row, lay.Tb_val):
+                            item(r0 + t_row, self.col(k, idx, lay.L_m - 1), ("b", k), float(t_val) * e)
+            n_dense = 0
+            for i in range(pp.nx):                                   # integration part
+                r0 = g0 + lay.l_d[i]
+                nodes = pp.dyn_nodes[i]
+                where = {"f": nodes["f"].G, "m": nodes["m"].G, "b": nodes["b"].G if lay.has_back else []}
+                for idx, e in where["m"]:                            # per-node columns: the reference's expanded entries
+                    if dense(idx):
+                        continue
+                    cb.segs[k].append(Seg(e, "I", pos, i))
+                    rows.append(r0 + Ir)
+                    cols.append(np.broadcast_to(self.col(k, idx, Ic), Ic.shape).astype(np.int64))
+                    pos += lay.nnzI_mid
+                for i_row, i_val in zip(lay.If_row, lay.If_val):
+                    for idx, e in where["f"]:
+                        if not dense(idx):
+                            item(r0 + i_row, self.col(k, idx, 0), ("f", k), -float(i_val) * e)
+                for i_row, i_val in zip(lay.Ib_row, lay.Ib_val):
+                    for idx, e in where["b"]:
+                        if not dense(idx):
+                            item(r0 + i_row, self.col(k, idx, lay.L_m - 1), ("b", k), -float(i_val) * e)
+                order = []                                           # dense columns, in order of first appearance
+                for lst in (where["f"], where["m"], where["b"], [(d, None) for d in tdf[i]], [(d, None) for d in tdb[i]]):
+                    for idx, _ in lst:
+                        if dense(idx) and idx not in order:
+                            order.append(idx)
+                total = lambda lst, d: sum((e for idx, e in lst if idx == d), sp.Integer(0))  # noqa: E731
+                for d in order:
+                    if total(where["m"], d) == 0:
+                        # a column only the boundary nodes know (a FUNC boundary value's static parameters): the rows of
+                        # the first / last interval, as scalar items
+                        ef, eb = total(where["f"], d), total(where["b"], d)
+                        for i_row, i_val in zip(lay.If_row, lay.If_val):
+                            if ef != 0:
+                                item(r0 + i_row, self.col(k, d), ("f", k), -float(i_val) * ef)
+                        if tdf[i].get(d, 0) != 0:
+                            item(r0 + int(lay.Tf_row[0]), self.col(k, d), ("f", k), tdf[i][d])
+                        for i_row, i_val in zip(lay.Ib_row, lay.Ib_val):
+                            if eb != 0:
+                                item(r0 + i_row, self.col(k, d), ("b", k), -float(i_val) * eb)
+                        if tdb[i].get(d, 0) != 0:
+                            for t_row in lay.Tb_row:
+                                item(r0 + t_row, self.col(k, d), ("b", k), tdb[i][d])
+                        continue
+                    cb.segs[k].append(Seg(total(where["m"], d), "D", pos, i, front=total(where["f"], d),
+                                          back=total(where["b"], d), tfront=tdf[i].get(d, sp.Integer(0)),
+                                          tback=tdb[i].get(d, sp.Integer(0))))
+                    rows.append(r0 + np.arange(lay.L_d, dtype=np.int64))
+                    cols.append(np.full(lay.L_d, self.col(k, d), dtype=np.int64))
+                    pos += lay.L_d
+                    n_dense += 1
+            self.jacc_dense.append(n_dense)
+            q = np.arange(lay.mid_lo, lay.mid_hi)
+            for j in range(len(pp.path)):                            # path constraints: unique as they are
+                r0 = self.path_off[k] + j * lay.L_m
+                nodes = pp.path_nodes[j]
+                for idx, e in nodes["f"].G:
+                    item(r0, self.col(k, idx, 0), ("f", k), e)
+                for idx, e in nodes["m"].G:
+                    cb.segs[k].append(Seg(e, "N", pos))
+                    rows.append(r0 + q)
+                    cols.append(np.broadcast_to(self.col(k, idx, q), q.shape).astype(np.int64))
+                    pos += lay.L_mid
+                if lay.has_back:
+                    for idx, e in nodes["b"].G:
+                        item(r0 + lay.L_m - 1, self.col(k, idx, lay.L_m - 1), ("b", k), e)
+            for (row, colv, key), expr in merged.items():
+                scalar(row, colv, 1.0, key, expr)
+        self._jacc = cb
+        self.nnz_Jc = pos
+        self.jacc_row = np.concatenate(rows) if rows else np.zeros(0, np.int64)
+        self.jacc_col = np.concatenate(cols) if cols else np.zeros(0, np.int64)
 
     # ------------------------------------------------------------------ Hessian of the Lagrangian
     def _plan_hessian(self):

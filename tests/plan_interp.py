@@ -118,7 +118,7 @@ class Interp:
         out = np.full(nnz, np.nan)
         for k, pp in enumerate(plan.phase_plans):
             lay = pp.layout
-            if cb is plan.jac:
+            if cb is plan.jac or cb is getattr(plan, "_jacc", None):
                 _, _, tv = lay.T_mid_structure()
                 for base in cb.tconst[k]:
                     out[base: base + lay.nnzT_mid] = tv
@@ -132,6 +132,18 @@ class Interp:
                     if with_lambda:
                         val = val * self.lam[plan.g_off[k] + lay.l_d[seg.state] + Ir]
                     out[seg.base: seg.base + lay.nnzI_mid] = val
+                elif seg.kind == "D":        # compact Jacobian: a dense-column entry contracted with the integration block
+                    e = np.array(v, dtype=np.float64)
+                    e[0] = self._eval_nodes(k, [seg.front], [0])[0][0]
+                    if lay.has_back:
+                        e[-1] = self._eval_nodes(k, [seg.back], [lay.L_m - 1])[0][0]
+                    tf, tb = (float(t[0]) for t in self._eval_nodes(k, [seg.tfront, seg.tback], [0]))
+                    for j in range(lay.N):
+                        A = lay.kinds[lay.kid_full[j]].full * lay.width[j] * 0.5
+                        nodes = lay.lm[j] + np.arange(int(lay.K[j]))
+                        r = seg.base + lay.ld[j] + np.arange(A.shape[0])
+                        out[r] = -(A @ e[nodes]) + (tb if j == lay.N - 1 else 0.0)
+                    out[seg.base] += tf
                 else:
                     out[seg.base: seg.base + lay.L_mid] = v[lay.mid_lo: lay.mid_hi]
         E = {}
@@ -174,6 +186,10 @@ class Interp:
                 out[b.pos: b.pos + b.count] = vals
             assert not np.isnan(out).any(), "plan does not cover every output slot"
         return out
+
+    def jacobian_compact(self):
+        plan = self.plan
+        return self._run(plan.jacc, plan.nnz_Jc, False)
 
     def hessian_compact(self):
         plan = self.plan

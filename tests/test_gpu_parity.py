@@ -1349,3 +1349,68 @@ def test_landing_blocks_keep_the_constant_jacobian_entries_across_recycling():
         close(h_new, ref.hessian(x_other, lam, sigma), what=f"H on a new x, {name}")
         close(g_new, ref.gradient(x_other), what=f"grad on that x, {name}")
     assert lib.pk_set_host_option(h, b"no_such_option", 1) != 0
+
+
+COMPACT_CASES = [("brachistochrone", "radau", dict(mesh=37, num_point=5)),
+                 ("brachistochrone", "lobatto", dict(mesh=23, num_point=6)),
+                 ("brachistochrone", "radau", dict(mesh=[0, 0.1, 0.15, 0.5, 0.9, 1.0], num_point=[3, 7, 2, 5, 1])),
+                 ("two_stage_rocket", "radau", dict(mesh=40, num_point=3)),
+                 ("two_stage_rocket", "lobatto", dict(mesh=11, num_point=4)),
+                 ("planar_quadrotor", "lobatto", dict(mesh=19, num_point=4)),
+                 ("planar_quadrotor", "radau", dict(mesh=300, num_point=6)),
+                 ("humanoid_wbc", "radau", dict(mesh=9, num_point=7)),
+                 ("humanoid_wbc", "lobatto", dict(mesh=6, num_point=5)),
+                 ("brachistochrone", "radau", dict(mesh=[0, 0.3, 1.0], num_point=[12, 20])),      # tables beyond one lane each
+                 ("derivative_model", "radau", {}), ("derivative_model", "lobatto", {}),          # system constraints on integrals
+                 ("lqr", "lobatto", dict(mesh=6, num_point=6))]
+
+
+@pytest.mark.parametrize("case", COMPACT_CASES)
+def test_compact_jacobian_equals_coalesced_oracle(case):
+    """pk_jacc: dense-column entries of the dynamics contracted with the integration block (one value per defect row); scatter-
+    added the compact triplets must equal the scatter-add of the oracle's (= the reference's) triplet list, on exactly the
+    reference's set of positions; the reference layout is still served afterwards."""
+    import scipy.sparse as ssp
+
+    bname, scheme, kw = case
+    system, _, guess = getattr(models, bname)(_ns(scheme, "pockit_amd"), **kw)
+    ref, _, _ = getattr(models, bname)(_ns(scheme, "oracle"), **kw)
+    x, lam, sigma = models.bench_inputs(system, guess)
+    shape = (system.plan.m, system.plan.n)
+    jr, jc = ref.jacobianstructure()
+    want = ssp.coo_array((ref.jacobian(x), (jr, jc)), shape=shape).tocsr()
+    system.set_jacobian_layout("compact")
+    cr, cc = system.jacobianstructure()
+    vals = system.jacobian(x)
+    assert len(vals) == len(cr) <= len(jr)
+    assert set(zip(cr.tolist(), cc.tolist())) == set(zip(np.asarray(jr).tolist(), np.asarray(jc).tolist()))
+    got = ssp.coo_array((vals, (cr, cc)), shape=shape).tocsr()
+    diff = abs(got - want)
+    scale = max(1.0, abs(want).max())
+    assert (diff.max() if diff.nnz else 0.0) <= (TOL if max(np.atleast_1d(kw.get("num_point", 4))) <= 12 else 1e-8) * scale
+    system.set_jacobian_layout("reference")
+    close(system.jacobian(x), ref.jacobian(x), what="reference layout still served",
+          tol=TOL if max(np.atleast_1d(kw.get("num_point", 4))) <= 12 else 1e-8)
+
+
+def test_compact_jacobian_at_full_size_reaches_the_unique_count():
+    """BASELINE configs C2 (brachistochrone 200 x 8: 111 965 -> 78 365 triplets, the number of distinct positions) and C5
+    (humanoid 5000 x 8) at full size against the oracle's scatter-added triplets."""
+    import scipy.sparse as ssp
+
+    for bname, mesh, K, expect in (("brachistochrone", 200, 8, 78365), ("humanoid_wbc", 5000, 8, None)):
+        system, _, guess = getattr(models, bname)(_ns("radau", "pockit_amd"), mesh, K)
+        ref, _, _ = getattr(models, bname)(_ns("radau", "oracle"), mesh, K)
+        x, lam, sigma = models.bench_inputs(system, guess)
+        shape = (system.plan.m, system.plan.n)
+        jr, jc = ref.jacobianstructure()
+        want = ssp.coo_array((ref.jacobian(x), (jr, jc)), shape=shape).tocsr()
+        system.set_jacobian_layout("compact")
+        cr, cc = system.jacobianstructure()
+        vals = system.jacobian(x)
+        if expect is not None:
+            assert len(vals) == expect == want.nnz
+        got = ssp.coo_array((vals, (cr, cc)), shape=shape).tocsr()
+        diff = abs(got - want)
+        assert (diff.max() if diff.nnz else 0.0) <= TOL * max(1.0, abs(want).max())
+        system._invalidate()

@@ -265,3 +265,37 @@ def test_compact_hessian_plan_coalesces_to_the_reference_matrix(name):
     close(got, want)
     if "brach" in name:                 # K-fold (and more) reduction where the dynamics are nonlinear
         assert plan.nnz_Hc * 4 <= plan.nnz_H
+
+
+@pytest.mark.parametrize("name", sorted(models.SMALL_CASES))
+def test_compact_jacobian_plan_coalesces_to_the_reference_matrix(name):
+    """Compact Jacobian layout (dense-column entries of the dynamics contracted with the integration block, scalar items
+    that meet on one position summed): no more triplets than the reference, every (row, column) of the reference and no
+    other, and the same matrix as the scatter-add of the reference's triplets; exactly one triplet per position wherever
+    no state's translation entry meets its own d f_i / d x_i and no system constraint depends on an integral."""
+    import scipy.sparse as ssp
+
+    builder, scheme, kw = models.SMALL_CASES[name]
+    gold = np.load(os.path.join(HERE, "golden", "small", name + ".npz"))
+    system, _, _ = builder(NS[scheme], **kw)
+    plan = system.plan
+    plan.jacc  # noqa: B018
+    assert plan.nnz_Jc <= plan.nnz_J
+    ref_pos = set(zip(gold["jr"].tolist(), gold["jc"].tolist()))
+    got_pos = set(zip(plan.jacc_row.tolist(), plan.jacc_col.tolist()))
+    assert got_pos == ref_pos
+    it = Interp(plan, gold["x"])
+    shape = (plan.m, plan.n)
+    want = ssp.coo_array((gold["J"], (gold["jr"], gold["jc"])), shape=shape).toarray()
+    got = ssp.coo_array((it.jacobian_compact(), (plan.jacc_row, plan.jacc_col)), shape=shape).toarray()
+    close(got, want)
+    self_dependent = any(i in fn.G_index.tolist() for pp in plan.phase_plans for i, fn in enumerate(pp.phase.F_d))
+    if not self_dependent and not plan.needs_I_con:
+        assert plan.nnz_Jc == len(ref_pos)
+    system.set_jacobian_layout("compact")
+    jr, jc = system.jacobianstructure()
+    assert len(jr) == plan.nnz_Jc
+    system.set_jacobian_layout("reference")
+    assert len(system.jacobianstructure()[0]) == plan.nnz_J
+    with pytest.raises(ValueError):
+        system.set_jacobian_layout("dense")
