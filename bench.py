@@ -222,9 +222,12 @@ def end_to_end(system, guess, steps, warmup):
     modes = ["fresh_arrays", "zero_copy_views"]
     if ev.src.compact:
         modes.append("fresh_arrays_compact_hessian")      # the same five callbacks for a solver handed the compact H structure
+    if ev.src.compact and ev.src.compact_j:
+        modes.append("fresh_arrays_compact_layouts")      # ... and the compact J structure as well
     for mode in modes:
         ev.zero_copy = mode == "zero_copy_views"
-        system.set_hessian_layout("compact" if mode.endswith("compact_hessian") else "reference")
+        system.set_hessian_layout("compact" if mode.endswith(("compact_hessian", "compact_layouts")) else "reference")
+        system.set_jacobian_layout("compact" if mode.endswith("compact_layouts") else "reference")
         rows = []
         for k in range(15 + 100):
             xk = xs[k & 1]
@@ -247,6 +250,11 @@ def end_to_end(system, guess, steps, warmup):
                      "min_ms_per_cycle": min(r[5] for r in rows) * 1e3, "max_ms_per_cycle": max(r[5] for r in rows) * 1e3}
     ev.zero_copy = False
     system.set_hessian_layout("reference")
+    system.set_jacobian_layout("reference")
+    if "fresh_arrays_compact_layouts" in out:
+        out["fresh_arrays_compact_layouts"]["jacobian_values"] = int(system.plan.nnz_Jc)
+        out["fresh_arrays_compact_layouts"]["jacobian_values_reference_layout"] = int(system.plan.nnz_J)
+        out["fresh_arrays_compact_layouts"]["hessian_values"] = int(system.plan.nnz_Hc)
     if "fresh_arrays_compact_hessian" in out:
         out["fresh_arrays_compact_hessian"]["hessian_values"] = int(system.plan.nnz_Hc)
         out["fresh_arrays_compact_hessian"]["hessian_values_reference_layout"] = int(system.plan.nnz_H)

@@ -170,6 +170,9 @@ int pk_callback_hess(pk_ctx* ctx, const double* x, const double* lambda, double 
 int pk_set_jac_constant_runs(pk_ctx* ctx, int n_runs, const int64_t* start, const int64_t* stop);
 int pk_fill_jac_constants(pk_ctx* ctx, double* jac /* nnz_J */);
 int pk_set_host_option(pk_ctx* ctx, const char* name, int value);
+/* layout of the Jacobian the host shim serves (pk_fetch(3), pk_callback_x(3), the J part of a landing block): 0 the reference's
+ * triplets (default), 1 the compact layout of pk_eval_jacc (a landing block is then [J compact (nnz_Jc) | grad f | g]) */
+int pk_set_jacobian_layout(pk_ctx* ctx, int compact);
 int pk_result_location(pk_ctx* ctx, int what /* 0..4 */, double** ptr);
 int pk_set_host_mode(pk_ctx* ctx, int prefetch, int host_direct);
 int pk_invalidate_x(pk_ctx* ctx);
@@ -220,7 +223,8 @@ int pk_eval_mesh_error_dev(pk_ctx* ctx, const double* d_x, double* d_T, double* 
  * ``seg[p] .. seg[p+1]``: the run of q belonging to CSR entry p (NULL when no entry repeats).  The CSR
  * structure itself (indptr, indices) is host data: pockit_amd/csr.py.  which = 2 maps the COMPACT Hessian values
  * (pk_eval_hessc, one value per distinct entry) onto the same CSR entries: when it is set, pk_eval_hess_csr(_dev) evaluate
- * the compact form and permute instead of writing and re-adding every repeated triplet. */
+ * the compact form and permute instead of writing and re-adding every repeated triplet.  which = 3 does the same for the
+ * Jacobian with the compact values of pk_eval_jacc (its few repeated positions are summed by the gather). */
 int pk_set_csr_map(pk_ctx* ctx, int which, const int32_t* seg /* n_unique + 1 or NULL */, const int32_t* perm,
                    int64_t n_unique, int64_t n_triplets);
 int pk_gather_csr_dev(pk_ctx* ctx, int which, const double* d_triplets, double* d_csr, void* stream);

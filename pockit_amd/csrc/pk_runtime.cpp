@@ -107,7 +107,8 @@ struct pk_ctx {
     int32_t *d_seg = nullptr, *d_perm = nullptr;
     double* d_vals = nullptr;
     int64_t n_unique = 0, n_triplets = 0;
-  } csr[3];      // + [2]: compact Hessian values -> the same CSR entries (a pure permutation: one value per entry)
+  } csr[4];      // + [2]: compact Hessian values -> the same CSR entries (a pure permutation: one value per entry)
+                 // + [3]: compact Jacobian values -> the CSR entries of J (the few repeated positions summed)
   // mesh error estimation (pk_set_mesh_error_tables)
   void* d_erriv = nullptr;
   int32_t* d_errgrp = nullptr;     // (first record, count) per wavefront of pk_err
@@ -171,7 +172,9 @@ struct pk_ctx {
   // Pieces [start, stop) of the Jacobian values that CHANGE with x.  Default: everything.  pk_set_jac_constant_runs takes
   // x-independent runs (the +-1 translation entries of phasebase.py:1071-1081 are 19 % of J at 12k nodes) out of the
   // per-iterate copy: they are put into a landing array once (pk_fill_jac_constants) and never cross PCIe again.
-  std::vector<std::pair<int64_t, int64_t>> jruns, jconst;
+  std::vector<std::pair<int64_t, int64_t>> jruns, jconst;      // (of the layout the shim serves; the other layout's are parked)
+  std::vector<std::pair<int64_t, int64_t>> jruns_other, jconst_other;
+  bool jac_compact = false;    // the host shim's Jacobian callback serves the compact layout (pk_set_jacobian_layout)
   bool target_filled = false;  // the caller's J landing array (target[3]) already holds the constant runs (pk_callback_x blocks)
   bool jac_filled = false;     // ... and so does the landing place of the CURRENT iterate: its copy skips them
   // profiling
@@ -221,7 +224,8 @@ void free_problem(pk_ctx* c) {
   for (auto& m : c->csr) { release(m.d_seg); release(m.d_perm); release(m.d_vals); m.n_unique = m.n_triplets = 0; }
   release(c->d_ib); release(c->d_db); release(c->d_lb);
   c->d_g = c->d_grad = nullptr;   // (interior pointers of the d_J allocation: one block [J | grad f | g])
-  c->jruns.clear(); c->jconst.clear();
+  c->jruns.clear(); c->jconst.clear(); c->jruns_other.clear(); c->jconst_other.clear();
+  c->jac_compact = false;
   c->lam_src = nullptr;
   if (c->h_Hc) { (void)hipHostFree(c->h_Hc); c->h_Hc = nullptr; }
   release(c->d_x); release(c->d_lam); release(c->d_f); release(c->d_J);
@@ -430,12 +434,12 @@ int copy_async(pk_ctx* c, double* dst, const double* src, size_t n, hipMemcpyKin
 }
 
 size_t result_count(const pk_ctx* c, int what) {
-  const size_t cnt[5] = {1, (size_t)c->n, (size_t)c->m, (size_t)c->nnz_J, (size_t)c->nnz_H};
+  const size_t cnt[5] = {1, (size_t)c->n, (size_t)c->m, (size_t)(c->jac_compact ? c->nnz_Jc : c->nnz_J), (size_t)c->nnz_H};
   return cnt[what];
 }
 
 double* device_result(pk_ctx* c, int what) {
-  double* src[5] = {c->d_f, c->d_grad, c->d_g, c->d_J, c->d_H};
+  double* src[5] = {c->d_f, c->d_grad, c->d_g, c->jac_compact ? c->d_Jc : c->d_J, c->d_H};
   return src[what];
 }
 
@@ -471,7 +475,8 @@ int enqueue_result_copies(pk_ctx* c, unsigned mask) {
     if (c->stored_direct[k]) continue;
     const bool pinned = !c->target[k] || c->target_pinned[k];
     if (k == 3 && c->jac_filled) {
-      for (const auto& r : c->jruns) add(c->d_J + r.first, c->landed[3] + r.first, (size_t)(r.second - r.first), pinned);
+      const double* dj = device_result(c, 3);
+      for (const auto& r : c->jruns) add(dj + r.first, c->landed[3] + r.first, (size_t)(r.second - r.first), pinned);
     } else {
       add(device_result(c, k), c->landed[k], result_count(c, k), pinned);
     }
@@ -724,6 +729,8 @@ int pk_set_problem(pk_ctx* c, const pk_problem_desc* pd) {
   c->d_g = c->d_grad + c->n;
   c->jruns.assign(1, std::make_pair((int64_t)0, (int64_t)c->nnz_J));
   c->jconst.clear();
+  c->jruns_other.assign(1, std::make_pair((int64_t)0, (int64_t)c->nnz_Jc));
+  c->jconst_other.clear();
   {   // hand-off slots of pk_cycle: one per x-kernel workgroup and reduction row, PK_EMPTY between launches
     const size_t slots = (2 * (size_t)c->n_tiles / PK_WAVES_PER_BLOCK + 2) * (size_t)c->md.nred;
     const std::vector<unsigned long long> empty(slots, (unsigned long long)PK_EMPTY);
@@ -914,8 +921,9 @@ int pk_eval_jacc(pk_ctx* c, const double* x, double* vals) {
 int pk_set_csr_map(pk_ctx* c, int which, const int32_t* seg, const int32_t* perm, int64_t n_unique, int64_t n_triplets) {
   int rc = ready(c);
   if (rc) return rc;
-  if (which < 0 || which > 2) return fail(c, 80, "pk_set_csr_map: which must be 0 (Jacobian), 1 (Hessian) or 2 (compact Hessian)");
-  const int64_t expect = which == 0 ? c->nnz_J : which == 1 ? c->nnz_H : c->nnz_Hc;
+  if (which < 0 || which > 3)
+    return fail(c, 80, "pk_set_csr_map: which must be 0 (Jacobian), 1 (Hessian), 2 (compact Hessian) or 3 (compact Jacobian)");
+  const int64_t expect = which == 0 ? c->nnz_J : which == 1 ? c->nnz_H : which == 2 ? c->nnz_Hc : c->nnz_Jc;
   if (!perm || n_unique <= 0 || n_unique > n_triplets || n_triplets != expect || n_triplets > INT32_MAX)
     return fail(c, 81, "pk_set_csr_map: map does not match the problem (%lld triplets expected)", (long long)expect);
   // validate on the host: the kernel indexes with these
@@ -944,7 +952,7 @@ int pk_set_csr_map(pk_ctx* c, int which, const int32_t* seg, const int32_t* perm
 int pk_gather_csr_dev(pk_ctx* c, int which, const double* d_triplets, double* d_csr, void* stream) {
   int rc = ready(c);
   if (rc) return rc;
-  if (which < 0 || which > 2 || c->csr[which].n_unique == 0) return fail(c, 84, "pk_gather_csr: call pk_set_csr_map first");
+  if (which < 0 || which > 3 || c->csr[which].n_unique == 0) return fail(c, 84, "pk_gather_csr: call pk_set_csr_map first");
   const auto& m = c->csr[which];
   PkArgs A = base_args(c, nullptr, nullptr, 0.0);
   A.csr_in = d_triplets; A.csr_seg = m.d_seg; A.csr_perm = m.d_perm; A.csr_out = d_csr; A.n_csr = (int32_t)m.n_unique;
@@ -955,6 +963,10 @@ int pk_gather_csr_dev(pk_ctx* c, int which, const double* d_triplets, double* d_
 
 int pk_eval_jac_csr_dev(pk_ctx* c, const double* d_x, double* d_csr, void* stream) {
   if (c) c->x_valid = false;      // (the triplets pass through the context's J buffer)
+  if (c && c->have_problem && c->csr[3].n_unique > 0 && c->nnz_Jc > 0) {      // from the compact evaluation, like the Hessian's
+    int rc = pk_eval_jacc_dev(c, d_x, c->d_Jc, stream);
+    return rc ? rc : pk_gather_csr_dev(c, 3, c->d_Jc, d_csr, stream);
+  }
   int rc = pk_eval_jac_dev(c, d_x, c ? c->d_J : nullptr, stream);
   return rc ? rc : pk_gather_csr_dev(c, 0, c->d_J, d_csr, stream);
 }
@@ -976,12 +988,13 @@ int pk_eval_jac_csr(pk_ctx* c, const double* x, double* vals) {
   int rc = ready(c);
   if (rc) return rc;
   if (!x || !vals) return fail(c, 60, "null host buffer");
-  if (c->csr[0].n_unique == 0) return fail(c, 84, "pk_eval_jac_csr: call pk_set_csr_map first");
+  const int jm = c->csr[3].n_unique > 0 ? 3 : 0;      // (both maps fill the same CSR entries)
+  if (c->csr[jm].n_unique == 0) return fail(c, 84, "pk_eval_jac_csr: call pk_set_csr_map first");
   PK_HIP(c, hipSetDevice(c->device));
   c->x_valid = false;
   PK_HIP(c, hipMemcpyAsync(c->d_x, x, sizeof(double) * (size_t)c->n, hipMemcpyHostToDevice, c->stream));
-  if ((rc = pk_eval_jac_csr_dev(c, c->d_x, c->csr[0].d_vals, nullptr))) return rc;
-  PK_HIP(c, hipMemcpyAsync(vals, c->csr[0].d_vals, sizeof(double) * (size_t)c->csr[0].n_unique, hipMemcpyDeviceToHost, c->stream));
+  if ((rc = pk_eval_jac_csr_dev(c, c->d_x, c->csr[jm].d_vals, nullptr))) return rc;
+  PK_HIP(c, hipMemcpyAsync(vals, c->csr[jm].d_vals, sizeof(double) * (size_t)c->csr[jm].n_unique, hipMemcpyDeviceToHost, c->stream));
   PK_HIP(c, hipStreamSynchronize(c->stream));
   return 0;
 }
@@ -1384,9 +1397,10 @@ int stage_lambda(pk_ctx* c, const double* lambda) {
 
 // a landing block of the caller's for the x-results of the next new iterate: [J (nnz_J) | grad f (n) | g (m)]
 void take_block(pk_ctx* c, double* block) {
+  const int64_t nj = c->jac_compact ? c->nnz_Jc : c->nnz_J;      // (a block follows the layout the Jacobian callback serves)
   c->target[3] = block;
-  c->target[1] = block ? block + c->nnz_J : nullptr;
-  c->target[2] = block ? block + c->nnz_J + c->n : nullptr;
+  c->target[1] = block ? block + nj : nullptr;
+  c->target[2] = block ? block + nj + c->n : nullptr;
   c->target_visible[1] = c->target_visible[2] = c->target_visible[3] = !c->host_direct;   // (copy targets; see pk_set_result_targets)
   c->target_filled = block != nullptr;      // (the contract of pk_callback_x: blocks were filled by pk_fill_jac_constants)
   c->target_pinned[1] = c->target_pinned[2] = c->target_pinned[3] = block != nullptr;      // (... and are pinned memory)
@@ -1412,7 +1426,9 @@ int pk_prepare_x(pk_ctx* c, const double* x) {
     o[k] = c->stored_direct[k] ? c->landed[k] : device_result(c, k);
   }
   if (c->stored_direct[0]) *(volatile unsigned long long*)c->landed[0] = (unsigned long long)PK_EMPTY;     // (see wait_result)
-  if ((rc = pk_eval_xpart_dev(c, c->d_x, o[0], o[1], o[2], o[3], nullptr))) return rc;
+  if ((rc = pk_eval_xpart_dev(c, c->d_x, o[0], o[1], o[2], c->jac_compact ? c->d_J : o[3], nullptr))) return rc;
+  // the compact layout of the Jacobian: its own kernel behind the fused x-kernel (whose reference-layout J stays on the device)
+  if (c->jac_compact && (rc = pk_eval_jacc_dev(c, c->d_x, o[3], nullptr))) return rc;
   // f and g are what a line search asks for at every trial point: always on their way; grad f and J in prefetch mode
   if ((rc = enqueue_result_copies(c, c->prefetch ? 0xFu : 0x5u))) return rc;
   c->x_valid = true;
@@ -1580,7 +1596,8 @@ int pk_callback_hess(pk_ctx* c, const double* x, const double* lambda, double si
   return pk_eval_hess_prepared(c, nullptr, sigma, nullptr);
 }
 
-// Runs [start[i], stop[i]) of the Jacobian values that never change with x (ascending, disjoint): the x-results' copy to the
+// Runs [start[i], stop[i]) of the Jacobian values -- in the layout the shim serves, pk_set_jacobian_layout; every layout keeps
+// its own -- that never change with x (ascending, disjoint): the x-results' copy to the
 // host skips them from now on.  The landing arrays must hold those values already: pk_fill_jac_constants writes them into
 // an array once (the context's own landing buffer is filled here).  n_runs = 0 restores the full copy.
 // Reference: the translation part of the Jacobian, phasebase.py:1071-1081, is recomputed and returned by every call there.
@@ -1590,7 +1607,7 @@ int pk_set_jac_constant_runs(pk_ctx* c, int n_runs, const int64_t* start, const 
   if (n_runs < 0 || (n_runs > 0 && (!start || !stop))) return fail(c, 66, "pk_set_jac_constant_runs: bad arguments");
   int64_t at = 0;
   for (int i = 0; i < n_runs; ++i) {
-    if (start[i] < at || stop[i] <= start[i] || stop[i] > c->nnz_J)
+    if (start[i] < at || stop[i] <= start[i] || stop[i] > (int64_t)result_count(c, 3))
       return fail(c, 66, "pk_set_jac_constant_runs: run %d [%lld, %lld) is out of order or out of range", i, (long long)start[i], (long long)stop[i]);
     at = stop[i];
   }
@@ -1605,11 +1622,11 @@ int pk_set_jac_constant_runs(pk_ctx* c, int n_runs, const int64_t* start, const 
     c->jconst.emplace_back(start[i], stop[i]);
     at = stop[i];
   }
-  if (at < c->nnz_J || c->jruns.empty()) c->jruns.emplace_back(at, (int64_t)c->nnz_J);
+  if (at < (int64_t)result_count(c, 3) || c->jruns.empty()) c->jruns.emplace_back(at, (int64_t)result_count(c, 3));
   if (n_runs == 0) return 0;
-  // one evaluation of J into the context's device buffer (whatever x it holds: the constant entries do not depend on it),
-  // from which the constants are taken
-  if ((rc = pk_eval_jac_dev(c, c->d_x, c->d_J, nullptr))) return rc;
+  // one evaluation of J (in the layout the shim serves) into the context's device buffer, whatever x it holds -- the
+  // constant entries do not depend on it --, from which the constants are taken
+  if ((rc = c->jac_compact ? pk_eval_jacc_dev(c, c->d_x, c->d_Jc, nullptr) : pk_eval_jac_dev(c, c->d_x, c->d_J, nullptr))) return rc;
   return pk_fill_jac_constants(c, c->h_out[3]);
 }
 
@@ -1619,9 +1636,28 @@ int pk_fill_jac_constants(pk_ctx* c, double* jac) {
   if (rc) return rc;
   if (!jac) return fail(c, 60, "null host buffer");
   PK_HIP(c, hipSetDevice(c->device));
+  const double* dj = device_result(c, 3);
   for (const auto& r : c->jconst)
-    PK_HIP(c, hipMemcpyAsync(jac + r.first, c->d_J + r.first, sizeof(double) * (size_t)(r.second - r.first), hipMemcpyDeviceToHost, c->stream));
+    PK_HIP(c, hipMemcpyAsync(jac + r.first, dj + r.first, sizeof(double) * (size_t)(r.second - r.first), hipMemcpyDeviceToHost, c->stream));
   PK_HIP(c, hipStreamSynchronize(c->stream));
+  return 0;
+}
+
+// Which layout the Jacobian of the host shim (pk_prepare_x / pk_fetch(3) / pk_callback_x(3), the J part of a landing block)
+// has: 0 the reference's triplets (default), 1 the compact layout of pk_eval_jacc.
+int pk_set_jacobian_layout(pk_ctx* c, int compact) {
+  int rc = ready(c);
+  if (rc) return rc;
+  if (compact && c->nnz_Jc <= 0) return fail(c, 52, "pk_set_jacobian_layout: no compact Jacobian layout was supplied to pk_set_problem");
+  PK_HIP(c, hipSetDevice(c->device));
+  PK_HIP(c, hipStreamSynchronize(c->stream));
+  if ((compact != 0) != c->jac_compact) {      // every layout has constant runs of its own
+    c->jruns.swap(c->jruns_other);
+    c->jconst.swap(c->jconst_other);
+  }
+  c->jac_compact = compact != 0;
+  c->x_valid = false;
+  for (int k = 0; k < 5; ++k) c->target[k] = nullptr;
   return 0;
 }
 

@@ -298,22 +298,54 @@ class Evaluator:
 
     def _host_setup(self):
         p = self.plan
+        self._jac_compact = False
+        self._nj = p.nnz_J          # Jacobian values of a landing block (the layout the Jacobian callback serves)
         self._blocks = runtime.PinnedRing(p.nnz_J + p.n + p.m)
+        self._blocks_ref = self._blocks
         self._ring_h = runtime.PinnedRing(p.nnz_H)
         self._ring_hc = None
         self._next = self._cur = None
         self._cur_views, self._handed = {}, set()
         self._c_f, self._c_fresh = C.c_double(), C.c_int()
         self._a_f, self._a_fresh = C.addressof(self._c_f), C.addressof(self._c_fresh)
-        runs = [(a, b) for a, b in p.jac_constant_runs()
-                if b - a >= (self.HEAD_RUN_MIN if a == 0 else self.INNER_RUN_MIN)]
-        if os.environ.get("POCKIT_AMD_JAC_CONSTANTS", "1") == "0":      # A/B: every iterate ships the whole Jacobian
-            runs = []
-        self.jac_constant_runs = runs
-        if runs:
-            lo = (C.c_int64 * len(runs))(*[a for a, _ in runs])
-            hi = (C.c_int64 * len(runs))(*[b for _, b in runs])
-            self.ctx.check(self.ctx.lib.pk_set_jac_constant_runs(self.ctx.handle, len(runs), lo, hi))
+        self._const_runs = {}
+        self.jac_constant_runs = self._register_constant_runs(False)
+
+    def _register_constant_runs(self, compact):
+        """The x-independent runs of the Jacobian (in the layout the shim serves right now) worth leaving out of the copy."""
+        if compact not in self._const_runs:
+            runs = [(a, b) for a, b in self.plan.jac_constant_runs(compact)
+                    if b - a >= (self.HEAD_RUN_MIN if a == 0 else self.INNER_RUN_MIN)]
+            if os.environ.get("POCKIT_AMD_JAC_CONSTANTS", "1") == "0":      # A/B: every iterate ships the whole Jacobian
+                runs = []
+            if runs:
+                lo = (C.c_int64 * len(runs))(*[a for a, _ in runs])
+                hi = (C.c_int64 * len(runs))(*[b for _, b in runs])
+                self.ctx.check(self.ctx.lib.pk_set_jac_constant_runs(self.ctx.handle, len(runs), lo, hi))
+            self._const_runs[compact] = runs
+        return self._const_runs[compact]
+
+    def set_jacobian_layout(self, compact):
+        """The layout ``jacobian()`` and the J part of the landing blocks have: the reference's triplets or the compact
+        layout (``plan.jacc_row/col``; an extra launch of pk_jacc behind the fused x-kernel, fewer values over PCIe)."""
+        compact = bool(compact)
+        if compact == self._jac_compact:
+            return
+        if compact and not self.src.compact_j:
+            raise NotImplementedError("the compact Jacobian layout is not available for intervals with more than 64 points")
+        self.ctx.check(self.ctx.lib.pk_set_jacobian_layout(self.ctx.handle, int(compact)))
+        p = self.plan
+        self._jac_compact = compact
+        self._nj = p.nnz_Jc if compact else p.nnz_J
+        if compact:
+            if getattr(self, "_blocks_compact", None) is None:
+                self._blocks_compact = runtime.PinnedRing(p.nnz_Jc + p.n + p.m)
+            self._blocks = self._blocks_compact
+        else:
+            self._blocks = self._blocks_ref
+        self.jac_constant_runs = self._register_constant_runs(compact)
+        self._next = self._cur = None
+        self._cur_views, self._handed = {}, set()
 
     def _next_block(self):
         """The landing block [J | grad f | g] of the next new iterate (None: zero-copy mode, or the caller holds on to every
@@ -338,9 +370,8 @@ class Evaluator:
         if it is None:
             self._cur_views = {}
         else:
-            p, root = self.plan, it.root
-            self._cur_views = {3: root[: p.nnz_J], 1: root[p.nnz_J: p.nnz_J + p.n],
-                               2: root[p.nnz_J + p.n: p.nnz_J + p.n + p.m]}
+            p, root, nj = self.plan, it.root, self._nj
+            self._cur_views = {3: root[: nj], 1: root[nj: nj + p.n], 2: root[nj + p.n: nj + p.n + p.m]}
 
     def _callback_x(self, what, x):
         x = self._x(x)
@@ -392,7 +423,7 @@ class Evaluator:
 
     def jacobian(self, x):
         self._callback_x(3, x)
-        return self._result(3, self.plan.nnz_J)
+        return self._result(3, self._nj)
 
     def _lam(self, lagrange):
         lam = np.ascontiguousarray(lagrange, dtype=np.float64)
@@ -484,7 +515,8 @@ class Evaluator:
         return out
 
     def jacobian_compact(self, x):
-        """Values of the compact (coalesced) Jacobian layout ``plan.jacc_row/col`` (one pk_jacc launch)."""
+        """Values of the compact (coalesced) Jacobian layout ``plan.jacc_row/col`` (one pk_jacc launch; the one-shot entry
+        point -- a solver loop uses ``set_jacobian_layout(True)`` and ``jacobian()``)."""
         if not self.src.compact_j:
             raise NotImplementedError("the compact Jacobian layout is not available for intervals with more than 64 points")
         x = self._x(x)
@@ -531,6 +563,16 @@ class Evaluator:
             self.ctx.check(self.ctx.lib.pk_set_csr_map(self.ctx.handle, 0 if which == "jac" else 1, seg,
                                                        m.perm.ctypes.data_as(runtime.c_int32_p), m.nnz, m.n_triplets))
             self._csr[which] = m
+            if which == "jac" and self.src.compact_j and not os.environ.get("POCKIT_AMD_CSR_FROM_TRIPLETS"):
+                # the CSR values of J from the compact evaluation: its few repeated positions are summed by the gather
+                plan.jacc  # noqa: B018  (builds the compact plan)
+                mc = CsrMap(plan.jacc_row, plan.jacc_col, (plan.m, plan.n))
+                if mc.n_triplets < m.n_triplets and mc.nnz == m.nnz and np.array_equal(mc.indices, m.indices) \
+                        and np.array_equal(mc.indptr, m.indptr):      # (only where the compact layout writes fewer values)
+                    segc = None if mc.seg is None else mc.seg.ctypes.data_as(runtime.c_int32_p)
+                    self.ctx.check(self.ctx.lib.pk_set_csr_map(self.ctx.handle, 3, segc,
+                                                               mc.perm.ctypes.data_as(runtime.c_int32_p), mc.nnz, mc.n_triplets))
+                    self._csr["jacc"] = mc
             if which == "hess" and self.src.compact and not os.environ.get("POCKIT_AMD_CSR_FROM_TRIPLETS"):
                 # the compact Hessian has one value per distinct (row, col): if its pattern is the full pattern's set of
                 # entries, the CSR values are a permutation of it (pk_eval_hess_csr then never writes the repeats)
@@ -585,8 +627,12 @@ class Evaluator:
         lam = np.ascontiguousarray(lagrange, dtype=np.float64)
         p = self.plan
         # pinned arrays of the caller's own (the block set aside for the next iterate of the callbacks, if there is one)
-        blk = self._next if self._next is not None else self._blocks.take_item()
-        self._next, hit = None, self._ring_h.take_item()
+        if self._jac_compact:       # (the one-call cycle writes the reference layout)
+            blk = self._blocks_ref.take_item()
+        else:
+            blk = self._next if self._next is not None else self._blocks.take_item()
+            self._next = None
+        hit = self._ring_h.take_item()
         if blk is not None:
             root = blk.root
             J, grad, g = root[: p.nnz_J], root[p.nnz_J: p.nnz_J + p.n], root[p.nnz_J + p.n: p.nnz_J + p.n + p.m]

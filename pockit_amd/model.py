@@ -555,6 +555,8 @@ class SystemBase:
         if layout not in ("reference", "compact"):
             raise ValueError('layout must be "reference" or "compact"')
         self._jacobian_layout = layout
+        if self._evaluator is not None:
+            self._evaluator.set_jacobian_layout(layout == "compact")
         return self
 
     def update(self) -> None:
@@ -593,6 +595,7 @@ class SystemBase:
         plan = self.plan
         if self._evaluator is None:
             self._evaluator = Evaluator(plan)
+            self._evaluator.set_jacobian_layout(self._jacobian_layout == "compact")
         return self._evaluator
 
     # ------------------------------------------------------------------ layout views (host, no GPU)
@@ -630,8 +633,6 @@ class SystemBase:
         return self.plan.jac_row, self.plan.jac_col
 
     def jacobian(self, x):
-        if self._jacobian_layout == "compact":
-            return self.evaluator.jacobian_compact(x)
         return self.evaluator.jacobian(x)
 
     def hessianstructure(self):

@@ -77,7 +77,8 @@ EXPORTS = ["pk_create", "pk_destroy", "pk_last_error", "pk_device_count", "pk_lo
            "pk_device_alloc", "pk_device_free", "pk_ipc_export", "pk_ipc_open", "pk_ipc_close", "pk_set_shared_grad_target",
            "pk_set_exchange", "pk_exchange_sums_dev", "pk_copy_runs_dev", "pk_set_exchange_inline",
            "pk_host_register", "pk_host_unregister", "pk_copy_dev", "pk_eval_xpart_dev",
-           "pk_eval_jacc", "pk_eval_jacc_dev", "pk_callback_x", "pk_callback_hess", "pk_set_jac_constant_runs", "pk_fill_jac_constants", "pk_set_host_option"]
+           "pk_eval_jacc", "pk_eval_jacc_dev", "pk_callback_x", "pk_callback_hess", "pk_set_jac_constant_runs", "pk_fill_jac_constants", "pk_set_host_option",
+           "pk_set_jacobian_layout"]
 
 _lib = None
 
@@ -164,6 +165,7 @@ def load_library():
     lib.pk_set_jac_constant_runs.argtypes = [vp, C.c_int, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
     lib.pk_fill_jac_constants.argtypes = [vp, vp]
     lib.pk_set_host_option.argtypes = [vp, C.c_char_p, C.c_int]
+    lib.pk_set_jacobian_layout.argtypes = [vp, C.c_int]
     lib.pk_eval_hessc.argtypes = [vp, dp, dp, C.c_double, dp]
     lib.pk_eval_jacc.argtypes = [vp, dp, dp]
     lib.pk_eval_jacc_dev.argtypes = [vp, vp, vp, vp]

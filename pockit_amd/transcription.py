@@ -492,17 +492,19 @@ class SystemPlan:
         self.jac_row = np.concatenate(rows) if rows else np.zeros(0, np.int64)
         self.jac_col = np.concatenate(cols) if cols else np.zeros(0, np.int64)
 
-    def jac_constant_runs(self):
-        """Runs ``[(start, stop)]`` of Jacobian positions whose value does not depend on x: the +-1 translation entries
-        (the reference recomputes them in every call, phasebase.py:1071-1081) and boundary / system items whose expression is
-        a number (a FREE boundary slot contributes ``coef * 1``).  A host shim fills them into its landing arrays once and
-        leaves them out of the per-iterate copy (``pk_set_jac_constant_runs``)."""
-        const = np.zeros(self.nnz_J + 1, dtype=np.int8)
+    def jac_constant_runs(self, compact=False):
+        """Runs ``[(start, stop)]`` of Jacobian positions (reference layout, or the compact one) whose value does not
+        depend on x: the +-1 translation entries (the reference recomputes them in every call, phasebase.py:1071-1081) and
+        boundary / system items whose expression is a number (a FREE boundary slot contributes ``coef * 1``).  A host
+        shim fills them into its landing arrays once and leaves them out of the per-iterate copy
+        (``pk_set_jac_constant_runs``)."""
+        cb, nnz = (self.jacc, self.nnz_Jc) if compact else (self.jac, self.nnz_J)
+        const = np.zeros(nnz + 1, dtype=np.int8)
         for k, pp in enumerate(self.phase_plans):
-            for base in self.jac.tconst[k]:
+            for base in cb.tconst[k]:
                 const[base: base + pp.layout.nnzT_mid] = 1
-        for it in self.jac.items:
-            if it.lam < 0 and not sp.sympify(self.jac.lists[it.lst][it.eid]).free_symbols:
+        for it in cb.items:
+            if it.lam < 0 and not sp.sympify(cb.lists[it.lst][it.eid]).free_symbols:
                 const[it.pos] = 1
         edges = np.flatnonzero(np.diff(np.concatenate(([0], const[:-1], [0]))))
         return [(int(a), int(b)) for a, b in zip(edges[0::2], edges[1::2])]

@@ -24,14 +24,14 @@ def test_library_exports_every_declared_symbol():
 
 
 def test_struct_sizes_match_the_c_abi():
-    # csrc/pk_abi.h: PkPhase 28 ints, PkTile 22 ints, PkKind 8 ints, PkItem {int64, double, int32, int32}
-    assert runtime.PHASE_DTYPE.itemsize == 28 * 4
+    # csrc/pk_abi.h: PkPhase 30 ints, PkTile 22 ints, PkKind 8 ints, PkItem {int64, double, int32, int32}
+    assert runtime.PHASE_DTYPE.itemsize == 30 * 4
     assert runtime.TILE_DTYPE.itemsize == 22 * 4
     assert runtime.KIND_DTYPE.itemsize == 8 * 4
     assert runtime.ITEM_DTYPE.itemsize == 24
     assert runtime.OUTER_DTYPE.itemsize == 40
     assert runtime.ERRIV_DTYPE.itemsize == 48
-    assert C.sizeof(runtime.ModelDesc) == 19 * 4
+    assert C.sizeof(runtime.ModelDesc) == 21 * 4
 
 
 def test_numpy_mirrors_agree_with_the_compiled_structs(tmp_path):

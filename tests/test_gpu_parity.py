@@ -1388,9 +1388,23 @@ def test_compact_jacobian_equals_coalesced_oracle(case):
     diff = abs(got - want)
     scale = max(1.0, abs(want).max())
     assert (diff.max() if diff.nnz else 0.0) <= (TOL if max(np.atleast_1d(kw.get("num_point", 4))) <= 12 else 1e-8) * scale
+    # the compact layout rides on the prepared-x protocol like the reference's: the other callbacks on the same iterate, a
+    # second iterate, arrays that stay valid; and the one-shot entry point gives the same values
+    tol = TOL if max(np.atleast_1d(kw.get("num_point", 4))) <= 12 else 1e-8
+    close(system.gradient(x), ref.gradient(x), what="grad beside the compact J", tol=tol)
+    close(system.constraints(x), ref.constraints(x), what="g beside the compact J", tol=tol)
+    x2 = x * (1 + 1e-4)
+    v2 = system.jacobian(x2)
+    assert np.array_equal(system.evaluator.jacobian_compact(x2), v2) and not np.shares_memory(v2, vals)
+    assert np.array_equal(system.jacobian(x), vals)
+    close(system.hessian(x2, lam, sigma), ref.hessian(x2, lam, sigma), what="H beside the compact J", tol=tol)
+    # CSR values of J gathered on the device from the compact evaluation
+    Jc = system.jacobian_csr(x)
+    dj = abs(Jc - want)
+    assert (dj.max() if dj.nnz else 0.0) <= tol * scale
+    assert ("jacc" in system.evaluator._csr) == (len(cr) < len(jr))
     system.set_jacobian_layout("reference")
-    close(system.jacobian(x), ref.jacobian(x), what="reference layout still served",
-          tol=TOL if max(np.atleast_1d(kw.get("num_point", 4))) <= 12 else 1e-8)
+    close(system.jacobian(x), ref.jacobian(x), what="reference layout still served", tol=tol)
 
 
 def test_compact_jacobian_at_full_size_reaches_the_unique_count():
