@@ -531,6 +531,16 @@ SMALL_CASES = {
     "humanoid_lgl_2x4": (humanoid_wbc, "lobatto", dict(mesh=2, num_point=4)),
 }
 
+# callback vectors of the reference beyond 12 points per interval (tests/golden/small_hi): its np.roots-based tables lose
+# digits there, the comparison's tolerance follows from the measured table error (tests/test_product_host.py)
+HIGH_ORDER_CASES = {
+    "brach_lgr_2x13": (brachistochrone, "radau", dict(mesh=2, num_point=13)),
+    "brach_lgr_3x16": (brachistochrone, "radau", dict(mesh=3, num_point=16)),
+    "quad_lgl_2x16": (planar_quadrotor, "lobatto", dict(mesh=2, num_point=16)),
+    "rocket_lgr_hp20": (two_stage_rocket, "radau", dict(mesh=[0, 0.4, 1.0], num_point=[20, 14])),
+    "brach_lgl_2x20": (brachistochrone, "lobatto", dict(mesh=2, num_point=20)),
+}
+
 # mesh error estimation / continuous refinement fixtures (K >= 2 everywhere: the reference's refinement
 # formula divides by log(K), phasebase.py:1579-1587)
 ERROR_CASES = {k: SMALL_CASES[k] for k in (

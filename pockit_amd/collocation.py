@@ -15,8 +15,72 @@ columns removed for the first/last interval) and the wave tiles the kernels iter
 from __future__ import annotations
 
 import functools
+import os
 
 import numpy as np
+
+# Which numerical recipe produces the nodes / weights / integration matrices.
+#   "accurate" (default)  three-term recurrence + Newton polishing + an exact Gauss rule: correct to ~1e-15 at every order
+#                         (pinned by the multiprecision tables of tests/golden/make_hiprec.py up to K = 128);
+#   "reference"           the reference's recipe -- interior nodes as np.roots of the monomial-basis Jacobi / Legendre
+#                         polynomial (radau/discretization.py:89-114, lobatto/discretization.py:80-110), integration matrix
+#                         by Gauss-Legendre with max(30, 3K) points on the barycentric basis (discretizationbase.py:98-180).
+#                         Its tables lose digits with K (quadrature weights: 1e-10 at K = 16, 1e-8 at K = 20); selecting it
+#                         makes results at K > 12 agree with the reference's to rounding instead of to that table error.
+_RECIPE = os.environ.get("POCKIT_AMD_TABLES", "accurate")
+
+
+def use_reference_recipe(flag: bool = True) -> None:
+    """Switch the table recipe (see ``_RECIPE``) for layouts built from now on."""
+    global _RECIPE
+    _RECIPE = "reference" if flag else "accurate"
+    for fn in (lgr_nodes_weights, lgl_nodes_weights, lgr_integration_matrix, lgl_integration_matrix, lgr_error_tables,
+               lgl_error_tables):
+        fn.cache_clear()
+
+
+def _reference_nodes(scheme, K):
+    import scipy.special
+
+    if scheme == "lgr":
+        inner = np.roots(scipy.special.jacobi(K - 1, 0, 1))
+        x = np.array(sorted([-1.0] + [r.real for r in inner]), dtype=np.float64)
+        w = (1.0 - x) / (K * np.polyval(scipy.special.legendre(K), x)) ** 2
+        return x, np.asarray(w, dtype=np.float64)
+    n = K - 1
+    Pn = scipy.special.legendre(n)
+    x = np.array(sorted([-1.0] + [r.real for r in np.roots(np.polyder(Pn))] + [1.0]), dtype=np.float64)
+    c = 2.0 / n / (n + 1)
+    w = np.array([c] + [c / np.polyval(Pn, xi) ** 2 for xi in x[1:-1]] + [c], dtype=np.float64)
+    return x, w
+
+
+def _reference_integration_matrix(nodes, out_nodes):
+    """The reference's quadrature of the Lagrange basis (a fixed Gauss-Legendre rule of max(30, 3K) points per output
+    node, barycentric evaluation), vectorised over the quadrature points."""
+    n = len(nodes)
+    gap = nodes[:, None] - nodes[None, :]
+    np.fill_diagonal(gap, 1.0)
+    bw = 1.0 / np.prod(gap, axis=1)
+    gx, gw = np.polynomial.legendre.leggauss(max(30, 3 * n))
+    A = np.zeros((len(out_nodes), n))
+    for i, b in enumerate(out_nodes):
+        if abs(b - 1.0) <= 1e-13:
+            continue                                   # (the row of the end point: an empty integral)
+        half = 0.5 * (b - 1.0)
+        t = half * gx + 0.5 * (b + 1.0)
+        if n == 1:
+            A[i, 0] = half * gw.sum()
+            continue
+        d = t[:, None] - nodes[None, :]
+        on_node = np.abs(d) <= 1e-13 * (1.0 + np.abs(nodes))[None, :]
+        d[on_node] = 1.0
+        terms = bw[None, :] / d
+        L = terms / terms.sum(axis=1, keepdims=True)
+        hit = on_node.any(axis=1)
+        L[hit] = on_node[hit].astype(np.float64)
+        A[i] = (half * gw) @ L
+    return A
 
 
 # ------------------------------------------------------------------------------ Legendre helpers
@@ -54,6 +118,8 @@ def lgr_nodes_weights(K: int):
     """Legendre-Gauss-Radau nodes on [-1, 1) including -1, and quadrature weights."""
     if K < 1:
         raise ValueError("Number of interpolation points must be at least 1.")
+    if _RECIPE == "reference":
+        return _reference_nodes("lgr", K)
     m = K - 1
     if m == 0:
         x = np.array([-1.0])
@@ -82,6 +148,8 @@ def lgl_nodes_weights(K: int):
         raise ValueError("Number of interpolation points must be at least 1.")
     if K == 1:
         return np.array([0.0]), np.array([2.0])
+    if _RECIPE == "reference":
+        return _reference_nodes("lgl", K)
     n = K - 1
     if n == 1:
         x = np.array([-1.0, 1.0])
@@ -103,6 +171,8 @@ def lgl_nodes_weights(K: int):
 
 def _integration_matrix(nodes, out_nodes):
     """A[i, j] = integral from +1 to out_nodes[i] of the j-th Lagrange basis on ``nodes``."""
+    if _RECIPE == "reference":
+        return _reference_integration_matrix(np.asarray(nodes, dtype=np.float64), np.asarray(out_nodes, dtype=np.float64))
     n = len(nodes)
     bw = np.array([1.0 / np.prod(nodes[j] - np.delete(nodes, j)) for j in range(n)])
     gx, gw = _gauss_legendre(n // 2 + 2)                       # exact for degree n-1

@@ -234,6 +234,28 @@ def main():
             tabs[f"lgl_I_{K}"] = I_lgl(K)
     np.savez_compressed(os.path.join(HERE, "tables.npz"), **tabs)
 
+    # the reference's tables beyond K = 12 (its np.roots-based nodes lose digits with K: the product's Newton-polished
+    # tables are compared with these AND with the multiprecision tables of make_hiprec.py, tests/test_product_host.py)
+    tabs = {}
+    for K in range(13, 25):
+        x, w = xw_lgr(K)
+        tabs[f"lgr_x_{K}"], tabs[f"lgr_w_{K}"], tabs[f"lgr_I_{K}"] = x, w, I_lgr(K)
+        x, w = xw_lgl(K)
+        tabs[f"lgl_x_{K}"], tabs[f"lgl_w_{K}"], tabs[f"lgl_I_{K}"] = x, w, I_lgl(K)
+    np.savez_compressed(os.path.join(HERE, "tables_hi.npz"), **tabs)
+
+    # callback vectors of the reference on meshes with 13 ... 20 points per interval
+    os.makedirs(os.path.join(HERE, "small_hi"), exist_ok=True)
+    for name, (builder, scheme, kw) in models.HIGH_ORDER_CASES.items():
+        if args.only and args.only not in name:
+            continue
+        system, phases, guess = builder(NS[scheme], **kw)
+        x, lam, _ = models.bench_inputs(system, guess)
+        out = evaluate(system, x, lam, 0.7)
+        out.update(x=x, lam=lam, sigma=np.float64(0.7))
+        np.savez_compressed(os.path.join(HERE, "small_hi", name + ".npz"), **out)
+        print("high-order fixture", name, len(out["J"]), len(out["H"]))
+
     if args.full:
         path = os.path.join(HERE, "full.json")
         full = {}

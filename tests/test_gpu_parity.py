@@ -372,6 +372,23 @@ def test_full_size_configs_match_reference_summary():
         check(g1, gold["g"], name + " cycle g")
         check(J1, gold["J"], name + " cycle J")
         check(H1, gold["H"], name + " cycle H")
+        # ... and EVERY entry of every array, callbacks and one-launch cycle, against the oracle (itself pinned to the same
+        # reference summaries at these sizes, tests/test_oracle_golden.py): a wrong run that the 64 samples and the sum miss
+        # cannot pass
+        ref, _, _ = builder(_ns(scheme, "oracle"), **kw)
+        want = (ref.objective(x), ref.gradient(x), ref.constraints(x), ref.jacobian(x), ref.hessian(x, lam, sigma))
+        jr, jc = system.jacobianstructure()
+        rr, rc = ref.jacobianstructure()
+        assert np.array_equal(jr, rr) and np.array_equal(jc, rc), name + " J structure"
+        hr, hc = system.hessianstructure()
+        rr, rc = ref.hessianstructure()
+        assert np.array_equal(hr, rr) and np.array_equal(hc, rc), name + " H structure"
+        got = (system.objective(x), system.gradient(x), system.constraints(x), system.jacobian(x),
+               system.hessian(x, lam, sigma))
+        for a, b, what in zip(got, want, ("f", "grad", "g", "J", "H")):
+            close(a, b, what=f"{name} callbacks {what} (all entries)")
+        for a, b, what in zip((f1, grad1, g1, J1, H1), want, ("f", "grad", "g", "J", "H")):
+            close(a, b, what=f"{name} cycle {what} (all entries)")
         system._invalidate()
 
 
@@ -1428,3 +1445,32 @@ def test_compact_jacobian_at_full_size_reaches_the_unique_count():
         diff = abs(got - want)
         assert (diff.max() if diff.nnz else 0.0) <= TOL * max(1.0, abs(want).max())
         system._invalidate()
+
+
+@pytest.mark.parametrize("name", sorted(models.HIGH_ORDER_CASES))
+def test_high_order_reference_vectors_with_the_reference_table_recipe(name):
+    """13 ... 20 points per interval on the GPU against the REFERENCE's own callback vectors (tests/golden/small_hi): with
+    ``collocation.use_reference_recipe()`` -- the reference's np.roots-based tables, which lose digits at these orders --
+    the kernels reproduce the reference to the stated 1e-11; with the product's accurate tables the difference is the
+    reference's table error (tests/test_tables_hiprec.py)."""
+    from pockit_amd import collocation
+
+    builder, scheme, kw = models.HIGH_ORDER_CASES[name]
+    gold = np.load(os.path.join(HERE, "golden", "small_hi", name + ".npz"))
+    collocation.use_reference_recipe(True)
+    try:
+        system, _, _ = builder(_ns(scheme, "pockit_amd"), **kw)
+        x, lam, sigma = gold["x"], gold["lam"], float(gold["sigma"])
+        jr, jc = system.jacobianstructure()
+        assert np.array_equal(jr, gold["jr"]) and np.array_equal(jc, gold["jc"])
+        close(system.objective(x), gold["f"], what="f")
+        close(system.gradient(x), gold["grad"], what="grad")
+        close(system.constraints(x), gold["g"], what="g")
+        close(system.jacobian(x), gold["J"], what="J")
+        close(system.hessian(x, lam, sigma), gold["H"], what="H")
+        f, grad, g, J, H = system.evaluator.cycle(x, lam, sigma)
+        close(J, gold["J"], what="cycle J")
+        close(H, gold["H"], what="cycle H")
+        system._invalidate()
+    finally:
+        collocation.use_reference_recipe(False)
