@@ -64,6 +64,14 @@ HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 HBM_ACHIEVABLE_GBPS = 6300.0   # what the guide's stream-type kernels reach (MI355X_MICROARCH.md: "~6.3 TB/s achievable")
 LAUNCH_FLOOR_US = 4.3          # a pk_cycle-shaped launch before its first output byte leaves
 KERNEL_IDS = {"pk_int": 0, "pk_fin": 1, "pk_g": 2, "pk_grad": 3, "pk_jac": 4, "pk_hess": 5, "pk_xall": 6, "pk_cycle": 12}
+
+
+def side_roofline(nbytes, us):
+    """Algorithmic bytes of one launch of a side kernel over its per-dispatch time, against the HBM roof."""
+    gbps = nbytes / (us * 1e-6) / 1e9 if us else None
+    return {"bound": "hbm", "algorithmic_bytes_per_launch": int(nbytes), "avg_launch_us": us, "achieved": gbps, "peak": HBM_PEAK_GBPS,
+            "unit": "GB/s", "frac": (gbps / HBM_PEAK_GBPS if gbps else None),
+            "frac_of_achievable": (gbps / HBM_ACHIEVABLE_GBPS if gbps else None)}
 MIN_REGION_S = 0.05        # the timed region lasts at least this long (R batches of `steps` cycles)
 EVENT_SPACING = 200        # cycles between two timing events of the region (an event costs ~3 us of GPU time)
 MIN_WARMUP = 500           # untimed launches before the timed region (single GPU), whatever --warmup says
@@ -682,14 +690,23 @@ class GpuWorkload:
             hargs = (h, ptr(self.dx), ptr(self.dlam), C.c_double(float(self.sigma)), ptr(hc), st)
             us = timed(9, "pk_hessc", lambda: lib.pk_eval_hessc_dev(*hargs))
             out["compact_hessian_mode"] = {"nnz_H_compact": int(plan.nnz_Hc), "nnz_H_reference": int(plan.nnz_H),
-                                           "pk_hessc_us": us, "finite": bool(torch.isfinite(hc).all())}
+                                           "pk_hessc_us": us, "finite": bool(torch.isfinite(hc).all()),
+                                           "roofline": side_roofline(8 * (plan.n + plan.m + plan.nnz_Hc), us)}
+        if ev.src.compact_j:
+            plan.jacc  # noqa: B018
+            jc = torch.zeros(max(plan.nnz_Jc, 1), dtype=torch.float64, device=dev)
+            us = timed(15, "pk_jacc", lambda: lib.pk_eval_jacc_dev(h, ptr(self.dx), ptr(jc), st))
+            out["compact_jacobian_mode"] = {"nnz_J_compact": int(plan.nnz_Jc), "nnz_J_reference": int(plan.nnz_J),
+                                            "pk_jacc_us": us, "finite": bool(torch.isfinite(jc).all()),
+                                            "roofline": side_roofline(8 * (plan.n + plan.nnz_Jc), us)}
         ev.mesh_error(self.x)                                           # uploads the tables on first use
         eT = torch.zeros(ev._err_len, dtype=torch.float64, device=dev)
         eI = torch.zeros_like(eT)
         torch.cuda.synchronize()
         us = timed(10, "pk_err", lambda: lib.pk_eval_mesh_error_dev(h, ptr(self.dx), ptr(eT), ptr(eI), st))
         out["mesh_error_estimation"] = {"pk_err_us": us, "rows": int(ev._err_len),
-                                        "finite": bool(torch.isfinite(eT).all() and torch.isfinite(eI).all())}
+                                        "finite": bool(torch.isfinite(eT).all() and torch.isfinite(eI).all()),
+                                        "roofline": side_roofline(8 * (plan.n + 2 * ev._err_len), us)}
         mj, mh = ev.csr_map("jac"), ev.csr_map("hess")
         cj = torch.zeros(mj.nnz, dtype=torch.float64, device=dev)
         ch = torch.zeros(mh.nnz, dtype=torch.float64, device=dev)
@@ -703,12 +720,17 @@ class GpuWorkload:
             lib.pk_eval_hessc_dev(h, ptr(self.dx), ptr(self.dlam), C.c_double(float(self.sigma)), ptr(hcv), st)
             csr["pk_csr_H_from_compact_us"] = timed(11, "pk_csr", lambda: lib.pk_gather_csr_dev(h, 2, ptr(hcv), ptr(ch), st))
         csr["finite"] = bool(torch.isfinite(cj).all() and torch.isfinite(ch).all())
+        # traffic of a gather: 4-byte index + 8-byte value per triplet, 8 bytes per CSR entry written
+        csr["roofline_J"] = side_roofline(12 * mj.n_triplets + 8 * mj.nnz, csr["pk_csr_J_us"])
+        csr["roofline_H_from_triplets"] = side_roofline(12 * mh.n_triplets + 8 * mh.nnz, csr["pk_csr_H_us"])
+        if "pk_csr_H_from_compact_us" in csr:
+            csr["roofline_H_from_compact"] = side_roofline(20 * mh.nnz, csr["pk_csr_H_from_compact_us"])
         out["csr_handoff"] = csr
         return out
 
     def all_kernel_us(self, steps=50):
         ev = self.ev
-        ev.profile(0x7FFF)
+        ev.profile(0xFFFF)
         for _ in range(steps):
             self.step()
         self.torch.cuda.synchronize()

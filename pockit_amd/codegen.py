@@ -426,6 +426,8 @@ class ModelSource:
             S.append("#define PK_XCD_REMAP 0")
         if os.environ.get("POCKIT_AMD_POLL_SLEEP"):                  # A/B switch: pause between the finalize workgroup's polls
             S.append(f"#define PK_POLL_SLEEP {int(os.environ['POCKIT_AMD_POLL_SLEEP'])}")
+        if os.environ.get("POCKIT_AMD_BIG_MFMA", "0") == "1":        # A/B switch: big intervals' products on the fp64 matrix cores
+            S.append("#define PK_BIG_MFMA 1")
         if os.environ.get("POCKIT_AMD_WIDE_STORES", "1") == "0":     # A/B switch: 8-byte stores in the streaming loop
             S.append("#define PK_WIDE_STORES 0")
         if os.environ.get("POCKIT_AMD_KA_LAZY", "1") == "0":         # A/B: pk_cycle's PkArgs loaded en bloc on entry
@@ -470,7 +472,8 @@ class ModelSource:
                                      for k, pp in enumerate(plan.phase_plans)])
         self.lds_x = 64 * max([1] + [pp.nx * (2 if self.big else 1) + sum(1 for sg in plan.jac.segs[k] if sg.kind == "I")
                                      for k, pp in enumerate(plan.phase_plans)])      # (big: + the node values [NX][256])
-        self.lds_e = 64 * max([1] + [2 * pp.nx + pp.nu for pp in plan.phase_plans])
+        # (mesh error estimation: [x | u | f] rows per wave; a workgroup-wide interval adds the interpolated [x | u] rows)
+        self.lds_e = 64 * max([1] + [3 * pp.nx + 2 * pp.nu for pp in plan.phase_plans])
         self.lds_jc = 64 * max([1] + [sum(1 for sg in plan.jacc.segs[k] if sg.kind in "ID") for k in range(nP)]) if self.compact_j else 64
         S.append(f"  static constexpr int LDS_G = {self.lds_g}, LDS_J = {self.lds_j}, LDS_H = {self.lds_h}, "
                  f"LDS_X = {self.lds_x}, LDS_E = {self.lds_e}, LDS_JC = {self.lds_jc};")

@@ -21,6 +21,7 @@
 #include <hip/hip_runtime.h>
 #include <hip/hip_ext.h>
 
+#include <algorithm>
 #include <climits>
 #include <cstddef>
 #include <cstdarg>
@@ -291,7 +292,7 @@ int launch_raw(pk_ctx* c, int k, void* args, size_t sz, unsigned grid, size_t ld
   EventPair ev{};
   if (grid == 0) return 0;
   // the tile kernels that stage their pattern tables keep one table block per wave in front of the model's staging area
-  if ((k == K_G || k == K_JAC || k == K_HESS || k == K_XALL || k == K_CYCLE || k == K_JACC) && !c->static_tabs)
+  if ((k == K_G || k == K_JAC || k == K_HESS || k == K_XALL || k == K_CYCLE || k == K_JACC || k == K_HESSC) && !c->static_tabs)
     lds_bytes += sizeof(double) * PK_WAVES_PER_BLOCK * (size_t)(2 * c->md.tab_cap + 2 * PK_WAVE + c->md.tab_cap / 2);
   if (k == K_CYCLE && c->xc_inline && c->xc_world > 1 && lds_bytes < sizeof(double) * 2 * 512)
     lds_bytes = sizeof(double) * 2 * 512;      // the finalize workgroup's exchange vectors (2 x PK_XC_CAP doubles)
@@ -885,7 +886,9 @@ int pk_eval_hessc_dev(pk_ctx* c, const double* d_x, const double* d_lam, double 
   A.o_hess = d_vals;
   A.items = (const PkItem*)c->d_items_hessc;
   A.n_items = c->n_items_hessc;
-  return launch(c, K_HESSC, A, tile_blocks(c) + 1, sizeof(double) * (size_t)(c->md.ne_hc > 0 ? c->md.ne_hc : 1), st);
+  size_t lds = sizeof(double) * PK_WAVES_PER_BLOCK * (size_t)c->md.lds_g;      // the tile's multiplier rows, [state][row]
+  if (lds < sizeof(double) * (size_t)c->md.ne_hc) lds = sizeof(double) * (size_t)c->md.ne_hc;
+  return launch(c, K_HESSC, A, tile_blocks(c) + 1, lds, st);
 }
 
 // compact (coalesced) Jacobian: dense-column entries of the dynamics contracted with the integration block first
@@ -941,8 +944,30 @@ int pk_set_csr_map(pk_ctx* c, int which, const int32_t* seg, const int32_t* perm
   auto& m = c->csr[which];
   release(m.d_seg); release(m.d_perm); release(m.d_vals);
   m.n_unique = m.n_triplets = 0;
-  if (seg && (rc = upload(c, (void**)&m.d_seg, seg, sizeof(int32_t) * (size_t)(n_unique + 1)))) return rc;
-  if ((rc = upload(c, (void**)&m.d_perm, perm, sizeof(int32_t) * (size_t)n_triplets))) return rc;
+  if (seg) {
+    // repeated entries: the device gets the runs per slice of 256 consecutive CSR entries, transposed and padded to the
+    // slice's longest run (see kernel_csr)
+    const int64_t nblk = (n_unique + PK_BLOCK - 1) / PK_BLOCK;
+    std::vector<int32_t> off((size_t)nblk + 1, 0);
+    int64_t total = 0;
+    for (int64_t b = 0; b < nblk; ++b) {
+      int32_t width = 0;
+      for (int64_t p = b * PK_BLOCK; p < n_unique && p < (b + 1) * PK_BLOCK; ++p) width = std::max(width, seg[p + 1] - seg[p]);
+      off[(size_t)b] = (int32_t)total;
+      total += (int64_t)width * PK_BLOCK;
+      if (total > INT32_MAX) return fail(c, 85, "pk_set_csr_map: the padded run table does not fit 32-bit offsets");
+    }
+    off[(size_t)nblk] = (int32_t)total;
+    std::vector<int32_t> sell((size_t)total, -1);
+    for (int64_t p = 0; p < n_unique; ++p) {
+      const int64_t b = p / PK_BLOCK, t = p % PK_BLOCK;
+      for (int32_t k = 0; k < seg[p + 1] - seg[p]; ++k) sell[(size_t)(off[(size_t)b] + (int64_t)k * PK_BLOCK + t)] = perm[seg[p] + k];
+    }
+    if ((rc = upload(c, (void**)&m.d_seg, off.data(), sizeof(int32_t) * off.size()))) return rc;
+    if ((rc = upload(c, (void**)&m.d_perm, sell.data(), sizeof(int32_t) * sell.size()))) return rc;
+  } else if ((rc = upload(c, (void**)&m.d_perm, perm, sizeof(int32_t) * (size_t)n_triplets))) {
+    return rc;
+  }
   PK_HIP(c, hipMalloc((void**)&m.d_vals, sizeof(double) * (size_t)n_unique));
   m.n_unique = n_unique;
   m.n_triplets = n_triplets;

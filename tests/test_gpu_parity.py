@@ -193,14 +193,20 @@ def test_maximum_supported_order_matches_the_plan_interpreter(case):
                                   ("planar_quadrotor", "radau", dict(mesh=[0, 0.5, 0.6, 1.0], num_point=[128, 6, 200])),
                                   ("planar_quadrotor", "lobatto", dict(mesh=[0, 0.5, 1.0], num_point=[256, 7])),
                                   ("two_stage_rocket", "radau", dict(mesh=[0, 0.4, 1.0], num_point=[70, 9])),
-                                  ("humanoid_wbc", "radau", dict(mesh=[0, 0.5, 1.0], num_point=[4, 80]))])
-def test_intervals_with_more_points_than_a_wavefront_has_lanes(case):
+                                  ("humanoid_wbc", "radau", dict(mesh=[0, 0.5, 1.0], num_point=[4, 80])),
+                                  ("planar_quadrotor", "radau", dict(mesh=[0, 0.5, 0.6, 1.0], num_point=[128, 6, 200]), "mfma"),
+                                  ("brachistochrone", "lobatto", dict(mesh=[0, 0.3, 0.6, 1.0], num_point=[66, 5, 130]), "mfma")])
+def test_intervals_with_more_points_than_a_wavefront_has_lanes(case, monkeypatch):
     """64 < num_point <= 256 (the reference has no limit, radau/discretization.py:488-521): such an interval is evaluated
     by a whole workgroup (PK_BIG code objects), next to ordinary wave tiles.  Reference: the NumPy execution of the same
-    plan with the product's own tables (the oracle's np.roots-based tables carry no digits at these orders)."""
+    plan with the product's own tables (pinned by the multiprecision tables of tests/test_tables_hiprec.py up to K = 128;
+    the oracle's np.roots-based tables carry no digits at these orders).  "mfma": the same with the interval's products on
+    the fp64 matrix cores (POCKIT_AMD_BIG_MFMA=1; measured slower than the VALU form, kept as a switch)."""
     from plan_interp import Interp
 
-    bname, scheme, kw = case
+    if len(case) == 4:
+        monkeypatch.setenv("POCKIT_AMD_BIG_MFMA", "1")
+    bname, scheme, kw = case[:3]
     system, _, guess = getattr(models, bname)(_ns(scheme, "pockit_amd"), **kw)
     x, lam, sigma = models.bench_inputs(system, guess)
     it = Interp(system.plan, x, lam, sigma)
