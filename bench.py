@@ -314,8 +314,10 @@ def host_sharded_end_to_end(name, intervals, rank, world, dist, steps, warmup):
         hs = HostShardedEvaluator(system.plan, rank, world, dist, device=torch.cuda.current_device(), timeout_s=90.0)
     except Exception as exc:  # noqa: BLE001
         problem = f"rank {rank}: {exc!r}"
-    verdicts = [None] * world
-    dist.all_gather_object(verdicts, problem)
+    verdicts = [problem]
+    if world > 1:
+        verdicts = [None] * world
+        dist.all_gather_object(verdicts, problem)
     failed = sorted(set(v for v in verdicts if v))
     if failed:
         if hs is not None:
@@ -362,7 +364,8 @@ def host_sharded_end_to_end(name, intervals, rank, world, dist, steps, warmup):
         out = {"error": repr(exc)}
     finally:
         hs.close()
-    dist.barrier()
+    if world > 1:
+        dist.barrier()
     return out
 
 
@@ -537,22 +540,44 @@ class GpuWorkload:
         self.dist.all_reduce(t, op=self.dist.ReduceOp.MIN)
         return float(t[0]) == 1.0
 
+    def agree(self, ok):
+        """True only if ``ok`` holds on EVERY rank (collective): the ranks then take the same branch before the next
+        collective or exchanging launch -- a rank that failed alone would otherwise leave the others in a different
+        sequence of collectives (a hang) or of exchange cycles (sums that wait for a peer that never posts)."""
+        if self.dist is None or self.world == 1:
+            return bool(ok)
+        t = self.torch.tensor([1.0 if ok else 0.0], dtype=self.torch.float64, device=self.dev)
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MIN)
+        return float(t[0]) == 1.0
+
     def time_mode(self, mode, steps=200):
-        """ms per cycle of another form of the exchange (short untimed warm-up, wall clock between barriers)."""
+        """ms per cycle of another form of the exchange (short untimed warm-up, wall clock between barriers).  Only LOCAL
+        work sits inside the try blocks; every decision is taken on all ranks from an all-reduced flag."""
+        err, step = None, None
         try:
             step = self.make_step(mode)
             for _ in range(10):
                 step()
-            self.sync()
-            if mode in ("sums", "direct") and not self.all_finite():      # (a timed-out exchange costs ~1 s per launch)
-                raise RuntimeError("sums not finite after ten back-to-back cycles")
-            t0 = time.perf_counter()
+        except Exception as exc:  # noqa: BLE001 -- a side figure must not cost the headline
+            err = repr(exc)
+        self.sync()
+        finite = True
+        if err is None and mode in ("sums", "direct"):      # (a timed-out exchange costs seconds per launch)
+            finite = bool(self.torch.isfinite(self.o["f"]).all())
+        if not self.agree(err is None and finite):
+            return err or ("sums not finite after ten back-to-back cycles" if not finite else
+                           "another rank failed in this form of the exchange")
+        t0 = time.perf_counter()
+        try:
             for _ in range(steps):
                 step()
-            self.sync()
-            return (time.perf_counter() - t0) / steps * 1e3
-        except Exception as exc:  # noqa: BLE001 -- a side figure must not cost the headline
-            return repr(exc)
+        except Exception as exc:  # noqa: BLE001
+            err = repr(exc)
+        self.sync()
+        ms = (time.perf_counter() - t0) / steps * 1e3
+        if not self.agree(err is None):
+            return err or "another rank failed while this form was timed"
+        return ms
 
     def sync(self):
         self.torch.cuda.synchronize()
@@ -838,6 +863,14 @@ def measure(name, intervals, steps, warmup, rank, world, dist, with_side=True, w
     if with_e2e and world > 1:
         res["end_to_end_host_sharded"] = host_sharded_end_to_end(name, intervals, rank, world, dist, e2e_steps or steps,
                                                                   e2e_warmup if e2e_warmup is not None else warmup)
+    if with_e2e and world == 1 and with_side and isinstance(res.get("end_to_end"), dict):
+        # N = 1 through the code path of the N > 1 headline (one rank, the shared pinned segment, run copies): must sit near
+        # the single-GPU headline -- what the N-GPU lines are compared with
+        try:
+            res["end_to_end"]["host_sharded_path_with_one_rank"] = host_sharded_end_to_end(
+                name, intervals, 0, 1, None, min(e2e_steps or steps, 20), 5)
+        except Exception as exc:  # noqa: BLE001
+            res["end_to_end"]["host_sharded_path_with_one_rank"] = {"error": repr(exc)}
     return res
 
 
@@ -896,6 +929,132 @@ def cold_compile_seconds(name, intervals):
             return time.perf_counter() - t0
     finally:
         hipbuild.CACHE_DIR = keep
+
+
+def assemble_line(args, res, e2e, n_gpus, intervals, ms, wall_ms, head_ms, basis):
+    """The JSON line of rank 0 (without the supplementary workloads): ``value`` = the host-landed cycle (``head_ms`` per
+    cycle; None -> the device-resident rate, said so in ``value_basis``), the device-resident launch rate and the roofline of
+    the dominant kernel beside it, and for N > 1 what the run saw of the machine (``multi_gpu``)."""
+    dev_value = n_gpus * 1e3 / ms
+    if head_ms is None:        # no host-landed figure (--no-end-to-end, or it failed): the device-resident rate, said so
+        head_ms = ms
+        basis = ("DEVICE-RESIDENT launch rate (x, lambda and all outputs stay in HBM): the host-landed cycle was not "
+                 "measured in this run" + (f" ({e2e.get('error')})" if isinstance(e2e, dict) and e2e.get("error") else ""))
+    value = n_gpus * 1e3 / head_ms
+    dom = res["dominant"]
+    dom_bytes = res["bytes"][dom[3:]] / n_gpus
+    x_once = res["bytes"]["cycle_x_once"] / n_gpus if dom == "pk_cycle" else None
+    # the kernel's average launch duration: HIP events over the timed region / launches when the cycle is ONE launch
+    # (launch + gap to the next launch: an upper bound of the kernel's own duration in this very run); a cycle of
+    # several launches, or N > 1 (the region holds the exchange too), uses the per-dispatch events
+    dom_us = ms * 1e3 if (dom == "pk_cycle" and n_gpus == 1) else res["dispatch_isolated_us"]
+    achieved = dom_bytes / (dom_us * 1e-6) / 1e9 if dom_us else None
+    traffic, profiled = None, None
+    tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    if os.path.exists(tpath):
+        try:
+            rec = json.load(open(tpath)).get(f"{args.workload}_{intervals}", {})
+            traffic = rec.get(dom)
+            profiled = rec.get(dom + "_profiled")     # {"avg_ns": ..., "calls": ..., "file": "profiles/..."} of the committed trace
+        except Exception:
+            traffic = None
+    out_bytes = 8 * (1 + res["n"] + res["m"] + res["nnz_J"] + res["nnz_H"]) / n_gpus
+    regime = ("hbm" if out_bytes > 256 * 2**20 else ("latency" if (dom_us and dom_us < 2 * LAUNCH_FLOOR_US) else "mall"))
+    line = {
+        "metric": "NLP-callback cycles/sec (f + grad f + g + J + H)",
+        "value": value,
+        "unit": "cycles/s" if n_gpus == 1 else "12k-node-equivalent cycles/s",
+        "n_gpus": n_gpus, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": head_ms,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f64", "data": "synthetic",
+        "value_basis": basis,
+        "config": {"workload": f"{args.workload} LGR {intervals} intervals x {POINTS.get(args.workload.replace('_lgl', ''), 0)}"
+                               f" points ({res['nodes']} nodes; n={res['n']}, m={res['m']}, nnz_J={res['nnz_J']}, "
+                               f"nnz_H={res['nnz_H']})",
+                   "sharding": ("single GPU" if n_gpus == 1 else
+                                f"mesh intervals over {n_gpus} GPUs (shares balanced by output volume); every rank uploads x over "
+                                f"its own PCIe link, evaluates its tiles and stores its owned runs of grad f / g / J / H straight "
+                                f"into ONE pinned host array shared by the ranks; rank 0 adds the partial sums in rank order -- "
+                                f"no collective in the data path (device-resident side forms: see device_resident)"),
+                   "tiles": res["tiles"], "intervals_per_wave": res["ipw"],
+                   "inputs": "example guess*(1+1e-3 U(-1,1)) seed 0; lambda N(0,1) seed 1; sigma 1"},
+        "timing": {"region": ("R back-to-back batches of exactly `steps` host-landed cycles on the host clock (a cycle ends with "
+                              "its Hessian in host memory), synchronize (+ barrier) around the region; ms_per_step = median "
+                              "batch / steps; see end_to_end" + ("" if n_gpus == 1 else "_host_sharded")),
+                   "headline": (e2e.get("headline") if (isinstance(e2e, dict) and n_gpus == 1) else
+                                ({k: e2e.get(k) for k in ("batches", "steps", "batch_ms_min_p10_p90_max")}
+                                 if isinstance(e2e, dict) else None))},
+        "device_resident": {
+            "value": dev_value, "unit": "cycles/s" if n_gpus == 1 else "12k-node-equivalent cycles/s", "ms_per_step": ms,
+            "what": ("the same cycle with x and lambda resident in HBM and all outputs left in HBM: ONE pk_cycle launch per "
+                     "cycle" + ("" if n_gpus == 1 else f" and GPU, exchange form '{res['exchange']}': "
+                                + SHARDING_NOTE[res["exchange"]].format(n=n_gpus))),
+            "timing": {"region": f"{res['batches']} back-to-back batches of exactly {args.steps} cycles (>= {MIN_REGION_S * 1e3:.0f} ms "
+                                 f"in total), a HIP event on the launch stream after every {res['event_group']} batches (an event "
+                                 f"drains the stream: ~3 us each), barrier + synchronize around the region; ms_per_step = median "
+                                 f"over the timed units of (unit duration / {res['event_group']} batches) / steps (max over ranks)",
+                       "batches": res["batches"], "batches_per_timing_event": res["event_group"],
+                       "batch_launch": res["batch_launch"],
+                       "median_batch_ms": res["median_batch_ms"],
+                       "batch_ms_min_p10_p90_max": [res["batch_ms_min"], res["batch_ms_p10"], res["batch_ms_p90"], res["batch_ms_max"]],
+                       "region_wall_s": res["region_wall_s"], "wall_ms_per_step_whole_region": wall_ms,
+                       "untimed_launches_before_the_region": res["untimed_launches"]}},
+        "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBPS,
+                     "unit": "GB/s", "frac": (achieved / HBM_PEAK_GBPS if achieved else None), "traffic": traffic,
+                     "regime": regime,
+                     "regime_note": ("latency: the launch lasts less than twice the ~4.3 us a launch of this shape costs before "
+                                     "its first byte leaves; mall: the outputs of one launch (rewritten every cycle) fit the "
+                                     "256 MiB Infinity Cache, FETCH/WRITE_SIZE count fabric requests; hbm: they do not"),
+                     "frac_of_achievable": (achieved / HBM_ACHIEVABLE_GBPS if achieved else None),
+                     "achievable_peak": HBM_ACHIEVABLE_GBPS,
+                     "frac_profiled": ((dom_bytes / (profiled["avg_ns"] * 1e-9) / 1e9 / HBM_PEAK_GBPS)
+                                       if (profiled and profiled.get("avg_ns")) else None),
+                     "profiled": profiled,
+                     "algorithmic_bytes_per_launch": dom_bytes,
+                     "avg_launch_us": dom_us,
+                     "frac_x_once": (x_once / (dom_us * 1e-6) / 1e9 / HBM_PEAK_GBPS if (x_once and dom_us) else None),
+                     "algorithmic_bytes_per_launch_x_counted_once": x_once,
+                     "dispatch_isolated_us": res["dispatch_isolated_us"],
+                     "frac_dispatch_isolated": (dom_bytes / (res["dispatch_isolated_us"] * 1e-6) / 1e9 / HBM_PEAK_GBPS
+                                                if res["dispatch_isolated_us"] else None),
+                     "dispatch_in_flight_us": res["dispatch_in_flight_us"],
+                     "dispatch_samples_isolated_in_flight": res["dispatch_samples"],
+                     "timing": ("measured on the device-resident region (device_resident.timing).  avg_launch_us: HIP events on "
+                                "the launch stream around every batch of that region, median "
+                                "batch / steps -- one launch plus the gap to the next one, i.e. an upper bound of the "
+                                "kernel's own duration in this run (the launches of a stream do not overlap); "
+                                "dispatch_isolated_us: start / stop events attached to the dispatch "
+                                "(hipExtModuleLaunchKernel), stream idle before each sampled launch; dispatch_in_flight_us: "
+                                "the same per-dispatch events on every 64th launch of a back-to-back run (start is stamped "
+                                "when the packet is taken up, before the launch ahead of it has drained).  A kernel trace "
+                                "(rocprofv3) slows the loop it observes (profiles/README.md): its per-kernel average lies "
+                                "between these figures; frac_profiled = the same bytes over the committed trace's average"
+                                if (dom == "pk_cycle" and n_gpus == 1) else
+                                "avg_launch_us: start / stop events attached to the dispatch, stream idle before each "
+                                "sampled launch")},
+        "kernels_only_without_exchange": (None if res["no_exchange_ms_per_step"] is None else {
+            "value": n_gpus * 1e3 / res["no_exchange_ms_per_step"], "unit": "12k-node-equivalent cycles/s",
+            "note": "rank 0's clock around the same per-rank pk_cycle launches with no collective "
+                    "(every rank keeps its own slices of grad/g/J/H)"}),
+        "exchange_forms": (None if res["exchange_forms_ms_per_step"] is None else {
+            "ms_per_step": res["exchange_forms_ms_per_step"],
+            "equivalent_cycles_per_s": {k: (n_gpus * 1e3 / v if isinstance(v, float) else v)
+                                        for k, v in res["exchange_forms_ms_per_step"].items()},
+            "note": "device-resident forms of a sharded cycle.  sums: slices stay in each GPU's HBM, only the sums over all "
+                    "nodes are exchanged (pk_xchg, peer "
+                    "mailboxes); direct: reassembly on rank 0's GPU by peer stores over xGMI; gather: RCCL gather of "
+                    "the packed runs to rank 0.  The reassembling forms move one shard per peer into ONE GPU every "
+                    "cycle and are bound by that GPU's xGMI links"}),
+        "ranks": res["ranks"],
+        "multi_gpu": res.get("multi_gpu"),
+        "exchange_check": res.get("exchange_check"),
+        "kernel_us": res["kernel_us"],
+        "cycle_algorithmic_bytes": res["bytes"]["cycle"],
+        "setup_s": res["setup_s"], "compile_s_in_setup": res["compile_s_in_setup"],
+        "outputs_finite": res["finite"],
+    }
+    return line, value, dev_value
 
 
 def spawn_ranks(args):
@@ -964,18 +1123,33 @@ def main():
     if world > 1 and not args.no_extra:
         for nm, iv, tag in (("two_stage_rocket", 1000, "C4 two_stage_rocket 2 phases x 1000 intervals x 4 points"),
                             ("humanoid_wbc", 5000, "C5 humanoid_wbc 5000 intervals x 8 points")):
+            # (only LOCAL work inside the try: building and compiling the model; whether to go on is decided on every rank
+            #  from an all-reduced flag -- a rank that failed alone must not leave the others inside a collective)
+            problem = None
             try:
-                r = measure(nm, iv, args.steps, min(args.warmup, 50), rank, world, dist, with_side=False,
-                            with_e2e=(nm == "humanoid_wbc" and not args.no_end_to_end))
-                tt = torch.tensor([r["ms_per_step"]], dtype=torch.float64, device="cuda")
-                dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-                strong[f"{nm}_{iv}_strong_scaled_over_{world}"] = {
-                    "config": tag, "nodes": r["nodes"], "scaling": "strong", "cycles_per_s": 1e3 / float(tt.item()),
-                    "ms_per_step": float(tt.item()), "exchange": r["exchange"], "exchange_forms_ms_per_step": r["exchange_forms_ms_per_step"],
-                    "ranks": r["ranks"], "cycle_bytes": r["bytes"]["cycle"],
-                    "end_to_end_host_sharded": r.get("end_to_end_host_sharded")}
+                import pockit_amd.radau as radau
+
+                build_workload(nm, iv, radau)[0].plan  # noqa: B018
             except Exception as exc:  # noqa: BLE001
-                strong[f"{nm}_{iv}_strong_scaled_over_{world}"] = {"error": repr(exc)}
+                problem = repr(exc)
+            flags = [None] * world
+            dist.all_gather_object(flags, problem)
+            if any(flags):
+                strong[f"{nm}_{iv}_strong_scaled_over_{world}"] = {"error": "; ".join(sorted(set(f for f in flags if f)))}
+                continue
+            r = measure(nm, iv, args.steps, min(args.warmup, 50), rank, world, dist, with_side=False,
+                        with_e2e=not args.no_end_to_end, e2e_steps=min(args.steps, 20), e2e_warmup=5)
+            tt = torch.tensor([r["ms_per_step"]], dtype=torch.float64, device="cuda")
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            hs = r.get("end_to_end_host_sharded")
+            strong[f"{nm}_{iv}_strong_scaled_over_{world}"] = {
+                "config": tag, "nodes": r["nodes"], "scaling": "strong",
+                "cycles_per_s": (hs.get("cycles_per_s") if isinstance(hs, dict) else None),
+                "value_basis": "host-landed sharded cycle (end_to_end_host_sharded); device_resident beside it",
+                "device_resident": {"cycles_per_s": 1e3 / float(tt.item()), "ms_per_step": float(tt.item()), "exchange": r["exchange"],
+                                    "exchange_forms_ms_per_step": r["exchange_forms_ms_per_step"]},
+                "ranks": r["ranks"], "cycle_bytes": r["bytes"]["cycle"],
+                "end_to_end_host_sharded": hs}
 
     # ---- the headline: the solver-visible (host-landed) cycle; the device-resident launch rate stays beside it
     e2e = res.get("end_to_end") if world == 1 else res.get("end_to_end_host_sharded")
@@ -994,125 +1168,7 @@ def main():
         dist.broadcast_object_list(box, src=0)
         head_ms, basis = box
     if rank == 0:
-        dev_value = n_gpus * 1e3 / ms
-        if head_ms is None:        # no host-landed figure (--no-end-to-end, or it failed): the device-resident rate, said so
-            head_ms = ms
-            basis = ("DEVICE-RESIDENT launch rate (x, lambda and all outputs stay in HBM): the host-landed cycle was not "
-                     "measured in this run" + (f" ({e2e.get('error')})" if isinstance(e2e, dict) and e2e.get("error") else ""))
-        value = n_gpus * 1e3 / head_ms
-        dom = res["dominant"]
-        dom_bytes = res["bytes"][dom[3:]] / n_gpus
-        x_once = res["bytes"]["cycle_x_once"] / n_gpus if dom == "pk_cycle" else None
-        # the kernel's average launch duration: HIP events over the timed region / launches when the cycle is ONE launch
-        # (launch + gap to the next launch: an upper bound of the kernel's own duration in this very run); a cycle of
-        # several launches, or N > 1 (the region holds the exchange too), uses the per-dispatch events
-        dom_us = ms * 1e3 if (dom == "pk_cycle" and n_gpus == 1) else res["dispatch_isolated_us"]
-        achieved = dom_bytes / (dom_us * 1e-6) / 1e9 if dom_us else None
-        traffic, profiled = None, None
-        tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-        if os.path.exists(tpath):
-            try:
-                rec = json.load(open(tpath)).get(f"{args.workload}_{intervals}", {})
-                traffic = rec.get(dom)
-                profiled = rec.get(dom + "_profiled")     # {"avg_ns": ..., "calls": ..., "file": "profiles/..."} of the committed trace
-            except Exception:
-                traffic = None
-        out_bytes = 8 * (1 + res["n"] + res["m"] + res["nnz_J"] + res["nnz_H"]) / n_gpus
-        regime = ("hbm" if out_bytes > 256 * 2**20 else ("latency" if (dom_us and dom_us < 2 * LAUNCH_FLOOR_US) else "mall"))
-        line = {
-            "metric": "NLP-callback cycles/sec (f + grad f + g + J + H)",
-            "value": value,
-            "unit": "cycles/s" if n_gpus == 1 else "12k-node-equivalent cycles/s",
-            "n_gpus": n_gpus, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": head_ms,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f64", "data": "synthetic",
-            "value_basis": basis,
-            "config": {"workload": f"{args.workload} LGR {intervals} intervals x {POINTS.get(args.workload.replace('_lgl', ''), 0)}"
-                                   f" points ({res['nodes']} nodes; n={res['n']}, m={res['m']}, nnz_J={res['nnz_J']}, "
-                                   f"nnz_H={res['nnz_H']})",
-                       "sharding": ("single GPU" if n_gpus == 1 else
-                                    f"mesh intervals over {n_gpus} GPUs (shares balanced by output volume); every rank uploads x over "
-                                    f"its own PCIe link, evaluates its tiles and stores its owned runs of grad f / g / J / H straight "
-                                    f"into ONE pinned host array shared by the ranks; rank 0 adds the partial sums in rank order -- "
-                                    f"no collective in the data path (device-resident side forms: see device_resident)"),
-                       "tiles": res["tiles"], "intervals_per_wave": res["ipw"],
-                       "inputs": "example guess*(1+1e-3 U(-1,1)) seed 0; lambda N(0,1) seed 1; sigma 1"},
-            "timing": {"region": ("R back-to-back batches of exactly `steps` host-landed cycles on the host clock (a cycle ends with "
-                                  "its Hessian in host memory), synchronize (+ barrier) around the region; ms_per_step = median "
-                                  "batch / steps; see end_to_end" + ("" if n_gpus == 1 else "_host_sharded")),
-                       "headline": (e2e.get("headline") if (isinstance(e2e, dict) and n_gpus == 1) else
-                                    ({k: e2e.get(k) for k in ("batches", "steps", "batch_ms_min_p10_p90_max")}
-                                     if isinstance(e2e, dict) else None))},
-            "device_resident": {
-                "value": dev_value, "unit": "cycles/s" if n_gpus == 1 else "12k-node-equivalent cycles/s", "ms_per_step": ms,
-                "what": ("the same cycle with x and lambda resident in HBM and all outputs left in HBM: ONE pk_cycle launch per "
-                         "cycle" + ("" if n_gpus == 1 else f" and GPU, exchange form '{res['exchange']}': "
-                                    + SHARDING_NOTE[res["exchange"]].format(n=n_gpus))),
-                "timing": {"region": f"{res['batches']} back-to-back batches of exactly {args.steps} cycles (>= {MIN_REGION_S * 1e3:.0f} ms "
-                                     f"in total), a HIP event on the launch stream after every {res['event_group']} batches (an event "
-                                     f"drains the stream: ~3 us each), barrier + synchronize around the region; ms_per_step = median "
-                                     f"over the timed units of (unit duration / {res['event_group']} batches) / steps (max over ranks)",
-                           "batches": res["batches"], "batches_per_timing_event": res["event_group"],
-                           "batch_launch": res["batch_launch"],
-                           "median_batch_ms": res["median_batch_ms"],
-                           "batch_ms_min_p10_p90_max": [res["batch_ms_min"], res["batch_ms_p10"], res["batch_ms_p90"], res["batch_ms_max"]],
-                           "region_wall_s": res["region_wall_s"], "wall_ms_per_step_whole_region": wall_ms,
-                           "untimed_launches_before_the_region": res["untimed_launches"]}},
-            "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBPS,
-                         "unit": "GB/s", "frac": (achieved / HBM_PEAK_GBPS if achieved else None), "traffic": traffic,
-                         "regime": regime,
-                         "regime_note": ("latency: the launch lasts less than twice the ~4.3 us a launch of this shape costs before "
-                                         "its first byte leaves; mall: the outputs of one launch (rewritten every cycle) fit the "
-                                         "256 MiB Infinity Cache, FETCH/WRITE_SIZE count fabric requests; hbm: they do not"),
-                         "frac_of_achievable": (achieved / HBM_ACHIEVABLE_GBPS if achieved else None),
-                         "achievable_peak": HBM_ACHIEVABLE_GBPS,
-                         "frac_profiled": ((dom_bytes / (profiled["avg_ns"] * 1e-9) / 1e9 / HBM_PEAK_GBPS)
-                                           if (profiled and profiled.get("avg_ns")) else None),
-                         "profiled": profiled,
-                         "algorithmic_bytes_per_launch": dom_bytes,
-                         "avg_launch_us": dom_us,
-                         "frac_x_once": (x_once / (dom_us * 1e-6) / 1e9 / HBM_PEAK_GBPS if (x_once and dom_us) else None),
-                         "algorithmic_bytes_per_launch_x_counted_once": x_once,
-                         "dispatch_isolated_us": res["dispatch_isolated_us"],
-                         "frac_dispatch_isolated": (dom_bytes / (res["dispatch_isolated_us"] * 1e-6) / 1e9 / HBM_PEAK_GBPS
-                                                    if res["dispatch_isolated_us"] else None),
-                         "dispatch_in_flight_us": res["dispatch_in_flight_us"],
-                         "dispatch_samples_isolated_in_flight": res["dispatch_samples"],
-                         "timing": ("measured on the device-resident region (device_resident.timing).  avg_launch_us: HIP events on "
-                                    "the launch stream around every batch of that region, median "
-                                    "batch / steps -- one launch plus the gap to the next one, i.e. an upper bound of the "
-                                    "kernel's own duration in this run (the launches of a stream do not overlap); "
-                                    "dispatch_isolated_us: start / stop events attached to the dispatch "
-                                    "(hipExtModuleLaunchKernel), stream idle before each sampled launch; dispatch_in_flight_us: "
-                                    "the same per-dispatch events on every 64th launch of a back-to-back run (start is stamped "
-                                    "when the packet is taken up, before the launch ahead of it has drained).  A kernel trace "
-                                    "(rocprofv3) slows the loop it observes (profiles/README.md): its per-kernel average lies "
-                                    "between these figures; frac_profiled = the same bytes over the committed trace's average"
-                                    if (dom == "pk_cycle" and n_gpus == 1) else
-                                    "avg_launch_us: start / stop events attached to the dispatch, stream idle before each "
-                                    "sampled launch")},
-            "kernels_only_without_exchange": (None if res["no_exchange_ms_per_step"] is None else {
-                "value": n_gpus * 1e3 / res["no_exchange_ms_per_step"], "unit": "12k-node-equivalent cycles/s",
-                "note": "rank 0's clock around the same per-rank pk_cycle launches with no collective "
-                        "(every rank keeps its own slices of grad/g/J/H)"}),
-            "exchange_forms": (None if res["exchange_forms_ms_per_step"] is None else {
-                "ms_per_step": res["exchange_forms_ms_per_step"],
-                "equivalent_cycles_per_s": {k: (n_gpus * 1e3 / v if isinstance(v, float) else v)
-                                            for k, v in res["exchange_forms_ms_per_step"].items()},
-                "note": "device-resident forms of a sharded cycle.  sums: slices stay in each GPU's HBM, only the sums over all "
-                        "nodes are exchanged (pk_xchg, peer "
-                        "mailboxes); direct: reassembly on rank 0's GPU by peer stores over xGMI; gather: RCCL gather of "
-                        "the packed runs to rank 0.  The reassembling forms move one shard per peer into ONE GPU every "
-                        "cycle and are bound by that GPU's xGMI links"}),
-            "ranks": res["ranks"],
-            "multi_gpu": res.get("multi_gpu"),
-            "exchange_check": res.get("exchange_check"),
-            "kernel_us": res["kernel_us"],
-            "cycle_algorithmic_bytes": res["bytes"]["cycle"],
-            "setup_s": res["setup_s"], "compile_s_in_setup": res["compile_s_in_setup"],
-            "outputs_finite": res["finite"],
-        }
+        line, value, dev_value = assemble_line(args, res, e2e, n_gpus, intervals, ms, wall_ms, head_ms, basis)
         line.update(res["side"])
         if res["end_to_end"] is not None:
             line["end_to_end"] = res["end_to_end"]

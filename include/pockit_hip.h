@@ -142,6 +142,7 @@ int pk_eval_cycle(pk_ctx* ctx, const double* x, const double* lambda, double sig
  * What SystemBase.hessian (systembase.py:820-835) becomes for a solver that was handed the compact structure. */
 int pk_eval_hessc_prepared(pk_ctx* ctx, const double* lambda, double sigma, double* vals, int vals_pinned);
 int pk_same_x(pk_ctx* ctx, const double* x);
+int pk_same_bits(const double* a, const double* b, size_t n);   /* 1 if equal bit for bit (memcmp), for host shims */
 int pk_prepare_x(pk_ctx* ctx, const double* x);
 int pk_fetch(pk_ctx* ctx, int what, double* out);
 int pk_eval_hess_prepared(pk_ctx* ctx, const double* lambda /* NULL: staged */, double sigma, double* vals);
@@ -154,7 +155,9 @@ int pk_set_result_targets(pk_ctx* ctx, double* f, double* grad, double* g, doubl
  *                     in `block`, pinned memory of the caller's laid out like the library's own buffers,
  *                     [J (nnz_J) | grad f (n) | g (m)] (NULL: the context's buffers, pk_host_buffer) -- the pieces of J that
  *                     change with x, grad f and g leave the device in ONE copy.  Then result `what` is waited for; f_out
- *                     receives f for what = 0.
+ *                     receives f for what = 0.  A block must stay allocated until every result of its iterate has been
+ *                     fetched or the context's stream has been synchronized (pk_sync, pk_destroy): all results of a new x
+ *                     are on their way into it whether or not they are asked for.
  *   pk_callback_hess  SystemBase.hessian (systembase.py:820-835): stages the multipliers, prepares a new x as above, evaluates
  *                     the Hessian of the Lagrangian into `hess` (pinned memory of the caller's or NULL = the context's
  *                     buffer; compact = 1: the compact layout of pk_eval_hessc, `hess` required) and waits for it.
@@ -262,6 +265,7 @@ int pk_set_cycle_graph(pk_ctx* ctx, int enable);
 /* single_launch = 1 (default): pk_cycle; 0: the two-launch form, pk_xall then pk_hess, which also reduces */
 int pk_set_cycle_mode(pk_ctx* ctx, int single_launch);
 int pk_sync(pk_ctx* ctx, void* stream);
+int pk_wait_idle(pk_ctx* ctx, void* stream);   /* the same by polling the stream (returns a few microseconds earlier) */
 
 /* Mesh-interval sharding across GPUs (one context per GPU, each holding its shard of the tiles):
  * ``secondary`` shards skip the boundary-node / system-level work (done once, on the primary);
@@ -294,7 +298,11 @@ int pk_host_register(pk_ctx* ctx, void* p, size_t bytes, void** dev_ptr);
 int pk_host_unregister(pk_ctx* ctx, void* p);
 int pk_copy_dev(pk_ctx* ctx, void* dst, const void* src, size_t bytes, void* stream);
 int pk_set_exchange(pk_ctx* ctx, int world, int rank, const void* d_boxes, const int32_t* d_idx, int n_sh, int stride);
-int pk_exchange_sums_dev(pk_ctx* ctx, const double* d_x, double* d_grad, double* d_f, int epoch /* <= 0: the context counts */,
+/* pk_set_exchange: every rank's mailbox holds 2 * world * stride words + 16 state words (zeroed here on this rank: the caller
+ * puts a barrier between the set-up and the first cycle).  pk_exchange_status: cycles exchanged so far and how many of them
+ * timed out waiting for a peer (then this rank's sums read NaN). */
+int pk_exchange_status(pk_ctx* ctx, void* stream, int64_t* cycles, int64_t* timed_out);
+int pk_exchange_sums_dev(pk_ctx* ctx, const double* d_x, double* d_grad, double* d_f, int epoch /* <= 0: counted on the device */,
                          int write_f, void* stream);
 /* 1: the finalize workgroup of pk_eval_cycle_dev's launch exchanges the partial sums itself -- a sharded cycle is ONE
  * launch per GPU; 0 (default): pk_exchange_sums_dev is a launch of its own behind it. */

@@ -117,6 +117,7 @@ struct PkErrIv {
 #define PK_MAX_PHASES 8
 #define PK_CYCLE_ARGS_OFFSET 24   // pk_cycle: bytes of leading scalar kernel arguments in front of its PkArgs
 #define PK_MAX_RANKS 64       // ranks of one sharded NLP (pk_xchg: one polling thread per peer)
+#define PK_XC_STATE 16        // state words behind the 2 x world x stride words of a rank's mailbox (cycle count, time-outs)
 
 // pk_cycle's in-launch hand-off: a slot of cpart / cpart2 is either PK_EMPTY (a quiet-NaN pattern no arithmetic
 // produces) or the value a tile workgroup published during the current launch.
@@ -175,7 +176,8 @@ struct PkArgs {
   int32_t n_outer;
   int32_t n_erriv;        // (pk_err: number of wave groups)
   int32_t n_csr;          // CSR entries
-  int32_t xc_world, xc_rank, xc_epoch, xc_nsh;   // ranks, this rank, cycle number (>= 1), number of shared gradient slots
+  int32_t xc_world, xc_rank, xc_epoch, xc_nsh;   // ranks, this rank, cycle number (> 0: given by the host; 0: counted on the
+                                                 // device, in the mailbox's state block), number of shared gradient slots
   int32_t xc_stride, rc_n;                       // mailbox words per sender (multiple of 16); chunks of the run table
   PkPhase ph[PK_MAX_PHASES];   // the phases by value (kernarg segment): no dependent global load
 };

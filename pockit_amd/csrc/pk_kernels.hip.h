@@ -2255,14 +2255,15 @@ __device__ __forceinline__ void fin_body(const PkArgs& A) {
 // rank gets bit-identical sums) -- one workgroup, no collective library call, no host round trip.  It runs INSIDE the
 // cycle's launch (pk_cycle's finalize workgroup, flags bit 6: a sharded cycle is ONE launch per GPU) or as a launch of
 // its own behind it (pk_xchg).
-// Mailbox of a rank: [parity 2][sender world][xc_stride] words, word 0 of a sender's slot = flag, data from word 1.
+// Mailbox of a rank: [parity 2][sender world][xc_stride] words, word 0 of a sender's slot = flag, data from word 1; behind
+// them PK_XC_STATE words of this rank's own state (word 0: cycles exchanged so far, word 1: exchanges that timed out).
 // Two parities: a rank that is one cycle ahead posts into the other half (it cannot be two ahead: it needs every
 // peer's flag of the cycle in between).  The poll is bounded (then the sums read NaN).
 // ============================================================================================
 #define PK_XC_CAP 512                                   // doubles of a partial vector (host checks)
 #ifndef PK_XC_POLL_LIMIT
-#define PK_XC_POLL_LIMIT (1 << 20)                      // poll rounds for a peer's flag: of the order of a second, then NaN
-#endif
+#define PK_XC_POLL_LIMIT (1 << 24)                      // poll rounds for a peer's flag (~0.5 us each: of the order of ten seconds --
+#endif                                                  // a peer may be held up by a module load or a page fault), then NaN + status
 __device__ __forceinline__ void sys_store(unsigned long long* p, unsigned long long v) {
   __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
@@ -2274,9 +2275,20 @@ __device__ __forceinline__ unsigned long long sys_load(unsigned long long* p) {
 // synchronized) -> total[0 .. n_small) (LDS, the sums over all ranks); all PK_BLOCK threads call it
 __device__ __forceinline__ void exchange_partials(const PkArgs& A, const double* mine, double* total, int n_small) {
   __shared__ int late;
+  __shared__ unsigned long long epoch_sh;
   const int t = threadIdx.x, W = A.xc_world, me = A.xc_rank;
-  const size_t half = (size_t)(A.xc_epoch & 1) * W * A.xc_stride;
-  if (t == 0) late = 0;
+  // The cycle number lives in DEVICE memory -- word 0 of the state block behind this rank's own mailbox -- and is advanced
+  // by the exchange itself: the launch arguments of a sharded cycle are then the same for every cycle and a batch of them
+  // can be replayed as a hipGraph (a host-side count, round 2, was a kernel argument that changed with every launch).
+  // xc_epoch > 0 overrides it (a caller that numbers the cycles itself).  Word 1 counts exchanges that gave up waiting.
+  unsigned long long* state = A.xc_box[me] + 2 * (size_t)W * A.xc_stride;
+  if (t == 0) {
+    late = 0;
+    epoch_sh = A.xc_epoch > 0 ? (unsigned long long)A.xc_epoch : sys_load(state) + 1ull;
+  }
+  __syncthreads();
+  const unsigned long long epoch = epoch_sh;
+  const size_t half = (size_t)(epoch & 1ull) * W * A.xc_stride;
   for (int i = t; i < n_small; i += PK_BLOCK) {
     const unsigned long long b = (unsigned long long)__double_as_longlong(mine[i]);
     for (int q = 0; q < W; ++q)
@@ -2284,12 +2296,12 @@ __device__ __forceinline__ void exchange_partials(const PkArgs& A, const double*
   }
   __threadfence_system();                               // my data before my flags, for every observer
   __syncthreads();
-  if (t < W && t != me) sys_store(A.xc_box[t] + half + (size_t)me * A.xc_stride, (unsigned long long)A.xc_epoch);
+  if (t < W && t != me) sys_store(A.xc_box[t] + half + (size_t)me * A.xc_stride, epoch);
   if (t < W && t != me) {                               // one polling thread per peer
     unsigned long long* flag = A.xc_box[me] + half + (size_t)t * A.xc_stride;
-    int tries = 0;
-    while (sys_load(flag) != (unsigned long long)A.xc_epoch && ++tries < PK_XC_POLL_LIMIT) __builtin_amdgcn_s_sleep(PK_POLL_SLEEP);
-    if (tries >= PK_XC_POLL_LIMIT) late = 1;
+    long tries = 0;
+    while (sys_load(flag) != epoch && ++tries < (long)PK_XC_POLL_LIMIT) __builtin_amdgcn_s_sleep(PK_POLL_SLEEP);
+    if (tries >= (long)PK_XC_POLL_LIMIT) late = 1;
   }
   __threadfence_system();
   __syncthreads();
@@ -2299,6 +2311,10 @@ __device__ __forceinline__ void exchange_partials(const PkArgs& A, const double*
       sum += q == me ? mine[i]
                      : __longlong_as_double((long long)sys_load(A.xc_box[me] + half + (size_t)q * A.xc_stride + 1 + i));
     total[i] = late ? __longlong_as_double(0x7FF8000000000000ll) : sum;
+  }
+  if (t == 0) {
+    if (A.xc_epoch <= 0) sys_store(state, epoch);       // (read again by the next launch of this stream)
+    if (late) sys_store(state + 1, sys_load(state + 1) + 1ull);      // the host reads it: pk_exchange_status
   }
   __syncthreads();
 }
@@ -2462,10 +2478,23 @@ __device__ __forceinline__ void kernel_xchg(const PkArgs& A) {
 // unpack passes of the RCCL gather / all-gather reassembly (A/B forms of the exchange): a rank's owned output positions
 // are a few dozen contiguous runs, cut into chunks of at most 16 Ki doubles by the host, one workgroup per chunk.
 __device__ __forceinline__ void kernel_runs(const PkArgs& A) {
+  typedef double pk_d2 __attribute__((ext_vector_type(2)));
   for (int c = blockIdx.x; c < A.rc_n; c += gridDim.x) {
     const int64_t so = A.rc_table[3 * c], dofs = A.rc_table[3 * c + 1], len = A.rc_table[3 * c + 2];
     const double* __restrict__ src = A.rc_src + so;
     double* __restrict__ dst = A.rc_dst + dofs;
+    if ((((uintptr_t)src ^ (uintptr_t)dst) & 8) == 0) {      // congruent modulo 16 bytes: 16 bytes per lane (the host-landed
+      const int64_t head = ((uintptr_t)src >> 3) & 1;         // sharded cycle stores these runs over PCIe)
+      const int64_t pairs = (len - (head < len ? head : len)) >> 1;
+      const pk_d2* __restrict__ s2 = reinterpret_cast<const pk_d2*>(src + head);
+      pk_d2* __restrict__ d2 = reinterpret_cast<pk_d2*>(dst + head);
+      for (int64_t i = threadIdx.x; i < pairs; i += PK_BLOCK) d2[i] = s2[i];
+      if (threadIdx.x == 0) {
+        if (head && len > 0) dst[0] = src[0];
+        if (head + 2 * pairs < len) dst[len - 1] = src[len - 1];
+      }
+      continue;
+    }
     for (int64_t i = threadIdx.x; i < len; i += PK_BLOCK) dst[i] = src[i];
   }
 }

@@ -65,7 +65,7 @@ struct pk_ctx {
   const unsigned long long* const* xc_box = nullptr;
   const int32_t* xc_idx = nullptr;
   int32_t xc_world = 0, xc_rank = 0, xc_nsh = 0, xc_stride = 0;
-  int32_t xc_epoch = 0;         // cycles exchanged so far (every rank counts the same)
+  unsigned long long* xc_own = nullptr;   // this rank's own mailbox (host copy of the pointer: state block, pk_exchange_status)
   bool xc_inline = false;       // pk_cycle's finalize workgroup exchanges the partial sums itself (pk_set_exchange_inline)
   bool split_xall = false;      // pk_xall with two waves per tile (values / Jacobian), see pk_set_problem
   int cycle_mode = 1;           // 1: single-launch pk_cycle; 0: pk_xall + pk_hess (pk_set_cycle_mode)
@@ -352,8 +352,8 @@ int enqueue_single_launch_cycle(pk_ctx* c, const double* d_x, const double* d_la
   if (c->xc_inline && c->xc_world > 1) {      // sharded: the sums over the ranks are exchanged inside this launch
     A.flags |= F_XCHG;
     A.xc_box = (unsigned long long* const*)c->xc_box; A.xc_idx = c->xc_idx;
-    A.xc_world = c->xc_world; A.xc_rank = c->xc_rank; A.xc_epoch = ++c->xc_epoch; A.xc_nsh = c->xc_nsh; A.xc_stride = c->xc_stride;
-  }
+    A.xc_world = c->xc_world; A.xc_rank = c->xc_rank; A.xc_epoch = 0; A.xc_nsh = c->xc_nsh; A.xc_stride = c->xc_stride;
+  }      // (xc_epoch = 0: the cycle number is kept in device memory, so these arguments never change -> graph-replayable)
   size_t dbl = PK_WAVES_PER_BLOCK * (size_t)(c->md.lds_x > c->md.lds_h ? c->md.lds_x : c->md.lds_h);
   if (dbl < (size_t)c->md.ne_j) dbl = (size_t)c->md.ne_j;
   if (dbl < (size_t)c->md.ne_h) dbl = (size_t)c->md.ne_h;
@@ -1166,10 +1166,9 @@ int pk_eval_cycle_dev(pk_ctx* c, const double* d_x, const double* d_lam, double 
   // performs the reductions).  With pk_set_cycle_graph the two launches are replayed from a cached hipGraph as
   // long as the pointers, sigma and the stream stay the same (an NLP solver's steady state).
   const pk_ctx::CycleKey key{d_x, d_lam, d_f, d_grad, d_g, d_jac, d_hess, sigma, st};
-  // (a sharded cycle is not replayed: its launch arguments -- exchange epoch, shard flags, shared-slot target, external
-  //  integral buffer -- change from cycle to cycle or with the pk_set_* calls below, which also drop a captured graph)
-  const bool graph = c->use_graph && c->profile_mask == 0 && !(c->xc_inline && c->xc_world > 1) && !c->shard_flags &&
-                     !c->external_prepass;
+  // (a sharded cycle replays too: its exchange counts the cycles in device memory, and every pk_set_* call that changes
+  //  a launch argument -- shard flags, shared-slot target, integral buffer, exchange form -- drops the captured graph)
+  const bool graph = c->use_graph && c->profile_mask == 0;
   if (graph && c->cyc_exec && c->cyc_key == key) {
     PK_HIP(c, hipGraphLaunch(c->cyc_exec, st));
     return 0;
@@ -1202,10 +1201,10 @@ int pk_eval_cycle_dev_repeat(pk_ctx* c, const double* d_x, const double* d_lam, 
   if (count < 0 || (xchg && !d_xgrad)) return fail(c, 50, "pk_eval_cycle_dev_repeat: bad count, or xchg without the gradient buffer of the exchange");
   // pk_set_cycle_graph(1): the whole batch is ONE hipGraph of `count` kernel nodes, captured once and replayed while
   // pointers, sigma, stream and count stay the same -- the host then pays one graph launch per batch instead of `count`
-  // kernel launches.  Not for sharded cycles (their exchange epoch is a kernel argument that advances with every launch).
+  // kernel launches.  Sharded cycles with the in-launch exchange included (the cycle number lives in device memory).
   const bool needs_I = c->md.prepass_grad || c->md.prepass_g || c->md.prepass_jac || c->md.prepass_hess;
-  const bool graph = c->use_graph && c->profile_mask == 0 && !xchg && c->xc_world <= 1 && !needs_I && count > 1 &&
-                     c->cycle_mode == 1 && !c->shard_flags && !c->external_prepass && d_lam;
+  const bool graph = c->use_graph && c->profile_mask == 0 && !xchg && !needs_I && count > 1 && c->cycle_mode == 1 &&
+                     !c->external_prepass && d_lam;
   if (graph) {
     hipStream_t st = pick(c, stream);
     const pk_ctx::CycleKey key{d_x, d_lam, d_f, d_grad, d_g, d_jac, d_hess, sigma, st};
@@ -1283,6 +1282,17 @@ int pk_sync(pk_ctx* c, void* stream) {
   return 0;
 }
 
+// the same by polling the stream's state: the host learns ~8 us earlier than through hipStreamSynchronize that a copy has
+// landed (tools/dma_probe.cpp); for callers on a latency path (the host-landed sharded cycle)
+int pk_wait_idle(pk_ctx* c, void* stream) {
+  if (!c) return fail(nullptr, 1, "null context");
+  hipStream_t st = pick(c, stream);
+  hipError_t e;
+  while ((e = hipStreamQuery(st)) == hipErrorNotReady) { }
+  if (e != hipSuccess) return fail(c, 100 + (int)e, "hipStreamQuery failed: %s", hipGetErrorString(e));
+  return 0;
+}
+
 // ---------------------------------------------------------------- host-buffer API
 #define PK_HOST_EVAL(IN_COPY, CALL, D_OUT, OUT, COUNT)                                                      \
   int rc = ready(c);                                                                                        \
@@ -1346,6 +1356,12 @@ int pk_same_x(pk_ctx* c, const double* x) {
   return std::memcmp(c->h_x, x, sizeof(double) * (size_t)c->n) == 0 ? 1 : 0;
 }
 
+// 1 if the two arrays of n doubles are equal bit for bit (what decides "is this the iterate I already evaluated": one pass
+// at memcmp speed, no temporary -- numpy.array_equal builds a boolean array of n elements first)
+int pk_same_bits(const double* a, const double* b, size_t n) {
+  return (a && b && std::memcmp(a, b, sizeof(double) * n) == 0) ? 1 : 0;
+}
+
 // the context's x / result buffers were used for something else (mesh error, one-shot evals, the cycle call)
 int pk_invalidate_x(pk_ctx* c) {
   if (!c) return fail(nullptr, 1, "null context");
@@ -1402,6 +1418,9 @@ int pk_host_alloc(size_t bytes, void** out) {
 
 int pk_host_free(void* p) {
   if (!p) return 0;
+  // (a landing block may still be the target of copies nobody asked for -- every result of a new x is on its way into it:
+  //  nothing may be in flight when the memory goes; found by the sanitized build, tests/fake_hip)
+  (void)hipDeviceSynchronize();
   hipError_t e = hipHostFree(p);
   if (e != hipSuccess) return fail(nullptr, 100 + (int)e, "hipHostFree failed: %s", hipGetErrorString(e));
   return 0;
@@ -1819,15 +1838,43 @@ int pk_set_shared_grad_target(pk_ctx* c, double* d_grad_shared) {
 int pk_set_exchange(pk_ctx* c, int world, int rank, const void* d_boxes, const int32_t* d_idx, int n_sh, int stride) {
   int rc = ready(c);
   if (rc) return rc;
+  // everything is checked before anything is stored: a refused call leaves the context as it was
   if (world < 1 || world > PK_MAX_RANKS || rank < 0 || rank >= world)
     return fail(c, 90, "pk_set_exchange: %d ranks (at most %d), rank %d", world, PK_MAX_RANKS, rank);
   if (c->md.n_I + n_sh > 512 || stride < 1 + c->md.n_I + n_sh)
     return fail(c, 91, "pk_set_exchange: partial vector of %d doubles (at most 512), slot of %d words", c->md.n_I + n_sh, stride);
-  c->xc_box = (const unsigned long long* const*)d_boxes;
-  c->xc_idx = d_idx;
   if (n_sh != c->n_gz) return fail(c, 94, "pk_set_exchange: %d shared gradient slots, the problem has %d", n_sh, c->n_gz);
+  if (!d_boxes) return fail(c, 93, "pk_set_exchange: no mailbox table");
+  PK_HIP(c, hipSetDevice(c->device));
+  PK_HIP(c, hipStreamSynchronize(c->stream));
+  std::vector<unsigned long long*> boxes((size_t)world, nullptr);
+  PK_HIP(c, hipMemcpy(boxes.data(), d_boxes, sizeof(void*) * (size_t)world, hipMemcpyDeviceToHost));
+  if (!boxes[(size_t)rank]) return fail(c, 93, "pk_set_exchange: this rank's own mailbox is missing from the table");
+  // this rank's mailbox starts empty and its cycle count at zero (stale flags of an earlier set-up cannot match: every rank
+  // resets here, and the caller's barrier behind the set-up comes before the first flag is raised)
+  const size_t words = 2 * (size_t)world * (size_t)stride + PK_XC_STATE;
+  PK_HIP(c, hipMemset(boxes[(size_t)rank], 0, sizeof(unsigned long long) * words));
+  PK_HIP(c, hipDeviceSynchronize());
+  c->xc_box = (const unsigned long long* const*)d_boxes;
+  c->xc_own = boxes[(size_t)rank];
+  c->xc_idx = d_idx;
   c->xc_world = world; c->xc_rank = rank; c->xc_nsh = n_sh; c->xc_stride = stride;
-  c->xc_epoch = 0;
+  drop_cycle_graph(c);
+  return 0;
+}
+
+// cycles exchanged so far and how many of them gave up waiting for a peer (their sums read NaN on THIS rank, while a late
+// peer still got finite ones: a caller checks this before it trusts f across the ranks).  Synchronizes the stream.
+int pk_exchange_status(pk_ctx* c, void* stream, int64_t* cycles, int64_t* timed_out) {
+  int rc = ready(c);
+  if (rc) return rc;
+  if (!c->xc_own) return fail(c, 92, "pk_exchange_status: call pk_set_exchange first");
+  PK_HIP(c, hipSetDevice(c->device));
+  PK_HIP(c, hipStreamSynchronize(pick(c, stream)));
+  unsigned long long st[2] = {0, 0};
+  PK_HIP(c, hipMemcpy(st, c->xc_own + 2 * (size_t)c->xc_world * (size_t)c->xc_stride, sizeof st, hipMemcpyDeviceToHost));
+  if (cycles) *cycles = (int64_t)st[0];
+  if (timed_out) *timed_out = (int64_t)st[1];
   return 0;
 }
 
@@ -1849,7 +1896,7 @@ int pk_exchange_sums_dev(pk_ctx* c, const double* d_x, double* d_grad, double* d
   int rc = ready(c);
   if (rc) return rc;
   if (!c->xc_box) return fail(c, 92, "pk_exchange_sums: call pk_set_exchange first");
-  if (epoch <= 0) epoch = ++c->xc_epoch;      // (the context counts the cycles; every rank counts the same)
+  if (epoch < 0) epoch = 0;                   // (0: the exchange counts the cycles itself, in device memory)
   PkArgs A = base_args(c, d_x, nullptr, 0.0);
   A.o_grad = d_grad; A.o_f = d_f;
   A.xc_box = (unsigned long long* const*)c->xc_box; A.xc_idx = c->xc_idx;

@@ -22,6 +22,7 @@ torch.distributed is used at set-up only (the segment's name).
 from __future__ import annotations
 
 import ctypes as C
+import os
 import time
 from multiprocessing import shared_memory
 
@@ -29,10 +30,11 @@ import numpy as np
 import sympy as sp
 
 from .evaluator import Evaluator, _intervals_per_wave
-from .sharding import owned_runs, run_table, shared_gradient_slots, tile_filter
+from .sharding import needed_x_runs, owned_runs, run_table, shared_gradient_slots, tile_filter
 
 CMD_EXIT, CMD_X, CMD_HESS = 0, 1, 2
-CTRL_WORDS = 64          # control block: [0] sequence number, [1] command, [8 + r] last sequence rank r completed
+CTRL_WORDS = 64          # control block: [0] sequence number, [1] command, [2] pid of rank 0 (liveness), [8 + r] last sequence
+                         # rank r completed
 
 
 class HostShardedEvaluator:
@@ -64,9 +66,20 @@ class HostShardedEvaluator:
         words = off["f"] + 8
         self.off = off
         name = [None]
+        self.shm = None
         if rank == 0:
             self.shm = shared_memory.SharedMemory(create=True, size=8 * words)
             name[0] = self.shm.name
+        try:
+            self._set_up(plan, rank, world, dist, name, words, off, n, m)
+        except BaseException:
+            # (a failure after the segment exists must not leave it behind in /dev/shm: it is held in memory)
+            self._registered = getattr(self, "_registered", False)
+            self.close()
+            raise
+
+    def _set_up(self, plan, rank, world, dist, name, words, off, n, m):
+        lib, h, chk = self.lib, self.h, self.chk
         if world > 1:
             dist.broadcast_object_list(name, src=0)
         if rank != 0:
@@ -81,11 +94,14 @@ class HostShardedEvaluator:
         self.ctrl = np.ndarray((CTRL_WORDS,), dtype=np.int64, buffer=self.shm.buf)
         if rank == 0:
             self.words[:] = 0.0
+            self.ctrl[2] = os.getpid()
         if world > 1:
             dist.barrier()
         self._host_base = C.c_void_p(self.words.ctypes.data)
         self._dev_base = C.c_void_p()
+        self._registered = False
         chk(lib.pk_host_register(h, self._host_base, 8 * words, C.byref(self._dev_base)))
+        self._registered = True
         view = lambda key, cnt: self.words[off[key]: off[key] + cnt]  # noqa: E731
         self.h_x, self.h_lam, self.h_sigma = view("x", n), view("lam", m), view("sigma", 1)
         self.h_part = view("part", world * self.n_small).reshape(world, self.n_small)
@@ -122,9 +138,34 @@ class HostShardedEvaluator:
             return self._upload_table(t)
 
         self.tab_x, self.tab_h = table(rx), table(rh)
+        # the +-1 translation entries of J never change (phasebase.py:1071-1081): after this rank's first x-part they are in
+        # the solver's array for good, and the per-iterate run copy leaves them out (19 % of J at 12k quadrotor nodes)
+        const = [(split_j0 + a, split_j0 + b) for split_j0 in (n + m,) for a, b in plan.jac_constant_runs() if b - a >= 4096]
+
+        def minus(runs, holes):
+            out = []
+            for a, b in runs:
+                cur = a
+                for ha, hb in holes:
+                    if hb <= cur or ha >= b:
+                        continue
+                    if ha > cur:
+                        out.append((cur, ha))
+                    cur = max(cur, hb)
+                if cur < b:
+                    out.append((cur, b))
+            return out
+
+        self.tab_x_changing = table(minus(rx, const)) if const else self.tab_x
+        self._x_filled = False
+        # what this rank reads of x: uploaded by a run copy over its own link (1 / N of x per link, not N copies of x)
+        xr = needed_x_runs(plan, self.ev.tables, rank == 0)
+        self.tab_xin = table(xr)
+        self.x_upload_doubles = int(sum(b - a for a, b in xr))
         sh = np.zeros((len(self.shared), 3), dtype=np.int64)
         sh[:, 0], sh[:, 1], sh[:, 2] = self.shared, self.n_I + np.arange(len(self.shared)), 1
         self.tab_sh = self._upload_table(sh)                # local grad -> d_small[n_I + i]
+        self.tab_part = self._upload_table(np.array([[0, rank * self.n_small, self.n_small]], dtype=np.int64))
         self._seq = 0
         self._x_seq = -1          # sequence number whose x-part results the segment holds
         # f = F_o(I, s) on the host (rank 0): the objective as a function of the integrals and static parameters
@@ -151,42 +192,73 @@ class HostShardedEvaluator:
 
     def _do_x_part(self):
         lib, h, chk, n, m = self.lib, self.h, self.chk, self.plan.n, self.plan.m
-        chk(lib.pk_copy_dev(h, self.d_x, self._dev("x"), 8 * n, None))                 # x over THIS rank's link
+        self._runs(self.tab_xin, self._dev("x"), self.d_x)                               # this rank's part of x, over ITS link
         # the fused x-kernel on this shard's tiles: its slices of grad f / g / J, its share of the integrals (-> d_small)
         # and its partial sums of the shared gradient slots (f is rank 0's to compute from the summed integrals)
         chk(lib.pk_eval_xpart_dev(h, self.d_x, self.d_f, self.d_out["grad"], self.d_out["g"], self.d_out["J"], None))
-        self._runs(self.tab_x, self.d_full, self._dev("out"))                            # owned runs -> the solver's arrays
+        # owned runs -> the solver's arrays (the first time all of them, then only what changes with x)
+        self._runs(self.tab_x_changing if self._x_filled else self.tab_x, self.d_full, self._dev("out"))
+        self._x_filled = True
         self._runs(self.tab_sh, self.d_out["grad"], self.d_small)                        # shared slots behind the integrals
-        chk(lib.pk_copy_dev(h, C.c_void_p(self._dev("part").value + 8 * self.rank * self.n_small), self.d_small,
-                            8 * self.n_small, None))
-        chk(lib.pk_sync(h, None))
+        self._runs(self.tab_part, self.d_small, self._dev("part"))       # (a kernel copy like the others: a DMA behind the
+        chk(lib.pk_wait_idle(h, None))                                    #  kernels costs a cross-engine hand-off, ~10 us)
 
     def _do_hess(self):
         lib, h, chk, m = self.lib, self.h, self.chk, self.plan.m
-        chk(lib.pk_copy_dev(h, self.d_lam, self._dev("lam"), 8 * m, None))
-        chk(lib.pk_eval_hess_dev(h, self.d_x, self.d_lam, float(self.h_sigma[0]), self.d_out["H"], None))
+        # the Hessian kernel reads the multipliers from the (page-locked) segment itself: every rank then moves only the rows
+        # of ITS tiles over its link, and there is no upload in front of the kernel
+        chk(lib.pk_eval_hess_dev(h, self.d_x, self._dev("lam"), float(self.h_sigma[0]), self.d_out["H"], None))
         self._runs(self.tab_h, self.d_full, self._dev("out"))
-        chk(lib.pk_sync(h, None))
+        chk(lib.pk_wait_idle(h, None))
 
     def _wait_all(self, seq):
-        t0 = time.perf_counter()
+        """Rank 0 waits for every rank's completion mark of ``seq`` (its own critical path: a spin, the clock looked at
+        every 4096 polls)."""
         done = self.ctrl[8: 8 + self.world]
+        t0, polls = None, 0
         while True:
             if np.all(done[1:] >= seq):
                 return
-            if time.perf_counter() - t0 > self.timeout_s:
-                raise RuntimeError(f"host-sharded cycle: ranks {np.nonzero(done < seq)[0].tolist()} did not finish sequence {seq}")
+            polls += 1
+            if polls & 0xFFF == 0:
+                now = time.perf_counter()
+                t0 = t0 or now
+                if now - t0 > self.timeout_s:
+                    raise RuntimeError(f"host-sharded cycle: ranks {np.nonzero(done < seq)[0].tolist()} did not finish "
+                                       f"sequence {seq} within {self.timeout_s:.0f} s")
 
     # ------------------------------------------------------------------ the other ranks
+    def _solver_alive(self):
+        pid = int(self.ctrl[2])
+        if pid <= 0:
+            return True
+        try:
+            os.kill(pid, 0)
+        except ProcessLookupError:
+            return False
+        except PermissionError:
+            return True
+        return True
+
     def serve(self):
-        """Ranks != 0: evaluate this rank's shard whenever rank 0 posts a command; returns on CMD_EXIT (or when nothing
-        arrives for ``timeout_s``)."""
-        last, t_idle = 0, time.perf_counter()
+        """Ranks != 0: evaluate this rank's shard whenever rank 0 posts a command; returns True on CMD_EXIT, False when
+        the solver's process has gone away.  A long linear solve or line search on rank 0 between two callbacks does not
+        strand the workers: there is no idle time-out, only the liveness of rank 0 (checked twice a second while idle).
+        Polling backs off -- a busy spin for the first 2 ms after a command (the next callback of an iterate follows within
+        microseconds), then 50 us sleeps, 1 ms sleeps after a second of silence."""
+        last, t_last = 0, time.perf_counter()
+        next_check = t_last + 0.5
         while True:
             seq = int(self.ctrl[0])
             if seq == last:
-                if time.perf_counter() - t_idle > self.timeout_s:
-                    return False
+                idle = time.perf_counter() - t_last
+                if idle > 2e-3:
+                    time.sleep(1e-3 if idle > 1.0 else 5e-5)
+                    now = time.perf_counter()
+                    if now >= next_check:
+                        next_check = now + 0.5
+                        if not self._solver_alive():
+                            return False
                 continue
             cmd = int(self.ctrl[1])
             if cmd == CMD_EXIT:
@@ -197,7 +269,7 @@ class HostShardedEvaluator:
             elif cmd == CMD_HESS:
                 self._do_hess()
             self.ctrl[8 + self.rank] = seq
-            last, t_idle = seq, time.perf_counter()
+            last, t_last = seq, time.perf_counter()
 
     # ------------------------------------------------------------------ rank 0: the callbacks
     def _post(self, cmd):
@@ -210,7 +282,7 @@ class HostShardedEvaluator:
         x = np.ascontiguousarray(x, dtype=np.float64)
         if x.shape != (self.plan.n,):
             raise ValueError(f"x must have shape ({self.plan.n},)")
-        if self._x_seq >= 0 and np.array_equal(x, self.h_x):
+        if self._x_seq >= 0 and self.lib.pk_same_bits(x.ctypes.data, self.h_x.ctypes.data, self.plan.n):
             return
         self.h_x[:] = x
         seq = self._post(CMD_X)
@@ -265,17 +337,21 @@ class HostShardedEvaluator:
     def close(self):
         if getattr(self, "shm", None) is None:
             return
-        if self.rank == 0 and self.world > 1:
+        if self.rank == 0 and self.world > 1 and getattr(self, "ctrl", None) is not None and getattr(self, "_seq", None) is not None:
             seq = self._post(CMD_EXIT)
             try:
+                keep, self.timeout_s = self.timeout_s, min(self.timeout_s, 10.0)
                 self._wait_all(seq)
+                self.timeout_s = keep
             except RuntimeError:
                 pass
         lib, h = self.lib, self.h
         if h:
             lib.pk_sync(h, None)
-            lib.pk_host_unregister(h, self._host_base)
-            for p in self._alloc:
+            if getattr(self, "_registered", False):
+                lib.pk_host_unregister(h, self._host_base)
+                self._registered = False
+            for p in getattr(self, "_alloc", []):
                 lib.pk_device_free(h, p)
         self._alloc = []
         self.out = self.h_x = self.h_lam = self.h_sigma = self.h_part = self.h_out = self.h_f = None

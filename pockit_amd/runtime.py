@@ -78,7 +78,7 @@ EXPORTS = ["pk_create", "pk_destroy", "pk_last_error", "pk_device_count", "pk_lo
            "pk_set_exchange", "pk_exchange_sums_dev", "pk_copy_runs_dev", "pk_set_exchange_inline",
            "pk_host_register", "pk_host_unregister", "pk_copy_dev", "pk_eval_xpart_dev",
            "pk_eval_jacc", "pk_eval_jacc_dev", "pk_callback_x", "pk_callback_hess", "pk_set_jac_constant_runs", "pk_fill_jac_constants", "pk_set_host_option",
-           "pk_set_jacobian_layout"]
+           "pk_set_jacobian_layout", "pk_exchange_status", "pk_wait_idle", "pk_same_bits"]
 
 _lib = None
 
@@ -166,6 +166,7 @@ def load_library():
     lib.pk_fill_jac_constants.argtypes = [vp, vp]
     lib.pk_set_host_option.argtypes = [vp, C.c_char_p, C.c_int]
     lib.pk_set_jacobian_layout.argtypes = [vp, C.c_int]
+    lib.pk_exchange_status.argtypes = [vp, vp, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
     lib.pk_eval_hessc.argtypes = [vp, dp, dp, C.c_double, dp]
     lib.pk_eval_jacc.argtypes = [vp, dp, dp]
     lib.pk_eval_jacc_dev.argtypes = [vp, vp, vp, vp]
@@ -192,6 +193,8 @@ def load_library():
     lib.pk_eval_hessc_prepared.argtypes = [vp, dp, C.c_double, dp, C.c_int]
     lib.pk_eval_cycle_dev_repeat.argtypes = [vp, vp, vp, C.c_double, vp, vp, vp, vp, vp, vp, C.c_int, C.c_int, vp]
     lib.pk_sync.argtypes = [vp, vp]
+    lib.pk_wait_idle.argtypes = [vp, vp]
+    lib.pk_same_bits.argtypes = [vp, vp, C.c_size_t]
     lib.pk_set_shard.argtypes = [vp, C.c_int, C.c_int, vp]
     lib.pk_eval_integrals_dev.argtypes = [vp, vp, vp]
     lib.pk_eval_f_from_integrals_dev.argtypes = [vp, vp, vp, vp]

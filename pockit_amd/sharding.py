@@ -126,6 +126,43 @@ def owned_runs(plan, tables, primary):
     return [(a, b) for a, b in runs if b > a]
 
 
+def needed_x_runs(plan, tables, primary):
+    """Contiguous runs [(start, stop)] of the NLP vector x that the tiles in ``tables`` (one rank's shard) read: per phase
+    and variable the nodes of its tiles (plus the LGR end slot behind the last one), the phase's t0 / tf and the static
+    parameters; ``primary`` adds the boundary nodes of every phase (the boundary / system-level work of rank 0).  A rank
+    uploads these over its own PCIe link instead of all of x: with N ranks every link carries 1 / N of x, not N copies."""
+    runs = []
+    tiles = tables.tiles
+    for k, pp in enumerate(plan.phase_plans):
+        lay = pp.layout
+        base = int(plan.l_p[k])
+        runs.append((base + lay.L - 2, base + lay.L))                      # t0, tf
+        spans = []
+        mine = tiles[(tiles["phase"] == k) & (tiles["nj"] > 0)]
+        if len(mine):
+            first, last = mine[0], mine[-1]
+            stride = int(lay.stride[int(last["j0"])])
+            spans.append((int(first["q0"]), int(last["q0"]) + int(last["nj"]) * stride + 1))
+        if primary:
+            spans += [(0, 1), (lay.L_m - 1, lay.L_m + 1)]
+        for i in range(pp.nx + pp.nu):
+            length = lay.state_len if i < pp.nx else lay.L_m
+            for lo, hi in spans:
+                lo, hi = max(lo, 0), min(hi + 1, length)                   # (+1: a slot more never hurts)
+                if hi > lo:
+                    runs.append((base + int(lay.l_v[i]) + lo, base + int(lay.l_v[i]) + hi))
+    if plan.n_s:
+        runs.append((plan.l_s, plan.r_s))
+    runs.sort()
+    merged = []
+    for a, b in runs:
+        if merged and a <= merged[-1][1]:
+            merged[-1] = (merged[-1][0], max(merged[-1][1], b))
+        else:
+            merged.append((a, b))
+    return merged
+
+
 def shared_gradient_slots(plan):
     """Gradient entries that are sums over all nodes (t0/tf of every phase, static parameters) plus the
     slots no node writes (LGR state end points): every rank's kernels write their own partial there."""
@@ -139,7 +176,7 @@ def shared_gradient_slots(plan):
     return np.array(sorted(set(int(v) for v in slots)), dtype=np.int64)
 
 
-CHUNK = 16384      # doubles per chunk of a run table (one workgroup of pk_runs per chunk)
+CHUNK = 4096       # doubles per chunk of a run table (one workgroup of pk_runs per chunk: 6 MB of runs = 190 workgroups)
 
 
 def run_table(runs, packed_first=0):
@@ -284,7 +321,7 @@ class PeerMailboxes:
         shared = shared_gradient_slots(plan)
         n_small = max(len(plan.I_syms), 1) + len(shared)
         self.stride = -(-(1 + n_small) // 16) * 16
-        words = 2 * world * self.stride
+        words = 2 * world * self.stride + 16          # (+ PK_XC_STATE: the rank's cycle count and time-out count)
         self.own, self.mapped = C.c_void_p(), []
         # Every rank walks through ALL collective calls below whatever fails locally (a rank that raised early would
         # leave the others waiting); the local failures are gathered and every rank takes the same decision.
@@ -322,6 +359,12 @@ class PeerMailboxes:
         chk(lib.pk_set_exchange(h, world, rank, C.c_void_p(self.table.data_ptr()), C.c_void_p(self.idx.data_ptr()),
                                 len(shared), self.stride))
         dist.barrier()                     # every rank has mapped every mailbox before the first flag is raised
+
+    def status(self, stream=None):
+        """(cycles exchanged so far, exchanges that gave up waiting for a peer) of this rank; synchronizes the stream."""
+        cyc, late = C.c_int64(), C.c_int64()
+        self.ev.ctx.check(self.ev.ctx.lib.pk_exchange_status(self.ev.ctx.handle, stream, C.byref(cyc), C.byref(late)))
+        return cyc.value, late.value
 
     def close(self):
         lib, h = self.ev.ctx.lib, self.ev.ctx.handle

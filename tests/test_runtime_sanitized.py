@@ -1,0 +1,28 @@
+"""The host runtime behind the C ABI (pockit_amd/csrc/pk_runtime.cpp: pinned landing blocks, double-buffered staging,
+prepared-x protocol, copy batching, polling waits, speculative Hessian, constant Jacobian runs, CSR run tables) built with
+``-fsanitize=address,undefined`` against a host-only stand-in of the HIP runtime (tests/fake_hip: deferred streams, "kernels"
+that write recomputable values) and driven through its protocols by tests/fake_hip/driver.cpp.  CPU only -- GPU sanitizers are
+not available on this pool.  SURVEY.md section 5 "race detection / sanitizers"."""
+import os
+import shutil
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+FAKE = os.path.join(ROOT, "tests", "fake_hip")
+
+
+@pytest.mark.skipif(shutil.which("g++") is None, reason="needs g++")
+def test_host_runtime_under_address_and_undefined_behaviour_sanitizers(tmp_path):
+    exe = str(tmp_path / "pk_runtime_sanitized")
+    cmd = ["g++", "-std=c++17", "-g", "-O1", "-fsanitize=address,undefined", "-fno-omit-frame-pointer",
+           "-fno-sanitize-recover=undefined", "-I", FAKE, "-I", ROOT,
+           os.path.join(ROOT, "pockit_amd", "csrc", "pk_runtime.cpp"), os.path.join(FAKE, "fake_hip.cpp"),
+           os.path.join(FAKE, "driver.cpp"), "-o", exe]
+    build = subprocess.run(cmd, capture_output=True, text=True)
+    assert build.returncode == 0, build.stderr[-4000:]
+    env = dict(os.environ, ASAN_OPTIONS="detect_leaks=1:abort_on_error=0", UBSAN_OPTIONS="print_stacktrace=1")
+    run = subprocess.run([exe], capture_output=True, text=True, env=env, timeout=600)
+    assert run.returncode == 0, (run.stdout[-2000:], run.stderr[-6000:])
+    assert "checks passed" in run.stdout and "ERROR" not in run.stderr and "runtime error" not in run.stderr
