@@ -151,8 +151,14 @@ class ModelSource:
     """Generates the HIP source of one SystemPlan; exposes the compile-time counts the runtime
     tables must agree with."""
 
-    def __init__(self, plan: SystemPlan, sharded: bool = False):
+    # outputs of one launch beyond this many bytes do not fit the 256 MiB Infinity Cache (MALL) any more
+    MALL_BYTES = 256 << 20
+
+    def __init__(self, plan: SystemPlan, sharded: bool = False, output_share: float = 1.0):
         self.plan = plan
+        # Bytes one launch of the cycle writes on THIS evaluator (a shard of a multi-GPU run writes its share): decides the
+        # cache policy of the streaming stores, the third mesh fact the code object depends on (after PK_TAB_CAP, PK_BIG).
+        self.output_bytes = 8.0 * (1 + plan.n + plan.m + plan.nnz_J + plan.nnz_H) * float(output_share)
         # sharded: the finalize workgroup of pk_cycle carries the in-launch exchange of the partial sums between the GPUs.
         # Single-GPU code objects are compiled without it (its mere presence cost the 12k-node cycle 3 %).
         self.sharded = bool(sharded) or os.environ.get("POCKIT_AMD_SHARDED", "0") == "1"
@@ -438,9 +444,17 @@ class ModelSource:
             S.append("#define PK_BIG 1")
         if self.sharded:
             S.append("#define PK_SHARDED 1")
-        stream = {"sc1nt": "sc1 nt", "nt": "nt", "plain": "", "sc0sc1": "sc0 sc1", "sc0sc1nt": "sc0 sc1 nt"}.get(
+        # Cache policy of the 16-byte streaming stores, by the size of what one launch writes (profiles/r03_store_policy_*.txt):
+        # inside the Infinity Cache agent-scope write-through ("sc1": +20 % over plain stores, nontemporal -15 ... -30 %);
+        # beyond it -- quadrotor from 262 MB = 300k nodes on -- the nontemporal form, which does not leave 300+ MB of lines
+        # for the MALL to evict one by one: 93 -> 50 us at 262 MB, 120 -> 58 us at 314 MB (0.47 -> 0.97 of the roof); the
+        # humanoid crosses over later (315 MB: 69 vs 87 us, 451 MB: 146 vs 117 us).  POCKIT_AMD_STREAM overrides (A/B).
+        stream = {"sc1": "sc1", "sc1nt": "sc1 nt", "nt": "nt", "plain": "", "sc0sc1": "sc0 sc1", "sc0sc1nt": "sc0 sc1 nt"}.get(
             os.environ.get("POCKIT_AMD_STREAM", ""))
-        if stream is not None:                                       # A/B switch: cache policy of the 16-byte streaming stores
+        if stream is None and self.output_bytes > self.MALL_BYTES:
+            stream = "nt"
+        self.stream_policy = "sc1" if stream is None else (stream or "plain")
+        if stream is not None:
             S.append(f'#define PK_STREAM_FLAGS "{stream}"')
         if os.environ.get("POCKIT_AMD_NT", "") in ("0", "1", "2", "3", "4"):   # A/B switch of the output store flavour
             S.append(f"#define PK_NT_STORES {os.environ['POCKIT_AMD_NT']}")

@@ -207,9 +207,10 @@ class Tables:
 
 
 class Evaluator:
-    def __init__(self, plan: SystemPlan, device: int = 0, intervals_per_wave=None, tile_filter=None, sharded=False):
+    def __init__(self, plan: SystemPlan, device: int = 0, intervals_per_wave=None, tile_filter=None, sharded=False,
+                 output_share=1.0):
         self.plan = plan
-        self.src = ModelSource(plan, sharded=sharded)
+        self.src = ModelSource(plan, sharded=sharded, output_share=output_share)
         # (compiled before the context is created: a box without a GPU -- the build container -- can still fill the
         # code-object cache by constructing evaluators, tools/warm_cache.sh)
         code = hipbuild.compile_model(self.src.source, fastmath=plan.system._fastmath)

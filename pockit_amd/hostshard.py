@@ -47,7 +47,8 @@ class HostShardedEvaluator:
         if intervals_per_wave is None:
             intervals_per_wave = _intervals_per_wave(plan, shards=world)
         self.ev = Evaluator(plan, device=device, intervals_per_wave=intervals_per_wave,
-                            tile_filter=tile_filter(rank, world, plan) if world > 1 else None)
+                            tile_filter=tile_filter(rank, world, plan) if world > 1 else None,
+                            output_share=1.0 / max(world, 1))
         lib, h, chk = self.ev.ctx.lib, self.ev.ctx.handle, self.ev.ctx.check
         self.lib, self.h, self.chk = lib, h, chk
         n, m = plan.n, plan.m
