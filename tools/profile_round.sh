@@ -15,6 +15,12 @@ rc=$?
 f=$(find "$out/prof_$tag" -name '*kernel_stats.csv' | head -1)
 [ -n "$f" ] && cp "$f" "$out/${tag}_kernel_stats.csv" && head -4 "$f" | cut -c1-160
 find "$out/prof_$tag" -name '*kernel_trace.csv' -delete      # the trace itself is large: keep only the stats
+# the headline's own command (the host-landed cycle: five callbacks, copies up and down): which kernels it runs and how long
+rocprofv3 --kernel-trace --stats --output-format csv -d "$out/prof_${tag}_e2e" -o p -- \
+  python3 "$repo/bench.py" --steps 20 --warmup 5 --no-extra --no-cpu-baseline > "$out/${tag}_bench_e2e_under_rocprofv3.json" 2> "$out/${tag}_rocprof_e2e.err"
+f=$(find "$out/prof_${tag}_e2e" -name '*kernel_stats.csv' | head -1)
+[ -n "$f" ] && cp "$f" "$out/${tag}_kernel_stats_e2e.csv"
+find "$out/prof_${tag}_e2e" -name '*kernel_trace.csv' -delete
 [ "$2" = "pmc" ] || exit $rc
 for c in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --pmc $c --output-format csv -d "$out/prof_${tag}_pmc_$c" -o p -- python3 "$repo/bench.py" $BENCH_ARGS > /dev/null 2>&1
