@@ -178,8 +178,6 @@ class ModelSource:
         # intervals with more points than a wavefront has lanes (64 < K <= 256) are evaluated by a whole workgroup: code
         # compiled into the object only when the mesh has such an interval (PK_BIG)
         self.big = any(int(pp.layout.K.max()) > 64 for pp in plan.phase_plans)
-        if self.big and plan.outer:
-            raise NotImplementedError("num_point > 64 together with system functions nonlinear in the integrals")
         self.compact = not plan.outer
         self.compact_j = not self.big             # (the compact Jacobian has no workgroup-per-interval path)
         for cbname in ("jac", "hess", "aux") + (("hessc",) if self.compact else ()) + (("jacc",) if self.compact_j else ()):
@@ -520,6 +518,13 @@ class ModelSource:
             S.append("  __device__ static __forceinline__ void bigh(int phase, const PkArgs& A, const PkTile& tl, "
                      "double* __restrict__ lds) {")
             S.append(switch("pk::big_hess<{P}>(A, tl, lds)"))
+            S.append("  }")
+            S.append("  __device__ static __forceinline__ void bigi(int phase, const PkArgs& A, const PkTile& tl, "
+                     "double* __restrict__ wint) {")
+            S.append(switch("pk::big_int<{P}>(A, tl, wint)"))
+            S.append("  }")
+            S.append("  __device__ static __forceinline__ void biga(int phase, const PkArgs& A, const PkTile& tl) {")
+            S.append(switch("pk::big_aux<{P}>(A, tl)"))
             S.append("  }")
         ncmax = max([1] + [pp.phase.n_c for pp in plan.phase_plans])
         for cbname, tag in (("jac", "J"), ("hess", "H"), ("aux", "A")):

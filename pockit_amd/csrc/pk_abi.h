@@ -62,7 +62,7 @@ struct PkTile {
   uint32_t magicI;     // d = nnzI   (entries per interval of the integration pattern)
   uint32_t magicR;     // d = R      (defect rows per interval)
   uint32_t magicT;     // d = nnzT   (translation entries per interval)
-  int32_t pad2;
+  int32_t stage;       // (device: staging slot of an interval with more than 256 points, set by pk_set_problem)
 };
 
 // Entry tables of one interval pattern (unit width).
@@ -109,7 +109,7 @@ struct PkErrIv {
   int32_t tab_off;
   int32_t tau_off;
   int32_t rows;        // output rows per state of the phase
-  int32_t pad;
+  int32_t stage;       // (device: staging slot of an interval with more than 263 augmented nodes, set by the library)
   int64_t out_off;     // start of the phase in the two output arrays ([n_x][rows] each)
   double width;        // interval width (fraction of the phase)
 };
@@ -166,6 +166,10 @@ struct PkArgs {
   const int64_t* rc_table;
   const double* rc_src;
   double* rc_dst;
+  // staging rows of intervals too long for the workgroup's LDS (more than 256 points): slot s of sub-slot u starts at
+  // big_stage + (4 s + u) * big_slot doubles, rows of big_row doubles   (u: 0 x-part / values, 1 Jacobian role, 2 Hessian;
+  // pk_err: its own buffer, one sub-slot per interval)
+  double* big_stage;
   int32_t n_tiles, n_items;
   int32_t n_items2, pad0;
   int32_t n_phase, n;
@@ -179,5 +183,6 @@ struct PkArgs {
   int32_t xc_world, xc_rank, xc_epoch, xc_nsh;   // ranks, this rank, cycle number (> 0: given by the host; 0: counted on the
                                                  // device, in the mailbox's state block), number of shared gradient slots
   int32_t xc_stride, rc_n;                       // mailbox words per sender (multiple of 16); chunks of the run table
+  int32_t big_row, big_slot;
   PkPhase ph[PK_MAX_PHASES];   // the phases by value (kernarg segment): no dependent global load
 };

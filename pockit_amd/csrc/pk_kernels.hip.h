@@ -1176,7 +1176,7 @@ __device__ __forceinline__ void tile_xall(const PkArgs& A, const PkTile& tl, dou
 
 #ifdef PK_BIG
 // ============================================================================================
-// Intervals with more points than a wavefront has lanes (64 < K <= PK_BIG_MAX): ONE WORKGROUP per interval.
+// Intervals with more points than a wavefront has lanes (K > 64): ONE WORKGROUP per interval.
 // The reference has no limit on num_point (radau/discretization.py:488-521); the wave tiles above do (lane = node).
 // Such an interval takes the first slot of a tile block (the host leaves the other three empty); its workgroup -- one
 // per role, as for ordinary tiles -- walks the nodes with all 256 threads (phase A: evaluation, per-node outputs,
@@ -1184,23 +1184,33 @@ __device__ __forceinline__ void tile_xall(const PkArgs& A, const PkTile& tl, dou
 // translation entries and the K^2 entries of every I-expanded segment (phase B; tables from global memory, 8-byte
 // stores).  Same arithmetic, same operation order as the tile path.  Compiled only into code objects whose mesh has such
 // an interval (codegen.py), so ordinary meshes carry none of it.
+// An interval with more than PK_BIG_MAX points does not fit the workgroup's LDS rows: its staged rows live in a slot of a
+// global staging buffer instead (PkArgs.big_stage; written and read by the waves of ONE workgroup, on one CU, either side
+// of a workgroup barrier), rows of PkArgs.big_row doubles.  Everything else is the same code.
 // ============================================================================================
 #define PK_BIG_MAX 256
+// where an interval of K points stages its rows: (row length, base) -- sub-slot u as in pk_abi.h
+struct BigStage { int KS; double* base; };
+__device__ __forceinline__ BigStage big_stage(const PkArgs& A, int K, int slot, int u, double* __restrict__ lds) {
+  if (K <= PK_BIG_MAX) return BigStage{PK_BIG_MAX, lds};
+  return BigStage{A.big_row, A.big_stage + ((size_t)slot * 4 + (size_t)u) * (size_t)A.big_slot};
+}
 template <class P, int ROLE>
 __device__ __forceinline__ void big_xall(const PkArgs& A, const PkTile& tl, double* __restrict__ lds,
                                          double* __restrict__ wint, double* __restrict__ wgrad, int pub_blk) {
   const PkPhase& ph = A.ph[P::INDEX];
   const int t = threadIdx.x, wave = t >> 6, lane = t & 63;
-  constexpr int KS = PK_BIG_MAX;
   const int K = tl.K, stride = K - P::SCHEME, R = stride;
+  const BigStage bs = big_stage(A, K, tl.stage, ROLE == 2 ? 1 : 0, lds);
+  const int KS = bs.KS;
   const int nq = stride + P::SCHEME;
   const int nown = (P::SCHEME && !tl.last) ? nq - 1 : nq;
   double s[PK_NS], dt, mt;
   phase_scalars<P>(A, ph, s, dt, mt);
   const PkSys sy{s, A.Ibuf, A.sigma, A.lam};
-  double* __restrict__ xs = lds;                          // [NX][KS] node values (boundary values substituted)
-  double* __restrict__ fs = lds + P::NX * KS;             // [NX][KS] dynamics values
-  double* __restrict__ js = lds + 2 * P::NX * KS;         // [J_NI][KS] Jacobian segment values
+  double* __restrict__ xs = bs.base;                      // [NX][KS] node values (boundary values substituted)
+  double* __restrict__ fs = bs.base + P::NX * KS;         // [NX][KS] dynamics values
+  double* __restrict__ js = bs.base + 2 * P::NX * KS;     // [J_NI][KS] Jacobian segment values
   pk_cbase_t segb = const_bases(A.lb + ph.jseg_off);
   pk_cbase_t tb = const_bases(A.lb + ph.jt_off);
   double oi[P::INT_N > 0 ? P::INT_N : 1], orr[P::GR_NR > 0 ? P::GR_NR : 1];
@@ -1318,11 +1328,13 @@ __device__ __forceinline__ void big_xall(const PkArgs& A, const PkTile& tl, doub
 }
 
 template <class P>
-__device__ __forceinline__ void big_hess(const PkArgs& A, const PkTile& tl, double* __restrict__ lds) {
+__device__ __forceinline__ void big_hess(const PkArgs& A, const PkTile& tl, double* __restrict__ lds0) {
   const PkPhase& ph = A.ph[P::INDEX];
   const int t = threadIdx.x;
-  constexpr int KS = PK_BIG_MAX;
   const int K = tl.K, stride = K - P::SCHEME;
+  const BigStage bs = big_stage(A, K, tl.stage, 2, lds0);
+  const int KS = bs.KS;
+  double* __restrict__ lds = bs.base;
   const int nq = stride + P::SCHEME;
   const int nown = (P::SCHEME && !tl.last) ? nq - 1 : nq;
   double s[PK_NS], dt, mt;
@@ -1354,6 +1366,55 @@ __device__ __forceinline__ void big_hess(const PkArgs& A, const PkTile& tl, doub
     for (int e = 0; e < P::H_NI; ++e) {
       const double lam = A.lam[ph.g_off + P::H_state(e) * ph.L_d + tl.r0 + r];
       put(&A.o_hess[segb[e] + tl.offI + p], val * lam * lds[e * KS + c]);
+    }
+  }
+}
+
+// integrals only (pk_int, the prepass of models whose system functions are nonlinear in the integrals): the interval's
+// nodes in the thread order of big_xall, per-wave sums into wint
+template <class P>
+__device__ __forceinline__ void big_int(const PkArgs& A, const PkTile& tl, double* __restrict__ wint) {
+  if (P::INT_N == 0) return;
+  const PkPhase& ph = A.ph[P::INDEX];
+  const int t = threadIdx.x, wave = t >> 6, lane = t & 63;
+  const int nq = tl.K, nown = (P::SCHEME && !tl.last) ? nq - 1 : nq;
+  double s[PK_NS], dt, mt;
+  phase_scalars<P>(A, ph, s, dt, mt);
+  double oi[P::INT_N > 0 ? P::INT_N : 1];
+#pragma unroll
+  for (int r = 0; r < P::INT_N; ++r) oi[r] = 0.0;
+  for (int c = t; c < nown; c += PK_BLOCK) {
+    double a[P::NARG], tau, w, o[P::INT_N > 0 ? P::INT_N : 1];
+    load_node<P>(A, ph, s, dt, mt, tl.q0 + c, a, tau, w);
+    P::mid_int(a, o);
+#pragma unroll
+    for (int r = 0; r < P::INT_N; ++r) oi[r] += o[r] * w;
+  }
+#pragma unroll
+  for (int r = 0; r < P::INT_N; ++r) {
+    const double v = wave_sum(oi[r]);
+    if (lane == 0) wint[wave * PK_NRED + r] = v;
+  }
+}
+
+// auxiliary pass of the outer-product path (tile_aux below) for such an interval
+template <class P>
+__device__ __forceinline__ void big_aux(const PkArgs& A, const PkTile& tl) {
+  if (P::A_NN == 0) return;
+  const PkPhase& ph = A.ph[P::INDEX];
+  const int nq = tl.K, nown = (P::SCHEME && !tl.last) ? nq - 1 : nq;
+  double s[PK_NS], dt, mt;
+  phase_scalars<P>(A, ph, s, dt, mt);
+  const PkSys sy{s, A.Ibuf, A.sigma, A.lam};
+  pk_cbase_t segb = const_bases(A.lb + ph.aseg_off);
+  for (int c = threadIdx.x; c < nown; c += PK_BLOCK) {
+    const int q = tl.q0 + c;
+    if (q >= ph.mid_lo && q < ph.mid_hi) {
+      double a[P::NARG], tau, w, o[P::A_NN + 1];
+      load_node<P>(A, ph, s, dt, mt, q, a, tau, w);
+      P::mid_aux(a, tau, dt, w, sy, nullptr, o);
+#pragma unroll
+      for (int e = 0; e < P::A_NN; ++e) A.o_aux[segb[e] + (q - ph.mid_lo)] = o[e];
     }
   }
 }
@@ -1671,6 +1732,11 @@ __device__ __forceinline__ void edge_block(const PkArgs& A, int mode, bool with_
 template <class Gen>
 __device__ __forceinline__ void kernel_int(const PkArgs& A) {
   PK_TILE_PROLOGUE(0);
+#ifdef PK_BIG
+  PkTile tl0;
+  if (big_block(A.tile, A.n_tiles, blk, tl0)) Gen::bigi(tl0.phase, A, tl0, wint);
+  else
+#endif
   Gen::tile_int(tl.phase, A, tl, pk_lds, wint + wave * PK_NRED, wgrad + wave * PK_NRED, lane);
   publish_block_partials(A.partial, wint, blk);
 }
@@ -1741,6 +1807,10 @@ template <class Gen>
 __device__ __forceinline__ void kernel_aux(const PkArgs& A) {
   if (PK_IS_EDGE_BLOCK()) return edge_block<Gen>(A, 2, false, A.items, A.n_items);
   PK_TILE_PROLOGUE(1);
+#ifdef PK_BIG
+  PkTile tl0;
+  if (big_block(A.tile, A.n_tiles, blk, tl0)) return Gen::biga(tl0.phase, A, tl0);
+#endif
   Gen::tile_aux(tl.phase, A, tl, pk_lds, wint, wgrad, lane);
 }
 
@@ -1837,18 +1907,22 @@ __device__ __forceinline__ void interval_err(const PkArgs& A, int first, int cnt
   }
 }
 
-// The same for ONE interval with more augmented nodes than a wave has lanes (64 <= K <= 256): all 256 threads of the
-// workgroup walk the K + 1 nodes / rows; the staged rows are PK_ERR_BIG_ROW doubles long.  Same arithmetic, same
-// operation order per node as interval_err.
-#define PK_ERR_BIG_ROW 264
+// The same for ONE interval with more augmented nodes than a wave has lanes (K >= 64): all 256 threads of the
+// workgroup walk the K + 1 nodes / rows; the staged rows are PK_ERR_BIG_LDS_ROW doubles long in LDS, or -- more than that
+// many augmented nodes -- PkArgs.big_row doubles in the interval's slot of the global staging buffer.  Same arithmetic,
+// same operation order per node as interval_err.
+#define PK_ERR_BIG_LDS_ROW 264
 template <class P>
-__device__ __forceinline__ void interval_err_big(const PkArgs& A, int first, double* __restrict__ lds) {
+__device__ __forceinline__ void interval_err_big(const PkArgs& A, int first, double* __restrict__ lds0) {
   const PkPhase& ph = A.ph[P::INDEX];
   double s[PK_NS], dt, mt;
   phase_scalars<P>(A, ph, s, dt, mt);
   const PkErrIv iv = A.erriv[first];
   const int K = iv.K, t = (int)threadIdx.x;
   const int ncx = K + 1 - P::SCHEME, na = K + 1, nr = K + 1 - P::SCHEME;
+  const bool in_lds = na <= PK_ERR_BIG_LDS_ROW;
+  const int PK_ERR_BIG_ROW = in_lds ? PK_ERR_BIG_LDS_ROW : A.big_row;
+  double* __restrict__ lds = in_lds ? lds0 : A.big_stage + (size_t)iv.stage * (size_t)A.big_slot;
   const double* __restrict__ Vx = A.errdb + iv.tab_off;
   const double* __restrict__ Vu = Vx + na * ncx;
   const double* __restrict__ Tm = Vu + na * K;

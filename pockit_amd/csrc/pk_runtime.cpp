@@ -71,6 +71,9 @@ struct pk_ctx {
   int cycle_mode = 1;           // 1: single-launch pk_cycle; 0: pk_xall + pk_hess (pk_set_cycle_mode)
   bool static_tabs = false;     // A/B (POCKIT_AMD_STATIC_TABS=1): the code object keeps its table blocks in static LDS
   bool has_big = false;         // the mesh has intervals with more than 64 points (one workgroup each, PK_BIG code objects)
+  // staging rows of intervals with more than 256 points (they do not fit the workgroup's LDS rows): slots in device memory
+  double *d_big_stage = nullptr, *d_err_stage = nullptr;
+  int32_t big_row = 0, big_slot = 0, err_row = 0, err_slot = 0;
   unsigned long long *d_cpart = nullptr, *d_cpart2 = nullptr;   // pk_cycle's hand-off slots (PK_EMPTY between launches)
   unsigned profile_mask = 0;
   unsigned profile_period = 1;  // time every n-th launch of a selected kernel
@@ -219,6 +222,7 @@ void free_problem(pk_ctx* c) {
   release(c->d_items_jacc); release(c->d_Jc);
   release(c->d_phases); release(c->d_tiles); release(c->d_kinds); release(c->d_items_jac); release(c->d_items_hess); release(c->d_items_aux); release(c->d_outer); release(c->d_aux); release(c->d_items_hessc); release(c->d_Hc);
   release(c->d_erriv); release(c->d_errgrp); release(c->d_errdb); release(c->d_errT); release(c->d_errI);
+  release(c->d_big_stage); release(c->d_err_stage);
   c->n_erriv = 0; c->n_err_out = 0;
   drop_cycle_graph(c);
   release(c->d_trace);
@@ -284,6 +288,7 @@ PkArgs base_args(pk_ctx* c, const double* d_x, const double* d_lam, double sigma
   for (size_t k = 0; k < c->h_phases.size(); ++k) A.ph[k] = c->h_phases[k];
   A.trace = c->d_trace;
   A.o_gshared = c->gshared;
+  A.big_stage = c->d_big_stage; A.big_row = c->big_row; A.big_slot = c->big_slot;
   return A;
 }
 
@@ -687,7 +692,28 @@ int pk_set_problem(pk_ctx* c, const pk_problem_desc* pd) {
   if ((rc = upload(c, &c->d_phases, pd->phases, sizeof(PkPhase) * (size_t)pd->n_phase))) return rc;
   c->h_phases.assign((const PkPhase*)pd->phases, (const PkPhase*)pd->phases + pd->n_phase);
 
-  if ((rc = upload(c, &c->d_tiles, pd->tiles, sizeof(PkTile) * (size_t)pd->n_tiles))) return rc;
+  {   // intervals with more than 256 points stage their rows in device memory: slot numbers into the tile records
+    std::vector<PkTile> tiles((const PkTile*)pd->tiles, (const PkTile*)pd->tiles + pd->n_tiles);
+    int32_t n_stage = 0, kmax = 0;
+    for (PkTile& t : tiles) {
+      t.stage = 0;
+      if (t.nj > 0 && t.K > 256) {
+        t.stage = n_stage++;
+        if (t.K > kmax) kmax = t.K;
+      }
+    }
+    release(c->d_big_stage);
+    c->big_row = c->big_slot = 0;
+    if (n_stage) {
+      const size_t rows = (size_t)(c->md.lds_x > c->md.lds_h ? c->md.lds_x : c->md.lds_h) / PK_WAVE;
+      c->big_row = (kmax + 7) & ~7;
+      const size_t slot = rows * (size_t)c->big_row;
+      if (slot > (size_t)INT32_MAX) return fail(c, 33, "pk_set_problem: an interval with %d points is too long for the staging buffer", kmax);
+      c->big_slot = (int32_t)slot;
+      PK_HIP(c, hipMalloc((void**)&c->d_big_stage, sizeof(double) * slot * 4 * (size_t)n_stage));
+    }
+    if ((rc = upload(c, &c->d_tiles, tiles.data(), sizeof(PkTile) * tiles.size()))) return rc;
+  }
   if ((rc = upload(c, &c->d_kinds, pd->kinds, sizeof(PkKind) * (size_t)pd->n_kinds))) return rc;
   if ((rc = upload(c, &c->d_items_jac, pd->items_jac, sizeof(PkItem) * (size_t)pd->n_items_jac))) return rc;
   if ((rc = upload(c, &c->d_items_hess, pd->items_hess, sizeof(PkItem) * (size_t)pd->n_items_hess))) return rc;
@@ -717,14 +743,11 @@ int pk_set_problem(pk_ctx* c, const pk_problem_desc* pd) {
     for (int32_t t = 0; t < pd->n_tiles; ++t)
       if (tl[t].nj > 0 && tl[t].K > PK_WAVE) {
         c->has_big = true;
-        if (t % PK_WAVES_PER_BLOCK || tl[t].nj != 1 || tl[t].K > 256)
-          return fail(c, 33, "pk_set_problem: tile %d: an interval with more than %d points must be alone in the first slot of a tile block (K <= 256)", t, PK_WAVE);
+        if (t % PK_WAVES_PER_BLOCK || tl[t].nj != 1)
+          return fail(c, 33, "pk_set_problem: tile %d: an interval with more than %d points must be alone in the first slot of a tile block", t, PK_WAVE);
         for (int32_t u = 1; u < PK_WAVES_PER_BLOCK && t + u < pd->n_tiles; ++u)
           if (tl[t + u].nj != 0) return fail(c, 33, "pk_set_problem: tile %d shares a block with a big interval", t + u);
       }
-    const bool needs_I = c->md.prepass_grad || c->md.prepass_g || c->md.prepass_jac || c->md.prepass_hess;
-    if (c->has_big && needs_I)
-      return fail(c, 34, "pk_set_problem: num_point > %d is not supported together with system functions nonlinear in the integrals", PK_WAVE);
   }
   c->d_grad = c->d_J + c->nnz_J;
   c->d_g = c->d_grad + c->n;
@@ -780,7 +803,6 @@ int pk_get_structure(pk_ctx* c, int32_t* jr, int32_t* jc, int32_t* hr, int32_t* 
 int pk_eval_f_dev(pk_ctx* c, const double* d_x, double* d_f, void* stream) {
   int rc = ready(c);
   if (rc) return rc;
-  if (c->has_big) return eval_one_via_xpart(c, d_x, 0, d_f, stream);
   return prepass(c, d_x, nullptr, 0.0, d_f, true, pick(c, stream));
 }
 
@@ -1059,7 +1081,7 @@ int pk_set_mesh_error_tables(pk_ctx* c, const void* intervals, int32_t n_interva
     const PkPhase& ph = c->h_phases[r.phase];
     const int na = r.K + 1, ncx = r.K + 1 - ph.scheme, nr = ncx;
     const int64_t tab = (int64_t)na * ncx + (int64_t)na * r.K + (int64_t)nr * ncx + (int64_t)nr * na;
-    if (r.K < 1 || r.K > 256 || r.lm < 0 || r.lm + ncx > ph.state_len || r.lm + r.K > ph.L_m || r.tab_off < 0 ||
+    if (r.K < 1 || r.lm < 0 || r.lm + ncx > ph.state_len || r.lm + r.K > ph.L_m || r.tab_off < 0 ||
         r.tab_off + tab > n_tables || r.tau_off < 0 || r.tau_off + na > n_tables || r.row0 < 0 || r.row0 + nr > r.rows ||
         r.out_off < 0 || r.out_off + (int64_t)ph.n_x * r.rows > n_out)
       return fail(c, 74, "pk_set_mesh_error_tables: record %d is inconsistent with the problem", g);
@@ -1085,9 +1107,27 @@ int pk_set_mesh_error_tables(pk_ctx* c, const void* intervals, int32_t n_interva
   }
   PK_HIP(c, hipSetDevice(c->device));
   PK_HIP(c, hipStreamSynchronize(c->stream));
-  release(c->d_erriv); release(c->d_errgrp); release(c->d_errdb); release(c->d_errT); release(c->d_errI);
-  c->n_erriv = 0; c->n_err_out = 0;
-  if ((rc = upload(c, &c->d_erriv, intervals, sizeof(PkErrIv) * (size_t)n_intervals))) return rc;
+  release(c->d_erriv); release(c->d_errgrp); release(c->d_errdb); release(c->d_errT); release(c->d_errI); release(c->d_err_stage);
+  c->n_erriv = 0; c->n_err_out = 0; c->err_row = c->err_slot = 0;
+  {   // intervals whose K + 1 augmented nodes do not fit the LDS rows of 264 doubles: slots of a staging buffer
+    std::vector<PkErrIv> ivs(iv, iv + n_intervals);
+    int32_t n_stage = 0, namax = 0;
+    for (PkErrIv& r : ivs) {
+      r.stage = 0;
+      if (r.K + 1 > 264) {
+        r.stage = n_stage++;
+        if (r.K + 1 > namax) namax = r.K + 1;
+      }
+    }
+    if (n_stage) {
+      c->err_row = (namax + 7) & ~7;
+      const size_t slot = ((size_t)c->md.lds_e / PK_WAVE) * (size_t)c->err_row;
+      if (slot > (size_t)INT32_MAX) return fail(c, 72, "pk_set_mesh_error_tables: an interval with %d points is too long for the staging buffer", namax - 1);
+      c->err_slot = (int32_t)slot;
+      PK_HIP(c, hipMalloc((void**)&c->d_err_stage, sizeof(double) * slot * (size_t)n_stage));
+    }
+    if ((rc = upload(c, &c->d_erriv, ivs.data(), sizeof(PkErrIv) * ivs.size()))) return rc;
+  }
   if ((rc = upload(c, (void**)&c->d_errgrp, groups, sizeof(int32_t) * 2 * (size_t)n_groups))) return rc;
   if ((rc = upload(c, (void**)&c->d_errdb, tables, sizeof(double) * (size_t)n_tables))) return rc;
   PK_HIP(c, hipMalloc((void**)&c->d_errT, sizeof(double) * (size_t)n_out));
@@ -1110,6 +1150,7 @@ int pk_eval_mesh_error_dev(pk_ctx* c, const double* d_x, double* d_T, double* d_
   A.n_erriv = c->n_erriv;
   A.o_errT = d_T;
   A.o_errI = d_I;
+  A.big_stage = c->d_err_stage; A.big_row = c->err_row; A.big_slot = c->err_slot;
   // (lds_e = 64 (2 n_x + n_u) doubles per wave; a workgroup-wide interval stages rows of 264 doubles)
   return launch(c, K_ERR, A, (unsigned)(c->n_erriv / PK_WAVES_PER_BLOCK),
                 sizeof(double) * ((size_t)c->md.lds_e / PK_WAVE) * 264, pick(c, stream));
@@ -1155,6 +1196,10 @@ int pk_eval_cycle_dev(pk_ctx* c, const double* d_x, const double* d_lam, double 
   // general path: the five callbacks one after the other.  A shard (pk_set_shard) may take the single launch too: its
   // finalize workgroup then leaves THIS shard's share of the integrals and of the shared gradient slots for the
   // caller's all-reduce, and f is the caller's to recompute (pk_eval_f_from_integrals_dev).
+  if (needs_I && c->has_big) {       // (big intervals: the fused x-kernel behind the integral prepass, then H)
+    if ((rc = pk_eval_xpart_dev(c, d_x, d_f, d_grad, d_g, d_jac, stream))) return rc;
+    return pk_eval_hess_dev(c, d_x, d_lam, sigma, d_hess, stream);
+  }
   if (needs_I || ((c->external_prepass || c->shard_flags) && c->cycle_mode != 1)) {
     if (!c->external_prepass && (rc = pk_eval_f_dev(c, d_x, d_f, stream))) return rc;
     if ((rc = pk_eval_grad_dev(c, d_x, d_grad, stream))) return rc;
@@ -1243,12 +1288,15 @@ int pk_eval_xpart_dev(pk_ctx* c, const double* d_x, double* d_f, double* d_grad,
   if (rc) return rc;
   hipStream_t st = pick(c, stream);
   const bool needs_I = c->md.prepass_grad || c->md.prepass_g || c->md.prepass_jac || c->md.prepass_hess;
-  if (needs_I) {
+  if (needs_I && !c->has_big) {
     if (!c->external_prepass && (rc = pk_eval_f_dev(c, d_x, d_f, stream))) return rc;
     if ((rc = pk_eval_grad_dev(c, d_x, d_grad, stream))) return rc;
     if ((rc = pk_eval_g_dev(c, d_x, d_g, stream))) return rc;
     return pk_eval_jac_dev(c, d_x, d_jac, stream);
   }
+  // (a mesh with intervals of more than 64 points has the fused x-kernel only: the integrals it needs come from the
+  //  integral prepass in front of it)
+  if (needs_I && !c->external_prepass && (rc = prepass(c, d_x, nullptr, 0.0, d_f, true, st))) return rc;
   PkArgs A = base_args(c, d_x, nullptr, 0.0);
   A.o_f = d_f; A.o_grad = d_grad; A.o_g = d_g; A.o_jac = d_jac;
   A.items = (const PkItem*)c->d_items_jac;
@@ -1257,7 +1305,8 @@ int pk_eval_xpart_dev(pk_ctx* c, const double* d_x, double* d_f, double* d_grad,
   if (lds < sizeof(double) * (size_t)c->md.ne_j) lds = sizeof(double) * (size_t)c->md.ne_j;
   A.flags |= xall_flags(c);
   if ((rc = launch(c, K_XALL, A, xall_blocks(c), lds, st))) return rc;
-  A.flags |= F_FIN_INT | F_WRITE_F | F_FIN_GRAD;
+  // (a shard of a model nonlinear in the integrals: the caller has summed the integrals over the ranks, they stay as they are)
+  A.flags |= ((needs_I && c->external_prepass) ? 0 : (F_FIN_INT | F_WRITE_F)) | F_FIN_GRAD;
   return launch(c, K_FIN, A, 1, 0, st);
 }
 

@@ -20,7 +20,9 @@ import numpy as np
 from . import collocation
 
 WAVE = 64
-BIG_MAX = 256      # an interval with 64 < K <= 256 points is handled by a whole workgroup (PK_BIG code objects)
+BIG_MAX = 256      # an interval with more than 64 points is handled by a whole workgroup (PK_BIG code objects); up to BIG_MAX its
+                   # per-node values are staged in LDS, beyond that in a slot of device memory (no limit on num_point, as
+                   # in the reference: radau/discretization.py:488-521)
 
 
 class Kind:
@@ -65,8 +67,6 @@ class MeshLayout:
         self.n_x, self.n_u = n_x, n_u
         lgr = scheme == "lgr"
         N = self.N = len(self.K)
-        if int(self.K.max()) > BIG_MAX:
-            raise NotImplementedError(f"num_point > {BIG_MAX} per interval is not supported by the HIP kernels")
         self.width = np.diff(self.mesh)
         mid = (self.mesh[1:] + self.mesh[:-1]) / 2
         self.stride = self.K if lgr else self.K - 1               # nodes an interval adds

@@ -49,7 +49,7 @@ PHASE_FIELDS = ["scheme", "n_x", "n_u", "n_c", "L_m", "L_d", "state_len", "L", "
                 "hseg_off", "red_off", "aseg_off", "hcseg_off", "ivK_off", "ivfull_off", "ivld_off", "n_int", "jcseg_off", "jct_off"]
 PHASE_DTYPE = np.dtype([(n, np.int32) for n in PHASE_FIELDS])
 TILE_FIELDS = ["phase", "j0", "nj", "kid", "kidf", "q0", "r0", "offI", "offT", "K", "last",
-               "nnzI", "nnzT", "irc_off", "iv_off", "tv_off", "full_off", "pad", "magicI", "magicR", "magicT", "pad2"]
+               "nnzI", "nnzT", "irc_off", "iv_off", "tv_off", "full_off", "pad", "magicI", "magicR", "magicT", "stage"]
 TILE_DTYPE = np.dtype([(n, np.uint32 if n.startswith("magic") else np.int32) for n in TILE_FIELDS])
 KIND_FIELDS = ["K", "R", "nnzI", "nnzT", "irc_off", "iv_off", "tv_off", "full_off"]
 KIND_DTYPE = np.dtype([(n, np.int32) for n in KIND_FIELDS])
@@ -57,7 +57,7 @@ ITEM_DTYPE = np.dtype([("pos", np.int64), ("coef", np.float64), ("eid", np.int32
 OUTER_DTYPE = np.dtype([("pos", np.int64), ("offA", np.int32), ("lenA", np.int32), ("offB", np.int32), ("lenB", np.int32),
                         ("offM", np.int32), ("flags", np.int32), ("count", np.int32), ("pad", np.int32)])
 ERRIV_DTYPE = np.dtype([("phase", np.int32), ("K", np.int32), ("lm", np.int32), ("row0", np.int32),
-                        ("tab_off", np.int32), ("tau_off", np.int32), ("rows", np.int32), ("pad", np.int32),
+                        ("tab_off", np.int32), ("tau_off", np.int32), ("rows", np.int32), ("stage", np.int32),
                         ("out_off", np.int64), ("width", np.float64)])
 
 WAVES_PER_BLOCK = 4  # PK_WAVES_PER_BLOCK of csrc/pk_abi.h

@@ -194,11 +194,16 @@ def test_maximum_supported_order_matches_the_plan_interpreter(case):
                                   ("planar_quadrotor", "lobatto", dict(mesh=[0, 0.5, 1.0], num_point=[256, 7])),
                                   ("two_stage_rocket", "radau", dict(mesh=[0, 0.4, 1.0], num_point=[70, 9])),
                                   ("humanoid_wbc", "radau", dict(mesh=[0, 0.5, 1.0], num_point=[4, 80])),
+                                  ("brachistochrone", "radau", dict(mesh=[0, 0.3, 1.0], num_point=[300, 5])),      # > 256: staged in device memory
+                                  ("brachistochrone", "lobatto", dict(mesh=[0, 0.2, 0.6, 1.0], num_point=[257, 70, 513])),
+                                  ("planar_quadrotor", "lobatto", dict(mesh=[0, 0.5, 1.0], num_point=[7, 400])),
+                                  ("planar_quadrotor", "radau", dict(mesh=[0, 0.4, 1.0], num_point=[264, 263])),   # (K + 1 = 264 / 265 augmented nodes)
                                   ("planar_quadrotor", "radau", dict(mesh=[0, 0.5, 0.6, 1.0], num_point=[128, 6, 200]), "mfma"),
                                   ("brachistochrone", "lobatto", dict(mesh=[0, 0.3, 0.6, 1.0], num_point=[66, 5, 130]), "mfma")])
 def test_intervals_with_more_points_than_a_wavefront_has_lanes(case, monkeypatch):
-    """64 < num_point <= 256 (the reference has no limit, radau/discretization.py:488-521): such an interval is evaluated
-    by a whole workgroup (PK_BIG code objects), next to ordinary wave tiles.  Reference: the NumPy execution of the same
+    """num_point > 64 (the reference has no limit, radau/discretization.py:488-521): such an interval is evaluated
+    by a whole workgroup (PK_BIG code objects), next to ordinary wave tiles; up to 256 points its per-node values are
+    staged in LDS, beyond that in the interval's slot of a staging buffer in device memory.  Reference: the NumPy execution of the same
     plan with the product's own tables (pinned by the multiprecision tables of tests/test_tables_hiprec.py up to K = 128;
     the oracle's np.roots-based tables carry no digits at these orders).  "mfma": the same with the interval's products on
     the fp64 matrix cores (POCKIT_AMD_BIG_MFMA=1; measured slower than the VALU form, kept as a switch)."""
@@ -233,8 +238,6 @@ def test_intervals_with_more_points_than_a_wavefront_has_lanes(case, monkeypatch
     f2, grad2, g2, J2, H2 = ev.cycle(x, lam, sigma)
     assert np.array_equal(J2, J) and np.array_equal(H2, H) and np.array_equal(g2, g)
     ev.set_cycle_mode(True)
-    with pytest.raises(NotImplementedError):
-        getattr(models, bname)(_ns(scheme, "pockit_amd"), mesh=1, num_point=257).plan
     system.set_hessian_layout("compact")                             # compact layout: pk_hessc walks such an interval 64 nodes at a time
     close(system.hessian(x, lam, sigma), it.hessian_compact(), what="compact H")
     system.set_hessian_layout("reference")
@@ -247,6 +250,44 @@ def test_intervals_with_more_points_than_a_wavefront_has_lanes(case, monkeypatch
         close(data[k][0], T, what=f"error T phase {k}")
         close(data[k][1], I, what=f"error I phase {k}")
     assert isinstance(system.check_continuous(guess), bool)
+
+
+@pytest.mark.parametrize("scheme,kw", [("radau", dict(mesh=(0, 0.2, 0.5, 1), num_point=(3, 80, 4))),
+                                       ("lobatto", dict(mesh=(0, 0.2, 0.5, 1), num_point=(3, 80, 4))),
+                                       ("radau", dict(mesh=(0, 0.4, 0.6, 1), num_point=(70, 5, 129))),
+                                       ("lobatto", dict(mesh=(0, 0.4, 0.6, 1), num_point=(70, 5, 129))),
+                                       ("lobatto", dict(mesh=(0, 0.5, 1), num_point=(290, 6)))])
+def test_model_nonlinear_in_the_integrals_on_intervals_with_more_than_64_points(scheme, kw):
+    """Objective and system constraints nonlinear in the integrals (outer-product Hessian blocks, easyderiv.py:323-459; the
+    integrals are needed before every other kernel) on a mesh with workgroup-wide intervals: the integral prepass (pk_int)
+    and the auxiliary pass (pk_aux) walk such an interval with a whole workgroup too.  Reference: the NumPy execution of
+    the same plan (tests/plan_interp.py)."""
+    from plan_interp import Interp
+
+    system, _, guess = models.derivative_model(_ns(scheme, "pockit_amd"), **kw)
+    assert system.plan.outer and system.evaluator.src.big
+    x, lam, sigma = models.bench_inputs(system, guess)
+    it = Interp(system.plan, x, lam, sigma)
+    want = dict(f=it.objective(), grad=it.gradient(), g=it.constraints(), J=it.jacobian(), H=it.hessian())
+    ev = system.evaluator
+    f, grad, g, J, H = ev.cycle(x, lam, sigma)
+    for name, got in (("f", f), ("grad", grad), ("g", g), ("J", J), ("H", H)):
+        close(got, want[name], what="cycle " + name)
+    close(system.objective(x), want["f"], what="f")
+    close(system.gradient(x), want["grad"], what="grad")
+    close(system.constraints(x), want["g"], what="g")
+    close(system.jacobian(x), want["J"], what="J")
+    close(system.hessian(x, lam, sigma), want["H"], what="H")
+    close(ev.objective_direct(x), want["f"], what="f direct")
+    close(ev.gradient_direct(x), want["grad"], what="grad direct")
+    close(ev.constraints_direct(x), want["g"], what="g direct")
+    close(ev.jacobian_direct(x), want["J"], what="J direct")
+    close(ev.hessian_direct(x, lam, sigma), want["H"], what="H direct")
+    # the same model on an ordinary mesh agrees with the oracle (pins the interpreter's outer-product path)
+    small, _, sg = models.derivative_model(_ns(scheme, "pockit_amd"))
+    ref, _, rg = models.derivative_model(_ns(scheme, "oracle"))
+    xs, ls, ss = models.bench_inputs(small, sg)
+    close(Interp(small.plan, xs, ls, ss).hessian(), ref.hessian(xs, ls, ss), what="interpreter vs oracle H")
 
 
 def test_prepared_x_cache_is_dropped_by_calls_that_reuse_the_context_buffers():
