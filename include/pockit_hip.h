@@ -274,6 +274,12 @@ int pk_wait_idle(pk_ctx* ctx, void* stream);   /* the same by polling the stream
  * (RCCL all-reduce) and only then calls the callbacks / pk_eval_f_from_integrals_dev. */
 int pk_set_shard(pk_ctx* ctx, int secondary, int external_prepass, double* d_integrals);
 int pk_eval_integrals_dev(pk_ctx* ctx, const double* d_x, void* stream);
+/* models nonlinear in the integrals (outer-product Hessian blocks, easyderiv.py:323-459) as shards: pk_eval_hess_dev leaves
+ * the quadrature-weighted gradient entries of the integrals of THIS shard's nodes in the auxiliary buffer (pk_aux_buffer;
+ * entries of other shards' nodes stay zero); the caller sums the buffers over the ranks into a buffer of its own and the
+ * primary rank forms the blocks from the sum with pk_eval_outer_dev (into the Hessian values, reference positions). */
+int pk_aux_buffer(pk_ctx* ctx, double** d_ptr, int64_t* count);
+int pk_eval_outer_dev(pk_ctx* ctx, const double* d_aux_sum, double* d_vals /* nnz_H */, void* stream);
 int pk_eval_f_from_integrals_dev(pk_ctx* ctx, const double* d_x, double* d_f, void* stream);
 
 /* Sharded cycles without a collective in the data path.  Every rank leaves its shard's slices of grad f / g / J / H in

@@ -890,10 +890,36 @@ int pk_eval_hess_dev(pk_ctx* c, const double* d_x, const double* d_lam, double s
     X.items = (const PkItem*)c->d_items_aux;
     X.n_items = c->n_items_aux;
     if ((rc = launch(c, K_AUX, X, tile_blocks(c) + 1, sizeof(double) * (size_t)(c->md.ne_a > 0 ? c->md.ne_a : 1), st))) return rc;
+    // a shard stops here: its auxiliary buffer holds the entries of ITS nodes, the caller sums the buffers over the
+    // ranks and has the primary rank form the blocks (pk_eval_outer_dev)
+    if (c->external_prepass) return 0;
     const unsigned grid = (unsigned)(c->n_outer < 4096 ? c->n_outer : 4096);
     return launch(c, K_OUTER, X, grid, 0, st);
   }
   return 0;
+}
+
+// sharded mode, models nonlinear in the integrals: the auxiliary buffer pk_eval_hess_dev fills on a shard (NULL / 0 for
+// models without outer-product blocks) ...
+int pk_aux_buffer(pk_ctx* c, double** ptr, int64_t* count) {
+  int rc = ready(c);
+  if (rc) return rc;
+  if (ptr) *ptr = c->n_outer > 0 ? c->d_aux : nullptr;
+  if (count) *count = c->n_outer > 0 ? (int64_t)c->n_aux : 0;
+  return 0;
+}
+
+// ... and the outer-product blocks of the Hessian from the buffer summed over the ranks (d_aux_sum: n_aux doubles, device)
+int pk_eval_outer_dev(pk_ctx* c, const double* d_aux_sum, double* d_vals, void* stream) {
+  int rc = ready(c);
+  if (rc) return rc;
+  if (c->n_outer <= 0) return 0;
+  if (!d_aux_sum || !d_vals) return fail(c, 50, "pk_eval_outer: null device buffer");
+  PkArgs X = base_args(c, nullptr, nullptr, 0.0);
+  X.o_hess = d_vals;
+  X.o_aux = const_cast<double*>(d_aux_sum);
+  const unsigned grid = (unsigned)(c->n_outer < 4096 ? c->n_outer : 4096);
+  return launch(c, K_OUTER, X, grid, 0, pick(c, stream));
 }
 
 // compact (coalesced) Hessian of the Lagrangian: one value per distinct (row, col) class of a node

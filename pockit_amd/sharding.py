@@ -428,9 +428,6 @@ class ShardedEvaluator:
         from .evaluator import Evaluator, Tables, _intervals_per_wave
 
         self.torch, self.rank, self.world, self.plan = torch, rank, world, plan
-        if world > 1 and plan.outer:
-            raise NotImplementedError("objectives / system constraints nonlinear in the integrals (outer-product "
-                                      "Hessian blocks) are evaluated on one GPU only; they are O(n^2) and small")
         if intervals_per_wave is None:          # the tiling is sized for ONE shard's share of the mesh
             intervals_per_wave = _intervals_per_wave(plan, shards=world)
         self.ev = Evaluator(plan, device=device, intervals_per_wave=intervals_per_wave,
@@ -456,6 +453,14 @@ class ShardedEvaluator:
         self.I = self.small[:n_I]
         lib, h = self.ev.ctx.lib, self.ev.ctx.handle
         self.ev.ctx.check(lib.pk_set_shard(h, int(rank != 0), 1, C.c_void_p(self.I.data_ptr())))
+        # objectives / system constraints nonlinear in the integrals (outer-product Hessian blocks, easyderiv.py:323-459):
+        # every shard fills the auxiliary entries of its own nodes, the sum over the ranks goes to the primary rank's blocks
+        self.aux_own = self.aux_sum = None
+        if plan.outer:
+            p_aux, n_aux = C.c_void_p(), C.c_int64()
+            self.ev.ctx.check(lib.pk_aux_buffer(h, C.byref(p_aux), C.byref(n_aux)))
+            self.aux_own = torch.as_tensor(_DeviceArray(p_aux.value, n_aux.value), device=dev)
+            self.aux_sum = torch.zeros(n_aux.value, dtype=torch.float64, device=dev)
         self.stream = torch.cuda.Stream(device=dev)
         self.peers, self.root, self._root_alloc, self._root_map, self.target = None, None, None, None, None
         self.inline_exchange = True      # the sums over the ranks are exchanged inside pk_cycle's launch (False: pk_xchg behind it)
@@ -635,10 +640,15 @@ class ShardedEvaluator:
             chk(lib.pk_eval_integrals_dev(h, px, st))                  # this shard's share of every integral
             if sharded:
                 dist.all_reduce(self.I)
-            chk(lib.pk_eval_grad_dev(h, px, ptr(o["grad"]), st))
-            chk(lib.pk_eval_g_dev(h, px, ptr(o["g"]), st))
-            chk(lib.pk_eval_jac_dev(h, px, ptr(o["J"]), st))
+            # (grad f, g, J: one kernel each, or -- meshes with workgroup-wide intervals -- the fused x-kernel)
+            chk(lib.pk_eval_xpart_dev(h, px, ptr(o["f"]), ptr(o["grad"]), ptr(o["g"]), ptr(o["J"]), st))
             chk(lib.pk_eval_hess_dev(h, px, ptr(lam), float(sigma), ptr(o["H"]), st))
+            if self.aux_sum is not None:
+                self.aux_sum.copy_(self.aux_own)
+                if sharded:
+                    dist.all_reduce(self.aux_sum)          # (a sum with zeros: every entry is filled by exactly one rank)
+                if self.rank == 0:
+                    chk(lib.pk_eval_outer_dev(h, ptr(self.aux_sum), ptr(o["H"]), st))
         if sharded:
             root = None if exchange == "allgather" else root
             if self.early_I:           # integrals are already global: keep them out of the second reduction

@@ -65,7 +65,7 @@ def _worker(rank, world, port, case, ret):
         name, scheme, kw = case
         builder = getattr(models, name)
         system, _, guess = builder(importlib.import_module(f"pockit_amd.{scheme}"), **kw)
-        ref, _, _ = builder(importlib.import_module(f"oracle.{scheme}"), **kw)
+        ref = _reference(system, builder, scheme, kw)
         x, lam, sigma = models.bench_inputs(system, guess)
         dev = torch.device("cuda", 0)
         torch.cuda.set_device(dev)
@@ -208,7 +208,12 @@ def test_two_process_peer_exchange_without_collectives(case):
 
 @pytest.mark.parametrize("case", [("two_stage_rocket", "radau", dict(mesh=40, num_point=4)),
                                   ("planar_quadrotor", "lobatto", dict(mesh=33, num_point=5)),
-                                  ("brachistochrone", "radau", dict(mesh=61, num_point=6))])
+                                  ("brachistochrone", "radau", dict(mesh=61, num_point=6)),
+                                  # objective / system constraints nonlinear in the integrals: the integrals are summed over the
+                                  # ranks before the other kernels, the outer-product blocks are formed by rank 0 from the summed
+                                  # auxiliary entries (easyderiv.py:323-459); the second mesh has a workgroup-wide interval
+                                  ("derivative_model", "radau", dict(mesh=(0, .1, .2, .35, .5, .6, .75, .9, 1), num_point=(3, 4, 3, 4, 5, 4, 3, 4))),
+                                  ("derivative_model", "lobatto", dict(mesh=(0, .2, .5, .7, 1), num_point=(4, 70, 5, 6)))])
 def test_two_process_sharded_cycle_matches_oracle(case):
     import torch.multiprocessing as mp
 
