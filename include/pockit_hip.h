@@ -314,6 +314,10 @@ int pk_exchange_sums_dev(pk_ctx* ctx, const double* d_x, double* d_grad, double*
  * launch per GPU; 0 (default): pk_exchange_sums_dev is a launch of its own behind it. */
 int pk_set_exchange_inline(pk_ctx* ctx, int enable);
 int pk_copy_runs_dev(pk_ctx* ctx, const int64_t* d_table, int n_chunks, const double* d_src, double* d_dst, void* stream);
+/* a progress mark: *d_dst = value once everything enqueued before it on the stream has finished (d_dst: device address of an
+ * 8-byte aligned word, e.g. inside a segment registered with pk_host_register -- the host-landed sharded cycle lets rank 0
+ * poll such words instead of waiting for the other processes to notice that their GPU has finished) */
+int pk_store_word_dev(pk_ctx* ctx, void* d_dst, int64_t value, void* stream);
 
 /* HIP-event timing of the individual kernels on the launch stream.
  * kernel ids: 0 pk_int, 1 pk_fin, 2 pk_g, 3 pk_grad, 4 pk_jac, 5 pk_hess, 6 pk_xall, 7 pk_aux, 8 pk_outer,

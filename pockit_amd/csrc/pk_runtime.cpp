@@ -419,6 +419,12 @@ __global__ void __launch_bounds__(256) pk_copy_kernel(const double* __restrict__
   }
 }
 
+// One 64-bit word stored behind everything enqueued before it on the stream (a progress mark in pinned host memory that
+// the host, or another process mapping the same segment, polls: seen a few microseconds before an event would report).
+__global__ void __launch_bounds__(64) pk_store_word_kernel(unsigned long long* dst, unsigned long long value) {
+  if (blockIdx.x == 0 && threadIdx.x == 0) *(volatile unsigned long long*)dst = value;
+}
+
 namespace {
 
 // dst[0 .. n) = src[0 .. n) on the context's stream: the copy kernel when asked for and possible, else the DMA engine
@@ -1988,6 +1994,16 @@ int pk_copy_runs_dev(pk_ctx* c, const int64_t* d_table, int n_chunks, const doub
   PkArgs A = base_args(c, nullptr, nullptr, 0.0);
   A.rc_table = d_table; A.rc_n = n_chunks; A.rc_src = d_src; A.rc_dst = d_dst;
   return launch(c, K_RUNS, A, (unsigned)(n_chunks < 8192 ? n_chunks : 8192), 0, pick(c, stream));
+}
+
+// *d_dst = value, in stream order (d_dst: device address of a 64-bit word, typically of a registered host segment)
+int pk_store_word_dev(pk_ctx* c, void* d_dst, int64_t value, void* stream) {
+  if (!c) return fail(nullptr, 1, "null context");
+  if (!d_dst || ((uintptr_t)d_dst & 7)) return fail(c, 60, "pk_store_word: destination must be an 8-byte aligned device address");
+  PK_HIP(c, hipSetDevice(c->device));
+  hipLaunchKernelGGL(pk_store_word_kernel, dim3(1), dim3(64), 0, pick(c, stream), (unsigned long long*)d_dst, (unsigned long long)value);
+  PK_HIP(c, hipGetLastError());
+  return 0;
 }
 
 // ---------------------------------------------------------------- profiling

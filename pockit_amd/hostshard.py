@@ -16,6 +16,12 @@ run-copy kernel (``pk_runs``) store its owned runs into the segment and publishe
 gradient slots]; rank 0 adds them in rank order and evaluates f = F_o(I, s) (systembase.py:592-605) on the host.  The
 Hessian works the same way with lambda and sigma.  No collective, no device-to-device traffic.
 
+Progress is reported by the GPUs themselves: behind its copies every rank's stream stores the sequence number into a mark
+word of the segment (``pk_store_word_dev``), first when the partial sums and the grad f / g slices have landed, then when
+the J slices have, and when the H slices have.  Rank 0 polls those words -- it never waits for another PROCESS to notice
+that its GPU has finished -- and returns objective / gradient / constraints while J is still on the links (``jacobian``
+waits for the second mark).  ``hessian`` launches on the prepared x before it compares x with it.
+
 Only models whose system-level functions are linear in the integrals (none of BASELINE's configs is otherwise).
 torch.distributed is used at set-up only (the segment's name).
 """
@@ -33,8 +39,11 @@ from .evaluator import Evaluator, _intervals_per_wave
 from .sharding import needed_x_runs, owned_runs, run_table, shared_gradient_slots, tile_filter
 
 CMD_EXIT, CMD_X, CMD_HESS = 0, 1, 2
-CTRL_WORDS = 64          # control block: [0] sequence number, [1] command, [2] pid of rank 0 (liveness), [8 + r] last sequence
-                         # rank r completed
+MAX_RANKS = 56
+CTRL_WORDS = 256         # control block: [0] sequence number, [1] command, [2] pid of rank 0 (liveness), [8 + r] last sequence
+                         # rank r's HOST loop has drained; progress marks written by rank r's GPU behind its copies (a one-word
+                         # kernel, pk_store_word_dev): [MARK_EARLY + r] sequence whose partial sums, grad f and g slices have
+MARK_EARLY, MARK_X, MARK_H = 64, 128, 192      # landed, [MARK_X + r] ... whose J slices have landed, [MARK_H + r] ... H slices
 
 
 class HostShardedEvaluator:
@@ -43,6 +52,8 @@ class HostShardedEvaluator:
     def __init__(self, plan, rank, world, dist, device=0, intervals_per_wave=None, timeout_s=120.0):
         if plan.outer or plan.needs_I_grad or plan.needs_I_con or plan.jac.needs_I or plan.hess.needs_I:
             raise NotImplementedError("the host-landed sharded cycle needs system functions that are linear in the integrals")
+        if world > MAX_RANKS:
+            raise ValueError(f"at most {MAX_RANKS} ranks")
         self.plan, self.rank, self.world, self.timeout_s = plan, rank, world, float(timeout_s)
         if intervals_per_wave is None:
             intervals_per_wave = _intervals_per_wave(plan, shards=world)
@@ -138,7 +149,10 @@ class HostShardedEvaluator:
             t[:, 1] = t[:, 0] + shift_dst          # destination offset = position in the packed layout (+ shift)
             return self._upload_table(t)
 
-        self.tab_x, self.tab_h = table(rx), table(rh)
+        # (grad f and g slices travel first: objective / gradient / constraints return while J is still on the link)
+        r_early = [(a, b) for a, b in rx if a < n + m]
+        rj = [(a, b) for a, b in rx if a >= n + m]
+        self.tab_early, self.tab_j, self.tab_h = table(r_early), table(rj), table(rh)
         # the +-1 translation entries of J never change (phasebase.py:1071-1081): after this rank's first x-part they are in
         # the solver's array for good, and the per-iterate run copy leaves them out (19 % of J at 12k quadrotor nodes)
         const = [(split_j0 + a, split_j0 + b) for split_j0 in (n + m,) for a, b in plan.jac_constant_runs() if b - a >= 4096]
@@ -157,8 +171,11 @@ class HostShardedEvaluator:
                     out.append((cur, b))
             return out
 
-        self.tab_x_changing = table(minus(rx, const)) if const else self.tab_x
+        self.tab_j_changing = table(minus(rj, const)) if const else self.tab_j
         self._x_filled = False
+        word = lambda i: C.c_void_p(self._dev_base.value + 8 * int(i))  # noqa: E731
+        self._mark_dev = {k: word(base + rank) for k, base in (("early", MARK_EARLY), ("x", MARK_X), ("h", MARK_H))}
+        self._marks = {k: self.ctrl[base: base + world] for k, base in (("early", MARK_EARLY), ("x", MARK_X), ("h", MARK_H))}
         # what this rank reads of x: uploaded by a run copy over its own link (1 / N of x per link, not N copies of x)
         xr = needed_x_runs(plan, self.ev.tables, rank == 0)
         self.tab_xin = table(xr)
@@ -191,30 +208,48 @@ class HostShardedEvaluator:
         if cnt:
             self.chk(self.lib.pk_copy_runs_dev(self.h, p, cnt, src, dst, None))
 
-    def _do_x_part(self):
-        lib, h, chk, n, m = self.lib, self.h, self.chk, self.plan.n, self.plan.m
+    def _do_x_part(self, seq):
+        """Enqueue this rank's share of an x-part; nothing here waits (the marks tell rank 0 what has landed)."""
+        lib, h, chk = self.lib, self.h, self.chk
         self._runs(self.tab_xin, self._dev("x"), self.d_x)                               # this rank's part of x, over ITS link
         # the fused x-kernel on this shard's tiles: its slices of grad f / g / J, its share of the integrals (-> d_small)
         # and its partial sums of the shared gradient slots (f is rank 0's to compute from the summed integrals)
         chk(lib.pk_eval_xpart_dev(h, self.d_x, self.d_f, self.d_out["grad"], self.d_out["g"], self.d_out["J"], None))
-        # owned runs -> the solver's arrays (the first time all of them, then only what changes with x)
-        self._runs(self.tab_x_changing if self._x_filled else self.tab_x, self.d_full, self._dev("out"))
-        self._x_filled = True
         self._runs(self.tab_sh, self.d_out["grad"], self.d_small)                        # shared slots behind the integrals
-        self._runs(self.tab_part, self.d_small, self._dev("part"))       # (a kernel copy like the others: a DMA behind the
-        chk(lib.pk_wait_idle(h, None))                                    #  kernels costs a cross-engine hand-off, ~10 us)
+        self._runs(self.tab_part, self.d_small, self._dev("part"))       # (kernel copies: a DMA behind the kernels costs a
+        self._runs(self.tab_early, self.d_full, self._dev("out"))        #  cross-engine hand-off, ~10 us)
+        chk(lib.pk_store_word_dev(h, self._mark_dev["early"], seq, None))
+        # owned runs of J -> the solver's array (the first time all of them, then only what changes with x)
+        self._runs(self.tab_j_changing if self._x_filled else self.tab_j, self.d_full, self._dev("out"))
+        self._x_filled = True
+        chk(lib.pk_store_word_dev(h, self._mark_dev["x"], seq, None))
 
-    def _do_hess(self):
-        lib, h, chk, m = self.lib, self.h, self.chk, self.plan.m
+    def _do_hess(self, seq):
+        lib, h, chk = self.lib, self.h, self.chk
         # the Hessian kernel reads the multipliers from the (page-locked) segment itself: every rank then moves only the rows
         # of ITS tiles over its link, and there is no upload in front of the kernel
         chk(lib.pk_eval_hess_dev(h, self.d_x, self._dev("lam"), float(self.h_sigma[0]), self.d_out["H"], None))
         self._runs(self.tab_h, self.d_full, self._dev("out"))
-        chk(lib.pk_wait_idle(h, None))
+        chk(lib.pk_store_word_dev(h, self._mark_dev["h"], seq, None))
+
+    def _wait_marks(self, which, seq):
+        """Rank 0 waits until every rank's GPU has stored the mark ``which`` of sequence ``seq`` (its own critical path: a
+        spin, the clock looked at every 4096 polls)."""
+        marks = self._marks[which]
+        t0, polls = None, 0
+        while True:
+            if marks.min() >= seq:
+                return
+            polls += 1
+            if polls & 0xFFF == 0:
+                now = time.perf_counter()
+                t0 = t0 or now
+                if now - t0 > self.timeout_s:
+                    raise RuntimeError(f"host-sharded cycle: ranks {np.nonzero(marks < seq)[0].tolist()} did not finish "
+                                       f"'{which}' of sequence {seq} within {self.timeout_s:.0f} s")
 
     def _wait_all(self, seq):
-        """Rank 0 waits for every rank's completion mark of ``seq`` (its own critical path: a spin, the clock looked at
-        every 4096 polls)."""
+        """Rank 0 waits until every other rank's host loop has drained ``seq`` (shutdown)."""
         done = self.ctrl[8: 8 + self.world]
         t0, polls = None, 0
         while True:
@@ -249,11 +284,16 @@ class HostShardedEvaluator:
         microseconds), then 50 us sleeps, 1 ms sleeps after a second of silence."""
         last, t_last = 0, time.perf_counter()
         next_check = t_last + 0.5
+        drained = True
         while True:
             seq = int(self.ctrl[0])
             if seq == last:
                 idle = time.perf_counter() - t_last
                 if idle > 2e-3:
+                    if not drained:          # (off rank 0's critical path: it reads the GPU's own marks)
+                        self.chk(self.lib.pk_wait_idle(self.h, None))
+                        self.ctrl[8 + self.rank] = last
+                        drained = True
                     time.sleep(1e-3 if idle > 1.0 else 5e-5)
                     now = time.perf_counter()
                     if now >= next_check:
@@ -263,13 +303,14 @@ class HostShardedEvaluator:
                 continue
             cmd = int(self.ctrl[1])
             if cmd == CMD_EXIT:
+                self.chk(self.lib.pk_wait_idle(self.h, None))
                 self.ctrl[8 + self.rank] = seq
                 return True
             if cmd == CMD_X:
-                self._do_x_part()
+                self._do_x_part(seq)
             elif cmd == CMD_HESS:
-                self._do_hess()
-            self.ctrl[8 + self.rank] = seq
+                self._do_hess(seq)
+            drained = False
             last, t_last = seq, time.perf_counter()
 
     # ------------------------------------------------------------------ rank 0: the callbacks
@@ -279,16 +320,25 @@ class HostShardedEvaluator:
         self.ctrl[0] = self._seq            # (x86: stores are not reordered with older stores)
         return self._seq
 
-    def _prepare(self, x):
+    def _as_x(self, x):
         x = np.ascontiguousarray(x, dtype=np.float64)
         if x.shape != (self.plan.n,):
             raise ValueError(f"x must have shape ({self.plan.n},)")
-        if self._x_seq >= 0 and self.lib.pk_same_bits(x.ctypes.data, self.h_x.ctypes.data, self.plan.n):
+        return x
+
+    def _is_prepared(self, x):
+        return self._x_seq >= 0 and bool(self.lib.pk_same_bits(x.ctypes.data, self.h_x.ctypes.data, self.plan.n))
+
+    def _prepare(self, x):
+        """A new x: post it, evaluate rank 0's own shard, wait until every rank's partial sums, grad f and g slices are in
+        the segment (J is still landing: ``jacobian`` waits for it), finish f and the shared gradient slots."""
+        x = self._as_x(x)
+        if self._is_prepared(x):
             return
         self.h_x[:] = x
         seq = self._post(CMD_X)
-        self._do_x_part()
-        self._wait_all(seq)
+        self._do_x_part(seq)
+        self._wait_marks("early", seq)
         small = self.h_part[0].copy()
         for r in range(1, self.world):        # rank order: reproducible sums
             small += self.h_part[r]
@@ -320,18 +370,29 @@ class HostShardedEvaluator:
 
     def jacobian(self, x):
         self._prepare(x)
+        self._wait_marks("x", self._x_seq)
         return self.out["J"]
 
     def hessian(self, x, lagrange, obj_factor):
         lam = np.ascontiguousarray(lagrange, dtype=np.float64)
         if lam.shape != (self.plan.m,):
             raise ValueError(f"lagrange must have shape ({self.plan.m},)")
-        self._prepare(x)
+        x = self._as_x(x)
         self.h_lam[:] = lam
         self.h_sigma[0] = float(obj_factor)
+        if self._x_seq >= 0:
+            # a solver asks for H at the x it has just evaluated: launch on the prepared x BEFORE comparing (the compare of
+            # n doubles then runs while the GPUs work); in the rare other case drain and start over on the new x
+            seq = self._post(CMD_HESS)
+            self._do_hess(seq)
+            same = self._is_prepared(x)
+            self._wait_marks("h", seq)
+            if same:
+                return self.out["H"]
+        self._prepare(x)
         seq = self._post(CMD_HESS)
-        self._do_hess()
-        self._wait_all(seq)
+        self._do_hess(seq)
+        self._wait_marks("h", seq)
         return self.out["H"]
 
     # ------------------------------------------------------------------ shutdown

@@ -31,21 +31,15 @@ def main():
     for k in range(reps):
         x = xs[k & 1]
         t = [pc()]
-        same = lib.pk_same_bits(x.ctypes.data, hs.h_x.ctypes.data, hs.plan.n)
+        same = hs._is_prepared(x)
         t.append(pc())                                   # 0 compare
         hs.h_x[:] = x
         t.append(pc())                                   # 1 x into the segment
         seq = hs._post(CMD_X)
-        hs._runs(hs.tab_xin, hs._dev("x"), hs.d_x)
-        t.append(pc())                                   # 2 enqueue x copy
-        hs.chk(lib.pk_eval_xpart_dev(h, hs.d_x, hs.d_f, hs.d_out["grad"], hs.d_out["g"], hs.d_out["J"], None))
-        t.append(pc())                                   # 3 enqueue xpart
-        hs._runs(hs.tab_x_changing, hs.d_full, hs._dev("out"))
-        hs._runs(hs.tab_sh, hs.d_out["grad"], hs.d_small)
-        hs._runs(hs.tab_part, hs.d_small, hs._dev("part"))
-        t.append(pc())                                   # 4 enqueue run copies
-        hs.chk(lib.pk_wait_idle(h, None))
-        t.append(pc())                                   # 5 wait
+        hs._do_x_part(seq)
+        t.append(pc())                                   # 2 enqueue the x-part
+        hs._wait_marks("early", seq)
+        t.append(pc())                                   # 3 wait: sums, grad f, g
         small = hs.h_part[0].copy()
         I = small[: hs.n_I]
         s = x[hs.plan.l_s: hs.plan.r_s]
@@ -53,20 +47,23 @@ def main():
         hs.h_f[0] = hs._F_o(*args) if hs._F_o is not None else hs._F_const
         hs.out["grad"][hs.shared] = small[hs.n_I:]
         hs._x_seq = seq
-        t.append(pc())                                   # 6 host sums, f
+        t.append(pc())                                   # 4 host sums, f
+        hs._is_prepared(x)
+        t.append(pc())                                   # 5 a same-x compare (gradient / constraints / jacobian each pay one)
+        hs._wait_marks("x", seq)
+        t.append(pc())                                   # 6 wait: J
         hs.h_lam[:] = lam
         hs.h_sigma[0] = sigma
         t.append(pc())                                   # 7 lambda into the segment
-        hs._post(CMD_HESS)
-        hs.chk(lib.pk_eval_hess_dev(h, hs.d_x, hs._dev("lam"), float(sigma), hs.d_out["H"], None))
-        hs._runs(hs.tab_h, hs.d_full, hs._dev("out"))
+        seq = hs._post(CMD_HESS)
+        hs._do_hess(seq)
         t.append(pc())                                   # 8 enqueue H
-        hs.chk(lib.pk_wait_idle(h, None))
+        hs._wait_marks("h", seq)
         t.append(pc())                                   # 9 wait H
         rows.append([t[i + 1] - t[i] for i in range(len(t) - 1)])
         assert not same
-    names = ["compare x", "x -> segment", "enqueue x run copy", "enqueue x-part", "enqueue run copies out", "wait",
-             "host sums + f", "lambda -> segment", "enqueue H + run copy", "wait H"]
+    names = ["compare x (differs)", "x -> segment", "enqueue x-part", "wait early mark", "host sums + f", "compare x (same)",
+             "wait J mark", "lambda -> segment", "enqueue H + run copy", "wait H mark"]
     tot = 0.0
     for i, nm in enumerate(names):
         v = statistics.median(r[i] for r in rows) * 1e6
@@ -75,7 +72,8 @@ def main():
     print(f"{'sum':28s} {tot:8.1f} us")
     batches = bench.timed_cycles(lambda k: bench.five_callbacks(hs, xs[k & 1], lam, sigma), 20, 5)
     print(f"five callbacks through hostshard (1 rank): {statistics.median(batches) / 20 * 1e6:.1f} us per cycle")
-    n_tab = [("tab_x", hs.tab_x[1]), ("tab_x_changing", hs.tab_x_changing[1]), ("tab_h", hs.tab_h[1]), ("tab_xin", hs.tab_xin[1])]
+    n_tab = [("tab_early", hs.tab_early[1]), ("tab_j", hs.tab_j[1]), ("tab_j_changing", hs.tab_j_changing[1]), ("tab_h", hs.tab_h[1]),
+             ("tab_xin", hs.tab_xin[1])]
     print("run-table chunks:", n_tab)
     hs.close()
     system2, _, guess2 = bench.build_workload("planar_quadrotor", intervals, radau)
