@@ -290,6 +290,32 @@ def test_model_nonlinear_in_the_integrals_on_intervals_with_more_than_64_points(
     close(Interp(small.plan, xs, ls, ss).hessian(), ref.hessian(xs, ls, ss), what="interpreter vs oracle H")
 
 
+def test_hessian_stored_into_the_landing_array_by_its_kernel_equals_the_copied_one():
+    """Host shim, small Hessians: pk_hess stores into the pinned landing array itself (host option "hess_direct", on by default up
+    to the copy-kernel threshold) instead of into device memory with a copy behind it.  The landing arrays are recycled and never
+    cleared: every entry must be written by the kernel, on every call -- checked with inputs that change from call to call."""
+    system, _, guess = models.planar_quadrotor(_ns("radau", "pockit_amd"), 150, 6)
+    x, lam, sigma = models.bench_inputs(system, guess)
+    ev = system.evaluator
+    lib, h = ev.ctx.lib, ev.ctx.handle
+    rng = np.random.default_rng(5)
+    inputs = [(x * (1 + 1e-3 * rng.standard_normal(x.size)), lam * rng.standard_normal(lam.size), float(rng.uniform(0.5, 2))) for _ in range(4)]
+    got = {}
+    for direct in (1, 0, 1):
+        ev.ctx.check(lib.pk_set_host_option(h, b"hess_direct", direct))
+        for k, (xk, lk, sk) in enumerate(inputs):
+            system.objective(xk)
+            H = np.array(system.hessian(xk, lk, sk))
+            assert np.all(np.isfinite(H))
+            if (k, ) in got:
+                assert np.array_equal(H, got[(k, )]), f"hess_direct={direct}, input {k}"
+            got[(k, )] = H
+    ref, _, _ = models.planar_quadrotor(_ns("radau", "oracle"), 150, 6)
+    xk, lk, sk = inputs[2]
+    close(got[(2, )], ref.hessian(xk, lk, sk), what="H")
+    ev.ctx.check(lib.pk_set_host_option(h, b"hess_direct", 1))
+
+
 def test_prepared_x_cache_is_dropped_by_calls_that_reuse_the_context_buffers():
     """objective / gradient / constraints / jacobian / hessian on x1 serve from ONE upload of x1; any other entry
     point that uploads a different x (mesh error, the one-launch cycle, the *_direct and CSR calls) in between must
