@@ -171,6 +171,10 @@ class HostShardedEvaluator:
                     out.append((cur, b))
             return out
 
+        # every rank's Hessian kernel writes only the entries of its own tiles (rank 0: also the boundary / system items), at
+        # the reference positions: a share of at most 8 MiB is stored straight into the segment (as the single-GPU shim does)
+        self.h_direct = 8 * sum(b - a for a, b in rh) <= (8 << 20) and os.environ.get("POCKIT_AMD_HOSTSHARD_H_DIRECT", "1") != "0"
+        self._h_host = C.c_void_p(self._dev_base.value + 8 * (off["out"] + split))
         self.tab_j_changing = table(minus(rj, const)) if const else self.tab_j
         self._x_filled = False
         word = lambda i: C.c_void_p(self._dev_base.value + 8 * int(i))  # noqa: E731
@@ -228,8 +232,11 @@ class HostShardedEvaluator:
         lib, h, chk = self.lib, self.h, self.chk
         # the Hessian kernel reads the multipliers from the (page-locked) segment itself: every rank then moves only the rows
         # of ITS tiles over its link, and there is no upload in front of the kernel
-        chk(lib.pk_eval_hess_dev(h, self.d_x, self._dev("lam"), float(self.h_sigma[0]), self.d_out["H"], None))
-        self._runs(self.tab_h, self.d_full, self._dev("out"))
+        if self.h_direct:      # a small share of H: the kernel's own stores go over the link (no copy launch behind it)
+            chk(lib.pk_eval_hess_dev(h, self.d_x, self._dev("lam"), float(self.h_sigma[0]), self._h_host, None))
+        else:
+            chk(lib.pk_eval_hess_dev(h, self.d_x, self._dev("lam"), float(self.h_sigma[0]), self.d_out["H"], None))
+            self._runs(self.tab_h, self.d_full, self._dev("out"))
         chk(lib.pk_store_word_dev(h, self._mark_dev["h"], seq, None))
 
     def _wait_marks(self, which, seq):
