@@ -171,6 +171,13 @@ struct pk_ctx {
   // reuse guard of the staging buffers without events: every enqueue takes a sequence number; an idle stream seen by the host
   // (wait_result) retires all numbers issued so far
   uint64_t op_seq = 0, idle_seq = 0;
+  // mark_wait: behind the last result copy of a batch a one-word kernel stores a counter into pinned memory (h_out[0][4]) and
+  // the waiting callback polls that word instead of the stream's state (the runtime's query answers several microseconds
+  // after the word is there; the stream is still asked now and then, so a failed launch does not hang the caller)
+  int mark_wait = 1;
+  unsigned long long mark_val = 0;     // value of the last mark enqueued
+  uint64_t mark_op_seq = 0;            // op_seq when it was enqueued: everything up to it has finished once the mark is seen
+  bool mark_pending = false;           // the last thing enqueued for the results is a mark nobody has waited for yet
   uint64_t xs_seq[2] = {0, 0}, lams_seq[2] = {0, 0};
   hipEvent_t ev_early = nullptr;     // behind the grad f | g copy of the current iterate (split_copy)
   bool early_valid = false;
@@ -464,6 +471,45 @@ double* device_result(pk_ctx* c, int what) {
 // caller's) the pieces are merged: the changing part of J, grad f and g leave in one DMA.  The pieces of J that never
 // change (pk_set_jac_constant_runs) are not copied at all.  f needs no copy when the kernel stored it into its pinned
 // landing place itself (a DMA of 8 bytes costs as much as one of 100 KB).
+int enqueue_mark(pk_ctx* c) {
+  if (!c->mark_wait || !c->spin_wait || !c->h_out[0]) return 0;
+  unsigned long long* word = reinterpret_cast<unsigned long long*>(c->h_out[0] + 4);
+  const unsigned long long value = ++c->mark_val;      // (a copy: the launch takes its arguments by value, now)
+  c->mark_op_seq = c->op_seq;
+  hipStream_t st = c->stream;
+  hipLaunchKernelGGL(pk_store_word_kernel, dim3(1), dim3(64), 0, st, word, value);
+  PK_HIP(c, hipGetLastError());
+  c->mark_pending = true;
+  return 0;
+}
+
+// everything enqueued for the results has finished: the pending mark has been stored, or (no mark) the stream is idle
+int wait_results_landed(pk_ctx* c) {
+  hipError_t e;
+  if (c->mark_pending) {
+    const volatile unsigned long long* word = reinterpret_cast<const volatile unsigned long long*>(c->h_out[0] + 4);
+    const unsigned long long want = c->mark_val;
+    for (long spins = 1; *word < want; ++spins) {
+      if ((spins & 0x3FFF) == 0) {          // now and then: has the stream finished (or failed) without storing the mark?
+        e = hipStreamQuery(c->stream);
+        if (e == hipSuccess) {
+          if (*word < want) return fail(c, 65, "the progress mark was not stored by its kernel");
+          break;
+        }
+        if (e != hipErrorNotReady) return fail(c, 100 + (int)e, "waiting for the results: %s", hipGetErrorString(e));
+      }
+    }
+    c->mark_pending = false;
+    if (c->mark_op_seq > c->idle_seq) c->idle_seq = c->mark_op_seq;
+    return 0;
+  }
+  const uint64_t seen = c->op_seq;
+  while ((e = hipStreamQuery(c->stream)) == hipErrorNotReady) { }
+  if (e != hipSuccess) return fail(c, 100 + (int)e, "hipStreamQuery failed: %s", hipGetErrorString(e));
+  c->idle_seq = seen;
+  return 0;
+}
+
 int enqueue_result_copies(pk_ctx* c, unsigned mask) {
   struct Piece { const double* src; double* dst; size_t count; bool pinned; };
   std::vector<Piece> pcs;
@@ -510,6 +556,7 @@ int enqueue_result_copies(pk_ctx* c, unsigned mask) {
     }
   }
   ++c->op_seq;
+  if ((rc = enqueue_mark(c))) return rc;
   if (!c->spin_wait) PK_HIP(c, hipEventRecord(c->ev_out[first], c->stream));      // (see wait_result)
   for (int k = 0; k < 5; ++k)
     if (((mask >> k) & 1u) && !c->enq[k]) { c->enq[k] = true; c->ev_of[k] = first; }
@@ -550,10 +597,8 @@ int wait_result(pk_ctx* c, int k) {
       c->done[1] = c->done[2] = true;
       return 0;
     }
-    const uint64_t seen = c->op_seq;
-    while ((e = hipStreamQuery(c->stream)) == hipErrorNotReady) { }
-    if (e != hipSuccess) return fail(c, 100 + (int)e, "hipStreamQuery failed: %s", hipGetErrorString(e));
-    c->idle_seq = seen;
+    int rc = wait_results_landed(c);
+    if (rc) return rc;
     for (int j = 0; j < 5; ++j)
       if (c->enq[j]) c->done[j] = true;
     return 0;
@@ -779,6 +824,8 @@ int pk_set_problem(pk_ctx* c, const pk_problem_desc* pd) {
       PK_HIP(c, hipEventCreateWithFlags(&c->ev_lams[b], hipEventDisableTiming));
     }
     PK_HIP(c, hipHostMalloc((void**)&c->h_out[0], sizeof(double) * 8, hipHostMallocDefault));
+    std::memset(c->h_out[0], 0, sizeof(double) * 8);      // ([0] f, [4] the progress mark of mark_wait)
+    c->mark_val = 0; c->mark_op_seq = 0; c->mark_pending = false;
     PK_HIP(c, hipHostMalloc((void**)&c->h_out[3], sizeof(double) * (cnt[3] + cnt[1] + cnt[2] + 1), hipHostMallocDefault));
     PK_HIP(c, hipHostMalloc((void**)&c->h_out[4], sizeof(double) * (cnt[4] + 1), hipHostMallocDefault));
     c->h_out[1] = c->h_out[3] + cnt[3];                      // (one block [J | grad f | g], like the device's)
@@ -1654,10 +1701,9 @@ int pk_eval_hessc_prepared(pk_ctx* c, const double* lambda, double sigma, double
   }
   if ((rc = copy_async(c, dst, c->d_Hc, (size_t)c->nnz_Hc, hipMemcpyDeviceToHost, bytes <= ((size_t)c->kernel_download << 20)))) return rc;
   ++c->op_seq;
+  if ((rc = enqueue_mark(c))) return rc;
   if (c->spin_wait) {      // (every earlier copy of this iterate has been waited for by its callback)
-    hipError_t e;
-    while ((e = hipStreamQuery(c->stream)) == hipErrorNotReady) { }
-    if (e != hipSuccess) return fail(c, 100 + (int)e, "hipStreamQuery failed: %s", hipGetErrorString(e));
+    if ((rc = wait_results_landed(c))) return rc;
   } else {
     PK_HIP(c, hipStreamSynchronize(c->stream));
   }
@@ -1694,6 +1740,7 @@ int pk_callback_hess(pk_ctx* c, const double* x, const double* lambda, double si
       if ((rc = copy_async(c, hess, c->d_Hc, (size_t)c->nnz_Hc, hipMemcpyDeviceToHost,
                            sizeof(double) * (size_t)c->nnz_Hc <= ((size_t)c->kernel_download << 20)))) return rc;
       ++c->op_seq;
+      if ((rc = enqueue_mark(c))) return rc;
     } else {
       c->landed[4] = c->target[4] ? c->target[4] : c->h_out[4];
       c->enq[4] = c->done[4] = false;
@@ -1707,13 +1754,10 @@ int pk_callback_hess(pk_ctx* c, const double* x, const double* lambda, double si
     if (same) {
       c->lam_staged = false;
       if (!compact) return wait_result(c, 4);
-      hipError_t e;
-      while ((e = hipStreamQuery(c->stream)) == hipErrorNotReady) { }
-      if (e != hipSuccess) return fail(c, 100 + (int)e, "hipStreamQuery failed: %s", hipGetErrorString(e));
-      c->idle_seq = seen;
-      return 0;
+      return wait_results_landed(c);
     }
     PK_HIP(c, hipStreamSynchronize(c->stream));       // (the discarded launch must not write behind the one that follows)
+    c->mark_pending = false;
     c->idle_seq = seen;
     c->x_valid = false;
   }
@@ -1815,6 +1859,7 @@ int pk_set_host_option(pk_ctx* c, const char* name, int value) {
   else if (!std::strcmp(name, "split_copy")) c->split_copy = value != 0;
   else if (!std::strcmp(name, "speculative_hess")) c->speculative_hess = value != 0;
   else if (!std::strcmp(name, "hess_direct")) c->hess_direct = value != 0;
+  else if (!std::strcmp(name, "mark_wait")) { c->mark_wait = value != 0; c->mark_pending = false; }
   else return fail(c, 67, "pk_set_host_option: unknown option \"%s\"", name);
   return 0;
 }

@@ -119,23 +119,25 @@ int main() {
     for (size_t i = 0; i < blk_len; ++i) blocks.back()[i] = NAN;
     OK(pk_fill_jac_constants(ctx, blocks.back()));
   }
-  const char* options[] = {"spin_wait", "lambda_direct", "chunk_upload", "kernel_upload", "kernel_download", "split_copy", "speculative_hess"};
-  const int defaults[] = {1, 1, 1, 1, 8, 1, 1};
+  const char* options[] = {"spin_wait", "lambda_direct", "chunk_upload", "kernel_upload", "kernel_download", "split_copy", "speculative_hess",
+                           "mark_wait", "hess_direct"};
+  const int defaults[] = {1, 1, 1, 1, 8, 1, 1, 1, 1};
+  const int n_options = 9;
   std::vector<double> x = fresh(S.n), lam = fresh(S.m);
   double f = 0.0;
   int is_new = 0;
-  for (int it = 0; it < 40; ++it) {
+  for (int it = 0; it < 64; ++it) {
     if (it % 3 == 0) {                                          // walk through every switch, one at a time off its default
-      for (int o = 0; o < 7; ++o) OK(pk_set_host_option(ctx, options[o], defaults[o]));
-      const int o = (it / 3) % 8;
-      if (o < 7) OK(pk_set_host_option(ctx, options[o], defaults[o] ? 0 : 1));
+      for (int o = 0; o < n_options; ++o) OK(pk_set_host_option(ctx, options[o], defaults[o]));
+      const int o = (it / 3) % (n_options + 1);
+      if (o < n_options) OK(pk_set_host_option(ctx, options[o], defaults[o] ? 0 : 1));
       OK(pk_set_host_mode(ctx, (it / 3) % 5 != 4, (it / 3) % 7 == 6));      // prefetch off / kernels storing into the targets now and then
     }
     x = fresh(S.n);
     const double sigma = U(rng);
     std::memset(g_where, ' ', 100);
     g_where[100] = 0;
-    std::snprintf(g_where, 100, "iterate %d, switch %d off default, prefetch %d, host_direct %d", it, (it / 3) % 8,
+    std::snprintf(g_where, 100, "iterate %d, switch %d off default, prefetch %d, host_direct %d", it, (it / 3) % (n_options + 1),
                   (it / 3) % 5 != 4, (it / 3) % 7 == 6);
     g_where[std::strlen(g_where)] = ' ';
     double* blk = blocks[(size_t)(it % 3)];
@@ -169,7 +171,7 @@ int main() {
     OK(pk_result_location(ctx, 4, &own));
     check_hess(x, lam, 0.5 * sigma, own, false);
   }
-  for (int o = 0; o < 7; ++o) OK(pk_set_host_option(ctx, options[o], defaults[o]));
+  for (int o = 0; o < n_options; ++o) OK(pk_set_host_option(ctx, options[o], defaults[o]));
   OK(pk_set_host_mode(ctx, 1, 0));
   CHECK(pk_set_host_option(ctx, "no such switch", 1) != 0);
 

@@ -11,6 +11,7 @@
 #include <cstdint>
 #include <cstring>
 #include <functional>
+#include <tuple>
 
 typedef int hipError_t;
 enum { hipSuccess = 0, hipErrorInvalidValue = 1, hipErrorNotReady = 600, hipErrorNotSupported = 801 };
@@ -109,6 +110,7 @@ void fake_hip_enqueue(hipStream_t s, std::function<void()> fn);
 #define hipLaunchKernelGGL(kernel, grid, block, shmem, stream, ...)                                     \
   do {                                                                                                  \
     const dim3 g_ = (grid), b_ = (block);                                                               \
+    auto args_ = std::make_tuple(__VA_ARGS__); /* by value, NOW: as a real launch takes them */          \
     fake_hip_enqueue((stream), [=]() {                                                                  \
       gridDim = g_;                                                                                     \
       blockDim = b_;                                                                                    \
@@ -116,7 +118,7 @@ void fake_hip_enqueue(hipStream_t s, std::function<void()> fn);
         for (unsigned tx_ = 0; tx_ < b_.x; ++tx_) {                                                     \
           blockIdx = dim3(bx_, 0, 0);                                                                   \
           threadIdx = dim3(tx_, 0, 0);                                                                  \
-          kernel(__VA_ARGS__);                                                                          \
+          std::apply(kernel, args_);                                                                    \
         }                                                                                               \
     });                                                                                                 \
   } while (0)
