@@ -547,8 +547,10 @@ int enqueue_result_copies(pk_ctx* c, unsigned mask) {
   // an event behind grad f | g only when something (J) follows them in this batch: otherwise the stream's state tells
   const bool want_early = early && c->spin_wait && ((mask >> 3) & 1u) && !c->enq[3] && !c->stored_direct[3] && pcs.size() > early_pieces;
   int rc;
+  bool any_dma = false;
   for (size_t i = 0; i < pcs.size(); ++i) {
     const bool by_kernel = pcs[i].pinned && sizeof(double) * pcs[i].count <= ((size_t)c->kernel_download << 20);
+    any_dma |= !by_kernel || (((uintptr_t)pcs[i].dst ^ (uintptr_t)pcs[i].src) & 8) != 0;
     if ((rc = copy_async(c, pcs[i].dst, pcs[i].src, pcs[i].count, hipMemcpyDeviceToHost, by_kernel))) return rc;
     if (want_early && i + 1 == early_pieces) {
       PK_HIP(c, hipEventRecord(c->ev_early, c->stream));
@@ -556,7 +558,9 @@ int enqueue_result_copies(pk_ctx* c, unsigned mask) {
     }
   }
   ++c->op_seq;
-  if ((rc = enqueue_mark(c))) return rc;
+  // (a mark kernel behind a DMA would wait for the hand-off between the two engines, ~10 us: large copies keep the stream poll)
+  c->mark_pending = false;
+  if (!any_dma && (rc = enqueue_mark(c))) return rc;
   if (!c->spin_wait) PK_HIP(c, hipEventRecord(c->ev_out[first], c->stream));      // (see wait_result)
   for (int k = 0; k < 5; ++k)
     if (((mask >> k) & 1u) && !c->enq[k]) { c->enq[k] = true; c->ev_of[k] = first; }
@@ -1699,9 +1703,11 @@ int pk_eval_hessc_prepared(pk_ctx* c, const double* lambda, double sigma, double
     if (!c->h_Hc) PK_HIP(c, hipHostMalloc((void**)&c->h_Hc, bytes, hipHostMallocDefault));
     dst = c->h_Hc;
   }
-  if ((rc = copy_async(c, dst, c->d_Hc, (size_t)c->nnz_Hc, hipMemcpyDeviceToHost, bytes <= ((size_t)c->kernel_download << 20)))) return rc;
+  const bool hc_by_kernel = bytes <= ((size_t)c->kernel_download << 20) && !(((uintptr_t)dst ^ (uintptr_t)c->d_Hc) & 8);
+  if ((rc = copy_async(c, dst, c->d_Hc, (size_t)c->nnz_Hc, hipMemcpyDeviceToHost, hc_by_kernel))) return rc;
   ++c->op_seq;
-  if ((rc = enqueue_mark(c))) return rc;
+  c->mark_pending = false;
+  if (hc_by_kernel && (rc = enqueue_mark(c))) return rc;
   if (c->spin_wait) {      // (every earlier copy of this iterate has been waited for by its callback)
     if ((rc = wait_results_landed(c))) return rc;
   } else {
@@ -1737,10 +1743,11 @@ int pk_callback_hess(pk_ctx* c, const double* x, const double* lambda, double si
     const size_t bytes = sizeof(double) * (size_t)c->nnz_Hc;
     if (compact) {
       if ((rc = pk_eval_hessc_dev(c, c->d_x, c->lam_src, sigma, c->d_Hc, nullptr))) return rc;
-      if ((rc = copy_async(c, hess, c->d_Hc, (size_t)c->nnz_Hc, hipMemcpyDeviceToHost,
-                           sizeof(double) * (size_t)c->nnz_Hc <= ((size_t)c->kernel_download << 20)))) return rc;
+      const bool hc_by_kernel = bytes <= ((size_t)c->kernel_download << 20) && !(((uintptr_t)hess ^ (uintptr_t)c->d_Hc) & 8);
+      if ((rc = copy_async(c, hess, c->d_Hc, (size_t)c->nnz_Hc, hipMemcpyDeviceToHost, hc_by_kernel))) return rc;
       ++c->op_seq;
-      if ((rc = enqueue_mark(c))) return rc;
+      c->mark_pending = false;
+      if (hc_by_kernel && (rc = enqueue_mark(c))) return rc;
     } else {
       c->landed[4] = c->target[4] ? c->target[4] : c->h_out[4];
       c->enq[4] = c->done[4] = false;
@@ -1748,7 +1755,6 @@ int pk_callback_hess(pk_ctx* c, const double* x, const double* lambda, double si
       if ((rc = pk_eval_hess_dev(c, c->d_x, c->lam_src, sigma, c->stored_direct[4] ? c->landed[4] : c->d_H, nullptr))) return rc;
       if ((rc = enqueue_result_copies(c, 1u << 4))) return rc;
     }
-    (void)bytes;
     const bool same = std::memcmp(c->h_x, x, sizeof(double) * (size_t)c->n) == 0;
     const uint64_t seen = c->op_seq;
     if (same) {
