@@ -173,6 +173,12 @@ int pk_set_result_targets(pk_ctx* ctx, double* f, double* grad, double* g, doubl
 int pk_callback_x(pk_ctx* ctx, int what, const double* x, double* block, double* f_out, int* fresh);
 int pk_callback_hess(pk_ctx* ctx, const double* x, const double* lambda, double sigma, double* block, double* hess,
                      int compact, int* fresh);
+/* all five results of one iterate in ONE call and ONE launch, for a caller that has the multipliers together with x
+ * (Evaluator.cycle; SystemBase's five callbacks evaluated at once): same staging and landing as the two callbacks above --
+ * `block` = [J | grad f | g] pinned with its constant entries filled in, `hess` = nnz_H pinned values -- returns when
+ * everything has landed; the iterate is then the prepared one (pk_callback_x on the same x is served from the block). */
+int pk_callback_cycle(pk_ctx* ctx, const double* x, const double* lambda, double sigma, double* block, double* hess,
+                      double* f_out);
 int pk_set_jac_constant_runs(pk_ctx* ctx, int n_runs, const int64_t* start, const int64_t* stop);
 int pk_fill_jac_constants(pk_ctx* ctx, double* jac /* nnz_J */);
 int pk_set_host_option(pk_ctx* ctx, const char* name, int value);

@@ -1652,6 +1652,47 @@ int pk_callback_x(pk_ctx* c, int what, const double* x, double* block, double* f
   return 0;
 }
 
+// ONE call for all five results of an iterate whose multipliers are known together with x (a solver written against the C
+// ABI; Evaluator.cycle): x and lambda are staged like in the callbacks, the whole cycle is ONE launch (pk_cycle), the results
+// land like the callbacks' -- [J (changing part) | grad f | g] in `block` (pinned, [J | grad f | g], constants filled in by
+// pk_fill_jac_constants), H in `hess` (pinned), f in the context's pinned word -- and the call returns when all of it is
+// there.  Reference layout of the Jacobian only.
+int pk_callback_cycle(pk_ctx* c, const double* x, const double* lambda, double sigma, double* block, double* hess, double* f_out) {
+  int rc = ready(c);
+  if (rc) return rc;
+  if (!x || !lambda || !block || !hess) return fail(c, 60, "null host buffer");
+  if (c->jac_compact) return fail(c, 68, "pk_callback_cycle: the one-launch cycle writes the reference layout of the Jacobian");
+  PK_HIP(c, hipSetDevice(c->device));
+  c->x_valid = false;
+  if ((rc = stage_lambda(c, lambda))) return rc;
+  c->target[0] = nullptr;
+  take_block(c, block);
+  c->target[4] = hess;
+  c->target_visible[4] = !c->host_direct;
+  c->target_pinned[4] = true;
+  if ((rc = stage_upload(c, c->h_xs, c->ev_xs, c->xs_seq, c->xbuf, x, c->d_x, (size_t)c->n, &c->h_x))) return rc;
+  for (int k = 0; k < 5; ++k) {
+    c->landed[k] = c->target[k] ? c->target[k] : c->h_out[k];
+    c->enq[k] = c->done[k] = false;
+  }
+  c->jac_filled = !c->jconst.empty() && c->target_filled && !c->host_direct;
+  c->early_valid = false;
+  double* o[5];
+  for (int k = 0; k < 5; ++k) {
+    c->stored_direct[k] = k == 0 || (k == 4 && hess_goes_direct(c) && c->target_visible[4]);
+    o[k] = c->stored_direct[k] ? c->landed[k] : (k == 4 ? c->d_H : device_result(c, k));
+  }
+  *(volatile unsigned long long*)c->landed[0] = (unsigned long long)PK_EMPTY;
+  if ((rc = pk_eval_cycle_dev(c, c->d_x, c->lam_src, sigma, o[0], o[1], o[2], o[3], o[4], nullptr))) return rc;
+  c->lam_staged = false;
+  if ((rc = enqueue_result_copies(c, 0x1Fu))) return rc;
+  c->x_valid = true;
+  if ((rc = wait_result(c, 4)) || (rc = wait_result(c, 3)) || (rc = wait_result(c, 0))) return rc;
+  c->done[1] = c->done[2] = true;
+  if (f_out) *f_out = c->landed[0][0];
+  return 0;
+}
+
 // Queue the upload of the multipliers of the next pk_eval_hess_prepared and return: the caller's check of x
 // (pk_same_x, a pass over n doubles) then runs while the DMA is in flight.
 int pk_stage_lambda(pk_ctx* c, const double* lambda) {

@@ -622,25 +622,28 @@ class Evaluator:
                                                       stream))
 
     def cycle(self, x, lagrange, obj_factor):
-        """All five outputs on the same x from the single-launch cycle (pk_cycle): returns (f, grad, g, J, H)."""
+        """All five outputs on the same x from ONE call and ONE launch (pk_cycle): returns (f, grad, g, J, H).  Staging and
+        landing are the callbacks' (pk_callback_cycle): x and lambda through the pinned staging buffers, [J | grad f | g] into a
+        landing block whose x-independent entries are already there, H into a pinned array of the Hessian ring.  Afterwards
+        the iterate is the prepared one: the callbacks on the same x are served from what has landed."""
         x = self._x(x)
-        self._invalidate_x()        # the context's x / result buffers are about to hold another iterate
-        lam = np.ascontiguousarray(lagrange, dtype=np.float64)
+        lam = self._lam(lagrange)
         p = self.plan
-        # pinned arrays of the caller's own (the block set aside for the next iterate of the callbacks, if there is one)
-        if self._jac_compact:       # (the one-call cycle writes the reference layout)
-            blk = self._blocks_ref.take_item()
-        else:
-            blk = self._next if self._next is not None else self._blocks.take_item()
-            self._next = None
-        hit = self._ring_h.take_item()
-        if blk is not None:
-            root = blk.root
-            J, grad, g = root[: p.nnz_J], root[p.nnz_J: p.nnz_J + p.n], root[p.nnz_J + p.n: p.nnz_J + p.n + p.m]
-            blk.ready = True        # (this call writes the whole Jacobian, constant entries included)
-        else:
-            J, grad, g = np.empty(p.nnz_J), np.empty(p.n), np.empty(p.m)
-        H = hit.array if hit is not None else np.empty(p.nnz_H)
+        it = None if self._jac_compact else self._next_block()      # (the one-launch cycle writes the reference layout)
+        hit = None if self.zero_copy else self._ring_h.take_item()
+        if it is not None and hit is not None:
+            rc = self.ctx.lib.pk_callback_cycle(self.ctx.handle, x.ctypes.data, lam.ctypes.data, float(obj_factor), it.address,
+                                                hit.address, self._a_f)
+            if rc:
+                self.ctx.check(rc)
+            self._became_current(it)
+            v = self._cur_views
+            self._handed = {1, 2, 3}
+            return np.float64(self._c_f.value), v[1], v[2], v[3], hit.array
+        # no landing block to be had (zero-copy mode, the caller holds on to every block, compact Jacobian layout): plain
+        # arrays, one copy per output
+        self._invalidate_x()        # the context's x / result buffers are about to hold another iterate
+        J, grad, g, H = np.empty(p.nnz_J), np.empty(p.n), np.empty(p.m), np.empty(p.nnz_H)
         f = np.empty(1)
         dp = runtime.as_dp
         self.ctx.check(self.ctx.lib.pk_eval_cycle(self.ctx.handle, dp(x), dp(lam), float(obj_factor), dp(f), dp(grad),

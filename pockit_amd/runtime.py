@@ -68,7 +68,7 @@ EXPORTS = ["pk_create", "pk_destroy", "pk_last_error", "pk_device_count", "pk_lo
            "pk_get_structure", "pk_eval_f", "pk_eval_grad", "pk_eval_g", "pk_eval_jac", "pk_eval_hess",
            "pk_eval_f_dev", "pk_eval_grad_dev", "pk_eval_g_dev", "pk_eval_jac_dev", "pk_eval_hess_dev",
            "pk_eval_cycle_dev", "pk_eval_cycle_dev_repeat", "pk_eval_hessc_prepared", "pk_sync", "pk_profile", "pk_profile_read", "pk_kernel_name",
-           "pk_set_shard", "pk_eval_integrals_dev", "pk_eval_f_from_integrals_dev", "pk_aux_buffer", "pk_eval_outer_dev", "pk_store_word_dev", "pk_eval_cycle",
+           "pk_set_shard", "pk_eval_integrals_dev", "pk_eval_f_from_integrals_dev", "pk_aux_buffer", "pk_eval_outer_dev", "pk_store_word_dev", "pk_callback_cycle", "pk_eval_cycle",
            "pk_prepare_x", "pk_fetch", "pk_eval_hess_prepared", "pk_host_buffer", "pk_eval_hessc", "pk_eval_hessc_dev",
            "pk_set_mesh_error_tables", "pk_eval_mesh_error", "pk_eval_mesh_error_dev", "pk_set_cycle_graph", "pk_profile_sampling",
            "pk_set_csr_map", "pk_gather_csr_dev", "pk_eval_jac_csr_dev", "pk_eval_hess_csr_dev", "pk_eval_jac_csr",
@@ -162,6 +162,7 @@ def load_library():
     # (raw addresses on the per-callback entry points: building a typed pointer costs more than the call)
     lib.pk_callback_x.argtypes = [vp, C.c_int, vp, vp, vp, vp]
     lib.pk_callback_hess.argtypes = [vp, vp, vp, C.c_double, vp, vp, C.c_int, vp]
+    lib.pk_callback_cycle.argtypes = [vp, vp, vp, C.c_double, vp, vp, vp]
     lib.pk_set_jac_constant_runs.argtypes = [vp, C.c_int, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
     lib.pk_fill_jac_constants.argtypes = [vp, vp]
     lib.pk_set_host_option.argtypes = [vp, C.c_char_p, C.c_int]

@@ -175,6 +175,35 @@ int main() {
   OK(pk_set_host_mode(ctx, 1, 0));
   CHECK(pk_set_host_option(ctx, "no such switch", 1) != 0);
 
+  // ---- all five results from one call (pk_callback_cycle): lands like the callbacks, the iterate becomes the prepared one
+  for (int it = 0; it < 12; ++it) {
+    if (it % 4 == 0) {
+      OK(pk_set_host_option(ctx, "mark_wait", it % 8 == 0));
+      OK(pk_set_host_option(ctx, "hess_direct", it % 3 != 0));
+      OK(pk_set_host_option(ctx, "lambda_direct", it != 4));
+    }
+    x = fresh(S.n);
+    lam = fresh(S.m);
+    const double sigma = U(rng);
+    std::snprintf(g_where, 100, "one-call cycle %d", it);
+    double* blk = blocks[(size_t)(it % 3)];
+    double* hb = hblocks[(size_t)(it % 3)];
+    for (int64_t p = 0; p < S.nnz_H; ++p) hb[p] = NAN;
+    f = NAN;
+    OK(pk_callback_cycle(ctx, x.data(), lam.data(), sigma, blk, hb, &f));
+    check_x_results(x, &f, blk + S.nnz_J, blk + S.nnz_J + S.n, blk, false);
+    check_hess(x, lam, sigma, hb, false);
+    OK(pk_callback_x(ctx, 3, x.data(), blocks[(size_t)((it + 1) % 3)], &f, &is_new));      // same x: served from what has landed
+    CHECK(is_new == 0);
+    lam = fresh(S.m);
+    OK(pk_callback_hess(ctx, x.data(), lam.data(), sigma, blocks[(size_t)((it + 1) % 3)], hb, 0, &is_new));
+    CHECK(is_new == 0);
+    check_hess(x, lam, sigma, hb, false);
+    check_x_results(x, nullptr, blk + S.nnz_J, blk + S.nnz_J + S.n, blk, false);
+  }
+  CHECK(pk_callback_cycle(ctx, x.data(), lam.data(), 1.0, nullptr, hblocks[0], &f) != 0);
+  for (int o = 0; o < n_options; ++o) OK(pk_set_host_option(ctx, options[o], defaults[o]));
+
   // ---- a C-ABI caller's plain arrays as targets: the whole Jacobian is copied, nothing assumed about them
   {
     std::vector<double> tf(1, NAN), tg((size_t)S.n, NAN), tc((size_t)S.m, NAN), tj((size_t)S.nnz_J, NAN), th((size_t)S.nnz_H, NAN);
