@@ -29,7 +29,11 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <atomic>
+#include <chrono>
+#include <memory>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/pockit_hip.h"
@@ -1491,10 +1495,173 @@ int pk_same_x(pk_ctx* c, const double* x) {
   return std::memcmp(c->h_x, x, sizeof(double) * (size_t)c->n) == 0 ? 1 : 0;
 }
 
+}  // extern "C"
+
+// ---------------------------------------------------------------- helper threads for the host's passes over x and lambda
+// The solver's thread compares x with the prepared iterate in every callback and copies x / lambda into staging memory: one
+// pass over n doubles each (14 us per 0.77 MB).  For one GPU they hide behind the transfers; for the host-landed sharded
+// cycle at N times the size they are rank 0's serial part.  pk_host_threads(k) starts k helpers that
+// take slices of such a pass.  A helper is "hot" (spinning on its mailbox) for 1 ms after the pool was last used and only
+// hot helpers are given work -- the caller never waits for a thread to wake up; cold helpers look at an activity counter
+// every 20 us (no condition variable, nothing to miss).  The caller always takes a slice itself and finishes alone when
+// no helper is hot.  One caller at a time (the solver's thread).
+namespace {
+struct HostPool {
+  struct alignas(128) Box {
+    std::atomic<uint64_t> posted{0}, done{0};
+    std::atomic<int> hot{0};
+    int op = 0;                       // 0 compare, 1 copy
+    const char* a = nullptr;
+    char* b = nullptr;
+    size_t bytes = 0;
+    std::atomic<int> differs{0};
+  };
+  std::vector<std::unique_ptr<Box>> box;
+  std::vector<std::thread> th;
+  std::atomic<uint64_t> activity{0};
+  std::atomic<bool> stop{false};
+
+  static void relax() {
+#if defined(__x86_64__) || defined(__i386__)
+    __builtin_ia32_pause();
+#endif
+  }
+  void work(Box* bx) {
+    using clock = std::chrono::steady_clock;
+    uint64_t seen = 0, act = activity.load(std::memory_order_acquire);
+    auto hot_until = clock::now();
+    for (;;) {
+      const uint64_t p = bx->posted.load(std::memory_order_acquire);
+      if (p != seen) {
+        if (bx->op == 0) { if (std::memcmp(bx->a, bx->b, bx->bytes) != 0) bx->differs.store(1, std::memory_order_relaxed); }
+        else std::memcpy(bx->b, bx->a, bx->bytes);
+        seen = p;
+        bx->done.store(p, std::memory_order_release);
+        hot_until = clock::now() + std::chrono::milliseconds(1);
+        continue;
+      }
+      if (stop.load(std::memory_order_acquire)) return;
+      if (bx->hot.load(std::memory_order_relaxed)) {
+        for (int i = 0; i < 64; ++i) relax();
+        const uint64_t a2 = activity.load(std::memory_order_acquire);
+        if (a2 != act) { act = a2; hot_until = clock::now() + std::chrono::milliseconds(1); }
+        else if (clock::now() > hot_until) {
+          bx->hot.store(0, std::memory_order_seq_cst);       // (a job posted while this store was on its way is seen by the
+          continue;                                          //  next pass of the loop: posted is read first)
+        }
+      } else {
+        std::this_thread::sleep_for(std::chrono::microseconds(20));
+        const uint64_t a2 = activity.load(std::memory_order_acquire);
+        if (a2 != act) {
+          act = a2;
+          hot_until = clock::now() + std::chrono::milliseconds(1);
+          bx->hot.store(1, std::memory_order_seq_cst);
+        }
+      }
+    }
+  }
+  explicit HostPool(int k) {
+    for (int i = 0; i < k; ++i) box.emplace_back(new Box());
+    for (int i = 0; i < k; ++i) th.emplace_back([this, i]() { work(box[(size_t)i].get()); });
+  }
+  ~HostPool() {
+    stop.store(true, std::memory_order_release);
+    for (auto& t : th) t.join();
+  }
+  // op over [a, a + bytes) / [b, b + bytes); returns 1 if a compare found a difference.  While no helper is hot the caller
+  // works through the pass in 256 KB pieces itself (a cold helper needs up to 20 us to notice the activity); as soon as
+  // some are, what is left is cut into one slice each (whole 4 KB pages) and the caller takes the first.
+  int run(int op, const char* a, char* b, size_t bytes) {
+    activity.fetch_add(1, std::memory_order_release);
+    auto one = [op](const char* pa, char* pb, size_t len) -> int {
+      if (op == 0) return std::memcmp(pa, pb, len) != 0;
+      std::memcpy(pb, pa, len);
+      return 0;
+    };
+    size_t at = 0;
+    std::vector<Box*> use;
+    use.reserve(box.size());
+    while (at < bytes) {
+      use.clear();
+      for (auto& bx : box)
+        if (bx->hot.load(std::memory_order_seq_cst)) use.push_back(bx.get());
+      const size_t left = bytes - at;
+      if (use.empty() || left <= ((size_t)256 << 10)) {
+        const size_t len = left < ((size_t)256 << 10) ? left : ((size_t)256 << 10);
+        if (one(a + at, b + at, len)) return 1;
+        at += len;
+        continue;
+      }
+      const size_t parts = use.size() + 1;
+      const size_t slice = (left / parts + 4095) & ~(size_t)4095;
+      size_t pos = at + slice;                         // [at, at + slice) is the caller's
+      std::vector<std::pair<Box*, uint64_t>> waits;
+      waits.reserve(use.size());
+      for (Box* bx : use) {
+        if (pos >= bytes) break;
+        const size_t len = bytes - pos < slice ? bytes - pos : slice;
+        bx->op = op; bx->a = a + pos; bx->b = b + pos; bx->bytes = len;
+        bx->differs.store(0, std::memory_order_relaxed);
+        const uint64_t id = bx->posted.load(std::memory_order_relaxed) + 1;
+        bx->posted.store(id, std::memory_order_release);
+        waits.emplace_back(bx, id);
+        pos += len;
+      }
+      int differs = one(a + at, b + at, slice < left ? slice : left);
+      if (pos < bytes) differs |= one(a + pos, b + pos, bytes - pos);
+      for (auto& w : waits) {                          // (always: a helper must not be left reading the caller's arrays)
+        while (w.first->done.load(std::memory_order_acquire) != w.second) relax();
+        differs |= w.first->differs.load(std::memory_order_relaxed);
+      }
+      return differs;
+    }
+    return 0;
+  }
+};
+std::unique_ptr<HostPool> g_pool;
+constexpr size_t kPoolMinBytes = (size_t)1 << 20;     // shorter passes are done by the caller alone
+}  // namespace
+
+extern "C" {
+
+// k helper threads for the host's passes over x / lambda (0: none, the default; at most 16).  Process-wide; call it from
+// the thread that calls pk_same_bits / pk_copy_bits / the callbacks, while none of them is running.
+int pk_host_threads(int k) {
+  if (k < 0 || k > 16) return fail(nullptr, 69, "pk_host_threads: between 0 and 16 helper threads");
+  g_pool.reset();
+  if (k > 0) g_pool.reset(new HostPool(k));
+  return 0;
+}
+
+// how many helpers are spinning right now (diagnostics)
+int pk_host_threads_hot(void) {
+  int k = 0;
+  if (g_pool)
+    for (auto& bx : g_pool->box) k += bx->hot.load(std::memory_order_relaxed);
+  return k;
+}
+
 // 1 if the two arrays of n doubles are equal bit for bit (what decides "is this the iterate I already evaluated": one pass
 // at memcmp speed, no temporary -- numpy.array_equal builds a boolean array of n elements first)
 int pk_same_bits(const double* a, const double* b, size_t n) {
-  return (a && b && std::memcmp(a, b, sizeof(double) * n) == 0) ? 1 : 0;
+  if (!a || !b) return 0;
+  const size_t bytes = sizeof(double) * n;
+  // (iterates that differ usually differ at the front: look there before anybody else is asked to help)
+  const size_t head = bytes < 4096 ? bytes : 4096;
+  if (g_pool) g_pool->activity.fetch_add(1, std::memory_order_release);      // (a callback is running: helpers, get ready)
+  if (std::memcmp(a, b, head) != 0) return 0;
+  if (g_pool && bytes >= kPoolMinBytes)
+    return g_pool->run(0, (const char*)a + head, (char*)const_cast<double*>(b) + head, bytes - head) ? 0 : 1;
+  return std::memcmp((const char*)a + head, (const char*)b + head, bytes - head) == 0 ? 1 : 0;
+}
+
+// dst[0 .. n) = src[0 .. n) (non-overlapping), with the helper threads of pk_host_threads when the arrays are large
+int pk_copy_bits(double* dst, const double* src, size_t n) {
+  if (!dst || !src) return fail(nullptr, 60, "null host buffer");
+  const size_t bytes = sizeof(double) * n;
+  if (g_pool && bytes >= kPoolMinBytes) (void)g_pool->run(1, (const char*)src, (char*)dst, bytes);
+  else std::memcpy(dst, src, bytes);
+  return 0;
 }
 
 // the context's x / result buffers were used for something else (mesh error, one-shot evals, the cycle call)

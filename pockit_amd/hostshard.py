@@ -190,6 +190,9 @@ class HostShardedEvaluator:
         self.tab_part = self._upload_table(np.array([[0, rank * self.n_small, self.n_small]], dtype=np.int64))
         self._seq = 0
         self._x_seq = -1          # sequence number whose x-part results the segment holds
+        # rank 0's own passes over x and lambda (staging them into the segment, the bitwise compare of every callback) grow
+        # with the whole system, not with a rank's share: from 1 MB on they are cut into slices for a few helper threads
+        self.helper_threads = self._start_helpers(world) if rank == 0 else 0
         # f = F_o(I, s) on the host (rank 0): the objective as a function of the integrals and static parameters
         if rank == 0:
             syms = list(plan.I_syms) + list(plan.s_syms)
@@ -197,6 +200,41 @@ class HostShardedEvaluator:
             self._F_const = float(sp.sympify(plan.system._expr_objective)) if not syms else None
 
     # ------------------------------------------------------------------ helpers
+    def _start_helpers(self, world):
+        """Helper threads of the library for rank 0's passes over x / lambda (pk_host_threads): as many as this rank's share
+        of the host's cores allows (at most 6; POCKIT_AMD_HOST_THREADS=k overrides, 0 = none), kept only if a measured pass
+        over x is at least a quarter faster with them (a container whose CPUs are time slices of one core gains nothing)."""
+        n = self.plan.n
+        env = os.environ.get("POCKIT_AMD_HOST_THREADS", "auto")
+        if 8 * n < (1 << 20) or env == "0":
+            return 0
+        cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+        k = int(env) if env.isdigit() else max(0, min(6, cores // max(world, 1) - 2))
+        if k < 1:
+            return 0
+        lib = self.lib
+        mine = np.array(self.h_x)
+        a, b = mine.ctypes.data, self.h_x.ctypes.data
+
+        def pass_us():
+            lib.pk_same_bits(a, b, n)
+            ts = []
+            for _ in range(9):
+                t = time.perf_counter()
+                lib.pk_same_bits(a, b, n)
+                ts.append(time.perf_counter() - t)
+            return sorted(ts)[len(ts) // 2]
+
+        lib.pk_host_threads(0)
+        alone = pass_us()
+        if lib.pk_host_threads(k):
+            return 0
+        helped = pass_us()
+        if helped > 0.75 * alone:
+            lib.pk_host_threads(0)
+            return 0
+        return k
+
     def _upload_table(self, t):
         t = np.ascontiguousarray(t, dtype=np.int64)
         p = C.c_void_p()
@@ -342,7 +380,7 @@ class HostShardedEvaluator:
         x = self._as_x(x)
         if self._is_prepared(x):
             return
-        self.h_x[:] = x
+        self.lib.pk_copy_bits(self.h_x.ctypes.data, x.ctypes.data, self.plan.n)
         seq = self._post(CMD_X)
         self._do_x_part(seq)
         self._wait_marks("early", seq)
@@ -385,7 +423,7 @@ class HostShardedEvaluator:
         if lam.shape != (self.plan.m,):
             raise ValueError(f"lagrange must have shape ({self.plan.m},)")
         x = self._as_x(x)
-        self.h_lam[:] = lam
+        self.lib.pk_copy_bits(self.h_lam.ctypes.data, lam.ctypes.data, self.plan.m)
         self.h_sigma[0] = float(obj_factor)
         if self._x_seq >= 0:
             # a solver asks for H at the x it has just evaluated: launch on the prepared x BEFORE comparing (the compare of
@@ -415,6 +453,9 @@ class HostShardedEvaluator:
             except RuntimeError:
                 pass
         lib, h = self.lib, self.h
+        if getattr(self, "helper_threads", 0):
+            lib.pk_host_threads(0)
+            self.helper_threads = 0
         if h:
             lib.pk_sync(h, None)
             if getattr(self, "_registered", False):

@@ -24,6 +24,7 @@ def main():
     xs, lam, sigma = bench.solver_inputs(system, guess)
     hs = HostShardedEvaluator(system.plan, 0, 1, None, device=0)
     lib, h = hs.lib, hs.h
+    print(f"n = {hs.plan.n}, helper threads of rank 0: {hs.helper_threads}")
     pc = time.perf_counter
     for k in range(20):
         bench.five_callbacks(hs, xs[k & 1], lam, sigma)
@@ -33,7 +34,7 @@ def main():
         t = [pc()]
         same = hs._is_prepared(x)
         t.append(pc())                                   # 0 compare
-        hs.h_x[:] = x
+        lib.pk_copy_bits(hs.h_x.ctypes.data, x.ctypes.data, hs.plan.n)
         t.append(pc())                                   # 1 x into the segment
         seq = hs._post(CMD_X)
         hs._do_x_part(seq)
@@ -52,7 +53,7 @@ def main():
         t.append(pc())                                   # 5 a same-x compare (gradient / constraints / jacobian each pay one)
         hs._wait_marks("x", seq)
         t.append(pc())                                   # 6 wait: J
-        hs.h_lam[:] = lam
+        lib.pk_copy_bits(hs.h_lam.ctypes.data, lam.ctypes.data, hs.plan.m)
         hs.h_sigma[0] = sigma
         t.append(pc())                                   # 7 lambda into the segment
         seq = hs._post(CMD_HESS)
