@@ -1492,7 +1492,7 @@ int pk_eval_cycle(pk_ctx* c, const double* x, const double* lambda, double sigma
 // 1 if x equals the x of the last pk_prepare_x bit for bit (the results held for it are still valid), else 0
 int pk_same_x(pk_ctx* c, const double* x) {
   if (!c || !c->have_problem || !x || !c->x_valid || !c->h_x) return 0;
-  return std::memcmp(c->h_x, x, sizeof(double) * (size_t)c->n) == 0 ? 1 : 0;
+  return pk_same_bits(c->h_x, x, (size_t)c->n);      // (with the helper threads of pk_host_threads, if the caller started any)
 }
 
 }  // extern "C"
@@ -1963,7 +1963,7 @@ int pk_callback_hess(pk_ctx* c, const double* x, const double* lambda, double si
       if ((rc = pk_eval_hess_dev(c, c->d_x, c->lam_src, sigma, c->stored_direct[4] ? c->landed[4] : c->d_H, nullptr))) return rc;
       if ((rc = enqueue_result_copies(c, 1u << 4))) return rc;
     }
-    const bool same = std::memcmp(c->h_x, x, sizeof(double) * (size_t)c->n) == 0;
+    const bool same = pk_same_bits(c->h_x, x, (size_t)c->n) != 0;
     const uint64_t seen = c->op_seq;
     if (same) {
       c->lam_staged = false;
