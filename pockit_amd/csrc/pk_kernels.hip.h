@@ -2241,7 +2241,7 @@ __device__ __forceinline__ void kernel_cycle(const PkTile* pre_tile, int pre_n_t
     if (A.trace != nullptr && threadIdx.x == 0) A.trace[(size_t)rec * 16 + 14] = __builtin_readcyclecounter();
 #endif
     if (blockIdx.x == 0) edge_block<Gen>(A, 0, true, A.items, A.n_items);
-    else if (blockIdx.x == 1) edge_block<Gen>(A, 1, false, A.items2, A.n_items2);
+    else if (blockIdx.x == 1) { if (!(pre_flags & 128)) edge_block<Gen>(A, 1, false, A.items2, A.n_items2); }
     else fin_handoff<Gen>(A);
 #ifdef PK_TRACE
     __builtin_amdgcn_s_waitcnt(0);
@@ -2256,6 +2256,9 @@ __device__ __forceinline__ void kernel_cycle(const PkTile* pre_tile, int pre_n_t
   const bool split = (pre_flags & 32) != 0;
   const int blk = split ? slot / 3 : slot >> 1;       // the tile block; its workgroups follow each other in dispatch order
   const int sub = slot - blk * (split ? 3 : 2);       // split: 0 Jacobian, 1 values, 2 Hessian; else 0 x-part, 1 Hessian
+  // (bit 7 of the flags: an x-only launch -- f, grad f, g, J of a new iterate whose multipliers are not known yet, the host
+  //  shim's pk_prepare_x; the Hessian workgroups of the grid leave at once)
+  if ((pre_flags & 128) && sub == (split ? 2 : 1)) return;
   PK_TILE_PROLOGUE_FROM(pre_tile, pre_n_tiles);
   PK_KA_COLLECT();
 #undef PK_KA_COLLECT

@@ -45,7 +45,7 @@ enum { K_INT = 0, K_FIN, K_G, K_GRAD, K_JAC, K_HESS, K_XALL, K_AUX, K_OUTER, K_H
 const char* const kKernelNames[K_COUNT] = {"pk_int", "pk_fin", "pk_g", "pk_grad", "pk_jac", "pk_hess", "pk_xall",
                                            "pk_aux", "pk_outer", "pk_hessc", "pk_err", "pk_csr", "pk_cycle", "pk_xchg", "pk_runs",
                                            "pk_jacc"};
-enum { F_WRITE_F = 1, F_SECONDARY = 2, F_FIN_INT = 8, F_FIN_GRAD = 16, F_SPLIT = 32, F_XCHG = 64 };
+enum { F_WRITE_F = 1, F_SECONDARY = 2, F_FIN_INT = 8, F_FIN_GRAD = 16, F_SPLIT = 32, F_XCHG = 64, F_NO_HESS = 128 };
 
 thread_local std::string g_create_error;
 
@@ -166,6 +166,7 @@ struct pk_ctx {
   int split_copy = 1;          // grad f | g leave in a copy of their own in front of J (+1 DMA), with an event behind it: the
                                // gradient and constraints callbacks return while J is still on the link, and the bitwise
                                // compares of x they and the Jacobian callback start with are hidden behind that copy
+  int xpart_single = 1;        // pk_eval_xpart_dev as ONE launch (pk_cycle without its Hessian role) instead of pk_xall + pk_fin
   int hess_direct = 1;         // the Hessian kernel stores into the pinned landing place itself when H is small enough for the
                                // copy kernel (kernel_download): no launch behind it, its reads of lambda and its stores share
                                // the link in both directions (12k nodes: 97 -> 93 us; at 83 MB the copy is faster)
@@ -359,9 +360,11 @@ unsigned xall_blocks(const pk_ctx* c) { return (c->split_xall ? 2u : 1u) * tile_
 int xall_flags(const pk_ctx* c) { return c->split_xall ? F_SPLIT : 0; }
 
 // the cycle as ONE launch (pk_cycle): [edge J | edge H | finalize | tile slots: x block(s) + Hessian block per group]
+// (d_lam == NULL: the x-part alone -- the Hessian workgroups of the grid leave at once)
 int enqueue_single_launch_cycle(pk_ctx* c, const double* d_x, const double* d_lam, double sigma, double* d_f,
                                 double* d_grad, double* d_g, double* d_jac, double* d_hess, hipStream_t st) {
   PkArgs A = base_args(c, d_x, d_lam, sigma);
+  if (!d_lam) A.flags |= F_NO_HESS;
   A.o_f = d_f; A.o_grad = d_grad; A.o_g = d_g; A.o_jac = d_jac; A.o_hess = d_hess;
   A.items = (const PkItem*)c->d_items_jac;
   A.n_items = c->n_items_jac;
@@ -1387,6 +1390,10 @@ int pk_eval_xpart_dev(pk_ctx* c, const double* d_x, double* d_f, double* d_grad,
   // (a mesh with intervals of more than 64 points has the fused x-kernel only: the integrals it needs come from the
   //  integral prepass in front of it)
   if (needs_I && !c->external_prepass && (rc = prepass(c, d_x, nullptr, 0.0, d_f, true, st))) return rc;
+  // ONE launch instead of pk_xall + pk_fin: pk_cycle's grid without its Hessian role -- the partial sums reach the finalize
+  // workgroup inside the launch (host shim at 12k nodes: f is in pinned memory ~5 us earlier, and so is everything behind it)
+  if (c->xpart_single && c->cycle_mode == 1 && !needs_I && !c->shard_flags && !c->external_prepass && c->profile_mask == 0)
+    return enqueue_single_launch_cycle(c, d_x, nullptr, 0.0, d_f, d_grad, d_g, d_jac, nullptr, st);
   PkArgs A = base_args(c, d_x, nullptr, 0.0);
   A.o_f = d_f; A.o_grad = d_grad; A.o_g = d_g; A.o_jac = d_jac;
   A.items = (const PkItem*)c->d_items_jac;
@@ -2073,6 +2080,7 @@ int pk_set_host_option(pk_ctx* c, const char* name, int value) {
   else if (!std::strcmp(name, "split_copy")) c->split_copy = value != 0;
   else if (!std::strcmp(name, "speculative_hess")) c->speculative_hess = value != 0;
   else if (!std::strcmp(name, "hess_direct")) c->hess_direct = value != 0;
+  else if (!std::strcmp(name, "xpart_single")) c->xpart_single = value != 0;
   else if (!std::strcmp(name, "mark_wait")) { c->mark_wait = value != 0; c->mark_pending = false; }
   else return fail(c, 67, "pk_set_host_option: unknown option \"%s\"", name);
   return 0;

@@ -120,13 +120,13 @@ int main() {
     OK(pk_fill_jac_constants(ctx, blocks.back()));
   }
   const char* options[] = {"spin_wait", "lambda_direct", "chunk_upload", "kernel_upload", "kernel_download", "split_copy", "speculative_hess",
-                           "mark_wait", "hess_direct"};
-  const int defaults[] = {1, 1, 1, 1, 8, 1, 1, 1, 1};
-  const int n_options = 9;
+                           "mark_wait", "hess_direct", "xpart_single"};
+  const int defaults[] = {1, 1, 1, 1, 8, 1, 1, 1, 1, 1};
+  const int n_options = 10;
   std::vector<double> x = fresh(S.n), lam = fresh(S.m);
   double f = 0.0;
   int is_new = 0;
-  for (int it = 0; it < 64; ++it) {
+  for (int it = 0; it < 70; ++it) {
     if (it % 3 == 0) {                                          // walk through every switch, one at a time off its default
       for (int o = 0; o < n_options; ++o) OK(pk_set_host_option(ctx, options[o], defaults[o]));
       const int o = (it / 3) % (n_options + 1);
