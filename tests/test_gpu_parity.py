@@ -254,9 +254,8 @@ def test_intervals_with_more_points_than_a_wavefront_has_lanes(case, monkeypatch
 
 @pytest.mark.parametrize("scheme,kw", [("radau", dict(mesh=(0, 0.2, 0.5, 1), num_point=(3, 80, 4))),
                                        ("lobatto", dict(mesh=(0, 0.2, 0.5, 1), num_point=(3, 80, 4))),
-                                       ("radau", dict(mesh=(0, 0.4, 0.6, 1), num_point=(70, 5, 129))),
-                                       ("lobatto", dict(mesh=(0, 0.4, 0.6, 1), num_point=(70, 5, 129))),
-                                       ("lobatto", dict(mesh=(0, 0.5, 1), num_point=(290, 6)))])
+                                       ("radau", dict(mesh=(0, 0.4, 0.6, 1), num_point=(70, 5, 97))),
+                                       ("lobatto", dict(mesh=(0, 0.5, 1), num_point=(258, 3)))])
 def test_model_nonlinear_in_the_integrals_on_intervals_with_more_than_64_points(scheme, kw):
     """Objective and system constraints nonlinear in the integrals (outer-product Hessian blocks, easyderiv.py:323-459; the
     integrals are needed before every other kernel) on a mesh with workgroup-wide intervals: the integral prepass (pk_int)
