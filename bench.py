@@ -171,6 +171,27 @@ def pcie_floor(plan, shipped_J):
         out[name] = {"MB": 8 * count / 1e6, "us": us, "GBps": 8 * count / us / 1e3}
         total += us
     out["floor_us"] = total
+    # the wire alone: the cycle's bytes at the rate a 64 MB DMA reaches in each direction on this box (no per-transfer cost at
+    # all) -- a strict lower bound, whatever engine moves the bytes
+    big = 8 << 20
+    d = torch.zeros(big, dtype=torch.float64, device=dev)
+    hbuf = torch.zeros(big, dtype=torch.float64).pin_memory()
+    rate = {}
+    for name, (src, dst) in (("up", (hbuf, d)), ("down", (d, hbuf))):
+        for _ in range(2):
+            dst.copy_(src, non_blocking=True)
+        torch.cuda.synchronize()
+        ts = []
+        for _ in range(5):
+            t0 = time.perf_counter()
+            dst.copy_(src, non_blocking=True)
+            torch.cuda.synchronize()
+            ts.append(time.perf_counter() - t0)
+        rate[name] = 8 * big / min(ts) / 1e9
+    up = 8 * (sizes["x_up"] + sizes["lambda_up"])
+    down = 8 * (sizes["xpart_down"] + sizes["hess_down"])
+    out["wire"] = {"GBps_up_64MB": rate["up"], "GBps_down_64MB": rate["down"], "bytes_up": up, "bytes_down": down,
+                   "us": up / rate["up"] / 1e3 + down / rate["down"] / 1e3}
     return out
 
 
@@ -285,8 +306,12 @@ def end_to_end(system, guess, steps, warmup):
         floor = pcie_floor(p, p.nnz_J - kept)
         out["pcie"] = floor
         out["pcie_frac"] = floor["floor_us"] / (out["headline"]["ms_per_step"] * 1e3)
+        out["pcie_wire_frac"] = floor["wire"]["us"] / (out["headline"]["ms_per_step"] * 1e3)
         out["pcie_frac_note"] = ("floor = x up + [J (changing part) | grad f | g] down + lambda up + H down, each measured here as "
-                                 "ONE pinned DMA + synchronize; pcie_frac = floor / measured cycle")
+                                 "ONE pinned DMA + synchronize; pcie_frac = floor / measured cycle (the shim moves the bytes with copy kernels and "
+                                 "waits on a word its GPU stores: on a box whose DMA path is slow the ratio exceeds 1); pcie_wire_frac = "
+                                 "(bytes up / rate of a 64 MB DMA up + bytes down / rate of a 64 MB DMA down) / measured cycle: the wire alone, "
+                                 "a strict bound")
     except Exception as exc:  # noqa: BLE001
         out["pcie"] = {"error": repr(exc)}
     out["what"] = ("objective, gradient, constraints, jacobian, hessian of System on a new x per cycle, NumPy arrays in "
