@@ -46,6 +46,31 @@ CTRL_WORDS = 256         # control block: [0] sequence number, [1] command, [2] 
 MARK_EARLY, MARK_X, MARK_H = 64, 128, 192      # landed, [MARK_X + r] ... whose J slices have landed, [MARK_H + r] ... H slices
 
 
+class _AttachedSegment:
+    """Rank 0's POSIX shared-memory segment mapped into another rank: plain shm_open + mmap.  (``SharedMemory(name=...)`` of
+    Python < 3.13 registers an ATTACHED segment with the resource tracker as if this process owned it -- a second unlink at
+    exit, or, with a tracker shared by spawned processes, rank 0's own registration removed.  Rank 0 owns the segment.)"""
+
+    def __init__(self, name, size):
+        import mmap
+
+        fd = os.open("/dev/shm/" + name.lstrip("/"), os.O_RDWR)
+        try:
+            self._mmap = mmap.mmap(fd, size)
+        finally:
+            os.close(fd)
+        self.name, self.buf = name, memoryview(self._mmap)
+
+    def close(self):
+        if self.buf is not None:
+            self.buf.release()
+            self.buf = None
+            self._mmap.close()
+
+    def unlink(self):          # (never: rank 0 does)
+        pass
+
+
 class HostShardedEvaluator:
     """See the module docstring.  ``dist``: an initialised torch.distributed module (any backend; used once)."""
 
@@ -95,13 +120,7 @@ class HostShardedEvaluator:
         if world > 1:
             dist.broadcast_object_list(name, src=0)
         if rank != 0:
-            self.shm = shared_memory.SharedMemory(name=name[0])
-            try:        # (Python < 3.13 registers an ATTACHED segment with the resource tracker too, which then tries to
-                from multiprocessing import resource_tracker      # unlink it a second time at exit: rank 0 owns it)
-
-                resource_tracker.unregister(self.shm._name, "shared_memory")
-            except Exception:  # noqa: BLE001
-                pass
+            self.shm = _AttachedSegment(name[0], 8 * words)
         self.words = np.ndarray((words,), dtype=np.float64, buffer=self.shm.buf)
         self.ctrl = np.ndarray((CTRL_WORDS,), dtype=np.int64, buffer=self.shm.buf)
         if rank == 0:
