@@ -175,7 +175,9 @@ int pk_set_result_targets(pk_ctx* ctx, double* f, double* grad, double* g, doubl
  *                     (1), "kernel_download" (8: up to that many MiB per copy), "split_copy" (1), "speculative_hess" (1), "mark_wait" (1: the callbacks wait on a word a one-thread
  *                     kernel stores behind the result copies instead of on the stream's state), "hess_direct"
  *                     (1: a Hessian of at most "kernel_download" MiB is stored into its pinned landing array by the kernel itself),
- *                     "xpart_single" (1: the x-results of a new iterate come from ONE launch, pk_cycle without its Hessian role)
+ *                     "xpart_single" (1: the x-results of a new iterate come from ONE launch, pk_cycle without its Hessian role),
+ *                     "small_direct" (1: an x of <= 128 KB is read by the kernels from its pinned staging buffer, x-results of
+ *                     <= 1 MB are stored by the kernel straight into the landing block: no upload / copy launches)
  *                     -- see pk_runtime.cpp. */
 int pk_callback_x(pk_ctx* ctx, int what, const double* x, double* block, double* f_out, int* fresh);
 int pk_callback_hess(pk_ctx* ctx, const double* x, const double* lambda, double sigma, double* block, double* hess,

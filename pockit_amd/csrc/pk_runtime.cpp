@@ -166,6 +166,10 @@ struct pk_ctx {
   int split_copy = 1;          // grad f | g leave in a copy of their own in front of J (+1 DMA), with an event behind it: the
                                // gradient and constraints callbacks return while J is still on the link, and the bitwise
                                // compares of x they and the Jacobian callback start with are hidden behind that copy
+  int small_direct = 1;        // small systems are bound by the number of launches, not by bytes: a kernel reads an x of at most
+                               // 128 KB from its pinned staging buffer (no upload launch) and stores x-results of at most 1 MB
+                               // straight into their pinned landing places (no copy launches) -- LQR 10x10: 53 -> us per iterate
+  const double* x_src = nullptr;   // where the kernels read the prepared x: d_x, or (small_direct) the pinned staging buffer
   int xpart_single = 1;        // pk_eval_xpart_dev as ONE launch (pk_cycle without its Hessian role) instead of pk_xall + pk_fin
   int hess_direct = 1;         // the Hessian kernel stores into the pinned landing place itself when H is small enough for the
                                // copy kernel (kernel_download): no launch behind it, its reads of lambda and its stores share
@@ -629,7 +633,7 @@ int stage_upload(pk_ctx* c, double* const bufs[2], hipEvent_t const evs[2], uint
   // the buffer was last read two iterates ago -- by an upload whose completion an idle stream seen since then implies
   // (polling waits), or whose event says so (event waits)
   if (seqs[cur] > c->idle_seq) {
-    if (c->spin_wait) {
+    if (c->spin_wait || !dst) {          // (no upload, no event: the kernels that read the buffer in place are awaited on the stream)
       const uint64_t seen = c->op_seq;
       PK_HIP(c, hipStreamSynchronize(c->stream));
       c->idle_seq = seen;
@@ -1736,6 +1740,11 @@ int pk_host_free(void* p) {
 }
 
 namespace {
+bool small_x(const pk_ctx* c) { return c->small_direct && sizeof(double) * (size_t)c->n <= ((size_t)128 << 10); }
+bool small_results(const pk_ctx* c) {
+  const size_t nj = (size_t)(c->jac_compact ? c->nnz_Jc : c->nnz_J);
+  return c->small_direct && sizeof(double) * (nj + (size_t)c->n + (size_t)c->m) <= ((size_t)1 << 20);
+}
 bool hess_goes_direct(const pk_ctx* c) {
   return c->hess_direct && sizeof(double) * (size_t)c->nnz_H <= ((size_t)c->kernel_download << 20);
 }
@@ -1770,22 +1779,24 @@ int pk_prepare_x(pk_ctx* c, const double* x) {
   if (!x) return fail(c, 60, "null host buffer");
   PK_HIP(c, hipSetDevice(c->device));
   c->x_valid = false;
-  if ((rc = stage_upload(c, c->h_xs, c->ev_xs, c->xs_seq, c->xbuf, x, c->d_x, (size_t)c->n, &c->h_x))) return rc;
+  const bool sx = small_x(c), sr = small_results(c);
+  if ((rc = stage_upload(c, c->h_xs, c->ev_xs, c->xs_seq, c->xbuf, x, sx ? nullptr : c->d_x, (size_t)c->n, &c->h_x))) return rc;
+  c->x_src = sx ? c->h_x : c->d_x;
   for (int k = 0; k < 5; ++k) {
     c->landed[k] = c->target[k] ? c->target[k] : c->h_out[k];
     c->enq[k] = c->done[k] = false;
   }
-  c->jac_filled = !c->jconst.empty() && (c->target[3] ? c->target_filled : true) && !c->host_direct;
+  c->jac_filled = !c->jconst.empty() && (c->target[3] ? c->target_filled : true) && !c->host_direct && !sr;
   c->early_valid = false;
   double* o[4];
   for (int k = 0; k < 4; ++k) {     // (f: stored by the kernel itself whenever its landing place is device-visible)
-    c->stored_direct[k] = (c->host_direct || k == 0) && (!c->target[k] || c->target_visible[k]);
+    c->stored_direct[k] = (c->host_direct || sr || k == 0) && (!c->target[k] || c->target_visible[k]);
     o[k] = c->stored_direct[k] ? c->landed[k] : device_result(c, k);
   }
   if (c->stored_direct[0]) *(volatile unsigned long long*)c->landed[0] = (unsigned long long)PK_EMPTY;     // (see wait_result)
-  if ((rc = pk_eval_xpart_dev(c, c->d_x, o[0], o[1], o[2], c->jac_compact ? c->d_J : o[3], nullptr))) return rc;
+  if ((rc = pk_eval_xpart_dev(c, c->x_src, o[0], o[1], o[2], c->jac_compact ? c->d_J : o[3], nullptr))) return rc;
   // the compact layout of the Jacobian: its own kernel behind the fused x-kernel (whose reference-layout J stays on the device)
-  if (c->jac_compact && (rc = pk_eval_jacc_dev(c, c->d_x, o[3], nullptr))) return rc;
+  if (c->jac_compact && (rc = pk_eval_jacc_dev(c, c->x_src, o[3], nullptr))) return rc;
   // f and g are what a line search asks for at every trial point: always on their way; grad f and J in prefetch mode
   if ((rc = enqueue_result_copies(c, c->prefetch ? 0xFu : 0x5u))) return rc;
   c->x_valid = true;
@@ -1844,20 +1855,22 @@ int pk_callback_cycle(pk_ctx* c, const double* x, const double* lambda, double s
   c->target[4] = hess;
   c->target_visible[4] = !c->host_direct;
   c->target_pinned[4] = true;
-  if ((rc = stage_upload(c, c->h_xs, c->ev_xs, c->xs_seq, c->xbuf, x, c->d_x, (size_t)c->n, &c->h_x))) return rc;
+  const bool sx = small_x(c), sr = small_results(c) && !c->host_direct;
+  if ((rc = stage_upload(c, c->h_xs, c->ev_xs, c->xs_seq, c->xbuf, x, sx ? nullptr : c->d_x, (size_t)c->n, &c->h_x))) return rc;
+  c->x_src = sx ? c->h_x : c->d_x;
   for (int k = 0; k < 5; ++k) {
     c->landed[k] = c->target[k] ? c->target[k] : c->h_out[k];
     c->enq[k] = c->done[k] = false;
   }
-  c->jac_filled = !c->jconst.empty() && c->target_filled && !c->host_direct;
+  c->jac_filled = !c->jconst.empty() && c->target_filled && !c->host_direct && !sr;
   c->early_valid = false;
   double* o[5];
   for (int k = 0; k < 5; ++k) {
-    c->stored_direct[k] = k == 0 || (k == 4 && hess_goes_direct(c) && c->target_visible[4]);
+    c->stored_direct[k] = k == 0 || (k == 4 && hess_goes_direct(c) && c->target_visible[4]) || (k >= 1 && k <= 3 && sr);
     o[k] = c->stored_direct[k] ? c->landed[k] : (k == 4 ? c->d_H : device_result(c, k));
   }
   *(volatile unsigned long long*)c->landed[0] = (unsigned long long)PK_EMPTY;
-  if ((rc = pk_eval_cycle_dev(c, c->d_x, c->lam_src, sigma, o[0], o[1], o[2], o[3], o[4], nullptr))) return rc;
+  if ((rc = pk_eval_cycle_dev(c, c->x_src, c->lam_src, sigma, o[0], o[1], o[2], o[3], o[4], nullptr))) return rc;
   c->lam_staged = false;
   if ((rc = enqueue_result_copies(c, 0x1Fu))) return rc;
   c->x_valid = true;
@@ -1890,7 +1903,7 @@ int pk_eval_hess_prepared(pk_ctx* c, const double* lambda, double sigma, double*
   c->landed[4] = c->target[4] ? c->target[4] : c->h_out[4];
   c->enq[4] = c->done[4] = false;
   c->stored_direct[4] = (c->host_direct || hess_goes_direct(c)) && (!c->target[4] || c->target_visible[4]);
-  if ((rc = pk_eval_hess_dev(c, c->d_x, c->lam_src, sigma, c->stored_direct[4] ? c->landed[4] : c->d_H, nullptr))) return rc;
+  if ((rc = pk_eval_hess_dev(c, c->x_src, c->lam_src, sigma, c->stored_direct[4] ? c->landed[4] : c->d_H, nullptr))) return rc;
   if ((rc = enqueue_result_copies(c, 1u << 4))) return rc;
   if ((rc = wait_result(c, 4))) return rc;
   if (vals && vals != c->landed[4]) std::memcpy(vals, c->landed[4], sizeof(double) * (size_t)c->nnz_H);
@@ -1911,7 +1924,7 @@ int pk_eval_hessc_prepared(pk_ctx* c, const double* lambda, double sigma, double
   PK_HIP(c, hipSetDevice(c->device));
   if (lambda && (rc = stage_lambda(c, lambda))) return rc;
   c->lam_staged = false;
-  if ((rc = pk_eval_hessc_dev(c, c->d_x, c->lam_src, sigma, c->d_Hc, nullptr))) return rc;
+  if ((rc = pk_eval_hessc_dev(c, c->x_src, c->lam_src, sigma, c->d_Hc, nullptr))) return rc;
   const size_t bytes = sizeof(double) * (size_t)c->nnz_Hc;
   double* dst = vals;
   if (!vals_pinned) {
@@ -1957,7 +1970,7 @@ int pk_callback_hess(pk_ctx* c, const double* x, const double* lambda, double si
   if (c->speculative_hess && c->x_valid && c->h_x) {
     const size_t bytes = sizeof(double) * (size_t)c->nnz_Hc;
     if (compact) {
-      if ((rc = pk_eval_hessc_dev(c, c->d_x, c->lam_src, sigma, c->d_Hc, nullptr))) return rc;
+      if ((rc = pk_eval_hessc_dev(c, c->x_src, c->lam_src, sigma, c->d_Hc, nullptr))) return rc;
       const bool hc_by_kernel = bytes <= ((size_t)c->kernel_download << 20) && !(((uintptr_t)hess ^ (uintptr_t)c->d_Hc) & 8);
       if ((rc = copy_async(c, hess, c->d_Hc, (size_t)c->nnz_Hc, hipMemcpyDeviceToHost, hc_by_kernel))) return rc;
       ++c->op_seq;
@@ -1967,7 +1980,7 @@ int pk_callback_hess(pk_ctx* c, const double* x, const double* lambda, double si
       c->landed[4] = c->target[4] ? c->target[4] : c->h_out[4];
       c->enq[4] = c->done[4] = false;
       c->stored_direct[4] = (c->host_direct || hess_goes_direct(c)) && (!c->target[4] || c->target_visible[4]);
-      if ((rc = pk_eval_hess_dev(c, c->d_x, c->lam_src, sigma, c->stored_direct[4] ? c->landed[4] : c->d_H, nullptr))) return rc;
+      if ((rc = pk_eval_hess_dev(c, c->x_src, c->lam_src, sigma, c->stored_direct[4] ? c->landed[4] : c->d_H, nullptr))) return rc;
       if ((rc = enqueue_result_copies(c, 1u << 4))) return rc;
     }
     const bool same = pk_same_bits(c->h_x, x, (size_t)c->n) != 0;
@@ -2081,6 +2094,7 @@ int pk_set_host_option(pk_ctx* c, const char* name, int value) {
   else if (!std::strcmp(name, "speculative_hess")) c->speculative_hess = value != 0;
   else if (!std::strcmp(name, "hess_direct")) c->hess_direct = value != 0;
   else if (!std::strcmp(name, "xpart_single")) c->xpart_single = value != 0;
+  else if (!std::strcmp(name, "small_direct")) c->small_direct = value != 0;
   else if (!std::strcmp(name, "mark_wait")) { c->mark_wait = value != 0; c->mark_pending = false; }
   else return fail(c, 67, "pk_set_host_option: unknown option \"%s\"", name);
   return 0;

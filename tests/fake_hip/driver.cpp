@@ -120,13 +120,16 @@ int main() {
     OK(pk_fill_jac_constants(ctx, blocks.back()));
   }
   const char* options[] = {"spin_wait", "lambda_direct", "chunk_upload", "kernel_upload", "kernel_download", "split_copy", "speculative_hess",
-                           "mark_wait", "hess_direct", "xpart_single"};
-  const int defaults[] = {1, 1, 1, 1, 8, 1, 1, 1, 1, 1};
-  const int n_options = 10;
+                           "mark_wait", "hess_direct", "xpart_single", "small_direct"};
+  int defaults[] = {1, 1, 1, 1, 8, 1, 1, 1, 1, 1, 1};
+  const int n_options = 11;
   std::vector<double> x = fresh(S.n), lam = fresh(S.m);
   double f = 0.0;
   int is_new = 0;
-  for (int it = 0; it < 70; ++it) {
+  // (the fake system is small: with "small_direct" the kernels read x in place and store into the landing blocks themselves;
+  //  the walk through the switches runs once in that mode and once with uploads and copies)
+  for (int it = 0; it < 144; ++it) {
+    defaults[10] = it < 72 ? 1 : 0;
     if (it % 3 == 0) {                                          // walk through every switch, one at a time off its default
       for (int o = 0; o < n_options; ++o) OK(pk_set_host_option(ctx, options[o], defaults[o]));
       const int o = (it / 3) % (n_options + 1);
@@ -176,8 +179,9 @@ int main() {
   CHECK(pk_set_host_option(ctx, "no such switch", 1) != 0);
 
   // ---- all five results from one call (pk_callback_cycle): lands like the callbacks, the iterate becomes the prepared one
-  for (int it = 0; it < 12; ++it) {
+  for (int it = 0; it < 16; ++it) {
     if (it % 4 == 0) {
+      OK(pk_set_host_option(ctx, "small_direct", it < 8));
       OK(pk_set_host_option(ctx, "mark_wait", it % 8 == 0));
       OK(pk_set_host_option(ctx, "hess_direct", it % 3 != 0));
       OK(pk_set_host_option(ctx, "lambda_direct", it != 4));

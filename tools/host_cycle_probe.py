@@ -21,7 +21,8 @@ import numpy as np  # noqa: E402
 from pockit_amd import benchmarks as models  # noqa: E402
 import pockit_amd.radau as radau  # noqa: E402
 
-CASES = {"quadrotor": (models.planar_quadrotor, 2000, 6), "humanoid": (models.humanoid_wbc, 5000, 8),
+CASES = {"lqr": (models.lqr, 10, 10), "brach20": (models.brachistochrone, 20, 8), "quad100": (models.planar_quadrotor, 100, 6),
+         "quad500": (models.planar_quadrotor, 500, 6), "quadrotor": (models.planar_quadrotor, 2000, 6), "humanoid": (models.humanoid_wbc, 5000, 8),
          "brachistochrone": (models.brachistochrone, 1250, 8), "rocket": (models.two_stage_rocket, 1000, 4)}
 case = os.environ.get("CASE", "quadrotor")
 builder, mesh, K = CASES[case]
@@ -102,7 +103,7 @@ def report(label, modes=("fresh arrays", "fresh arrays, compact Hessian")):
 print("2. System callbacks (defaults)")
 report("defaults", ("fresh arrays", "zero-copy views", "fresh arrays, compact Hessian"))
 print("3. switches")
-DEFAULTS = {"xpart_single": 1, "mark_wait": 1, "hess_direct": 1, "spin_wait": 1, "lambda_direct": 1, "chunk_upload": 1, "kernel_upload": 1, "kernel_download": 8, "split_copy": 1,
+DEFAULTS = {"small_direct": 1, "xpart_single": 1, "mark_wait": 1, "hess_direct": 1, "spin_wait": 1, "lambda_direct": 1, "chunk_upload": 1, "kernel_upload": 1, "kernel_download": 8, "split_copy": 1,
             "speculative_hess": 1}
 if os.environ.get("PROBE_ONLY"):          # PROBE_ONLY=hess_direct,split_copy: A/B of these switches only
     DEFAULTS = {k: v for k, v in DEFAULTS.items() if k in os.environ["PROBE_ONLY"].split(",")}
