@@ -1781,6 +1781,10 @@ int pk_prepare_x(pk_ctx* c, const double* x) {
   c->x_valid = false;
   const bool sx = small_x(c), sr = small_results(c);
   if ((rc = stage_upload(c, c->h_xs, c->ev_xs, c->xs_seq, c->xbuf, x, sx ? nullptr : c->d_x, (size_t)c->n, &c->h_x))) return rc;
+  // (small x: every kernel of this iterate -- the x-part now, the Hessian later -- reads the staging buffer in place.  The
+  //  buffer is written again two stagings from now; every kernel of this iterate has been awaited by then: a callback returns
+  //  only when its result has landed, a discarded speculative launch is synchronized, and stage_upload waits for the stream
+  //  if nothing since the buffer's staging has been seen idle)
   c->x_src = sx ? c->h_x : c->d_x;
   for (int k = 0; k < 5; ++k) {
     c->landed[k] = c->target[k] ? c->target[k] : c->h_out[k];
