@@ -176,6 +176,8 @@ int pk_set_result_targets(pk_ctx* ctx, double* f, double* grad, double* g, doubl
  *                     kernel stores behind the result copies instead of on the stream's state), "hess_direct"
  *                     (1: a Hessian of at most "kernel_download" MiB is stored into its pinned landing array by the kernel itself),
  *                     "xpart_single" (1: the x-results of a new iterate come from ONE launch, pk_cycle without its Hessian role),
+ *                     "adaptive_prefetch" (1: grad f and J of a new iterate are copied ahead only
+ *                     if they were asked for at the previous one -- a line search's rejected trial points ask for f and g only),
  *                     "small_direct" (1: an x of <= 128 KB is read by the kernels from its pinned staging buffer, x-results of
  *                     <= 1 MB are stored by the kernel straight into the landing block: no upload / copy launches)
  *                     -- see pk_runtime.cpp. */

@@ -150,6 +150,11 @@ struct pk_ctx {
   bool done[5] = {false, false, false, false, false};                  // ... and known to have landed
   bool stored_direct[5] = {false, false, false, false, false};         // the kernel stored result k into its landing place
   int prefetch = 1;            // 1: every x-only result is copied out right behind the kernel; 0: on first request
+  int adaptive_prefetch = 1;   // ... but grad f and J only while the solver keeps asking for them: an iterate whose Jacobian was
+                               // never asked for was a rejected trial point of a line search (f and g only), and the copy of
+                               // its J (122 us of link time at 12k nodes) stood in the way of the next trial point's upload;
+                               // the new x behind such an iterate gets grad f / J on request
+  bool cur_J_asked = true;     // grad f or J of the prepared iterate has been asked for
   int host_direct = 0;         // 1: the kernels store into the (pinned, device-visible) host targets themselves
   // Host-shim tuning (pk_set_host_option; defaults = what measured fastest on MI355X, tools/dma_probe.cpp):
   int spin_wait = 1;           // results are awaited by polling (the event's state / f's own pinned word), not hipEventSynchronize
@@ -1802,7 +1807,9 @@ int pk_prepare_x(pk_ctx* c, const double* x) {
   // the compact layout of the Jacobian: its own kernel behind the fused x-kernel (whose reference-layout J stays on the device)
   if (c->jac_compact && (rc = pk_eval_jacc_dev(c, c->x_src, o[3], nullptr))) return rc;
   // f and g are what a line search asks for at every trial point: always on their way; grad f and J in prefetch mode
-  if ((rc = enqueue_result_copies(c, c->prefetch ? 0xFu : 0x5u))) return rc;
+  const bool ahead = c->prefetch && (!c->adaptive_prefetch || c->cur_J_asked);
+  c->cur_J_asked = false;
+  if ((rc = enqueue_result_copies(c, ahead ? 0xFu : 0x5u))) return rc;
   c->x_valid = true;
   return 0;
 }
@@ -1814,6 +1821,7 @@ int pk_fetch(pk_ctx* c, int what, double* out) {
   if (rc) return rc;
   if (what < 0 || what > 3) return fail(c, 61, "pk_fetch: what must be 0 (f), 1 (grad), 2 (g) or 3 (jac)");
   if (!c->x_valid) return fail(c, 64, "pk_fetch: no prepared x (pk_prepare_x)");
+  if (what == 1 || what == 3) c->cur_J_asked = true;
   if (!c->enq[what] && (rc = enqueue_result_copies(c, (1u << what) | (what == 1 ? 8u : 0u)))) return rc;   // (an accepted point: J follows grad f)
   if ((rc = wait_result(c, what))) return rc;
   if (out && out != c->landed[what]) std::memcpy(out, c->landed[what], sizeof(double) * result_count(c, what));
@@ -1878,6 +1886,7 @@ int pk_callback_cycle(pk_ctx* c, const double* x, const double* lambda, double s
   c->lam_staged = false;
   if ((rc = enqueue_result_copies(c, 0x1Fu))) return rc;
   c->x_valid = true;
+  c->cur_J_asked = true;
   if ((rc = wait_result(c, 4)) || (rc = wait_result(c, 3)) || (rc = wait_result(c, 0))) return rc;
   c->done[1] = c->done[2] = true;
   if (f_out) *f_out = c->landed[0][0];
@@ -2099,6 +2108,7 @@ int pk_set_host_option(pk_ctx* c, const char* name, int value) {
   else if (!std::strcmp(name, "hess_direct")) c->hess_direct = value != 0;
   else if (!std::strcmp(name, "xpart_single")) c->xpart_single = value != 0;
   else if (!std::strcmp(name, "small_direct")) c->small_direct = value != 0;
+  else if (!std::strcmp(name, "adaptive_prefetch")) { c->adaptive_prefetch = value != 0; c->cur_J_asked = true; }
   else if (!std::strcmp(name, "mark_wait")) { c->mark_wait = value != 0; c->mark_pending = false; }
   else return fail(c, 67, "pk_set_host_option: unknown option \"%s\"", name);
   return 0;

@@ -120,16 +120,16 @@ int main() {
     OK(pk_fill_jac_constants(ctx, blocks.back()));
   }
   const char* options[] = {"spin_wait", "lambda_direct", "chunk_upload", "kernel_upload", "kernel_download", "split_copy", "speculative_hess",
-                           "mark_wait", "hess_direct", "xpart_single", "small_direct"};
-  int defaults[] = {1, 1, 1, 1, 8, 1, 1, 1, 1, 1, 1};
-  const int n_options = 11;
+                           "mark_wait", "hess_direct", "xpart_single", "small_direct", "adaptive_prefetch"};
+  int defaults[] = {1, 1, 1, 1, 8, 1, 1, 1, 1, 1, 1, 1};
+  const int n_options = 12;
   std::vector<double> x = fresh(S.n), lam = fresh(S.m);
   double f = 0.0;
   int is_new = 0;
   // (the fake system is small: with "small_direct" the kernels read x in place and store into the landing blocks themselves;
   //  the walk through the switches runs once in that mode and once with uploads and copies)
-  for (int it = 0; it < 144; ++it) {
-    defaults[10] = it < 72 ? 1 : 0;
+  for (int it = 0; it < 156; ++it) {
+    defaults[10] = it < 78 ? 1 : 0;
     if (it % 3 == 0) {                                          // walk through every switch, one at a time off its default
       for (int o = 0; o < n_options; ++o) OK(pk_set_host_option(ctx, options[o], defaults[o]));
       const int o = (it / 3) % (n_options + 1);
@@ -177,6 +177,29 @@ int main() {
   for (int o = 0; o < n_options; ++o) OK(pk_set_host_option(ctx, options[o], defaults[o]));
   OK(pk_set_host_mode(ctx, 1, 0));
   CHECK(pk_set_host_option(ctx, "no such switch", 1) != 0);
+
+  // ---- a line search: rejected trial points ask for f and g only, the accepted one for everything (adaptive prefetch)
+  for (int small = 0; small < 2; ++small) {
+    OK(pk_set_host_option(ctx, "small_direct", small));
+    for (int it = 0; it < 24; ++it) {
+      x = fresh(S.n);
+      std::snprintf(g_where, 100, "line search %d (small %d)", it, small);
+      double* blk = blocks[(size_t)(it % 3)];
+      OK(pk_callback_x(ctx, 0, x.data(), blk, &f, &is_new));
+      CHECK(is_new == 1 && f == fake_f(x.data(), S.n));
+      OK(pk_callback_x(ctx, 2, x.data(), blk, &f, &is_new));
+      check_x_results(x, nullptr, nullptr, blk + S.nnz_J + S.n, nullptr, false);
+      if (it % 3 != 2) continue;                                  // (two rejected trial points, then an accepted one)
+      OK(pk_callback_x(ctx, 1, x.data(), blk, &f, &is_new));
+      OK(pk_callback_x(ctx, 3, x.data(), blk, &f, &is_new));
+      CHECK(is_new == 0);
+      check_x_results(x, nullptr, blk + S.nnz_J, blk + S.nnz_J + S.n, blk, false);
+      lam = fresh(S.m);
+      OK(pk_callback_hess(ctx, x.data(), lam.data(), 0.75, blk, hblocks[(size_t)(it % 3)], 0, &is_new));
+      check_hess(x, lam, 0.75, hblocks[(size_t)(it % 3)], false);
+    }
+  }
+  OK(pk_set_host_option(ctx, "small_direct", 1));
 
   // ---- all five results from one call (pk_callback_cycle): lands like the callbacks, the iterate becomes the prepared one
   for (int it = 0; it < 16; ++it) {
