@@ -38,7 +38,7 @@ import sympy as sp
 from .evaluator import Evaluator, _intervals_per_wave
 from .sharding import needed_x_runs, owned_runs, run_table, shared_gradient_slots, tile_filter
 
-CMD_EXIT, CMD_X, CMD_HESS = 0, 1, 2
+CMD_EXIT, CMD_X, CMD_HESS, CMD_X_TRIAL, CMD_J = 0, 1, 2, 3, 4      # (CMD_X_TRIAL: an x-part whose J slices stay on the GPUs until CMD_J)
 MAX_RANKS = 56
 CTRL_WORDS = 256         # control block: [0] sequence number, [1] command, [2] pid of rank 0 (liveness), [8 + r] last sequence
                          # rank r's HOST loop has drained; progress marks written by rank r's GPU behind its copies (a one-word
@@ -209,6 +209,7 @@ class HostShardedEvaluator:
         self.tab_part = self._upload_table(np.array([[0, rank * self.n_small, self.n_small]], dtype=np.int64))
         self._seq = 0
         self._x_seq = -1          # sequence number whose x-part results the segment holds
+        self._j_asked, self._j_seq = True, -1      # (grad f / J asked for at the prepared iterate; sequence whose mark says J is in)
         # rank 0's own passes over x and lambda (staging them into the segment, the bitwise compare of every callback) grow
         # with the whole system, not with a rank's share: from 1 MB on they are cut into slices for a few helper threads
         self.helper_threads = self._start_helpers(world) if rank == 0 else 0
@@ -269,8 +270,10 @@ class HostShardedEvaluator:
         if cnt:
             self.chk(self.lib.pk_copy_runs_dev(self.h, p, cnt, src, dst, None))
 
-    def _do_x_part(self, seq):
-        """Enqueue this rank's share of an x-part; nothing here waits (the marks tell rank 0 what has landed)."""
+    def _do_x_part(self, seq, with_j=True):
+        """Enqueue this rank's share of an x-part; nothing here waits (the marks tell rank 0 what has landed).  ``with_j`` False:
+        the J slices stay in device memory (a line search's trial point asks for f and g only; ``_do_j`` sends them if the
+        point is accepted)."""
         lib, h, chk = self.lib, self.h, self.chk
         self._runs(self.tab_xin, self._dev("x"), self.d_x)                               # this rank's part of x, over ITS link
         # the fused x-kernel on this shard's tiles: its slices of grad f / g / J, its share of the integrals (-> d_small)
@@ -280,10 +283,14 @@ class HostShardedEvaluator:
         self._runs(self.tab_part, self.d_small, self._dev("part"))       # (kernel copies: a DMA behind the kernels costs a
         self._runs(self.tab_early, self.d_full, self._dev("out"))        #  cross-engine hand-off, ~10 us)
         chk(lib.pk_store_word_dev(h, self._mark_dev["early"], seq, None))
+        if with_j:
+            self._do_j(seq)
+
+    def _do_j(self, seq):
         # owned runs of J -> the solver's array (the first time all of them, then only what changes with x)
         self._runs(self.tab_j_changing if self._x_filled else self.tab_j, self.d_full, self._dev("out"))
         self._x_filled = True
-        chk(lib.pk_store_word_dev(h, self._mark_dev["x"], seq, None))
+        self.chk(self.lib.pk_store_word_dev(self.h, self._mark_dev["x"], seq, None))
 
     def _do_hess(self, seq):
         lib, h, chk = self.lib, self.h, self.chk
@@ -372,6 +379,10 @@ class HostShardedEvaluator:
                 return True
             if cmd == CMD_X:
                 self._do_x_part(seq)
+            elif cmd == CMD_X_TRIAL:
+                self._do_x_part(seq, with_j=False)
+            elif cmd == CMD_J:
+                self._do_j(seq)
             elif cmd == CMD_HESS:
                 self._do_hess(seq)
             drained = False
@@ -400,8 +411,14 @@ class HostShardedEvaluator:
         if self._is_prepared(x):
             return
         self.lib.pk_copy_bits(self.h_x.ctypes.data, x.ctypes.data, self.plan.n)
-        seq = self._post(CMD_X)
-        self._do_x_part(seq)
+        # J slices go ahead only while the solver keeps asking for grad f / J: an iterate it did not ask them for was a rejected
+        # trial point of a line search, and its J on the links stood in the way of the next trial point's x
+        ahead = self._j_asked
+        self._j_asked, self._j_seq = False, (None if ahead else -1)
+        seq = self._post(CMD_X if ahead else CMD_X_TRIAL)
+        self._do_x_part(seq, with_j=ahead)
+        if ahead:
+            self._j_seq = seq
         self._wait_marks("early", seq)
         small = self.h_part[0].copy()
         for r in range(1, self.world):        # rank order: reproducible sums
@@ -426,6 +443,7 @@ class HostShardedEvaluator:
 
     def gradient(self, x):
         self._prepare(x)
+        self._j_asked = True
         return self.out["grad"]
 
     def constraints(self, x):
@@ -434,7 +452,11 @@ class HostShardedEvaluator:
 
     def jacobian(self, x):
         self._prepare(x)
-        self._wait_marks("x", self._x_seq)
+        self._j_asked = True
+        if self._j_seq == -1:                  # (the prepared iterate was taken for a trial point: its J is still on the GPUs)
+            self._j_seq = self._post(CMD_J)
+            self._do_j(self._j_seq)
+        self._wait_marks("x", self._j_seq)
         return self.out["J"]
 
     def hessian(self, x, lagrange, obj_factor):

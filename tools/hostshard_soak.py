@@ -53,6 +53,10 @@ def worker(rank, world, port, iters, ret):
             xk, lk, sk = inputs[k]
             wf, wg, wc, wj, wh = want[k]
             res = {}
+            if it % 7 == 3:                    # a rejected trial point: f and g only (the next iterate's J then comes on request)
+                ok = float(hs.objective(xk)) == wf and np.array_equal(hs.constraints(xk), wc)
+                bad += 0 if ok else 1
+                continue
             order = [0, 1, 2, 3] if it % 3 else list(rng.permutation(4))
             if it % 5 == 4:
                 res[4] = hs.hessian(xk, lk, sk)
