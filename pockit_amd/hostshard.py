@@ -414,11 +414,10 @@ class HostShardedEvaluator:
         # J slices go ahead only while the solver keeps asking for grad f / J: an iterate it did not ask them for was a rejected
         # trial point of a line search, and its J on the links stood in the way of the next trial point's x
         ahead = self._j_asked
-        self._j_asked, self._j_seq = False, (None if ahead else -1)
+        self._j_asked = False
         seq = self._post(CMD_X if ahead else CMD_X_TRIAL)
         self._do_x_part(seq, with_j=ahead)
-        if ahead:
-            self._j_seq = seq
+        self._j_seq = seq if ahead else -1       # (-1: the J slices of this iterate are still on the GPUs)
         self._wait_marks("early", seq)
         small = self.h_part[0].copy()
         for r in range(1, self.world):        # rank order: reproducible sums
