@@ -1536,6 +1536,9 @@ struct HostPool {
   std::vector<std::thread> th;
   std::atomic<uint64_t> activity{0};
   std::atomic<bool> stop{false};
+  std::atomic<long> jobs{0};          // slices executed by helpers (diagnostics)
+  int slow_waits = 0;                 // passes in which the caller waited more than 300 us for a helper (a host whose
+  bool given_up = false;              // "CPUs" are time slices of fewer cores): after three of them the helpers are left alone
 
   static void relax() {
 #if defined(__x86_64__) || defined(__i386__)
@@ -1552,6 +1555,7 @@ struct HostPool {
         if (bx->op == 0) { if (std::memcmp(bx->a, bx->b, bx->bytes) != 0) bx->differs.store(1, std::memory_order_relaxed); }
         else std::memcpy(bx->b, bx->a, bx->bytes);
         seen = p;
+        jobs.fetch_add(1, std::memory_order_relaxed);
         bx->done.store(p, std::memory_order_release);
         hot_until = clock::now() + std::chrono::milliseconds(1);
         continue;
@@ -1599,8 +1603,9 @@ struct HostPool {
     use.reserve(box.size());
     while (at < bytes) {
       use.clear();
-      for (auto& bx : box)
-        if (bx->hot.load(std::memory_order_seq_cst)) use.push_back(bx.get());
+      if (!given_up)
+        for (auto& bx : box)
+          if (bx->hot.load(std::memory_order_seq_cst)) use.push_back(bx.get());
       const size_t left = bytes - at;
       if (use.empty() || left <= ((size_t)256 << 10)) {
         const size_t len = left < ((size_t)256 << 10) ? left : ((size_t)256 << 10);
@@ -1625,10 +1630,16 @@ struct HostPool {
       }
       int differs = one(a + at, b + at, slice < left ? slice : left);
       if (pos < bytes) differs |= one(a + pos, b + pos, bytes - pos);
+      const auto t_wait = std::chrono::steady_clock::now();
+      bool slow = false;
       for (auto& w : waits) {                          // (always: a helper must not be left reading the caller's arrays)
-        while (w.first->done.load(std::memory_order_acquire) != w.second) relax();
+        for (unsigned spins = 1; w.first->done.load(std::memory_order_acquire) != w.second; ++spins) {
+          relax();
+          if (!slow && (spins & 0xFF) == 0 && std::chrono::steady_clock::now() - t_wait > std::chrono::microseconds(300)) slow = true;
+        }
         differs |= w.first->differs.load(std::memory_order_relaxed);
       }
+      if (slow && ++slow_waits >= 3) given_up = true;
       return differs;
     }
     return 0;
@@ -1649,11 +1660,15 @@ int pk_host_threads(int k) {
   return 0;
 }
 
+long pk_host_threads_jobs(void) { return g_pool ? g_pool->jobs.load(std::memory_order_relaxed) : 0; }   // slices helpers have taken
+
 // how many helpers are spinning right now (diagnostics)
 int pk_host_threads_hot(void) {
   int k = 0;
-  if (g_pool)
+  if (g_pool) {
+    if (g_pool->given_up) return -1;       // (the helpers proved slower than the caller alone on this host: not used any more)
     for (auto& bx : g_pool->box) k += bx->hot.load(std::memory_order_relaxed);
+  }
   return k;
 }
 

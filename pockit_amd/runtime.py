@@ -78,7 +78,7 @@ EXPORTS = ["pk_create", "pk_destroy", "pk_last_error", "pk_device_count", "pk_lo
            "pk_set_exchange", "pk_exchange_sums_dev", "pk_copy_runs_dev", "pk_set_exchange_inline",
            "pk_host_register", "pk_host_unregister", "pk_copy_dev", "pk_eval_xpart_dev",
            "pk_eval_jacc", "pk_eval_jacc_dev", "pk_callback_x", "pk_callback_hess", "pk_set_jac_constant_runs", "pk_fill_jac_constants", "pk_set_host_option",
-           "pk_set_jacobian_layout", "pk_exchange_status", "pk_wait_idle", "pk_same_bits", "pk_copy_bits", "pk_host_threads", "pk_host_threads_hot"]
+           "pk_set_jacobian_layout", "pk_exchange_status", "pk_wait_idle", "pk_same_bits", "pk_copy_bits", "pk_host_threads", "pk_host_threads_hot", "pk_host_threads_jobs"]
 
 _lib = None
 
@@ -198,6 +198,7 @@ def load_library():
     lib.pk_same_bits.argtypes = [vp, vp, C.c_size_t]
     lib.pk_copy_bits.argtypes = [vp, vp, C.c_size_t]
     lib.pk_host_threads.argtypes = [C.c_int]
+    lib.pk_host_threads_jobs.restype = C.c_long
     lib.pk_set_shard.argtypes = [vp, C.c_int, C.c_int, vp]
     lib.pk_eval_integrals_dev.argtypes = [vp, vp, vp]
     lib.pk_eval_f_from_integrals_dev.argtypes = [vp, vp, vp, vp]
