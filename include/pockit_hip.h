@@ -150,7 +150,7 @@ int pk_copy_bits(double* dst, const double* src, size_t n);      /* dst = src (n
 int pk_host_threads(int k);
 long pk_host_threads_jobs(void); /* slices of passes the helpers have executed so far (diagnostics) */
 int pk_host_threads_hot(void);   /* how many of them are spinning right now (diagnostics); -1: the pool gave up -- the caller waited
-                                  * more than 300 us for a helper three times (a host whose CPUs are time slices of fewer cores) */
+                                  * more than 1 ms for a helper three times (a host whose CPUs are time slices of fewer cores) */
 int pk_prepare_x(pk_ctx* ctx, const double* x);
 int pk_fetch(pk_ctx* ctx, int what, double* out);
 int pk_eval_hess_prepared(pk_ctx* ctx, const double* lambda /* NULL: staged */, double sigma, double* vals);

@@ -1537,7 +1537,7 @@ struct HostPool {
   std::atomic<uint64_t> activity{0};
   std::atomic<bool> stop{false};
   std::atomic<long> jobs{0};          // slices executed by helpers (diagnostics)
-  int slow_waits = 0;                 // passes in which the caller waited more than 300 us for a helper (a host whose
+  int slow_waits = 0;                 // passes in which the caller waited more than 1 ms for a helper (a host whose
   bool given_up = false;              // "CPUs" are time slices of fewer cores): after three of them the helpers are left alone
 
   static void relax() {
@@ -1635,7 +1635,7 @@ struct HostPool {
       for (auto& w : waits) {                          // (always: a helper must not be left reading the caller's arrays)
         for (unsigned spins = 1; w.first->done.load(std::memory_order_acquire) != w.second; ++spins) {
           relax();
-          if (!slow && (spins & 0xFF) == 0 && std::chrono::steady_clock::now() - t_wait > std::chrono::microseconds(300)) slow = true;
+          if (!slow && (spins & 0xFF) == 0 && std::chrono::steady_clock::now() - t_wait > std::chrono::milliseconds(1)) slow = true;
         }
         differs |= w.first->differs.load(std::memory_order_relaxed);
       }
@@ -1666,7 +1666,7 @@ long pk_host_threads_jobs(void) { return g_pool ? g_pool->jobs.load(std::memory_
 int pk_host_threads_hot(void) {
   int k = 0;
   if (g_pool) {
-    if (g_pool->given_up) return -1;       // (the helpers proved slower than the caller alone on this host: not used any more)
+    if (g_pool->given_up) return -1;       // (the caller waited a millisecond for a helper three times: not used any more)
     for (auto& bx : g_pool->box) k += bx->hot.load(std::memory_order_relaxed);
   }
   return k;

@@ -42,5 +42,12 @@ def test_host_helper_threads_under_sanitizers(tmp_path, sanitizer):
     assert build.returncode == 0, build.stderr[-4000:]
     env = dict(os.environ, TSAN_OPTIONS="halt_on_error=1", ASAN_OPTIONS="detect_leaks=1:abort_on_error=0")
     run = subprocess.run([exe], capture_output=True, text=True, env=env, timeout=600)
+    if sanitizer == "thread" and run.returncode != 0 and "unexpected memory mapping" in run.stderr:
+        # (ThreadSanitizer cannot place its shadow under this kernel's address-space randomisation: once more without it)
+        if shutil.which("setarch") is None:
+            pytest.skip("ThreadSanitizer cannot start on this kernel (unexpected memory mapping) and setarch is missing")
+        run = subprocess.run(["setarch", "-R", exe], capture_output=True, text=True, env=env, timeout=600)
+        if run.returncode != 0 and ("unexpected memory mapping" in run.stderr or "setarch" in run.stderr):
+            pytest.skip("ThreadSanitizer cannot start on this kernel (unexpected memory mapping)")
     assert run.returncode == 0, (run.stdout[-2000:], run.stderr[-6000:])
     assert "checks passed" in run.stdout and "WARNING: ThreadSanitizer" not in run.stderr and "ERROR" not in run.stderr
