@@ -382,6 +382,7 @@ def host_sharded_end_to_end(name, intervals, rank, world, dist, steps, warmup):
                    "per_callback_ms": {nm: per[i] * 1e3 for i, nm in enumerate(names)},
                    "bytes_to_host_per_cycle": 8 * (1 + p.n + p.m + p.nnz_J + p.nnz_H), "ranks": world, "finite": finite,
                    "host_helper_threads_of_rank_0": int(hs.helper_threads),
+                   "host_helper_threads_gave_up": bool(hs.helper_threads and hs.lib.pk_host_threads_hot() < 0),
                    "what": "objective, gradient, constraints, jacobian, hessian on a new x per cycle with NumPy arrays in and "
                            "out; every rank evaluates its share of the mesh intervals and its run-copy kernel stores its "
                            "own slices straight into ONE shared pinned host array over its own PCIe link; rank 0 adds the "
