@@ -578,6 +578,27 @@ def test_scipy_trust_constr_solves_lqr_on_the_gpu_evaluator():
     assert abs(var.x[0][-1] - s[0]) < 1e-9 and abs(var.x[0][0] - 1.0) < 1e-12
 
 
+@pytest.mark.parametrize("scheme,mesh,num_point", [("radau", 10, 8), ("lobatto", 6, 6)])
+def test_scipy_trust_constr_solves_the_brachistochrone_to_the_cycloid_time(scheme, mesh, num_point):
+    """A second IPOPT-free end-to-end solve, nonlinear this time (free final time, path bounds, trigonometric dynamics): SciPy's
+    trust-constr on the GPU callbacks (objective, gradient, constraints, Jacobian, Hessians of objective and constraints) must
+    reach the analytic optimum of the brachistochrone (0, 0) -> (2, 2): the cycloid's descent time theta sqrt(R / g)."""
+    from scipy.optimize import brentq
+
+    from pockit_amd.optimizer import scipy as scipy_solver
+
+    ns = _ns(scheme, "pockit_amd")
+    system, (phase,), guess = models.brachistochrone(ns, mesh, num_point)
+    (var,), res = scipy_solver.solve(system, guess, {"maxiter": 400, "gtol": 1e-9, "xtol": 1e-11})
+    theta = brentq(lambda t: (t - np.sin(t)) / (1 - np.cos(t)) - 1.0, 0.1, 2 * np.pi - 0.1)      # x_f / y_f = 1
+    radius = 2.0 / (1 - np.cos(theta))
+    optimum = theta * np.sqrt(radius / 9.81)
+    assert res.status in (1, 2) and res.constr_violation < 1e-10
+    assert abs(res.fun - optimum) <= 1e-7, (res.fun, optimum)
+    assert abs(var.t_f - optimum) <= 1e-7                                                        # (the objective is the final time)
+    assert abs(var.x[0][-1] - 2.0) < 1e-12 and abs(var.x[1][-1] - 2.0) < 1e-12
+
+
 @pytest.mark.parametrize("case", [("brachistochrone", "radau", dict(mesh=37, num_point=5)),
                                   ("brachistochrone", "lobatto", dict(mesh=23, num_point=6)),
                                   ("brachistochrone", "radau", dict(mesh=[0, 0.1, 0.15, 0.5, 0.9, 1.0], num_point=[3, 7, 2, 5, 1])),
