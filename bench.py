@@ -236,7 +236,9 @@ def end_to_end(system, guess, steps, warmup):
     xs, lam, sigma = solver_inputs(system, guess)
     ev = system.evaluator
     names = ("objective", "gradient", "constraints", "jacobian", "hessian")
-    out = {}
+    # (systems whose x has 2 MB or more: the solver thread's passes over x and lambda -- a compare per callback, the staging
+    #  copies -- are cut into slices for helper threads of the library; none at the 12k-node headline)
+    out = {"host_helper_threads": int(getattr(ev, "host_helper_threads", 0))}
     torch.cuda.synchronize()
     t_region = time.perf_counter()
     batches = timed_cycles(lambda k: five_callbacks(system, xs[k & 1], lam, sigma), steps, warmup)

@@ -652,7 +652,7 @@ int stage_upload(pk_ctx* c, double* const bufs[2], hipEvent_t const evs[2], uint
   int rc;
   for (size_t lo = 0; lo < count; lo += step) {
     const size_t len = count - lo < step ? count - lo : step;
-    std::memcpy(bufs[cur] + lo, src + lo, sizeof(double) * len);
+    (void)pk_copy_bits(bufs[cur] + lo, src + lo, len);      // (memcpy; with the helper threads of pk_host_threads from 1 MB on)
     if (dst && (rc = copy_async(c, dst + lo, bufs[cur] + lo, len, hipMemcpyHostToDevice, c->kernel_upload != 0))) return rc;
   }
   seqs[cur] = ++c->op_seq;          // (a consumer kernel reading the buffer itself is enqueued right behind: same number)

@@ -208,8 +208,9 @@ class Tables:
 
 class Evaluator:
     def __init__(self, plan: SystemPlan, device: int = 0, intervals_per_wave=None, tile_filter=None, sharded=False,
-                 output_share=1.0):
+                 output_share=1.0, host_helpers=True):
         self.plan = plan
+        self._want_host_helpers = bool(host_helpers) and tile_filter is None
         self.src = ModelSource(plan, sharded=sharded, output_share=output_share)
         # (compiled before the context is created: a box without a GPU -- the build container -- can still fill the
         # code-object cache by constructing evaluators, tools/warm_cache.sh)
@@ -311,6 +312,8 @@ class Evaluator:
         self._a_f, self._a_fresh = C.addressof(self._c_f), C.addressof(self._c_fresh)
         self._const_runs = {}
         self.jac_constant_runs = self._register_constant_runs(False)
+        # large systems: the solver thread's passes over x and lambda (a compare per callback, the staging copies) get helpers
+        self.host_helper_threads = runtime.host_helpers(self.ctx.lib, p.n) if self._want_host_helpers else 0
 
     def _register_constant_runs(self, compact):
         """The x-independent runs of the Jacobian (in the layout the shim serves right now) worth leaving out of the copy."""

@@ -84,7 +84,7 @@ class HostShardedEvaluator:
             intervals_per_wave = _intervals_per_wave(plan, shards=world)
         self.ev = Evaluator(plan, device=device, intervals_per_wave=intervals_per_wave,
                             tile_filter=tile_filter(rank, world, plan) if world > 1 else None,
-                            output_share=1.0 / max(world, 1))
+                            output_share=1.0 / max(world, 1), host_helpers=False)
         lib, h, chk = self.ev.ctx.lib, self.ev.ctx.handle, self.ev.ctx.check
         self.lib, self.h, self.chk = lib, h, chk
         n, m = plan.n, plan.m
@@ -245,7 +245,10 @@ class HostShardedEvaluator:
                 ts.append(time.perf_counter() - t)
             return sorted(ts)[len(ts) // 2]
 
+        from . import runtime
+
         lib.pk_host_threads(0)
+        runtime.host_helpers_stopped()
         alone = pass_us()
         if lib.pk_host_threads(k):
             return 0
@@ -494,7 +497,10 @@ class HostShardedEvaluator:
                 pass
         lib, h = self.lib, self.h
         if getattr(self, "helper_threads", 0):
+            from . import runtime
+
             lib.pk_host_threads(0)
+            runtime.host_helpers_stopped()
             self.helper_threads = 0
         if h:
             lib.pk_sync(h, None)

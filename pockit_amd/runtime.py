@@ -319,3 +319,56 @@ class PinnedRing:
     def take(self):
         it = self.take_item()
         return None if it is None else it.array
+
+
+# ---------------------------------------------------------------- helper threads for the host's passes over x / lambda
+_HOST_HELPERS = {"k": None}       # None: not decided in this process yet; 0: tried and dropped; k: running
+
+
+def host_helpers(lib, n, world=1):
+    """Start the library's helper threads (``pk_host_threads``) for a solver thread whose x has ``n`` doubles -- once per process,
+    only from 2 MB on, as many as this process's share of the host's cores allows (at most 6; POCKIT_AMD_HOST_THREADS=k
+    overrides, 0 = none), and only if a measured pass over n doubles is at least a quarter faster with them.  Returns the
+    number of helpers running.  A bitwise compare of x per callback and the staging copies of x and lambda are the host's
+    share of an iterate: 90 us per pass at the 40k-node configuration."""
+    import os
+    import time
+
+    env = os.environ.get("POCKIT_AMD_HOST_THREADS", "auto")
+    if 8 * n < (2 << 20) or env == "0":
+        return _HOST_HELPERS["k"] or 0
+    if _HOST_HELPERS["k"] is not None:
+        return _HOST_HELPERS["k"]
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    k = int(env) if env.isdigit() else max(0, min(6, cores // max(world, 1) - 2))
+    _HOST_HELPERS["k"] = 0
+    if k < 1:
+        return 0
+    a = np.zeros(n)
+    b = np.zeros(n)
+    pa, pb = a.ctypes.data, b.ctypes.data
+
+    def pass_us():
+        lib.pk_same_bits(pa, pb, n)
+        ts = []
+        for _ in range(9):
+            t = time.perf_counter()
+            lib.pk_same_bits(pa, pb, n)
+            ts.append(time.perf_counter() - t)
+        return sorted(ts)[len(ts) // 2]
+
+    lib.pk_host_threads(0)
+    alone = pass_us()
+    if lib.pk_host_threads(k):
+        return 0
+    helped = pass_us()
+    if helped > 0.75 * alone:
+        lib.pk_host_threads(0)
+        return 0
+    _HOST_HELPERS["k"] = k
+    return k
+
+
+def host_helpers_stopped():
+    """(somebody called pk_host_threads(0): the next large evaluator may try again)"""
+    _HOST_HELPERS["k"] = None

@@ -432,7 +432,7 @@ class ShardedEvaluator:
             intervals_per_wave = _intervals_per_wave(plan, shards=world)
         self.ev = Evaluator(plan, device=device, intervals_per_wave=intervals_per_wave,
                             tile_filter=tile_filter(rank, world, plan) if world > 1 else None, sharded=world > 1,
-                            output_share=1.0 / max(world, 1))
+                            output_share=1.0 / max(world, 1), host_helpers=False)
         self.dev = dev = torch.device("cuda", device)
         n_I = max(len(plan.I_syms), 1)
         # integrals that later kernels need (models nonlinear in I) must be global *before* those kernels
