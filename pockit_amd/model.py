@@ -572,10 +572,12 @@ class SystemBase:
 
     # ------------------------------------------------------------------ plan / evaluator (lazy)
     def _stamp(self):
-        return tuple(p._version for p in self._phase)
+        return tuple([p._version for p in self._phase])
 
     @property
     def plan(self):
+        if self._plan is not None and self._built_for == self._stamp():
+            return self._plan
         from .transcription import SystemPlan
 
         if self._plan is None or self._built_for != self._stamp():
@@ -590,6 +592,9 @@ class SystemBase:
     def evaluator(self):
         """The GPU evaluator; built (code generation + hipcc + upload) on first use.
         Raises RuntimeError when the HIP library or a GPU is missing -- there is no CPU path."""
+        ev = self._evaluator       # (a solver calls this five times per iterate: the common case first)
+        if ev is not None and self._plan is not None and self._built_for == self._stamp():
+            return ev
         from .evaluator import Evaluator
 
         plan = self.plan
