@@ -179,7 +179,7 @@ class ModelSource:
         # compiled into the object only when the mesh has such an interval (PK_BIG)
         self.big = any(int(pp.layout.K.max()) > 64 for pp in plan.phase_plans)
         self.compact = not plan.outer
-        self.compact_j = not self.big             # (the compact Jacobian has no workgroup-per-interval path)
+        self.compact_j = True
         for cbname in ("jac", "hess", "aux") + (("hessc",) if self.compact else ()) + (("jacc",) if self.compact_j else ()):
             cb = getattr(plan, cbname)
             off, table = 0, {}
@@ -525,6 +525,10 @@ class ModelSource:
             S.append("  }")
             S.append("  __device__ static __forceinline__ void biga(int phase, const PkArgs& A, const PkTile& tl) {")
             S.append(switch("pk::big_aux<{P}>(A, tl)"))
+            S.append("  }")
+            S.append("  __device__ static __forceinline__ void bigjc(int phase, const PkArgs& A, const PkTile& tl, "
+                     "double* __restrict__ lds) {")
+            S.append(switch("pk::big_jacc<{P}>(A, tl, lds)"))
             S.append("  }")
         ncmax = max([1] + [pp.phase.n_c for pp in plan.phase_plans])
         for cbname, tag in (("jac", "J"), ("hess", "H"), ("aux", "A")):

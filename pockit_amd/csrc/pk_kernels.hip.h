@@ -1419,6 +1419,82 @@ __device__ __forceinline__ void big_aux(const PkArgs& A, const PkTile& tl) {
   }
 }
 
+// compact Jacobian (tile_jacc above) of such an interval: the expanded and the dense-column segment values of all nodes are
+// staged ([JC_NI + JC_ND][KS], sub-slot 3 beyond 256 points), then the translation entries, the dense rows (one K-term product
+// per defect row and dense-column segment) and the K^2 entries of every expanded segment are walked by all 256 threads
+template <class P>
+__device__ __forceinline__ void big_jacc(const PkArgs& A, const PkTile& tl, double* __restrict__ lds0) {
+  const PkPhase& ph = A.ph[P::INDEX];
+  const int t = threadIdx.x;
+  const int K = tl.K, stride = K - P::SCHEME, R = stride;
+  const int nq = stride + P::SCHEME;
+  const int nown = (P::SCHEME && !tl.last) ? nq - 1 : nq;
+  const BigStage bs = big_stage(A, K, tl.stage, 3, lds0);
+  const int KS = bs.KS;
+  double* __restrict__ sv = bs.base;
+  double* __restrict__ dsv = bs.base + P::JC_NI * KS;
+  double s[PK_NS], dt, mt;
+  phase_scalars<P>(A, ph, s, dt, mt);
+  const PkSys sy{s, A.Ibuf, A.sigma, A.lam};
+  pk_cbase_t segb = const_bases(A.lb + ph.jcseg_off);
+  pk_cbase_t tb = const_bases(A.lb + ph.jct_off);
+  for (int c = t; c < nq; c += PK_BLOCK) {
+    const int q = tl.q0 + c;
+    double a[P::NARG], tau, w, o[P::JC_NI + P::JC_ND + P::JC_NN + 1];
+    load_node<P>(A, ph, s, dt, mt, q, a, tau, w);
+    P::mid_jacc(a, tau, dt, w, sy, nullptr, o);
+    if (P::JC_ND > 0) {              // the boundary nodes carry their own expressions of the dense-column entries
+      if (q == 0) P::front_jacc_dense(a, tau, dt, w, sy, nullptr, o + P::JC_NI);
+      else if (P::SCHEME == 1 && q == ph.L_m - 1) P::back_jacc_dense(a, tau, dt, w, sy, nullptr, o + P::JC_NI);
+    }
+#pragma unroll
+    for (int e = 0; e < P::JC_NI + P::JC_ND; ++e) sv[e * KS + c] = o[e];
+    if (c < nown && q >= ph.mid_lo && q < ph.mid_hi) {
+#pragma unroll
+      for (int e = 0; e < P::JC_NN; ++e)
+        put(&A.o_jac[segb[P::JC_NI + P::JC_ND + e] + (q - ph.mid_lo)], o[P::JC_NI + P::JC_ND + e]);
+    }
+  }
+  __syncthreads();
+  const double width = A.db[ph.width_off + tl.j0];
+  const double* __restrict__ tvg = A.db + tl.tv_off;       // constant translation entries
+  for (int p = t; p < tl.nnzT; p += PK_BLOCK) {
+    const double v = tvg[p];
+#pragma unroll
+    for (int i = 0; i < P::NX; ++i) put(&A.o_jac[tb[i] + tl.offT + p], v);
+  }
+  if (P::JC_ND > 0) {
+    constexpr int ND = P::JC_ND > 0 ? P::JC_ND : 1;
+    const double* __restrict__ full = A.db + tl.full_off;
+    double a[P::NARG], tau, w, tf[ND], tbk[ND];
+    load_node<P>(A, ph, s, dt, mt, tl.q0, a, tau, w);        // (the static parameters, for the boundary shares)
+    P::jacc_tdense(a, tf, tbk);
+    const bool last_iv = tl.j0 == ph.n_int - 1;
+    for (int r = t; r < R; r += PK_BLOCK) {
+      double acc[ND];
+#pragma unroll
+      for (int e = 0; e < P::JC_ND; ++e) acc[e] = 0.0;
+      for (int c = 0; c < K; ++c) {
+        const double wgt = full[r * K + c] * width * 0.5;
+#pragma unroll
+        for (int e = 0; e < P::JC_ND; ++e) acc[e] += wgt * dsv[e * KS + c];
+      }
+      const bool first = tl.r0 + r == 0;
+#pragma unroll
+      for (int e = 0; e < P::JC_ND; ++e)
+        put(&A.o_jac[segb[P::JC_NI + e] + tl.r0 + r], (first ? tf[e] : 0.0) + (last_iv ? tbk[e] : 0.0) - acc[e]);
+    }
+  }
+  const int32_t* __restrict__ rcg = A.ib + tl.irc_off;
+  const double* __restrict__ ivg = A.db + tl.iv_off;
+  for (int p = t; p < tl.nnzI; p += PK_BLOCK) {
+    const int c = rcg[2 * p + 1];
+    const double val = -(ivg[p] * width * 0.5);
+#pragma unroll
+    for (int e = 0; e < P::JC_NI; ++e) put(&A.o_jac[segb[e] + tl.offI + p], val * sv[e * KS + c]);
+  }
+}
+
 // does tile block `blk` hold an interval with more points than a wave has lanes?  (wave-uniform; tl0 receives its record)
 __device__ __forceinline__ bool big_block(const PkTile* tiles, int n_tiles, int blk, PkTile& tl0) {
   const int t0 = blk * PK_WAVES_PER_BLOCK;
@@ -1800,6 +1876,10 @@ template <class Gen>
 __device__ __forceinline__ void kernel_jacc(const PkArgs& A) {
   if (PK_IS_EDGE_BLOCK()) return edge_block<Gen>(A, 4, false, A.items, A.n_items);
   PK_TILE_PROLOGUE(1);
+#ifdef PK_BIG
+  PkTile tl0;
+  if (big_block(A.tile, A.n_tiles, blk, tl0)) return Gen::bigjc(tl0.phase, A, tl0, PK_STAGE(A));
+#endif
   Gen::tile_jacc(tl.phase, A, tl, PK_STAGE(A) + wave * Gen::LDS_JC, wint, wgrad, lane);
 }
 

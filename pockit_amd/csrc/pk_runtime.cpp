@@ -779,7 +779,8 @@ int pk_set_problem(pk_ctx* c, const pk_problem_desc* pd) {
     release(c->d_big_stage);
     c->big_row = c->big_slot = 0;
     if (n_stage) {
-      const size_t rows = (size_t)(c->md.lds_x > c->md.lds_h ? c->md.lds_x : c->md.lds_h) / PK_WAVE;
+      size_t rows = (size_t)(c->md.lds_x > c->md.lds_h ? c->md.lds_x : c->md.lds_h) / PK_WAVE;
+      if ((size_t)c->md.lds_jc / PK_WAVE > rows) rows = (size_t)c->md.lds_jc / PK_WAVE;
       c->big_row = (kmax + 7) & ~7;
       const size_t slot = rows * (size_t)c->big_row;
       if (slot > (size_t)INT32_MAX) return fail(c, 33, "pk_set_problem: an interval with %d points is too long for the staging buffer", kmax);

@@ -335,8 +335,6 @@ class Evaluator:
         compact = bool(compact)
         if compact == self._jac_compact:
             return
-        if compact and not self.src.compact_j:
-            raise NotImplementedError("the compact Jacobian layout is not available for intervals with more than 64 points")
         self.ctx.check(self.ctx.lib.pk_set_jacobian_layout(self.ctx.handle, int(compact)))
         p = self.plan
         self._jac_compact = compact
@@ -521,8 +519,6 @@ class Evaluator:
     def jacobian_compact(self, x):
         """Values of the compact (coalesced) Jacobian layout ``plan.jacc_row/col`` (one pk_jacc launch; the one-shot entry
         point -- a solver loop uses ``set_jacobian_layout(True)`` and ``jacobian()``)."""
-        if not self.src.compact_j:
-            raise NotImplementedError("the compact Jacobian layout is not available for intervals with more than 64 points")
         x = self._x(x)
         self._invalidate_x()        # the context's x buffer is about to hold another iterate
         out = np.empty(self.plan.nnz_Jc)

@@ -531,8 +531,6 @@ class SystemPlan:
         cb = CallbackPlan(nP)
         rows, cols, pos = [], [], 0
         nI = len(self.I_syms)
-        if any(int(pp.layout.K.max()) > 64 for pp in self.phase_plans):
-            raise NotImplementedError("the compact Jacobian layout is not available for intervals with more than 64 points")
 
         def scalar(row, colv, coef, key, expr):
             nonlocal pos

@@ -241,6 +241,11 @@ def test_intervals_with_more_points_than_a_wavefront_has_lanes(case, monkeypatch
     system.set_hessian_layout("compact")                             # compact layout: pk_hessc walks such an interval 64 nodes at a time
     close(system.hessian(x, lam, sigma), it.hessian_compact(), what="compact H")
     system.set_hessian_layout("reference")
+    system.set_jacobian_layout("compact")                            # compact Jacobian: pk_jacc gives such an interval a workgroup too
+    close(system.jacobian(x), it.jacobian_compact(), what="compact J")
+    close(system.evaluator.jacobian_compact(x), it.jacobian_compact(), what="compact J, one-shot")
+    system.set_jacobian_layout("reference")
+    close(system.jacobian(x), want["J"], what="J after the layout switch")
     # mesh error estimation: an interval with K + 1 > 64 augmented nodes is walked by a whole workgroup of pk_err
     import plan_interp
 
@@ -282,6 +287,9 @@ def test_model_nonlinear_in_the_integrals_on_intervals_with_more_than_64_points(
     close(ev.constraints_direct(x), want["g"], what="g direct")
     close(ev.jacobian_direct(x), want["J"], what="J direct")
     close(ev.hessian_direct(x, lam, sigma), want["H"], what="H direct")
+    system.set_jacobian_layout("compact")          # (dense t0 / tf / static columns: the contracted rows of a workgroup-wide interval)
+    close(system.jacobian(x), it.jacobian_compact(), what="compact J")
+    system.set_jacobian_layout("reference")
     # the same model on an ordinary mesh agrees with the oracle (pins the interpreter's outer-product path)
     small, _, sg = models.derivative_model(_ns(scheme, "pockit_amd"))
     ref, _, rg = models.derivative_model(_ns(scheme, "oracle"))
