@@ -1402,7 +1402,9 @@ int pk_eval_xpart_dev(pk_ctx* c, const double* d_x, double* d_f, double* d_grad,
   if (needs_I && !c->external_prepass && (rc = prepass(c, d_x, nullptr, 0.0, d_f, true, st))) return rc;
   // ONE launch instead of pk_xall + pk_fin: pk_cycle's grid without its Hessian role -- the partial sums reach the finalize
   // workgroup inside the launch (host shim at 12k nodes: f is in pinned memory ~5 us earlier, and so is everything behind it)
-  if (c->xpart_single && c->cycle_mode == 1 && !needs_I && !c->shard_flags && !c->external_prepass && c->profile_mask == 0)
+  // (a shard takes it too, like pk_eval_cycle_dev: its finalize workgroup leaves THIS shard's share of the integrals and of
+  //  the shared gradient slots for the caller to add up; never with the in-launch exchange, which belongs to whole cycles)
+  if (c->xpart_single && c->cycle_mode == 1 && !needs_I && c->profile_mask == 0 && !(c->xc_inline && c->xc_world > 1))
     return enqueue_single_launch_cycle(c, d_x, nullptr, 0.0, d_f, d_grad, d_g, d_jac, nullptr, st);
   PkArgs A = base_args(c, d_x, nullptr, 0.0);
   A.o_f = d_f; A.o_grad = d_grad; A.o_g = d_g; A.o_jac = d_jac;
