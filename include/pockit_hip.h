@@ -180,6 +180,7 @@ int pk_set_result_targets(pk_ctx* ctx, double* f, double* grad, double* g, doubl
  *                     "xpart_single" (1: the x-results of a new iterate come from ONE launch, pk_cycle without its Hessian role),
  *                     "adaptive_prefetch" (1: grad f and J of a new iterate are copied ahead only
  *                     if they were asked for at the previous one -- a line search's rejected trial points ask for f and g only),
+ *                     "small_x_kb" (128: the x threshold of small_direct in KB, an A/B knob),
  *                     "small_direct" (1: an x of <= 128 KB is read by the kernels from its pinned staging buffer, x-results of
  *                     <= 1 MB are stored by the kernel straight into the landing block: no upload / copy launches)
  *                     -- see pk_runtime.cpp. */

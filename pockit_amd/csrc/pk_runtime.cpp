@@ -174,6 +174,7 @@ struct pk_ctx {
   int small_direct = 1;        // small systems are bound by the number of launches, not by bytes: a kernel reads an x of at most
                                // 128 KB from its pinned staging buffer (no upload launch) and stores x-results of at most 1 MB
                                // straight into their pinned landing places (no copy launches) -- LQR 10x10: 53 -> us per iterate
+  int small_x_kb = 128;            // (the x threshold of small_direct, in KB: an A/B knob)
   const double* x_src = nullptr;   // where the kernels read the prepared x: d_x, or (small_direct) the pinned staging buffer
   int xpart_single = 1;        // pk_eval_xpart_dev as ONE launch (pk_cycle without its Hessian role) instead of pk_xall + pk_fin
   int hess_direct = 1;         // the Hessian kernel stores into the pinned landing place itself when H is small enough for the
@@ -1763,7 +1764,7 @@ int pk_host_free(void* p) {
 }
 
 namespace {
-bool small_x(const pk_ctx* c) { return c->small_direct && sizeof(double) * (size_t)c->n <= ((size_t)128 << 10); }
+bool small_x(const pk_ctx* c) { return c->small_direct && sizeof(double) * (size_t)c->n <= ((size_t)c->small_x_kb << 10); }
 bool small_results(const pk_ctx* c) {
   const size_t nj = (size_t)(c->jac_compact ? c->nnz_Jc : c->nnz_J);
   return c->small_direct && sizeof(double) * (nj + (size_t)c->n + (size_t)c->m) <= ((size_t)1 << 20);
@@ -2126,6 +2127,7 @@ int pk_set_host_option(pk_ctx* c, const char* name, int value) {
   else if (!std::strcmp(name, "hess_direct")) c->hess_direct = value != 0;
   else if (!std::strcmp(name, "xpart_single")) c->xpart_single = value != 0;
   else if (!std::strcmp(name, "small_direct")) c->small_direct = value != 0;
+  else if (!std::strcmp(name, "small_x_kb")) c->small_x_kb = value < 0 ? 0 : (value > (1 << 20) ? (1 << 20) : value);
   else if (!std::strcmp(name, "adaptive_prefetch")) { c->adaptive_prefetch = value != 0; c->cur_J_asked = true; }
   else if (!std::strcmp(name, "mark_wait")) { c->mark_wait = value != 0; c->mark_pending = false; }
   else return fail(c, 67, "pk_set_host_option: unknown option \"%s\"", name);

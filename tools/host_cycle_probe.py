@@ -103,12 +103,12 @@ def report(label, modes=("fresh arrays", "fresh arrays, compact Hessian")):
 print("2. System callbacks (defaults)")
 report("defaults", ("fresh arrays", "zero-copy views", "fresh arrays, compact Hessian"))
 print("3. switches")
-DEFAULTS = {"small_direct": 1, "xpart_single": 1, "mark_wait": 1, "hess_direct": 1, "spin_wait": 1, "lambda_direct": 1, "chunk_upload": 1, "kernel_upload": 1, "kernel_download": 8, "split_copy": 1,
+DEFAULTS = {"small_x_kb": 128, "small_direct": 1, "xpart_single": 1, "mark_wait": 1, "hess_direct": 1, "spin_wait": 1, "lambda_direct": 1, "chunk_upload": 1, "kernel_upload": 1, "kernel_download": 8, "split_copy": 1,
             "speculative_hess": 1}
 if os.environ.get("PROBE_ONLY"):          # PROBE_ONLY=hess_direct,split_copy: A/B of these switches only
     DEFAULTS = {k: v for k, v in DEFAULTS.items() if k in os.environ["PROBE_ONLY"].split(",")}
 for name, dflt in DEFAULTS.items():
-    for other in ((0, 4, 64, 1024) if name == "kernel_download" else (1 - dflt,)):
+    for other in ((0, 4, 64, 1024) if name == "kernel_download" else (0, 512, 1024, 8192) if name == "small_x_kb" else (1 - dflt,)):
         ev.ctx.check(lib.pk_set_host_option(h, name.encode(), other))
         report(f"{name} = {other}")
     ev.ctx.check(lib.pk_set_host_option(h, name.encode(), dflt))
