@@ -323,6 +323,32 @@ def test_hessian_stored_into_the_landing_array_by_its_kernel_equals_the_copied_o
     ev.ctx.check(lib.pk_set_host_option(h, b"hess_direct", 1))
 
 
+@pytest.mark.parametrize("mesh", [12, 301])          # (a small system: kernels store into the landing block; a larger one: copies)
+def test_line_search_trial_points_then_an_accepted_point(mesh):
+    """What IPOPT's backtracking does to the callbacks: rejected trial points ask for the objective and the constraints only,
+    the accepted point for everything.  Behind a rejected point grad f / J are no longer copied ahead (host option
+    "adaptive_prefetch") but fetched when asked for -- every value must still be the one of ITS x."""
+    system, _, guess = models.planar_quadrotor(_ns("radau", "pockit_amd"), mesh, 6)
+    ref, _, _ = models.planar_quadrotor(_ns("radau", "oracle"), mesh, 6)
+    x, lam, sigma = models.bench_inputs(system, guess)
+    rng = np.random.default_rng(mesh)
+    for it in range(6):
+        for _ in range(it % 3):                                   # 0, 1 or 2 rejected trial points
+            xt = x * (1 + 1e-3 * rng.standard_normal(x.size))
+            close(system.objective(xt), ref.objective(xt), what="trial f")
+            close(system.constraints(xt), ref.constraints(xt), what="trial g")
+        xa = x * (1 + 1e-3 * rng.standard_normal(x.size))
+        close(system.objective(xa), ref.objective(xa), what="f")
+        g = system.constraints(xa)
+        grad = system.gradient(xa)
+        J = system.jacobian(xa)
+        H = system.hessian(xa, lam, sigma)
+        close(grad, ref.gradient(xa), what="grad")
+        close(g, ref.constraints(xa), what="g")
+        close(J, ref.jacobian(xa), what="J")
+        close(H, ref.hessian(xa, lam, sigma), what="H")
+
+
 def test_prepared_x_cache_is_dropped_by_calls_that_reuse_the_context_buffers():
     """objective / gradient / constraints / jacobian / hessian on x1 serve from ONE upload of x1; any other entry
     point that uploads a different x (mesh error, the one-launch cycle, the *_direct and CSR calls) in between must
