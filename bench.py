@@ -255,7 +255,21 @@ def end_to_end(system, guess, steps, warmup):
         modes.append("fresh_arrays_compact_hessian")      # the same five callbacks for a solver handed the compact H structure
     if ev.src.compact and ev.src.compact_j:
         modes.append("fresh_arrays_compact_layouts")      # ... and the compact J structure as well
+    started_helpers = False
+    if not ev.host_helper_threads:
+        # a side figure, NOT the headline: the same five callbacks with the library's helper threads taking slices of the solver
+        # thread's own passes over x and lambda (compares, staging copies) although x is below the 2 MB from which they start by
+        # themselves -- what POCKIT_AMD_HOST_THREADS=k buys a solver that has cores to spare
+        modes.append("fresh_arrays_host_helpers")
     for mode in modes:
+        if mode == "fresh_arrays_host_helpers":
+            from pockit_amd import runtime as _rt
+
+            k_helpers = _rt.host_helpers(ev.ctx.lib, system.plan.n, force=True)
+            started_helpers = k_helpers > 0
+            if not started_helpers:
+                out[mode] = {"host_helper_threads": 0, "note": "a measured pass was not a quarter faster with helpers on this host"}
+                continue
         ev.zero_copy = mode == "zero_copy_views"
         system.set_hessian_layout("compact" if mode.endswith(("compact_hessian", "compact_layouts")) else "reference")
         system.set_jacobian_layout("compact" if mode.endswith("compact_layouts") else "reference")
@@ -279,6 +293,13 @@ def end_to_end(system, guess, steps, warmup):
         out[mode] = {"cycles_per_s": 1.0 / m[5], "ms_per_cycle": m[5] * 1e3,
                      "per_callback_ms": {nm: m[i] * 1e3 for i, nm in enumerate(names)},
                      "min_ms_per_cycle": min(r[5] for r in rows) * 1e3, "max_ms_per_cycle": max(r[5] for r in rows) * 1e3}
+        if mode == "fresh_arrays_host_helpers":
+            out[mode]["host_helper_threads"] = int(k_helpers)
+    if started_helpers:
+        from pockit_amd import runtime as _rt
+
+        ev.ctx.lib.pk_host_threads(0)
+        _rt.host_helpers_stopped()
     ev.zero_copy = False
     system.set_hessian_layout("reference")
     system.set_jacobian_layout("reference")

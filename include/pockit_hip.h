@@ -144,7 +144,7 @@ int pk_eval_hessc_prepared(pk_ctx* ctx, const double* lambda, double sigma, doub
 int pk_same_x(pk_ctx* ctx, const double* x);
 int pk_same_bits(const double* a, const double* b, size_t n);   /* 1 if equal bit for bit (memcmp), for host shims */
 int pk_copy_bits(double* dst, const double* src, size_t n);      /* dst = src (non-overlapping), for host shims */
-/* k helper threads (0 = none, the default; <= 16) that take slices of pk_same_bits / pk_copy_bits passes of 1 MB and more:
+/* k helper threads (0 = none, the default; <= 16) that take slices of pk_same_bits / pk_copy_bits passes of 256 KB and more:
  * rank 0 of the host-landed sharded cycle stages and compares an x that is N times as long as one GPU's.
  * Process-wide; helpers spin for 1 ms after the last pass, otherwise they sleep in 20 us steps. */
 int pk_host_threads(int k);

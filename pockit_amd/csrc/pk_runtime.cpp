@@ -1650,7 +1650,7 @@ struct HostPool {
   }
 };
 std::unique_ptr<HostPool> g_pool;
-constexpr size_t kPoolMinBytes = (size_t)1 << 20;     // shorter passes are done by the caller alone
+constexpr size_t kPoolMinBytes = (size_t)256 << 10;   // shorter passes are done by the caller alone
 }  // namespace
 
 extern "C" {

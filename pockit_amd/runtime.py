@@ -325,7 +325,7 @@ class PinnedRing:
 _HOST_HELPERS = {"k": None}       # None: not decided in this process yet; 0: tried and dropped; k: running
 
 
-def host_helpers(lib, n, world=1):
+def host_helpers(lib, n, world=1, force=False):
     """Start the library's helper threads (``pk_host_threads``) for a solver thread whose x has ``n`` doubles -- once per process,
     only from 2 MB on, as many as this process's share of the host's cores allows (at most 6; POCKIT_AMD_HOST_THREADS=k
     overrides, 0 = none), and only if a measured pass over n doubles is at least a quarter faster with them.  Returns the
@@ -335,7 +335,10 @@ def host_helpers(lib, n, world=1):
     import time
 
     env = os.environ.get("POCKIT_AMD_HOST_THREADS", "auto")
-    if 8 * n < (2 << 20) or env == "0":
+    # (``force``, or an explicit POCKIT_AMD_HOST_THREADS=k: also for an x below 2 MB -- the library uses helpers from 256 KB per
+    #  pass on.  Not the default there: the helpers spin for a millisecond after every pass, which a tight loop of small
+    #  iterates turns into permanently busy cores)
+    if env == "0" or (8 * n < (2 << 20) and not force and not env.isdigit()):
         return _HOST_HELPERS["k"] or 0
     if _HOST_HELPERS["k"] is not None:
         return _HOST_HELPERS["k"]
