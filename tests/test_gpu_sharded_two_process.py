@@ -270,6 +270,20 @@ def _host_worker(rank, world, port, case, ret):
                     a, b = np.asarray(got[key], dtype=np.float64), np.asarray(want[key], dtype=np.float64)
                     assert a.shape == b.shape, key
                     err = max(err, float(np.max(np.abs(a - b)) / scale(b)) if b.size else 0.0)
+            # a line search: two rejected trial points (objective and constraints only), then an accepted one whose J slices
+            # were not sent ahead and come on request (CMD_X_TRIAL / CMD_J)
+            for rep in range(3, 6):
+                xk = x * (1.0 + 1e-3 * rep)
+                got_f, got_g = hs.objective(xk), hs.constraints(xk)
+                err = max(err, abs(float(got_f) - ref.objective(xk)) / scale(np.array([ref.objective(xk)])),
+                          float(np.max(np.abs(np.asarray(got_g) - ref.constraints(xk))) / scale(ref.constraints(xk))))
+            xk = x * (1.0 + 7e-3)
+            hs.h_out[:] = np.nan
+            got = dict(f=hs.objective(xk), g=hs.constraints(xk), grad=hs.gradient(xk), J=hs.jacobian(xk), H=hs.hessian(xk, lam, sigma))
+            want = dict(f=ref.objective(xk), grad=ref.gradient(xk), g=ref.constraints(xk), J=ref.jacobian(xk), H=ref.hessian(xk, lam, sigma))
+            for key in ("f", "grad", "g", "J", "H"):
+                a, b = np.asarray(got[key], dtype=np.float64), np.asarray(want[key], dtype=np.float64)
+                err = max(err, float(np.max(np.abs(a - b)) / scale(b)) if b.size else 0.0)
             err = float("inf") if not np.isfinite(err) else err
         hs.close()
         flag = torch.tensor([err])
