@@ -22,7 +22,10 @@ the J slices have, and when the H slices have.  Rank 0 polls those words -- it n
 that its GPU has finished -- and returns objective / gradient / constraints while J is still on the links (``jacobian``
 waits for the second mark).  ``hessian`` launches on the prepared x before it compares x with it.
 
-Only models whose system-level functions are linear in the integrals (none of BASELINE's configs is otherwise).
+Models whose objective or system constraints are nonlinear in the integrals (easyderiv.py:323-459; none of BASELINE's configs)
+take one more round trip per x: every rank's share of the integrals first (``CMD_INT``), rank 0 adds them up and hands the totals
+back, then the x-part proper; the outer-product blocks of their Hessian are formed by rank 0's GPU from all ranks' auxiliary
+entries, which travel through the segment too.
 torch.distributed is used at set-up only (the segment's name).
 """
 from __future__ import annotations
@@ -38,12 +41,15 @@ import sympy as sp
 from .evaluator import Evaluator, _intervals_per_wave
 from .sharding import needed_x_runs, owned_runs, run_table, shared_gradient_slots, tile_filter
 
-CMD_EXIT, CMD_X, CMD_HESS, CMD_X_TRIAL, CMD_J = 0, 1, 2, 3, 4      # (CMD_X_TRIAL: an x-part whose J slices stay on the GPUs until CMD_J)
+CMD_EXIT, CMD_X, CMD_HESS, CMD_X_TRIAL, CMD_J, CMD_INT = 0, 1, 2, 3, 4, 5
+# (CMD_X_TRIAL: an x-part whose J slices stay on the GPUs until CMD_J; CMD_INT: models nonlinear in the integrals -- every rank's
+#  share of the integrals first, rank 0 adds them up and hands the totals back before the x-part proper)
 MAX_RANKS = 56
-CTRL_WORDS = 256         # control block: [0] sequence number, [1] command, [2] pid of rank 0 (liveness), [8 + r] last sequence
+CTRL_WORDS = 384         # control block: [0] sequence number, [1] command, [2] pid of rank 0 (liveness), [8 + r] last sequence
                          # rank r's HOST loop has drained; progress marks written by rank r's GPU behind its copies (a one-word
                          # kernel, pk_store_word_dev): [MARK_EARLY + r] sequence whose partial sums, grad f and g slices have
 MARK_EARLY, MARK_X, MARK_H = 64, 128, 192      # landed, [MARK_X + r] ... whose J slices have landed, [MARK_H + r] ... H slices
+MARK_INT, MARK_AUX = 256, 320                  # (models nonlinear in the integrals: rank r's integrals / auxiliary entries are in)
 
 
 class _AttachedSegment:
@@ -75,8 +81,10 @@ class HostShardedEvaluator:
     """See the module docstring.  ``dist``: an initialised torch.distributed module (any backend; used once)."""
 
     def __init__(self, plan, rank, world, dist, device=0, intervals_per_wave=None, timeout_s=120.0):
-        if plan.outer or plan.needs_I_grad or plan.needs_I_con or plan.jac.needs_I or plan.hess.needs_I:
-            raise NotImplementedError("the host-landed sharded cycle needs system functions that are linear in the integrals")
+        # objective / system constraints nonlinear in the integrals (easyderiv.py:323-459): the integrals must be complete before
+        # every other kernel, and the outer-product Hessian blocks are formed by rank 0 from all ranks' auxiliary entries
+        self.needs_I = bool(plan.outer or plan.needs_I_grad or plan.needs_I_con or plan.jac.needs_I or plan.hess.needs_I)
+        self.n_aux = int(plan.n_aux) if plan.outer else 0
         if world > MAX_RANKS:
             raise ValueError(f"at most {MAX_RANKS} ranks")
         self.plan, self.rank, self.world, self.timeout_s = plan, rank, world, float(timeout_s)
@@ -98,7 +106,9 @@ class HostShardedEvaluator:
         off["x"] = off["sigma"] + 8
         off["lam"] = off["x"] + n
         off["part"] = off["lam"] + m
-        off["out"] = -(-(off["part"] + world * self.n_small) // 16) * 16       # 128-byte aligned
+        off["I"] = off["part"] + world * self.n_small            # (the summed integrals, handed back to every rank)
+        off["aux"] = off["I"] + self.n_I                         # (all ranks' auxiliary entries, for rank 0's outer-product blocks)
+        off["out"] = -(-(off["aux"] + self.n_aux) // 16) * 16    # 128-byte aligned
         off["f"] = off["out"] + self.total
         words = off["f"] + 8
         self.off = off
@@ -136,6 +146,7 @@ class HostShardedEvaluator:
         view = lambda key, cnt: self.words[off[key]: off[key] + cnt]  # noqa: E731
         self.h_x, self.h_lam, self.h_sigma = view("x", n), view("lam", m), view("sigma", 1)
         self.h_part = view("part", world * self.n_small).reshape(world, self.n_small)
+        self.h_I = view("I", self.n_I)
         self.h_out, self.h_f = view("out", self.total), view("f", 1)
         self.out = {"grad": self.h_out[:n], "g": self.h_out[n: n + m], "J": self.h_out[n + m: n + m + plan.nnz_J],
                     "H": self.h_out[n + m + plan.nnz_J:]}
@@ -197,8 +208,19 @@ class HostShardedEvaluator:
         self.tab_j_changing = table(minus(rj, const)) if const else self.tab_j
         self._x_filled = False
         word = lambda i: C.c_void_p(self._dev_base.value + 8 * int(i))  # noqa: E731
-        self._mark_dev = {k: word(base + rank) for k, base in (("early", MARK_EARLY), ("x", MARK_X), ("h", MARK_H))}
-        self._marks = {k: self.ctrl[base: base + world] for k, base in (("early", MARK_EARLY), ("x", MARK_X), ("h", MARK_H))}
+        bases = (("early", MARK_EARLY), ("x", MARK_X), ("h", MARK_H), ("int", MARK_INT), ("aux", MARK_AUX))
+        self._mark_dev = {k: word(base + rank) for k, base in bases}
+        self._marks = {k: self.ctrl[base: base + world] for k, base in bases}
+        if self.needs_I:
+            self.tab_int = self._upload_table(np.array([[0, rank * self.n_small, self.n_I]], dtype=np.int64))   # d_small -> part
+            self.tab_I_in = self._upload_table(np.array([[0, 0, self.n_I]], dtype=np.int64))                    # h_I -> d_small
+        if self.n_aux:
+            from .sharding import owned_aux_runs
+
+            p_aux, cnt = C.c_void_p(), C.c_int64()
+            chk(lib.pk_aux_buffer(h, C.byref(p_aux), C.byref(cnt)))
+            self.d_aux = p_aux
+            self.tab_aux = table(owned_aux_runs(plan, self.ev.tables, rank == 0))
         # what this rank reads of x: uploaded by a run copy over its own link (1 / N of x per link, not N copies of x)
         xr = needed_x_runs(plan, self.ev.tables, rank == 0)
         self.tab_xin = table(xr)
@@ -278,7 +300,10 @@ class HostShardedEvaluator:
         the J slices stay in device memory (a line search's trial point asks for f and g only; ``_do_j`` sends them if the
         point is accepted)."""
         lib, h, chk = self.lib, self.h, self.chk
-        self._runs(self.tab_xin, self._dev("x"), self.d_x)                               # this rank's part of x, over ITS link
+        if self.needs_I:       # (x came up with CMD_INT; now the integrals summed over the ranks, where the kernels read them)
+            self._runs(self.tab_I_in, self._dev("I"), self.d_small)
+        else:
+            self._runs(self.tab_xin, self._dev("x"), self.d_x)                           # this rank's part of x, over ITS link
         # the fused x-kernel on this shard's tiles: its slices of grad f / g / J, its share of the integrals (-> d_small)
         # and its partial sums of the shared gradient slots (f is rank 0's to compute from the summed integrals)
         chk(lib.pk_eval_xpart_dev(h, self.d_x, self.d_f, self.d_out["grad"], self.d_out["g"], self.d_out["J"], None))
@@ -288,6 +313,13 @@ class HostShardedEvaluator:
         chk(lib.pk_store_word_dev(h, self._mark_dev["early"], seq, None))
         if with_j:
             self._do_j(seq)
+
+    def _do_int(self, seq):
+        """Models nonlinear in the integrals, first half of an x-part: x up, this shard's share of every integral, into the segment."""
+        self._runs(self.tab_xin, self._dev("x"), self.d_x)
+        self.chk(self.lib.pk_eval_integrals_dev(self.h, self.d_x, None))
+        self._runs(self.tab_int, self.d_small, self._dev("part"))
+        self.chk(self.lib.pk_store_word_dev(self.h, self._mark_dev["int"], seq, None))
 
     def _do_j(self, seq):
         # owned runs of J -> the solver's array (the first time all of them, then only what changes with x)
@@ -299,10 +331,17 @@ class HostShardedEvaluator:
         lib, h, chk = self.lib, self.h, self.chk
         # the Hessian kernel reads the multipliers from the (page-locked) segment itself: every rank then moves only the rows
         # of ITS tiles over its link, and there is no upload in front of the kernel
-        if self.h_direct:      # a small share of H: the kernel's own stores go over the link (no copy launch behind it)
-            chk(lib.pk_eval_hess_dev(h, self.d_x, self._dev("lam"), float(self.h_sigma[0]), self._h_host, None))
-        else:
-            chk(lib.pk_eval_hess_dev(h, self.d_x, self._dev("lam"), float(self.h_sigma[0]), self.d_out["H"], None))
+        target = self._h_host if self.h_direct else self.d_out["H"]      # (a small share of H: the kernel's own stores go over
+        chk(lib.pk_eval_hess_dev(h, self.d_x, self._dev("lam"), float(self.h_sigma[0]), target, None))      # the link, no copy)
+        if self.n_aux:
+            # outer-product blocks: every rank's auxiliary entries (of ITS nodes) into the segment; rank 0 forms the blocks from
+            # all of them (the only place a rank waits for the others inside a command)
+            self._runs(self.tab_aux, self.d_aux, self._dev("aux"))
+            chk(lib.pk_store_word_dev(h, self._mark_dev["aux"], seq, None))
+            if self.rank == 0:
+                self._wait_marks("aux", seq)
+                chk(lib.pk_eval_outer_dev(h, self._dev("aux"), target, None))
+        if not self.h_direct:
             self._runs(self.tab_h, self.d_full, self._dev("out"))
         chk(lib.pk_store_word_dev(h, self._mark_dev["h"], seq, None))
 
@@ -386,6 +425,8 @@ class HostShardedEvaluator:
                 self._do_x_part(seq, with_j=False)
             elif cmd == CMD_J:
                 self._do_j(seq)
+            elif cmd == CMD_INT:
+                self._do_int(seq)
             elif cmd == CMD_HESS:
                 self._do_hess(seq)
             drained = False
@@ -416,6 +457,14 @@ class HostShardedEvaluator:
         self.lib.pk_copy_bits(self.h_x.ctypes.data, x.ctypes.data, self.plan.n)
         # J slices go ahead only while the solver keeps asking for grad f / J: an iterate it did not ask them for was a rejected
         # trial point of a line search, and its J on the links stood in the way of the next trial point's x
+        if self.needs_I:
+            seq = self._post(CMD_INT)
+            self._do_int(seq)
+            self._wait_marks("int", seq)
+            total = self.h_part[0, : self.n_I].copy()
+            for r in range(1, self.world):    # rank order: reproducible sums
+                total += self.h_part[r, : self.n_I]
+            self.h_I[:] = total
         ahead = self._j_asked
         self._j_asked = False
         seq = self._post(CMD_X if ahead else CMD_X_TRIAL)
@@ -425,7 +474,7 @@ class HostShardedEvaluator:
         small = self.h_part[0].copy()
         for r in range(1, self.world):        # rank order: reproducible sums
             small += self.h_part[r]
-        I = small[: self.n_I]
+        I = self.h_I if self.needs_I else small[: self.n_I]      # (needs_I: every rank's d_small[:n_I] held the TOTALS)
         s = x[self.plan.l_s: self.plan.r_s]
         args = [float(v) for v in I[: len(self.plan.I_syms)]] + [float(v) for v in s]
         self.h_f[0] = self._F_o(*args) if self._F_o is not None else self._F_const

@@ -126,6 +126,31 @@ def owned_runs(plan, tables, primary):
     return [(a, b) for a, b in runs if b > a]
 
 
+def owned_aux_runs(plan, tables, primary):
+    """Contiguous runs [(start, stop)] of the AUXILIARY buffer (the quadrature-weighted gradient entries of the integrals, one per
+    middle node, that the outer-product Hessian blocks of a model nonlinear in the integrals are formed from; plan.aux) filled
+    by the tiles in ``tables``; ``primary`` adds the boundary / system-level scalars (rank 0's)."""
+    runs = []
+    tiles = tables.tiles
+    for k, pp in enumerate(plan.phase_plans):
+        lay = pp.layout
+        mine = tiles[(tiles["phase"] == k) & (tiles["nj"] > 0)]
+        if len(mine) == 0:
+            continue
+        first, last = mine[0], mine[-1]
+        stride = int(lay.stride[int(last["j0"])])
+        q_lo = int(first["q0"])
+        nq = int(last["nj"]) * stride + (1 if lay.scheme == "lgl" else 0)
+        q_hi = int(last["q0"]) + (nq - 1 if (lay.scheme == "lgl" and not last["last"]) else nq)
+        m_lo, m_hi = max(q_lo, lay.mid_lo), min(q_hi, lay.mid_hi)
+        if m_hi > m_lo:
+            for sg in plan.aux.segs[k]:
+                runs.append((sg.base + m_lo - lay.mid_lo, sg.base + m_hi - lay.mid_lo))
+    if primary:
+        runs += [(it.pos, it.pos + 1) for it in plan.aux.items]
+    return [(a, b) for a, b in runs if b > a]
+
+
 def needed_x_runs(plan, tables, primary):
     """Contiguous runs [(start, stop)] of the NLP vector x that the tiles in ``tables`` (one rank's shard) read: per phase
     and variable the nodes of its tiles (plus the LGR end slot behind the last one), the phase's t0 / tf and the static

@@ -301,7 +301,11 @@ def _host_worker(rank, world, port, case, ret):
 @pytest.mark.parametrize("world", [2, 3])
 @pytest.mark.parametrize("case", [("two_stage_rocket", "radau", dict(mesh=40, num_point=4)),
                                   ("planar_quadrotor", "lobatto", dict(mesh=33, num_point=5)),
-                                  ("brachistochrone", "radau", dict(mesh=[0, 0.2, 0.3, 0.5, 0.8, 1.0], num_point=[70, 5, 6, 66, 7]))])
+                                  ("brachistochrone", "radau", dict(mesh=[0, 0.2, 0.3, 0.5, 0.8, 1.0], num_point=[70, 5, 6, 66, 7])),
+                                  # nonlinear in the integrals: the integrals go round first (CMD_INT), rank 0 forms the outer-product
+                                  # Hessian blocks from every rank's auxiliary entries
+                                  ("derivative_model", "radau", dict(mesh=(0, .1, .2, .35, .5, .6, .75, .9, 1), num_point=(3, 4, 3, 4, 5, 4, 3, 4))),
+                                  ("derivative_model", "lobatto", dict(mesh=(0, .2, .5, .7, 1), num_point=(4, 70, 5, 6)))])
 def test_host_landed_sharded_cycle_matches_oracle(case, world):
     import torch.multiprocessing as mp
 
