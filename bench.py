@@ -4,1107 +4,58 @@
     python bench.py --gpus N --steps K --warmup W
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
-A *step* is one NLP-callback cycle as a solver sees it (what the reference's
-``SystemBase`` returns to cyipopt, systembase.py:602-835 / optimizer/ipopt.py:41-53): objective, gradient, constraints,
-jacobian, hessian of ``System`` called in IPOPT's order on a NEW x, host NumPy arrays in, host NumPy arrays the caller owns
-out (reference triplet layout).  ``value`` = those cycles per second: x and lambda cross PCIe up, every result crosses it
-down (round 2's headline was the device-resident launch rate of the same cycle; it is kept, with its roofline, under
-``device_resident`` / ``roofline``: the kernel's quality is read there, the solver's throughput in ``value``).
+A *step* is one NLP-callback cycle (systembase.py:602-835 of the reference): objective, gradient,
+constraints, jacobian, hessian on one x, lambda, sigma.  Workload (BASELINE.json metric: "at 10k LGR nodes"):
+planar_quadrotor re-meshed on LGR 2000 intervals x 6 points = 12 000 nodes (configs[2]), x = example guess * (1 + 1e-3 U),
+lambda ~ N(0,1), sigma = 1, all seeded.  N > 1: 2000*N intervals of the same model sharded by mesh interval over the N GPUs
+(weak scaling), figures in 12k-node-equivalent cycles/s.
 
-Workload (BASELINE.json metric: "at 10k LGR nodes"): planar_quadrotor re-meshed on LGR 2000 intervals x 6 points =
-12 000 nodes (configs[2], the ~10k-node headline of BASELINE.md), x = example guess * (1 + 1e-3 U), lambda ~ N(0,1),
-sigma = 1, all seeded.  For N > 1 the mesh is 2000*N intervals of the same model, sharded by mesh interval over the N
-GPUs (weak scaling: 2000 intervals per GPU), every GPU landing its slices of the outputs in ONE host array over its own
-PCIe link (pockit_amd/hostshard.py); ``value`` is then in 12k-node-equivalent cycles/s (= N * cycles/s of the N-times
-larger system).
+What is printed: rank 0 prints ONE short JSON line LAST (strict JSON, < 4 KB, fixed keys: tools/benchlib/line.py) and
+writes everything else it measured -- timing statistics, per-callback tables, side kernels, the other BASELINE workloads --
+to ``bench_detail.json`` beside this file (and to gpurun_out/ when that directory exists).
+* ``value`` / ``ms_per_step`` / ``device_resident``: the cycle with x, lambda and all outputs resident in HBM, ONE pk_cycle
+  launch per cycle; R back-to-back batches of EXACTLY ``steps`` launches, HIP events on the launch stream, barrier +
+  synchronize around the region, median batch / steps, max over ranks.  ``roofline`` is computed from this region.
+* ``end_to_end``: the host-landed (solver-visible) cycle -- the five callbacks of ``System`` on a new x, NumPy arrays in,
+  caller-owned NumPy arrays out, reference triplet layout; PCIe-inclusive, therefore never ``value``.
+* ``cpu_baseline``: the oracle (CPU restatement of the reference) on the same workload and inputs, one host thread, a
+  bounded sample; ``parity``: every entry of the GPU path's f, grad f, g, J, H on those inputs against the oracle's.
 
-Timing of ``value``: after the warm-up cycles, R back-to-back batches of EXACTLY ``steps`` cycles (R such that the region
-lasts >= 0.2 s), each batch bracketed by the host clock -- a cycle ends with its Hessian in host memory, so the host clock
-sees all of it --, the whole region by synchronize (+ barrier); ``ms_per_step`` = median batch / steps (max over ranks).
-Timing of ``device_resident``: a cycle there is ONE 5 us launch; R batches of ``steps`` launches enqueued by the library
-(or replayed as a hipGraph, whichever is faster on the box), HIP events on the launch stream every >= 200 cycles, median.
-
-One JSON line is printed by rank 0 (see the repository prompt for the contract), carrying ``roofline`` for the
-dominant kernel (HIP events on the launch stream over the device-resident region) and ``cpu_baseline`` (the oracle =
-CPU restatement of the reference, timed on the host on the same five callbacks).
-"""
+Layout: tools/benchlib/workloads.py (workloads, inputs, algorithmic bytes, CPU baseline), timing.py (the GPU legs),
+line.py (assembly of the line and of the detail record; importable without a GPU)."""
 import os
 
 for _v in ("OMP_NUM_THREADS", "OPENBLAS_NUM_THREADS", "MKL_NUM_THREADS", "NUMEXPR_NUM_THREADS"):
     os.environ.setdefault(_v, "1")
 
 import argparse  # noqa: E402
-import ctypes as C  # noqa: E402
 import json  # noqa: E402
-import statistics  # noqa: E402
 import subprocess  # noqa: E402
 import sys  # noqa: E402
-import time  # noqa: E402
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-import numpy as np  # noqa: E402
-
-SHARDING_NOTE = {
-    "sums": "mesh intervals over {n} GPUs (shares balanced by output volume), one pk_cycle launch per rank on its tiles; every "
-            "rank's slices of grad/g/J/H stay in its own HBM at the reference positions; the sums over all nodes (integrals -> "
-            "f, gradient entries of t0/tf/static parameters) are exchanged through peer-mapped mailboxes by the launch's finalize "
-            "workgroup (or, where that is slower or unavailable, by a one-workgroup launch pk_xchg behind it: see "
-            "exchange_forms) -- no collective in the data path",
-    "direct": "mesh intervals over {n} GPUs, one pk_cycle launch per rank; the other ranks' kernels store their slices "
-              "straight into rank 0's buffer through hipIpc peer mappings (xGMI), pk_xchg flags completion",
-    "gather": "mesh intervals over {n} GPUs, one pk_cycle launch per rank, run-copy pack + RCCL gather to rank 0 + run-copy "
-              "unpack of the owned runs of grad/g/J/H (+ the partial sums)",
-    "allgather": "mesh intervals over {n} GPUs, one pk_cycle launch per rank, run-copy pack + RCCL all-gather + run-copy "
-                 "unpack of the owned runs of grad/g/J/H, tiny all-reduce of the partial sums",
-}
-HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
-HBM_ACHIEVABLE_GBPS = 6300.0   # what the guide's stream-type kernels reach (MI355X_MICROARCH.md: "~6.3 TB/s achievable")
-LAUNCH_FLOOR_US = 4.3          # a pk_cycle-shaped launch before its first output byte leaves (DESIGN.md section 5)
-KERNEL_IDS = {"pk_int": 0, "pk_fin": 1, "pk_g": 2, "pk_grad": 3, "pk_jac": 4, "pk_hess": 5, "pk_xall": 6, "pk_cycle": 12}
+from tools.benchlib import line as L  # noqa: E402
+from tools.benchlib.workloads import cpu_baseline  # noqa: E402
 
 
-def side_roofline(nbytes, us):
-    """Algorithmic bytes of one launch of a side kernel over its per-dispatch time, against the HBM roof."""
-    gbps = nbytes / (us * 1e-6) / 1e9 if us else None
-    return {"bound": "hbm", "algorithmic_bytes_per_launch": int(nbytes), "avg_launch_us": us, "achieved": gbps, "peak": HBM_PEAK_GBPS,
-            "unit": "GB/s", "frac": (gbps / HBM_PEAK_GBPS if gbps else None),
-            "frac_of_achievable": (gbps / HBM_ACHIEVABLE_GBPS if gbps else None)}
-MIN_REGION_S = 0.05        # the timed region lasts at least this long (R batches of `steps` cycles)
-EVENT_SPACING = 200        # cycles between two timing events of the region (an event costs ~3 us of GPU time)
-MIN_WARMUP = 500           # untimed launches before the timed region (single GPU), whatever --warmup says
-ISOLATED_SAMPLES = 200     # per-dispatch kernel timings on an idle stream (what a profiler's kernel trace measures)
-POINTS = {"planar_quadrotor": 6, "brachistochrone": 8, "two_stage_rocket": 4, "humanoid_wbc": 8}
-
-
-def algorithmic_bytes(plan):
-    """Per-kernel algorithmic traffic of one cycle:
-    B = 8 (5n + m + 1 + n + m + nnz_J + nnz_H): x read by each callback, lambda once, outputs once."""
-    n, m = plan.n, plan.m
-    per = {
-        "f": 8 * (n + 1),
-        "grad": 8 * (n + n),
-        "g": 8 * (n + m),
-        "jac": 8 * (n + plan.nnz_J),
-        "hess": 8 * (n + m + plan.nnz_H),
-    }
-    per["cycle"] = sum(per.values())
-    per["xall"] = 8 * (n + 1 + n + m + plan.nnz_J)      # fused x-kernel: x read once, f partials + grad + g + J written
-    per["cycle_x_once"] = per["cycle"] - 8 * 4 * n       # the single-launch cycle reads x once from HBM
-    return per
-
-
-def build_workload(name, intervals, ns):
-    from pockit_amd import benchmarks as models
-
-    if name.endswith("_lgl"):                       # Lobatto variant of a workload (side line of the bench)
-        import pockit_amd.lobatto as lobatto
-
-        return build_workload(name[:-4], intervals, lobatto)
-    return getattr(models, name)(ns, intervals, POINTS[name])
-
-
-def cpu_baseline(name, intervals, budget_s=12.0, max_cycles=5000):
-    """The oracle (NumPy restatement of the reference algorithm, single thread) on the same workload: the same five
-    callbacks with host arrays in and out."""
-    from pockit_amd import benchmarks as models
-    import oracle.radau
-
-    system, _, guess = build_workload(name, intervals, oracle.radau)
-    x, lam, sigma = models.bench_inputs(system, guess)
-
-    def cycle():
-        system.objective(x)
-        system.gradient(x)
-        system.constraints(x)
-        system.jacobian(x)
-        system.hessian(x, lam, sigma)
-
-    for _ in range(2):
-        cycle()
-    t0 = time.perf_counter()
-    n = 0
-    while n < max_cycles and time.perf_counter() - t0 < budget_s:
-        cycle()
-        n += 1
-    dt = time.perf_counter() - t0
-    return {"value": n / dt, "unit": "cycles/s", "cores": 1, "kind": "port",
-            "sample": f"{n} full cycles of the same workload ({name} LGR {intervals} intervals) in {dt:.1f} s, "
-                      f"NumPy oracle, 1 thread of {os.cpu_count()} host CPUs"}
-
-
-def solver_inputs(system, guess):
-    """x of consecutive cycles: two arrays with different values used in turn (every cycle sees a new x; a solver's iterate
-    was just written by the solver, i.e. it is warm in the host's caches -- two arrays keep that, eight 4.8 MB arrays of
-    the 40k-node system would come from DRAM every time)."""
-    from pockit_amd import benchmarks as models
-
-    x, lam, sigma = models.bench_inputs(system, guess)
-    return [x * (1.0 + 1e-9 * k) for k in range(2)], lam, sigma
-
-
-def pcie_floor(plan, shipped_J):
-    """The link of THIS box for the cycle's four transfers -- x up, [J (changing part) | grad f | g] down, lambda up, H down --
-    each as ONE pinned DMA + synchronize (what tools/pcie_probe.py measures), median of 30: the floor the host-landed
-    cycle is read against (``end_to_end.pcie_frac`` = floor / measured cycle)."""
-    import torch
-
-    dev = torch.device("cuda", torch.cuda.current_device())
-    sizes = {"x_up": plan.n, "xpart_down": shipped_J + plan.n + plan.m, "lambda_up": plan.m, "hess_down": plan.nnz_H}
-    out, total = {}, 0.0
-    for name, count in sizes.items():
-        d = torch.zeros(max(count, 1), dtype=torch.float64, device=dev)
-        hbuf = torch.zeros(max(count, 1), dtype=torch.float64).pin_memory()
-        src, dst = (hbuf, d) if name.endswith("_up") else (d, hbuf)
-        for _ in range(5):
-            dst.copy_(src, non_blocking=True)
-        torch.cuda.synchronize()
-        ts = []
-        for _ in range(30):
-            t0 = time.perf_counter()
-            dst.copy_(src, non_blocking=True)
-            torch.cuda.synchronize()
-            ts.append(time.perf_counter() - t0)
-        us = statistics.median(ts) * 1e6
-        out[name] = {"MB": 8 * count / 1e6, "us": us, "GBps": 8 * count / us / 1e3}
-        total += us
-    out["floor_us"] = total
-    # the wire alone: the cycle's bytes at the rate a 64 MB DMA reaches in each direction on this box (no per-transfer cost at
-    # all) -- a strict lower bound, whatever engine moves the bytes
-    big = 8 << 20
-    d = torch.zeros(big, dtype=torch.float64, device=dev)
-    hbuf = torch.zeros(big, dtype=torch.float64).pin_memory()
-    rate = {}
-    for name, (src, dst) in (("up", (hbuf, d)), ("down", (d, hbuf))):
-        for _ in range(2):
-            dst.copy_(src, non_blocking=True)
-        torch.cuda.synchronize()
-        ts = []
-        for _ in range(5):
-            t0 = time.perf_counter()
-            dst.copy_(src, non_blocking=True)
-            torch.cuda.synchronize()
-            ts.append(time.perf_counter() - t0)
-        rate[name] = 8 * big / min(ts) / 1e9
-    up = 8 * (sizes["x_up"] + sizes["lambda_up"])
-    down = 8 * (sizes["xpart_down"] + sizes["hess_down"])
-    out["wire"] = {"GBps_up_64MB": rate["up"], "GBps_down_64MB": rate["down"], "bytes_up": up, "bytes_down": down,
-                   "us": up / rate["up"] / 1e3 + down / rate["down"] / 1e3}
-    return out
-
-
-def five_callbacks(system, xk, lam, sigma):
-    system.objective(xk)
-    system.gradient(xk)
-    system.constraints(xk)
-    system.jacobian(xk)
-    system.hessian(xk, lam, sigma)
-
-
-def timed_cycles(cycle, steps, warmup, min_region_s=0.2, max_batches=400):
-    """``warmup`` untimed cycles, then R back-to-back batches of exactly ``steps`` cycles, each batch on the host clock.
-    ``cycle(k)`` runs cycle number k.  Returns the batch durations in seconds."""
-    k = 0
-    for _ in range(max(warmup, 10)):
-        cycle(k)
-        k += 1
-    t0 = time.perf_counter()
-    for _ in range(steps):
-        cycle(k)
-        k += 1
-    est = (time.perf_counter() - t0) / steps
-    R = int(min(max_batches, max(5, -(-min_region_s // (est * steps)))))
-    batches = []
-    for _ in range(R):
-        t0 = time.perf_counter()
-        for _ in range(steps):
-            cycle(k)
-            k += 1
-        batches.append(time.perf_counter() - t0)
-    return batches
-
-
-def end_to_end(system, guess, steps, warmup):
-    """The headline: the five callbacks of ``System`` (what cyipopt calls, optimizer/ipopt.py) with host NumPy arrays in
-    and out, every cycle on a NEW x, every callback returning an array the caller owns (the reference's semantics), in
-    the reference's triplet layout.  Beside it: the time of every callback, the same with zero-copy views / the compact
-    Hessian layout, all five outputs from one call, and the PCIe floor of this box measured in the same run."""
-    import torch
-
-    xs, lam, sigma = solver_inputs(system, guess)
-    ev = system.evaluator
-    names = ("objective", "gradient", "constraints", "jacobian", "hessian")
-    # (systems whose x has 2 MB or more: the solver thread's passes over x and lambda -- a compare per callback, the staging
-    #  copies -- are cut into slices for helper threads of the library; none at the 12k-node headline)
-    out = {"host_helper_threads": int(getattr(ev, "host_helper_threads", 0))}
-    torch.cuda.synchronize()
-    t_region = time.perf_counter()
-    batches = timed_cycles(lambda k: five_callbacks(system, xs[k & 1], lam, sigma), steps, warmup)
-    torch.cuda.synchronize()
-    wall = time.perf_counter() - t_region
-    q = sorted(batches)
-    med = statistics.median(batches)
-    out["headline"] = {"ms_per_step": med / steps * 1e3, "cycles_per_s": steps / med, "batches": len(batches), "steps": steps,
-                       "batch_ms_min_p10_p90_max": [q[0] * 1e3, q[int(0.1 * (len(q) - 1))] * 1e3, q[int(0.9 * (len(q) - 1))] * 1e3,
-                                                    q[-1] * 1e3],
-                       "region_wall_s": wall}
-    modes = ["fresh_arrays", "zero_copy_views"]
-    if ev.src.compact:
-        modes.append("fresh_arrays_compact_hessian")      # the same five callbacks for a solver handed the compact H structure
-    if ev.src.compact and ev.src.compact_j:
-        modes.append("fresh_arrays_compact_layouts")      # ... and the compact J structure as well
-    started_helpers = False
-    if not ev.host_helper_threads:
-        # a side figure, NOT the headline: the same five callbacks with the library's helper threads taking slices of the solver
-        # thread's own passes over x and lambda (compares, staging copies) although x is below the 2 MB from which they start by
-        # themselves -- what POCKIT_AMD_HOST_THREADS=k buys a solver that has cores to spare
-        modes.append("fresh_arrays_host_helpers")
-    for mode in modes:
-        if mode == "fresh_arrays_host_helpers":
-            from pockit_amd import runtime as _rt
-
-            k_helpers = _rt.host_helpers(ev.ctx.lib, system.plan.n, force=True)
-            started_helpers = k_helpers > 0
-            if not started_helpers:
-                out[mode] = {"host_helper_threads": 0, "note": "a measured pass was not a quarter faster with helpers on this host"}
-                continue
-        ev.zero_copy = mode == "zero_copy_views"
-        system.set_hessian_layout("compact" if mode.endswith(("compact_hessian", "compact_layouts")) else "reference")
-        system.set_jacobian_layout("compact" if mode.endswith("compact_layouts") else "reference")
-        rows = []
-        for k in range(15 + 100):
-            xk = xs[k & 1]
-            t = [time.perf_counter()]
-            system.objective(xk)
-            t.append(time.perf_counter())
-            system.gradient(xk)
-            t.append(time.perf_counter())
-            system.constraints(xk)
-            t.append(time.perf_counter())
-            system.jacobian(xk)
-            t.append(time.perf_counter())
-            system.hessian(xk, lam, sigma)
-            t.append(time.perf_counter())
-            if k >= 15:
-                rows.append([t[i + 1] - t[i] for i in range(5)] + [t[5] - t[0]])
-        m = [statistics.median(r[i] for r in rows) for i in range(6)]
-        out[mode] = {"cycles_per_s": 1.0 / m[5], "ms_per_cycle": m[5] * 1e3,
-                     "per_callback_ms": {nm: m[i] * 1e3 for i, nm in enumerate(names)},
-                     "min_ms_per_cycle": min(r[5] for r in rows) * 1e3, "max_ms_per_cycle": max(r[5] for r in rows) * 1e3}
-        if mode == "fresh_arrays_host_helpers":
-            out[mode]["host_helper_threads"] = int(k_helpers)
-    if started_helpers:
-        from pockit_amd import runtime as _rt
-
-        ev.ctx.lib.pk_host_threads(0)
-        _rt.host_helpers_stopped()
-    ev.zero_copy = False
-    system.set_hessian_layout("reference")
-    system.set_jacobian_layout("reference")
-    if "fresh_arrays_compact_layouts" in out:
-        out["fresh_arrays_compact_layouts"]["jacobian_values"] = int(system.plan.nnz_Jc)
-        out["fresh_arrays_compact_layouts"]["jacobian_values_reference_layout"] = int(system.plan.nnz_J)
-        out["fresh_arrays_compact_layouts"]["hessian_values"] = int(system.plan.nnz_Hc)
-    if "fresh_arrays_compact_hessian" in out:
-        out["fresh_arrays_compact_hessian"]["hessian_values"] = int(system.plan.nnz_Hc)
-        out["fresh_arrays_compact_hessian"]["hessian_values_reference_layout"] = int(system.plan.nnz_H)
-    # all five outputs from ONE call when the caller has lambda at hand (Evaluator.cycle: one pk_cycle launch, the copies
-    # into pinned arrays of the caller's own, one synchronization) -- not what IPOPT's call order allows, shown beside it
-    rows = []
-    for k in range(15 + 100):
-        t0 = time.perf_counter()
-        ev.cycle(xs[k & 1], lam, sigma)
-        if k >= 15:
-            rows.append(time.perf_counter() - t0)
-    out["one_call_cycle"] = {"cycles_per_s": 1.0 / statistics.median(rows), "ms_per_cycle": statistics.median(rows) * 1e3}
-    p = system.plan
-    kept = sum(b - a for a, b in ev.jac_constant_runs)
-    out["jacobian_values_never_shipped"] = {"count": int(kept), "of": int(p.nnz_J),
-                                            "what": "x-independent entries (translation part, phasebase.py:1071-1081): filled "
-                                                    "into every landing array once, left out of the per-iterate copy"}
-    out["bytes_over_pcie_per_cycle"] = 8 * (p.n + p.m + 1 + p.n + p.m + p.nnz_J - kept + p.nnz_H)
-    try:
-        floor = pcie_floor(p, p.nnz_J - kept)
-        out["pcie"] = floor
-        out["pcie_frac"] = floor["floor_us"] / (out["headline"]["ms_per_step"] * 1e3)
-        out["pcie_wire_frac"] = floor["wire"]["us"] / (out["headline"]["ms_per_step"] * 1e3)
-        out["pcie_frac_note"] = ("floor = x up + [J (changing part) | grad f | g] down + lambda up + H down, each measured here as "
-                                 "ONE pinned DMA + synchronize; pcie_frac = floor / measured cycle (the shim moves the bytes with copy kernels and "
-                                 "waits on a word its GPU stores: on a box whose DMA path is slow the ratio exceeds 1); pcie_wire_frac = "
-                                 "(bytes up / rate of a 64 MB DMA up + bytes down / rate of a 64 MB DMA down) / measured cycle: the wire alone, "
-                                 "a strict bound")
-    except Exception as exc:  # noqa: BLE001
-        out["pcie"] = {"error": repr(exc)}
-    out["what"] = ("objective, gradient, constraints, jacobian, hessian of System on a new x per cycle, NumPy arrays in "
-                   "and out; headline / fresh_arrays: every callback returns an array the caller owns (the reference's "
-                   "semantics; pinned memory the copy wrote directly), zero_copy_views: views of the context's pinned buffers "
-                   "(what the IPOPT adapter enables, cyipopt copies at once); fresh_arrays_compact_hessian: the same with "
-                   "System.set_hessian_layout('compact') -- one Hessian value per distinct position of a node (SURVEY 8(f) rank "
-                   "1), an optional mode with fewer bytes over PCIe")
-    return out
-
-
-def host_sharded_end_to_end(name, intervals, rank, world, dist, steps, warmup):
-    """N > 1, the headline: the five callbacks with host arrays, every rank landing its slices in ONE shared pinned host
-    array over its own PCIe link (pockit_amd.hostshard; SURVEY 8(e) "each GPU D2H's its own slices straight into the pinned
-    host array") -- the form that hands a host-side solver the reassembled COO triplets.  Rank 0 plays the solver, the other
-    ranks serve.  Every rank walks through the same collectives whatever fails locally."""
-    import torch
-
-    from pockit_amd.hostshard import HostShardedEvaluator
-    import pockit_amd.radau as radau
-
-    hs, problem, system = None, None, None
-    try:
-        system, _, guess = build_workload(name, intervals, radau)
-        hs = HostShardedEvaluator(system.plan, rank, world, dist, device=torch.cuda.current_device(), timeout_s=90.0)
-    except Exception as exc:  # noqa: BLE001
-        problem = f"rank {rank}: {exc!r}"
-    verdicts = [problem]
-    if world > 1:
-        verdicts = [None] * world
-        dist.all_gather_object(verdicts, problem)
-    failed = sorted(set(v for v in verdicts if v))
-    if failed:
-        if hs is not None:
-            hs.close()
-        return {"error": "; ".join(failed)}
-    out = None
-    try:
-        if rank != 0:
-            hs.serve()
-        else:
-            xs, lam, sigma = solver_inputs(system, guess)
-            names = ("objective", "gradient", "constraints", "jacobian", "hessian")
-            batches = timed_cycles(lambda k: five_callbacks(hs, xs[k & 1], lam, sigma), steps, warmup)
-            med = statistics.median(batches)
-            q = sorted(batches)
-            rows = []
-            for k in range(40):
-                xk = xs[k & 1]
-                t = [time.perf_counter()]
-                hs.objective(xk)
-                t.append(time.perf_counter())
-                hs.gradient(xk)
-                t.append(time.perf_counter())
-                hs.constraints(xk)
-                t.append(time.perf_counter())
-                hs.jacobian(xk)
-                t.append(time.perf_counter())
-                hs.hessian(xk, lam, sigma)
-                t.append(time.perf_counter())
-                rows.append([t[i + 1] - t[i] for i in range(5)])
-            per = [statistics.median(r[i] for r in rows) for i in range(5)]
-            p = system.plan
-            finite = bool(np.isfinite(hs.h_out).all() and np.isfinite(hs.h_f[0]))
-            out = {"cycles_per_s": steps / med, "ms_per_cycle": med / steps * 1e3, "batches": len(batches), "steps": steps,
-                   "batch_ms_min_p10_p90_max": [q[0] * 1e3, q[int(0.1 * (len(q) - 1))] * 1e3, q[int(0.9 * (len(q) - 1))] * 1e3,
-                                                q[-1] * 1e3],
-                   "per_callback_ms": {nm: per[i] * 1e3 for i, nm in enumerate(names)},
-                   "bytes_to_host_per_cycle": 8 * (1 + p.n + p.m + p.nnz_J + p.nnz_H), "ranks": world, "finite": finite,
-                   "host_helper_threads_of_rank_0": int(hs.helper_threads),
-                   "host_helper_threads_gave_up": bool(hs.helper_threads and hs.lib.pk_host_threads_hot() < 0),
-                   "what": "objective, gradient, constraints, jacobian, hessian on a new x per cycle with NumPy arrays in and "
-                           "out; every rank evaluates its share of the mesh intervals and its run-copy kernel stores its "
-                           "own slices straight into ONE shared pinned host array over its own PCIe link; rank 0 adds the "
-                           "partial sums and evaluates f on the host (pockit_amd/hostshard.py)"}
-    except Exception as exc:  # noqa: BLE001
-        out = {"error": repr(exc)}
-    finally:
-        hs.close()
-    if world > 1:
-        dist.barrier()
-    return out
-
-
-class GpuWorkload:
-    """One workload set up on this rank: plan, evaluator, device-resident inputs / outputs, the step function."""
-
-    def __init__(self, name, intervals, rank, world, dist):
-        import torch
-
-        from pockit_amd import benchmarks as models, hipbuild
-        import pockit_amd.radau as radau
-        from pockit_amd.sharding import ShardedEvaluator
-
-        self.torch, self.name, self.intervals, self.rank, self.world, self.dist = torch, name, intervals, rank, world, dist
-        t0 = time.perf_counter()
-        c0 = hipbuild.COMPILE_SECONDS["total"]
-        self.system, _, self.guess = build_workload(name, intervals, radau)
-        self.plan = plan = self.system.plan
-        self.x, self.lam, self.sigma = models.bench_inputs(self.system, self.guess)
-        self.dev = dev = torch.device("cuda", torch.cuda.current_device())
-        self.sev = sev = ShardedEvaluator(plan, rank, world, device=dev.index)
-        self.setup_s = time.perf_counter() - t0
-        self.compile_s_in_setup = hipbuild.COMPILE_SECONDS["total"] - c0
-        self.ev = ev = sev.ev
-        self.lib, self.h = ev.ctx.lib, ev.ctx.handle
-        self.dx = torch.from_numpy(self.x).to(dev)
-        self.dlam = torch.from_numpy(self.lam).to(dev)
-        self.o = o = sev.out
-        # a stream of our own (the sharded evaluator's): torch's default stream has the null handle, which the C ABI reads
-        # as "the context's stream"; launches, exchange and the timing events all go to this one
-        self.stream = sev.stream
-        st = C.c_void_p(self.stream.cuda_stream)
-        ptr = lambda t: C.c_void_p(t.data_ptr())  # noqa: E731
-        self.cycle_args = (self.h, ptr(self.dx), ptr(self.dlam), C.c_double(float(self.sigma)), ptr(o["f"]), ptr(o["grad"]),
-                           ptr(o["g"]), ptr(o["J"]), ptr(o["H"]), st)       # built once: the loop is host-launch bound
-        self.exchange = "single GPU"
-        lib, cycle_args, check = self.lib, self.cycle_args, ev.ctx.check
-        if world == 1:
-            def step():
-                rc = lib.pk_eval_cycle_dev(*cycle_args)
-                if rc:
-                    check(rc)
-
-            def many(count):      # `count` cycles enqueued by the library itself (no interpreter between the launches)
-                rc = lib.pk_eval_cycle_dev_repeat(*cycle_args, count, 0, None)
-                if rc:
-                    check(rc)
-
-            step.many = many
-            check(lib.pk_set_shard(self.h, 0, 0, None))
-        else:
-            # N > 1.  Default form "sums": every rank leaves its slices in its own HBM, only the sums over all nodes are
-            # exchanged (peer-mapped mailboxes inside one launch, no collective) -- the weak-scaling form.  A/B forms:
-            # "direct" (reassembly on rank 0's GPU by peer stores), "gather" / "allgather" (RCCL reassembly).
-            self.mode = os.environ.get("POCKIT_AMD_BENCH_EXCHANGE", "sums")
-            self.peer_error = None
-            try:
-                if self.fused_ok(plan):
-                    sev.enable_peer_exchange(dist, root=0)
-            except Exception as exc:          # no peer access between the GPUs: the RCCL forms remain
-                self.peer_error = repr(exc)
-                print(f"[bench] peer-mapped exchange not available ({exc!r}); using the RCCL gather form", file=sys.stderr)
-            self.exchange_fallback = None
-            if sev.peers is not None and not self.peer_exchange_works():
-                # the in-launch exchange needs every rank's launch to be running at the same time and the peers' system-scope
-                # stores to become visible to a polling workgroup; the two-launch form (pk_xchg behind pk_cycle) asks for
-                # less -- try it before giving the mailboxes up altogether
-                self.exchange_fallback = "in-launch exchange failed its probe; pk_xchg in a launch of its own"
-                print(f"[bench] {self.exchange_fallback}", file=sys.stderr)
-                sev.inline_exchange = False
-                if not self.peer_exchange_works():
-                    self.peer_error = "the peers' flags did not arrive (no coherent peer access between these GPUs?)"
-                    print(f"[bench] peer-mapped exchange set up but not working: {self.peer_error}; using the RCCL gather form",
-                          file=sys.stderr)
-                    sev.peers.close()
-                    sev.peers = None
-            if sev.peers is None and self.mode in ("sums", "direct"):
-                self.mode = "gather"
-            self.sums_forms_ms = None
-            if sev.peers is not None and self.mode == "sums" and sev.inline_exchange:
-                # both forms of "sums" work: the headline takes the faster one on THIS machine (every rank decides on the
-                # same figures: the slowest rank's time of each form)
-                t = []
-                for inline in (True, False):
-                    sev.inline_exchange = inline
-                    ms = self.time_mode("sums", steps=200)
-                    t.append(ms if isinstance(ms, float) else float("inf"))
-                tt = torch.tensor(t, dtype=torch.float64, device=self.dev)
-                dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-                t = [float(v) for v in tt.cpu()]
-                self.sums_forms_ms = {"in_launch": t[0], "pk_xchg_behind_pk_cycle": t[1]}
-                sev.inline_exchange = bool(t[0] <= t[1])
-                if not sev.inline_exchange:
-                    self.exchange_fallback = "pk_xchg in a launch of its own is faster here than the in-launch exchange"
-            self.inline_default = sev.inline_exchange
-            step = self.make_step(self.mode)
-            # guard of the headline loop: a burst of back-to-back cycles (ranks drift apart, unlike in the one-cycle probe)
-            # must leave finite sums on every rank -- else step down: in-launch -> pk_xchg behind pk_cycle -> RCCL gather
-            while self.mode in ("sums", "direct"):
-                for _ in range(50):
-                    step()
-                self.sync()
-                if self.all_finite():
-                    break
-                if self.mode == "sums" and sev.inline_exchange:
-                    self.exchange_fallback = "in-launch exchange lost sums in a back-to-back burst; pk_xchg in a launch of its own"
-                    sev.inline_exchange = self.inline_default = False
-                else:
-                    self.exchange_fallback = f"{self.mode}: sums not finite in a back-to-back burst; RCCL gather"
-                    self.mode = "gather"
-                print(f"[bench] {self.exchange_fallback}", file=sys.stderr)
-                step = self.make_step(self.mode)
-            self.exchange = self.mode
-        self.step = step
-        self.bytes = B = algorithmic_bytes(plan)
-        self.fused = not (plan.needs_I_grad or plan.needs_I_con or plan.jac.needs_I or plan.hess.needs_I)
-        if self.fused and world == 1 and os.environ.get("POCKIT_AMD_CYCLE_MODE", "1") == "0":   # A/B: the two-launch form
-            ev.set_cycle_mode(False)
-            self.dominant = "pk_xall" if B["xall"] >= B["hess"] else "pk_hess"
-        elif self.fused:
-            self.dominant = "pk_cycle"           # ONE launch does the whole cycle: its algorithmic bytes are SURVEY 8(d)'s B
-        else:
-            self.dominant = "pk_jac" if B["jac"] >= B["hess"] else "pk_hess"
-
-    def peer_exchange_works(self):
-        """One "sums" cycle behind a barrier: every rank must end up with a finite f, the same on all ranks (a peer whose
-        flag never becomes visible makes the bounded poll give up and the sums read NaN).  Every rank takes the same
-        decision."""
-        torch, dist = self.torch, self.dist
-        self.sync()
-        f = float("nan")
-        try:                                   # (local work only inside the try: the collectives below are unconditional)
-            self.sev.cycle(self.dx, self.dlam, self.sigma, dist, exchange="sums")
-            torch.cuda.synchronize()
-            f = float(self.o["f"].cpu()[0])
-        except Exception as exc:  # noqa: BLE001
-            print(f"[bench] peer exchange probe failed: {exc!r}", file=sys.stderr)
-        bad = 0.0 if np.isfinite(f) else 1.0
-        t = torch.tensor([f if bad == 0.0 else 0.0, -f if bad == 0.0 else 0.0, bad], dtype=torch.float64, device=self.dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        return bool(float(t[2]) == 0.0 and float(t[0]) == -float(t[1]))      # nobody failed, max f == min f
-
-    @staticmethod
-    def fused_ok(plan):
-        return not (plan.needs_I_grad or plan.needs_I_con or plan.jac.needs_I or plan.hess.needs_I)
-
-    def make_step(self, mode):
-        sev, dist = self.sev, self.dist
-        if mode in ("sums", "direct"):
-            return sev.fast_step(self.dx, self.dlam, self.sigma, exchange=mode)
-        root = None if mode == "allgather" else 0
-
-        def step():
-            sev.cycle(self.dx, self.dlam, self.sigma, dist, root=root)
-
-        if root is not None:
-            try:                                       # one untimed cycle: a backend without gather falls back to all-gather
-                step()
-                self.torch.cuda.synchronize()
-            except (RuntimeError, NotImplementedError) as exc:
-                print(f"[bench] gather-to-root not available ({exc!r}); using the all-gather form", file=sys.stderr)
-                return self.make_step("allgather")
-        return step
-
-    def all_finite(self):
-        """f finite on every rank (collective)."""
-        torch = self.torch
-        ok = 1.0 if bool(torch.isfinite(self.o["f"]).all()) else 0.0
-        if self.dist is None or self.world == 1:
-            return ok == 1.0
-        t = torch.tensor([ok], dtype=torch.float64, device=self.dev)
-        self.dist.all_reduce(t, op=self.dist.ReduceOp.MIN)
-        return float(t[0]) == 1.0
-
-    def agree(self, ok):
-        """True only if ``ok`` holds on EVERY rank (collective): the ranks then take the same branch before the next
-        collective or exchanging launch -- a rank that failed alone would otherwise leave the others in a different
-        sequence of collectives (a hang) or of exchange cycles (sums that wait for a peer that never posts)."""
-        if self.dist is None or self.world == 1:
-            return bool(ok)
-        t = self.torch.tensor([1.0 if ok else 0.0], dtype=self.torch.float64, device=self.dev)
-        self.dist.all_reduce(t, op=self.dist.ReduceOp.MIN)
-        return float(t[0]) == 1.0
-
-    def time_mode(self, mode, steps=200):
-        """ms per cycle of another form of the exchange (short untimed warm-up, wall clock between barriers).  Only LOCAL
-        work sits inside the try blocks; every decision is taken on all ranks from an all-reduced flag."""
-        err, step = None, None
+def write_detail(detail):
+    """bench_detail.json beside bench.py (+ a copy under gpurun_out/ when present, so that it comes back from a GPU box)."""
+    text = json.dumps(L.sanitize(detail), allow_nan=False, indent=1)
+    paths = [os.path.join(ROOT, "bench_detail.json")]
+    if os.path.isdir(os.path.join(ROOT, "gpurun_out")):
+        paths.append(os.path.join(ROOT, "gpurun_out", "bench_detail.json"))
+    written = None
+    for p in paths:
         try:
-            step = self.make_step(mode)
-            for _ in range(10):
-                step()
-        except Exception as exc:  # noqa: BLE001 -- a side figure must not cost the headline
-            err = repr(exc)
-        self.sync()
-        finite = True
-        if err is None and mode in ("sums", "direct"):      # (a timed-out exchange costs seconds per launch)
-            finite = bool(self.torch.isfinite(self.o["f"]).all())
-        if not self.agree(err is None and finite):
-            return err or ("sums not finite after ten back-to-back cycles" if not finite else
-                           "another rank failed in this form of the exchange")
-        t0 = time.perf_counter()
-        try:
-            for _ in range(steps):
-                step()
-        except Exception as exc:  # noqa: BLE001
-            err = repr(exc)
-        self.sync()
-        ms = (time.perf_counter() - t0) / steps * 1e3
-        if not self.agree(err is None):
-            return err or "another rank failed while this form was timed"
-        return ms
-
-    def sync(self):
-        self.torch.cuda.synchronize()
-        if self.dist is not None and self.world > 1:
-            self.dist.barrier()
-            self.torch.cuda.synchronize()
-
-    def timed_region(self, steps, warmup):
-        """Warm-up, then R back-to-back batches of exactly ``steps`` cycles (events between the batches on the launch
-        stream), bracketed by barrier + synchronize.  Returns the batch durations (ms) and the wall clock."""
-        torch, step, stream = self.torch, self.step, self.stream
-        n_warm = max(warmup, MIN_WARMUP) if self.world == 1 else max(warmup, 3)
-        for _ in range(n_warm):
-            step()
-        self.sync()
-        # size of the region: estimate the step time on a short untimed stretch
-        t0 = time.perf_counter()
-        probe = max(steps, 1000 if self.world == 1 else 20)     # (long enough for the closing synchronize not to count)
-        for _ in range(probe):
-            step()
-        self.sync()
-        est = (time.perf_counter() - t0) / probe
-        R = int(min(4000, max(5, -(-MIN_REGION_S // (est * steps)))))
-        if self.world > 1:                                   # every rank must run the same number of batches
-            t = torch.tensor([R], dtype=torch.int64, device=self.dev)
-            self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
-            R = int(t.item())
-        # How a batch reaches the stream (one GPU): `steps` kernel launches enqueued by the library, or ONE replay of a
-        # hipGraph of `steps` kernel nodes (pk_set_cycle_graph: 0.4 us of host time per cycle instead of ~4, a kernel
-        # ~2 % longer).  On a box whose host needs longer per launch than the kernel runs the first form is paced by the
-        # host; both are timed on a short stretch and the faster one carries the region.
-        self.batch_launch = {"form": f"{steps} kernel launches per batch"}
-        if self.world == 1 and hasattr(step, "many") and self.dominant == "pk_cycle" and os.environ.get("POCKIT_AMD_BENCH_GRAPH", "auto") != "0":
-            ms = {}
-            for form in ("launches", "graph"):
-                try:
-                    self.ev.set_cycle_graph(form == "graph")
-                    step.many(steps)                               # (captures the graph)
-                    self.sync()
-                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                    nb = max(10, 4000 // steps)
-                    e0.record(stream)
-                    for _ in range(nb):
-                        step.many(steps)
-                    e1.record(stream)
-                    self.sync()
-                    ms[form] = e0.elapsed_time(e1) / (nb * steps)
-                except Exception as exc:  # noqa: BLE001 -- a box whose runtime refuses the capture keeps the plain launches
-                    if form == "launches":
-                        raise
-                    print(f"[bench] graph form of a batch not available ({exc!r}); plain launches", file=sys.stderr)
-                    ms[form] = float("inf")
-                    self.ev.set_cycle_graph(False)
-                    self.sync()
-            use_graph = ms["graph"] < float("inf") and (ms["graph"] < ms["launches"] or os.environ.get("POCKIT_AMD_BENCH_GRAPH") == "1")
-            self.ev.set_cycle_graph(use_graph)
-            if use_graph:
-                step.many(steps)
-                self.sync()
-            self.batch_launch = {"form": (f"one hipGraph of {steps} kernel nodes per batch" if use_graph
-                                          else f"{steps} kernel launches per batch"),
-                                 "probe_us_per_cycle": {k: (v * 1e3 if v < float("inf") else None) for k, v in ms.items()}}
-        # An event between two launches is not free: it drains the stream (measured: ~3 us of GPU time each, 3 % of a
-        # 20-cycle batch).  Events are therefore recorded after every `group` batches, group * steps >= EVENT_SPACING
-        # cycles; a timed unit is `group` whole batches and its duration / group is what enters the statistics.
-        group = max(1, -(-EVENT_SPACING // steps))
-        R = -(-R // group) * group
-        events = [torch.cuda.Event(enable_timing=True) for _ in range(R // group + 1)]
-        self.sync()
-        t0 = time.perf_counter()
-        events[0].record(stream)
-        many = getattr(step, "many", None)      # a batch = ONE call into the library that enqueues `steps` cycles
-        for b in range(R):
-            if many is not None:
-                many(steps)
-            else:
-                for _ in range(steps):
-                    step()
-            if (b + 1) % group == 0:
-                events[(b + 1) // group].record(stream)
-        self.sync()
-        wall = time.perf_counter() - t0
-        batch_ms = [events[u].elapsed_time(events[u + 1]) / group for u in range(R // group)]
-        self.event_group = group
-        self.region_batches = R
-        if self.world == 1 and hasattr(step, "many"):
-            self.ev.set_cycle_graph(False)
-        return batch_ms, wall, n_warm + probe
-
-    def dispatch_times(self, kernel):
-        """Per-dispatch duration of ``kernel`` from HIP events attached to the dispatch itself
-        (hipExtModuleLaunchKernel start / stop events on the launch stream), two ways:
-        * ``isolated``: the stream is idle before every sampled launch -- the kernel's own start-to-end, what a kernel
-          trace (rocprofv3) measures, because a profiler keeps consecutive dispatches apart;
-        * ``in_flight``: every 64th launch of a back-to-back run -- there the stop-minus-start of a dispatch also holds
-          its wait for the tail of the launch before it."""
-        ev, step = self.ev, self.step
-        kid = KERNEL_IDS[kernel]
-        self.sync()
-        ev.profile(1 << kid, period=1)
-        n0, ms0 = ev.profile_read()[kernel]
-        for _ in range(ISOLATED_SAMPLES):
-            step()
-            self.stream.synchronize()
-        n1, ms1 = ev.profile_read()[kernel]
-        ev.profile(1 << kid, period=64)
-        for _ in range(64 * 40):
-            step()
-        self.sync()
-        n2, ms2 = ev.profile_read()[kernel]
-        ev.profile(0)
-        iso = (ms1 - ms0) / max(n1 - n0, 1) * 1e3
-        fl = (ms2 - ms1) / max(n2 - n1, 1) * 1e3
-        return iso, fl, n1 - n0, n2 - n1
-
-    def side_kernels(self):
-        """Kernel times of the optional modes (compact Hessian, mesh error estimation, CSR hand-off), 50 launches each."""
-        torch, ev, lib, h, plan, dev = self.torch, self.ev, self.lib, self.h, self.plan, self.dev
-        st = C.c_void_p(self.stream.cuda_stream)
-        ptr = lambda t: C.c_void_p(t.data_ptr())  # noqa: E731
-        out = {}
-
-        def timed(kid, name, fn):
-            ev.profile(1 << kid)
-            n0, ms0 = ev.profile_read()[name]
-            for _ in range(50):
-                fn()
-            torch.cuda.synchronize()
-            n1, ms1 = ev.profile_read()[name]
-            ev.profile(0)
-            return (ms1 - ms0) / max(n1 - n0, 1) * 1e3
-
-        if ev.src.compact:
-            hc = torch.zeros(max(plan.nnz_Hc, 1), dtype=torch.float64, device=dev)
-            hargs = (h, ptr(self.dx), ptr(self.dlam), C.c_double(float(self.sigma)), ptr(hc), st)
-            us = timed(9, "pk_hessc", lambda: lib.pk_eval_hessc_dev(*hargs))
-            out["compact_hessian_mode"] = {"nnz_H_compact": int(plan.nnz_Hc), "nnz_H_reference": int(plan.nnz_H),
-                                           "pk_hessc_us": us, "finite": bool(torch.isfinite(hc).all()),
-                                           "roofline": side_roofline(8 * (plan.n + plan.m + plan.nnz_Hc), us)}
-        if ev.src.compact_j:
-            plan.jacc  # noqa: B018
-            jc = torch.zeros(max(plan.nnz_Jc, 1), dtype=torch.float64, device=dev)
-            us = timed(15, "pk_jacc", lambda: lib.pk_eval_jacc_dev(h, ptr(self.dx), ptr(jc), st))
-            out["compact_jacobian_mode"] = {"nnz_J_compact": int(plan.nnz_Jc), "nnz_J_reference": int(plan.nnz_J),
-                                            "pk_jacc_us": us, "finite": bool(torch.isfinite(jc).all()),
-                                            "roofline": side_roofline(8 * (plan.n + plan.nnz_Jc), us)}
-        ev.mesh_error(self.x)                                           # uploads the tables on first use
-        eT = torch.zeros(ev._err_len, dtype=torch.float64, device=dev)
-        eI = torch.zeros_like(eT)
-        torch.cuda.synchronize()
-        us = timed(10, "pk_err", lambda: lib.pk_eval_mesh_error_dev(h, ptr(self.dx), ptr(eT), ptr(eI), st))
-        out["mesh_error_estimation"] = {"pk_err_us": us, "rows": int(ev._err_len),
-                                        "finite": bool(torch.isfinite(eT).all() and torch.isfinite(eI).all()),
-                                        "roofline": side_roofline(8 * (plan.n + 2 * ev._err_len), us)}
-        mj, mh = ev.csr_map("jac"), ev.csr_map("hess")
-        cj = torch.zeros(mj.nnz, dtype=torch.float64, device=dev)
-        ch = torch.zeros(mh.nnz, dtype=torch.float64, device=dev)
-        torch.cuda.synchronize()
-        csr = {"nnz_J_csr": int(mj.nnz), "nnz_H_csr": int(mh.nnz)}
-        for which, src, dst in ((0, self.o["J"], cj), (1, self.o["H"], ch)):
-            csr["pk_csr_J_us" if which == 0 else "pk_csr_H_us"] = timed(
-                11, "pk_csr", lambda: lib.pk_gather_csr_dev(h, which, ptr(src), ptr(dst), st))
-        if "hessc" in ev._csr:      # the route pk_eval_hess_csr takes: compact evaluation (pk_hessc) + a pure permutation
-            hcv = torch.zeros(max(plan.nnz_Hc, 1), dtype=torch.float64, device=dev)
-            lib.pk_eval_hessc_dev(h, ptr(self.dx), ptr(self.dlam), C.c_double(float(self.sigma)), ptr(hcv), st)
-            csr["pk_csr_H_from_compact_us"] = timed(11, "pk_csr", lambda: lib.pk_gather_csr_dev(h, 2, ptr(hcv), ptr(ch), st))
-        csr["finite"] = bool(torch.isfinite(cj).all() and torch.isfinite(ch).all())
-        # traffic of a gather: 4-byte index + 8-byte value per triplet, 8 bytes per CSR entry written
-        csr["roofline_J"] = side_roofline(12 * mj.n_triplets + 8 * mj.nnz, csr["pk_csr_J_us"])
-        csr["roofline_H_from_triplets"] = side_roofline(12 * mh.n_triplets + 8 * mh.nnz, csr["pk_csr_H_us"])
-        if "pk_csr_H_from_compact_us" in csr:
-            csr["roofline_H_from_compact"] = side_roofline(20 * mh.nnz, csr["pk_csr_H_from_compact_us"])
-        out["csr_handoff"] = csr
-        return out
-
-    def all_kernel_us(self, steps=50):
-        ev = self.ev
-        ev.profile(0xFFFF)
-        for _ in range(steps):
-            self.step()
-        self.torch.cuda.synchronize()
-        allk = {k: (v[1] / v[0] * 1e3 if v[0] else 0.0) for k, v in ev.profile_read().items()}
-        ev.profile(0)
-        return allk
-
-    def finite(self):
-        return all(bool(self.torch.isfinite(self.o[k]).all()) for k in ("f", "grad", "g", "J", "H"))
-
-    def close(self):
-        self.sev.close()
-
-
-def measure(name, intervals, steps, warmup, rank, world, dist, with_side=True, with_e2e=True, e2e_steps=None, e2e_warmup=None):
-    """Everything the JSON line says about one workload on this rank."""
-    w = GpuWorkload(name, intervals, rank, world, dist)
-    batch_ms, wall, untimed = w.timed_region(steps, warmup)
-    R = w.region_batches
-    med = statistics.median(batch_ms)
-    q = sorted(batch_ms)
-    Rq = len(q)
-    res = dict(name=name, intervals=intervals, nodes=int(sum(pp.layout.L_m for pp in w.plan.phase_plans)),
-               n=w.plan.n, m=w.plan.m, nnz_J=w.plan.nnz_J, nnz_H=w.plan.nnz_H, steps=steps, batches=R,
-               median_batch_ms=med, ms_per_step=med / steps, event_group=w.event_group, batch_launch=w.batch_launch,
-               batch_ms_p10=q[int(0.1 * (Rq - 1))], batch_ms_p90=q[int(0.9 * (Rq - 1))], batch_ms_min=q[0], batch_ms_max=q[-1],
-               region_wall_s=wall, wall_ms_per_step=wall / (R * steps) * 1e3, untimed_launches=untimed,
-               setup_s=w.setup_s, compile_s_in_setup=w.compile_s_in_setup, bytes=w.bytes, dominant=w.dominant,
-               exchange=w.exchange, tiles=int(len(w.ev.tables.tiles)), ipw=int(w.ev.tables.intervals_per_wave))
-    # N > 1: the same loop without the exchange (every rank keeps its slices), to separate the kernels from the collectives
-    res["no_exchange_ms_per_step"] = None
-    if world > 1 and w.fused:
-        w.sync()
-        w.lib.pk_set_exchange_inline(w.h, 0)
-        w.lib.pk_set_shared_grad_target(w.h, None)
-        t1 = time.perf_counter()
-        n = max(steps, 200)
-        for _ in range(n):
-            w.lib.pk_eval_cycle_dev(*w.cycle_args)
-        w.stream.synchronize()
-        res["no_exchange_ms_per_step"] = (time.perf_counter() - t1) / n * 1e3
-        w.sync()
-        w.step = w.make_step(w.exchange)
-    res["exchange_forms_ms_per_step"] = None
-    res["ranks"] = None
-    if world > 1:
-        forms = {}
-        if w.sev.peers is not None:             # the other form of "sums": exchange in-launch / as a second launch (pk_xchg)
-            w.sev.inline_exchange = not w.inline_default
-            forms["sums_two_launches" if w.inline_default else "sums_in_launch"] = w.time_mode("sums")
-            w.sev.inline_exchange = w.inline_default
-            forms["sums_form_of_the_headline"] = "in-launch" if w.inline_default else "pk_xchg behind pk_cycle"
-            forms["sums_forms_probe_ms"] = w.sums_forms_ms
-            forms["fallback"] = w.exchange_fallback
-        for mode in ("sums", "direct", "gather"):
-            if mode == w.exchange:
-                forms[mode] = res["ms_per_step"]
-            elif mode in ("sums", "direct") and w.sev.peers is None:
-                forms[mode] = "peer-mapped exchange not available: " + str(w.peer_error)
-            else:
-                forms[mode] = w.time_mode(mode)
-        res["exchange_forms_ms_per_step"] = forms
-        w.step = w.make_step(w.exchange)
-    iso, fl, n_iso, n_fl = w.dispatch_times(w.dominant)
-    res.update(dispatch_isolated_us=iso, dispatch_in_flight_us=fl, dispatch_samples=[n_iso, n_fl])
-    res["kernel_us"] = w.all_kernel_us()
-    if world > 1:       # the sums every rank ends up with must be bit-identical (same additions in rank order everywhere)
-        from pockit_amd.sharding import shared_gradient_slots
-
-        w.step()
-        w.sync()
-        sh = w.torch.as_tensor(shared_gradient_slots(w.plan), device=w.dev)
-        mine_sums = (float(w.o["f"].cpu()[0]), [float(v) for v in w.o["grad"][sh].cpu()])
-        sums = [None] * world
-        dist.all_gather_object(sums, mine_sums)
-        same = all(s_ == sums[0] for s_ in sums) if w.exchange in ("sums", "allgather") else None
-        res["exchange_check"] = {"f_per_rank": [s_[0] for s_ in sums], "sums_identical_on_every_rank": same,
-                                 "finite": bool(np.isfinite(sums[0][0]))}
-    if world > 1:       # per rank: share of the output positions, tiles, kernel times (rank 0 prints them)
-        mine = {"rank": rank, "tiles": int((w.ev.tables.tiles["nj"] > 0).sum()),
-                "owned_output_doubles": int(sum(b - a for a, b in w.sev.runs[rank])),
-                "pk_cycle_us": iso, "pk_xchg_us": res["kernel_us"].get("pk_xchg"), "setup_s": w.setup_s}
-        allr = [None] * world
-        dist.all_gather_object(allr, mine)
-        res["ranks"] = allr
-    res["finite"] = w.finite()
-    if world > 1:
-        res["multi_gpu"] = multi_gpu_facts(w.torch, dist, rank, world, w)
-    # (the supplementary figures must not cost the headline: a failure is reported in their place)
-    try:
-        res["side"] = w.side_kernels() if (with_side and world == 1) else {}
-    except Exception as exc:  # noqa: BLE001
-        res["side"] = {"side_kernels_error": repr(exc)}
-    res["end_to_end"] = None
-    w.close()
-    if with_e2e and world == 1:
-        import pockit_amd.radau as radau
-
-        try:
-            system, _, guess = build_workload(name, intervals, radau)
-            res["end_to_end"] = end_to_end(system, guess, e2e_steps or steps, e2e_warmup if e2e_warmup is not None else warmup)
-            system._invalidate()
-        except Exception as exc:  # noqa: BLE001
-            res["end_to_end"] = {"error": repr(exc)}
-    if with_e2e and world > 1:
-        res["end_to_end_host_sharded"] = host_sharded_end_to_end(name, intervals, rank, world, dist, e2e_steps or steps,
-                                                                  e2e_warmup if e2e_warmup is not None else warmup)
-    if with_e2e and world == 1 and with_side and isinstance(res.get("end_to_end"), dict):
-        # N = 1 through the code path of the N > 1 headline (one rank, the shared pinned segment, run copies): must sit near
-        # the single-GPU headline -- what the N-GPU lines are compared with
-        try:
-            res["end_to_end"]["host_sharded_path_with_one_rank"] = host_sharded_end_to_end(
-                name, intervals, 0, 1, None, min(e2e_steps or steps, 20), 5)
-        except Exception as exc:  # noqa: BLE001
-            res["end_to_end"]["host_sharded_path_with_one_rank"] = {"error": repr(exc)}
-    return res
-
-
-def multi_gpu_facts(torch, dist, rank, world, w):
-    """What the N > 1 line says about the machine it ran on: the ranks RCCL saw, every rank's device, the peer-access
-    matrix between the ranks' devices, and which device-resident exchange form carried the side figures and why (all
-    ranks take part: collectives only, no local failure changes the sequence)."""
-    try:
-        props = torch.cuda.get_device_properties(torch.cuda.current_device())
-        mine = {"rank": rank, "device": int(torch.cuda.current_device()), "name": props.name,
-                "visible_devices": int(torch.cuda.device_count())}
-    except Exception as exc:  # noqa: BLE001
-        mine = {"rank": rank, "error": repr(exc)}
-    devs = [None] * world
-    dist.all_gather_object(devs, mine)
-    row = []
-    for other in devs:
-        try:
-            a, b = mine.get("device"), other.get("device")
-            row.append(None if (a is None or b is None) else (True if a == b and other["rank"] == rank else
-                                                               bool(torch.cuda.can_device_access_peer(a, b)) if a != b else "same device"))
-        except Exception as exc:  # noqa: BLE001
-            row.append(repr(exc))
-    rows = [None] * world
-    dist.all_gather_object(rows, row)
-    try:
-        backend = str(dist.get_backend())
-    except Exception:  # noqa: BLE001
-        backend = "unknown"
-    return {"ranks_seen_by_rccl": int(dist.get_world_size()), "backend": backend + (" (= RCCL on ROCm)" if backend == "nccl" else
-                                                                                   " (rehearsal: NOT a measurement)"),
-            "devices": devs, "peer_access": rows,
-            "headline_form": "host-landed sharded cycle (every GPU lands its slices in one host array over its own PCIe link): "
-                             "the form that hands a host-side solver the reassembled COO triplets",
-            "device_resident_form": w.exchange, "device_resident_form_fallback": getattr(w, "exchange_fallback", None),
-            "peer_exchange_error": getattr(w, "peer_error", None)}
-
-
-def cold_compile_seconds(name, intervals):
-    """hipcc time of the headline model's code object with an empty cache (what a first run of a new model pays once;
-    every later run finds the object in pockit_amd/_cache by the hash of its generated source)."""
-    import tempfile
-
-    from pockit_amd import hipbuild
-    from pockit_amd.codegen import ModelSource
-    import pockit_amd.radau as radau
-
-    system, _, _ = build_workload(name, min(intervals, 50), radau)      # (the generated source is mesh-independent)
-    src = ModelSource(system.plan)
-    keep = hipbuild.CACHE_DIR
-    try:
-        with tempfile.TemporaryDirectory() as tmp:
-            hipbuild.CACHE_DIR = tmp
-            t0 = time.perf_counter()
-            hipbuild.compile_model(src.source, fastmath=system._fastmath, keep_source=False)
-            return time.perf_counter() - t0
-    finally:
-        hipbuild.CACHE_DIR = keep
-
-
-def assemble_line(args, res, e2e, n_gpus, intervals, ms, wall_ms, head_ms, basis):
-    """The JSON line of rank 0 (without the supplementary workloads): ``value`` = the host-landed cycle (``head_ms`` per
-    cycle; None -> the device-resident rate, said so in ``value_basis``), the device-resident launch rate and the roofline of
-    the dominant kernel beside it, and for N > 1 what the run saw of the machine (``multi_gpu``)."""
-    dev_value = n_gpus * 1e3 / ms
-    if head_ms is None:        # no host-landed figure (--no-end-to-end, or it failed): the device-resident rate, said so
-        head_ms = ms
-        basis = ("DEVICE-RESIDENT launch rate (x, lambda and all outputs stay in HBM): the host-landed cycle was not "
-                 "measured in this run" + (f" ({e2e.get('error')})" if isinstance(e2e, dict) and e2e.get("error") else ""))
-    value = n_gpus * 1e3 / head_ms
-    dom = res["dominant"]
-    dom_bytes = res["bytes"][dom[3:]] / n_gpus
-    x_once = res["bytes"]["cycle_x_once"] / n_gpus if dom == "pk_cycle" else None
-    # the kernel's average launch duration: HIP events over the timed region / launches when the cycle is ONE launch
-    # (launch + gap to the next launch: an upper bound of the kernel's own duration in this very run); a cycle of
-    # several launches, or N > 1 (the region holds the exchange too), uses the per-dispatch events
-    dom_us = ms * 1e3 if (dom == "pk_cycle" and n_gpus == 1) else res["dispatch_isolated_us"]
-    achieved = dom_bytes / (dom_us * 1e-6) / 1e9 if dom_us else None
-    traffic, profiled = None, None
-    tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-    if os.path.exists(tpath):
-        try:
-            rec = json.load(open(tpath)).get(f"{args.workload}_{intervals}", {})
-            traffic = rec.get(dom)
-            profiled = rec.get(dom + "_profiled")     # {"avg_ns": ..., "calls": ..., "file": "profiles/..."} of the committed trace
-        except Exception:
-            traffic = None
-    out_bytes = 8 * (1 + res["n"] + res["m"] + res["nnz_J"] + res["nnz_H"]) / n_gpus
-    regime = ("hbm" if out_bytes > 256 * 2**20 else ("latency" if (dom_us and dom_us < 2 * LAUNCH_FLOOR_US) else "mall"))
-    line = {
-        "metric": "NLP-callback cycles/sec (f + grad f + g + J + H)",
-        "value": value,
-        "unit": "cycles/s" if n_gpus == 1 else "12k-node-equivalent cycles/s",
-        "n_gpus": n_gpus, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": head_ms,
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "f64", "data": "synthetic",
-        "value_basis": basis,
-        "config": {"workload": f"{args.workload} LGR {intervals} intervals x {POINTS.get(args.workload.replace('_lgl', ''), 0)}"
-                               f" points ({res['nodes']} nodes; n={res['n']}, m={res['m']}, nnz_J={res['nnz_J']}, "
-                               f"nnz_H={res['nnz_H']})",
-                   "sharding": ("single GPU" if n_gpus == 1 else
-                                f"mesh intervals over {n_gpus} GPUs (shares balanced by output volume); every rank uploads x over "
-                                f"its own PCIe link, evaluates its tiles and stores its owned runs of grad f / g / J / H straight "
-                                f"into ONE pinned host array shared by the ranks; rank 0 adds the partial sums in rank order -- "
-                                f"no collective in the data path (device-resident side forms: see device_resident)"),
-                   "tiles": res["tiles"], "intervals_per_wave": res["ipw"],
-                   "inputs": "example guess*(1+1e-3 U(-1,1)) seed 0; lambda N(0,1) seed 1; sigma 1"},
-        "timing": {"region": ("R back-to-back batches of exactly `steps` host-landed cycles on the host clock (a cycle ends with "
-                              "its Hessian in host memory), synchronize (+ barrier) around the region; ms_per_step = median "
-                              "batch / steps; see end_to_end" + ("" if n_gpus == 1 else "_host_sharded")),
-                   "headline": (e2e.get("headline") if (isinstance(e2e, dict) and n_gpus == 1) else
-                                ({k: e2e.get(k) for k in ("batches", "steps", "batch_ms_min_p10_p90_max")}
-                                 if isinstance(e2e, dict) else None))},
-        "device_resident": {
-            "value": dev_value, "unit": "cycles/s" if n_gpus == 1 else "12k-node-equivalent cycles/s", "ms_per_step": ms,
-            "what": ("the same cycle with x and lambda resident in HBM and all outputs left in HBM: ONE pk_cycle launch per "
-                     "cycle" + ("" if n_gpus == 1 else f" and GPU, exchange form '{res['exchange']}': "
-                                + SHARDING_NOTE[res["exchange"]].format(n=n_gpus))),
-            "timing": {"region": f"{res['batches']} back-to-back batches of exactly {args.steps} cycles (>= {MIN_REGION_S * 1e3:.0f} ms "
-                                 f"in total), a HIP event on the launch stream after every {res['event_group']} batches (an event "
-                                 f"drains the stream: ~3 us each), barrier + synchronize around the region; ms_per_step = median "
-                                 f"over the timed units of (unit duration / {res['event_group']} batches) / steps (max over ranks)",
-                       "batches": res["batches"], "batches_per_timing_event": res["event_group"],
-                       "batch_launch": res["batch_launch"],
-                       "median_batch_ms": res["median_batch_ms"],
-                       "batch_ms_min_p10_p90_max": [res["batch_ms_min"], res["batch_ms_p10"], res["batch_ms_p90"], res["batch_ms_max"]],
-                       "region_wall_s": res["region_wall_s"], "wall_ms_per_step_whole_region": wall_ms,
-                       "untimed_launches_before_the_region": res["untimed_launches"]}},
-        "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBPS,
-                     "unit": "GB/s", "frac": (achieved / HBM_PEAK_GBPS if achieved else None), "traffic": traffic,
-                     "regime": regime,
-                     "regime_note": ("latency: the launch lasts less than twice the ~4.3 us a launch of this shape costs before "
-                                     "its first byte leaves; mall: the outputs of one launch (rewritten every cycle) fit the "
-                                     "256 MiB Infinity Cache, FETCH/WRITE_SIZE count fabric requests; hbm: they do not"),
-                     "frac_of_achievable": (achieved / HBM_ACHIEVABLE_GBPS if achieved else None),
-                     "achievable_peak": HBM_ACHIEVABLE_GBPS,
-                     "frac_profiled": ((dom_bytes / (profiled["avg_ns"] * 1e-9) / 1e9 / HBM_PEAK_GBPS)
-                                       if (profiled and profiled.get("avg_ns")) else None),
-                     "profiled": profiled,
-                     "algorithmic_bytes_per_launch": dom_bytes,
-                     "avg_launch_us": dom_us,
-                     "frac_x_once": (x_once / (dom_us * 1e-6) / 1e9 / HBM_PEAK_GBPS if (x_once and dom_us) else None),
-                     "algorithmic_bytes_per_launch_x_counted_once": x_once,
-                     "dispatch_isolated_us": res["dispatch_isolated_us"],
-                     "frac_dispatch_isolated": (dom_bytes / (res["dispatch_isolated_us"] * 1e-6) / 1e9 / HBM_PEAK_GBPS
-                                                if res["dispatch_isolated_us"] else None),
-                     "dispatch_in_flight_us": res["dispatch_in_flight_us"],
-                     "dispatch_samples_isolated_in_flight": res["dispatch_samples"],
-                     "timing": ("measured on the device-resident region (device_resident.timing).  avg_launch_us: HIP events on "
-                                "the launch stream around every batch of that region, median "
-                                "batch / steps -- one launch plus the gap to the next one, i.e. an upper bound of the "
-                                "kernel's own duration in this run (the launches of a stream do not overlap); "
-                                "dispatch_isolated_us: start / stop events attached to the dispatch "
-                                "(hipExtModuleLaunchKernel), stream idle before each sampled launch; dispatch_in_flight_us: "
-                                "the same per-dispatch events on every 64th launch of a back-to-back run (start is stamped "
-                                "when the packet is taken up, before the launch ahead of it has drained).  A kernel trace "
-                                "(rocprofv3) slows the loop it observes (profiles/README.md): its per-kernel average lies "
-                                "between these figures; frac_profiled = the same bytes over the committed trace's average"
-                                if (dom == "pk_cycle" and n_gpus == 1) else
-                                "avg_launch_us: start / stop events attached to the dispatch, stream idle before each "
-                                "sampled launch")},
-        "kernels_only_without_exchange": (None if res["no_exchange_ms_per_step"] is None else {
-            "value": n_gpus * 1e3 / res["no_exchange_ms_per_step"], "unit": "12k-node-equivalent cycles/s",
-            "note": "rank 0's clock around the same per-rank pk_cycle launches with no collective "
-                    "(every rank keeps its own slices of grad/g/J/H)"}),
-        "exchange_forms": (None if res["exchange_forms_ms_per_step"] is None else {
-            "ms_per_step": res["exchange_forms_ms_per_step"],
-            "equivalent_cycles_per_s": {k: (n_gpus * 1e3 / v if isinstance(v, float) else v)
-                                        for k, v in res["exchange_forms_ms_per_step"].items()},
-            "note": "device-resident forms of a sharded cycle.  sums: slices stay in each GPU's HBM, only the sums over all "
-                    "nodes are exchanged (pk_xchg, peer "
-                    "mailboxes); direct: reassembly on rank 0's GPU by peer stores over xGMI; gather: RCCL gather of "
-                    "the packed runs to rank 0.  The reassembling forms move one shard per peer into ONE GPU every "
-                    "cycle and are bound by that GPU's xGMI links"}),
-        "ranks": res["ranks"],
-        "multi_gpu": res.get("multi_gpu"),
-        "exchange_check": res.get("exchange_check"),
-        "kernel_us": res["kernel_us"],
-        "cycle_algorithmic_bytes": res["bytes"]["cycle"],
-        "setup_s": res["setup_s"], "compile_s_in_setup": res["compile_s_in_setup"],
-        "outputs_finite": res["finite"],
-    }
-    return line, value, dev_value
+            with open(p, "w") as fh:
+                fh.write(text)
+            written = written or os.path.relpath(p, ROOT)
+        except OSError:
+            pass
+    return written
 
 
 def spawn_ranks(args):
@@ -1144,6 +95,8 @@ def main():
 
     import torch
 
+    from tools.benchlib.timing import cold_compile_seconds, measure, other_workloads, strong_scaled_workloads
+
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU path in pockit_amd)")
     torch.cuda.set_device(local_rank % torch.cuda.device_count())
@@ -1162,103 +115,36 @@ def main():
 
     intervals = args.intervals * n_gpus          # weak scaling: per-GPU share stays args.intervals
     res = measure(args.workload, intervals, args.steps, args.warmup, rank, world, dist,
-                  with_e2e=not args.no_end_to_end)
+                  with_e2e=not args.no_end_to_end, keep_outputs=not args.no_cpu_baseline)
     t = torch.tensor([res["ms_per_step"], res["wall_ms_per_step"]], dtype=torch.float64, device="cuda")
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     ms, wall_ms = float(t[0].item()), float(t[1].item())
 
     # N > 1: BASELINE.json's sharded configs at their full size, STRONG-scaled over the N GPUs (every rank takes part)
-    strong = {}
-    if world > 1 and not args.no_extra:
-        for nm, iv, tag in (("two_stage_rocket", 1000, "C4 two_stage_rocket 2 phases x 1000 intervals x 4 points"),
-                            ("humanoid_wbc", 5000, "C5 humanoid_wbc 5000 intervals x 8 points")):
-            # (only LOCAL work inside the try: building and compiling the model; whether to go on is decided on every rank
-            #  from an all-reduced flag -- a rank that failed alone must not leave the others inside a collective)
-            problem = None
-            try:
-                import pockit_amd.radau as radau
+    strong = strong_scaled_workloads(args, rank, world, dist) if (world > 1 and not args.no_extra) else {}
 
-                build_workload(nm, iv, radau)[0].plan  # noqa: B018
-            except Exception as exc:  # noqa: BLE001
-                problem = repr(exc)
-            flags = [None] * world
-            dist.all_gather_object(flags, problem)
-            if any(flags):
-                strong[f"{nm}_{iv}_strong_scaled_over_{world}"] = {"error": "; ".join(sorted(set(f for f in flags if f)))}
-                continue
-            r = measure(nm, iv, args.steps, min(args.warmup, 50), rank, world, dist, with_side=False,
-                        with_e2e=not args.no_end_to_end, e2e_steps=min(args.steps, 20), e2e_warmup=5)
-            tt = torch.tensor([r["ms_per_step"]], dtype=torch.float64, device="cuda")
-            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-            hs = r.get("end_to_end_host_sharded")
-            strong[f"{nm}_{iv}_strong_scaled_over_{world}"] = {
-                "config": tag, "nodes": r["nodes"], "scaling": "strong",
-                "cycles_per_s": (hs.get("cycles_per_s") if isinstance(hs, dict) else None),
-                "value_basis": "host-landed sharded cycle (end_to_end_host_sharded); device_resident beside it",
-                "device_resident": {"cycles_per_s": 1e3 / float(tt.item()), "ms_per_step": float(tt.item()), "exchange": r["exchange"],
-                                    "exchange_forms_ms_per_step": r["exchange_forms_ms_per_step"]},
-                "ranks": r["ranks"], "cycle_bytes": r["bytes"]["cycle"],
-                "end_to_end_host_sharded": hs}
-
-    # ---- the headline: the solver-visible (host-landed) cycle; the device-resident launch rate stays beside it
-    e2e = res.get("end_to_end") if world == 1 else res.get("end_to_end_host_sharded")
-    head_ms, basis = None, None
-    if rank == 0 and isinstance(e2e, dict) and "error" not in e2e:
-        if world == 1 and "headline" in e2e:
-            head_ms = e2e["headline"]["ms_per_step"]
-            basis = ("host-landed cycle: the five callbacks of System on a new x, NumPy arrays in, caller-owned NumPy arrays out, "
-                     "reference triplet layout (end_to_end.headline)")
-        elif world > 1 and "ms_per_cycle" in e2e:
-            head_ms = e2e["ms_per_cycle"]
-            basis = ("host-landed sharded cycle: the five callbacks on rank 0, every GPU landing its slices of grad f / g / J / H in "
-                     "ONE pinned host array over its own PCIe link (end_to_end_host_sharded)")
-    if world > 1:          # every rank prints / decides on rank 0's figure
-        box = [head_ms, basis]
-        dist.broadcast_object_list(box, src=0)
-        head_ms, basis = box
     if rank == 0:
-        line, value, dev_value = assemble_line(args, res, e2e, n_gpus, intervals, ms, wall_ms, head_ms, basis)
-        line.update(res["side"])
-        if res["end_to_end"] is not None:
-            line["end_to_end"] = res["end_to_end"]
-        if res.get("end_to_end_host_sharded") is not None:
-            line["end_to_end_host_sharded"] = res["end_to_end_host_sharded"]
+        e2e = res.get("end_to_end") if world == 1 else res.get("end_to_end_host_sharded")
+        detail = L.detail_record(args, res, e2e, n_gpus, intervals, ms, wall_ms, ROOT)
+        cb, parity = None, None
+        if not args.no_cpu_baseline and n_gpus == 1:      # (required by the contract: a failure here is a failure of the run)
+            cb, parity = cpu_baseline(args.workload, intervals, gpu_outputs=res.get("outputs"))
+            detail["cpu_baseline"], detail["parity"] = cb, parity
         if n_gpus == 1 and not args.no_extra:
             try:
-                line["compile_s_cold"] = cold_compile_seconds(args.workload, intervals)
-            except Exception as exc:
-                line["compile_s_cold"] = repr(exc)
-        if not args.no_cpu_baseline and n_gpus == 1:
-            cb = cpu_baseline(args.workload, intervals)      # (required by the contract: a failure here is a failure of the run)
-            line["cpu_baseline"] = cb
-            line["speedup_vs_cpu_baseline"] = value / cb["value"]
-            line["speedup_basis"] = "value (" + basis.split(":")[0] + ") / cpu_baseline, both host arrays in and out"
-            line["device_resident_ratio_vs_cpu_baseline"] = dev_value / cb["value"]
-        if not args.no_extra and n_gpus > 1:
-            line["other_workloads"] = strong
-        if not args.no_extra and n_gpus == 1:
-            extra = {}
-            for nm, iv in (("brachistochrone", 1250), ("brachistochrone", 200), ("two_stage_rocket", 1000),
-                           ("humanoid_wbc", 5000), ("planar_quadrotor_lgl", 2000)):
-                try:
-                    r = measure(nm, iv, args.steps, min(args.warmup, 500), 0, 1, None,
-                                with_side=(nm == "humanoid_wbc"), with_e2e=(nm == "humanoid_wbc" and not args.no_end_to_end),
-                                e2e_steps=min(args.steps, 20), e2e_warmup=5)
-                    b = r["bytes"][r["dominant"][3:]]
-                    e = {"nodes": r["nodes"], "cycles_per_s": 1e3 / r["ms_per_step"], "ms_per_step": r["ms_per_step"],
-                         "batches": r["batches"], "dominant": r["dominant"], "dispatch_isolated_us": r["dispatch_isolated_us"],
-                         "dominant_GBps": b / (r["dispatch_isolated_us"] * 1e-6) / 1e9 if r["dispatch_isolated_us"] else None,
-                         "dominant_GBps_back_to_back": b / (r["ms_per_step"] * 1e-3) / 1e9,
-                         "cycle_bytes": r["bytes"]["cycle"], "setup_s": r["setup_s"]}
-                    e.update(r["side"])
-                    if r["end_to_end"] is not None:
-                        e["end_to_end"] = r["end_to_end"]
-                    extra[f"{nm}_{iv}"] = e
-                except Exception as exc:  # keep the headline line even if a side workload fails
-                    extra[f"{nm}_{iv}"] = {"error": repr(exc)}
-            line["other_workloads"] = extra
-        print(json.dumps(line))
+                detail["compile_s_cold"] = cold_compile_seconds(args.workload, intervals)
+            except Exception as exc:  # noqa: BLE001
+                detail["compile_s_cold"] = repr(exc)
+            detail["other_workloads"] = other_workloads(args)
+        elif n_gpus > 1 and not args.no_extra:
+            detail["other_workloads"] = strong
+        short_parity = None if parity is None else {k: parity[k] for k in ("max_rel_err", "tol", "ok")}
+        line = L.short_line(args, res, e2e, n_gpus, intervals, ms, ROOT, cpu_baseline=cb, parity=short_parity)
+        detail["line"] = line
+        line["detail_file"] = write_detail(detail)
+        sys.stdout.flush()
+        print(L.dumps_line(line), flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

@@ -47,29 +47,32 @@ def _record(n_gpus):
 
 @pytest.mark.parametrize("n_gpus", [2, 8])
 def test_the_line_of_a_multi_gpu_run_carries_what_the_run_saw(n_gpus):
-    import bench
+    from tools.benchlib import line as L
 
     args = argparse.Namespace(steps=20, warmup=5, workload="planar_quadrotor", gpus=n_gpus)
     rec = _record(n_gpus)
     e2e = rec["end_to_end_host_sharded"]
-    line, value, dev_value = bench.assemble_line(args, rec, e2e, n_gpus, 2000 * n_gpus, rec["ms_per_step"], rec["wall_ms_per_step"],
-                                                 e2e["ms_per_cycle"], "host-landed sharded cycle: ...")
-    json.dumps(line)                                            # one JSON line
-    assert line["n_gpus"] == n_gpus and line["scaling"] == "weak" and line["unit"] == "12k-node-equivalent cycles/s"
-    # the headline is the form that hands the solver the reassembled triplets: N x the host-landed rate
-    assert line["value"] == pytest.approx(n_gpus * 3000.0) and line["ms_per_step"] == pytest.approx(1 / 3.0)
-    assert "host-landed" in line["value_basis"] and "PCIe" in line["config"]["sharding"]
-    mg = line["multi_gpu"]
-    assert mg["ranks_seen_by_rccl"] == n_gpus and len(mg["peer_access"]) == n_gpus and len(mg["devices"]) == n_gpus
+    line = L.short_line(args, rec, e2e, n_gpus, 2000 * n_gpus, rec["ms_per_step"], ROOT)
+    text = L.dumps_line(line)                                   # one strict JSON line the driver can parse
+    assert len(text) < 4096 and json.loads(text)["n_gpus"] == n_gpus
+    assert line["scaling"] == "weak" and line["unit"] == "12k-node-equivalent cycles/s"
+    # value = the device-resident cycle (inputs and outputs in HBM), N x the per-GPU launch rate; never the PCIe-inclusive one
+    assert line["value_is"] == "device_resident"
+    assert line["value"] == pytest.approx(n_gpus * 1e3 / rec["ms_per_step"]) and line["device_resident"]["value"] == line["value"]
+    # the form that hands the solver the reassembled triplets stays beside it, named
+    assert line["end_to_end"]["value"] == pytest.approx(n_gpus * 3000.0) and line["end_to_end"]["ms_per_step"] == pytest.approx(1 / 3.0)
+    assert line["multi_gpu"]["ranks_seen_by_rccl"] == n_gpus and "backend" in line["multi_gpu"]
+    assert line["roofline"]["kernel"] == "pk_cycle" and line["roofline"]["regime"] in ("latency", "mall", "hbm")
+    # the detail record keeps what the run saw of the machine
+    d = L.detail_record(args, rec, e2e, n_gpus, 2000 * n_gpus, rec["ms_per_step"], rec["wall_ms_per_step"], ROOT)
+    mg = d["multi_gpu"]
+    assert len(mg["peer_access"]) == n_gpus and len(mg["devices"]) == n_gpus
     for key in ("backend", "headline_form", "device_resident_form", "device_resident_form_fallback", "peer_exchange_error"):
         assert key in mg
-    # the device-resident forms stay beside it, named
-    assert line["device_resident"]["value"] == pytest.approx(n_gpus * 1e3 / rec["ms_per_step"])
-    assert set(("sums", "direct", "gather")) <= set(line["exchange_forms"]["ms_per_step"])
-    assert line["roofline"]["kernel"] == "pk_cycle" and line["roofline"]["regime"] in ("latency", "mall", "hbm")
-    # without a host-landed figure the device-resident rate carries the line, and says so
-    line2, _, _ = bench.assemble_line(args, rec, {"error": "x"}, n_gpus, 2000 * n_gpus, rec["ms_per_step"], rec["wall_ms_per_step"], None, None)
-    assert "DEVICE-RESIDENT" in line2["value_basis"] and line2["value"] == line2["device_resident"]["value"]
+    assert set(("sums", "direct", "gather")) <= set(d["exchange_forms"]["ms_per_step"])
+    # a failed host-landed leg leaves the headline alone and says what failed
+    line2 = L.short_line(args, rec, {"error": "x"}, n_gpus, 2000 * n_gpus, rec["ms_per_step"], ROOT)
+    assert line2["value"] == line["value"] and line2["end_to_end"]["value"] is None and line2["end_to_end"]["error"] == "x"
 
 
 class _FakeLib:
@@ -166,10 +169,10 @@ def test_a_peer_mapping_that_fails_on_one_rank_degrades_every_rank_alike(bad):
 def _facts_worker(rank, world, port, ret):
     os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    import bench
+    from tools.benchlib import timing
 
     w = argparse.Namespace(exchange="gather", exchange_fallback="sums: peers' flags did not arrive", peer_error="no peer access")
-    ret[rank] = json.dumps(bench.multi_gpu_facts(torch, dist, rank, world, w), sort_keys=True)
+    ret[rank] = json.dumps(timing.multi_gpu_facts(torch, dist, rank, world, w), sort_keys=True)
     dist.barrier()
     dist.destroy_process_group()
 
