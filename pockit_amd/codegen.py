@@ -147,16 +147,58 @@ def _emit_body_uncached(outs, needed, defs, finals, indent):
     return "\n".join(lines)
 
 
+def split_groups(n_i, n_n, cap):
+    """Partition the derivative entries a role evaluates per node -- ``n_i`` I-expanded segments (staged in LDS, streamed
+    K^2-fold) and ``n_n`` per-node segments (stored directly) -- into groups a wave evaluates, stages and streams one after
+    the other: [(i0, ni, n0, nn)].  One group while the set is small (the kernels then run exactly the single-pass code of
+    rounds 1-3); otherwise balanced runs of at most ``cap`` I segments, then runs of at most ``cap`` per-node segments.  The
+    reference has no such notion (phasebase.py:1211-1337 loops over any number of entries): the groups bound what ONE pass
+    keeps in LDS (64 doubles per staged segment and wave), in VGPRs (two values per segment in the streaming loop) and in
+    SGPRs (one run pointer per segment), so a model's size no longer meets a wall of the hardware."""
+    if n_i <= cap and n_i + n_n <= cap + cap // 2:
+        return [(0, n_i, 0, n_n)]
+    out = []
+    for total, kind in ((n_i, 0), (n_n, 1)):
+        if total == 0:
+            continue
+        ng = -(-total // cap)
+        lo = 0
+        for g in range(ng):
+            cnt = total // ng + (1 if g < total % ng else 0)
+            out.append((lo, cnt, 0, 0) if kind == 0 else (0, 0, lo, cnt))
+            lo += cnt
+    return out
+
+
+def split_chunks(n, cap):
+    """Balanced runs of at most ``cap`` per-node outputs: [(lo, count)]; one run while n <= cap + cap / 2."""
+    if n <= cap + cap // 2:
+        return [(0, n)]
+    ng = -(-n // cap)
+    out, lo = [], 0
+    for g in range(ng):
+        cnt = n // ng + (1 if g < n % ng else 0)
+        out.append((lo, cnt))
+        lo += cnt
+    return out
+
+
 class ModelSource:
     """Generates the HIP source of one SystemPlan; exposes the compile-time counts the runtime
     tables must agree with."""
+
+    # most segments ONE pass of a tile wave evaluates, stages and streams (split_groups); POCKIT_AMD_GROUP_CAP overrides,
+    # and the evaluator halves it for a model whose kernels would still spill registers (hipbuild.resource_usage)
+    GROUP_CAP = 32
 
     # outputs of one launch beyond this many bytes do not stay in the 256 MiB (268 MB) Infinity Cache (MALL) any more: x,
     # lambda and the tables live there too, and the step was measured between 209 and 262 MB of outputs
     MALL_BYTES = 240_000_000
 
-    def __init__(self, plan: SystemPlan, sharded: bool = False, output_share: float = 1.0):
+    def __init__(self, plan: SystemPlan, sharded: bool = False, output_share: float = 1.0, group_cap=None):
         self.plan = plan
+        self.group_cap = int(group_cap or os.environ.get("POCKIT_AMD_GROUP_CAP") or self.GROUP_CAP)
+        self.groups = {}          # (callback, phase) -> [(i0, ni, n0, nn)]
         # Bytes one launch of the cycle writes on THIS evaluator (a shard of a multi-GPU run writes its share): decides the
         # cache policy of the streaming stores, the third mesh fact the code object depends on (after PK_TAB_CAP, PK_BIG).
         self.output_bytes = 8.0 * (1 + plan.n + plan.m + plan.nnz_J + plan.nnz_H) * float(output_share)
@@ -284,6 +326,10 @@ class ModelSource:
         S.append("  }")
 
         # ---- Jacobian / Hessian segments ----
+        def ctable(name, values):
+            vals = ", ".join(str(v) for v in values) or "0"
+            return (f"  __host__ __device__ static constexpr int {name}(int g) {{ constexpr int t[] = {{{vals}}}; return t[g]; }}")
+
         for cbname, tag in (("jac", "J"), ("hess", "H"), ("aux", "A")):
             cb = getattr(plan, cbname)
             segs = cb.segs[k]
@@ -292,11 +338,27 @@ class ModelSource:
             S.append(f"  static constexpr int {tag}_NI = {len(isegs)}, {tag}_NN = {len(nsegs)};")
             states = ", ".join(str(s.state) for s in isegs) or "0"
             S.append(f"  __device__ static __forceinline__ int {tag}_state(int e) {{ constexpr int t[] = {{{states}}}; return t[e]; }}")
-            outs = [(f"o[{e}]", s.expr) for e, s in enumerate(isegs)]
-            outs += [(f"o[{len(isegs) + e}]", s.expr) for e, s in enumerate(nsegs)]
-            S.append(f"  __device__ static __forceinline__ void mid_{cbname}({sig_node}, double* __restrict__ o) {{")
-            S.append(_emit_body(outs, base, nm))
-            S.append("  }")
+            groups = split_groups(len(isegs), len(nsegs), self.group_cap) if cbname != "aux" else [(0, len(isegs), 0, len(nsegs))]
+            self.groups[(cbname, k)] = groups
+            S.append(f"  static constexpr int {tag}_NG = {len(groups)}, {tag}_GMAX = {max(g[1] for g in groups)};")
+            for col, nm_ in enumerate(("gi0", "gni", "gn0", "gnn")):
+                S.append(ctable(f"{tag}_{nm_}", [g[col] for g in groups]))
+            if len(groups) == 1:
+                outs = [(f"o[{e}]", s.expr) for e, s in enumerate(isegs)]
+                outs += [(f"o[{len(isegs) + e}]", s.expr) for e, s in enumerate(nsegs)]
+                S.append(f"  __device__ static __forceinline__ void mid_{cbname}({sig_node}, double* __restrict__ o) {{")
+                S.append(_emit_body(outs, base, nm))
+                S.append("  }")
+                S.append(f"  __device__ static __forceinline__ void mid_{cbname}_g(pk::Grp<0>, {sig_node}, double* __restrict__ o) {{")
+                S.append(f"    mid_{cbname}(a, pk_tau, pk_dt, pk_w, sy, lp, o);\n  }}")
+            else:
+                # one straight-line function PER GROUP, each with its own joint CSE: o = [the group's I segments | its N segments]
+                for gi, (i0, ni, n0, nn) in enumerate(groups):
+                    outs = [(f"o[{e}]", s.expr) for e, s in enumerate(isegs[i0:i0 + ni])]
+                    outs += [(f"o[{ni + e}]", s.expr) for e, s in enumerate(nsegs[n0:n0 + nn])]
+                    S.append(f"  __device__ static __forceinline__ void mid_{cbname}_g(pk::Grp<{gi}>, {sig_node}, double* __restrict__ o) {{")
+                    S.append(_emit_body(outs, base, nm))
+                    S.append("  }")
             for w, wname in (("f", "front"), ("b", "back")):
                 exprs = cb.lists.get((w, k), [])
                 outs = [(f"E[{e}]", ex) for e, ex in enumerate(exprs)]
@@ -310,18 +372,25 @@ class ModelSource:
                             "const double* __restrict__ ltb")
         if self.compact:
             cb = plan.hessc
-            S.append(f"  static constexpr int HC_NN = {len(cb.segs[k])};")
-            S.append(f"  __device__ static __forceinline__ void mid_hessc({sig_c}, double* __restrict__ o) {{")
-            S.append(_emit_body([(f"o[{e}]", sg.expr) for e, sg in enumerate(cb.segs[k])], base, nm))
-            S.append("  }")
+            chunks = split_chunks(len(cb.segs[k]), self.group_cap)
+            self.groups[("hessc", k)] = chunks
+            S.append(f"  static constexpr int HC_NN = {len(cb.segs[k])}, HC_NG = {len(chunks)};")
+            S.append(ctable("HC_c0", [c[0] for c in chunks]))
+            S.append(ctable("HC_cn", [c[1] for c in chunks]))
+            for gi, (lo, cnt) in enumerate(chunks):
+                S.append(f"  __device__ static __forceinline__ void mid_hessc_g(pk::Grp<{gi}>, {sig_c}, double* __restrict__ o) {{")
+                S.append(_emit_body([(f"o[{e}]", sg.expr) for e, sg in enumerate(cb.segs[k][lo:lo + cnt])], base, nm))
+                S.append("  }")
             for w, wname in (("f", "front"), ("b", "back")):
                 exprs = cb.lists.get((w, k), [])
                 S.append(f"  __device__ static __forceinline__ void {wname}_hessc({sig_c}, double* __restrict__ E) {{")
                 S.append(_emit_body([(f"E[{e}]", ex) for e, ex in enumerate(exprs)], base, nm))
                 S.append("  }")
         else:
-            S.append("  static constexpr int HC_NN = 0;")
-            S.append(f"  __device__ static __forceinline__ void mid_hessc({sig_c}, double* __restrict__ o) {{}}")
+            S.append("  static constexpr int HC_NN = 0, HC_NG = 1;")
+            S.append(ctable("HC_c0", [0]))
+            S.append(ctable("HC_cn", [0]))
+            S.append(f"  __device__ static __forceinline__ void mid_hessc_g(pk::Grp<0>, {sig_c}, double* __restrict__ o) {{}}")
 
         # ---- compact Jacobian: expanded (per-node column), contracted (dense column) and per-node entries ----
         if self.compact_j:
@@ -331,25 +400,54 @@ class ModelSource:
             cd = [sg for sg in segs if sg.kind == "D"]
             cn = [sg for sg in segs if sg.kind == "N"]
             S.append(f"  static constexpr int JC_NI = {len(ci)}, JC_ND = {len(cd)}, JC_NN = {len(cn)};")
-            S.append(f"  __device__ static __forceinline__ void mid_jacc({sig_node}, double* __restrict__ o) {{")
-            S.append(_emit_body([(f"o[{e}]", sg.expr) for e, sg in enumerate(ci + cd + cn)], base, nm))
-            S.append("  }")
-            for wname, attr in (("front", "front"), ("back", "back")):
-                S.append(f"  __device__ static __forceinline__ void {wname}_jacc_dense({sig_node}, double* __restrict__ o) {{")
-                S.append(_emit_body([(f"o[{e}]", getattr(sg, attr)) for e, sg in enumerate(cd)], base, nm))
+            cap = self.group_cap
+            if len(ci) + len(cd) <= cap and len(ci) + len(cd) + len(cn) <= cap + cap // 2:
+                jgroups = [(-1, 0, 0)]                      # one pass over everything (the single-pass kernel code)
+            else:                                           # runs of one kind each: expanded, dense-column, per-node
+                jgroups = [(kind, lo, cnt) for kind, lst in ((0, ci), (1, cd), (2, cn)) for lo, cnt in split_chunks(len(lst), cap) if cnt]
+            self.groups[("jacc", k)] = jgroups
+            S.append(f"  static constexpr int JC_NG = {len(jgroups)}, "
+                     f"JC_GMAX = {len(ci) + len(cd) if jgroups[0][0] < 0 else max([1] + [c for kd, _, c in jgroups if kd < 2])};")
+            S.append(ctable("JC_gk", [g[0] for g in jgroups]))
+            S.append(ctable("JC_g0", [g[1] for g in jgroups]))
+            S.append(ctable("JC_gn", [g[2] for g in jgroups]))
+            if jgroups[0][0] < 0:
+                S.append(f"  __device__ static __forceinline__ void mid_jacc({sig_node}, double* __restrict__ o) {{")
+                S.append(_emit_body([(f"o[{e}]", sg.expr) for e, sg in enumerate(ci + cd + cn)], base, nm))
                 S.append("  }")
-            S.append("  __device__ static __forceinline__ void jacc_tdense(const double* __restrict__ a, "
-                     "double* __restrict__ otf, double* __restrict__ otb) {")
-            S.append(_emit_body([(f"otf[{e}]", sg.tfront) for e, sg in enumerate(cd)] +
-                                [(f"otb[{e}]", sg.tback) for e, sg in enumerate(cd)], base, nm))
-            S.append("  }")
+                for wname, attr in (("front", "front"), ("back", "back")):
+                    S.append(f"  __device__ static __forceinline__ void {wname}_jacc_dense({sig_node}, double* __restrict__ o) {{")
+                    S.append(_emit_body([(f"o[{e}]", getattr(sg, attr)) for e, sg in enumerate(cd)], base, nm))
+                    S.append("  }")
+                S.append("  __device__ static __forceinline__ void jacc_tdense(const double* __restrict__ a, "
+                         "double* __restrict__ otf, double* __restrict__ otb) {")
+                S.append(_emit_body([(f"otf[{e}]", sg.tfront) for e, sg in enumerate(cd)] +
+                                    [(f"otb[{e}]", sg.tback) for e, sg in enumerate(cd)], base, nm))
+                S.append("  }")
+            else:
+                for gi, (kind, lo, cnt) in enumerate(jgroups):
+                    part = (ci, cd, cn)[kind][lo:lo + cnt]
+                    S.append(f"  __device__ static __forceinline__ void mid_jacc_g(pk::Grp<{gi}>, {sig_node}, double* __restrict__ o) {{")
+                    S.append(_emit_body([(f"o[{e}]", sg.expr) for e, sg in enumerate(part)], base, nm))
+                    S.append("  }")
+                    if kind != 1:
+                        continue
+                    for wname, attr in (("front", "front"), ("back", "back")):
+                        S.append(f"  __device__ static __forceinline__ void {wname}_jacc_dense_g(pk::Grp<{gi}>, {sig_node}, double* __restrict__ o) {{")
+                        S.append(_emit_body([(f"o[{e}]", getattr(sg, attr)) for e, sg in enumerate(part)], base, nm))
+                        S.append("  }")
+                    S.append(f"  __device__ static __forceinline__ void jacc_tdense_g(pk::Grp<{gi}>, const double* __restrict__ a, "
+                             "double* __restrict__ otf, double* __restrict__ otb) {")
+                    S.append(_emit_body([(f"otf[{e}]", sg.tfront) for e, sg in enumerate(part)] +
+                                        [(f"otb[{e}]", sg.tback) for e, sg in enumerate(part)], base, nm))
+                    S.append("  }")
             for w, wname in (("f", "front"), ("b", "back")):
                 exprs = cb.lists.get((w, k), [])
                 S.append(f"  __device__ static __forceinline__ void {wname}_jacc({sig_node}, double* __restrict__ E) {{")
                 S.append(_emit_body([(f"E[{e}]", ex) for e, ex in enumerate(exprs)], base, nm))
                 S.append("  }")
         else:
-            S.append("  static constexpr int JC_NI = 0, JC_ND = 0, JC_NN = 0;")
+            S.append("  static constexpr int JC_NI = 0, JC_ND = 0, JC_NN = 0, JC_NG = 1, JC_GMAX = 1;")
             S.append(f"  __device__ static __forceinline__ void mid_jacc({sig_node}, double* __restrict__ o) {{}}")
             S.append(f"  __device__ static __forceinline__ void front_jacc_dense({sig_node}, double* __restrict__ o) {{}}")
             S.append(f"  __device__ static __forceinline__ void back_jacc_dense({sig_node}, double* __restrict__ o) {{}}")
@@ -375,12 +473,23 @@ class ModelSource:
         outs += [(f"ov[{a}]", e) for a, e in enumerate(plan.grad_var[k]["m"])]
         outs += [(f"ot[{r}]", plan.grad_red[k]["m"].get(sl, sp.Integer(0))) for r, sl in enumerate(slots)]
         outs += [(f"op[{r}]", pp.integ[plan.I_owner[a][1]].F) for r, a in enumerate(loc)]
-        S.append("  __device__ static __forceinline__ void mid_xall(const double* __restrict__ a, double pk_tau, "
-                 "double pk_dt, double pk_w, const PkSys& sy, double* __restrict__ og, double* __restrict__ oj, "
-                 "double* __restrict__ ov, double* __restrict__ ot, double* __restrict__ op) {")
-        S.append("    const double* lp = nullptr; (void)lp;")
-        S.append(_emit_body(outs, base, nm))
-        S.append("  }")
+        if len(self.groups[("jac", k)]) == 1:
+            S.append("  __device__ static __forceinline__ void mid_xall(const double* __restrict__ a, double pk_tau, "
+                     "double pk_dt, double pk_w, const PkSys& sy, double* __restrict__ og, double* __restrict__ oj, "
+                     "double* __restrict__ ov, double* __restrict__ ot, double* __restrict__ op) {")
+            S.append("    const double* lp = nullptr; (void)lp;")
+            S.append(_emit_body(outs, base, nm))
+            S.append("  }")
+        else:
+            # grouped Jacobian: the x-kernels evaluate the VALUES part here (g, gradient entries, integrands) and the Jacobian
+            # segments group by group with mid_jac_g, as pk_jac does
+            vouts = [o_ for o_ in outs if not o_[0].startswith("oj[")]
+            S.append("  __device__ static __forceinline__ void mid_xval(const double* __restrict__ a, double pk_tau, "
+                     "double pk_dt, double pk_w, const PkSys& sy, double* __restrict__ og, "
+                     "double* __restrict__ ov, double* __restrict__ ot, double* __restrict__ op) {")
+            S.append("    const double* lp = nullptr; (void)lp;")
+            S.append(_emit_body(vouts, base, nm))
+            S.append("  }")
         S.append("};")
         return "\n".join(S)
 
@@ -476,18 +585,24 @@ class ModelSource:
             out.append(f"{indent}  default: break;\n{indent}}}")
             return "\n".join(out)
 
+        self.grouped = any(len(v) > 1 for v in self.groups.values())
+        if self.grouped and self.big:
+            raise NotImplementedError("a model whose derivative set is evaluated in groups, on a mesh with an interval of more than "
+                                      "64 points: the workgroup-wide interval code is single-pass")
         S.append("struct Gen {")
         # LDS doubles per wave for the staged per-node values
         self.lds_g = 64 * max([1] + [pp.nx for pp in plan.phase_plans])
-        self.lds_j = 64 * max([1] + [sum(1 for sg in plan.jac.segs[k] if sg.kind == "I") for k in range(nP)])
+        # (rows of 64 doubles per wave; a role evaluated in groups stages one group at a time: its largest group counts)
+        gmax = lambda cb, k: max(g[1] for g in self.groups[(cb, k)])  # noqa: E731
+        self.lds_j = 64 * max([1] + [gmax("jac", k) for k in range(nP)])
         # Hessian: staged segment values + the tile's defect multipliers [state][row]
-        self.lds_h = 64 * max([1] + [pp.nx + sum(1 for sg in plan.hess.segs[k] if sg.kind == "I")
-                                     for k, pp in enumerate(plan.phase_plans)])
-        self.lds_x = 64 * max([1] + [pp.nx * (2 if self.big else 1) + sum(1 for sg in plan.jac.segs[k] if sg.kind == "I")
+        self.lds_h = 64 * max([1] + [pp.nx + gmax("hess", k) for k, pp in enumerate(plan.phase_plans)])
+        self.lds_x = 64 * max([1] + [pp.nx * (2 if self.big else 1) + gmax("jac", k)
                                      for k, pp in enumerate(plan.phase_plans)])      # (big: + the node values [NX][256])
         # (mesh error estimation: [x | u | f] rows per wave; a workgroup-wide interval adds the interpolated [x | u] rows)
         self.lds_e = 64 * max([1] + [3 * pp.nx + 2 * pp.nu for pp in plan.phase_plans])
-        self.lds_jc = 64 * max([1] + [sum(1 for sg in plan.jacc.segs[k] if sg.kind in "ID") for k in range(nP)]) if self.compact_j else 64
+        self.lds_jc = 64 * max([1] + [(sum(1 for sg in plan.jacc.segs[k] if sg.kind in "ID") if self.groups[("jacc", k)][0][0] < 0 else
+                                       max([1] + [c for kd, _, c in self.groups[("jacc", k)] if kd < 2])) for k in range(nP)]) if self.compact_j else 64
         S.append(f"  static constexpr int LDS_G = {self.lds_g}, LDS_J = {self.lds_j}, LDS_H = {self.lds_h}, "
                  f"LDS_X = {self.lds_x}, LDS_E = {self.lds_e}, LDS_JC = {self.lds_jc};")
         S.append("  __device__ static __forceinline__ void interval_err(int phase, const PkArgs& A, int first, int cnt, "

@@ -43,6 +43,11 @@ struct PkSys {
 
 namespace pk {
 
+// Group tag of the generated per-group model functions (mid_jac_g(Grp<2>, ...)): a role whose derivative set is large is
+// evaluated, staged and streamed in groups of segments, one after the other inside the wave (codegen.split_groups).
+template <int G>
+struct Grp {};
+
 // Tables that no kernel ever writes (segment bases, tile records) are read through the constant address
 // space: uniform addresses then become scalar loads (s_load, SGPR results) and -- being invariant -- the
 // compiler may hoist them above stores and barriers instead of paying a vector-memory round trip right before
@@ -98,6 +103,17 @@ template <int N>
 __device__ __forceinline__ void settle(double (&v)[N]) {
 #pragma unroll
   for (int i = 0; i < N; ++i) asm volatile("" : "+v"(v[i]));
+}
+
+// Between two group passes of a role the node arguments are made opaque to the compiler (no instruction is emitted): every
+// pass then evaluates its own straight-line function from registers it must assume new.  Without this the optimizer merges
+// the common subexpressions of ALL passes into one block and keeps them live across the passes -- the register pressure the
+// groups exist to bound (orbit_transfer's compact Hessian: 256 VGPRs + 92 AGPRs + scratch whatever the group size).
+template <int N>
+__device__ __forceinline__ void fresh_args(double (&a)[N], double& tau, double& dt, double& w) {
+  settle(a);
+  asm volatile("" : "+v"(tau), "+v"(w));
+  (void)dt;      // (wave-uniform, in SGPRs: the few terms of dt alone may be shared between the passes)
 }
 
 // End of the load part of phase A: every vector load of the wave has returned (s_waitcnt vmcnt(0), explicit so that
@@ -501,6 +517,7 @@ __device__ __forceinline__ void defect_ends(const PkArgs& A, const PkPhase& ph, 
   }
 }
 
+#define PK_DOT_UNROLL_MAX 96
 // one defect row: acc_i += sum_c (I_hat[r, c] * d / 2) * f_i(c), K known at compile time
 template <class P, int K>
 __device__ __forceinline__ void defect_dot(const double* __restrict__ full, const double* __restrict__ f, double width,
@@ -513,6 +530,23 @@ __device__ __forceinline__ void defect_dot(const double* __restrict__ full, cons
 #pragma unroll
     for (int i = 0; i < P::NX; ++i) acc[i] += a[c] * f[i * PK_WAVE + c];
   }
+}
+
+template <class P>
+__device__ __forceinline__ void defect_loop(const double* __restrict__ full, const double* __restrict__ f, double width,
+                                            double* acc, int K) {
+#pragma unroll 4
+  for (int c = 0; c < K; ++c) {
+    const double a = full[c] * width * 0.5;
+#pragma unroll
+    for (int i = 0; i < P::NX; ++i) acc[i] += a * f[i * PK_WAVE + c];
+  }
+}
+template <class P, int K>
+__device__ __forceinline__ void defect_dot_k(const double* __restrict__ full, const double* __restrict__ f, double width,
+                                             double* acc) {
+  if constexpr (K * P::NX <= PK_DOT_UNROLL_MAX) defect_dot<P, K>(full, f, width, acc);
+  else defect_loop<P>(full, f, width, acc, K);
 }
 
 // collocation defects of the tile's rows:  (x_q - x_end) - dt * sum_c (I_hat[r,c] d/2) f_i(c)
@@ -534,22 +568,19 @@ __device__ __forceinline__ void write_defects(const PkArgs& A, const PkPhase& ph
   if (STAGED) {
     const double width = T.wd[jj];
     const double* __restrict__ full = T.full + r * g.K;
-    switch (g.K) {   // K <= 8: fully unrolled so that all LDS reads of a row are in flight together
-      case 1: defect_dot<P, 1>(full, f, width, acc); break;
-      case 2: defect_dot<P, 2>(full, f, width, acc); break;
-      case 3: defect_dot<P, 3>(full, f, width, acc); break;
-      case 4: defect_dot<P, 4>(full, f, width, acc); break;
-      case 5: defect_dot<P, 5>(full, f, width, acc); break;
-      case 6: defect_dot<P, 6>(full, f, width, acc); break;
-      case 7: defect_dot<P, 7>(full, f, width, acc); break;
-      case 8: defect_dot<P, 8>(full, f, width, acc); break;
+    // K <= 8: fully unrolled so that all LDS reads of a row are in flight together -- while a row's NX * K values fit the
+    // register file comfortably (PK_DOT_UNROLL_MAX doubles; 16 states x 8 points would hold 256 VGPRs for the reads alone)
+    switch (g.K) {
+      case 1: defect_dot_k<P, 1>(full, f, width, acc); break;
+      case 2: defect_dot_k<P, 2>(full, f, width, acc); break;
+      case 3: defect_dot_k<P, 3>(full, f, width, acc); break;
+      case 4: defect_dot_k<P, 4>(full, f, width, acc); break;
+      case 5: defect_dot_k<P, 5>(full, f, width, acc); break;
+      case 6: defect_dot_k<P, 6>(full, f, width, acc); break;
+      case 7: defect_dot_k<P, 7>(full, f, width, acc); break;
+      case 8: defect_dot_k<P, 8>(full, f, width, acc); break;
       default:         // 9 <= K <= 16, tables staged in LDS as well
-#pragma unroll 4
-        for (int c = 0; c < g.K; ++c) {
-          const double a = full[c] * width * 0.5;
-#pragma unroll
-          for (int i = 0; i < P::NX; ++i) acc[i] += a * f[i * PK_WAVE + c];
-        }
+        defect_loop<P>(full, f, width, acc, g.K);
         break;
     }
   } else {
@@ -591,7 +622,8 @@ __device__ __forceinline__ void write_translation(const PkArgs& A, const PkPhase
 // streaming phase: out[base_e + offI + p] = -(I_hat[t] d/2) * sv_e[col(p)] (* lambda[row(p)])
 // (phasebase.py:1120-1124 and 1280-1285 -- the gather-multiply-concatenate that dominates the reference)
 // lam_s: the tile's multiplier rows staged in LDS as lam_s[state * 64 + row]   (Hessian only)
-template <class P, int NI, bool HESS, bool STAGED, class Bases>
+// E0: index of the group's first segment among the role's I-expanded segments (0: the role is one group)
+template <class P, int NI, bool HESS, bool STAGED, int E0, class Bases>
 __device__ __forceinline__ void stream_loop(const PkArgs& A, const PkPhase& ph, const PkTile& tl, const TileGeom& g,
                                             const TileTabs& T, const double* __restrict__ sv,
                                             const double* __restrict__ lam_s, const Bases& bases,
@@ -600,7 +632,7 @@ __device__ __forceinline__ void stream_loop(const PkArgs& A, const PkPhase& ph, 
   // per-lane part the stores take the `saddr + voffset` form (no 64-bit address arithmetic per store)
   double* __restrict__ run[NI > 0 ? NI : 1];
 #pragma unroll
-  for (int e = 0; e < NI; ++e) run[e] = out + (bases[e] + tl.offI);
+  for (int e = 0; e < NI; ++e) run[e] = out + (bases[E0 + e] + tl.offI);
   const int nnz = tl.nnzI;
   const int tot = tl.nj * nnz;
 #if PK_WIDE_STORES
@@ -624,7 +656,7 @@ __device__ __forceinline__ void stream_loop(const PkArgs& A, const PkPhase& ph, 
         const double* __restrict__ lam = lam_s + jj * g.R + (rc & 0xFFFF);
 #pragma unroll
         for (int e = 0; e < NI; ++e)
-          v[u][e] = HESS ? val * lam[P::H_state(e) * PK_WAVE] * col[e * PK_WAVE] : val * col[e * PK_WAVE];
+          v[u][e] = HESS ? val * lam[P::H_state(E0 + e) * PK_WAVE] * col[e * PK_WAVE] : val * col[e * PK_WAVE];
       }
 #pragma unroll
       for (int e = 0; e < NI; ++e) {
@@ -667,7 +699,7 @@ __device__ __forceinline__ void stream_loop(const PkArgs& A, const PkPhase& ph, 
         const double* __restrict__ lam = lam_s + jj * g.R + (rc & 0xFFFF);
 #pragma unroll
         for (int e = 0; e < NI; ++e)
-          v[u][e] = HESS ? val * lam[P::H_state(e) * PK_WAVE] * col[e * PK_WAVE] : val * col[e * PK_WAVE];
+          v[u][e] = HESS ? val * lam[P::H_state(E0 + e) * PK_WAVE] * col[e * PK_WAVE] : val * col[e * PK_WAVE];
       }
 #ifdef PK_TRACE
       if (PK_DIAG(131072)) {    // tracing builds only: the loop without its stores (lookups and products kept alive)
@@ -701,7 +733,7 @@ __device__ __forceinline__ void stream_loop(const PkArgs& A, const PkPhase& ph, 
     if (HESS) {
       const double* __restrict__ lam = lam_s + jj * g.R + r;
 #pragma unroll
-      for (int e = 0; e < NI; ++e) put(&run[e][p], val * lam[P::H_state(e) * PK_WAVE] * col[e * PK_WAVE]);
+      for (int e = 0; e < NI; ++e) put(&run[e][p], val * lam[P::H_state(E0 + e) * PK_WAVE] * col[e * PK_WAVE]);
     } else {
 #pragma unroll
       for (int e = 0; e < NI; ++e) put(&run[e][p], val * col[e * PK_WAVE]);
@@ -709,13 +741,13 @@ __device__ __forceinline__ void stream_loop(const PkArgs& A, const PkPhase& ph, 
   }
 }
 
-template <class P, int NI, bool HESS, bool STAGED, class Bases>
+template <class P, int NI, bool HESS, bool STAGED, int E0 = 0, class Bases>
 __device__ __forceinline__ void stream_expanded(const PkArgs& A, const PkPhase& ph, const PkTile& tl,
                                                 const TileGeom& g, const TileTabs& T, const double* __restrict__ sv,
                                                 const double* __restrict__ lam_s, const Bases& segb,
                                                 double* __restrict__ out, int lane) {
   if (NI == 0 || tl.nj * tl.nnzI == 0) return;
-  stream_loop<P, NI, HESS, STAGED>(A, ph, tl, g, T, sv, lam_s, segb, out, lane);
+  stream_loop<P, NI, HESS, STAGED, E0>(A, ph, tl, g, T, sv, lam_s, segb, out, lane);
 }
 
 // Phase B is compiled twice -- tables staged in LDS (K <= 8) or read from global memory -- and the wave branches
@@ -857,8 +889,7 @@ __device__ __forceinline__ void tile_grad(const PkArgs& A, const PkTile& tl, dou
 // Jacobian      (phasebase.py:1070-1152)
 // ============================================================================================
 template <class P>
-__device__ __forceinline__ void tile_jac(const PkArgs& A, const PkTile& tl, double* __restrict__ sv,
-                                         double* __restrict__, double* __restrict__, int lane) {
+__device__ __forceinline__ void tile_jac_single(const PkArgs& A, const PkTile& tl, double* __restrict__ sv, int lane) {
   const PkPhase& ph = A.ph[P::INDEX];
   const TileGeom g = tile_geom<P>(tl);
   double s[PK_NS], dt, mt;
@@ -891,6 +922,80 @@ __device__ __forceinline__ void tile_jac(const PkArgs& A, const PkTile& tl, doub
   if (tl.nj == 0) return;
   PK_PHASE_B(T, (write_translation<P, STAGED>(A, ph, tl, T, tbase, lane),
                  stream_expanded<P, P::J_NI, false, STAGED>(A, ph, tl, g, T, sv, nullptr, segb, A.o_jac, lane)));
+}
+
+
+// ---- a role evaluated in GROUPS of segments (codegen.split_groups; P::J_NG / P::H_NG > 1) ------------------------------
+// One pass per group inside the wave: evaluate the group's entries at the node (its own straight-line function with its own
+// joint CSE), stage its I-expanded segment values in the wave's LDS rows, stream their K^2-fold runs, next group.  Output
+// positions, tile ownership and operation order per entry are those of the single-pass code: a segment is one contiguous run
+// of the output array whatever pass writes it.  What a pass keeps live is bounded by the group (LDS rows, the streaming
+// loop's value registers and run pointers), so the number of derivative entries of a model is unbounded, as in the reference
+// (phasebase.py:1083-1124, 1234-1285 loop over any number of entries).  Between two passes the wave orders its own LDS
+// accesses (wave_lds_sync); the node arguments stay in registers, so a later pass issues no vector load.
+template <class P, int G, bool STAGED>
+__device__ __forceinline__ void jac_group_b(const PkArgs& A, const PkPhase& ph, const PkTile& tl, const TileGeom& g,
+                                            const TileTabs& T, const double* __restrict__ jsv,
+                                            const SegBases<P::J_NI + P::J_NN>& segb, int lane) {
+  stream_expanded<P, P::J_gni(G), false, STAGED, P::J_gi0(G)>(A, ph, tl, g, T, jsv, nullptr, segb, A.o_jac, lane);
+}
+template <class P, int G>
+__device__ __forceinline__ void jac_groups(const PkArgs& A, const PkPhase& ph, const PkTile& tl, const TileGeom& g,
+                                           const TileTabs& T, double (&a)[P::NARG], double& tau, double& dt, double& w,
+                                           const PkSys& sy, double* __restrict__ jsv,
+                                           const SegBases<P::J_NI + P::J_NN>& segb, int lane, int q, bool live) {
+  if constexpr (G < P::J_NG) {
+    constexpr int NI = P::J_gni(G), N0 = P::J_gn0(G), NN = P::J_gnn(G);
+    if constexpr (G > 0) fresh_args(a, tau, dt, w);
+    if (live) {
+      double o[NI + NN + 1];
+      P::mid_jac_g(Grp<G>{}, a, tau, dt, w, sy, nullptr, o);
+#pragma unroll
+      for (int e = 0; e < NI; ++e) jsv[e * PK_WAVE + lane] = o[e];
+      if (NN > 0 && lane < g.nown && q >= ph.mid_lo && q < ph.mid_hi) {
+#pragma unroll
+        for (int e = 0; e < NN; ++e) put(&A.o_jac[segb[P::J_NI + N0 + e] + (q - ph.mid_lo)], o[NI + e]);
+      }
+    }
+    if constexpr (NI > 0) {
+      wave_lds_sync();
+      if (tl.nj != 0) PK_PHASE_B(T, (jac_group_b<P, G, STAGED>(A, ph, tl, g, T, jsv, segb, lane)));
+      wave_lds_sync();                 // (the next pass overwrites the rows this one streamed from)
+    }
+    jac_groups<P, G + 1>(A, ph, tl, g, T, a, tau, dt, w, sy, jsv, segb, lane, q, live);
+  }
+}
+
+template <class P>
+__device__ __forceinline__ void tile_jac_grouped(const PkArgs& A, const PkTile& tl, double* __restrict__ sv, int lane) {
+  const PkPhase& ph = A.ph[P::INDEX];
+  const TileGeom g = tile_geom<P>(tl);
+  double s[PK_NS], dt, mt;
+  phase_scalars<P>(A, ph, s, dt, mt);
+  const PkSys sy{s, A.Ibuf, A.sigma, A.lam};
+  SegBases<P::J_NI + P::J_NN> segb;
+  SegBases<P::NX> tbase;
+  segb.load(A.lb, ph.jseg_off, lane);
+  tbase.load(A.lb, ph.jt_off, lane);
+  const bool fit = tabs_fit(A, tl, g);
+  const TabRegs tr = tabs_issue(A, ph, tl, g, fit, lane);
+  const int q = tl.q0 + lane;
+  double a[P::NARG], tau, w;
+  load_node<P>(A, ph, s, dt, mt, q, a, tau, w);
+  const TileTabs T = tabs_commit(A, tl, g, tr, fit, lane);
+  segb.settle();
+  tbase.settle();
+  loads_done();
+  wave_lds_sync();
+  if (tl.nj != 0) PK_PHASE_B(T, (write_translation<P, STAGED>(A, ph, tl, T, tbase, lane)));
+  jac_groups<P, 0>(A, ph, tl, g, T, a, tau, dt, w, sy, sv, segb, lane, q, lane < g.nq);
+}
+
+template <class P>
+__device__ __forceinline__ void tile_jac(const PkArgs& A, const PkTile& tl, double* __restrict__ sv,
+                                         double* __restrict__, double* __restrict__, int lane) {
+  if constexpr (P::J_NG == 1) tile_jac_single<P>(A, tl, sv, lane);
+  else tile_jac_grouped<P>(A, tl, sv, lane);
 }
 
 // ============================================================================================
@@ -932,8 +1037,7 @@ __device__ __forceinline__ void write_dense_rows(const PkArgs& A, const PkPhase&
 }
 
 template <class P>
-__device__ __forceinline__ void tile_jacc(const PkArgs& A, const PkTile& tl, double* __restrict__ sv,
-                                          double* __restrict__, double* __restrict__, int lane) {
+__device__ __forceinline__ void tile_jacc_single(const PkArgs& A, const PkTile& tl, double* __restrict__ sv, int lane) {
   const PkPhase& ph = A.ph[P::INDEX];
   const TileGeom g = tile_geom<P>(tl);
   double s[PK_NS], dt, mt;
@@ -975,12 +1079,107 @@ __device__ __forceinline__ void tile_jacc(const PkArgs& A, const PkTile& tl, dou
                  stream_expanded<P, P::JC_NI, false, STAGED>(A, ph, tl, g, T, sv, nullptr, segb, A.o_jac, lane)));
 }
 
+// the compact Jacobian in groups (see jac_groups): runs of expanded segments (kind 0: staged + streamed), of dense-column
+// segments (kind 1: staged, contracted with the integration block per defect row) and of per-node segments (kind 2)
+template <class P, int G, bool STAGED>
+__device__ __forceinline__ void jacc_group_b(const PkArgs& A, const PkPhase& ph, const PkTile& tl, const TileGeom& g,
+                                             const TileTabs& T, const double* __restrict__ a, const double* __restrict__ sv,
+                                             const SegBases<P::JC_NI + P::JC_ND + P::JC_NN>& segb, int lane) {
+  constexpr int KIND = P::JC_gk(G), LO = P::JC_g0(G), CN = P::JC_gn(G);
+  if constexpr (KIND == 0) {
+    stream_expanded<P, CN, false, STAGED, LO>(A, ph, tl, g, T, sv, nullptr, segb, A.o_jac, lane);
+  } else {
+    const int nrows = tl.nj * g.R;
+    if (lane >= nrows) return;
+    const int jj = magic_div((uint32_t)lane, tl.magicR), r = lane - jj * g.R;
+    const double* __restrict__ f = sv + jj * g.stride;
+    const double* __restrict__ full = STAGED ? T.full + r * g.K : A.db + tl.full_off + r * g.K;
+    const double width = STAGED ? T.wd[jj] : A.db[ph.width_off + tl.j0 + jj];
+    double acc[CN], tf[CN], tb[CN];
+#pragma unroll
+    for (int e = 0; e < CN; ++e) acc[e] = 0.0;
+#pragma unroll 4
+    for (int c = 0; c < g.K; ++c) {
+      const double wt = full[c] * width * 0.5;      // (I_hat * d) / 2 as the reference scales it
+#pragma unroll
+      for (int e = 0; e < CN; ++e) acc[e] += wt * f[e * PK_WAVE + c];
+    }
+    P::jacc_tdense_g(Grp<G>{}, a, tf, tb);
+    const bool first = tl.r0 + lane == 0, last_iv = tl.j0 + jj == ph.n_int - 1;
+#pragma unroll
+    for (int e = 0; e < CN; ++e)
+      put(&A.o_jac[segb[P::JC_NI + LO + e] + tl.r0 + lane], (first ? tf[e] : 0.0) + (last_iv ? tb[e] : 0.0) - acc[e]);
+  }
+}
+template <class P, int G>
+__device__ __forceinline__ void jacc_groups(const PkArgs& A, const PkPhase& ph, const PkTile& tl, const TileGeom& g,
+                                            const TileTabs& T, double (&a)[P::NARG], double& tau, double& dt, double& w,
+                                            const PkSys& sy, double* __restrict__ sv,
+                                            const SegBases<P::JC_NI + P::JC_ND + P::JC_NN>& segb, int lane, int q, bool live) {
+  if constexpr (G < P::JC_NG) {
+    constexpr int KIND = P::JC_gk(G), LO = P::JC_g0(G), CN = P::JC_gn(G);
+    if constexpr (G > 0) fresh_args(a, tau, dt, w);
+    if (live) {
+      double o[CN + 1];
+      P::mid_jacc_g(Grp<G>{}, a, tau, dt, w, sy, nullptr, o);
+      if constexpr (KIND == 1) {      // the boundary nodes carry their own expressions of the dense-column entries
+        if (q == 0) P::front_jacc_dense_g(Grp<G>{}, a, tau, dt, w, sy, nullptr, o);
+        else if (P::SCHEME == 1 && q == ph.L_m - 1) P::back_jacc_dense_g(Grp<G>{}, a, tau, dt, w, sy, nullptr, o);
+      }
+      if constexpr (KIND < 2) {
+#pragma unroll
+        for (int e = 0; e < CN; ++e) sv[e * PK_WAVE + lane] = o[e];
+      } else if (lane < g.nown && q >= ph.mid_lo && q < ph.mid_hi) {
+#pragma unroll
+        for (int e = 0; e < CN; ++e) put(&A.o_jac[segb[P::JC_NI + P::JC_ND + LO + e] + (q - ph.mid_lo)], o[e]);
+      }
+    }
+    if constexpr (KIND < 2) {
+      wave_lds_sync();
+      if (tl.nj != 0) PK_PHASE_B(T, (jacc_group_b<P, G, STAGED>(A, ph, tl, g, T, a, sv, segb, lane)));
+      wave_lds_sync();
+    }
+    jacc_groups<P, G + 1>(A, ph, tl, g, T, a, tau, dt, w, sy, sv, segb, lane, q, live);
+  }
+}
+
+template <class P>
+__device__ __forceinline__ void tile_jacc_grouped(const PkArgs& A, const PkTile& tl, double* __restrict__ sv, int lane) {
+  const PkPhase& ph = A.ph[P::INDEX];
+  const TileGeom g = tile_geom<P>(tl);
+  double s[PK_NS], dt, mt;
+  phase_scalars<P>(A, ph, s, dt, mt);
+  const PkSys sy{s, A.Ibuf, A.sigma, A.lam};
+  SegBases<P::JC_NI + P::JC_ND + P::JC_NN> segb;
+  SegBases<P::NX> tbase;
+  segb.load(A.lb, ph.jcseg_off, lane);
+  tbase.load(A.lb, ph.jct_off, lane);
+  const bool fit = tabs_fit(A, tl, g);
+  const TabRegs tr = tabs_issue(A, ph, tl, g, fit, lane);
+  const int q = tl.q0 + lane;
+  double a[P::NARG], tau, w;
+  load_node<P>(A, ph, s, dt, mt, q, a, tau, w);
+  const TileTabs T = tabs_commit(A, tl, g, tr, fit, lane);
+  segb.settle();
+  tbase.settle();
+  loads_done();
+  wave_lds_sync();
+  if (tl.nj != 0) PK_PHASE_B(T, (write_translation<P, STAGED>(A, ph, tl, T, tbase, lane)));
+  jacc_groups<P, 0>(A, ph, tl, g, T, a, tau, dt, w, sy, sv, segb, lane, q, lane < g.nq);
+}
+
+template <class P>
+__device__ __forceinline__ void tile_jacc(const PkArgs& A, const PkTile& tl, double* __restrict__ sv,
+                                          double* __restrict__, double* __restrict__, int lane) {
+  if constexpr (P::JC_gk(0) < 0) tile_jacc_single<P>(A, tl, sv, lane);      // (one pass over all kinds)
+  else tile_jacc_grouped<P>(A, tl, sv, lane);
+}
+
 // ============================================================================================
 // Hessian of the Lagrangian      (phasebase.py:1211-1337, systembase.py:735-835)
 // ============================================================================================
 template <class P>
-__device__ __forceinline__ void tile_hess(const PkArgs& A, const PkTile& tl, double* __restrict__ sv,
-                                          double* __restrict__, double* __restrict__, int lane) {
+__device__ __forceinline__ void tile_hess_single(const PkArgs& A, const PkTile& tl, double* __restrict__ sv, int lane) {
   const PkPhase& ph = A.ph[P::INDEX];
   const TileGeom g = tile_geom<P>(tl);
   double s[PK_NS], dt, mt;
@@ -1031,6 +1230,80 @@ __device__ __forceinline__ void tile_hess(const PkArgs& A, const PkTile& tl, dou
 #endif
 }
 
+// the Hessian role in groups (see jac_groups): lam_s = the tile's defect multipliers, staged once behind the group rows
+template <class P, int G, bool STAGED>
+__device__ __forceinline__ void hess_group_b(const PkArgs& A, const PkPhase& ph, const PkTile& tl, const TileGeom& g,
+                                             const TileTabs& T, const double* __restrict__ sv,
+                                             const double* __restrict__ lam_s, const SegBases<P::H_NI + P::H_NN>& segb,
+                                             int lane) {
+  stream_expanded<P, P::H_gni(G), true, STAGED, P::H_gi0(G)>(A, ph, tl, g, T, sv, lam_s, segb, A.o_hess, lane);
+}
+template <class P, int G>
+__device__ __forceinline__ void hess_groups(const PkArgs& A, const PkPhase& ph, const PkTile& tl, const TileGeom& g,
+                                            const TileTabs& T, double (&a)[P::NARG], double& tau, double& dt, double& w,
+                                            const PkSys& sy, double (&lp)[P::NC > 0 ? P::NC : 1], double* __restrict__ sv,
+                                            const double* __restrict__ lam_s, const SegBases<P::H_NI + P::H_NN>& segb,
+                                            int lane, int q, bool live) {
+  if constexpr (G < P::H_NG) {
+    constexpr int NI = P::H_gni(G), N0 = P::H_gn0(G), NN = P::H_gnn(G);
+    if constexpr (G > 0) {
+      fresh_args(a, tau, dt, w);
+      settle(lp);
+    }
+    if (live) {
+      double o[NI + NN + 1];
+      P::mid_hess_g(Grp<G>{}, a, tau, dt, w, sy, lp, o);
+#pragma unroll
+      for (int e = 0; e < NI; ++e) sv[e * PK_WAVE + lane] = o[e];
+      if (NN > 0 && lane < g.nown && q >= ph.mid_lo && q < ph.mid_hi) {
+#pragma unroll
+        for (int e = 0; e < NN; ++e) put(&A.o_hess[segb[P::H_NI + N0 + e] + (q - ph.mid_lo)], o[NI + e]);
+      }
+    }
+    if constexpr (NI > 0) {
+      wave_lds_sync();
+      if (tl.nj != 0) PK_PHASE_B(T, (hess_group_b<P, G, STAGED>(A, ph, tl, g, T, sv, lam_s, segb, lane)));
+      wave_lds_sync();                 // (the next pass overwrites the rows this one streamed from)
+    }
+    hess_groups<P, G + 1>(A, ph, tl, g, T, a, tau, dt, w, sy, lp, sv, lam_s, segb, lane, q, live);
+  }
+}
+
+template <class P>
+__device__ __forceinline__ void tile_hess_grouped(const PkArgs& A, const PkTile& tl, double* __restrict__ sv, int lane) {
+  const PkPhase& ph = A.ph[P::INDEX];
+  const TileGeom g = tile_geom<P>(tl);
+  double s[PK_NS], dt, mt;
+  phase_scalars<P>(A, ph, s, dt, mt);
+  const PkSys sy{s, A.Ibuf, A.sigma, A.lam};
+  SegBases<P::H_NI + P::H_NN> segb;
+  segb.load(A.lb, ph.hseg_off, lane);
+  double* __restrict__ lam_s = sv + P::H_GMAX * PK_WAVE;       // the tile's defect multipliers, [state][row]
+  const bool fit = tabs_fit(A, tl, g);
+  const TabRegs tr = tabs_issue(A, ph, tl, g, fit, lane);
+  const int q = tl.q0 + lane;
+  double a[P::NARG], tau, w, lp[P::NC > 0 ? P::NC : 1], lrow[P::NX];
+  const int row = min(tl.r0 + lane, ph.L_d - 1);
+#pragma unroll
+  for (int i = 0; i < P::NX; ++i) lrow[i] = A.lam[ph.g_off + i * ph.L_d + row];
+  load_node<P>(A, ph, s, dt, mt, q, a, tau, w);
+#pragma unroll
+  for (int j = 0; j < P::NC; ++j) lp[j] = A.lam[ph.path_off + j * ph.L_m + min(q, ph.L_m - 1)];
+  const TileTabs T = tabs_commit(A, tl, g, tr, fit, lane);
+#pragma unroll
+  for (int i = 0; i < P::NX; ++i) lam_s[i * PK_WAVE + lane] = lrow[i];
+  segb.settle();
+  loads_done();
+  hess_groups<P, 0>(A, ph, tl, g, T, a, tau, dt, w, sy, lp, sv, lam_s, segb, lane, q, lane < g.nq);
+}
+
+template <class P>
+__device__ __forceinline__ void tile_hess(const PkArgs& A, const PkTile& tl, double* __restrict__ sv,
+                                          double* __restrict__, double* __restrict__, int lane) {
+  if constexpr (P::H_NG == 1) tile_hess_single<P>(A, tl, sv, lane);
+  else tile_hess_grouped<P>(A, tl, sv, lane);
+}
+
 // ============================================================================================
 // fused x-callbacks: f (integrand sums), grad f, g and J of one tile from ONE evaluation of the node
 // (one joint CSE over all model functions; x read once).  Used by pk_eval_cycle_dev.
@@ -1063,9 +1336,9 @@ __device__ __forceinline__ void xall_phase_b(const PkArgs& A, const PkPhase& ph,
 // pub_blk >= 0 (pk_cycle, roles 0 / 1): the workgroup hands its partial sums to the launch's finalize workgroup as
 // soon as they exist (handoff_put) -- before its own staging, defect and streaming work.
 template <class P, int ROLE>
-__device__ __forceinline__ void tile_xall(const PkArgs& A, const PkTile& tl, double* __restrict__ sv,
-                                          double* __restrict__ wint, double* __restrict__ wgrad, int lane,
-                                          int pub_blk) {
+__device__ __forceinline__ void tile_xall_single(const PkArgs& A, const PkTile& tl, double* __restrict__ sv,
+                                                 double* __restrict__ wint, double* __restrict__ wgrad, int lane,
+                                                 int pub_blk) {
   const PkPhase& ph = A.ph[P::INDEX];
   const TileGeom g = tile_geom<P>(tl);
   PK_TRACE_REC(ROLE == 2 ? 1 : 0);
@@ -1172,6 +1445,111 @@ __device__ __forceinline__ void tile_xall(const PkArgs& A, const PkTile& tl, dou
   __builtin_amdgcn_s_waitcnt(0);      // all stores acknowledged
   PK_MARK(9);
 #endif
+}
+
+// The fused x-part of a model whose Jacobian is evaluated in groups: the VALUES part (g, grad f, integrand sums; P::mid_xval)
+// exactly as in the single-pass code, then the Jacobian segments group by group (jac_groups, the passes of pk_jac).
+template <class P, int ROLE, bool STAGED>
+__device__ __forceinline__ void xval_phase_b(const PkArgs& A, const PkPhase& ph, const PkTile& tl, const TileGeom& g,
+                                             const TileTabs& T, const double* s, double dt, const double* __restrict__ sv,
+                                             const double* xr, double* xe, const SegBases<P::NX>& tbase, int lane) {
+  write_defects<P, STAGED>(A, ph, tl, g, T, s, dt, sv, xr, xe, lane);
+  if (tl.nj != 0) write_translation<P, STAGED>(A, ph, tl, T, tbase, lane);
+}
+template <class P, int ROLE>
+__device__ __forceinline__ void tile_xall_grouped(const PkArgs& A, const PkTile& tl, double* __restrict__ sv,
+                                                  double* __restrict__ wint, double* __restrict__ wgrad, int lane,
+                                                  int pub_blk) {
+  const PkPhase& ph = A.ph[P::INDEX];
+  const TileGeom g = tile_geom<P>(tl);
+  double s[PK_NS], dt, mt;
+  phase_scalars<P>(A, ph, s, dt, mt);
+  const PkSys sy{s, A.Ibuf, A.sigma, A.lam};
+  SegBases<P::J_NI + P::J_NN> segb;
+  SegBases<P::NX> tbase;
+  if (ROLE != 1) segb.load(A.lb, ph.jseg_off, lane);
+  if (ROLE != 2) tbase.load(A.lb, ph.jt_off, lane);
+  double* __restrict__ jsv = sv + P::NX * PK_WAVE;
+  const bool fit = tabs_fit(A, tl, g);
+  const TabRegs tr = tabs_issue(A, ph, tl, g, fit, lane);
+  const int q = tl.q0 + lane;
+  double a[P::NARG], tau, w, xr[P::NX], xe[P::NX];
+  load_node<P>(A, ph, s, dt, mt, q, a, tau, w);
+  const TileTabs T = tabs_commit(A, tl, g, tr, fit, lane);
+  if (ROLE != 1) segb.settle();
+  if (ROLE != 2) tbase.settle();
+  if (ROLE != 2) {
+    defect_ends<P>(A, ph, tl, g, a, xe, lane);
+    settle(xe);
+  }
+  loads_done();
+#pragma unroll
+  for (int i = 0; i < P::NX; ++i) xr[i] = a[i];
+  const bool live = lane < g.nq;
+  if (ROLE != 2) {
+    double oi[P::INT_N > 0 ? P::INT_N : 1], orr[P::GR_NR > 0 ? P::GR_NR : 1];
+#pragma unroll
+    for (int r = 0; r < P::INT_N; ++r) oi[r] = 0.0;
+#pragma unroll
+    for (int r = 0; r < P::GR_NR; ++r) orr[r] = 0.0;
+    double og[P::G_NOUT], ov[P::NX + P::NU];
+    if (live) {
+      double ot[P::GR_NR > 0 ? P::GR_NR : 1], op[P::INT_N > 0 ? P::INT_N : 1];
+      P::mid_xval(a, tau, dt, w, sy, og, ov, ot, op);
+      if (lane < g.nown) {
+#pragma unroll
+        for (int r = 0; r < P::INT_N; ++r) oi[r] = op[r] * w;
+#pragma unroll
+        for (int r = 0; r < P::GR_NR; ++r) orr[r] = ot[r];
+        node_gradient_eval<P>(ph, q, a, tau, dt, w, sy, ov, orr, true);   // boundary nodes re-evaluate their own entries
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < P::INT_N; ++r) {
+      const double v = wave_sum(oi[r]);
+      if (lane == 0) wint[r] = v;
+    }
+#pragma unroll
+    for (int r = 0; r < P::GR_NR; ++r) {
+      const double v = wave_sum(orr[r]);
+      if (lane == 0) wgrad[r] = v;
+    }
+    if (pub_blk >= 0) {
+      __syncthreads();                                      // (all four waves of the workgroup have this role)
+      if ((int)threadIdx.x < PK_NRED) {                     // same order as publish_block_partials
+        double vi = 0.0, vg = 0.0;
+#pragma unroll
+        for (int wv = 0; wv < PK_WAVES_PER_BLOCK; ++wv) {
+          vi += wint[wv * PK_NRED + threadIdx.x];
+          vg += wgrad[wv * PK_NRED + threadIdx.x];
+        }
+        handoff_put(A.cpart + (size_t)pub_blk * PK_NRED + threadIdx.x, vi);
+        handoff_put(A.cpart2 + (size_t)pub_blk * PK_NRED + threadIdx.x, vg);
+      }
+    }
+    if (live) {
+      if (lane < g.nown) node_gradient_store<P>(A, ph, q, ov);
+#pragma unroll
+      for (int i = 0; i < P::NX; ++i) sv[i * PK_WAVE + lane] = og[i];
+      if (lane < g.nown) {
+#pragma unroll
+        for (int j = 0; j < P::NC; ++j) put(&A.o_g[ph.path_off + j * ph.L_m + q], og[P::NX + j]);
+      }
+    }
+    wave_lds_sync();
+    PK_PHASE_B(T, (xval_phase_b<P, ROLE, STAGED>(A, ph, tl, g, T, s, dt, sv, xr, xe, tbase, lane)));
+  } else {
+    wave_lds_sync();                                        // (the table blocks the wave staged for itself)
+  }
+  if (ROLE != 1) jac_groups<P, 0>(A, ph, tl, g, T, a, tau, dt, w, sy, jsv, segb, lane, q, live);
+}
+
+template <class P, int ROLE>
+__device__ __forceinline__ void tile_xall(const PkArgs& A, const PkTile& tl, double* __restrict__ sv,
+                                          double* __restrict__ wint, double* __restrict__ wgrad, int lane,
+                                          int pub_blk) {
+  if constexpr (P::J_NG == 1) tile_xall_single<P, ROLE>(A, tl, sv, wint, wgrad, lane, pub_blk);
+  else tile_xall_grouped<P, ROLE>(A, tl, sv, wint, wgrad, lane, pub_blk);
 }
 
 #ifdef PK_BIG
@@ -1576,6 +1954,26 @@ __device__ __forceinline__ void tile_mu(const PkArgs& A, const PkPhase& ph, cons
   }
 }
 
+// the per-node values of the compact Hessian, chunk by chunk (one chunk unless the model is large: codegen.split_chunks)
+template <class P, int G>
+__device__ __forceinline__ void hessc_chunks(const PkArgs& A, const PkPhase& ph, pk_cbase_t segb, double (&a)[P::NARG],
+                                             double& tau, double& dt, double& w, const PkSys& sy,
+                                             double (&lp)[P::NC > 0 ? P::NC : 1], double (&mu)[P::NX], int q) {
+  if constexpr (G < P::HC_NG) {
+    constexpr int C0 = P::HC_c0(G), CN = P::HC_cn(G);
+    if constexpr (G > 0) {
+      fresh_args(a, tau, dt, w);
+      settle(lp);
+      settle(mu);
+    }
+    double o[CN + 1];
+    P::mid_hessc_g(Grp<G>{}, a, tau, dt, w, sy, lp, mu, nullptr, nullptr, o);
+#pragma unroll
+    for (int e = 0; e < CN; ++e) put(&A.o_hess[segb[C0 + e] + (q - ph.mid_lo)], o[e]);
+    hessc_chunks<P, G + 1>(A, ph, segb, a, tau, dt, w, sy, lp, mu, q);
+  }
+}
+
 // One wave per tile: lane = node.  The tile's rows of the defect multipliers (lane = row, coalesced) and its integration
 // block are staged in LDS while the node loads are in flight, so the K-term contraction per node and state reads LDS only
 // (the first version read lambda and the block from global memory inside the loop: K (1 + NX) dependent-latency loads per
@@ -1595,15 +1993,13 @@ __device__ __forceinline__ void tile_hessc(const PkArgs& A, const PkTile& tl, do
     for (int c = lane; c < g.nown; c += PK_WAVE) {
       const int q = tl.q0 + c;
       if (q >= ph.mid_lo && q < ph.mid_hi) {
-        double a[P::NARG], tau, w, o[P::HC_NN + 1], lp[P::NC > 0 ? P::NC : 1], mu[P::NX];
+        double a[P::NARG], tau, w, lp[P::NC > 0 ? P::NC : 1], mu[P::NX];
         load_node<P>(A, ph, s, dt, mt, q, a, tau, w);
 #pragma unroll
         for (int j = 0; j < P::NC; ++j) lp[j] = A.lam[ph.path_off + j * ph.L_m + q];
         const int jj = c / g.stride;
         node_mu<P>(A, ph, tl.j0 + jj, c - jj * g.stride, mu);
-        P::mid_hessc(a, tau, dt, w, sy, lp, mu, nullptr, nullptr, o);
-#pragma unroll
-        for (int e = 0; e < P::HC_NN; ++e) put(&A.o_hess[segb[e] + (q - ph.mid_lo)], o[e]);
+        hessc_chunks<P, 0>(A, ph, segb, a, tau, dt, w, sy, lp, mu, q);
       }
     }
     return;
@@ -1641,10 +2037,7 @@ __device__ __forceinline__ void tile_hessc(const PkArgs& A, const PkTile& tl, do
       interval_mu<P>(A, ph, ivK[jp], A.db + ivF[jp], A.db[ph.width_off + jp], ivL[jp], ivK[jp] - 1, mu);
     }
   }
-  double o[P::HC_NN + 1];
-  P::mid_hessc(a, tau, dt, w, sy, lp, mu, nullptr, nullptr, o);
-#pragma unroll
-  for (int e = 0; e < P::HC_NN; ++e) put(&A.o_hess[segb[e] + (q - ph.mid_lo)], o[e]);
+  hessc_chunks<P, 0>(A, ph, segb, a, tau, dt, w, sy, lp, mu, q);
 }
 
 // boundary node of the compact Hessian: also the contracted multipliers of the boundary columns

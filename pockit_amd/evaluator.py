@@ -206,15 +206,30 @@ class Tables:
         self.intervals_per_wave = ipw
 
 
+def compile_plan(plan: SystemPlan, sharded=False, output_share=1.0):
+    """Generated source + gfx950 code object of a plan.  A model whose kernels would spill vector registers or touch scratch
+    memory at the default group size is generated again with smaller groups (codegen.split_groups: fewer derivative entries
+    evaluated, staged and streamed per pass) until none does -- every cap tried stays cached, so this costs a model its extra
+    compiles once.  Returns (ModelSource, code object)."""
+    cap, fast = None, plan.system._fastmath
+    while True:
+        src = ModelSource(plan, sharded=sharded, output_share=output_share, group_cap=cap)
+        code = hipbuild.compile_model(src.source, fastmath=fast)
+        bad = hipbuild.spills(hipbuild.resource_usage(src.source, fastmath=fast))
+        if not bad or src.group_cap <= 4 or os.environ.get("POCKIT_AMD_GROUP_CAP"):
+            src.spilling_kernels = bad
+            return src, code
+        cap = src.group_cap // 2
+
+
 class Evaluator:
     def __init__(self, plan: SystemPlan, device: int = 0, intervals_per_wave=None, tile_filter=None, sharded=False,
                  output_share=1.0, host_helpers=True):
         self.plan = plan
         self._want_host_helpers = bool(host_helpers) and tile_filter is None
-        self.src = ModelSource(plan, sharded=sharded, output_share=output_share)
         # (compiled before the context is created: a box without a GPU -- the build container -- can still fill the
         # code-object cache by constructing evaluators, tools/warm_cache.sh)
-        code = hipbuild.compile_model(self.src.source, fastmath=plan.system._fastmath)
+        self.src, code = compile_plan(plan, sharded=sharded, output_share=output_share)
         self.ctx = runtime.Context(device)            # raises RuntimeError without a GPU
         lib, h = self.ctx.lib, self.ctx.handle
         md = runtime.ModelDesc()

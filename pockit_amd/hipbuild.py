@@ -93,14 +93,62 @@ def write_index(keep):
                 os.remove(os.path.join(CACHE_DIR, name))
 
 
+def _parse_resource_usage(stderr: str) -> dict:
+    """``-Rpass-analysis=kernel-resource-usage`` remarks -> {kernel: {sgpr, vgpr, agpr, scratch, occupancy, sgpr_spill,
+    vgpr_spill, lds}} (registers per lane, scratch in bytes per lane)."""
+    keys = {"TotalSGPRs": "sgpr", "SGPRs": "sgpr", "VGPRs": "vgpr", "AGPRs": "agpr", "ScratchSize [bytes/lane]": "scratch",
+            "Occupancy [waves/SIMD]": "occupancy", "SGPRs Spill": "sgpr_spill", "VGPRs Spill": "vgpr_spill",
+            "LDS Size [bytes/block]": "lds"}
+    out, cur = {}, None
+    for line in stderr.splitlines():
+        if "remark:" not in line:
+            continue
+        body = line.split("remark:", 1)[1].split("[-Rpass-analysis")[0].strip()
+        if body.startswith("Function Name:"):
+            cur = out.setdefault(body.split(":", 1)[1].strip(), {})
+            continue
+        if cur is None or ":" not in body:
+            continue
+        name, val = body.rsplit(":", 1)
+        if name.strip() in keys:
+            try:
+                cur[keys[name.strip()]] = int(val.strip())
+            except ValueError:
+                pass
+    return out
+
+
+def resource_usage(source: str, fastmath: bool = False):
+    """What the compiler said about every kernel of a model's code object (registers, spills, scratch, occupancy): recorded
+    by ``compile_model`` beside the object.  None for an object compiled before the record existed."""
+    import json
+
+    path = os.path.join(CACHE_DIR, _key(source, fastmath) + ".res.json")
+    if not os.path.exists(path):
+        return None
+    with open(path) as fh:
+        return json.load(fh)
+
+
+def spills(usage) -> dict:
+    """The kernels of ``usage`` that spill vector registers to scratch memory: {kernel: (vgpr_spill, scratch bytes)}.
+    (A few bytes of private segment WITHOUT a spilled register -- pk_hessc shows 20 -- are the register allocator's
+    emergency slot for scalar spills: the ISA holds no scratch instruction; tools/examples_resources.py lists them.)"""
+    return {k: (v.get("vgpr_spill", 0), v.get("scratch", 0)) for k, v in (usage or {}).items() if v.get("vgpr_spill", 0) > 0}
+
+
+def _key(source: str, fastmath: bool) -> str:
+    return hashlib.sha256((source + _kernel_header_hash() + str(bool(fastmath)) + " ".join(PRELOAD_FLAGS + EXTRA_FLAGS)).encode()
+                          ).hexdigest()[:32]
+
+
 # wall-clock seconds this process spent in hipcc for model code objects (cache misses); bench.py reports it
 COMPILE_SECONDS = {"total": 0.0, "count": 0, "last": 0.0}
 
 
 def compile_model(source: str, fastmath: bool = False, keep_source: bool = True) -> bytes:
     """Return the gfx950 code object of a generated model source (compiling on a cache miss)."""
-    key = hashlib.sha256((source + _kernel_header_hash() + str(bool(fastmath)) + " ".join(PRELOAD_FLAGS + EXTRA_FLAGS)).encode()
-                         ).hexdigest()[:32]
+    key = _key(source, fastmath)
     os.makedirs(CACHE_DIR, exist_ok=True)
     path = os.path.join(CACHE_DIR, key + ".hsaco")
     gen = os.path.join(CACHE_DIR, key + ".gen")
@@ -119,10 +167,19 @@ def compile_model(source: str, fastmath: bool = False, keep_source: bool = True)
             with open(src, "w") as fh:
                 fh.write(source)
             cmd = [_hipcc(), f"--offload-arch={ARCH}", "-O3", "-std=c++17", "--genco", f"-I{CSRC}", src, "-o",
-                   os.path.join(tmp, "model.hsaco")] + PRELOAD_FLAGS + EXTRA_FLAGS
+                   os.path.join(tmp, "model.hsaco"), "-Rpass-analysis=kernel-resource-usage"] + PRELOAD_FLAGS + EXTRA_FLAGS
             if fastmath:  # reassociation subset of fast-math (reference: numba fastmath=True, fastfunc.py:24,35)
                 cmd += ["-fassociative-math", "-freciprocal-math", "-fno-signed-zeros", "-fno-trapping-math"]
-            _run(cmd)
+            res = _run(cmd)
+            try:        # the compiler's per-kernel register / spill / scratch report, kept beside the object
+                import json
+
+                fd, staged = tempfile.mkstemp(dir=CACHE_DIR, prefix=key + ".", suffix=".part")
+                with os.fdopen(fd, "w") as fh:
+                    json.dump(_parse_resource_usage(res.stderr), fh)
+                os.replace(staged, os.path.join(CACHE_DIR, key + ".res.json"))
+            except OSError:
+                pass
             # publish atomically through a name of our own: ranks that start cold together (bench.py under torchrun,
             # the two-process test) all compile the same model and must not share a staging file
             fd, staged = tempfile.mkstemp(dir=CACHE_DIR, prefix=key + ".", suffix=".part")
