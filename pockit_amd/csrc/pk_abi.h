@@ -170,8 +170,12 @@ struct PkArgs {
   // big_stage + (4 s + u) * big_slot doubles, rows of big_row doubles   (u: 0 x-part / values, 1 Jacobian role, 2 Hessian;
   // pk_err: its own buffer, one sub-slot per interval)
   double* big_stage;
+  // Status words in pinned host memory (system-scope atomics): [0] in-launch hand-offs of pk_cycle's partial sums that gave
+  // up waiting (the sums of that launch read NaN), [1] exchanges between the ranks that gave up (pk_xchg / in-launch).  The
+  // library compares them with what it has seen after every wait and turns a change into error 97 (pk_runtime.cpp).
+  unsigned long long* status;
   int32_t n_tiles, n_items;
-  int32_t n_items2, pad0;
+  int32_t n_items2, poll_limit;   // poll_limit > 0: poll rounds before a hand-off gives up (tests; 0: PK_POLL_LIMIT)
   int32_t n_phase, n;
   int32_t l_s, n_s, n_sys, m;
   int32_t gz_off, n_gz;   // ib: gradient slots the finalize kernel zero-fills

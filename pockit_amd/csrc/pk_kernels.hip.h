@@ -312,8 +312,8 @@ __device__ __forceinline__ void mfma_rows(const double* __restrict__ Amat, int l
 // (ordered before the next launch by the end of this one).  The data word is its own flag, so there is nothing to
 // order against it -- an arrival counter would need a release that writes back the whole dirty L2 (the variant
 // DESIGN.md section 5 measured at +6 us).  Forward progress: the publishers never wait for anything, the poller
-// occupies one workgroup slot; the poll is bounded (PK_POLL_LIMIT), after which the slot reads as NaN and the
-// launch ends with NaN in f / the gradient slots instead of hanging.
+// occupies one workgroup slot; the poll is bounded (PK_POLL_LIMIT), after which the slot reads as NaN, the launch ends with
+// NaN in f / the gradient slots instead of hanging AND counts the event in PkArgs.status: the library turns it into an error.
 #ifndef PK_POLL_SLEEP
 #define PK_POLL_SLEEP 4       // s_sleep between two poll rounds (x 64 cycles)
 #endif
@@ -2850,8 +2850,9 @@ __device__ __forceinline__ void exchange_partials(const PkArgs& A, const double*
   if (t < W && t != me) {                               // one polling thread per peer
     unsigned long long* flag = A.xc_box[me] + half + (size_t)t * A.xc_stride;
     long tries = 0;
-    while (sys_load(flag) != epoch && ++tries < (long)PK_XC_POLL_LIMIT) __builtin_amdgcn_s_sleep(PK_POLL_SLEEP);
-    if (tries >= (long)PK_XC_POLL_LIMIT) late = 1;
+    const long xlimit = A.poll_limit > 0 ? (long)A.poll_limit : (long)PK_XC_POLL_LIMIT;
+    while (sys_load(flag) != epoch && ++tries < xlimit) __builtin_amdgcn_s_sleep(PK_POLL_SLEEP);
+    if (tries >= xlimit) late = 1;
   }
   __threadfence_system();
   __syncthreads();
@@ -2865,6 +2866,10 @@ __device__ __forceinline__ void exchange_partials(const PkArgs& A, const double*
   if (t == 0) {
     if (A.xc_epoch <= 0) sys_store(state, epoch);       // (read again by the next launch of this stream)
     if (late) sys_store(state + 1, sys_load(state + 1) + 1ull);      // the host reads it: pk_exchange_status
+    if (late && A.status != nullptr) {
+      __hip_atomic_fetch_add(A.status + 1, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      __threadfence_system();
+    }
   }
   __syncthreads();
 }
@@ -2920,14 +2925,19 @@ __device__ __forceinline__ void fin_handoff(const PkArgs& A) {
                                        : nullptr;
     }
     // one poll round = the slots of ALL rows in flight together (one memory round trip), repeated until none is empty
-    for (int tries = 0; tries < PK_POLL_LIMIT; ++tries) {
-      bool empty = false;
+    const int limit = A.poll_limit > 0 ? A.poll_limit : PK_POLL_LIMIT;
+    bool empty = true;
+    for (int tries = 0; tries < limit && empty; ++tries) {
+      empty = false;
 #pragma unroll
       for (int row = 0; row < Gen::N_ROWS; ++row) bits[row] = slot[row] ? handoff_peek(slot[row]) : 0ull;
 #pragma unroll
       for (int row = 0; row < Gen::N_ROWS; ++row) empty |= bits[row] == PK_EMPTY;
-      if (!empty) break;
-      __builtin_amdgcn_s_sleep(PK_POLL_SLEEP);
+      if (empty) __builtin_amdgcn_s_sleep(PK_POLL_SLEEP);
+    }
+    if (empty && A.status != nullptr) {     // gave up: the sums of this launch are NaN -- tell the host, ahead of f
+      __hip_atomic_fetch_add(A.status, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      __threadfence_system();
     }
 #pragma unroll
     for (int row = 0; row < Gen::N_ROWS; ++row)

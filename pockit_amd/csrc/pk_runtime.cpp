@@ -79,6 +79,9 @@ struct pk_ctx {
   double *d_big_stage = nullptr, *d_err_stage = nullptr;
   int32_t big_row = 0, big_slot = 0, err_row = 0, err_slot = 0;
   unsigned long long *d_cpart = nullptr, *d_cpart2 = nullptr;   // pk_cycle's hand-off slots (PK_EMPTY between launches)
+  size_t cpart_slots = 0;
+  unsigned long long status_seen[2] = {0, 0};   // PkArgs.status as of the last check (handoff_check)
+  int poll_limit = 0;                           // > 0: poll rounds before a hand-off gives up ("poll_limit" host option; tests)
   unsigned profile_mask = 0;
   unsigned profile_period = 1;  // time every n-th launch of a selected kernel
   unsigned profile_seen[K_COUNT] = {};
@@ -314,6 +317,8 @@ PkArgs base_args(pk_ctx* c, const double* d_x, const double* d_lam, double sigma
   A.trace = c->d_trace;
   A.o_gshared = c->gshared;
   A.big_stage = c->d_big_stage; A.big_row = c->big_row; A.big_slot = c->big_slot;
+  A.status = c->h_out[0] ? reinterpret_cast<unsigned long long*>(c->h_out[0] + 6) : nullptr;
+  A.poll_limit = c->poll_limit;
   return A;
 }
 
@@ -500,8 +505,37 @@ int enqueue_mark(pk_ctx* c) {
   return 0;
 }
 
+// A hand-off that gave up waiting (pk_cycle's finalize workgroup for the partial sums of its own launch; the exchange of the
+// sums between the ranks) leaves NaN in f and in the gradient entries shared by all nodes -- indistinguishable, for a solver,
+// from a model that evaluates to NaN (which the reference passes on unchecked, examples/_plotting.py:58-63, and so do we).
+// The kernels count such events in two status words in pinned memory (PkArgs.status); every waiting entry point compares
+// them with what it saw last and turns a change into error 97: the hand-off slots are put back to PK_EMPTY (a publisher that
+// arrived after the give-up left its value behind), the staged iterate is dropped, the message says what happened.
+int handoff_check(pk_ctx* c) {
+  if (!c->h_out[0]) return 0;
+  const volatile unsigned long long* st = reinterpret_cast<const volatile unsigned long long*>(c->h_out[0] + 6);
+  const unsigned long long a = st[0], b = st[1];
+  if (a == c->status_seen[0] && b == c->status_seen[1]) return 0;
+  const unsigned long long da = a - c->status_seen[0], db = b - c->status_seen[1];
+  (void)hipStreamSynchronize(c->stream);
+  if (c->d_cpart && c->cpart_slots) {
+    const std::vector<unsigned long long> empty(c->cpart_slots, (unsigned long long)PK_EMPTY);
+    (void)hipMemcpy(c->d_cpart, empty.data(), sizeof(unsigned long long) * c->cpart_slots, hipMemcpyHostToDevice);
+    (void)hipMemcpy(c->d_cpart2, empty.data(), sizeof(unsigned long long) * c->cpart_slots, hipMemcpyHostToDevice);
+  }
+  c->status_seen[0] = st[0];
+  c->status_seen[1] = st[1];
+  c->x_valid = false;
+  c->lam_staged = false;
+  if (da)
+    return fail(c, 97, "pk_cycle: the finalize workgroup gave up waiting for %llu partial sum(s) of its own launch; f and the "
+                       "gradient entries shared by all nodes of this iterate are NaN (hand-off slots reset)", da);
+  return fail(c, 97, "%llu exchange(s) of the partial sums between the ranks gave up waiting for a peer; f and the shared "
+                     "gradient entries of this iterate are NaN on this rank", db);
+}
+
 // everything enqueued for the results has finished: the pending mark has been stored, or (no mark) the stream is idle
-int wait_results_landed(pk_ctx* c) {
+int wait_results_landed_raw(pk_ctx* c) {
   hipError_t e;
   if (c->mark_pending) {
     const volatile unsigned long long* word = reinterpret_cast<const volatile unsigned long long*>(c->h_out[0] + 4);
@@ -525,6 +559,11 @@ int wait_results_landed(pk_ctx* c) {
   if (e != hipSuccess) return fail(c, 100 + (int)e, "hipStreamQuery failed: %s", hipGetErrorString(e));
   c->idle_seq = seen;
   return 0;
+}
+
+int wait_results_landed(pk_ctx* c) {
+  const int rc = wait_results_landed_raw(c);
+  return rc ? rc : handoff_check(c);
 }
 
 int enqueue_result_copies(pk_ctx* c, unsigned mask) {
@@ -591,7 +630,7 @@ int enqueue_result_copies(pk_ctx* c, unsigned mask) {
 // pinned landing place, is awaited on its own word (PK_EMPTY until the system-scope store lands), every copied result by
 // polling the stream -- the result copies are the last thing an iterate enqueues, and an idle stream means every result
 // enqueued so far has landed.
-int wait_result(pk_ctx* c, int k) {
+int wait_result_raw(pk_ctx* c, int k) {
   if (c->done[k]) return 0;
   if (k == 0 && c->stored_direct[0] && c->spin_wait) {
     const volatile unsigned long long* word = (const volatile unsigned long long*)c->landed[0];
@@ -601,7 +640,11 @@ int wait_result(pk_ctx* c, int k) {
         const hipError_t e = hipStreamQuery(c->stream);
         if (e == hipSuccess) {
           c->idle_seq = seen;
-          if (*word == (unsigned long long)PK_EMPTY) return fail(c, 65, "the objective was not stored by its kernel");
+          if (*word == (unsigned long long)PK_EMPTY) {
+            // (an f computed from a hand-off that gave up carries the sentinel's own NaN payload: say what happened)
+            const int hc = handoff_check(c);
+            return hc ? hc : fail(c, 65, "the objective was not stored by its kernel");
+          }
           break;
         }
         if (e != hipErrorNotReady) return fail(c, 100 + (int)e, "waiting for f: %s", hipGetErrorString(e));
@@ -618,7 +661,7 @@ int wait_result(pk_ctx* c, int k) {
       c->done[1] = c->done[2] = true;
       return 0;
     }
-    int rc = wait_results_landed(c);
+    int rc = wait_results_landed_raw(c);
     if (rc) return rc;
     for (int j = 0; j < 5; ++j)
       if (c->enq[j]) c->done[j] = true;
@@ -627,6 +670,11 @@ int wait_result(pk_ctx* c, int k) {
   PK_HIP(c, hipEventSynchronize(c->ev_out[c->ev_of[k]]));
   c->done[k] = true;
   return 0;
+}
+
+int wait_result(pk_ctx* c, int k) {
+  const int rc = wait_result_raw(c, k);
+  return rc ? rc : handoff_check(c);
 }
 
 // stage `count` doubles in the next staging buffer of a double-buffered pair and queue their upload (dst == nullptr: stage
@@ -836,6 +884,7 @@ int pk_set_problem(pk_ctx* c, const pk_problem_desc* pd) {
     const std::vector<unsigned long long> empty(slots, (unsigned long long)PK_EMPTY);
     if ((rc = upload(c, (void**)&c->d_cpart, empty.data(), sizeof(unsigned long long) * slots))) return rc;
     if ((rc = upload(c, (void**)&c->d_cpart2, empty.data(), sizeof(unsigned long long) * slots))) return rc;
+    c->cpart_slots = slots;
   }
   {
     const size_t cnt[5] = {1, (size_t)c->n, (size_t)c->m, (size_t)c->nnz_J, (size_t)c->nnz_H};
@@ -846,7 +895,8 @@ int pk_set_problem(pk_ctx* c, const pk_problem_desc* pd) {
       PK_HIP(c, hipEventCreateWithFlags(&c->ev_lams[b], hipEventDisableTiming));
     }
     PK_HIP(c, hipHostMalloc((void**)&c->h_out[0], sizeof(double) * 8, hipHostMallocDefault));
-    std::memset(c->h_out[0], 0, sizeof(double) * 8);      // ([0] f, [4] the progress mark of mark_wait)
+    std::memset(c->h_out[0], 0, sizeof(double) * 8);      // ([0] f, [4] the progress mark of mark_wait, [6] [7] PkArgs.status)
+    c->status_seen[0] = c->status_seen[1] = 0;
     c->mark_val = 0; c->mark_op_seq = 0; c->mark_pending = false;
     PK_HIP(c, hipHostMalloc((void**)&c->h_out[3], sizeof(double) * (cnt[3] + cnt[1] + cnt[2] + 1), hipHostMallocDefault));
     PK_HIP(c, hipHostMalloc((void**)&c->h_out[4], sizeof(double) * (cnt[4] + 1), hipHostMallocDefault));
@@ -1438,7 +1488,7 @@ int pk_set_cycle_graph(pk_ctx* c, int enable) {
 int pk_sync(pk_ctx* c, void* stream) {
   if (!c) return fail(nullptr, 1, "null context");
   PK_HIP(c, hipStreamSynchronize(pick(c, stream)));
-  return 0;
+  return handoff_check(c);
 }
 
 // the same by polling the stream's state: the host learns ~8 us earlier than through hipStreamSynchronize that a copy has
@@ -1449,7 +1499,7 @@ int pk_wait_idle(pk_ctx* c, void* stream) {
   hipError_t e;
   while ((e = hipStreamQuery(st)) == hipErrorNotReady) { }
   if (e != hipSuccess) return fail(c, 100 + (int)e, "hipStreamQuery failed: %s", hipGetErrorString(e));
-  return 0;
+  return handoff_check(c);
 }
 
 // ---------------------------------------------------------------- host-buffer API
@@ -1464,7 +1514,7 @@ int pk_wait_idle(pk_ctx* c, void* stream) {
   if ((rc = (CALL))) return rc;                                                                             \
   PK_HIP(c, hipMemcpyAsync((OUT), (D_OUT), sizeof(double) * (size_t)(COUNT), hipMemcpyDeviceToHost, c->stream)); \
   PK_HIP(c, hipStreamSynchronize(c->stream));                                                               \
-  return 0;
+  return handoff_check(c);
 
 int pk_eval_f(pk_ctx* c, const double* x, double* f) { PK_HOST_EVAL((void)0, pk_eval_f_dev(c, c->d_x, c->d_f, nullptr), c->d_f, f, 1) }
 
@@ -1500,7 +1550,7 @@ int pk_eval_cycle(pk_ctx* c, const double* x, const double* lambda, double sigma
   PK_HIP(c, hipMemcpyAsync(jac, c->d_J, sizeof(double) * (size_t)c->nnz_J, hipMemcpyDeviceToHost, c->stream));
   PK_HIP(c, hipMemcpyAsync(hess, c->d_H, sizeof(double) * (size_t)c->nnz_H, hipMemcpyDeviceToHost, c->stream));
   PK_HIP(c, hipStreamSynchronize(c->stream));
-  return 0;
+  return handoff_check(c);
 }
 
 // ---------------------------------------------------------------- host shim: the "new x" protocol
@@ -2130,6 +2180,7 @@ int pk_set_host_option(pk_ctx* c, const char* name, int value) {
   else if (!std::strcmp(name, "small_x_kb")) c->small_x_kb = value < 0 ? 0 : (value > (1 << 20) ? (1 << 20) : value);
   else if (!std::strcmp(name, "adaptive_prefetch")) { c->adaptive_prefetch = value != 0; c->cur_J_asked = true; }
   else if (!std::strcmp(name, "mark_wait")) { c->mark_wait = value != 0; c->mark_pending = false; }
+  else if (!std::strcmp(name, "poll_limit")) { c->poll_limit = value < 0 ? 0 : value; drop_cycle_graph(c); }
   else return fail(c, 67, "pk_set_host_option: unknown option \"%s\"", name);
   return 0;
 }

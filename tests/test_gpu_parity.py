@@ -1601,3 +1601,35 @@ def test_high_order_reference_vectors_with_the_reference_table_recipe(name):
         system._invalidate()
     finally:
         collocation.use_reference_recipe(False)
+
+
+def test_a_hand_off_that_gives_up_is_an_error_not_a_silent_nan():
+    """pk_cycle's finalize workgroup receives the partial sums of its own launch through hand-off slots and gives up after a
+    bounded number of polls.  With the bound shortened to ONE poll round (host option ``poll_limit``) it gives up before the
+    tile workgroups of a 12k-node launch can have published: the callbacks must raise (error 97, pk_last_error says what
+    happened) instead of handing the solver NaN; the library resets the hand-off slots, so the next iterate is right again.
+    A NaN that comes from the MODEL still flows through unchecked, as in the reference (examples/_plotting.py:58-63)."""
+    import pockit_amd.radau as radau
+
+    system, _, guess = models.planar_quadrotor(radau, 2000, 6)
+    x, lam, sigma = models.bench_inputs(system, guess)
+    ev = system.evaluator
+    lib, h = ev.ctx.lib, ev.ctx.handle
+    good = ev.cycle(x, lam, sigma)
+    assert np.isfinite(good[0])
+    ev.ctx.check(lib.pk_set_host_option(h, b"poll_limit", 1))
+    try:
+        with pytest.raises(RuntimeError, match="gave up waiting"):
+            ev.cycle(x * (1.0 + 1e-9), lam, sigma)
+        with pytest.raises(RuntimeError, match="error 97"):
+            system.objective(x * (1.0 + 2e-9))         # the solver-side callbacks report it too (f is waited for first)
+    finally:
+        ev.ctx.check(lib.pk_set_host_option(h, b"poll_limit", 0))
+    again = ev.cycle(x, lam, sigma)
+    for a, b in zip(again, good):
+        assert np.array_equal(np.asarray(a), np.asarray(b))
+    close(system.objective(x), good[0], what="f after the reset")
+    bad = x.copy()
+    bad[5] = np.nan                                    # a state value: the model itself now evaluates to NaN
+    f = system.objective(bad)                          # no exception
+    assert np.isnan(f) or np.isnan(system.constraints(bad)).any()
