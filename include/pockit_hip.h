@@ -58,6 +58,7 @@ typedef struct pk_model_desc {
   int32_t sharded;      /* 1 if the code object was generated with PK_SHARDED (in-launch exchange between GPUs)       */
   int32_t lds_jc;       /* LDS doubles per wave of the compact Jacobian kernel (pk_jacc)                                */
   int32_t ne_jc;        /* scalar expressions of the compact Jacobian                                                   */
+  int32_t max_phases;   /* PK_MAX_PHASES the code object was compiled with (0: 8): phase records in its kernel arguments */
 } pk_model_desc;
 
 /* One (model, mesh) instance: sizes plus the table blobs built by pockit_amd/evaluator.py.
@@ -287,6 +288,11 @@ int pk_eval_cycle_dev_repeat(pk_ctx* ctx, const double* d_x, const double* d_lam
 int pk_set_cycle_graph(pk_ctx* ctx, int enable);
 /* single_launch = 1 (default): pk_cycle; 0: the two-launch form, pk_xall then pk_hess, which also reduces */
 int pk_set_cycle_mode(pk_ctx* ctx, int single_launch);
+/* Which layouts pk_eval_cycle_dev[_repeat] writes: 0 = the reference's triplet lists (systembase.py:676-693, 820-835), 1 = the
+ * compact layouts of pk_set_problem (nnz_Jc / nnz_Hc values: pk_eval_jacc / pk_eval_hessc).  A compact
+ * cycle stays ONE launch: the compact kernels' tile code runs in the Jacobian / Hessian roles of pk_cycle.  Error 69 for a
+ * model whose system functions are nonlinear in the integrals or a mesh with an interval of more than 64 points. */
+int pk_set_cycle_layout(pk_ctx* ctx, int jac_compact, int hess_compact);
 int pk_sync(pk_ctx* ctx, void* stream);
 int pk_wait_idle(pk_ctx* ctx, void* stream);   /* the same by polling the stream (returns a few microseconds earlier) */
 

@@ -244,6 +244,73 @@ def two_stage_rocket(ns, mesh=96, num_point=1):
     return system, [p1, p2], [g1, g2, static]
 
 
+def three_stage_rocket(ns, mesh=96, num_point=1):
+    """Stand-in for BASELINE.json's literal configs[3] ("multiphase_two_stage_rocket, 3 phases x 1000 intervals"): the
+    reference's example has TWO phases (examples/multiphase_two_stage_rocket.py:90-113); this is the same vertical-ascent
+    model with a THIRD burn stage and a second mass drop, linked through static parameters in the same way (FUNC boundary
+    values and times of twelve static parameters).  Not a reference program -- a synthetic workload for the phase fan-out."""
+    gravity, m0 = 1.0, 1.0
+    prop = (0.06, 0.08, 0.06)
+    drop = (0.20, 0.12)
+    thrust, flow = (2.40, 1.60, 1.10), (0.080, 0.045, 0.030)
+    target_alt = 2.6
+    m_start = [m0, m0 - prop[0] - drop[0], m0 - prop[0] - drop[0] - prop[1] - drop[1]]
+    m_dry = [m_start[k] - prop[k] for k in range(3)]
+
+    system = ns.System(
+        ["h_sep_1", "v_sep_1", "m_before_1", "m_after_1", "t_sep_1",
+         "h_sep_2", "v_sep_2", "m_before_2", "m_after_2", "t_sep_2", "m_final", "t_final"]
+    )
+    h1, v1, mb1, ma1, t1, h2, v2, mb2, ma2, t2, m_f, t_f = system.s
+
+    def stage(phase, k, boundaries, times):
+        altitude, velocity, mass = phase.x
+        (throttle,) = phase.u
+        phase.set_dynamics([velocity, thrust[k] * throttle / mass - gravity, -flow[k] * throttle])
+        phase.set_integral([throttle**2])
+        phase.set_phase_constraint(
+            [throttle, altitude, velocity, mass],
+            [0.0, 0.0, 0.0, m_dry[k]],
+            [1.0, target_alt, 3.0, m_start[k]],
+            [True, False, False, False],
+        )
+        phase.set_boundary_condition(*boundaries, *times)
+        phase.set_discretization(mesh, num_point)
+
+    p1 = system.new_phase(["altitude_1", "velocity_1", "mass_1"], ["throttle_1"])
+    stage(p1, 0, ([0.0, 0.0, m0], [h1, v1, mb1]), (0.0, t1))
+    p2 = system.new_phase(["altitude_2", "velocity_2", "mass_2"], ["throttle_2"])
+    stage(p2, 1, ([h1, v1, ma1], [h2, v2, mb2]), (t1, t2))
+    p3 = system.new_phase(["altitude_3", "velocity_3", "mass_3"], ["throttle_3"])
+    stage(p3, 2, ([h2, v2, ma2], [target_alt, 0.0, m_f]), (t2, t_f))
+
+    system.set_phase([p1, p2, p3])
+    system.set_objective(t_f + 0.04 * (p1.I[0] + p2.I[0] + p3.I[0]))
+    system.set_system_constraint(
+        [h1, v1, mb1, ma1 - mb1, t1, h2 - h1, v2, mb2, ma2 - mb2, t2 - t1, m_f, t_f - t2, t_f],
+        [0.10, 0.05, m_dry[0], -drop[0], 0.20, 0.05, 0.05, m_dry[1], -drop[1], 0.20, m_dry[2], 0.30, 1.00],
+        [1.80, 2.50, m_dry[0], -drop[0], 3.00, 1.80, 2.50, m_start[1], -drop[1], 4.00, m_start[2], 5.00, 9.00],
+    )
+
+    knots_t = [0.0, 1.10, 2.40, 4.20]
+    knots_h = [0.0, 0.40, 1.30, target_alt]
+    knots_v = [0.0, 0.80, 0.90, 0.0]
+    guesses = []
+    for k, p in enumerate((p1, p2, p3)):
+        g = ns.linear_guess(p, 0.0)
+        g.t_0, g.t_f = knots_t[k], knots_t[k + 1]
+        span = knots_t[k + 1] - knots_t[k]
+        tau = (g.t_x - knots_t[k]) / span
+        g.x[0] = knots_h[k] + (knots_h[k + 1] - knots_h[k]) * tau
+        g.x[1] = knots_v[k] * (1 - tau) + knots_v[k + 1] * tau + 0.3 * np.sin(np.pi * tau)
+        g.x[2] = m_start[k] + (m_dry[k] + 0.4 * prop[k] - m_start[k]) * tau
+        g.u[0] = np.where((g.t_u - knots_t[k]) / span < 0.6, 0.85, 0.1)
+        guesses.append(g)
+    static = [knots_h[1], knots_v[1], m_dry[0] + 0.4 * prop[0], m_start[1], knots_t[1],
+              knots_h[2], knots_v[2], m_dry[1] + 0.4 * prop[1], m_start[2], knots_t[2], m_dry[2] + 0.4 * prop[2], knots_t[3]]
+    return system, [p1, p2, p3], guesses + [static]
+
+
 # --------------------------------------------------------------------------- humanoid WBC
 _H = dict(
     TORSO=0.60, UPPER=0.38, FORE=0.30, HORIZON=2.5, KP=36.0, KD=12.0,
@@ -353,6 +420,89 @@ def humanoid_wbc(ns, mesh=10, num_point=4):
     au = (60.0 * tu - 180.0 * tu**2 + 120.0 * tu**3) / c["HORIZON"] ** 2
     for j in range(5):
         guess.u[j] = d[j] * au
+    return system, [phase], [guess]
+
+
+def humanoid_team(ns, mesh=10, num_point=4, copies=4, coupling=6.0):
+    """Stand-in for BASELINE.json's literal configs[4] ("humanoid_whole_body_control, ~40-state"): the reference's example
+    has 10 states + 5 controls (examples/humanoid_whole_body_control.py:160-180).  This is ``copies`` of that whole-body
+    model in ONE phase -- 10 x copies states, 5 x copies controls -- whose torsos are coupled by springs (torso k is pulled
+    towards torso k + 1), so the derivative set does not fall apart into independent blocks.  Not a reference program: a
+    synthetic wide model for the width scaling of the kernels (its derivative set is evaluated in groups)."""
+    c = _H
+    right0 = _humanoid_hands_numeric(c["Q0"])[0]
+    left_target = _humanoid_hands_numeric(c["Q_LEFT_TARGET"])[1]
+    joints = ("torso", "right_shoulder", "right_elbow", "left_shoulder", "left_elbow")
+    system = ns.System(0)
+    phase = system.new_phase(
+        [f"{j}_angle_{k}" for k in range(copies) for j in joints] + [f"{j}_rate_{k}" for k in range(copies) for j in joints],
+        [f"null_{j}_acceleration_{k}" for k in range(copies) for j in joints])
+    nq = 5 * copies
+    Q = [sp.Matrix(phase.x[5 * k:5 * k + 5]) for k in range(copies)]
+    QD = [sp.Matrix(phase.x[nq + 5 * k:nq + 5 * k + 5]) for k in range(copies)]
+    Z = [sp.Matrix(phase.u[5 * k:5 * k + 5]) for k in range(copies)]
+    tau = phase.t / c["HORIZON"]
+    prog = 10.0 * tau**3 - 15.0 * tau**4 + 6.0 * tau**5
+    prog_r = (30.0 * tau**2 - 60.0 * tau**3 + 30.0 * tau**4) / c["HORIZON"]
+    prog_a = (60.0 * tau - 180.0 * tau**2 + 120.0 * tau**3) / c["HORIZON"] ** 2
+    disp = sp.Matrix(c["RIGHT_DISP"])
+    accel, cost = [], 0
+    for k in range(copies):
+        q, qd, z = Q[k], QD[k], Z[k]
+        _, rs, re, ls, le = q
+        sh = sp.Matrix([0.0, c["TORSO"]])
+        right_hand = sh + sp.Matrix([c["UPPER"] * sp.cos(rs) + c["FORE"] * sp.cos(rs + re),
+                                     c["UPPER"] * sp.sin(rs) + c["FORE"] * sp.sin(rs + re)])
+        left_hand = sh + sp.Matrix([-c["UPPER"] * sp.cos(ls) - c["FORE"] * sp.cos(ls + le),
+                                    c["UPPER"] * sp.sin(ls) + c["FORE"] * sp.sin(ls + le)])
+        Jr = right_hand.jacobian(q)
+        Jl = left_hand.jacobian(q)
+        Jr_dot = sp.zeros(2, 5)
+        for i in range(5):
+            Jr_dot += Jr.diff(q[i]) * qd[i]
+        arm = Jr[:, 1:3]
+        det = arm[0, 0] * arm[1, 1] - arm[0, 1] * arm[1, 0]
+        arm_inv = sp.Matrix([[arm[1, 1], -arm[0, 1]], [-arm[1, 0], arm[0, 0]]]) / det
+        pinv = sp.zeros(5, 2)
+        pinv[1:3, :] = arm_inv
+        null_proj = sp.diag(1.0, 0.0, 0.0, 1.0, 1.0)
+        scale = 1.0 + 0.1 * k                                    # (the copies follow slightly different reference motions)
+        des_p = sp.Matrix(right0) + disp * prog * scale
+        des_v = disp * prog_r * scale
+        des_a = disp * prog_a * scale
+        a_ref = des_a + c["KP"] * (des_p - right_hand) + c["KD"] * (des_v - Jr * qd)
+        qdd = pinv * (a_ref - Jr_dot * qd) + null_proj * z
+        qdd[0] += -coupling * (q[0] - Q[(k + 1) % copies][0])     # torso spring to the next copy
+        accel.append(qdd)
+        left_err = left_hand - sp.Matrix(left_target)
+        left_vel = Jl * qd
+        cost += (c["W_LEFT_POS"] * left_err.dot(left_err) + c["W_LEFT_VEL"] * left_vel.dot(left_vel)
+                 + c["W_TORSO"] * q[0] ** 2 + c["W_QD"] * qd.dot(qd) + c["W_NULL"] * z.dot(z))
+    phase.set_dynamics([v for qd in QD for v in qd] + [a for qdd in accel for a in qdd])
+    phase.set_integral([cost])
+    phase.set_phase_constraint(
+        [*phase.x, *phase.u],
+        [*(list(c["Q_LO"]) * copies), *([-c["MAX_QD"]] * nq), *([-c["MAX_NULL"]] * nq)],
+        [*(list(c["Q_HI"]) * copies), *([c["MAX_QD"]] * nq), *([c["MAX_NULL"]] * nq)],
+    )
+    phase.set_boundary_condition([*(list(c["Q0"]) * copies), *np.zeros(nq)], [None] * (2 * nq), 0.0, c["HORIZON"])
+    phase.set_discretization(mesh, num_point)
+    system.set_phase([phase])
+    system.set_objective(phase.I[0])
+
+    guess = ns.linear_guess(phase, 0.0)
+    final = np.array([0.03, -0.36, 0.92, -0.45, 1.00])
+    d = final - np.array(c["Q0"])
+    tx = guess.t_x / c["HORIZON"]
+    px = 10.0 * tx**3 - 15.0 * tx**4 + 6.0 * tx**5
+    rx = (30.0 * tx**2 - 60.0 * tx**3 + 30.0 * tx**4) / c["HORIZON"]
+    tu = guess.t_u / c["HORIZON"]
+    au = (60.0 * tu - 180.0 * tu**2 + 120.0 * tu**3) / c["HORIZON"] ** 2
+    for k in range(copies):
+        for j in range(5):
+            guess.x[5 * k + j] = c["Q0"][j] + d[j] * px
+            guess.x[nq + 5 * k + j] = d[j] * rx
+            guess.u[5 * k + j] = d[j] * au
     return system, [phase], [guess]
 
 

@@ -520,6 +520,13 @@ class ModelSource:
         nP = self.nphase
         S = []
         S.append("// Generated by pockit_amd.codegen -- model code only; kernels are in pk_kernels.hip.h")
+        # phase records the kernels take by value in their arguments: 8 unless the model has more (pk_abi.h)
+        self.max_phases = 8 if nP <= 8 else nP
+        if nP > 24:
+            raise ValueError(f"{nP} phases: the MI355X evaluator passes at most 24 phase records in its kernel arguments "
+                             "(PK_HOST_MAX_PHASES, pk_abi.h)")
+        if self.max_phases != 8:
+            S.append(f"#define PK_MAX_PHASES {self.max_phases}")
         S.append(f"#define PK_NRED {self.nred}")
         S.append(f"#define PK_NPHASE {nP}")
         S.append(f"#define PK_NS {max(plan.n_s, 1)}")
@@ -603,6 +610,8 @@ class ModelSource:
         self.lds_e = 64 * max([1] + [3 * pp.nx + 2 * pp.nu for pp in plan.phase_plans])
         self.lds_jc = 64 * max([1] + [(sum(1 for sg in plan.jacc.segs[k] if sg.kind in "ID") if self.groups[("jacc", k)][0][0] < 0 else
                                        max([1] + [c for kd, _, c in self.groups[("jacc", k)] if kd < 2])) for k in range(nP)]) if self.compact_j else 64
+        # (a cycle launch that serves the compact Jacobian runs tile_jacc in the x-part's LDS rows)
+        self.lds_x = max(self.lds_x, self.lds_jc)
         S.append(f"  static constexpr int LDS_G = {self.lds_g}, LDS_J = {self.lds_j}, LDS_H = {self.lds_h}, "
                  f"LDS_X = {self.lds_x}, LDS_E = {self.lds_e}, LDS_JC = {self.lds_jc};")
         S.append("  __device__ static __forceinline__ void interval_err(int phase, const PkArgs& A, int first, int cnt, "
@@ -615,7 +624,7 @@ class ModelSource:
         S.append("  }")
         targets = [(n, f"pk::tile_{n}<{{P}}>") for n in ("int", "g", "grad", "jac", "hess", "aux", "hessc", "jacc")]
         targets += [("xall", "pk::tile_xall<{P}, 0>"), ("xall1", "pk::tile_xall<{P}, 1>"),
-                    ("xall2", "pk::tile_xall<{P}, 2>")]
+                    ("xall2", "pk::tile_xall<{P}, 2>"), ("xall1c", "pk::tile_xall<{P}, 1, true>")]
         for name, target in targets:
             pub = name.startswith("xall")      # the x-kernels take the hand-off block of a pk_cycle launch (-1: none)
             S.append(f"  __device__ static __forceinline__ void tile_{name}(int phase, const PkArgs& A, const PkTile& tl, "

@@ -1309,7 +1309,9 @@ __device__ __forceinline__ void tile_hess(const PkArgs& A, const PkTile& tl, dou
 // (one joint CSE over all model functions; x read once).  Used by pk_eval_cycle_dev.
 // LDS: [NX dynamics values | J_NI Jacobian segments] x 64 lanes.
 // ============================================================================================
-template <class P, int ROLE, bool STAGED>
+// CJ: the launch serves the COMPACT Jacobian layout (pk_cycle, flags bit 9): the values wave leaves the translation entries
+// to the wave that runs tile_jacc (the compact layout has runs of its own for them)
+template <class P, int ROLE, bool STAGED, bool CJ>
 __device__ __forceinline__ void xall_phase_b(const PkArgs& A, const PkPhase& ph, const PkTile& tl, const TileGeom& g,
                                              const TileTabs& T, const double* s, double dt,
                                              const double* __restrict__ sv, const double* __restrict__ jsv,
@@ -1321,7 +1323,7 @@ __device__ __forceinline__ void xall_phase_b(const PkArgs& A, const PkPhase& ph,
   if (tl.nj == 0) return;
   // the constant translation entries of J go out with the VALUES wave: the Jacobian wave's streaming is the longest
   // chain of the launch (wave timeline), the values wave has ~1 us of slack after its defect rows
-  if (ROLE != 2 && !PK_DIAG(16384)) write_translation<P, STAGED>(A, ph, tl, T, tbase, lane);
+  if (ROLE != 2 && !CJ && !PK_DIAG(16384)) write_translation<P, STAGED>(A, ph, tl, T, tbase, lane);
   PK_MARK(7);
   if (ROLE == 1) return;
   if (!PK_DIAG(32768))
@@ -1335,7 +1337,7 @@ __device__ __forceinline__ void xall_phase_b(const PkArgs& A, const PkPhase& ph,
 // halved.  A workgroup holds four waves of ONE role (four consecutive tiles).
 // pub_blk >= 0 (pk_cycle, roles 0 / 1): the workgroup hands its partial sums to the launch's finalize workgroup as
 // soon as they exist (handoff_put) -- before its own staging, defect and streaming work.
-template <class P, int ROLE>
+template <class P, int ROLE, bool CJ>
 __device__ __forceinline__ void tile_xall_single(const PkArgs& A, const PkTile& tl, double* __restrict__ sv,
                                                  double* __restrict__ wint, double* __restrict__ wgrad, int lane,
                                                  int pub_blk) {
@@ -1439,7 +1441,7 @@ __device__ __forceinline__ void tile_xall_single(const PkArgs& A, const PkTile& 
   wave_lds_sync();
   PK_MARK(5);
   if (PK_DIAG(256)) return;   // diagnostic build switches: skip the phases after the staging (all / one by one)
-  PK_PHASE_B(T, (xall_phase_b<P, ROLE, STAGED>(A, ph, tl, g, T, s, dt, sv, jsv, xr, xe, segb, tbase, lane PK_TRACE_ARG)));
+  PK_PHASE_B(T, (xall_phase_b<P, ROLE, STAGED, CJ>(A, ph, tl, g, T, s, dt, sv, jsv, xr, xe, segb, tbase, lane PK_TRACE_ARG)));
   PK_MARK(8);
 #ifdef PK_TRACE
   __builtin_amdgcn_s_waitcnt(0);      // all stores acknowledged
@@ -1449,14 +1451,14 @@ __device__ __forceinline__ void tile_xall_single(const PkArgs& A, const PkTile& 
 
 // The fused x-part of a model whose Jacobian is evaluated in groups: the VALUES part (g, grad f, integrand sums; P::mid_xval)
 // exactly as in the single-pass code, then the Jacobian segments group by group (jac_groups, the passes of pk_jac).
-template <class P, int ROLE, bool STAGED>
+template <class P, int ROLE, bool STAGED, bool CJ>
 __device__ __forceinline__ void xval_phase_b(const PkArgs& A, const PkPhase& ph, const PkTile& tl, const TileGeom& g,
                                              const TileTabs& T, const double* s, double dt, const double* __restrict__ sv,
                                              const double* xr, double* xe, const SegBases<P::NX>& tbase, int lane) {
   write_defects<P, STAGED>(A, ph, tl, g, T, s, dt, sv, xr, xe, lane);
-  if (tl.nj != 0) write_translation<P, STAGED>(A, ph, tl, T, tbase, lane);
+  if (!CJ && tl.nj != 0) write_translation<P, STAGED>(A, ph, tl, T, tbase, lane);
 }
-template <class P, int ROLE>
+template <class P, int ROLE, bool CJ>
 __device__ __forceinline__ void tile_xall_grouped(const PkArgs& A, const PkTile& tl, double* __restrict__ sv,
                                                   double* __restrict__ wint, double* __restrict__ wgrad, int lane,
                                                   int pub_blk) {
@@ -1537,19 +1539,19 @@ __device__ __forceinline__ void tile_xall_grouped(const PkArgs& A, const PkTile&
       }
     }
     wave_lds_sync();
-    PK_PHASE_B(T, (xval_phase_b<P, ROLE, STAGED>(A, ph, tl, g, T, s, dt, sv, xr, xe, tbase, lane)));
+    PK_PHASE_B(T, (xval_phase_b<P, ROLE, STAGED, CJ>(A, ph, tl, g, T, s, dt, sv, xr, xe, tbase, lane)));
   } else {
     wave_lds_sync();                                        // (the table blocks the wave staged for itself)
   }
   if (ROLE != 1) jac_groups<P, 0>(A, ph, tl, g, T, a, tau, dt, w, sy, jsv, segb, lane, q, live);
 }
 
-template <class P, int ROLE>
+template <class P, int ROLE, bool CJ = false>
 __device__ __forceinline__ void tile_xall(const PkArgs& A, const PkTile& tl, double* __restrict__ sv,
                                           double* __restrict__ wint, double* __restrict__ wgrad, int lane,
                                           int pub_blk) {
-  if constexpr (P::J_NG == 1) tile_xall_single<P, ROLE>(A, tl, sv, wint, wgrad, lane, pub_blk);
-  else tile_xall_grouped<P, ROLE>(A, tl, sv, wint, wgrad, lane, pub_blk);
+  if constexpr (P::J_NG == 1) tile_xall_single<P, ROLE, CJ>(A, tl, sv, wint, wgrad, lane, pub_blk);
+  else tile_xall_grouped<P, ROLE, CJ>(A, tl, sv, wint, wgrad, lane, pub_blk);
 }
 
 #ifdef PK_BIG
@@ -2713,8 +2715,9 @@ __device__ __forceinline__ void kernel_cycle(const PkTile* pre_tile, int pre_n_t
 #ifdef PK_TRACE
     if (A.trace != nullptr && threadIdx.x == 0) A.trace[(size_t)rec * 16 + 14] = __builtin_readcyclecounter();
 #endif
-    if (blockIdx.x == 0) edge_block<Gen>(A, 0, true, A.items, A.n_items);
-    else if (blockIdx.x == 1) { if (!(pre_flags & 128)) edge_block<Gen>(A, 1, false, A.items2, A.n_items2); }
+    // (flags bit 9 / bit 8: the launch serves the compact Jacobian / Hessian layout -- the host passes that layout's items)
+    if (blockIdx.x == 0) edge_block<Gen>(A, (pre_flags & 512) ? 4 : 0, true, A.items, A.n_items);
+    else if (blockIdx.x == 1) { if (!(pre_flags & 128)) edge_block<Gen>(A, (pre_flags & 256) ? 3 : 1, false, A.items2, A.n_items2); }
     else fin_handoff<Gen>(A);
 #ifdef PK_TRACE
     __builtin_amdgcn_s_waitcnt(0);
@@ -2745,14 +2748,28 @@ __device__ __forceinline__ void kernel_cycle(const PkTile* pre_tile, int pre_n_t
     return;
   }
 #endif
-  if (sub == (split ? 2 : 1))
-    Gen::tile_hess(tl.phase, A, tl, PK_STAGE(A) + wave * Gen::LDS_H, wint, wgrad, lane);
-  else if (!split)
-    Gen::tile_xall(tl.phase, A, tl, PK_STAGE(A) + wave * Gen::LDS_X, wint + wave * PK_NRED, wgrad + wave * PK_NRED, lane, blk);
-  else if (sub == 0)
-    Gen::tile_xall2(tl.phase, A, tl, PK_STAGE(A) + wave * Gen::LDS_X, wint + wave * PK_NRED, wgrad + wave * PK_NRED, lane, -1);
-  else
-    Gen::tile_xall1(tl.phase, A, tl, PK_STAGE(A) + wave * Gen::LDS_X, wint + wave * PK_NRED, wgrad + wave * PK_NRED, lane, blk);
+  // The compact layouts ride in the same launch (flags bit 8: Hessian, bit 9: Jacobian; the host sets them only for meshes
+  // without workgroup-wide intervals): the Hessian workgroups run the per-node compact kernel body (tile_hessc), the
+  // Jacobian role runs tile_jacc, the values role leaves the translation entries to it -- a compact cycle is ONE launch too.
+  const bool ch = (pre_flags & 256) != 0, cj = (pre_flags & 512) != 0;
+  if (sub == (split ? 2 : 1)) {
+    if (ch) Gen::tile_hessc(tl.phase, A, tl, PK_STAGE(A) + wave * Gen::LDS_G, wint, wgrad, lane);
+    else Gen::tile_hess(tl.phase, A, tl, PK_STAGE(A) + wave * Gen::LDS_H, wint, wgrad, lane);
+  } else if (!split) {
+    if (cj) {      // (unsplit x-part: values, then the compact Jacobian, in the same wave and the same LDS rows)
+      Gen::tile_xall1c(tl.phase, A, tl, PK_STAGE(A) + wave * Gen::LDS_X, wint + wave * PK_NRED, wgrad + wave * PK_NRED, lane, blk);
+      pk::wave_lds_sync();
+      Gen::tile_jacc(tl.phase, A, tl, PK_STAGE(A) + wave * Gen::LDS_X, wint, wgrad, lane);
+    } else {
+      Gen::tile_xall(tl.phase, A, tl, PK_STAGE(A) + wave * Gen::LDS_X, wint + wave * PK_NRED, wgrad + wave * PK_NRED, lane, blk);
+    }
+  } else if (sub == 0) {
+    if (cj) Gen::tile_jacc(tl.phase, A, tl, PK_STAGE(A) + wave * Gen::LDS_X, wint, wgrad, lane);
+    else Gen::tile_xall2(tl.phase, A, tl, PK_STAGE(A) + wave * Gen::LDS_X, wint + wave * PK_NRED, wgrad + wave * PK_NRED, lane, -1);
+  } else {
+    if (cj) Gen::tile_xall1c(tl.phase, A, tl, PK_STAGE(A) + wave * Gen::LDS_X, wint + wave * PK_NRED, wgrad + wave * PK_NRED, lane, blk);
+    else Gen::tile_xall1(tl.phase, A, tl, PK_STAGE(A) + wave * Gen::LDS_X, wint + wave * PK_NRED, wgrad + wave * PK_NRED, lane, blk);
+  }
 }
 
 // The reductions over all workgroups, by ONE workgroup (all 256 threads must call it).

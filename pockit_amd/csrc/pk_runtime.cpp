@@ -37,6 +37,7 @@
 #include <vector>
 
 #include "../../include/pockit_hip.h"
+#define PK_MAX_PHASES 24      // (= PK_HOST_MAX_PHASES: the host-side PkArgs holds the most a code object may ask for)
 #include "pk_abi.h"
 
 namespace {
@@ -45,7 +46,8 @@ enum { K_INT = 0, K_FIN, K_G, K_GRAD, K_JAC, K_HESS, K_XALL, K_AUX, K_OUTER, K_H
 const char* const kKernelNames[K_COUNT] = {"pk_int", "pk_fin", "pk_g", "pk_grad", "pk_jac", "pk_hess", "pk_xall",
                                            "pk_aux", "pk_outer", "pk_hessc", "pk_err", "pk_csr", "pk_cycle", "pk_xchg", "pk_runs",
                                            "pk_jacc"};
-enum { F_WRITE_F = 1, F_SECONDARY = 2, F_FIN_INT = 8, F_FIN_GRAD = 16, F_SPLIT = 32, F_XCHG = 64, F_NO_HESS = 128 };
+enum { F_WRITE_F = 1, F_SECONDARY = 2, F_FIN_INT = 8, F_FIN_GRAD = 16, F_SPLIT = 32, F_XCHG = 64, F_NO_HESS = 128,
+       F_COMPACT_H = 256, F_COMPACT_J = 512 };
 
 thread_local std::string g_create_error;
 
@@ -207,6 +209,7 @@ struct pk_ctx {
   std::vector<std::pair<int64_t, int64_t>> jruns, jconst;      // (of the layout the shim serves; the other layout's are parked)
   std::vector<std::pair<int64_t, int64_t>> jruns_other, jconst_other;
   bool jac_compact = false;    // the host shim's Jacobian callback serves the compact layout (pk_set_jacobian_layout)
+  int cycle_layout = 0;        // what pk_eval_cycle_dev writes: bit 0 compact Jacobian, bit 1 compact Hessian (pk_set_cycle_layout)
   bool target_filled = false;  // the caller's J landing array (target[3]) already holds the constant runs (pk_callback_x blocks)
   bool jac_filled = false;     // ... and so does the landing place of the CURRENT iterate: its copy skips them
   // profiling
@@ -322,6 +325,11 @@ PkArgs base_args(pk_ctx* c, const double* d_x, const double* d_lam, double sigma
   return A;
 }
 
+// bytes of PkArgs the loaded code object declares: the head and as many phase records as it was compiled for
+size_t args_bytes(const pk_ctx* c) {
+  return offsetof(PkArgs, ph) + sizeof(PkPhase) * (size_t)(c->md.max_phases > 0 ? c->md.max_phases : 8);
+}
+
 int launch_raw(pk_ctx* c, int k, void* args, size_t sz, unsigned grid, size_t lds_bytes, hipStream_t st) {
   void* config[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, args, HIP_LAUNCH_PARAM_BUFFER_SIZE, &sz, HIP_LAUNCH_PARAM_END};
   EventPair ev{};
@@ -356,7 +364,7 @@ int launch_raw(pk_ctx* c, int k, void* args, size_t sz, unsigned grid, size_t ld
 }
 
 int launch(pk_ctx* c, int k, PkArgs& A, unsigned grid, size_t lds_bytes, hipStream_t st) {
-  return launch_raw(c, k, &A, sizeof(PkArgs), grid, lds_bytes, st);
+  return launch_raw(c, k, &A, args_bytes(c), grid, lds_bytes, st);
 }
 
 unsigned tile_blocks(const pk_ctx* c) { return (unsigned)((c->n_tiles + PK_WAVES_PER_BLOCK - 1) / PK_WAVES_PER_BLOCK); }
@@ -376,15 +384,20 @@ int xall_flags(const pk_ctx* c) { return c->split_xall ? F_SPLIT : 0; }
 
 // the cycle as ONE launch (pk_cycle): [edge J | edge H | finalize | tile slots: x block(s) + Hessian block per group]
 // (d_lam == NULL: the x-part alone -- the Hessian workgroups of the grid leave at once)
+// layout: bit 0 -- d_jac receives the COMPACT Jacobian (the Jacobian role of the launch runs pk_jacc's tile code), bit 1 --
+// d_hess receives the COMPACT Hessian (the Hessian workgroups run pk_hessc's); -1: what pk_set_cycle_layout chose
 int enqueue_single_launch_cycle(pk_ctx* c, const double* d_x, const double* d_lam, double sigma, double* d_f,
-                                double* d_grad, double* d_g, double* d_jac, double* d_hess, hipStream_t st) {
+                                double* d_grad, double* d_g, double* d_jac, double* d_hess, hipStream_t st, int layout = -1) {
+  if (layout < 0) layout = c->cycle_layout;
   PkArgs A = base_args(c, d_x, d_lam, sigma);
   if (!d_lam) A.flags |= F_NO_HESS;
   A.o_f = d_f; A.o_grad = d_grad; A.o_g = d_g; A.o_jac = d_jac; A.o_hess = d_hess;
-  A.items = (const PkItem*)c->d_items_jac;
-  A.n_items = c->n_items_jac;
-  A.items2 = (const PkItem*)c->d_items_hess;
-  A.n_items2 = c->n_items_hess;
+  A.items = (const PkItem*)((layout & 1) ? c->d_items_jacc : c->d_items_jac);
+  A.n_items = (layout & 1) ? c->n_items_jacc : c->n_items_jac;
+  A.items2 = (const PkItem*)((layout & 2) ? c->d_items_hessc : c->d_items_hess);
+  A.n_items2 = (layout & 2) ? c->n_items_hessc : c->n_items_hess;
+  if (layout & 1) A.flags |= F_COMPACT_J;
+  if (layout & 2) A.flags |= F_COMPACT_H;
   A.flags |= F_FIN_INT | F_WRITE_F | F_FIN_GRAD | xall_flags(c);
   if (c->xc_inline && c->xc_world > 1) {      // sharded: the sums over the ranks are exchanged inside this launch
     A.flags |= F_XCHG;
@@ -394,6 +407,13 @@ int enqueue_single_launch_cycle(pk_ctx* c, const double* d_x, const double* d_la
   size_t dbl = PK_WAVES_PER_BLOCK * (size_t)(c->md.lds_x > c->md.lds_h ? c->md.lds_x : c->md.lds_h);
   if (dbl < (size_t)c->md.ne_j) dbl = (size_t)c->md.ne_j;
   if (dbl < (size_t)c->md.ne_h) dbl = (size_t)c->md.ne_h;
+  if (layout & 1) {      // (tile_jacc stages in the x-part's rows: lds_x >= lds_jc by construction, codegen.py)
+    if (dbl < (size_t)c->md.ne_jc) dbl = (size_t)c->md.ne_jc;
+  }
+  if (layout & 2) {
+    if (dbl < PK_WAVES_PER_BLOCK * (size_t)c->md.lds_g) dbl = PK_WAVES_PER_BLOCK * (size_t)c->md.lds_g;
+    if (dbl < (size_t)c->md.ne_hc) dbl = (size_t)c->md.ne_hc;
+  }
   const unsigned per_group = c->split_xall ? 3u : 2u;
   const unsigned grid = tile_blocks(c) * per_group + 3u;
   // pk_cycle's kernarg segment: the scalars a tile wave needs first (preloaded into SGPRs), then the PkArgs
@@ -405,13 +425,14 @@ int enqueue_single_launch_cycle(pk_ctx* c, const double* d_x, const double* d_la
   static_assert(offsetof(CycleArgs, A) == PK_CYCLE_ARGS_OFFSET, "layout of pk_cycle's kernel arguments");
   K.tile = A.tile; K.n_tiles = A.n_tiles; K.flags = A.flags; K.grid = (int32_t)grid; K.pad = 0;
   K.A = A;
-  return launch_raw(c, K_CYCLE, &K, sizeof K, grid, sizeof(double) * dbl, st);
+  return launch_raw(c, K_CYCLE, &K, offsetof(CycleArgs, A) + args_bytes(c), grid, sizeof(double) * dbl, st);
 }
 
 int enqueue_fused_cycle(pk_ctx* c, const double* d_x, const double* d_lam, double sigma, double* d_f, double* d_grad,
                         double* d_g, double* d_jac, double* d_hess, hipStream_t st) {
   int rc;
   if (c->cycle_mode == 1) return enqueue_single_launch_cycle(c, d_x, d_lam, sigma, d_f, d_grad, d_g, d_jac, d_hess, st);
+  if (c->cycle_layout) return fail(c, 69, "the two-launch cycle (pk_set_cycle_mode 0) writes the reference layouts only");
   PkArgs A = base_args(c, d_x, nullptr, 0.0);
   A.o_f = d_f; A.o_grad = d_grad; A.o_g = d_g; A.o_jac = d_jac;
   A.items = (const PkItem*)c->d_items_jac;
@@ -781,6 +802,9 @@ int pk_load_model(pk_ctx* c, const void* code_object, size_t len, const pk_model
   for (int k = 0; k < K_COUNT; ++k) PK_HIP(c, hipModuleGetFunction(&c->fn[k], c->module, kKernelNames[k]));
   c->md = *md;
   if (md->tab_cap != 64 && md->tab_cap != 256) return fail(c, 23, "pk_load_model: table capacity %d (64 or 256)", md->tab_cap);
+  if (md->max_phases < 0 || md->max_phases > PK_HOST_MAX_PHASES || md->n_phase > (md->max_phases > 0 ? md->max_phases : 8))
+    return fail(c, 24, "pk_load_model: %d phases, code object compiled for %d (the library passes at most %d phase records in "
+                       "the kernel arguments)", md->n_phase, md->max_phases > 0 ? md->max_phases : 8, PK_HOST_MAX_PHASES);
   const size_t lds_max = 160 * 1024;
   const size_t need[4] = {(size_t)md->lds_g, (size_t)md->lds_j, (size_t)md->lds_h, (size_t)md->lds_x};
   for (size_t v : need)
@@ -794,7 +818,9 @@ int pk_set_problem(pk_ctx* c, const pk_problem_desc* pd) {
   if (!c) return fail(nullptr, 1, "null context");
   if (!c->have_model) return fail(c, 2, "pk_set_problem: load a model first");
   if (!pd) return fail(c, 30, "pk_set_problem: null descriptor");
-  if (pd->n_phase > PK_MAX_PHASES) return fail(c, 32, "pk_set_problem: at most %d phases are supported", PK_MAX_PHASES);
+  if (pd->n_phase > (c->md.max_phases > 0 ? c->md.max_phases : 8))
+    return fail(c, 32, "pk_set_problem: %d phases, but the code object was generated for at most %d", pd->n_phase,
+                c->md.max_phases > 0 ? c->md.max_phases : 8);
   if (pd->n_phase != c->md.n_phase) return fail(c, 31, "pk_set_problem: %d phases but the model was generated for %d", pd->n_phase, c->md.n_phase);
   PK_HIP(c, hipSetDevice(c->device));
   PK_HIP(c, hipStreamSynchronize(c->stream));
@@ -803,6 +829,7 @@ int pk_set_problem(pk_ctx* c, const pk_problem_desc* pd) {
   c->n_phase = pd->n_phase; c->n_tiles = pd->n_tiles; c->nnz_J = pd->nnz_J; c->nnz_H = pd->nnz_H;
   c->n_items_jac = pd->n_items_jac; c->n_items_hess = pd->n_items_hess; c->gz_off = pd->gz_off; c->n_gz = pd->n_gz;
   c->n_items_aux = pd->n_items_aux; c->n_outer = pd->n_outer; c->n_aux = pd->n_aux;
+  c->cycle_layout = 0;
   c->n_items_hessc = pd->n_items_hessc; c->nnz_Hc = pd->nnz_Hc;
   c->n_items_jacc = pd->n_items_jacc; c->nnz_Jc = pd->nnz_Jc;
   // Small meshes are bound by the serial chain of one wave, not by throughput: let two waves share a tile in
@@ -1350,6 +1377,8 @@ int pk_eval_cycle_dev(pk_ctx* c, const double* d_x, const double* d_lam, double 
   // general path: the five callbacks one after the other.  A shard (pk_set_shard) may take the single launch too: its
   // finalize workgroup then leaves THIS shard's share of the integrals and of the shared gradient slots for the
   // caller's all-reduce, and f is the caller's to recompute (pk_eval_f_from_integrals_dev).
+  if (c->cycle_layout && (needs_I || c->has_big || c->cycle_mode != 1))
+    return fail(c, 69, "pk_eval_cycle: the compact layouts ride in the single-launch cycle only");
   if (needs_I && c->has_big) {       // (big intervals: the fused x-kernel behind the integral prepass, then H)
     if ((rc = pk_eval_xpart_dev(c, d_x, d_f, d_grad, d_g, d_jac, stream))) return rc;
     return pk_eval_hess_dev(c, d_x, d_lam, sigma, d_hess, stream);
@@ -1437,6 +1466,12 @@ int pk_eval_cycle_dev_repeat(pk_ctx* c, const double* d_x, const double* d_lam, 
 // runs on a new x.  A shard (pk_set_shard) leaves ITS share of the integrals in the integral buffer and its partial sums
 // in the shared gradient slots; its f is not meaningful (the caller adds the integrals over the shards first).  Models
 // whose system functions are nonlinear in the integrals run the callbacks one after the other.
+// can the x-part of an iterate come from ONE pk_cycle launch without its Hessian role?
+static bool xpart_is_one_launch(const pk_ctx* c) {
+  const bool needs_I = c->md.prepass_grad || c->md.prepass_g || c->md.prepass_jac || c->md.prepass_hess;
+  return c->xpart_single && c->cycle_mode == 1 && !needs_I && c->profile_mask == 0 && !(c->xc_inline && c->xc_world > 1);
+}
+
 int pk_eval_xpart_dev(pk_ctx* c, const double* d_x, double* d_f, double* d_grad, double* d_g, double* d_jac, void* stream) {
   int rc = ready(c);
   if (rc) return rc;
@@ -1455,8 +1490,8 @@ int pk_eval_xpart_dev(pk_ctx* c, const double* d_x, double* d_f, double* d_grad,
   // workgroup inside the launch (host shim at 12k nodes: f is in pinned memory ~5 us earlier, and so is everything behind it)
   // (a shard takes it too, like pk_eval_cycle_dev: its finalize workgroup leaves THIS shard's share of the integrals and of
   //  the shared gradient slots for the caller to add up; never with the in-launch exchange, which belongs to whole cycles)
-  if (c->xpart_single && c->cycle_mode == 1 && !needs_I && c->profile_mask == 0 && !(c->xc_inline && c->xc_world > 1))
-    return enqueue_single_launch_cycle(c, d_x, nullptr, 0.0, d_f, d_grad, d_g, d_jac, nullptr, st);
+  if (xpart_is_one_launch(c))
+    return enqueue_single_launch_cycle(c, d_x, nullptr, 0.0, d_f, d_grad, d_g, d_jac, nullptr, st, 0);
   PkArgs A = base_args(c, d_x, nullptr, 0.0);
   A.o_f = d_f; A.o_grad = d_grad; A.o_g = d_g; A.o_jac = d_jac;
   A.items = (const PkItem*)c->d_items_jac;
@@ -1468,6 +1503,24 @@ int pk_eval_xpart_dev(pk_ctx* c, const double* d_x, double* d_f, double* d_grad,
   // (a shard of a model nonlinear in the integrals: the caller has summed the integrals over the ranks, they stay as they are)
   A.flags |= ((needs_I && c->external_prepass) ? 0 : (F_FIN_INT | F_WRITE_F)) | F_FIN_GRAD;
   return launch(c, K_FIN, A, 1, 0, st);
+}
+
+// Which layouts pk_eval_cycle_dev writes into d_jac / d_hess: 0 the reference's triplets (default), 1 the compact layout
+// (nnz_Jc / nnz_Hc values, the structures of pk_set_problem).  The compact layouts ride in the SAME single launch: the
+// Jacobian role runs pk_jacc's tile code, the Hessian workgroups pk_hessc's -- a compact cycle is one launch too.
+int pk_set_cycle_layout(pk_ctx* c, int jac_compact, int hess_compact) {
+  int rc = ready(c);
+  if (rc) return rc;
+  if (jac_compact && c->nnz_Jc <= 0) return fail(c, 52, "pk_set_cycle_layout: no compact Jacobian layout was supplied to pk_set_problem");
+  if (hess_compact && c->nnz_Hc <= 0) return fail(c, 51, "pk_set_cycle_layout: no compact Hessian layout was supplied to pk_set_problem");
+  const bool needs_I = c->md.prepass_grad || c->md.prepass_g || c->md.prepass_jac || c->md.prepass_hess;
+  if ((jac_compact || hess_compact) && (needs_I || c->has_big))
+    return fail(c, 69, "pk_set_cycle_layout: the compact layouts ride in the single-launch cycle, which this model / mesh does not "
+                       "use (system functions nonlinear in the integrals, or an interval with more than 64 points)");
+  c->cycle_layout = (jac_compact ? 1 : 0) | (hess_compact ? 2 : 0);
+  drop_cycle_graph(c);
+  if (c->rep_exec) { (void)hipGraphExecDestroy(c->rep_exec); c->rep_exec = nullptr; }
+  return 0;
 }
 
 // 1 (default): the cycle is ONE launch (pk_cycle); 0: two launches (pk_xall, then pk_hess with the reductions)
@@ -1872,9 +1925,15 @@ int pk_prepare_x(pk_ctx* c, const double* x) {
     o[k] = c->stored_direct[k] ? c->landed[k] : device_result(c, k);
   }
   if (c->stored_direct[0]) *(volatile unsigned long long*)c->landed[0] = (unsigned long long)PK_EMPTY;     // (see wait_result)
-  if ((rc = pk_eval_xpart_dev(c, c->x_src, o[0], o[1], o[2], c->jac_compact ? c->d_J : o[3], nullptr))) return rc;
-  // the compact layout of the Jacobian: its own kernel behind the fused x-kernel (whose reference-layout J stays on the device)
-  if (c->jac_compact && (rc = pk_eval_jacc_dev(c, c->x_src, o[3], nullptr))) return rc;
+  if (c->jac_compact && !c->has_big && xpart_is_one_launch(c)) {
+    // the compact layout of the Jacobian from the SAME launch: its Jacobian role runs pk_jacc's tile code (no reference-layout
+    // J is written, no second kernel)
+    if ((rc = enqueue_single_launch_cycle(c, c->x_src, nullptr, 0.0, o[0], o[1], o[2], o[3], nullptr, c->stream, 1))) return rc;
+  } else {
+    if ((rc = pk_eval_xpart_dev(c, c->x_src, o[0], o[1], o[2], c->jac_compact ? c->d_J : o[3], nullptr))) return rc;
+    // the compact layout of the Jacobian: its own kernel behind the fused x-kernel (whose reference-layout J stays on the device)
+    if (c->jac_compact && (rc = pk_eval_jacc_dev(c, c->x_src, o[3], nullptr))) return rc;
+  }
   // f and g are what a line search asks for at every trial point: always on their way; grad f and J in prefetch mode
   const bool ahead = c->prefetch && (!c->adaptive_prefetch || c->cur_J_asked);
   c->cur_J_asked = false;

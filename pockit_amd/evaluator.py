@@ -243,6 +243,7 @@ class Evaluator:
         md.ne_jc = self.src.list_off["jacc"]["total"] if self.src.compact_j else 0
         md.tab_cap = self.src.tab_cap
         md.sharded = int(self.src.sharded)
+        md.max_phases = self.src.max_phases
         self._err_views = None
         self._csr = {}
         md.prepass_f = 1
@@ -424,6 +425,12 @@ class Evaluator:
         if what in self._handed:             # asked twice for the same iterate: the first array is the caller's
             return own.copy()
         self._handed.add(what)
+        if what == 3 and self.jac_constant_runs:
+            # The landing block keeps the x-independent entries of J (the +-1 translation part) from iterate to iterate: they
+            # were filled in once and never cross PCIe again.  A caller that scaled this array in place would corrupt them for
+            # every later Jacobian served from the block, so the array is handed out READ-ONLY (the reference returns a fresh
+            # writable array; ``.copy()`` gives one, POCKIT_AMD_JAC_CONSTANTS=0 ships the whole Jacobian every time).
+            own.flags.writeable = False
         return own
 
     def objective(self, x):
@@ -686,6 +693,15 @@ class Evaluator:
     def set_cycle_mode(self, single_launch=True):
         """True (default): one cycle = one launch (pk_cycle).  False: pk_xall, then pk_hess with the reductions."""
         self.ctx.check(self.ctx.lib.pk_set_cycle_mode(self.ctx.handle, int(bool(single_launch))))
+
+    def set_cycle_layout(self, jacobian_compact=False, hessian_compact=False):
+        """What ``cycle_dev`` writes into its J / H buffers: the reference's triplet lists (default) or the compact layouts
+        (``plan.nnz_Jc`` / ``plan.nnz_Hc`` values) -- from the same single launch."""
+        if hessian_compact and not self.src.compact:
+            raise NotImplementedError("compact Hessian layout is not available for this model")
+        if jacobian_compact:
+            self.plan.jacc  # noqa: B018
+        self.ctx.check(self.ctx.lib.pk_set_cycle_layout(self.ctx.handle, int(bool(jacobian_compact)), int(bool(hessian_compact))))
 
     def profile_read(self):
         """{kernel name: (launches, total_ms)} accumulated while profiling was enabled."""

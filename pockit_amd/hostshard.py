@@ -60,7 +60,12 @@ class _AttachedSegment:
     def __init__(self, name, size):
         import mmap
 
-        fd = os.open("/dev/shm/" + name.lstrip("/"), os.O_RDWR)
+        try:                                   # (what SharedMemory itself calls; no resource-tracker registration)
+            import _posixshmem
+
+            fd = _posixshmem.shm_open("/" + name.lstrip("/"), os.O_RDWR, mode=0o600)
+        except ImportError:
+            fd = os.open("/dev/shm/" + name.lstrip("/"), os.O_RDWR)
         try:
             self._mmap = mmap.mmap(fd, size)
         finally:
@@ -88,11 +93,31 @@ class HostShardedEvaluator:
         if world > MAX_RANKS:
             raise ValueError(f"at most {MAX_RANKS} ranks")
         self.plan, self.rank, self.world, self.timeout_s = plan, rank, world, float(timeout_s)
-        if intervals_per_wave is None:
-            intervals_per_wave = _intervals_per_wave(plan, shards=world)
-        self.ev = Evaluator(plan, device=device, intervals_per_wave=intervals_per_wave,
-                            tile_filter=tile_filter(rank, world, plan) if world > 1 else None,
-                            output_share=1.0 / max(world, 1), host_helpers=False)
+        self.zero_copy = False      # True: callbacks return live views of the shared segment (valid until the next iterate)
+        self.ev = None
+        # Rank-local work that can fail alone (code generation, hipcc, pk_load_model, pk_set_problem): every rank reports its
+        # verdict BEFORE the first collective of the set-up, and all raise the same error if any failed -- a rank that raised
+        # alone would leave the others in the broadcast / barrier below until the backend's time-out.
+        problem = None
+        try:
+            if intervals_per_wave is None:
+                intervals_per_wave = _intervals_per_wave(plan, shards=world)
+            self.ev = Evaluator(plan, device=device, intervals_per_wave=intervals_per_wave,
+                                tile_filter=tile_filter(rank, world, plan) if world > 1 else None,
+                                output_share=1.0 / max(world, 1), host_helpers=False)
+        except Exception as exc:  # noqa: BLE001 -- reported to every rank below
+            problem = f"rank {rank}: {exc!r}"
+        if world > 1:
+            verdicts = [None] * world
+            dist.all_gather_object(verdicts, problem)
+        else:
+            verdicts = [problem]
+        failed = sorted(v for v in verdicts if v)
+        if failed:
+            if self.ev is not None:
+                self.ev.close()
+                self.ev = None
+            raise RuntimeError("HostShardedEvaluator: the rank-local set-up failed: " + "; ".join(failed))
         lib, h, chk = self.ev.ctx.lib, self.ev.ctx.handle, self.ev.ctx.check
         self.lib, self.h, self.chk = lib, h, chk
         n, m = plan.n, plan.m
@@ -115,8 +140,12 @@ class HostShardedEvaluator:
         name = [None]
         self.shm = None
         if rank == 0:
-            self.shm = shared_memory.SharedMemory(create=True, size=8 * words)
-            name[0] = self.shm.name
+            try:
+                self.shm = shared_memory.SharedMemory(create=True, size=8 * words)
+                name[0] = self.shm.name
+            except Exception as exc:  # noqa: BLE001 -- the other ranks learn it from the broadcast (name None)
+                name[0] = None
+                self._shm_error = repr(exc)
         try:
             self._set_up(plan, rank, world, dist, name, words, off, n, m)
         except BaseException:
@@ -129,6 +158,9 @@ class HostShardedEvaluator:
         lib, h, chk = self.lib, self.h, self.chk
         if world > 1:
             dist.broadcast_object_list(name, src=0)
+        if name[0] is None:
+            raise RuntimeError("HostShardedEvaluator: rank 0 could not create the shared segment"
+                               + (f" ({self._shm_error})" if rank == 0 else ""))
         if rank != 0:
             self.shm = _AttachedSegment(name[0], 8 * words)
         self.words = np.ndarray((words,), dtype=np.float64, buffer=self.shm.buf)
@@ -269,8 +301,12 @@ class HostShardedEvaluator:
 
         from . import runtime
 
-        lib.pk_host_threads(0)
-        runtime.host_helpers_stopped()
+        # The pool is process-wide (pk_host_threads): one that another evaluator of this process started is shared, and never
+        # stopped from here -- that evaluator may be in a pass on another thread right now.
+        self._own_helpers = False
+        running = runtime._HOST_HELPERS["k"]
+        if running:
+            return int(running)
         alone = pass_us()
         if lib.pk_host_threads(k):
             return 0
@@ -278,6 +314,8 @@ class HostShardedEvaluator:
         if helped > 0.75 * alone:
             lib.pk_host_threads(0)
             return 0
+        self._own_helpers = True
+        runtime._HOST_HELPERS["k"] = k
         return k
 
     def _upload_table(self, t):
@@ -488,29 +526,45 @@ class HostShardedEvaluator:
     def hessianstructure(self):
         return self.plan.hess_row, self.plan.hess_col
 
+    def _result(self, key):
+        """What a callback returns: an array the caller owns (the reference's semantics), or -- ``zero_copy``, which a solver
+        adapter sets when the solver copies at once, as cyipopt does -- the live view of the shared segment, valid until the
+        next iterate overwrites it."""
+        view = self.out[key]
+        return view if self.zero_copy else view.copy()
+
+    def _alive(self):
+        if self.shm is None or self.out is None:
+            raise RuntimeError("HostShardedEvaluator is closed")
+
     def objective(self, x):
+        self._alive()
         self._prepare(x)
         return np.float64(self.h_f[0])
 
     def gradient(self, x):
+        self._alive()
         self._prepare(x)
         self._j_asked = True
-        return self.out["grad"]
+        return self._result("grad")
 
     def constraints(self, x):
+        self._alive()
         self._prepare(x)
-        return self.out["g"]
+        return self._result("g")
 
     def jacobian(self, x):
+        self._alive()
         self._prepare(x)
         self._j_asked = True
         if self._j_seq == -1:                  # (the prepared iterate was taken for a trial point: its J is still on the GPUs)
             self._j_seq = self._post(CMD_J)
             self._do_j(self._j_seq)
         self._wait_marks("x", self._j_seq)
-        return self.out["J"]
+        return self._result("J")
 
     def hessian(self, x, lagrange, obj_factor):
+        self._alive()
         lam = np.ascontiguousarray(lagrange, dtype=np.float64)
         if lam.shape != (self.plan.m,):
             raise ValueError(f"lagrange must have shape ({self.plan.m},)")
@@ -525,12 +579,12 @@ class HostShardedEvaluator:
             same = self._is_prepared(x)
             self._wait_marks("h", seq)
             if same:
-                return self.out["H"]
+                return self._result("H")
         self._prepare(x)
         seq = self._post(CMD_HESS)
         self._do_hess(seq)
         self._wait_marks("h", seq)
-        return self.out["H"]
+        return self._result("H")
 
     # ------------------------------------------------------------------ shutdown
     def close(self):
@@ -545,12 +599,12 @@ class HostShardedEvaluator:
             except RuntimeError:
                 pass
         lib, h = self.lib, self.h
-        if getattr(self, "helper_threads", 0):
+        if getattr(self, "helper_threads", 0) and getattr(self, "_own_helpers", False):      # (only the pool this object started)
             from . import runtime
 
             lib.pk_host_threads(0)
             runtime.host_helpers_stopped()
-            self.helper_threads = 0
+        self.helper_threads = 0
         if h:
             lib.pk_sync(h, None)
             if getattr(self, "_registered", False):
@@ -560,8 +614,9 @@ class HostShardedEvaluator:
                 lib.pk_device_free(h, p)
         self._alloc = []
         self.out = self.h_x = self.h_lam = self.h_sigma = self.h_part = self.h_out = self.h_f = None
-        self.words = self.ctrl = None
-        self.ev.close()
+        self.words = self.ctrl = self.h_I = self._marks = None
+        if self.ev is not None:
+            self.ev.close()
         try:
             self.shm.close()
             if self.rank == 0:

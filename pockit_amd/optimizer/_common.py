@@ -54,7 +54,8 @@ def preprocess(system, guess, optimizer_options=None):
     for k in range(system.n_p):
         start[plan.l_p[k]: plan.r_p[k]] = parts[k].data
     if system.n_s:
-        start[plan.l_s: plan.r_s] = np.fromiter((float(v) for v in parts[-1]), dtype=np.float64, count=system.n_s)
+        # (a static guess of the wrong length is an error, as in the reference's slice assignment, _common.py:33)
+        start[plan.l_s: plan.r_s] = np.array([float(v) for v in parts[-1]], dtype=np.float64)
     return start, bare, ({} if optimizer_options is None else optimizer_options)
 
 

@@ -20,7 +20,7 @@ class ModelDesc(C.Structure):
     _fields_ = [(n, C.c_int32) for n in
                 ("n_phase", "n_I", "nred", "lds_g", "lds_j", "lds_h", "ne_j", "ne_h", "prepass_f", "prepass_grad",
                  "prepass_g", "prepass_jac", "prepass_hess", "lds_x", "ne_a", "ne_hc", "lds_e", "tab_cap", "sharded",
-                 "lds_jc", "ne_jc")]
+                 "lds_jc", "ne_jc", "max_phases")]
 
 
 class ProblemDesc(C.Structure):
@@ -78,7 +78,7 @@ EXPORTS = ["pk_create", "pk_destroy", "pk_last_error", "pk_device_count", "pk_lo
            "pk_set_exchange", "pk_exchange_sums_dev", "pk_copy_runs_dev", "pk_set_exchange_inline",
            "pk_host_register", "pk_host_unregister", "pk_copy_dev", "pk_eval_xpart_dev",
            "pk_eval_jacc", "pk_eval_jacc_dev", "pk_callback_x", "pk_callback_hess", "pk_set_jac_constant_runs", "pk_fill_jac_constants", "pk_set_host_option",
-           "pk_set_jacobian_layout", "pk_exchange_status", "pk_wait_idle", "pk_same_bits", "pk_copy_bits", "pk_host_threads", "pk_host_threads_hot", "pk_host_threads_jobs"]
+           "pk_set_jacobian_layout", "pk_exchange_status", "pk_wait_idle", "pk_same_bits", "pk_copy_bits", "pk_host_threads", "pk_host_threads_hot", "pk_host_threads_jobs", "pk_set_cycle_layout"]
 
 _lib = None
 
@@ -177,6 +177,7 @@ def load_library():
     lib.pk_eval_mesh_error_dev.argtypes = [vp, vp, vp, vp, vp]
     lib.pk_set_cycle_graph.argtypes = [vp, C.c_int]
     lib.pk_set_cycle_mode.argtypes = [vp, C.c_int]
+    lib.pk_set_cycle_layout.argtypes = [vp, C.c_int, C.c_int]
     lib.pk_profile_sampling.argtypes = [vp, C.c_int]
     lib.pk_set_csr_map.argtypes = [vp, C.c_int, c_int32_p, c_int32_p, C.c_int64, C.c_int64]
     lib.pk_gather_csr_dev.argtypes = [vp, C.c_int, vp, vp, vp]

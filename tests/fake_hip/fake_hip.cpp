@@ -161,13 +161,15 @@ static void run_kernel(const std::string& name, const std::vector<char>& argbuf)
     for (int64_t i = 0; i < n; ++i) A.o_grad[i] = fake_grad(A.x, n, i);
   if ((x_part || name == "pk_g") && A.o_g)
     for (int64_t j = 0; j < m; ++j) A.o_g[j] = fake_g(A.x, n, j);
-  if ((x_part || name == "pk_jac") && A.o_jac)
+  // (pk_cycle serves the compact layouts itself when its flags say so: bit 9 the Jacobian, bit 8 the Hessian)
+  const bool cyc_cj = name == "pk_cycle" && (A.flags & 512), cyc_ch = name == "pk_cycle" && (A.flags & 256);
+  if ((x_part || name == "pk_jac") && A.o_jac && !cyc_cj)
     for (int64_t p = 0; p < S.nnz_J; ++p) A.o_jac[p] = fake_jac(A.x, n, p, is_const(S.jconst, p));
-  if (name == "pk_jacc" && A.o_jac)
+  if ((name == "pk_jacc" || cyc_cj) && A.o_jac)
     for (int64_t p = 0; p < S.nnz_Jc; ++p) A.o_jac[p] = fake_jac(A.x, n, p, is_const(S.jconst_compact, p)) + 0.25;
-  if ((name == "pk_hess" || name == "pk_cycle") && A.o_hess)
+  if ((name == "pk_hess" || name == "pk_cycle") && A.o_hess && !cyc_ch)
     for (int64_t p = 0; p < S.nnz_H; ++p) A.o_hess[p] = fake_hess(A.x, A.lam, A.sigma, n, m, p);
-  if (name == "pk_hessc" && A.o_hess)
+  if ((name == "pk_hessc" || cyc_ch) && A.o_hess)
     for (int64_t p = 0; p < S.nnz_Hc; ++p) A.o_hess[p] = fake_hess(A.x, A.lam, A.sigma, n, m, p) - 0.5;
   if (name == "pk_csr" && A.csr_out) {
     for (int p = 0; p < A.n_csr; ++p) A.csr_out[p] = A.csr_seg ? -7.0 : A.csr_in[A.csr_perm[p]];

@@ -1346,19 +1346,34 @@ def test_adaptive_solve_check_refine_loop_converges():
     assert errors[-1] <= 1e-6 * max(1.0, abs(optimum)) and errors[-1] < errors[0], errors
 
 
-def test_ipopt_adapter_protocol_with_a_stand_in_cyipopt(monkeypatch):
+@pytest.mark.parametrize("layout", ["compact", "reference"])
+def test_ipopt_adapter_protocol_with_a_stand_in_cyipopt(layout, monkeypatch):
     """cyipopt / Ipopt are not installed here, so the adapter is driven by a stand-in ``cyipopt.Problem`` that
     does what cyipopt does with a ``problem_obj`` (cyipopt's Problem.__init__/solve contract: structure queried
     once, every callback result copied into the solver's own arrays at once, callbacks in IPOPT's per-iteration
     order) and checks every value it receives against the oracle.  This covers the adapter's wiring and the
-    evaluator's zero-copy mode (results handed out as views of pinned buffers that the next call reuses)."""
+    evaluator's zero-copy mode (results handed out as views of pinned buffers that the next call reuses).
+    ``layout="compact"`` (the adapter's default): the solver is handed the compact structures; what it assembles from
+    them -- repeated positions summed, as IPOPT does -- must equal the oracle's scatter-added reference triplets.
+    ``layout="reference"``: structures and values are the reference's, entry by entry."""
     import sys
     import types
+
+    import scipy.sparse as ssp
 
     ns = _ns("radau", "pockit_amd")
     system, phases, guess = models.two_stage_rocket(ns, 12, 4)
     ref, _, _ = models.two_stage_rocket(_ns("radau", "oracle"), 12, 4)
     seen = {"iters": 0, "options": {}}
+    rjr, rjc = ref.jacobianstructure()
+    rhr, rhc = ref.hessianstructure()
+
+    def assembled(vals, rows, cols, shape):
+        return ssp.coo_array((np.asarray(vals, dtype=np.float64), (rows, cols)), shape=shape).tocsr()
+
+    def same_matrix(a, b, what):
+        diff = abs(a - b)
+        assert (diff.max() if diff.nnz else 0.0) <= TOL * max(1.0, abs(b).max()), what
 
     class Problem:
         def __init__(self, n, m, problem_obj, lb, ub, cl, cu):
@@ -1366,11 +1381,14 @@ def test_ipopt_adapter_protocol_with_a_stand_in_cyipopt(monkeypatch):
             assert np.array_equal(lb, ref.v_lb) and np.array_equal(ub, ref.v_ub)
             assert np.array_equal(cl, ref.c_lb) and np.array_equal(cu, ref.c_ub)
             self.n, self.m, self.obj = n, m, problem_obj
-            jr, jc = problem_obj.jacobianstructure()
-            hr, hc = problem_obj.hessianstructure()
-            assert np.array_equal(jr, ref.jacobianstructure()[0]) and np.array_equal(jc, ref.jacobianstructure()[1])
-            assert np.array_equal(hr, ref.hessianstructure()[0]) and np.array_equal(hc, ref.hessianstructure()[1])
-            self.nnz_j, self.nnz_h = len(jr), len(hr)
+            self.jr, self.jc = problem_obj.jacobianstructure()
+            self.hr, self.hc = problem_obj.hessianstructure()
+            if layout == "reference":
+                assert np.array_equal(self.jr, rjr) and np.array_equal(self.jc, rjc)
+                assert np.array_equal(self.hr, rhr) and np.array_equal(self.hc, rhc)
+            else:       # fewer values than the reference's lists, lower triangle kept
+                assert len(self.hr) < len(rhr) and len(self.jr) <= len(rjr) and np.all(np.asarray(self.hr) >= np.asarray(self.hc))
+            self.nnz_j, self.nnz_h = len(self.jr), len(self.hr)
 
         def add_option(self, key, value):
             seen["options"][key] = value
@@ -1391,8 +1409,13 @@ def test_ipopt_adapter_protocol_with_a_stand_in_cyipopt(monkeypatch):
                 close(got["f"], ref.objective(x), what="f")
                 close(got["g"], ref.constraints(x), what="g")
                 close(got["grad"], ref.gradient(x), what="grad")
-                close(got["J"], ref.jacobian(x), what="J")
-                close(got["H"], ref.hessian(x, lam, sigma), what="H")
+                if layout == "reference":
+                    close(got["J"], ref.jacobian(x), what="J")
+                    close(got["H"], ref.hessian(x, lam, sigma), what="H")
+                same_matrix(assembled(got["J"], self.jr, self.jc, (self.m, self.n)),
+                            assembled(ref.jacobian(x), rjr, rjc, (self.m, self.n)), "J as the solver assembles it")
+                same_matrix(assembled(got["H"], self.hr, self.hc, (self.n, self.n)),
+                            assembled(ref.hessian(x, lam, sigma), rhr, rhc, (self.n, self.n)), "H as the solver assembles it")
                 x = x * (1.0 + 1e-3 * rng.uniform(-1, 1, size=len(x)))
                 seen["iters"] += 1
             return x, {"status": 0, "status_msg": b"stand-in", "obj_val": got["f"]}
@@ -1402,10 +1425,15 @@ def test_ipopt_adapter_protocol_with_a_stand_in_cyipopt(monkeypatch):
     monkeypatch.setitem(sys.modules, "cyipopt", fake)
     from pockit_amd.optimizer import ipopt
 
-    solution, info = ipopt.solve(system, guess, {"tol": 1e-8, "print_level": 0})
+    if layout == "compact":
+        solution, info = ipopt.solve(system, guess, {"tol": 1e-8, "print_level": 0})          # (the default)
+    else:
+        solution, info = ipopt.solve(system, guess, {"tol": 1e-8, "print_level": 0}, layout="reference")
     assert seen["iters"] == 4 and seen["options"] == {"tol": 1e-8, "print_level": 0} and info["status"] == 0
     assert len(solution) == len(phases) + 1 and all(len(v.data) == p.L for v, p in zip(solution, phases))
     assert len(solution[-1]) == system.n_s and system.evaluator.zero_copy is False
+    # the system's own layout settings are back (the reference's lists: the drop-in default of the callbacks themselves)
+    assert np.array_equal(system.hessianstructure()[0], rhr) and np.array_equal(system.jacobianstructure()[0], rjr)
 
 
 @pytest.mark.parametrize("name", sorted(models.BANG_BANG_CASES))
@@ -1633,3 +1661,71 @@ def test_a_hand_off_that_gives_up_is_an_error_not_a_silent_nan():
     bad[5] = np.nan                                    # a state value: the model itself now evaluates to NaN
     f = system.objective(bad)                          # no exception
     assert np.isnan(f) or np.isnan(system.constraints(bad)).any()
+
+
+@pytest.mark.parametrize("case", [("brachistochrone", "radau", dict(mesh=200, num_point=8)),        # C2: free t_f (dense columns)
+                                  ("two_stage_rocket", "radau", dict(mesh=60, num_point=4)),          # two phases, static parameters
+                                  ("planar_quadrotor", "lobatto", dict(mesh=40, num_point=6)),        # LGL: shared end nodes
+                                  ("humanoid_wbc", "radau", dict(mesh=30, num_point=8)),
+                                  ("lqr", "radau", dict(mesh=7, num_point=12))])                     # K > 8: tables from global memory
+@pytest.mark.parametrize("split", ["1", "0"])
+def test_compact_layouts_ride_in_the_single_launch_cycle(case, split, monkeypatch):
+    """pk_set_cycle_layout: the compact Jacobian / Hessian come out of the SAME single launch as f, grad f and g -- the
+    Jacobian role of pk_cycle runs pk_jacc's tile code, its Hessian workgroups pk_hessc's.  f, grad f, g must be bit-identical
+    to the reference-layout cycle, the compact values bit-identical to the stand-alone compact kernels, and the matrices
+    equal to the oracle's scatter-added triplets; split and unsplit x-part."""
+    import scipy.sparse as ssp
+    import torch
+
+    monkeypatch.setenv("POCKIT_AMD_SPLIT", split)
+    bname, scheme, kw = case
+    system, _, guess = getattr(models, bname)(_ns(scheme, "pockit_amd"), **kw)
+    ref, _, _ = getattr(models, bname)(_ns(scheme, "oracle"), **kw)
+    plan, ev = system.plan, system.evaluator
+    x, lam, sigma = models.bench_inputs(system, guess)
+    plan.jacc  # noqa: B018
+    dev = torch.device("cuda", 0)
+    dx, dlam = torch.from_numpy(x).to(dev), torch.from_numpy(lam).to(dev)
+
+    def run(nj, nh):
+        sizes = (("f", 1), ("grad", plan.n), ("g", plan.m), ("J", nj), ("H", nh))
+        o = {k: torch.full((max(n, 1),), float("nan"), dtype=torch.float64, device=dev) for k, n in sizes}
+        torch.cuda.synchronize()
+        for _ in range(2):
+            ev.cycle_dev(dx.data_ptr(), dlam.data_ptr(), sigma, *[o[k].data_ptr() for k, _ in sizes])
+        ev.sync()
+        return {k: v.cpu().numpy()[:n] for (k, n), v in zip(sizes, o.values())}
+
+    full = run(plan.nnz_J, plan.nnz_H)
+    ev.set_cycle_layout(True, True)
+    try:
+        comp = run(plan.nnz_Jc, plan.nnz_Hc)
+    finally:
+        ev.set_cycle_layout(False, False)
+    again = run(plan.nnz_J, plan.nnz_H)
+    for k in ("f", "grad", "g"):
+        assert np.array_equal(comp[k], full[k]), k
+    for k in ("f", "grad", "g", "J", "H"):
+        assert np.array_equal(again[k], full[k]), k + " after switching back"
+    assert np.array_equal(comp["J"], ev.jacobian_compact(x)), "compact J: the launch's Jacobian role vs pk_jacc"
+    assert np.array_equal(comp["H"], ev.hessian_compact(x, lam, sigma)), "compact H: the launch's Hessian role vs pk_hessc"
+    jr, jc = ref.jacobianstructure()
+    hr, hc = ref.hessianstructure()
+    for got, (r, c), want, (rr, rc_), shape, what in (
+            (comp["J"], (plan.jacc_row, plan.jacc_col), ref.jacobian(x), (jr, jc), (plan.m, plan.n), "J"),
+            (comp["H"], (plan.hessc_row, plan.hessc_col), ref.hessian(x, lam, sigma), (hr, hc), (plan.n, plan.n), "H")):
+        a = ssp.coo_array((got, (r, c)), shape=shape).tocsr()
+        b = ssp.coo_array((want, (rr, rc_)), shape=shape).tocsr()
+        diff = abs(a - b)
+        assert (diff.max() if diff.nnz else 0.0) <= TOL * max(1.0, abs(b).max()), what
+    # the solver-side callbacks in the compact Jacobian layout take the same launch (no second kernel, no reference-layout J)
+    system.set_jacobian_layout("compact")
+    try:
+        x2 = x * (1.0 + 1e-9)
+        vals = system.jacobian(x2)
+        assert np.array_equal(vals, ev.jacobian_compact(x2))
+        close(system.constraints(x2), ref.constraints(x2), what="g beside the compact J")
+        close(system.gradient(x2), ref.gradient(x2), what="grad f beside the compact J")
+    finally:
+        system.set_jacobian_layout("reference")
+    system._invalidate()

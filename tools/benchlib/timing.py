@@ -245,6 +245,7 @@ def host_sharded_end_to_end(name, intervals, rank, world, dist, steps, warmup):
         else:
             xs, lam, sigma = solver_inputs(system, guess)
             names = ("objective", "gradient", "constraints", "jacobian", "hessian")
+            hs.zero_copy = True      # (views of the shared pinned segment, what a solver adapter sets when the solver copies at once)
             batches = timed_cycles(lambda k: five_callbacks(hs, xs[k & 1], lam, sigma), steps, warmup)
             med = statistics.median(batches)
             q = sorted(batches)
