@@ -598,7 +598,9 @@ class ModelSource:
                                       "64 points: the workgroup-wide interval code is single-pass")
         S.append("struct Gen {")
         # LDS doubles per wave for the staged per-node values
-        self.lds_g = 64 * max([1] + [pp.nx for pp in plan.phase_plans])
+        # (pk_g: the dynamics values [nx][64]; pk_hessc: the multiplier rows [nx][64] + the base offsets of its output runs)
+        n_hc = (lambda k: len(plan.hessc.segs[k])) if self.compact else (lambda k: 0)
+        self.lds_g = 64 * max([1] + [pp.nx + -(-n_hc(k) // 64) for k, pp in enumerate(plan.phase_plans)])
         # (rows of 64 doubles per wave; a role evaluated in groups stages one group at a time: its largest group counts)
         gmax = lambda cb, k: max(g[1] for g in self.groups[(cb, k)])  # noqa: E731
         self.lds_j = 64 * max([1] + [gmax("jac", k) for k in range(nP)])

@@ -1475,18 +1475,12 @@ __device__ __forceinline__ void tile_xall_grouped(const PkArgs& A, const PkTile&
   const bool fit = tabs_fit(A, tl, g);
   const TabRegs tr = tabs_issue(A, ph, tl, g, fit, lane);
   const int q = tl.q0 + lane;
-  double a[P::NARG], tau, w, xr[P::NX], xe[P::NX];
+  double a[P::NARG], tau, w;
   load_node<P>(A, ph, s, dt, mt, q, a, tau, w);
   const TileTabs T = tabs_commit(A, tl, g, tr, fit, lane);
   if (ROLE != 1) segb.settle();
   if (ROLE != 2) tbase.settle();
-  if (ROLE != 2) {
-    defect_ends<P>(A, ph, tl, g, a, xe, lane);
-    settle(xe);
-  }
   loads_done();
-#pragma unroll
-  for (int i = 0; i < P::NX; ++i) xr[i] = a[i];
   const bool live = lane < g.nq;
   if (ROLE != 2) {
     double oi[P::INT_N > 0 ? P::INT_N : 1], orr[P::GR_NR > 0 ? P::GR_NR : 1];
@@ -1538,8 +1532,13 @@ __device__ __forceinline__ void tile_xall_grouped(const PkArgs& A, const PkTile&
         for (int j = 0; j < P::NC; ++j) put(&A.o_g[ph.path_off + j * ph.L_m + q], og[P::NX + j]);
       }
     }
+    // the end-slot state values of the defect rows only now (wave shuffles of the node values; a full LGR tile reaches one
+    // slot past the wave): a wide model would otherwise carry NX more register pairs through the evaluation above.  The
+    // node's own values ARE its row's x_q (a[0 .. NX) until the Jacobian passes make them opaque).
+    double xe[P::NX];
+    defect_ends<P>(A, ph, tl, g, a, xe, lane);
     wave_lds_sync();
-    PK_PHASE_B(T, (xval_phase_b<P, ROLE, STAGED, CJ>(A, ph, tl, g, T, s, dt, sv, xr, xe, tbase, lane)));
+    PK_PHASE_B(T, (xval_phase_b<P, ROLE, STAGED, CJ>(A, ph, tl, g, T, s, dt, sv, a, xe, tbase, lane)));
   } else {
     wave_lds_sync();                                        // (the table blocks the wave staged for itself)
   }
@@ -1958,7 +1957,7 @@ __device__ __forceinline__ void tile_mu(const PkArgs& A, const PkPhase& ph, cons
 
 // the per-node values of the compact Hessian, chunk by chunk (one chunk unless the model is large: codegen.split_chunks)
 template <class P, int G>
-__device__ __forceinline__ void hessc_chunks(const PkArgs& A, const PkPhase& ph, pk_cbase_t segb, double (&a)[P::NARG],
+__device__ __forceinline__ void hessc_chunks(const PkArgs& A, const PkPhase& ph, const long long* __restrict__ segb, double (&a)[P::NARG],
                                              double& tau, double& dt, double& w, const PkSys& sy,
                                              double (&lp)[P::NC > 0 ? P::NC : 1], double (&mu)[P::NX], int q) {
   if constexpr (G < P::HC_NG) {
@@ -1990,8 +1989,14 @@ __device__ __forceinline__ void tile_hessc(const PkArgs& A, const PkTile& tl, do
   double s[PK_NS], dt, mt;
   phase_scalars<P>(A, ph, s, dt, mt);
   const PkSys sy{s, A.Ibuf, A.sigma, A.lam};
-  pk_cbase_t segb = const_bases(A.lb + ph.hcseg_off);
+  // The base offsets of the HC_NN output runs are staged in the wave's LDS behind its multiplier rows (coalesced load, one
+  // broadcast ds_read at every store).  As scalar loads -- an SGPR pair per output, all hoisted to the top by the scheduler --
+  // they spilled 40 SGPRs and cost the kernel a private segment; held in a VGPR pair and handed over by v_readlane they
+  // were hoisted just the same (123 SGPR spills).
+  long long* __restrict__ segb = reinterpret_cast<long long*>(lam_s + P::NX * PK_WAVE);
+  for (int e = lane; e < P::HC_NN; e += PK_WAVE) segb[e] = (long long)A.lb[ph.hcseg_off + e];
   if (tl.K > PK_WAVE) {
+    wave_lds_sync();
     for (int c = lane; c < g.nown; c += PK_WAVE) {
       const int q = tl.q0 + c;
       if (q >= ph.mid_lo && q < ph.mid_hi) {
@@ -2679,7 +2684,11 @@ __device__ __forceinline__ void kernel_xall(const PkArgs& A) {
 // the grid size), passed as leading scalar kernel arguments: with kernarg preloading (gfx940+,
 // -amdgpu-kernarg-preload-count) they arrive in SGPRs with the wave, so the record load is not queued behind a first
 // round trip to the kernarg segment.
-template <class Gen>
+// COMPACT = false: pk_cycle, the reference layouts only.  COMPACT = true: pk_cyclec, the same launch with the roles of the
+// compact layouts selectable by the flags -- a kernel of its own, because the compact Hessian's per-node code raises the
+// register count of whatever kernel holds it (humanoid: 166 -> 177 VGPRs = 3 -> 2 waves per SIMD, +3.5 % on the 40k-node cycle
+// when it sat in pk_cycle itself; profiles/r04_c_ab_compact_roles.txt).
+template <class Gen, bool COMPACT>
 __device__ __forceinline__ void kernel_cycle(const PkTile* pre_tile, int pre_n_tiles, int pre_flags, int pre_grid,
                                              const PkArgs& A) {
 #if PK_KA_LAZY
@@ -2716,8 +2725,10 @@ __device__ __forceinline__ void kernel_cycle(const PkTile* pre_tile, int pre_n_t
     if (A.trace != nullptr && threadIdx.x == 0) A.trace[(size_t)rec * 16 + 14] = __builtin_readcyclecounter();
 #endif
     // (flags bit 9 / bit 8: the launch serves the compact Jacobian / Hessian layout -- the host passes that layout's items)
-    if (blockIdx.x == 0) edge_block<Gen>(A, (pre_flags & 512) ? 4 : 0, true, A.items, A.n_items);
-    else if (blockIdx.x == 1) { if (!(pre_flags & 128)) edge_block<Gen>(A, (pre_flags & 256) ? 3 : 1, false, A.items2, A.n_items2); }
+    if (blockIdx.x == 0) edge_block<Gen>(A, (COMPACT && (pre_flags & 512)) ? 4 : 0, true, A.items, A.n_items);
+    else if (blockIdx.x == 1) {
+      if (!(pre_flags & 128)) edge_block<Gen>(A, (COMPACT && (pre_flags & 256)) ? 3 : 1, false, A.items2, A.n_items2);
+    }
     else fin_handoff<Gen>(A);
 #ifdef PK_TRACE
     __builtin_amdgcn_s_waitcnt(0);
@@ -2751,7 +2762,7 @@ __device__ __forceinline__ void kernel_cycle(const PkTile* pre_tile, int pre_n_t
   // The compact layouts ride in the same launch (flags bit 8: Hessian, bit 9: Jacobian; the host sets them only for meshes
   // without workgroup-wide intervals): the Hessian workgroups run the per-node compact kernel body (tile_hessc), the
   // Jacobian role runs tile_jacc, the values role leaves the translation entries to it -- a compact cycle is ONE launch too.
-  const bool ch = (pre_flags & 256) != 0, cj = (pre_flags & 512) != 0;
+  const bool ch = COMPACT && (pre_flags & 256) != 0, cj = COMPACT && (pre_flags & 512) != 0;
   if (sub == (split ? 2 : 1)) {
     if (ch) Gen::tile_hessc(tl.phase, A, tl, PK_STAGE(A) + wave * Gen::LDS_G, wint, wgrad, lane);
     else Gen::tile_hess(tl.phase, A, tl, PK_STAGE(A) + wave * Gen::LDS_H, wint, wgrad, lane);
@@ -3083,6 +3094,19 @@ __device__ __forceinline__ void kernel_fin(const PkArgs& A) {
 
 }  // namespace pk
 
+/* PK_KA_LAZY: the PkArgs are read from the kernarg segment where a wave uses them, not en bloc on entry.  As a by-value
+   argument every field any path of the kernel touches is loaded in the entry block and stays live (100 SGPRs, spills to VGPR
+   lanes, scalar waits in front of the tile-record load); read lazily a tile wave loads what its phase and role need (60
+   SGPRs).  Two-phase rocket: 158k -> 193k cycles/s.  &A of a by-value kernel argument IS its place in the kernarg segment
+   (constant address space). */
+#define PK_DEFINE_CYCLE(GEN, NAME, COMPACT)                                                                       \
+  extern "C" __global__ __launch_bounds__(PK_BLOCK) void NAME(const PkTile* pre_tile, int32_t pre_n_tiles,        \
+                                                              int32_t pre_flags, int32_t pre_grid, PkArgs A) {     \
+    const PkArgs PK_CONST_AS* A_ = (const PkArgs PK_CONST_AS*)(                                                    \
+        (const char PK_CONST_AS*)__builtin_amdgcn_kernarg_segment_ptr() + PK_CYCLE_ARGS_OFFSET);                   \
+    pk::kernel_cycle<GEN, COMPACT>(pre_tile, pre_n_tiles, pre_flags, pre_grid, PK_KA_LAZY ? *(const PkArgs*)A_ : A); \
+  }
+
 #define PK_DEFINE_KERNELS(GEN)                                                                         \
   extern "C" __global__ __launch_bounds__(PK_BLOCK) void pk_int(PkArgs A) { pk::kernel_int<GEN>(A); }   \
   extern "C" __global__ __launch_bounds__(PK_BLOCK) void pk_fin(PkArgs A) { pk::kernel_fin<GEN>(A); }   \
@@ -3099,14 +3123,5 @@ __device__ __forceinline__ void kernel_fin(const PkArgs& A) {
   extern "C" __global__ __launch_bounds__(PK_BLOCK) void pk_csr(PkArgs A) { pk::kernel_csr(A); }             \
   extern "C" __global__ __launch_bounds__(PK_BLOCK) void pk_xchg(PkArgs A) { pk::kernel_xchg<GEN>(A); }     \
   extern "C" __global__ __launch_bounds__(PK_BLOCK) void pk_runs(PkArgs A) { pk::kernel_runs(A); }           \
-  extern "C" __global__ __launch_bounds__(PK_BLOCK) void pk_cycle(const PkTile* pre_tile, int32_t pre_n_tiles,  \
-                                                                  int32_t pre_flags, int32_t pre_grid, PkArgs A) { \
-    /* PK_KA_LAZY: the PkArgs are read from the kernarg segment where a wave uses them, not en bloc on entry.   \
-       As a by-value argument every field any path of the kernel touches is loaded in the entry block and stays \
-       live (100 SGPRs, spills to VGPR lanes, scalar waits in front of the tile-record load); read lazily a    \
-       tile wave loads what its phase and role need (60 SGPRs).  Two-phase rocket: 158k -> 193k cycles/s.       \
-       &A of a by-value kernel argument IS its place in the kernarg segment (constant address space). */       \
-    const PkArgs PK_CONST_AS* A_ = (const PkArgs PK_CONST_AS*)(                                                  \
-        (const char PK_CONST_AS*)__builtin_amdgcn_kernarg_segment_ptr() + PK_CYCLE_ARGS_OFFSET);                 \
-    pk::kernel_cycle<GEN>(pre_tile, pre_n_tiles, pre_flags, pre_grid, PK_KA_LAZY ? *(const PkArgs*)A_ : A);     \
-  }
+  PK_DEFINE_CYCLE(GEN, pk_cycle, false)                                                                   \
+  PK_DEFINE_CYCLE(GEN, pk_cyclec, true)

@@ -42,10 +42,11 @@
 
 namespace {
 
-enum { K_INT = 0, K_FIN, K_G, K_GRAD, K_JAC, K_HESS, K_XALL, K_AUX, K_OUTER, K_HESSC, K_ERR, K_CSR, K_CYCLE, K_XCHG, K_RUNS, K_JACC, K_COUNT };
+enum { K_INT = 0, K_FIN, K_G, K_GRAD, K_JAC, K_HESS, K_XALL, K_AUX, K_OUTER, K_HESSC, K_ERR, K_CSR, K_CYCLE, K_XCHG, K_RUNS, K_JACC,
+       K_CYCLEC, K_COUNT };
 const char* const kKernelNames[K_COUNT] = {"pk_int", "pk_fin", "pk_g", "pk_grad", "pk_jac", "pk_hess", "pk_xall",
                                            "pk_aux", "pk_outer", "pk_hessc", "pk_err", "pk_csr", "pk_cycle", "pk_xchg", "pk_runs",
-                                           "pk_jacc"};
+                                           "pk_jacc", "pk_cyclec"};
 enum { F_WRITE_F = 1, F_SECONDARY = 2, F_FIN_INT = 8, F_FIN_GRAD = 16, F_SPLIT = 32, F_XCHG = 64, F_NO_HESS = 128,
        F_COMPACT_H = 256, F_COMPACT_J = 512 };
 
@@ -335,9 +336,10 @@ int launch_raw(pk_ctx* c, int k, void* args, size_t sz, unsigned grid, size_t ld
   EventPair ev{};
   if (grid == 0) return 0;
   // the tile kernels that stage their pattern tables keep one table block per wave in front of the model's staging area
-  if ((k == K_G || k == K_JAC || k == K_HESS || k == K_XALL || k == K_CYCLE || k == K_JACC || k == K_HESSC) && !c->static_tabs)
+  if ((k == K_G || k == K_JAC || k == K_HESS || k == K_XALL || k == K_CYCLE || k == K_CYCLEC || k == K_JACC || k == K_HESSC) &&
+      !c->static_tabs)
     lds_bytes += sizeof(double) * PK_WAVES_PER_BLOCK * (size_t)(2 * c->md.tab_cap + 2 * PK_WAVE + c->md.tab_cap / 2);
-  if (k == K_CYCLE && c->xc_inline && c->xc_world > 1 && lds_bytes < sizeof(double) * 2 * 512)
+  if ((k == K_CYCLE || k == K_CYCLEC) && c->xc_inline && c->xc_world > 1 && lds_bytes < sizeof(double) * 2 * 512)
     lds_bytes = sizeof(double) * 2 * 512;      // the finalize workgroup's exchange vectors (2 x PK_XC_CAP doubles)
   if (lds_bytes > 160 * 1024) return fail(c, 22, "%s needs %zu bytes of LDS per workgroup (> 160 KiB)", kKernelNames[k], lds_bytes);
   // every `profile_period`-th launch of a selected kernel is timed (the timed launch path costs ~2-3 us of host
@@ -425,7 +427,9 @@ int enqueue_single_launch_cycle(pk_ctx* c, const double* d_x, const double* d_la
   static_assert(offsetof(CycleArgs, A) == PK_CYCLE_ARGS_OFFSET, "layout of pk_cycle's kernel arguments");
   K.tile = A.tile; K.n_tiles = A.n_tiles; K.flags = A.flags; K.grid = (int32_t)grid; K.pad = 0;
   K.A = A;
-  return launch_raw(c, K_CYCLE, &K, offsetof(CycleArgs, A) + args_bytes(c), grid, sizeof(double) * dbl, st);
+  // (the compact layouts: pk_cyclec, the same launch compiled with their roles -- a kernel of its own so that pk_cycle's
+  //  register count stays what the reference layouts need)
+  return launch_raw(c, layout ? K_CYCLEC : K_CYCLE, &K, offsetof(CycleArgs, A) + args_bytes(c), grid, sizeof(double) * dbl, st);
 }
 
 int enqueue_fused_cycle(pk_ctx* c, const double* d_x, const double* d_lam, double sigma, double* d_f, double* d_grad,

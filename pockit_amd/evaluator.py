@@ -207,19 +207,27 @@ class Tables:
 
 
 def compile_plan(plan: SystemPlan, sharded=False, output_share=1.0):
-    """Generated source + gfx950 code object of a plan.  A model whose kernels would spill vector registers or touch scratch
-    memory at the default group size is generated again with smaller groups (codegen.split_groups: fewer derivative entries
-    evaluated, staged and streamed per pass) until none does -- every cap tried stays cached, so this costs a model its extra
-    compiles once.  Returns (ModelSource, code object)."""
-    cap, fast = None, plan.system._fastmath
-    while True:
+    """Generated source + gfx950 code object of a plan.  A model whose kernels would spill vector registers to scratch memory
+    at the default group size is generated again with smaller groups (codegen.split_groups: fewer derivative entries
+    evaluated, staged and streamed per pass) while that lowers the number of spilled registers -- pressure that comes from
+    the width of the model itself (one register pair per state and array) is not cured by smaller groups, and the search
+    stops at the first size that does not help.  Every size tried stays cached, so a model pays its extra compiles once.
+    Returns (ModelSource, code object); ``ModelSource.spilling_kernels`` says what is left."""
+    fast = plan.system._fastmath
+
+    def build(cap):
         src = ModelSource(plan, sharded=sharded, output_share=output_share, group_cap=cap)
         code = hipbuild.compile_model(src.source, fastmath=fast)
-        bad = hipbuild.spills(hipbuild.resource_usage(src.source, fastmath=fast))
-        if not bad or src.group_cap <= 4 or os.environ.get("POCKIT_AMD_GROUP_CAP"):
-            src.spilling_kernels = bad
-            return src, code
-        cap = src.group_cap // 2
+        src.spilling_kernels = hipbuild.spills(hipbuild.resource_usage(src.source, fastmath=fast))
+        return src, code, sum(v[0] for v in src.spilling_kernels.values())
+
+    best = build(None)
+    while best[2] > 0 and best[0].group_cap > 4 and best[0].grouped and not os.environ.get("POCKIT_AMD_GROUP_CAP"):
+        trial = build(best[0].group_cap // 2)
+        if trial[2] >= best[2]:
+            break
+        best = trial
+    return best[0], best[1]
 
 
 class Evaluator:

@@ -63,7 +63,7 @@ ERRIV_DTYPE = np.dtype([("phase", np.int32), ("K", np.int32), ("lm", np.int32), 
 WAVES_PER_BLOCK = 4  # PK_WAVES_PER_BLOCK of csrc/pk_abi.h
 WAVE = 64  # PK_WAVE
 KERNELS = ["pk_int", "pk_fin", "pk_g", "pk_grad", "pk_jac", "pk_hess", "pk_xall", "pk_aux", "pk_outer", "pk_hessc", "pk_err", "pk_csr",
-           "pk_cycle", "pk_xchg", "pk_runs", "pk_jacc"]
+           "pk_cycle", "pk_xchg", "pk_runs", "pk_jacc", "pk_cyclec"]
 EXPORTS = ["pk_create", "pk_destroy", "pk_last_error", "pk_device_count", "pk_load_model", "pk_set_problem",
            "pk_get_structure", "pk_eval_f", "pk_eval_grad", "pk_eval_g", "pk_eval_jac", "pk_eval_hess",
            "pk_eval_f_dev", "pk_eval_grad_dev", "pk_eval_g_dev", "pk_eval_jac_dev", "pk_eval_hess_dev",

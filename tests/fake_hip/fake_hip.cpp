@@ -150,24 +150,25 @@ static bool is_const(const std::vector<std::pair<int64_t, int64_t>>& runs, int64
 
 static void run_kernel(const std::string& name, const std::vector<char>& argbuf) {
   const FakeSizes& S = g_sizes;
-  const size_t off = name == "pk_cycle" ? PK_CYCLE_ARGS_OFFSET : 0;
+  const bool cyc = name == "pk_cycle" || name == "pk_cyclec";
+  const size_t off = cyc ? PK_CYCLE_ARGS_OFFSET : 0;
   if (argbuf.size() < off + sizeof(PkArgs)) return;      // (the host-side copy kernel goes another way)
   PkArgs A;
   std::memcpy(&A, argbuf.data() + off, sizeof A);
   const int n = S.n, m = S.m;
-  const bool x_part = name == "pk_xall" || name == "pk_cycle";
-  if ((name == "pk_fin" || name == "pk_cycle") && (A.flags & 1) && A.o_f) A.o_f[0] = fake_f(A.x, n);
+  const bool x_part = name == "pk_xall" || cyc;
+  if ((name == "pk_fin" || cyc) && (A.flags & 1) && A.o_f) A.o_f[0] = fake_f(A.x, n);
   if ((x_part || name == "pk_grad") && A.o_grad)
     for (int64_t i = 0; i < n; ++i) A.o_grad[i] = fake_grad(A.x, n, i);
   if ((x_part || name == "pk_g") && A.o_g)
     for (int64_t j = 0; j < m; ++j) A.o_g[j] = fake_g(A.x, n, j);
   // (pk_cycle serves the compact layouts itself when its flags say so: bit 9 the Jacobian, bit 8 the Hessian)
-  const bool cyc_cj = name == "pk_cycle" && (A.flags & 512), cyc_ch = name == "pk_cycle" && (A.flags & 256);
+  const bool cyc_cj = name == "pk_cyclec" && (A.flags & 512), cyc_ch = name == "pk_cyclec" && (A.flags & 256);
   if ((x_part || name == "pk_jac") && A.o_jac && !cyc_cj)
     for (int64_t p = 0; p < S.nnz_J; ++p) A.o_jac[p] = fake_jac(A.x, n, p, is_const(S.jconst, p));
   if ((name == "pk_jacc" || cyc_cj) && A.o_jac)
     for (int64_t p = 0; p < S.nnz_Jc; ++p) A.o_jac[p] = fake_jac(A.x, n, p, is_const(S.jconst_compact, p)) + 0.25;
-  if ((name == "pk_hess" || name == "pk_cycle") && A.o_hess && !cyc_ch)
+  if ((name == "pk_hess" || cyc) && A.o_hess && !cyc_ch)
     for (int64_t p = 0; p < S.nnz_H; ++p) A.o_hess[p] = fake_hess(A.x, A.lam, A.sigma, n, m, p);
   if ((name == "pk_hessc" || cyc_ch) && A.o_hess)
     for (int64_t p = 0; p < S.nnz_Hc; ++p) A.o_hess[p] = fake_hess(A.x, A.lam, A.sigma, n, m, p) - 0.5;

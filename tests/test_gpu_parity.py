@@ -1729,3 +1729,65 @@ def test_compact_layouts_ride_in_the_single_launch_cycle(case, split, monkeypatc
     finally:
         system.set_jacobian_layout("reference")
     system._invalidate()
+
+
+def _all_five(system, x, lam, sigma):
+    return (system.objective(x), system.gradient(x), system.constraints(x), system.jacobian(x), system.hessian(x, lam, sigma))
+
+
+@pytest.mark.parametrize("case", [("three_stage_rocket", "radau", dict(mesh=12, num_point=4)),
+                                  ("three_stage_rocket", "lobatto", dict(mesh=9, num_point=5)),
+                                  ("three_stage_rocket", "radau", dict(mesh=1000, num_point=4)),      # BASELINE configs[3], literally
+                                  ("humanoid_team", "radau", dict(mesh=6, num_point=5)),
+                                  ("humanoid_team", "lobatto", dict(mesh=5, num_point=4))])
+def test_stand_ins_for_the_literal_baseline_configs_match_the_oracle(case):
+    """BASELINE.json words configs[3] as "3 phases x 1000 intervals" and configs[4] as "~40-state"; the reference's example
+    programs have 2 phases and 10 states.  Synthetic stand-ins with exactly those shapes --
+    benchmarks.three_stage_rocket (3 phases, 12 static parameters, FUNC boundary values and times) and
+    benchmarks.humanoid_team (40 states + 20 controls, derivative set evaluated in groups) -- against the oracle: structures
+    exactly, every entry of the five callbacks and of the one-launch cycle to 1e-11."""
+    bname, scheme, kw = case
+    system, _, guess = getattr(models, bname)(_ns(scheme, "pockit_amd"), **kw)
+    ref, _, _ = getattr(models, bname)(_ns(scheme, "oracle"), **kw)
+    x, lam, sigma = models.bench_inputs(system, guess)
+    for a, b in zip(system.jacobianstructure() + system.hessianstructure(), ref.jacobianstructure() + ref.hessianstructure()):
+        assert np.array_equal(a, b)
+    want = _all_five(ref, x, lam, sigma)
+    for a, b, what in zip(_all_five(system, x, lam, sigma), want, ("f", "grad", "g", "J", "H")):
+        close(a, b, what=f"{bname} callbacks {what}")
+    for a, b, what in zip(system.evaluator.cycle(x, lam, sigma), want, ("f", "grad", "g", "J", "H")):
+        close(a, b, what=f"{bname} cycle {what}")
+    ev = system.evaluator
+    close(ev.jacobian_direct(x), want[3], what=f"{bname} pk_jac")
+    close(ev.hessian_direct(x, lam, sigma), want[4], what=f"{bname} pk_hess")
+    system._invalidate()
+
+
+def test_forty_state_stand_in_at_forty_thousand_nodes():
+    """humanoid_team at BASELINE configs[4]'s literal size (40 states, 5000 intervals x 8 points = 40 000 nodes; 24 M Jacobian
+    and 29 M Hessian values per cycle).  The oracle needs minutes per callback there, so: entry-by-entry oracle parity at
+    300 x 8 (the same code object, tiles and groups), and at 5000 x 8 the size-independent properties -- every output finite,
+    the one-launch cycle equal to the five callbacks bit for bit, and H linear in (lambda, sigma)."""
+    ns = _ns("radau", "pockit_amd")
+    small, _, guess = models.humanoid_team(ns, 300, 8)
+    ref, _, _ = models.humanoid_team(_ns("radau", "oracle"), 300, 8)
+    x, lam, sigma = models.bench_inputs(small, guess)
+    for a, b, what in zip(small.evaluator.cycle(x, lam, sigma), _all_five(ref, x, lam, sigma), ("f", "grad", "g", "J", "H")):
+        close(a, b, what=f"300 x 8 cycle {what}")
+    small._invalidate()
+    system, _, guess = models.humanoid_team(ns, 5000, 8)
+    assert system.plan.n == 40 * 40001 + 20 * 40000 + 2
+    x, lam, sigma = models.bench_inputs(system, guess)
+    ev = system.evaluator
+    f, grad, g, J, H = ev.cycle(x, lam, sigma)
+    for v in (grad, g, J, H):
+        assert np.isfinite(v).all()
+    assert np.array_equal(system.constraints(x), g) and np.array_equal(system.jacobian(x), J)
+    assert np.array_equal(system.hessian(x, lam, sigma), H)
+    rng = np.random.default_rng(5)
+    lam2 = rng.standard_normal(lam.shape)
+    H1 = np.array(system.hessian(x, lam, 1.0))
+    H2 = np.array(system.hessian(x, lam2, 0.25))
+    H12 = np.array(system.hessian(x, 2.0 * lam - 3.0 * lam2, 2.0 * 1.0 - 3.0 * 0.25))
+    close(H12, 2.0 * H1 - 3.0 * H2, what="H is linear in (lambda, sigma)", tol=1e-10)
+    system._invalidate()

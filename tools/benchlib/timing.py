@@ -890,8 +890,10 @@ def strong_scaled_workloads(args, rank, world, dist):
     return strong
 
 
+# (three_stage_rocket / humanoid_team: synthetic stand-ins for BASELINE.json's LITERAL configs[3] "3 phases x 1000 intervals" and
+#  configs[4] "~40-state, 5000 x 8" -- the reference's examples have 2 phases and 10 states; pockit_amd/benchmarks.py)
 OTHER_WORKLOADS = (("brachistochrone", 1250), ("brachistochrone", 200), ("two_stage_rocket", 1000), ("humanoid_wbc", 5000),
-                   ("planar_quadrotor_lgl", 2000))
+                   ("planar_quadrotor_lgl", 2000), ("three_stage_rocket", 1000), ("humanoid_team", 5000))
 
 
 def other_workloads(args, which=OTHER_WORKLOADS):

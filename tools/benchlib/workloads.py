@@ -22,7 +22,8 @@ MIN_REGION_S = 0.05        # the timed region lasts at least this long (R batche
 EVENT_SPACING = 200        # cycles between two timing events of the region (an event costs ~3 us of GPU time)
 MIN_WARMUP = 500           # untimed launches before the timed region (single GPU), whatever --warmup says
 ISOLATED_SAMPLES = 200     # per-dispatch kernel timings on an idle stream (what a profiler's kernel trace measures)
-POINTS = {"planar_quadrotor": 6, "brachistochrone": 8, "two_stage_rocket": 4, "humanoid_wbc": 8}
+POINTS = {"planar_quadrotor": 6, "brachistochrone": 8, "two_stage_rocket": 4, "humanoid_wbc": 8, "three_stage_rocket": 4,
+          "humanoid_team": 8}
 
 
 def algorithmic_bytes(plan):
