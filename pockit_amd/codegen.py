@@ -593,9 +593,6 @@ class ModelSource:
             return "\n".join(out)
 
         self.grouped = any(len(v) > 1 for v in self.groups.values())
-        if self.grouped and self.big:
-            raise NotImplementedError("a model whose derivative set is evaluated in groups, on a mesh with an interval of more than "
-                                      "64 points: the workgroup-wide interval code is single-pass")
         S.append("struct Gen {")
         # LDS doubles per wave for the staged per-node values
         # (pk_g: the dynamics values [nx][64]; pk_hessc: the multiplier rows [nx][64] + the base offsets of its output runs)

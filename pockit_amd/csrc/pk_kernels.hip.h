@@ -1574,6 +1574,83 @@ __device__ __forceinline__ BigStage big_stage(const PkArgs& A, int K, int slot, 
   if (K <= PK_BIG_MAX) return BigStage{PK_BIG_MAX, lds};
   return BigStage{A.big_row, A.big_stage + ((size_t)slot * 4 + (size_t)u) * (size_t)A.big_slot};
 }
+// ---- workgroup-wide intervals of a model whose derivative set is evaluated in groups (P::J_NG / P::H_NG > 1; see
+// jac_groups): every pass walks the interval's nodes again (a thread owns several nodes, so the node arguments are loaded per
+// pass), stages its group's rows, synchronizes the workgroup, walks the K^2 entries of its segments and synchronizes again.
+template <class P, int G>
+__device__ __forceinline__ void big_jac_groups(const PkArgs& A, const PkPhase& ph, const PkTile& tl, const double* s, double dt,
+                                               double mt, const PkSys& sy, double* __restrict__ js, int KS, pk_cbase_t segb,
+                                               double width, int nq, int nown) {
+  if constexpr (G < P::J_NG) {
+    constexpr int I0 = P::J_gi0(G), NI = P::J_gni(G), N0 = P::J_gn0(G), NN = P::J_gnn(G);
+    const int t = threadIdx.x;
+    for (int c = t; c < nq; c += PK_BLOCK) {
+      const int q = tl.q0 + c;
+      double a[P::NARG], tau, w, o[NI + NN + 1];
+      load_node<P>(A, ph, s, dt, mt, q, a, tau, w);
+      P::mid_jac_g(Grp<G>{}, a, tau, dt, w, sy, nullptr, o);
+#pragma unroll
+      for (int e = 0; e < NI; ++e) js[e * KS + c] = o[e];
+      if (NN > 0 && c < nown && q >= ph.mid_lo && q < ph.mid_hi) {
+#pragma unroll
+        for (int e = 0; e < NN; ++e) put(&A.o_jac[segb[P::J_NI + N0 + e] + (q - ph.mid_lo)], o[NI + e]);
+      }
+    }
+    if constexpr (NI > 0) {
+      __syncthreads();
+      const int32_t* __restrict__ rcg = A.ib + tl.irc_off;
+      const double* __restrict__ ivg = A.db + tl.iv_off;
+      for (int p = t; p < tl.nnzI; p += PK_BLOCK) {
+        const int c = rcg[2 * p + 1];
+        const double val = -(ivg[p] * width * 0.5);
+#pragma unroll
+        for (int e = 0; e < NI; ++e) put(&A.o_jac[segb[I0 + e] + tl.offI + p], val * js[e * KS + c]);
+      }
+      __syncthreads();
+    }
+    big_jac_groups<P, G + 1>(A, ph, tl, s, dt, mt, sy, js, KS, segb, width, nq, nown);
+  }
+}
+template <class P, int G>
+__device__ __forceinline__ void big_hess_groups(const PkArgs& A, const PkPhase& ph, const PkTile& tl, const double* s, double dt,
+                                                double mt, const PkSys& sy, double* __restrict__ lds, int KS, pk_cbase_t segb,
+                                                double width, int nq, int nown) {
+  if constexpr (G < P::H_NG) {
+    constexpr int I0 = P::H_gi0(G), NI = P::H_gni(G), N0 = P::H_gn0(G), NN = P::H_gnn(G);
+    const int t = threadIdx.x;
+    for (int c = t; c < nq; c += PK_BLOCK) {
+      const int q = tl.q0 + c;
+      double a[P::NARG], tau, w, lp[P::NC > 0 ? P::NC : 1], o[NI + NN + 1];
+      load_node<P>(A, ph, s, dt, mt, q, a, tau, w);
+#pragma unroll
+      for (int j = 0; j < P::NC; ++j) lp[j] = A.lam[ph.path_off + j * ph.L_m + min(q, ph.L_m - 1)];
+      P::mid_hess_g(Grp<G>{}, a, tau, dt, w, sy, lp, o);
+#pragma unroll
+      for (int e = 0; e < NI; ++e) lds[e * KS + c] = o[e];
+      if (NN > 0 && c < nown && q >= ph.mid_lo && q < ph.mid_hi) {
+#pragma unroll
+        for (int e = 0; e < NN; ++e) put(&A.o_hess[segb[P::H_NI + N0 + e] + (q - ph.mid_lo)], o[NI + e]);
+      }
+    }
+    if constexpr (NI > 0) {
+      __syncthreads();
+      const int32_t* __restrict__ rcg = A.ib + tl.irc_off;
+      const double* __restrict__ ivg = A.db + tl.iv_off;
+      for (int p = t; p < tl.nnzI; p += PK_BLOCK) {
+        const int r = rcg[2 * p], c = rcg[2 * p + 1];
+        const double val = -(ivg[p] * width * 0.5);
+#pragma unroll
+        for (int e = 0; e < NI; ++e) {
+          const double lam = A.lam[ph.g_off + P::H_state(I0 + e) * ph.L_d + tl.r0 + r];
+          put(&A.o_hess[segb[I0 + e] + tl.offI + p], val * lam * lds[e * KS + c]);
+        }
+      }
+      __syncthreads();
+    }
+    big_hess_groups<P, G + 1>(A, ph, tl, s, dt, mt, sy, lds, KS, segb, width, nq, nown);
+  }
+}
+
 template <class P, int ROLE>
 __device__ __forceinline__ void big_xall(const PkArgs& A, const PkTile& tl, double* __restrict__ lds,
                                          double* __restrict__ wint, double* __restrict__ wgrad, int pub_blk) {
@@ -1607,7 +1684,8 @@ __device__ __forceinline__ void big_xall(const PkArgs& A, const PkTile& tl, doub
 #pragma unroll
       for (int i = 0; i < P::NX; ++i) xs[i * KS + c] = a[i];
     }
-    P::mid_xall(a, tau, dt, w, sy, og, oj, ov, ot, op);
+    if constexpr (P::J_NG == 1) P::mid_xall(a, tau, dt, w, sy, og, oj, ov, ot, op);
+    else if (ROLE != 2) P::mid_xval(a, tau, dt, w, sy, og, ov, ot, op);      // (grouped: the Jacobian comes pass by pass below)
     if (ROLE != 2) {
       if (c < nown) {
 #pragma unroll
@@ -1622,12 +1700,14 @@ __device__ __forceinline__ void big_xall(const PkArgs& A, const PkTile& tl, doub
 #pragma unroll
       for (int i = 0; i < P::NX; ++i) fs[i * KS + c] = og[i];
     }
-    if (ROLE != 1) {
+    if constexpr (P::J_NG == 1) {
+      if (ROLE != 1) {
 #pragma unroll
-      for (int e = 0; e < P::J_NI; ++e) js[e * KS + c] = oj[e];
-      if (c < nown && q >= ph.mid_lo && q < ph.mid_hi) {
+        for (int e = 0; e < P::J_NI; ++e) js[e * KS + c] = oj[e];
+        if (c < nown && q >= ph.mid_lo && q < ph.mid_hi) {
 #pragma unroll
-        for (int e = 0; e < P::J_NN; ++e) put(&A.o_jac[segb[P::J_NI + e] + (q - ph.mid_lo)], oj[P::J_NI + e]);
+          for (int e = 0; e < P::J_NN; ++e) put(&A.o_jac[segb[P::J_NI + e] + (q - ph.mid_lo)], oj[P::J_NI + e]);
+        }
       }
     }
   }
@@ -1694,15 +1774,19 @@ __device__ __forceinline__ void big_xall(const PkArgs& A, const PkTile& tl, doub
       for (int i = 0; i < P::NX; ++i) put(&A.o_jac[tb[i] + tl.offT + p], v);
     }
   }
-  if (ROLE != 1) {
-    const int32_t* __restrict__ rcg = A.ib + tl.irc_off;
-    const double* __restrict__ ivg = A.db + tl.iv_off;
-    for (int p = t; p < tl.nnzI; p += PK_BLOCK) {
-      const int c = rcg[2 * p + 1];
-      const double val = -(ivg[p] * width * 0.5);
+  if constexpr (P::J_NG == 1) {
+    if (ROLE != 1) {
+      const int32_t* __restrict__ rcg = A.ib + tl.irc_off;
+      const double* __restrict__ ivg = A.db + tl.iv_off;
+      for (int p = t; p < tl.nnzI; p += PK_BLOCK) {
+        const int c = rcg[2 * p + 1];
+        const double val = -(ivg[p] * width * 0.5);
 #pragma unroll
-      for (int e = 0; e < P::J_NI; ++e) put(&A.o_jac[segb[e] + tl.offI + p], val * js[e * KS + c]);
+        for (int e = 0; e < P::J_NI; ++e) put(&A.o_jac[segb[e] + tl.offI + p], val * js[e * KS + c]);
+      }
     }
+  } else if (ROLE != 1) {
+    big_jac_groups<P, 0>(A, ph, tl, s, dt, mt, sy, js, KS, segb, width, nq, nown);
   }
 }
 
@@ -1720,6 +1804,9 @@ __device__ __forceinline__ void big_hess(const PkArgs& A, const PkTile& tl, doub
   phase_scalars<P>(A, ph, s, dt, mt);
   const PkSys sy{s, A.Ibuf, A.sigma, A.lam};
   pk_cbase_t segb = const_bases(A.lb + ph.hseg_off);
+  if constexpr (P::H_NG > 1) {
+    big_hess_groups<P, 0>(A, ph, tl, s, dt, mt, sy, lds, KS, segb, A.db[ph.width_off + tl.j0], nq, nown);
+  } else {
   for (int c = t; c < nq; c += PK_BLOCK) {
     const int q = tl.q0 + c;
     double a[P::NARG], tau, w, lp[P::NC > 0 ? P::NC : 1], o[P::H_NI + P::H_NN + 1];
@@ -1746,6 +1833,7 @@ __device__ __forceinline__ void big_hess(const PkArgs& A, const PkTile& tl, doub
       const double lam = A.lam[ph.g_off + P::H_state(e) * ph.L_d + tl.r0 + r];
       put(&A.o_hess[segb[e] + tl.offI + p], val * lam * lds[e * KS + c]);
     }
+  }
   }
 }
 
@@ -1798,6 +1886,68 @@ __device__ __forceinline__ void big_aux(const PkArgs& A, const PkTile& tl) {
   }
 }
 
+template <class P, int G>
+__device__ __forceinline__ void big_jacc_groups(const PkArgs& A, const PkPhase& ph, const PkTile& tl, const double* s, double dt,
+                                                double mt, const PkSys& sy, double* __restrict__ sv, int KS, pk_cbase_t segb,
+                                                double width, int nq, int nown) {
+  if constexpr (G < P::JC_NG) {
+    constexpr int KIND = P::JC_gk(G), LO = P::JC_g0(G), CN = P::JC_gn(G);
+    const int t = threadIdx.x, K = tl.K, R = K - P::SCHEME;
+    for (int c = t; c < nq; c += PK_BLOCK) {
+      const int q = tl.q0 + c;
+      double a[P::NARG], tau, w, o[CN + 1];
+      load_node<P>(A, ph, s, dt, mt, q, a, tau, w);
+      P::mid_jacc_g(Grp<G>{}, a, tau, dt, w, sy, nullptr, o);
+      if constexpr (KIND == 1) {      // the boundary nodes carry their own expressions of the dense-column entries
+        if (q == 0) P::front_jacc_dense_g(Grp<G>{}, a, tau, dt, w, sy, nullptr, o);
+        else if (P::SCHEME == 1 && q == ph.L_m - 1) P::back_jacc_dense_g(Grp<G>{}, a, tau, dt, w, sy, nullptr, o);
+      }
+      if constexpr (KIND < 2) {
+#pragma unroll
+        for (int e = 0; e < CN; ++e) sv[e * KS + c] = o[e];
+      } else if (c < nown && q >= ph.mid_lo && q < ph.mid_hi) {
+#pragma unroll
+        for (int e = 0; e < CN; ++e) put(&A.o_jac[segb[P::JC_NI + P::JC_ND + LO + e] + (q - ph.mid_lo)], o[e]);
+      }
+    }
+    if constexpr (KIND < 2) {
+      __syncthreads();
+      if constexpr (KIND == 0) {
+        const int32_t* __restrict__ rcg = A.ib + tl.irc_off;
+        const double* __restrict__ ivg = A.db + tl.iv_off;
+        for (int p = t; p < tl.nnzI; p += PK_BLOCK) {
+          const int c = rcg[2 * p + 1];
+          const double val = -(ivg[p] * width * 0.5);
+#pragma unroll
+          for (int e = 0; e < CN; ++e) put(&A.o_jac[segb[LO + e] + tl.offI + p], val * sv[e * KS + c]);
+        }
+      } else {
+        const double* __restrict__ full = A.db + tl.full_off;
+        double a[P::NARG], tau, w, tf[CN], tbk[CN];
+        load_node<P>(A, ph, s, dt, mt, tl.q0, a, tau, w);        // (the static parameters, for the boundary shares)
+        P::jacc_tdense_g(Grp<G>{}, a, tf, tbk);
+        const bool last_iv = tl.j0 == ph.n_int - 1;
+        for (int r = t; r < R; r += PK_BLOCK) {
+          double acc[CN];
+#pragma unroll
+          for (int e = 0; e < CN; ++e) acc[e] = 0.0;
+          for (int c = 0; c < K; ++c) {
+            const double wgt = full[r * K + c] * width * 0.5;
+#pragma unroll
+            for (int e = 0; e < CN; ++e) acc[e] += wgt * sv[e * KS + c];
+          }
+          const bool first = tl.r0 + r == 0;
+#pragma unroll
+          for (int e = 0; e < CN; ++e)
+            put(&A.o_jac[segb[P::JC_NI + LO + e] + tl.r0 + r], (first ? tf[e] : 0.0) + (last_iv ? tbk[e] : 0.0) - acc[e]);
+        }
+      }
+      __syncthreads();
+    }
+    big_jacc_groups<P, G + 1>(A, ph, tl, s, dt, mt, sy, sv, KS, segb, width, nq, nown);
+  }
+}
+
 // compact Jacobian (tile_jacc above) of such an interval: the expanded and the dense-column segment values of all nodes are
 // staged ([JC_NI + JC_ND][KS], sub-slot 3 beyond 256 points), then the translation entries, the dense rows (one K-term product
 // per defect row and dense-column segment) and the K^2 entries of every expanded segment are walked by all 256 threads
@@ -1817,6 +1967,15 @@ __device__ __forceinline__ void big_jacc(const PkArgs& A, const PkTile& tl, doub
   const PkSys sy{s, A.Ibuf, A.sigma, A.lam};
   pk_cbase_t segb = const_bases(A.lb + ph.jcseg_off);
   pk_cbase_t tb = const_bases(A.lb + ph.jct_off);
+  if constexpr (P::JC_gk(0) >= 0) {      // evaluated in groups: the translation entries, then pass by pass
+    const double* __restrict__ tvg = A.db + tl.tv_off;
+    for (int p = t; p < tl.nnzT; p += PK_BLOCK) {
+      const double v = tvg[p];
+#pragma unroll
+      for (int i = 0; i < P::NX; ++i) put(&A.o_jac[tb[i] + tl.offT + p], v);
+    }
+    big_jacc_groups<P, 0>(A, ph, tl, s, dt, mt, sy, sv, KS, segb, A.db[ph.width_off + tl.j0], nq, nown);
+  } else {
   for (int c = t; c < nq; c += PK_BLOCK) {
     const int q = tl.q0 + c;
     double a[P::NARG], tau, w, o[P::JC_NI + P::JC_ND + P::JC_NN + 1];
@@ -1871,6 +2030,7 @@ __device__ __forceinline__ void big_jacc(const PkArgs& A, const PkTile& tl, doub
     const double val = -(ivg[p] * width * 0.5);
 #pragma unroll
     for (int e = 0; e < P::JC_NI; ++e) put(&A.o_jac[segb[e] + tl.offI + p], val * sv[e * KS + c]);
+  }
   }
 }
 

@@ -199,7 +199,13 @@ def test_maximum_supported_order_matches_the_plan_interpreter(case):
                                   ("planar_quadrotor", "lobatto", dict(mesh=[0, 0.5, 1.0], num_point=[7, 400])),
                                   ("planar_quadrotor", "radau", dict(mesh=[0, 0.4, 1.0], num_point=[264, 263])),   # (K + 1 = 264 / 265 augmented nodes)
                                   ("planar_quadrotor", "radau", dict(mesh=[0, 0.5, 0.6, 1.0], num_point=[128, 6, 200]), "mfma"),
-                                  ("brachistochrone", "lobatto", dict(mesh=[0, 0.3, 0.6, 1.0], num_point=[66, 5, 130]), "mfma")])
+                                  ("brachistochrone", "lobatto", dict(mesh=[0, 0.3, 0.6, 1.0], num_point=[66, 5, 130]), "mfma"),
+                                  # derivative set evaluated in GROUPS (forced by a group size of 3) on such intervals
+                                  ("planar_quadrotor", "radau", dict(mesh=[0, 0.5, 0.6, 1.0], num_point=[128, 6, 200]), "groups"),
+                                  ("brachistochrone", "lobatto", dict(mesh=[0, 0.3, 0.6, 1.0], num_point=[66, 5, 130]), "groups"),
+                                  ("two_stage_rocket", "radau", dict(mesh=[0, 0.4, 1.0], num_point=[70, 9]), "groups"),
+                                  ("humanoid_wbc", "radau", dict(mesh=[0, 0.5, 1.0], num_point=[4, 80]), "groups"),
+                                  ("planar_quadrotor", "lobatto", dict(mesh=[0, 0.5, 1.0], num_point=[7, 400]), "groups")])
 def test_intervals_with_more_points_than_a_wavefront_has_lanes(case, monkeypatch):
     """num_point > 64 (the reference has no limit, radau/discretization.py:488-521): such an interval is evaluated
     by a whole workgroup (PK_BIG code objects), next to ordinary wave tiles; up to 256 points its per-node values are
@@ -209,8 +215,10 @@ def test_intervals_with_more_points_than_a_wavefront_has_lanes(case, monkeypatch
     the fp64 matrix cores (POCKIT_AMD_BIG_MFMA=1; measured slower than the VALU form, kept as a switch)."""
     from plan_interp import Interp
 
-    if len(case) == 4:
+    if len(case) == 4 and case[3] == "mfma":
         monkeypatch.setenv("POCKIT_AMD_BIG_MFMA", "1")
+    if len(case) == 4 and case[3] == "groups":
+        monkeypatch.setenv("POCKIT_AMD_GROUP_CAP", "3")
     bname, scheme, kw = case[:3]
     system, _, guess = getattr(models, bname)(_ns(scheme, "pockit_amd"), **kw)
     x, lam, sigma = models.bench_inputs(system, guess)
@@ -218,6 +226,7 @@ def test_intervals_with_more_points_than_a_wavefront_has_lanes(case, monkeypatch
     want = dict(f=it.objective(), grad=it.gradient(), g=it.constraints(), J=it.jacobian(), H=it.hessian())
     ev = system.evaluator
     assert ev.src.big == (max(kw["num_point"]) > 64)
+    assert ev.src.grouped == (len(case) == 4 and case[3] == "groups")
     f, grad, g, J, H = ev.cycle(x, lam, sigma)                       # pk_cycle: the three roles of every big block
     close(f, want["f"], what="cycle f")
     close(grad, want["grad"], what="cycle grad")
@@ -1790,4 +1799,66 @@ def test_forty_state_stand_in_at_forty_thousand_nodes():
     H2 = np.array(system.hessian(x, lam2, 0.25))
     H12 = np.array(system.hessian(x, 2.0 * lam - 3.0 * lam2, 2.0 * 1.0 - 3.0 * 0.25))
     close(H12, 2.0 * H1 - 3.0 * H2, what="H is linear in (lambda, sigma)", tol=1e-10)
+    system._invalidate()
+
+
+@pytest.mark.parametrize("cap", ["2", "5"])
+@pytest.mark.parametrize("case", [("brachistochrone", "radau", dict(mesh=37, num_point=5)),
+                                  ("brachistochrone", "lobatto", dict(mesh=23, num_point=6)),
+                                  ("two_stage_rocket", "radau", dict(mesh=40, num_point=3)),
+                                  ("planar_quadrotor", "lobatto", dict(mesh=19, num_point=4)),
+                                  ("planar_quadrotor", "radau", dict(mesh=11, num_point=12)),       # K > 8: staged tables of 256 entries
+                                  ("lqr", "radau", dict(mesh=5, num_point=20)),                     # K > 16: tables from global memory
+                                  ("humanoid_wbc", "radau", dict(mesh=9, num_point=7)),
+                                  ("derivative_model", "radau", {}),                                # nonlinear in the integrals
+                                  ("func_times_model", "lobatto", {})])
+def test_a_derivative_set_evaluated_in_groups_gives_the_single_pass_results(case, cap, monkeypatch):
+    """Segment-grouped evaluation (codegen.split_groups; what a model with hundreds of derivative entries gets by itself)
+    forced on small models by a group size of 2 / 5: every role -- stand-alone callbacks, fused x-part, one-launch cycle,
+    compact layouts, split and unsplit -- must give the oracle's values and the single-pass code's structures; the groups
+    only change which pass of a wave writes a segment's run."""
+    import scipy.sparse as ssp
+
+    bname, scheme, kw = case
+    ref, _, _ = getattr(models, bname)(_ns(scheme, "oracle"), **kw)
+    monkeypatch.setenv("POCKIT_AMD_GROUP_CAP", cap)
+    system, _, guess = getattr(models, bname)(_ns(scheme, "pockit_amd"), **kw)
+    x, lam, sigma = models.bench_inputs(system, guess)
+    want = _all_five(ref, x, lam, sigma)
+    if isinstance(kw.get("num_point"), int) and kw["num_point"] > 12:
+        # (the oracle's np.roots-based tables lose digits beyond 12 points per interval: the NumPy execution of the product's
+        #  own plan is the reference there, as for every high-order case; structures still come from the oracle)
+        from plan_interp import Interp
+
+        it = Interp(system.plan, x, lam, sigma)
+        want = (it.objective(), it.gradient(), it.constraints(), it.jacobian(), it.hessian())
+    ev = system.evaluator
+    assert ev.src.group_cap == int(cap) and (ev.src.grouped or bname == "lqr")      # (lqr: two entries, one group even so)
+    for a, b, what in zip(_all_five(system, x, lam, sigma), want, ("f", "grad", "g", "J", "H")):
+        close(a, b, what=f"callbacks {what}")
+    close(ev.jacobian_direct(x), want[3], what="pk_jac")
+    close(ev.hessian_direct(x, lam, sigma), want[4], what="pk_hess")
+    close(ev.constraints_direct(x), want[2], what="pk_g")
+    if not system.plan.outer:
+        for a, b, what in zip(ev.cycle(x, lam, sigma), want, ("f", "grad", "g", "J", "H")):
+            close(a, b, what=f"cycle {what}")
+        n, m = system.plan.n, system.plan.m
+        jr, jc = ref.jacobianstructure()
+        hr, hc = ref.hessianstructure()
+        system.set_hessian_layout("compact")
+        system.set_jacobian_layout("compact")
+        try:
+            cr, cc = system.hessianstructure()
+            a = ssp.coo_array((system.hessian(x, lam, sigma), (cr, cc)), shape=(n, n)).tocsr()
+            b = ssp.coo_array((want[4], (hr, hc)), shape=(n, n)).tocsr()
+            d = abs(a - b)
+            assert (d.max() if d.nnz else 0.0) <= TOL * max(1.0, abs(b).max()), "compact H"
+            cr, cc = system.jacobianstructure()
+            a = ssp.coo_array((system.jacobian(x), (cr, cc)), shape=(m, n)).tocsr()
+            b = ssp.coo_array((want[3], (jr, jc)), shape=(m, n)).tocsr()
+            d = abs(a - b)
+            assert (d.max() if d.nnz else 0.0) <= TOL * max(1.0, abs(b).max()), "compact J"
+        finally:
+            system.set_hessian_layout("reference")
+            system.set_jacobian_layout("reference")
     system._invalidate()

@@ -178,7 +178,8 @@ def short_line(args, res, e2e, n_gpus, intervals, ms, root, cpu_baseline=None, p
                      "dispatch_isolated_us": _num(roof["dispatch_isolated_us"]),
                      "profiled": ({"file": prof.get("file"), "avg_ns": prof.get("avg_ns"), "calls": prof.get("calls")} if prof else None)},
         "cpu_baseline": None,
-        "device_resident": {"value": _num(value, 7), "ms_per_step": _num(ms, 7)},
+        "device_resident": {"value": _num(value, 7), "ms_per_step": _num(ms, 7),
+                            "compact_layouts_value": _num(((res.get("side") or {}).get("compact_cycle_mode") or {}).get("cycles_per_s"))},
         "end_to_end": end_to_end_of(e2e, n_gpus),
         "parity": parity,
         "outputs_finite": bool(res.get("finite")),

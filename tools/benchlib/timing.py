@@ -642,6 +642,23 @@ class GpuWorkload:
             out["compact_jacobian_mode"] = {"nnz_J_compact": int(plan.nnz_Jc), "nnz_J_reference": int(plan.nnz_J),
                                             "pk_jacc_us": us, "finite": bool(torch.isfinite(jc).all()),
                                             "roofline": side_roofline(8 * (plan.n + plan.nnz_Jc), us)}
+        if ev.src.compact and ev.src.compact_j and self.dominant == "pk_cycle":
+            # the whole cycle in the COMPACT layouts from ONE launch (pk_cyclec: the compact kernels' tile code in the Jacobian /
+            # Hessian roles of the cycle launch); per-dispatch events, stream idle before every sampled launch
+            try:
+                ev.set_cycle_layout(True, True)
+                cargs = (h, ptr(self.dx), ptr(self.dlam), C.c_double(float(self.sigma)), ptr(self.o["f"]), ptr(self.o["grad"]),
+                         ptr(self.o["g"]), ptr(jc), ptr(hc), st)
+                us = timed(16, "pk_cyclec", lambda: lib.pk_eval_cycle_dev(*cargs))
+                nb = 8 * (5 * plan.n + plan.m + 1 + plan.n + plan.m + plan.nnz_Jc + plan.nnz_Hc)
+                out["compact_cycle_mode"] = {"pk_cyclec_us": us, "cycles_per_s": (1e6 / us if us else None),
+                                             "nnz_J_compact": int(plan.nnz_Jc), "nnz_H_compact": int(plan.nnz_Hc),
+                                             "finite": bool(torch.isfinite(jc).all() and torch.isfinite(hc).all()),
+                                             "roofline": side_roofline(nb, us)}
+            except Exception as exc:  # noqa: BLE001
+                out["compact_cycle_mode"] = {"error": repr(exc)}
+            finally:
+                ev.set_cycle_layout(False, False)
         ev.mesh_error(self.x)                                           # uploads the tables on first use
         eT = torch.zeros(ev._err_len, dtype=torch.float64, device=dev)
         eI = torch.zeros_like(eT)
