@@ -13,8 +13,8 @@ to ``pockit_amd`` -- up to its call of ``ipopt.solve``, which is intercepted, an
 
 That is the drop-in claim on the programs users actually write: same modeling API, same NLP.  Prints one JSON object.
 Run in a process of its own (the shims and the module aliases must not leak into the test process).
-Usage: check_examples.py [name-substring ...]     (POCKIT_AMD_ALL_EXAMPLES=1: also the four whose NumPy execution takes a minute;
-POCKIT_AMD_EXAMPLES_COMPILE=1: also generate and compile every model's gfx950 code object with hipcc, no GPU needed)"""
+Usage: check_examples.py [name-substring ...]     (all 33 programs by default; POCKIT_AMD_EXAMPLES_COMPILE=1: also generate
+and compile every model's gfx950 code object with hipcc, no GPU needed)"""
 import importlib
 import json
 import os
@@ -28,7 +28,6 @@ import warnings
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(os.path.dirname(HERE))
 EXAMPLES = "/root/reference/examples"
-SLOW = ("drone_stabilization", "humanoid_whole_body_control", "orbit_transfer", "rocket_powered_descent")
 sys.dont_write_bytecode = True
 os.environ.setdefault("MPLBACKEND", "Agg")
 warnings.simplefilter("ignore")
@@ -163,12 +162,9 @@ def check(name):
 
 def main():
     only = sys.argv[1:]
-    every = os.environ.get("POCKIT_AMD_ALL_EXAMPLES") == "1"
     out = {}
     for name in sorted(p for p in os.listdir(EXAMPLES) if p.endswith(".py") and not p.startswith("_")):
         if only and not any(o in name for o in only):
-            continue
-        if not every and not only and name[:-3] in SLOW:
             continue
         t0 = time.time()
         try:

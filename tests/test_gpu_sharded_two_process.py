@@ -50,13 +50,19 @@ def _reference(system, builder, scheme, kw):
 
 
 
-def _worker(rank, world, port, case, ret):
+def _worker(rank, world, port, case, ret, backend="gloo"):
+    """backend "gloo": both ranks on GPU 0, collectives host-staged (RCCL refuses two ranks on one device).  backend "nccl"
+    (= RCCL on ROCm): one GPU per rank, the gather / all-gather of the owned runs go over RCCL itself, device buffers in and out."""
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     import torch
     import torch.distributed as dist
 
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    gpu = rank if backend == "nccl" else 0
+    if backend == "nccl":
+        torch.cuda.set_device(gpu)
+    dist.init_process_group(backend, rank=rank, world_size=world)
     try:
         import importlib
 
@@ -67,11 +73,11 @@ def _worker(rank, world, port, case, ret):
         system, _, guess = builder(importlib.import_module(f"pockit_amd.{scheme}"), **kw)
         ref = _reference(system, builder, scheme, kw)
         x, lam, sigma = models.bench_inputs(system, guess)
-        dev = torch.device("cuda", 0)
+        dev = torch.device("cuda", gpu)
         torch.cuda.set_device(dev)
-        sev = ShardedEvaluator(system.plan, rank, world, device=0, intervals_per_wave=2)
+        sev = ShardedEvaluator(system.plan, rank, world, device=gpu, intervals_per_wave=2)
         dx, dlam = torch.from_numpy(x).to(dev), torch.from_numpy(lam).to(dev)
-        hd = HostStagedCollectives(dist)
+        hd = dist if backend == "nccl" else HostStagedCollectives(dist)
         err = 0.0
         for rep in range(2):                       # twice: buffers are reused between cycles
             torch.cuda.synchronize()
@@ -92,7 +98,7 @@ def _worker(rank, world, port, case, ret):
         for key in keys:
             got = o[key].cpu().numpy()
             err = max(err, float(np.max(np.abs(got - want[key])) / max(1.0, np.max(np.abs(want[key])))))
-        flag = torch.tensor([err])
+        flag = torch.tensor([err], device=dev if backend == "nccl" else "cpu")
         dist.all_reduce(flag, op=dist.ReduceOp.MAX)
         if rank == 0:
             ret.put(float(flag.item()))
@@ -315,6 +321,34 @@ def test_host_landed_sharded_cycle_matches_oracle(case, world):
     ctx = mp.get_context("spawn")
     ret = ctx.Queue()
     procs = [ctx.Process(target=_host_worker, args=(r, world, port, case, ret)) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(300)
+    assert all(p.exitcode == 0 for p in procs), [p.exitcode for p in procs]
+    err = ret.get(timeout=5)
+    assert isinstance(err, float), err
+    assert err <= 1e-11, err
+
+
+@pytest.mark.parametrize("case", [("two_stage_rocket", "radau", dict(mesh=40, num_point=4)),
+                                  ("planar_quadrotor", "lobatto", dict(mesh=33, num_point=5))])
+def test_two_process_sharded_cycle_over_rccl(case):
+    """The RCCL forms of the reassembly -- all-gather and gather-to-root of the packed owned runs (sharding.py, what
+    ``bench.py --gpus N`` times as the "gather" exchange form) -- with backend ``nccl`` (= RCCL on ROCm) and ONE GPU PER RANK:
+    device buffers straight into the collectives over xGMI.  Needs two visible GPUs; on a one-GPU box (this pool's) it is
+    skipped, and the same code runs over gloo with host staging in test_two_process_sharded_cycle_matches_oracle."""
+    import torch
+    import torch.multiprocessing as mp
+
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two GPUs: RCCL refuses two ranks on one device")
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    ret = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, case, ret, "nccl")) for r in range(2)]
     for p in procs:
         p.start()
     for p in procs:
