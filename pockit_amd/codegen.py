@@ -483,9 +483,12 @@ class ModelSource:
         else:
             # grouped Jacobian: the x-kernels evaluate the VALUES part here (g, gradient entries, integrands) and the Jacobian
             # segments group by group with mid_jac_g, as pk_jac does
-            vouts = [o_ for o_ in outs if not o_[0].startswith("oj[")]
+            # (the dynamics values go straight into the staging rows -- ogl[i * ogs] is row i at this lane / node, ogs the row
+            #  length --, so that a wide model does not carry n_x more register pairs to the end of the function)
+            vouts = [((f"ogl[{int(lv[3:-1])} * ogs]" if (lv.startswith("og[") and int(lv[3:-1]) < nx) else lv), e)
+                     for lv, e in outs if not lv.startswith("oj[")]
             S.append("  __device__ static __forceinline__ void mid_xval(const double* __restrict__ a, double pk_tau, "
-                     "double pk_dt, double pk_w, const PkSys& sy, double* __restrict__ og, "
+                     "double pk_dt, double pk_w, const PkSys& sy, double* __restrict__ ogl, int ogs, double* __restrict__ og, "
                      "double* __restrict__ ov, double* __restrict__ ot, double* __restrict__ op) {")
             S.append("    const double* lp = nullptr; (void)lp;")
             S.append(_emit_body(vouts, base, nm))

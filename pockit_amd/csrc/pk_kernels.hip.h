@@ -600,6 +600,59 @@ __device__ __forceinline__ void write_defects(const PkArgs& A, const PkPhase& ph
   }
 }
 
+// ---- the same for a WIDE model (more than PK_WIDE_NX states): the rows are walked in chunks of PK_WIDE_CHUNK states, each
+// chunk fetching its end-slot values (wave shuffles of the node values `a`, the tile's last LGR interval from memory) and
+// keeping its row sums in PK_WIDE_CHUNK register pairs -- 40 states held 3 x 40 pairs (node values, end slots, sums) through
+// the whole phase before.  Same products, same order per row.
+#define PK_WIDE_NX 16
+#define PK_WIDE_CHUNK 8
+template <class P, bool STAGED, int I0, int CN>
+__device__ __forceinline__ void defect_chunk(const PkArgs& A, const PkPhase& ph, const PkTile& tl, const TileGeom& g,
+                                             const TileTabs& T, const double* s, double dt, const double* __restrict__ fsv,
+                                             const double* a, int lane) {
+  const int nrows = tl.nj * g.R;
+  const int jj = min(magic_div((uint32_t)lane, tl.magicR), max(tl.nj - 1, 0)), r = lane - jj * g.R;
+  const int src = (jj + 1) * g.stride;
+  double xe[CN];
+#pragma unroll
+  for (int e = 0; e < CN; ++e) xe[e] = __shfl(a[I0 + e], src & (PK_WAVE - 1), PK_WAVE);      // (every lane takes part)
+  if (lane >= nrows) return;
+  if (src >= PK_WAVE) {
+    const double* __restrict__ xp = A.x + ph.x_off;
+#pragma unroll
+    for (int e = 0; e < CN; ++e) xe[e] = xp[(I0 + e) * ph.state_len + tl.q0 + src];
+  }
+  const int endslot = tl.q0 + src;
+  const int back_slot = P::SCHEME ? ph.L_m - 1 : ph.L_m;
+  const double* __restrict__ f = fsv + jj * g.stride;
+  const double* __restrict__ full = STAGED ? T.full + r * g.K : A.db + tl.full_off + r * g.K;
+  const double width = STAGED ? T.wd[jj] : A.db[ph.width_off + tl.j0 + jj];
+  double acc[CN];
+#pragma unroll
+  for (int e = 0; e < CN; ++e) acc[e] = 0.0;
+#pragma unroll 4
+  for (int c = 0; c < g.K; ++c) {
+    const double wc = full[c] * width * 0.5;      // (I_hat * d) / 2 as the reference scales it
+#pragma unroll
+    for (int e = 0; e < CN; ++e) acc[e] += wc * f[(I0 + e) * PK_WAVE + c];
+  }
+#pragma unroll
+  for (int e = 0; e < CN; ++e) {
+    if (endslot == back_slot) xe[e] = P::back_value(I0 + e, xe[e], s);
+    put(&A.o_g[ph.g_off + (I0 + e) * ph.L_d + tl.r0 + lane], (a[I0 + e] - xe[e]) - acc[e] * dt);
+  }
+}
+template <class P, bool STAGED, int I0 = 0>
+__device__ __forceinline__ void write_defects_wide(const PkArgs& A, const PkPhase& ph, const PkTile& tl, const TileGeom& g,
+                                                   const TileTabs& T, const double* s, double dt,
+                                                   const double* __restrict__ fsv, const double* a, int lane) {
+  if constexpr (I0 < P::NX) {
+    constexpr int CN = P::NX - I0 < PK_WIDE_CHUNK ? P::NX - I0 : PK_WIDE_CHUNK;
+    defect_chunk<P, STAGED, I0, CN>(A, ph, tl, g, T, s, dt, fsv, a, lane);
+    write_defects_wide<P, STAGED, I0 + PK_WIDE_CHUNK>(A, ph, tl, g, T, s, dt, fsv, a, lane);
+  }
+}
+
 // constant translation entries of every state (phasebase.py:1077)
 template <class P, bool STAGED>
 __device__ __forceinline__ void write_translation(const PkArgs& A, const PkPhase& ph, const PkTile& tl,
@@ -839,11 +892,15 @@ __device__ __forceinline__ void tile_g(const PkArgs& A, const PkTile& tl, double
   double a[P::NARG], tau, w, xr[P::NX], xe[P::NX];
   load_node<P>(A, ph, s, dt, mt, q, a, tau, w);
   const TileTabs T = tabs_commit(A, tl, g, tr, fit, lane);
-  defect_ends<P>(A, ph, tl, g, a, xe, lane);
-  settle(xe);
+  if constexpr (P::NX <= PK_WIDE_NX) {
+    defect_ends<P>(A, ph, tl, g, a, xe, lane);
+    settle(xe);
+  }
   loads_done();
+  if constexpr (P::NX <= PK_WIDE_NX) {
 #pragma unroll
-  for (int i = 0; i < P::NX; ++i) xr[i] = a[i];
+    for (int i = 0; i < P::NX; ++i) xr[i] = a[i];
+  }
   if (lane < g.nq) {
     double o[P::G_NOUT];
     P::mid_g(a, o);
@@ -855,7 +912,8 @@ __device__ __forceinline__ void tile_g(const PkArgs& A, const PkTile& tl, double
     }
   }
   wave_lds_sync();
-  PK_PHASE_B(T, (write_defects<P, STAGED>(A, ph, tl, g, T, s, dt, sv, xr, xe, lane)));
+  if constexpr (P::NX <= PK_WIDE_NX) PK_PHASE_B(T, (write_defects<P, STAGED>(A, ph, tl, g, T, s, dt, sv, xr, xe, lane)));
+  else PK_PHASE_B(T, (write_defects_wide<P, STAGED>(A, ph, tl, g, T, s, dt, sv, a, lane)));
 }
 
 // ============================================================================================
@@ -1455,7 +1513,8 @@ template <class P, int ROLE, bool STAGED, bool CJ>
 __device__ __forceinline__ void xval_phase_b(const PkArgs& A, const PkPhase& ph, const PkTile& tl, const TileGeom& g,
                                              const TileTabs& T, const double* s, double dt, const double* __restrict__ sv,
                                              const double* xr, double* xe, const SegBases<P::NX>& tbase, int lane) {
-  write_defects<P, STAGED>(A, ph, tl, g, T, s, dt, sv, xr, xe, lane);
+  if constexpr (P::NX <= PK_WIDE_NX) write_defects<P, STAGED>(A, ph, tl, g, T, s, dt, sv, xr, xe, lane);
+  else write_defects_wide<P, STAGED>(A, ph, tl, g, T, s, dt, sv, xr, lane);
   if (!CJ && tl.nj != 0) write_translation<P, STAGED>(A, ph, tl, T, tbase, lane);
 }
 template <class P, int ROLE, bool CJ>
@@ -1491,13 +1550,16 @@ __device__ __forceinline__ void tile_xall_grouped(const PkArgs& A, const PkTile&
     double og[P::G_NOUT], ov[P::NX + P::NU];
     if (live) {
       double ot[P::GR_NR > 0 ? P::GR_NR : 1], op[P::INT_N > 0 ? P::INT_N : 1];
-      P::mid_xval(a, tau, dt, w, sy, og, ov, ot, op);
+      P::mid_xval(a, tau, dt, w, sy, sv + lane, PK_WAVE, og, ov, ot, op);      // (dynamics values: straight into the LDS rows)
       if (lane < g.nown) {
 #pragma unroll
         for (int r = 0; r < P::INT_N; ++r) oi[r] = op[r] * w;
 #pragma unroll
         for (int r = 0; r < P::GR_NR; ++r) orr[r] = ot[r];
         node_gradient_eval<P>(ph, q, a, tau, dt, w, sy, ov, orr, true);   // boundary nodes re-evaluate their own entries
+        node_gradient_store<P>(A, ph, q, ov);      // (at once: a wide model's n_x + n_u entries leave the registers here)
+#pragma unroll
+        for (int j = 0; j < P::NC; ++j) put(&A.o_g[ph.path_off + j * ph.L_m + q], og[P::NX + j]);
       }
     }
 #pragma unroll
@@ -1523,20 +1585,11 @@ __device__ __forceinline__ void tile_xall_grouped(const PkArgs& A, const PkTile&
         handoff_put(A.cpart2 + (size_t)pub_blk * PK_NRED + threadIdx.x, vg);
       }
     }
-    if (live) {
-      if (lane < g.nown) node_gradient_store<P>(A, ph, q, ov);
-#pragma unroll
-      for (int i = 0; i < P::NX; ++i) sv[i * PK_WAVE + lane] = og[i];
-      if (lane < g.nown) {
-#pragma unroll
-        for (int j = 0; j < P::NC; ++j) put(&A.o_g[ph.path_off + j * ph.L_m + q], og[P::NX + j]);
-      }
-    }
     // the end-slot state values of the defect rows only now (wave shuffles of the node values; a full LGR tile reaches one
     // slot past the wave): a wide model would otherwise carry NX more register pairs through the evaluation above.  The
     // node's own values ARE its row's x_q (a[0 .. NX) until the Jacobian passes make them opaque).
-    double xe[P::NX];
-    defect_ends<P>(A, ph, tl, g, a, xe, lane);
+    double xe[P::NX <= PK_WIDE_NX ? P::NX : 1];
+    if constexpr (P::NX <= PK_WIDE_NX) defect_ends<P>(A, ph, tl, g, a, xe, lane);
     wave_lds_sync();
     PK_PHASE_B(T, (xval_phase_b<P, ROLE, STAGED, CJ>(A, ph, tl, g, T, s, dt, sv, a, xe, tbase, lane)));
   } else {
@@ -1685,7 +1738,8 @@ __device__ __forceinline__ void big_xall(const PkArgs& A, const PkTile& tl, doub
       for (int i = 0; i < P::NX; ++i) xs[i * KS + c] = a[i];
     }
     if constexpr (P::J_NG == 1) P::mid_xall(a, tau, dt, w, sy, og, oj, ov, ot, op);
-    else if (ROLE != 2) P::mid_xval(a, tau, dt, w, sy, og, ov, ot, op);      // (grouped: the Jacobian comes pass by pass below)
+    else if (ROLE != 2) P::mid_xval(a, tau, dt, w, sy, fs + c, KS, og, ov, ot, op);   // (grouped: dynamics values straight
+                                                                                     //  into the rows, the Jacobian pass by pass below)
     if (ROLE != 2) {
       if (c < nown) {
 #pragma unroll
@@ -1697,8 +1751,10 @@ __device__ __forceinline__ void big_xall(const PkArgs& A, const PkTile& tl, doub
 #pragma unroll
         for (int j = 0; j < P::NC; ++j) put(&A.o_g[ph.path_off + j * ph.L_m + q], og[P::NX + j]);
       }
+      if constexpr (P::J_NG == 1) {
 #pragma unroll
-      for (int i = 0; i < P::NX; ++i) fs[i * KS + c] = og[i];
+        for (int i = 0; i < P::NX; ++i) fs[i * KS + c] = og[i];
+      }
     }
     if constexpr (P::J_NG == 1) {
       if (ROLE != 1) {

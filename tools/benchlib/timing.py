@@ -843,8 +843,9 @@ def multi_gpu_facts(torch, dist, rank, world, w):
     return {"ranks_seen_by_rccl": int(dist.get_world_size()), "backend": backend + (" (= RCCL on ROCm)" if backend == "nccl" else
                                                                                    " (rehearsal: NOT a measurement)"),
             "devices": devs, "peer_access": rows,
-            "headline_form": "host-landed sharded cycle (every GPU lands its slices in one host array over its own PCIe link): "
-                             "the form that hands a host-side solver the reassembled COO triplets",
+            "end_to_end_form": "host-landed sharded cycle (every GPU lands its slices in one host array over its own PCIe link): "
+                               "the form that hands a host-side solver the reassembled COO triplets",
+            "headline_form": "device-resident sharded cycle (value), exchange form below",
             "device_resident_form": w.exchange, "device_resident_form_fallback": getattr(w, "exchange_fallback", None),
             "peer_exchange_error": getattr(w, "peer_error", None)}
 

@@ -20,6 +20,7 @@ for v in values:
                          + extra, env=env, capture_output=True, text=True)
     try:
         d = json.loads(out.stdout.strip().splitlines()[-1])
+        d = {**json.load(open(os.path.join(root, "bench_detail.json"))), **d}      # (the long tables live in the detail file)
         ku = {k: round(x, 2) for k, x in d["kernel_us"].items() if x}
         print(f"{var}={v} tiles={d['config']['tiles']} cycles/s={d['value']:.0f} ms={d['ms_per_step']:.4f} "
               f"roof={d['roofline']['kernel']}:{d['roofline']['achieved']:.0f}GB/s kernels_us={ku}", flush=True)

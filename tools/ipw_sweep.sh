@@ -6,6 +6,7 @@ for ipw in ${IPWS:-1 2 3 4 5 7 10}; do
   python3 - <<PY
 import json
 d=json.loads(open("gpurun_out/ipw_${split}_$ipw.json").read().strip().splitlines()[-1])
+d={**json.load(open("bench_detail.json")), **d}      # (the long tables live in the detail file)
 print("split",$split,"ipw",$ipw, round(d["value"]), {k:round(v,2) for k,v in d["kernel_us"].items() if v}, "|", " ".join(f"{k.split('_')[0][:5]}{k.split('_')[-1]}:{round(v['cycles_per_s'])}" for k,v in d["other_workloads"].items()))
 PY
 done
