@@ -196,5 +196,12 @@ def compile_model(source: str, fastmath: bool = False, keep_source: bool = True)
         COMPILE_SECONDS["last"] = time.perf_counter() - t_start
         COMPILE_SECONDS["total"] += COMPILE_SECONDS["last"]
         COMPILE_SECONDS["count"] += 1
+        log = os.environ.get("POCKIT_AMD_COMPILE_LOG")      # (tests/conftest.py: which objects a session had to compile)
+        if log:
+            try:
+                with open(log, "a") as fh:
+                    fh.write(f"{key} {COMPILE_SECONDS['last']:.1f}\n")
+            except OSError:
+                pass
     with open(path, "rb") as fh:
         return fh.read()
