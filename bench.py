@@ -38,7 +38,18 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 from tools.benchlib import line as L  # noqa: E402
-from tools.benchlib.workloads import cpu_baseline  # noqa: E402
+from tools.benchlib.workloads import algorithmic_bytes, build_workload, cpu_baseline, solver_inputs  # noqa: E402,F401
+
+
+def __getattr__(name):
+    """The developer tools under tools/ take the timing legs (GpuWorkload, measure, five_callbacks, timed_cycles ...) from this
+    module, as before the split: they live in tools/benchlib/timing.py."""
+    from tools.benchlib import timing
+
+    try:
+        return getattr(timing, name)
+    except AttributeError:
+        raise AttributeError(f"module 'bench' has no attribute {name!r}") from None
 
 
 def write_detail(detail):
