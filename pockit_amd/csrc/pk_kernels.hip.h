@@ -2211,6 +2211,7 @@ __device__ __forceinline__ void tile_hessc(const PkArgs& A, const PkTile& tl, do
   // were hoisted just the same (123 SGPR spills).
   long long* __restrict__ segb = reinterpret_cast<long long*>(lam_s + P::NX * PK_WAVE);
   for (int e = lane; e < P::HC_NN; e += PK_WAVE) segb[e] = (long long)A.lb[ph.hcseg_off + e];
+#ifdef PK_BIG      // (such intervals exist only on meshes whose code object is generated with PK_BIG)
   if (tl.K > PK_WAVE) {
     wave_lds_sync();
     for (int c = lane; c < g.nown; c += PK_WAVE) {
@@ -2227,6 +2228,7 @@ __device__ __forceinline__ void tile_hessc(const PkArgs& A, const PkTile& tl, do
     }
     return;
   }
+#endif
   const bool fit = tabs_fit(A, tl, g);
   const TabRegs tr = tabs_issue(A, ph, tl, g, fit, lane);
   const int q = tl.q0 + lane;

@@ -175,7 +175,7 @@ def short_line(args, res, e2e, n_gpus, intervals, ms, root, cpu_baseline=None, p
         "roofline": {"kernel": roof["kernel"], "bound": "hbm", "algorithmic_bytes_per_launch": int(roof["algorithmic_bytes_per_launch"]),
                      "avg_launch_us": _num(roof["avg_launch_us"]), "achieved": _num(roof["achieved"]), "peak": HBM_PEAK_GBPS,
                      "unit": "GB/s", "frac": _num(roof["frac"], 4), "traffic": roof["traffic"], "regime": roof["regime"],
-                     "dispatch_isolated_us": _num(roof["dispatch_isolated_us"]),
+                     "dispatch_isolated_us": _num(roof["dispatch_isolated_us"]), "frac_profiled": _num(roof["frac_profiled"], 4),
                      "profiled": ({"file": prof.get("file"), "avg_ns": prof.get("avg_ns"), "calls": prof.get("calls")} if prof else None)},
         "cpu_baseline": None,
         "device_resident": {"value": _num(value, 7), "ms_per_step": _num(ms, 7),
