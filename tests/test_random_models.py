@@ -60,11 +60,13 @@ def test_oracle_and_plan_match_the_reference_on_a_random_model(scheme, seed):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("cap", [None, "3"])
+@pytest.mark.parametrize("cap,ipw", [(None, None), ("3", None), ("3", "1"), (None, "2")])
 @pytest.mark.parametrize("scheme,seed", CASES)
-def test_gpu_matches_the_reference_on_a_random_model(scheme, seed, cap, monkeypatch):
+def test_gpu_matches_the_reference_on_a_random_model(scheme, seed, cap, ipw, monkeypatch):
     if cap:
         monkeypatch.setenv("POCKIT_AMD_GROUP_CAP", cap)      # the derivative set in groups of three
+    if ipw:
+        monkeypatch.setenv("POCKIT_AMD_IPW", ipw)            # one / two intervals per wave: many ragged tiles
     g = gold(scheme, seed)
     x, lam, sigma = g["x"].copy(), g["lam"].copy(), float(g["sigma"])
     system, _ = rm.random_model(importlib.import_module(f"pockit_amd.{scheme}"), seed, scheme)
