@@ -634,6 +634,26 @@ class ModelSource:
                      f"{', int pub_blk' if pub else ''}) {{")
             S.append(switch(f"{target}(A, tl, lds, wint, wgrad, lane{', pub_blk' if pub else ''})"))
             S.append("  }")
+        # pk_cycle of a model evaluated in groups gives every pass of the Jacobian / Hessian role a wave of its own
+        self.j_ngmax = max([1] + [len(self.groups[("jac", k)]) for k in range(nP)])
+        self.h_ngmax = max([1] + [len(self.groups[("hess", k)]) for k in range(nP)])
+        self.cycle_subs = (1 + self.j_ngmax + self.h_ngmax) if (self.j_ngmax > 1 or self.h_ngmax > 1) else 0
+        # Pass-parallel roles pay when several workgroups of the launch fit a CU: every workgroup of pk_cycle gets the launch's
+        # LDS size (the largest role's rows + the table blocks).  Measured at 2000 x 4 (tools/fat_model_probe.py): orbit_transfer
+        # (23 rows = 56 KB, 23 workgroups per tile block) 40 -> 22 us per cycle; drone_stabilization (47 rows = 105 KB: one
+        # workgroup per CU, so nine workgroups per tile block queue up behind each other) 15 -> 20 us -- it keeps the passes
+        # in one wave.  POCKIT_AMD_PASS_PARALLEL=0|1 overrides (A/B).
+        wg_bytes = 8 * 4 * (max(self.lds_x, self.lds_h, self.lds_g) + 2 * self.tab_cap + 2 * 64 + self.tab_cap // 2)
+        want = os.environ.get("POCKIT_AMD_PASS_PARALLEL", "auto")
+        if want == "0" or (want != "1" and 2 * wg_bytes > 160 * 1024):
+            self.cycle_subs = 0
+        S.append(f"  static constexpr bool GROUPED = {'true' if self.cycle_subs else 'false'};")
+        S.append(f"  static constexpr int J_NGMAX = {self.j_ngmax}, H_NGMAX = {self.h_ngmax};")
+        for name, fn in (("jacg", "tile_jac_pick"), ("hessg", "tile_hess_pick")):
+            S.append(f"  __device__ static __forceinline__ void tile_{name}(int phase, int grp, const PkArgs& A, const PkTile& tl, "
+                     f"double* __restrict__ lds, int lane) {{")
+            S.append(switch(f"pk::{fn}<{{P}}>(grp, A, tl, lds, lane)"))
+            S.append("  }")
         if self.big:
             for name, target in (("bigx0", "pk::big_xall<{P}, 0>"), ("bigx1", "pk::big_xall<{P}, 1>"),
                                  ("bigx2", "pk::big_xall<{P}, 2>")):

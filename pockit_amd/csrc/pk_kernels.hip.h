@@ -997,14 +997,14 @@ __device__ __forceinline__ void jac_group_b(const PkArgs& A, const PkPhase& ph, 
                                             const SegBases<P::J_NI + P::J_NN>& segb, int lane) {
   stream_expanded<P, P::J_gni(G), false, STAGED, P::J_gi0(G)>(A, ph, tl, g, T, jsv, nullptr, segb, A.o_jac, lane);
 }
-template <class P, int G>
+template <class P, int G, bool ONE = false>
 __device__ __forceinline__ void jac_groups(const PkArgs& A, const PkPhase& ph, const PkTile& tl, const TileGeom& g,
                                            const TileTabs& T, double (&a)[P::NARG], double& tau, double& dt, double& w,
                                            const PkSys& sy, double* __restrict__ jsv,
                                            const SegBases<P::J_NI + P::J_NN>& segb, int lane, int q, bool live) {
   if constexpr (G < P::J_NG) {
     constexpr int NI = P::J_gni(G), N0 = P::J_gn0(G), NN = P::J_gnn(G);
-    if constexpr (G > 0) fresh_args(a, tau, dt, w);
+    if constexpr (G > 0 && !ONE) fresh_args(a, tau, dt, w);
     if (live) {
       double o[NI + NN + 1];
       P::mid_jac_g(Grp<G>{}, a, tau, dt, w, sy, nullptr, o);
@@ -1018,9 +1018,9 @@ __device__ __forceinline__ void jac_groups(const PkArgs& A, const PkPhase& ph, c
     if constexpr (NI > 0) {
       wave_lds_sync();
       if (tl.nj != 0) PK_PHASE_B(T, (jac_group_b<P, G, STAGED>(A, ph, tl, g, T, jsv, segb, lane)));
-      wave_lds_sync();                 // (the next pass overwrites the rows this one streamed from)
+      if constexpr (!ONE) wave_lds_sync();      // (the next pass overwrites the rows this one streamed from)
     }
-    jac_groups<P, G + 1>(A, ph, tl, g, T, a, tau, dt, w, sy, jsv, segb, lane, q, live);
+    if constexpr (!ONE) jac_groups<P, G + 1>(A, ph, tl, g, T, a, tau, dt, w, sy, jsv, segb, lane, q, live);
   }
 }
 
@@ -1054,6 +1054,38 @@ __device__ __forceinline__ void tile_jac(const PkArgs& A, const PkTile& tl, doub
                                          double* __restrict__, double* __restrict__, int lane) {
   if constexpr (P::J_NG == 1) tile_jac_single<P>(A, tl, sv, lane);
   else tile_jac_grouped<P>(A, tl, sv, lane);
+}
+
+// pk_cycle of a model evaluated in groups: every PASS of the Jacobian / Hessian role is a wave of its own (the workgroups of
+// a tile block are [Jacobian pass 0 .. | values | Hessian pass 0 ..], kernel_cycle) -- the passes of a role are independent
+// of each other (each evaluates its own group from the node), so running them side by side instead of one after the other
+// multiplies the waves in flight by the number of groups; the stand-alone kernels (pk_jac, pk_hess, pk_xall) keep the loop.
+// `grp` is wave-uniform (it comes from the workgroup index): the pick is a chain of scalar branches.
+template <class P, int G>
+__device__ __forceinline__ void tile_jac_one(const PkArgs& A, const PkTile& tl, double* __restrict__ sv, int lane) {
+  const PkPhase& ph = A.ph[P::INDEX];
+  const TileGeom g = tile_geom<P>(tl);
+  double s[PK_NS], dt, mt;
+  phase_scalars<P>(A, ph, s, dt, mt);
+  const PkSys sy{s, A.Ibuf, A.sigma, A.lam};
+  SegBases<P::J_NI + P::J_NN> segb;
+  segb.load(A.lb, ph.jseg_off, lane);
+  const bool fit = tabs_fit(A, tl, g);
+  const TabRegs tr = tabs_issue(A, ph, tl, g, fit, lane);
+  const int q = tl.q0 + lane;
+  double a[P::NARG], tau, w;
+  load_node<P>(A, ph, s, dt, mt, q, a, tau, w);
+  const TileTabs T = tabs_commit(A, tl, g, tr, fit, lane);
+  segb.settle();
+  loads_done();
+  jac_groups<P, G, true>(A, ph, tl, g, T, a, tau, dt, w, sy, sv, segb, lane, q, lane < g.nq);
+}
+template <class P, int G = 0>
+__device__ __forceinline__ void tile_jac_pick(int grp, const PkArgs& A, const PkTile& tl, double* __restrict__ sv, int lane) {
+  if constexpr (G < P::J_NG) {
+    if (grp == G) tile_jac_one<P, G>(A, tl, sv, lane);
+    else tile_jac_pick<P, G + 1>(grp, A, tl, sv, lane);
+  }
 }
 
 // ============================================================================================
@@ -1296,7 +1328,7 @@ __device__ __forceinline__ void hess_group_b(const PkArgs& A, const PkPhase& ph,
                                              int lane) {
   stream_expanded<P, P::H_gni(G), true, STAGED, P::H_gi0(G)>(A, ph, tl, g, T, sv, lam_s, segb, A.o_hess, lane);
 }
-template <class P, int G>
+template <class P, int G, bool ONE = false>
 __device__ __forceinline__ void hess_groups(const PkArgs& A, const PkPhase& ph, const PkTile& tl, const TileGeom& g,
                                             const TileTabs& T, double (&a)[P::NARG], double& tau, double& dt, double& w,
                                             const PkSys& sy, double (&lp)[P::NC > 0 ? P::NC : 1], double* __restrict__ sv,
@@ -1304,7 +1336,7 @@ __device__ __forceinline__ void hess_groups(const PkArgs& A, const PkPhase& ph, 
                                             int lane, int q, bool live) {
   if constexpr (G < P::H_NG) {
     constexpr int NI = P::H_gni(G), N0 = P::H_gn0(G), NN = P::H_gnn(G);
-    if constexpr (G > 0) {
+    if constexpr (G > 0 && !ONE) {
       fresh_args(a, tau, dt, w);
       settle(lp);
     }
@@ -1321,9 +1353,9 @@ __device__ __forceinline__ void hess_groups(const PkArgs& A, const PkPhase& ph, 
     if constexpr (NI > 0) {
       wave_lds_sync();
       if (tl.nj != 0) PK_PHASE_B(T, (hess_group_b<P, G, STAGED>(A, ph, tl, g, T, sv, lam_s, segb, lane)));
-      wave_lds_sync();                 // (the next pass overwrites the rows this one streamed from)
+      if constexpr (!ONE) wave_lds_sync();      // (the next pass overwrites the rows this one streamed from)
     }
-    hess_groups<P, G + 1>(A, ph, tl, g, T, a, tau, dt, w, sy, lp, sv, lam_s, segb, lane, q, live);
+    if constexpr (!ONE) hess_groups<P, G + 1>(A, ph, tl, g, T, a, tau, dt, w, sy, lp, sv, lam_s, segb, lane, q, live);
   }
 }
 
@@ -1360,6 +1392,46 @@ __device__ __forceinline__ void tile_hess(const PkArgs& A, const PkTile& tl, dou
                                           double* __restrict__, double* __restrict__, int lane) {
   if constexpr (P::H_NG == 1) tile_hess_single<P>(A, tl, sv, lane);
   else tile_hess_grouped<P>(A, tl, sv, lane);
+}
+
+template <class P, int G>
+__device__ __forceinline__ void tile_hess_one(const PkArgs& A, const PkTile& tl, double* __restrict__ sv, int lane) {
+  const PkPhase& ph = A.ph[P::INDEX];
+  const TileGeom g = tile_geom<P>(tl);
+  double s[PK_NS], dt, mt;
+  phase_scalars<P>(A, ph, s, dt, mt);
+  const PkSys sy{s, A.Ibuf, A.sigma, A.lam};
+  SegBases<P::H_NI + P::H_NN> segb;
+  segb.load(A.lb, ph.hseg_off, lane);
+  double* __restrict__ lam_s = sv + P::H_GMAX * PK_WAVE;       // the tile's defect multipliers, [state][row]
+  const bool fit = tabs_fit(A, tl, g);
+  const TabRegs tr = tabs_issue(A, ph, tl, g, fit, lane);
+  const int q = tl.q0 + lane;
+  double a[P::NARG], tau, w, lp[P::NC > 0 ? P::NC : 1], lrow[P::NX];
+  const int row = min(tl.r0 + lane, ph.L_d - 1);
+  constexpr bool needs_rows = P::H_gni(G) > 0;                 // (a pass of per-node segments only reads no defect multiplier)
+  if (needs_rows) {
+#pragma unroll
+    for (int i = 0; i < P::NX; ++i) lrow[i] = A.lam[ph.g_off + i * ph.L_d + row];
+  }
+  load_node<P>(A, ph, s, dt, mt, q, a, tau, w);
+#pragma unroll
+  for (int j = 0; j < P::NC; ++j) lp[j] = A.lam[ph.path_off + j * ph.L_m + min(q, ph.L_m - 1)];
+  const TileTabs T = tabs_commit(A, tl, g, tr, fit, lane);
+  if (needs_rows) {
+#pragma unroll
+    for (int i = 0; i < P::NX; ++i) lam_s[i * PK_WAVE + lane] = lrow[i];
+  }
+  segb.settle();
+  loads_done();
+  hess_groups<P, G, true>(A, ph, tl, g, T, a, tau, dt, w, sy, lp, sv, lam_s, segb, lane, q, lane < g.nq);
+}
+template <class P, int G = 0>
+__device__ __forceinline__ void tile_hess_pick(int grp, const PkArgs& A, const PkTile& tl, double* __restrict__ sv, int lane) {
+  if constexpr (G < P::H_NG) {
+    if (grp == G) tile_hess_one<P, G>(A, tl, sv, lane);
+    else tile_hess_pick<P, G + 1>(grp, A, tl, sv, lane);
+  }
 }
 
 // ============================================================================================
@@ -2958,6 +3030,37 @@ __device__ __forceinline__ void kernel_cycle(const PkTile* pre_tile, int pre_n_t
     return;
   }
   const int slot = pk::xcd_tile_block((int)blockIdx.x, 3, pre_grid);
+  if constexpr (Gen::GROUPED) {
+    // A model evaluated in groups: the workgroups of a tile block are [Jacobian pass 0 .. NJ-1 | values | Hessian pass 0 .. NH-1]
+    // (NJ / NH: the most passes any phase has; a phase with fewer leaves the surplus workgroups at once).
+    constexpr int NJ = Gen::J_NGMAX, NH = Gen::H_NGMAX, PER = 1 + NJ + NH;
+    const int blk = slot / PER, sub = slot - blk * PER;
+    if ((pre_flags & 128) && sub > NJ) return;            // (x-only launch: no Hessian)
+    const bool ch = COMPACT && (pre_flags & 256) != 0, cj = COMPACT && (pre_flags & 512) != 0;
+    if ((cj && sub > 0 && sub < NJ) || (ch && sub > NJ + 1)) return;      // (the compact roles run their passes in one wave)
+    PK_TILE_PROLOGUE_FROM(pre_tile, pre_n_tiles);
+    PK_KA_COLLECT();
+#ifdef PK_BIG
+    PkTile tl0;
+    if (big_block(pre_tile, pre_n_tiles, blk, tl0)) {     // (a workgroup-wide interval: its roles walk their passes themselves)
+      if (sub == 0) Gen::bigx2(tl0.phase, A, tl0, PK_STAGE(A), wint, wgrad, -1);
+      else if (sub == NJ) Gen::bigx1(tl0.phase, A, tl0, PK_STAGE(A), wint, wgrad, blk);
+      else if (sub == NJ + 1) Gen::bigh(tl0.phase, A, tl0, PK_STAGE(A));
+      return;
+    }
+#endif
+    if (sub < NJ) {
+      if (cj) Gen::tile_jacc(tl.phase, A, tl, PK_STAGE(A) + wave * Gen::LDS_X, wint, wgrad, lane);
+      else Gen::tile_jacg(tl.phase, sub, A, tl, PK_STAGE(A) + wave * Gen::LDS_X, lane);
+    } else if (sub == NJ) {
+      if (cj) Gen::tile_xall1c(tl.phase, A, tl, PK_STAGE(A) + wave * Gen::LDS_X, wint + wave * PK_NRED, wgrad + wave * PK_NRED, lane, blk);
+      else Gen::tile_xall1(tl.phase, A, tl, PK_STAGE(A) + wave * Gen::LDS_X, wint + wave * PK_NRED, wgrad + wave * PK_NRED, lane, blk);
+    } else {
+      if (ch) Gen::tile_hessc(tl.phase, A, tl, PK_STAGE(A) + wave * Gen::LDS_G, wint, wgrad, lane);
+      else Gen::tile_hessg(tl.phase, sub - NJ - 1, A, tl, PK_STAGE(A) + wave * Gen::LDS_H, lane);
+    }
+    return;
+  }
   const bool split = (pre_flags & 32) != 0;
   const int blk = split ? slot / 3 : slot >> 1;       // the tile block; its workgroups follow each other in dispatch order
   const int sub = slot - blk * (split ? 3 : 2);       // split: 0 Jacobian, 1 values, 2 Hessian; else 0 x-part, 1 Hessian

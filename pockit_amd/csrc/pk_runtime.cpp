@@ -416,7 +416,9 @@ int enqueue_single_launch_cycle(pk_ctx* c, const double* d_x, const double* d_la
     if (dbl < PK_WAVES_PER_BLOCK * (size_t)c->md.lds_g) dbl = PK_WAVES_PER_BLOCK * (size_t)c->md.lds_g;
     if (dbl < (size_t)c->md.ne_hc) dbl = (size_t)c->md.ne_hc;
   }
-  const unsigned per_group = c->split_xall ? 3u : 2u;
+  // workgroups per tile block: [Jacobian | values | Hessian] (x-part split) or [x-part | Hessian]; a model evaluated in groups:
+  // one per pass of the Jacobian / Hessian role beside the values workgroup (md.cycle_subs, codegen.py)
+  const unsigned per_group = c->md.cycle_subs > 0 ? (unsigned)c->md.cycle_subs : (c->split_xall ? 3u : 2u);
   const unsigned grid = tile_blocks(c) * per_group + 3u;
   // pk_cycle's kernarg segment: the scalars a tile wave needs first (preloaded into SGPRs), then the PkArgs
   struct CycleArgs {
@@ -806,6 +808,7 @@ int pk_load_model(pk_ctx* c, const void* code_object, size_t len, const pk_model
   for (int k = 0; k < K_COUNT; ++k) PK_HIP(c, hipModuleGetFunction(&c->fn[k], c->module, kKernelNames[k]));
   c->md = *md;
   if (md->tab_cap != 64 && md->tab_cap != 256) return fail(c, 23, "pk_load_model: table capacity %d (64 or 256)", md->tab_cap);
+  if (md->cycle_subs < 0 || md->cycle_subs > 4096) return fail(c, 25, "pk_load_model: cycle_subs %d", md->cycle_subs);
   if (md->max_phases < 0 || md->max_phases > PK_HOST_MAX_PHASES || md->n_phase > (md->max_phases > 0 ? md->max_phases : 8))
     return fail(c, 24, "pk_load_model: %d phases, code object compiled for %d (the library passes at most %d phase records in "
                        "the kernel arguments)", md->n_phase, md->max_phases > 0 ? md->max_phases : 8, PK_HOST_MAX_PHASES);

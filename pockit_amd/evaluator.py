@@ -252,6 +252,7 @@ class Evaluator:
         md.tab_cap = self.src.tab_cap
         md.sharded = int(self.src.sharded)
         md.max_phases = self.src.max_phases
+        md.cycle_subs = self.src.cycle_subs
         self._err_views = None
         self._csr = {}
         md.prepass_f = 1
