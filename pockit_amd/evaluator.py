@@ -23,7 +23,7 @@ from .transcription import SystemPlan
 N_CU = 256      # compute units of an MI355X (one workgroup of the cycle per CU is the sweet spot, see _intervals_per_wave)
 
 
-def _intervals_per_wave(plan, override=None, shards=1):
+def _intervals_per_wave(plan, override=None, shards=1, subs=0):
     """Intervals per wavefront, up to 64 nodes per wave (Layout.tiles caps it).  Measured on MI355X with pk_cycle
     (tools/ipw_sweep.sh): at 12k nodes the cycle is bound by the number of vector-memory
     instructions a CU has to issue and by the time the dispatcher needs to start the waves, so fuller waves
@@ -60,8 +60,10 @@ def _intervals_per_wave(plan, override=None, shards=1):
             t = math.ceil(max(n_p / shards - 1, 0) / min(ipw, cap)) + 1        # (the first interval is a kind of its own)
             tiles += -(-t // runtime.WAVES_PER_BLOCK) * runtime.WAVES_PER_BLOCK
         roles = 3 if tiles <= 1024 else 2          # (pk_set_problem: the x-part is split into two roles up to 1024 tiles)
+        if subs:
+            roles = int(subs)
         per_cu = math.ceil((roles * tiles // runtime.WAVES_PER_BLOCK + 3) / N_CU)
-        cost = per_cu * (ipw * (1.0 if roles == 3 else 1.5) + 4.0)      # (+4: a workgroup's fixed work, in intervals)
+        cost = per_cu * (ipw * (1.5 if roles == 2 else 1.0) + 4.0)      # (+4: a workgroup's fixed work, in intervals)
         if best is None or cost <= best[0]:
             best = (cost, ipw)
     return best[1]
@@ -86,7 +88,7 @@ class Tables:
 
     ``tile_filter(phase_index, tiles) -> tiles`` lets a rank keep only its shard of the tiles."""
 
-    def __init__(self, plan: SystemPlan, src: ModelSource, intervals_per_wave=None, tile_filter=None):
+    def __init__(self, plan: SystemPlan, src: ModelSource, intervals_per_wave=None, tile_filter=None, shards=1):
         ib, db, lb = [], [], []
 
         def put(store, arr, dtype):
@@ -98,7 +100,7 @@ class Tables:
         nP = len(plan.phase_plans)
         phases = np.zeros(nP, dtype=runtime.PHASE_DTYPE)
         kinds, tiles = [], []
-        ipw = _intervals_per_wave(plan, intervals_per_wave)
+        ipw = _intervals_per_wave(plan, intervals_per_wave, shards=shards, subs=getattr(src, "cycle_subs", 0))
         for k, pp in enumerate(plan.phase_plans):
             lay = pp.layout
             kind0 = len(kinds)
@@ -265,7 +267,8 @@ class Evaluator:
         self.zero_copy = False   # True: callbacks return views of pinned buffers (set by the IPOPT adapter)
         self.ctx.check(lib.pk_load_model(h, code, len(code), C.byref(md)))
         self.model_desc = md
-        self.set_tables(Tables(plan, self.src, intervals_per_wave, tile_filter))
+        # (the tiling is sized for ONE shard's share of the mesh: output_share = 1 / number of shards)
+        self.set_tables(Tables(plan, self.src, intervals_per_wave, tile_filter, shards=max(1, int(round(1.0 / output_share)))))
 
     def set_tables(self, tb: Tables):
         plan, lib, h = self.plan, self.ctx.lib, self.ctx.handle

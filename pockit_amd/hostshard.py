@@ -38,7 +38,7 @@ from multiprocessing import shared_memory
 import numpy as np
 import sympy as sp
 
-from .evaluator import Evaluator, _intervals_per_wave
+from .evaluator import Evaluator
 from .sharding import needed_x_runs, owned_runs, run_table, shared_gradient_slots, tile_filter
 
 CMD_EXIT, CMD_X, CMD_HESS, CMD_X_TRIAL, CMD_J, CMD_INT = 0, 1, 2, 3, 4, 5
@@ -100,8 +100,6 @@ class HostShardedEvaluator:
         # alone would leave the others in the broadcast / barrier below until the backend's time-out.
         problem = None
         try:
-            if intervals_per_wave is None:
-                intervals_per_wave = _intervals_per_wave(plan, shards=world)
             self.ev = Evaluator(plan, device=device, intervals_per_wave=intervals_per_wave,
                                 tile_filter=tile_filter(rank, world, plan) if world > 1 else None,
                                 output_share=1.0 / max(world, 1), host_helpers=False)

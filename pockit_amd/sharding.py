@@ -450,11 +450,10 @@ class ShardedEvaluator:
         import torch
 
         from .codegen import ModelSource
-        from .evaluator import Evaluator, Tables, _intervals_per_wave
+        from .evaluator import Evaluator, Tables
 
         self.torch, self.rank, self.world, self.plan = torch, rank, world, plan
-        if intervals_per_wave is None:          # the tiling is sized for ONE shard's share of the mesh
-            intervals_per_wave = _intervals_per_wave(plan, shards=world)
+        # (intervals_per_wave None: the evaluator sizes the tiling for ONE shard's share of the mesh, from output_share)
         self.ev = Evaluator(plan, device=device, intervals_per_wave=intervals_per_wave,
                             tile_filter=tile_filter(rank, world, plan) if world > 1 else None, sharded=world > 1,
                             output_share=1.0 / max(world, 1), host_helpers=False)

@@ -245,7 +245,11 @@ def test_intervals_with_more_points_than_a_wavefront_has_lanes(case, monkeypatch
     close(ev.hessian_direct(x, lam, sigma), want["H"], what="H direct")
     ev.set_cycle_mode(False)                                         # two-launch cycle, unsplit and split x-part
     f2, grad2, g2, J2, H2 = ev.cycle(x, lam, sigma)
-    assert np.array_equal(J2, J) and np.array_equal(H2, H) and np.array_equal(g2, g)
+    if ev.src.cycle_subs:      # every pass a workgroup of its own in pk_cycle, a loop in pk_xall / pk_hess: the compiler
+        for a, b, what in ((J2, J, "J"), (H2, H, "H"), (g2, g, "g")):     # contracts the same expressions differently
+            close(a, b, tol=1e-13, what="two launches against one: " + what)
+    else:
+        assert np.array_equal(J2, J) and np.array_equal(H2, H) and np.array_equal(g2, g)
     ev.set_cycle_mode(True)
     system.set_hessian_layout("compact")                             # compact layout: pk_hessc walks such an interval 64 nodes at a time
     close(system.hessian(x, lam, sigma), it.hessian_compact(), what="compact H")

@@ -50,6 +50,7 @@ for name in ("humanoid_whole_body_control", "drone_stabilization", "rocket_power
     groups = {f"{cb}": len(g) for (cb, k), g in ev.src.groups.items() if len(g) > 1}
     finite = all(bool(torch.isfinite(o).all()) for o in outs)
     print(f"{name:30s} {intervals} x {K}: n={plan.n} nnz_J={plan.nnz_J} nnz_H={plan.nnz_H} B={B / 1e6:.1f} MB  groups={groups or 'single pass'}  "
+          f"ipw={ev.tables.intervals_per_wave} tiles={len(ev.tables.tiles)} subs={ev.src.cycle_subs}  "
           f"{wall:.1f} us/cycle  {B / wall / 1e6:.2f} TB/s = {B / wall / 1e6 / 8:.3f} of 8 TB/s  finite={finite}  setup {setup:.1f} s",
           flush=True)
     system._invalidate()
