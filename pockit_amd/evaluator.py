@@ -229,6 +229,22 @@ def compile_plan(plan: SystemPlan, sharded=False, output_share=1.0):
         if trial[2] >= best[2]:
             break
         best = trial
+    # The cycle of a model evaluated in groups is fastest with every pass as a workgroup of its own (ModelSource.cycle_subs,
+    # DESIGN.md section 3c), which needs two workgroups of the launch on a CU: when the groups need too much LDS for that,
+    # half the size is tried (rocket_powered_descent at 2000 x 4: 22.6 -> 11.3 us per cycle, drone_stabilization 15.2 -> 13.6;
+    # profiles/r04_y_fat_pp_sweep.txt) -- unless it brings spills back.
+    src = best[0]
+    if (src.grouped and not src.cycle_subs and not os.environ.get("POCKIT_AMD_GROUP_CAP")
+            and os.environ.get("POCKIT_AMD_PASS_PARALLEL", "auto") == "auto"):
+        cap = src.group_cap
+        while cap > 8:
+            cap //= 2
+            if not ModelSource(plan, sharded=sharded, output_share=output_share, group_cap=cap).cycle_subs:
+                continue                     # (generated only: e.g. the values role of a wide model alone needs the LDS)
+            trial = build(cap)
+            if trial[2] <= best[2]:
+                best = trial
+            break
     return best[0], best[1]
 
 
