@@ -98,7 +98,7 @@ def _worker(rank, world, port, case, ret, backend="gloo"):
         for key in keys:
             got = o[key].cpu().numpy()
             err = max(err, float(np.max(np.abs(got - want[key])) / max(1.0, np.max(np.abs(want[key])))))
-        flag = torch.tensor([err], device=dev if backend == "nccl" else "cpu")
+        flag = torch.tensor([float(err)], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
         dist.all_reduce(flag, op=dist.ReduceOp.MAX)
         if rank == 0:
             ret.put(float(flag.item()))
@@ -177,7 +177,7 @@ def _peer_worker(rank, world, port, case, ret):
                 err = max(err, float(np.max(np.abs(got - want)) / scale(want)))
                 err = max(err, abs(float(o["f"].cpu()[0]) - f_want) / max(1.0, abs(f_want)))
             dist.barrier()
-        flag = torch.tensor([err])
+        flag = torch.tensor([float(err)], dtype=torch.float64)   # (one dtype on every rank, whatever produced the maximum)
         dist.all_reduce(flag, op=dist.ReduceOp.MAX)
         sev.close()
         if rank == 0:
@@ -292,7 +292,7 @@ def _host_worker(rank, world, port, case, ret):
                 err = max(err, float(np.max(np.abs(a - b)) / scale(b)) if b.size else 0.0)
             err = float("inf") if not np.isfinite(err) else err
         hs.close()
-        flag = torch.tensor([err])
+        flag = torch.tensor([float(err)], dtype=torch.float64)   # (one dtype on every rank, whatever produced the maximum)
         dist.all_reduce(flag, op=dist.ReduceOp.MAX)
         if rank == 0:
             ret.put(float(flag.item()))
@@ -321,6 +321,33 @@ def test_host_landed_sharded_cycle_matches_oracle(case, world):
     ctx = mp.get_context("spawn")
     ret = ctx.Queue()
     procs = [ctx.Process(target=_host_worker, args=(r, world, port, case, ret)) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(300)
+    assert all(p.exitcode == 0 for p in procs), [p.exitcode for p in procs]
+    err = ret.get(timeout=5)
+    assert isinstance(err, float), err
+    assert err <= 1e-11, err
+
+
+@pytest.mark.parametrize("form", ["device", "peer", "host"])
+@pytest.mark.parametrize("case", [("humanoid_wbc", "radau", dict(mesh=24, num_point=4)),
+                                  ("two_stage_rocket", "lobatto", dict(mesh=30, num_point=5))])
+def test_sharded_cycle_of_a_model_evaluated_in_groups(case, form, monkeypatch):
+    """The derivative set in groups of three, every pass of the cycle a workgroup of its own, each rank
+    on its share of the mesh intervals: the sharded forms (collectives, peer stores, host-landed) against the oracle."""
+    import torch.multiprocessing as mp
+
+    monkeypatch.setenv("POCKIT_AMD_GROUP_CAP", "3")         # (the spawned ranks inherit the environment)
+    monkeypatch.setenv("POCKIT_AMD_PASS_PARALLEL", "1")
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    ret = ctx.Queue()
+    target = dict(device=_worker, peer=_peer_worker, host=_host_worker)[form]
+    procs = [ctx.Process(target=target, args=(r, 2, port, case, ret)) for r in range(2)]
     for p in procs:
         p.start()
     for p in procs:
