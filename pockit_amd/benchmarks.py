@@ -707,3 +707,34 @@ FULL_CASES = {
     "C4_rocket_lgr_2x1000x4": (two_stage_rocket, "radau", dict(mesh=1000, num_point=4)),
     "C5_humanoid_lgr_5000x8": (humanoid_wbc, "radau", dict(mesh=5000, num_point=8)),
 }
+
+
+def phase_relay(ns, phases=10, mesh=3, num_point=3):
+    """Synthetic workload for the phase fan-out (the reference puts no limit on the number of phases, systembase.py:148-187):
+    ``phases`` short phases of one state and one control handed over through static parameters -- phase k starts at the
+    value s_(k-1) its predecessor ends with (FUNC boundary values), fixed times [k, k + 1], damping and an integrand that
+    differ per phase; objective: the sum of the integrals plus a pull on the hand-over values.  Not a reference program."""
+    system = ns.System(max(phases - 1, 0))
+    S = list(system.s)
+    out, guesses = [], []
+    for k in range(phases):
+        p = system.new_phase(1, 1)
+        (x,), (u,) = p.x, p.u
+        p.set_dynamics([u - (0.1 + 0.05 * k) * x + 0.02 * sp.sin(p.t)])
+        p.set_integral([u**2 + (0.3 + 0.01 * k) * (x - 1.0) ** 2])
+        p.set_phase_constraint([u], [-4.0], [4.0])
+        x0 = 1.5 if k == 0 else S[k - 1]
+        xf = S[k] if k < phases - 1 else 1.0
+        p.set_boundary_condition([x0], [xf], float(k), float(k + 1))
+        p.set_discretization(mesh, num_point)
+        out.append(p)
+    system.set_phase(out)
+    system.set_objective(sum(p.I[0] for p in out) + sum(0.05 * (s - 1.2) ** 2 for s in S))
+    for k, p in enumerate(out):
+        g = ns.linear_guess(p, 0.0)
+        g.x[0] = 1.5 - 0.5 * (k + (g.t_x - k)) / phases
+        g.u[0] = 0.1
+        guesses.append(g)
+    if S:
+        guesses.append([1.5 - 0.5 * (k + 1) / phases for k in range(len(S))])
+    return system, out, guesses

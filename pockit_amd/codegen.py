@@ -525,8 +525,8 @@ class ModelSource:
         S.append("// Generated by pockit_amd.codegen -- model code only; kernels are in pk_kernels.hip.h")
         # phase records the kernels take by value in their arguments: 8 unless the model has more (pk_abi.h)
         self.max_phases = 8 if nP <= 8 else nP
-        if nP > 24:
-            raise ValueError(f"{nP} phases: the MI355X evaluator passes at most 24 phase records in its kernel arguments "
+        if nP > 128:
+            raise ValueError(f"{nP} phases: the MI355X evaluator passes at most 128 phase records in its kernel arguments "
                              "(PK_HOST_MAX_PHASES, pk_abi.h)")
         if self.max_phases != 8:
             S.append(f"#define PK_MAX_PHASES {self.max_phases}")

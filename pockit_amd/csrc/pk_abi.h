@@ -117,11 +117,11 @@ struct PkErrIv {
 // Phases a code object holds BY VALUE in its kernel arguments (PkArgs.ph, last member).  The reference puts no limit on the
 // number of phases (systembase.py:148-187); here the code generator raises the constant for a model with more than 8
 // (codegen.py emits the #define in front of this header) and the library passes offsetof(PkArgs, ph) + that many records, up
-// to PK_HOST_MAX_PHASES -- what fits the 4 KB kernel-argument segment beside the rest of PkArgs.
+// to PK_HOST_MAX_PHASES = 15 KB of records -- this stack takes 32 KB of kernel arguments (tools/kernarg_probe.hip, measured).
 #ifndef PK_MAX_PHASES
 #define PK_MAX_PHASES 8
 #endif
-#define PK_HOST_MAX_PHASES 24
+#define PK_HOST_MAX_PHASES 128
 #define PK_CYCLE_ARGS_OFFSET 24   // pk_cycle: bytes of leading scalar kernel arguments in front of its PkArgs
 #define PK_MAX_RANKS 64       // ranks of one sharded NLP (pk_xchg: one polling thread per peer)
 #define PK_XC_STATE 16        // state words behind the 2 x world x stride words of a rank's mailbox (cycle count, time-outs)

@@ -37,7 +37,7 @@
 #include <vector>
 
 #include "../../include/pockit_hip.h"
-#define PK_MAX_PHASES 24      // (= PK_HOST_MAX_PHASES: the host-side PkArgs holds the most a code object may ask for)
+#define PK_MAX_PHASES 128     // (= PK_HOST_MAX_PHASES: the host-side PkArgs holds the most a code object may ask for)
 #include "pk_abi.h"
 
 namespace {
@@ -306,9 +306,11 @@ int ready(pk_ctx* c) {
   return 0;
 }
 
+size_t args_bytes(const pk_ctx* c);
+
 PkArgs base_args(pk_ctx* c, const double* d_x, const double* d_lam, double sigma) {
-  PkArgs A;
-  std::memset(&A, 0, sizeof A);
+  PkArgs A;      // (only the bytes the code object declares are filled and launched: the head and its phase records)
+  std::memset(static_cast<void*>(&A), 0, args_bytes(c));
   A.x = d_x; A.lam = d_lam; A.sigma = sigma;
   A.phase = (const PkPhase*)c->d_phases; A.tile = (const PkTile*)c->d_tiles; A.kind = (const PkKind*)c->d_kinds;
   A.items = nullptr; A.ib = c->d_ib; A.db = c->d_db; A.lb = c->d_lb;
@@ -428,7 +430,7 @@ int enqueue_single_launch_cycle(pk_ctx* c, const double* d_x, const double* d_la
   } K;
   static_assert(offsetof(CycleArgs, A) == PK_CYCLE_ARGS_OFFSET, "layout of pk_cycle's kernel arguments");
   K.tile = A.tile; K.n_tiles = A.n_tiles; K.flags = A.flags; K.grid = (int32_t)grid; K.pad = 0;
-  K.A = A;
+  std::memcpy(static_cast<void*>(&K.A), &A, args_bytes(c));
   // (the compact layouts: pk_cyclec, the same launch compiled with their roles -- a kernel of its own so that pk_cycle's
   //  register count stays what the reference layouts need)
   return launch_raw(c, layout ? K_CYCLEC : K_CYCLE, &K, offsetof(CycleArgs, A) + args_bytes(c), grid, sizeof(double) * dbl, st);

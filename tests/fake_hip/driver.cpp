@@ -84,6 +84,11 @@ int main() {
   md.tab_cap = 65;
   CHECK(pk_load_model(ctx, image, sizeof image, &md) != 0);    // refused capacity
   md.tab_cap = 64;
+  md.max_phases = PK_HOST_MAX_PHASES + 1;
+  CHECK(pk_load_model(ctx, image, sizeof image, &md) != 0);    // more phase records than the kernel arguments hold
+  md.max_phases = PK_HOST_MAX_PHASES; md.n_phase = PK_HOST_MAX_PHASES;
+  OK(pk_load_model(ctx, image, sizeof image, &md));            // (the most: accepted)
+  md.max_phases = 0; md.n_phase = 1;
   OK(pk_load_model(ctx, image, sizeof image, &md));
   PkPhase ph{};
   pk_problem_desc pd{};

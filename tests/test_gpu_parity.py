@@ -1776,6 +1776,34 @@ def test_stand_ins_for_the_literal_baseline_configs_match_the_oracle(case):
     system._invalidate()
 
 
+@pytest.mark.parametrize("case", [("radau", 10, dict(mesh=3, num_point=3)), ("lobatto", 30, dict(mesh=[0, 0.3, 1.0], num_point=[3, 4]))])
+def test_more_phases_than_the_default_kernel_arguments_hold(case):
+    """The reference puts no limit on the number of phases (systembase.py:148-187).  A code object holds its phase records
+    by value in the kernel arguments: 8 by default, as many as the model has beyond that (PK_MAX_PHASES emitted by the code
+    generator, up to PK_HOST_MAX_PHASES = 128).  benchmarks.phase_relay -- short phases handed over through static
+    parameters -- with 10 and 30 phases against the oracle: structures exactly, callbacks and the one-launch cycle to 1e-11."""
+    scheme, n_phases, kw = case
+    system, _, guess = models.phase_relay(_ns(scheme, "pockit_amd"), phases=n_phases, **kw)
+    ref, _, _ = models.phase_relay(_ns(scheme, "oracle"), phases=n_phases, **kw)
+    x, lam, sigma = models.bench_inputs(system, guess)
+    for a, b in zip(system.jacobianstructure() + system.hessianstructure(), ref.jacobianstructure() + ref.hessianstructure()):
+        assert np.array_equal(a, b)
+    assert system.evaluator.src.max_phases == n_phases
+    want = _all_five(ref, x, lam, sigma)
+    for a, b, what in zip(_all_five(system, x, lam, sigma), want, ("f", "grad", "g", "J", "H")):
+        close(a, b, what=f"{n_phases} phases, callbacks {what}")
+    for a, b, what in zip(system.evaluator.cycle(x, lam, sigma), want, ("f", "grad", "g", "J", "H")):
+        close(a, b, what=f"{n_phases} phases, cycle {what}")
+    system.set_hessian_layout("compact")
+    (hr, hc), Hc = system.hessianstructure(), system.hessian(x, lam, sigma)
+    rr, rc = ref.hessianstructure()
+    A, B = np.zeros((x.size, x.size)), np.zeros((x.size, x.size))
+    np.add.at(A, (hr, hc), Hc)
+    np.add.at(B, (rr, rc), want[4])
+    close(A, B, what=f"{n_phases} phases, compact H")
+    system._invalidate()
+
+
 def test_forty_state_stand_in_at_forty_thousand_nodes():
     """humanoid_team at BASELINE configs[4]'s literal size (40 states, 5000 intervals x 8 points = 40 000 nodes; 24 M Jacobian
     and 29 M Hessian values per cycle).  The oracle needs minutes per callback there, so: entry-by-entry oracle parity at
