@@ -5,7 +5,9 @@
 #include <stdint.h>
 
 #define PK_WAVE 64
+#ifndef PK_WAVES_PER_BLOCK     // (experiments: POCKIT_AMD_WPB builds library and code objects with another value)
 #define PK_WAVES_PER_BLOCK 4
+#endif
 #define PK_BLOCK (PK_WAVE * PK_WAVES_PER_BLOCK)
 
 // One phase of the problem on its mesh.

@@ -60,7 +60,7 @@ ERRIV_DTYPE = np.dtype([("phase", np.int32), ("K", np.int32), ("lm", np.int32), 
                         ("tab_off", np.int32), ("tau_off", np.int32), ("rows", np.int32), ("stage", np.int32),
                         ("out_off", np.int64), ("width", np.float64)])
 
-WAVES_PER_BLOCK = 4  # PK_WAVES_PER_BLOCK of csrc/pk_abi.h
+WAVES_PER_BLOCK = int(os.environ.get("POCKIT_AMD_WPB") or 4)  # PK_WAVES_PER_BLOCK of csrc/pk_abi.h (POCKIT_AMD_WPB: experiments)
 WAVE = 64  # PK_WAVE
 KERNELS = ["pk_int", "pk_fin", "pk_g", "pk_grad", "pk_jac", "pk_hess", "pk_xall", "pk_aux", "pk_outer", "pk_hessc", "pk_err", "pk_csr",
            "pk_cycle", "pk_xchg", "pk_runs", "pk_jacc", "pk_cyclec"]
