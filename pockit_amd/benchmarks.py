@@ -738,3 +738,12 @@ def phase_relay(ns, phases=10, mesh=3, num_point=3):
     if S:
         guesses.append([1.5 - 0.5 * (k + 1) / phases for k in range(len(S))])
     return system, out, guesses
+
+
+# (reference-generated fixtures of the synthetic workloads as well: tests/golden/small)
+SMALL_CASES["relay_lgr_10"] = (phase_relay, "radau", dict(phases=10, mesh=3, num_point=3))
+SMALL_CASES["relay_lgl_12"] = (phase_relay, "lobatto", dict(phases=12, mesh=[0, 0.3, 1.0], num_point=[3, 4]))
+SMALL_CASES["rocket3_lgr_3x4"] = (three_stage_rocket, "radau", dict(mesh=3, num_point=4))
+SMALL_CASES["team_lgl_2x3"] = (humanoid_team, "lobatto", dict(mesh=2, num_point=3))
+# (cases the CPU suite's NumPy plan interpreter needs minutes for; the oracle test and the GPU tests run them)
+SLOW_ON_CPU = {"team_lgl_2x3"}

@@ -212,7 +212,7 @@ def test_setter_errors_match_reference_messages():
 
 
 # ------------------------------------------------------------------ transcription compiler
-@pytest.mark.parametrize("name", sorted(models.SMALL_CASES))
+@pytest.mark.parametrize("name", sorted(n for n in models.SMALL_CASES if n not in models.SLOW_ON_CPU))
 def test_plan_reproduces_reference(name):
     """Triplet structure identical to the reference; the evaluation plan (executed in NumPy exactly
     as the kernels consume it) reproduces the reference's f, grad f, g, J, H."""
@@ -246,7 +246,7 @@ def test_nonlinear_in_integrals_uses_outer_blocks():
     assert covered == plan.nnz_H
 
 
-@pytest.mark.parametrize("name", sorted(n for n in models.SMALL_CASES if not n.startswith(NONLINEAR_IN_I)))
+@pytest.mark.parametrize("name", sorted(n for n in models.SMALL_CASES if not n.startswith(NONLINEAR_IN_I) and n not in models.SLOW_ON_CPU))
 def test_compact_hessian_plan_coalesces_to_the_reference_matrix(name):
     """Compact layout (mu = I^T lambda, entries of a node summed per position): fewer triplets, same matrix
     as the scatter-add of the reference's triplets (the accumulation IPOPT performs)."""
@@ -267,7 +267,7 @@ def test_compact_hessian_plan_coalesces_to_the_reference_matrix(name):
         assert plan.nnz_Hc * 4 <= plan.nnz_H
 
 
-@pytest.mark.parametrize("name", sorted(models.SMALL_CASES))
+@pytest.mark.parametrize("name", sorted(n for n in models.SMALL_CASES if n not in models.SLOW_ON_CPU))
 def test_compact_jacobian_plan_coalesces_to_the_reference_matrix(name):
     """Compact Jacobian layout (dense-column entries of the dynamics contracted with the integration block, scalar items
     that meet on one position summed): no more triplets than the reference, every (row, column) of the reference and no
