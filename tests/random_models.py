@@ -24,8 +24,9 @@ def _expr(rng, syms, n_terms=None):
     return sum((_term(rng, syms) for _ in range(n)), sp.Integer(0))
 
 
-def random_model(ns, seed, scheme="radau"):
-    """-> (system, phases).  ``scheme`` only bounds the points per interval from below (LGL needs two)."""
+def random_model(ns, seed, scheme="radau", mesh_scale=1):
+    """-> (system, phases).  ``scheme`` only bounds the points per interval from below (LGL needs two); ``mesh_scale`` > 1
+    multiplies the number of mesh intervals (the soak run: several wave tiles per phase; the fixtures use 1)."""
     rng = np.random.default_rng(seed)
     n_s = int(rng.integers(0, 3))
     system = ns.System(n_s)
@@ -68,7 +69,7 @@ def random_model(ns, seed, scheme="radau"):
         t0 = [0.0, None, (S[0] * 0.1 if S else 0.0)][int(rng.integers(3))]
         tf = [None, float(np.round(rng.uniform(1.5, 3.0), 2)), ((S[-1] ** 2 + 2.0) if S else None)][int(rng.integers(3))]
         p.set_boundary_condition(x0, xf, t0, tf)
-        n_int = int(rng.integers(1, 6))
+        n_int = int(rng.integers(1, 6)) * int(mesh_scale)
         cuts = np.sort(rng.uniform(0.1, 0.9, size=n_int - 1)) if n_int > 1 else np.zeros(0)
         mesh = np.concatenate([[0.0], np.round(cuts, 3), [1.0]])
         if np.any(np.diff(mesh) <= 1e-3):
