@@ -23,7 +23,7 @@ from .transcription import SystemPlan
 N_CU = 256      # compute units of an MI355X (one workgroup of the cycle per CU is the sweet spot, see _intervals_per_wave)
 
 
-def _intervals_per_wave(plan, override=None, shards=1, subs=0):
+def _intervals_per_wave(plan, override=None, shards=1, subs=0, want_workgroups=False):
     """Intervals per wavefront, up to 64 nodes per wave (Layout.tiles caps it).  Measured on MI355X with pk_cycle
     (tools/ipw_sweep.sh): at 12k nodes the cycle is bound by the number of vector-memory
     instructions a CU has to issue and by the time the dispatcher needs to start the waves, so fuller waves
@@ -65,8 +65,14 @@ def _intervals_per_wave(plan, override=None, shards=1, subs=0):
         per_cu = math.ceil((roles * tiles // runtime.WAVES_PER_BLOCK + 3) / N_CU)
         cost = per_cu * (ipw * (1.5 if roles == 2 else 1.0) + 4.0)      # (+4: a workgroup's fixed work, in intervals)
         if best is None or cost <= best[0]:
-            best = (cost, ipw)
-    return best[1]
+            best = (cost, ipw, roles * tiles // runtime.WAVES_PER_BLOCK + 3)
+    return best[2] if want_workgroups else best[1]
+
+
+def _launch_underfills_the_chip(plan, shards=1):
+    """True when the one-launch cycle of this mesh, tiled by default, has no more workgroups than the GPU has CUs: the
+    cycle's time is then one wave's chain, not throughput (see compile_plan)."""
+    return bool(plan.phase_plans) and _intervals_per_wave(plan, shards=shards, want_workgroups=True) <= N_CU
 
 
 def magic_number(d: int) -> int:
@@ -223,6 +229,19 @@ def compile_plan(plan: SystemPlan, sharded=False, output_share=1.0):
         src.spilling_kernels = hipbuild.spills(hipbuild.resource_usage(src.source, fastmath=fast))
         return src, code, sum(v[0] for v in src.spilling_kernels.values())
 
+    # A launch that underfills the chip (small and medium meshes: what the reference's example programs use) is as slow as
+    # one wave's chain of evaluation, staging and streaming: groups of 16 instead of 32 split the roles of a moderately
+    # large model into passes that run as workgroups of their own (humanoid 25 ... 500 x 8: 8.3 -> 7.3 ... 6.6 us per cycle);
+    # with the chip full (humanoid 5000 x 8) the single pass is 4 % faster (profiles/r04_ze_*.txt).  The choice is a fact of
+    # the mesh like PK_TAB_CAP: a refinement that crosses the line costs one more (cached) compile.
+    best = None
+    free = not os.environ.get("POCKIT_AMD_GROUP_CAP") and os.environ.get("POCKIT_AMD_PASS_PARALLEL", "auto") == "auto"
+    if free and _launch_underfills_the_chip(plan, max(1, int(round(1.0 / output_share)))):
+        probe = ModelSource(plan, sharded=sharded, output_share=output_share, group_cap=ModelSource.GROUP_CAP // 2)
+        if probe.grouped and probe.cycle_subs:
+            trial = build(probe.group_cap)
+            if trial[2] == 0:
+                return trial[0], trial[1]
     best = build(None)
     while best[2] > 0 and best[0].group_cap > 4 and best[0].grouped and not os.environ.get("POCKIT_AMD_GROUP_CAP"):
         trial = build(best[0].group_cap // 2)

@@ -37,13 +37,15 @@ def compile_one(job):
     scheme, seed, scale = job
     from pockit_amd.evaluator import compile_plan
 
-    n = 0
+    from pockit_amd import hipbuild
+
+    keys = []
     for v in VARIANTS:
         set_variant(v)
         system, _ = rm.random_model(importlib.import_module(f"pockit_amd.{scheme}"), seed, scheme, mesh_scale=scale)
-        compile_plan(system.plan)
-        n += 1
-    return n
+        src, _ = compile_plan(system.plan)
+        keys.append(hipbuild._key(src.source, system.plan.system._fastmath))
+    return keys
 
 
 def err(a, b):
@@ -112,6 +114,7 @@ def main():
     ap.add_argument("--scale", type=int, default=4, help="mesh intervals x this factor (default 4: 4 ... 20 intervals per phase)")
     ap.add_argument("--compile-only", action="store_true")
     ap.add_argument("--jobs", type=int, default=4)
+    ap.add_argument("--keys", default=None, help="with --compile-only: append the cache keys of the code objects to this file")
     args = ap.parse_args()
     jobs = cases(args.lo, args.hi, args.scale)
     t0 = time.time()
@@ -120,8 +123,11 @@ def main():
 
         with mp.get_context("spawn").Pool(args.jobs) as pool:
             done = 0
-            for n in pool.imap_unordered(compile_one, jobs):
-                done += n
+            for keys in pool.imap_unordered(compile_one, jobs):
+                done += len(keys)
+                if args.keys:
+                    with open(args.keys, "a") as fh:
+                        fh.write("\n".join(keys) + "\n")
                 if done % 20 == 0:
                     print(f"{done} code objects, {time.time() - t0:.0f} s", flush=True)
         print(f"compiled / found {done} code objects in {time.time() - t0:.0f} s")

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """GPU box: the one-launch cycle of the benchmark configurations, device-resident -- us per launch and the fraction of the HBM
 roof on the cycle's algorithmic bytes.  A light stand-in for bench.py in A/B loops over build switches (POCKIT_AMD_*).
-Usage: cycle_probe.py [C2 C3 C4 C5 ...]"""
+Usage: cycle_probe.py [C2 C3 C4 C5 | name:intervals:points ...]"""
 import os
 import sys
 import time
@@ -17,7 +17,7 @@ CONFIGS = {"C2": ("brachistochrone", 200, 8), "C3": ("planar_quadrotor", 2000, 6
            "C5": ("humanoid_wbc", 5000, 8)}
 dev = torch.device("cuda", 0)
 for tag in (sys.argv[1:] or ["C3", "C5"]):
-    name, mesh, K = CONFIGS[tag]
+    name, mesh, K = CONFIGS[tag] if tag in CONFIGS else (tag.split(":")[0], int(tag.split(":")[1]), int(tag.split(":")[2]))
     system, _, guess = getattr(benchmarks, name)(radau, mesh=mesh, num_point=K)
     x, lam, sigma = benchmarks.bench_inputs(system, guess)
     plan, ev = system.plan, system.evaluator
@@ -38,6 +38,7 @@ for tag in (sys.argv[1:] or ["C3", "C5"]):
         best = wall if best is None else min(best, wall)
     B = 8 * (5 * plan.n + plan.m + 1 + plan.n + plan.m + plan.nnz_J + plan.nnz_H)
     finite = all(bool(torch.isfinite(o).all()) for o in outs)
-    print(f"{tag} {name} {mesh} x {K}: ipw={ev.tables.intervals_per_wave} tiles={len(ev.tables.tiles)}  {best:.2f} us/cycle  "
+    subs = f" groups={ {cb: len(g) for (cb, k), g in ev.src.groups.items() if len(g) > 1} } subs={ev.src.cycle_subs}" if ev.src.grouped else ""
+    print(f"{tag} {name} {mesh} x {K}:{subs} ipw={ev.tables.intervals_per_wave} tiles={len(ev.tables.tiles)}  {best:.2f} us/cycle  "
           f"{B / best / 1e6 / 8:.3f} of 8 TB/s  checksum J {float(outs[3].sum()):.9e} H {float(outs[4].sum()):.9e} finite={finite}", flush=True)
     system._invalidate()
