@@ -883,7 +883,8 @@ def test_batches_enqueued_by_the_library_equal_single_cycles():
 def test_single_launch_cycle_equals_two_launch_cycle_bit_for_bit(case, split, monkeypatch):
     """pk_cycle (x-kernel, Hessian and finalize workgroups in ONE launch, partial sums handed over inside the
     launch) runs the same waves and the same fixed-shape reductions as pk_xall -> pk_hess(+reductions): all five
-    outputs must be bit-identical, for split (<= 1024 tiles) and unsplit launches, and equal to the oracle."""
+    outputs must be bit-identical, for split (<= 1024 tiles) and unsplit launches, and equal to the oracle (a model whose
+    cycle runs pass-parallel -- the humanoid on this mesh, DESIGN.md section 3c -- agrees to 1e-13 instead)."""
     import torch
 
     monkeypatch.setenv("POCKIT_AMD_SPLIT", split)      # two waves per tile in the x-part (values / Jacobian) or one
@@ -911,7 +912,10 @@ def test_single_launch_cycle_equals_two_launch_cycle_bit_for_bit(case, split, mo
     finally:
         ev.set_cycle_mode(True)
     for k, _ in sizes:
-        assert np.array_equal(single[k], two[k]), k
+        if ev.src.cycle_subs:      # passes as workgroups of their own in pk_cycle, as a loop in pk_xall / pk_hess: the same
+            close(single[k], two[k], tol=1e-13, what=k)     # expressions compiled in different surroundings (last bits)
+        else:
+            assert np.array_equal(single[k], two[k]), k
     close(single["f"][0], ref.objective(x), what="f")
     close(single["grad"], ref.gradient(x), what="grad")
     close(single["g"], ref.constraints(x), what="g")
