@@ -223,8 +223,15 @@ def compile_plan(plan: SystemPlan, sharded=False, output_share=1.0):
     Returns (ModelSource, code object); ``ModelSource.spilling_kernels`` says what is left."""
     fast = plan.system._fastmath
 
-    def build(cap):
-        src = ModelSource(plan, sharded=sharded, output_share=output_share, group_cap=cap)
+    generated = {}
+
+    def generate(cap):
+        if cap not in generated:
+            generated[cap] = ModelSource(plan, sharded=sharded, output_share=output_share, group_cap=cap)
+        return generated[cap]
+
+    def build(cap, src=None):
+        src = src or generate(cap)
         code = hipbuild.compile_model(src.source, fastmath=fast)
         src.spilling_kernels = hipbuild.spills(hipbuild.resource_usage(src.source, fastmath=fast))
         return src, code, sum(v[0] for v in src.spilling_kernels.values())
@@ -234,16 +241,16 @@ def compile_plan(plan: SystemPlan, sharded=False, output_share=1.0):
     # large model into passes that run as workgroups of their own (humanoid 25 ... 500 x 8: 8.3 -> 7.3 ... 6.6 us per cycle);
     # with the chip full (humanoid 5000 x 8) the single pass is 4 % faster (profiles/r04_ze_*.txt).  The choice is a fact of
     # the mesh like PK_TAB_CAP: a refinement that crosses the line costs one more (cached) compile.
-    best = None
-    free = not os.environ.get("POCKIT_AMD_GROUP_CAP") and os.environ.get("POCKIT_AMD_PASS_PARALLEL", "auto") == "auto"
+    fixed_cap = bool(os.environ.get("POCKIT_AMD_GROUP_CAP"))
+    free = not fixed_cap and os.environ.get("POCKIT_AMD_PASS_PARALLEL", "auto") == "auto"
     if free and _launch_underfills_the_chip(plan, max(1, int(round(1.0 / output_share)))):
-        probe = ModelSource(plan, sharded=sharded, output_share=output_share, group_cap=ModelSource.GROUP_CAP // 2)
+        probe = generate(ModelSource.GROUP_CAP // 2)
         if probe.grouped and probe.cycle_subs:
-            trial = build(probe.group_cap)
+            trial = build(probe.group_cap, probe)
             if trial[2] == 0:
                 return trial[0], trial[1]
     best = build(None)
-    while best[2] > 0 and best[0].group_cap > 4 and best[0].grouped and not os.environ.get("POCKIT_AMD_GROUP_CAP"):
+    while best[2] > 0 and best[0].group_cap > 4 and best[0].grouped and not fixed_cap:
         trial = build(best[0].group_cap // 2)
         if trial[2] >= best[2]:
             break
@@ -253,14 +260,14 @@ def compile_plan(plan: SystemPlan, sharded=False, output_share=1.0):
     # half the size is tried (rocket_powered_descent at 2000 x 4: 22.6 -> 11.3 us per cycle, drone_stabilization 15.2 -> 13.6;
     # profiles/r04_y_fat_pp_sweep.txt) -- unless it brings spills back.
     src = best[0]
-    if (src.grouped and not src.cycle_subs and not os.environ.get("POCKIT_AMD_GROUP_CAP")
-            and os.environ.get("POCKIT_AMD_PASS_PARALLEL", "auto") == "auto"):
+    if free and src.grouped and not src.cycle_subs:
         cap = src.group_cap
         while cap > 8:
             cap //= 2
-            if not ModelSource(plan, sharded=sharded, output_share=output_share, group_cap=cap).cycle_subs:
+            probe = generate(cap)
+            if not probe.cycle_subs:
                 continue                     # (generated only: e.g. the values role of a wide model alone needs the LDS)
-            trial = build(cap)
+            trial = build(cap, probe)
             if trial[2] <= best[2]:
                 best = trial
             break
