@@ -353,8 +353,10 @@ class GpuWorkload:
                 # less -- try it before giving the mailboxes up altogether
                 self.exchange_fallback = "in-launch exchange failed its probe; pk_xchg in a launch of its own"
                 print(f"[bench] {self.exchange_fallback}", file=sys.stderr)
+                self.acknowledge_give_ups()
                 sev.inline_exchange = False
                 if not self.peer_exchange_works():
+                    self.acknowledge_give_ups()
                     self.peer_error = "the peers' flags did not arrive (no coherent peer access between these GPUs?)"
                     print(f"[bench] peer-mapped exchange set up but not working: {self.peer_error}; using the RCCL gather form",
                           file=sys.stderr)
@@ -388,6 +390,7 @@ class GpuWorkload:
                 self.sync()
                 if self.all_finite():
                     break
+                self.acknowledge_give_ups()
                 if self.mode == "sums" and sev.inline_exchange:
                     self.exchange_fallback = "in-launch exchange lost sums in a back-to-back burst; pk_xchg in a launch of its own"
                     sev.inline_exchange = self.inline_default = False
@@ -425,6 +428,15 @@ class GpuWorkload:
         t = torch.tensor([f if bad == 0.0 else 0.0, -f if bad == 0.0 else 0.0, bad], dtype=torch.float64, device=self.dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         return bool(float(t[2]) == 0.0 and float(t[0]) == -float(t[1]))      # nobody failed, max f == min f
+
+    def acknowledge_give_ups(self):
+        """An exchange form that failed its probe left "gave up waiting" counts in the library's status words; the next
+        waiting entry point would report them as error 97.  Take note of them here, for the form that is being abandoned,
+        so that the form tried next starts clean."""
+        try:
+            self.sev.ev.sync()
+        except RuntimeError as exc:
+            print(f"[bench] (abandoned exchange form) {exc}", file=sys.stderr)
 
     @staticmethod
     def fused_ok(plan):
