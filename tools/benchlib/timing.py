@@ -347,6 +347,11 @@ class GpuWorkload:
                 self.peer_error = repr(exc)
                 print(f"[bench] peer-mapped exchange not available ({exc!r}); using the RCCL gather form", file=sys.stderr)
             self.exchange_fallback = None
+            # (rehearsal of the fallback chain on a box where the peer exchange works: POCKIT_AMD_BENCH_POLL_LIMIT=1 makes
+            #  every hand-off of the two probes below give up at once)
+            rehearse = int(os.environ.get("POCKIT_AMD_BENCH_POLL_LIMIT", "0"))
+            if rehearse:
+                check(lib.pk_set_host_option(self.h, b"poll_limit", rehearse))
             if sev.peers is not None and not self.peer_exchange_works():
                 # the in-launch exchange needs every rank's launch to be running at the same time and the peers' system-scope
                 # stores to become visible to a polling workgroup; the two-launch form (pk_xchg behind pk_cycle) asks for
@@ -362,6 +367,8 @@ class GpuWorkload:
                           file=sys.stderr)
                     sev.peers.close()
                     sev.peers = None
+            if rehearse:
+                check(lib.pk_set_host_option(self.h, b"poll_limit", 0))
             if sev.peers is None and self.mode in ("sums", "direct"):
                 self.mode = "gather"
             self.sums_forms_ms = None
