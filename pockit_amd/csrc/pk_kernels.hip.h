@@ -2547,12 +2547,29 @@ __device__ __forceinline__ void kernel_hess(const PkArgs& A) {
     if (A.flags & (8 | 16)) fin_body<Gen>(A);
     return;
   }
-  PK_TILE_PROLOGUE(2);
+  if constexpr (Gen::GROUPED) {
+    // a model evaluated in groups: every pass of a tile block is a workgroup of its own, as in pk_cycle -- the grid has
+    // H_NGMAX workgroups per block (md.hess_subs); the Hessian callback of such a model is one pass long, not all of them
+    constexpr int NH = Gen::H_NGMAX;
+    const int slot = pk::xcd_tile_block((int)blockIdx.x, 2, (int)gridDim.x);
+    const int blk = slot / NH, pass = slot - blk * NH;
+    PK_TILE_PROLOGUE_AT();
 #ifdef PK_BIG
-  PkTile tl0;
-  if (big_block(A.tile, A.n_tiles, blk, tl0)) return Gen::bigh(tl0.phase, A, tl0, PK_STAGE(A));
+    PkTile tl0;
+    if (big_block(A.tile, A.n_tiles, blk, tl0)) {      // (a workgroup-wide interval walks its passes itself)
+      if (pass == 0) Gen::bigh(tl0.phase, A, tl0, PK_STAGE(A));
+      return;
+    }
 #endif
-  Gen::tile_hess(tl.phase, A, tl, PK_STAGE(A) + wave * Gen::LDS_H, wint, wgrad, lane);
+    Gen::tile_hessg(tl.phase, pass, A, tl, PK_STAGE(A) + wave * Gen::LDS_H, lane);
+  } else {
+    PK_TILE_PROLOGUE(2);
+#ifdef PK_BIG
+    PkTile tl0;
+    if (big_block(A.tile, A.n_tiles, blk, tl0)) return Gen::bigh(tl0.phase, A, tl0, PK_STAGE(A));
+#endif
+    Gen::tile_hess(tl.phase, A, tl, PK_STAGE(A) + wave * Gen::LDS_H, wint, wgrad, lane);
+  }
 }
 
 template <class Gen>

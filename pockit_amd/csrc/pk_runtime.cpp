@@ -372,6 +372,9 @@ int launch(pk_ctx* c, int k, PkArgs& A, unsigned grid, size_t lds_bytes, hipStre
 }
 
 unsigned tile_blocks(const pk_ctx* c) { return (unsigned)((c->n_tiles + PK_WAVES_PER_BLOCK - 1) / PK_WAVES_PER_BLOCK); }
+// pk_hess: edge and reduction workgroups + one workgroup per tile block -- per PASS of a block for a model evaluated in groups
+// whose code object runs the passes as workgroups of their own (md.hess_subs, codegen.py)
+unsigned hess_grid(const pk_ctx* c) { return tile_blocks(c) * (c->md.hess_subs > 0 ? (unsigned)c->md.hess_subs : 1u) + 2u; }
 
 int prepass(pk_ctx* c, const double* d_x, const double* d_lam, double sigma, double* d_f, bool write_f, hipStream_t st) {
   PkArgs A = base_args(c, d_x, d_lam, sigma);
@@ -457,7 +460,7 @@ int enqueue_fused_cycle(pk_ctx* c, const double* d_x, const double* d_lam, doubl
   H.flags |= F_FIN_INT | F_WRITE_F | F_FIN_GRAD | xall_flags(c);
   lds = sizeof(double) * PK_WAVES_PER_BLOCK * (size_t)c->md.lds_h;
   if (lds < sizeof(double) * (size_t)c->md.ne_h) lds = sizeof(double) * (size_t)c->md.ne_h;
-  return launch(c, K_HESS, H, tile_blocks(c) + 2, lds, st);
+  return launch(c, K_HESS, H, hess_grid(c), lds, st);
 }
 
 hipStream_t pick(pk_ctx* c, void* stream) { return stream ? (hipStream_t)stream : c->stream; }
@@ -811,6 +814,8 @@ int pk_load_model(pk_ctx* c, const void* code_object, size_t len, const pk_model
   c->md = *md;
   if (md->tab_cap != 64 && md->tab_cap != 256) return fail(c, 23, "pk_load_model: table capacity %d (64 or 256)", md->tab_cap);
   if (md->cycle_subs < 0 || md->cycle_subs > 4096) return fail(c, 25, "pk_load_model: cycle_subs %d", md->cycle_subs);
+  if (md->hess_subs < 0 || md->hess_subs > 4096 || (md->hess_subs > 0) != (md->cycle_subs > 0))
+    return fail(c, 25, "pk_load_model: hess_subs %d with cycle_subs %d", md->hess_subs, md->cycle_subs);
   if (md->max_phases < 0 || md->max_phases > PK_HOST_MAX_PHASES || md->n_phase > (md->max_phases > 0 ? md->max_phases : 8))
     return fail(c, 24, "pk_load_model: %d phases, code object compiled for %d (the library passes at most %d phase records in "
                        "the kernel arguments)", md->n_phase, md->max_phases > 0 ? md->max_phases : 8, PK_HOST_MAX_PHASES);
@@ -1047,7 +1052,7 @@ int pk_eval_hess_dev(pk_ctx* c, const double* d_x, const double* d_lam, double s
   A.n_items = c->n_items_hess;
   size_t lds = sizeof(double) * PK_WAVES_PER_BLOCK * (size_t)c->md.lds_h;
   if (lds < sizeof(double) * (size_t)c->md.ne_h) lds = sizeof(double) * (size_t)c->md.ne_h;
-  if ((rc = launch(c, K_HESS, A, tile_blocks(c) + 2, lds, st))) return rc;
+  if ((rc = launch(c, K_HESS, A, hess_grid(c), lds, st))) return rc;
   if (c->n_outer > 0) {   // objective / system constraints nonlinear in the integrals: outer-product blocks
     PkArgs X = base_args(c, d_x, d_lam, sigma);
     X.o_hess = d_vals;

@@ -297,6 +297,7 @@ class Evaluator:
         md.sharded = int(self.src.sharded)
         md.max_phases = self.src.max_phases
         md.cycle_subs = self.src.cycle_subs
+        md.hess_subs = self.src.h_ngmax if self.src.cycle_subs else 0
         self._err_views = None
         self._csr = {}
         md.prepass_f = 1
