@@ -245,7 +245,7 @@ def test_intervals_with_more_points_than_a_wavefront_has_lanes(case, monkeypatch
     close(ev.hessian_direct(x, lam, sigma), want["H"], what="H direct")
     ev.set_cycle_mode(False)                                         # two-launch cycle, unsplit and split x-part
     f2, grad2, g2, J2, H2 = ev.cycle(x, lam, sigma)
-    if ev.src.cycle_subs:      # every pass a workgroup of its own in pk_cycle, a loop in pk_xall / pk_hess: the compiler
+    if ev.src.cycle_subs:      # every pass a workgroup of its own in pk_cycle / pk_hess, a loop in pk_xall: the compiler
         for a, b, what in ((J2, J, "J"), (H2, H, "H"), (g2, g, "g")):     # contracts the same expressions differently
             close(a, b, tol=1e-13, what="two launches against one: " + what)
     else:
@@ -912,7 +912,7 @@ def test_single_launch_cycle_equals_two_launch_cycle_bit_for_bit(case, split, mo
     finally:
         ev.set_cycle_mode(True)
     for k, _ in sizes:
-        if ev.src.cycle_subs:      # passes as workgroups of their own in pk_cycle, as a loop in pk_xall / pk_hess: the same
+        if ev.src.cycle_subs:      # passes as workgroups of their own in pk_cycle / pk_hess, as a loop in pk_xall: the same
             close(single[k], two[k], tol=1e-13, what=k)     # expressions compiled in different surroundings (last bits)
         else:
             assert np.array_equal(single[k], two[k]), k
