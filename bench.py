@@ -27,6 +27,8 @@ import os
 
 for _v in ("OMP_NUM_THREADS", "OPENBLAS_NUM_THREADS", "MKL_NUM_THREADS", "NUMEXPR_NUM_THREADS"):
     os.environ.setdefault(_v, "1")
+# (multi-process GPU work on this pool: the host driver only supports dmabuf IPC -- hipIpc handles of the peer mailboxes, RCCL)
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
 import argparse  # noqa: E402
 import json  # noqa: E402
