@@ -53,3 +53,30 @@ def test_the_three_large_example_models_fit_and_do_not_spill(name):
     for kernel, u in usage.items():
         assert u.get("vgpr_spill", 0) == 0 and u.get("scratch", 0) == 0, (kernel, u)
     del single
+
+
+def test_group_size_follows_the_launch_not_only_the_model(monkeypatch):
+    """evaluator.compile_plan's rule for launches that underfill the chip: the humanoid on a small or
+    medium mesh is generated with groups of 16 and runs its Hessian passes as workgroups of their own; on BASELINE's C5
+    mesh (474 workgroups) it keeps the single pass; a model with few segments is the same code either way.  (The rule and
+    the generator only -- no hipcc.)"""
+    from pockit_amd import benchmarks, radau
+    from pockit_amd.evaluator import _intervals_per_wave, _launch_underfills_the_chip
+
+    for key in ("POCKIT_AMD_GROUP_CAP", "POCKIT_AMD_PASS_PARALLEL", "POCKIT_AMD_IPW"):
+        monkeypatch.delenv(key, raising=False)
+    small, _, _ = benchmarks.humanoid_wbc(radau, mesh=25, num_point=8)
+    full, _, _ = benchmarks.humanoid_wbc(radau, mesh=5000, num_point=8)
+    quad, _, _ = benchmarks.planar_quadrotor(radau, mesh=100, num_point=6)
+    assert _launch_underfills_the_chip(small.plan) and _launch_underfills_the_chip(quad.plan)
+    assert not _launch_underfills_the_chip(full.plan)
+    assert _intervals_per_wave(full.plan, want_workgroups=True) == 474
+    half = ModelSource(small.plan, group_cap=ModelSource.GROUP_CAP // 2)
+    assert half.grouped and half.cycle_subs == 1 + half.j_ngmax + half.h_ngmax and half.h_ngmax >= 2
+    assert "GROUPED = true" in half.source
+    whole = ModelSource(small.plan)
+    assert not whole.grouped and whole.cycle_subs == 0 and "GROUPED = false" in whole.source
+    # a model with at most 16 segments per role: the same source text, hence the same code object, whatever the rule says
+    assert ModelSource(quad.plan, group_cap=ModelSource.GROUP_CAP // 2).source == ModelSource(quad.plan).source
+    # the tiling model counts the pass-parallel workgroups: fuller waves for a model with many passes
+    assert _intervals_per_wave(small.plan, subs=half.cycle_subs) >= _intervals_per_wave(small.plan)
