@@ -15,7 +15,9 @@ import pockit_amd.radau as radau  # noqa: E402
 
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 4000
 CASES = [("quadrotor LGR 2000x6", models.planar_quadrotor, (2000, 6), N), ("rocket LGR 2x1000x4", models.two_stage_rocket, (1000, 4), N),
-         ("brachistochrone LGR 20x8", models.brachistochrone, (20, 8), 2 * N), ("humanoid LGR 5000x8", models.humanoid_wbc, (5000, 8), max(N // 20, 50))]
+         ("brachistochrone LGR 20x8", models.brachistochrone, (20, 8), 2 * N), ("humanoid LGR 5000x8", models.humanoid_wbc, (5000, 8), max(N // 20, 50)),
+         # (pass-parallel x-part and Hessian callback: the humanoid on a mesh that underfills the chip)
+         ("humanoid LGR 100x8", models.humanoid_wbc, (100, 8), N)]
 total_bad = 0
 for label, builder, args, iters in CASES:
     system, _, guess = builder(radau, *args)
