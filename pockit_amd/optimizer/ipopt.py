@@ -5,24 +5,32 @@
 Layouts.  IPOPT needs no particular triplet list, only that ``jacobianstructure()`` / ``hessianstructure()`` and the values
 agree (it sums repeated positions itself).  The reference hands it one Hessian triplet per nonzero of the integration matrix
 and derivative entry (phasebase.py:1280-1285: 4.3x more values than distinct positions at 12k nodes, 6.6x at 40k), and those
-values cross PCIe every iteration.  By default the solve therefore runs on the COMPACT layouts (one value per distinct
-position of a node) whenever the model has them: the same matrices, fewer bytes (+16 % cycles/s
-at 12k nodes, +70 % at 40k).  ``layout="reference"`` keeps the reference's triplet lists; the system's own layout settings
-are restored when the solve returns."""
+values cross PCIe every iteration.  By default (``layout="auto"``) the solve therefore runs on the COMPACT layouts (one value
+per distinct position of a node) whenever the model has them and the reference's Jacobian +
+Hessian values are at least ``AUTO_COMPACT_BYTES`` per iterate: the same matrices, fewer bytes (+16 % cycles/s at 12k nodes,
++70 % at 40k, x2 for a brachistochrone at 10k).  Below that size -- most of the reference's example programs -- an iterate
+costs what its launches cost, and the compact kernels' chain is 3-8 % longer than the reference layout's
+(tools/layout_crossover_probe.py, profiles/r04_zn_layout_crossover.txt): the reference layouts stay.  ``layout="compact"`` /
+``layout="reference"`` force one or the other; the system's own layout settings are restored when the solve returns."""
 from __future__ import annotations
 
 from ._common import postprocess, preprocess
 
 
-def solve(system, guess, optimizer_options=None, *, layout="compact"):
-    if layout not in ("compact", "reference"):
-        raise ValueError('layout must be "compact" or "reference"')
+AUTO_COMPACT_BYTES = 1 << 20      # measured crossover: 0.67 MB 1.03, 1.3 MB 0.98, 2.1 MB 0.93 (compact / reference iterate time)
+
+
+def solve(system, guess, optimizer_options=None, *, layout="auto"):
+    if layout not in ("auto", "compact", "reference"):
+        raise ValueError('layout must be "auto", "compact" or "reference"')
     try:
         import cyipopt
     except ImportError as exc:  # cyipopt / Ipopt are third-party and not part of this package
         raise ImportError("pockit_amd.optimizer.ipopt needs cyipopt (pip install cyipopt) and Ipopt") from exc
     x_0, guess_is_variable, optimizer_options = preprocess(system, guess, optimizer_options)
     keep = (system._hessian_layout, system._jacobian_layout)
+    if layout == "auto":
+        layout = "compact" if 8 * (system.plan.nnz_J + system.plan.nnz_H) >= AUTO_COMPACT_BYTES else "reference"
     if layout == "compact" and not system.plan.outer:      # (models nonlinear in the integrals keep the reference layout)
         system.set_hessian_layout("compact")
         system.set_jacobian_layout("compact")

@@ -1363,16 +1363,17 @@ def test_adaptive_solve_check_refine_loop_converges():
     assert errors[-1] <= 1e-6 * max(1.0, abs(optimum)) and errors[-1] < errors[0], errors
 
 
-@pytest.mark.parametrize("layout", ["compact", "reference"])
+@pytest.mark.parametrize("layout", ["compact", "reference", "auto small", "auto large"])
 def test_ipopt_adapter_protocol_with_a_stand_in_cyipopt(layout, monkeypatch):
     """cyipopt / Ipopt are not installed here, so the adapter is driven by a stand-in ``cyipopt.Problem`` that
     does what cyipopt does with a ``problem_obj`` (cyipopt's Problem.__init__/solve contract: structure queried
     once, every callback result copied into the solver's own arrays at once, callbacks in IPOPT's per-iteration
     order) and checks every value it receives against the oracle.  This covers the adapter's wiring and the
     evaluator's zero-copy mode (results handed out as views of pinned buffers that the next call reuses).
-    ``layout="compact"`` (the adapter's default): the solver is handed the compact structures; what it assembles from
-    them -- repeated positions summed, as IPOPT does -- must equal the oracle's scatter-added reference triplets.
-    ``layout="reference"``: structures and values are the reference's, entry by entry."""
+    ``layout="compact"``: the solver is handed the compact structures; what it assembles from them -- repeated positions
+    summed, as IPOPT does -- must equal the oracle's scatter-added reference triplets.  ``layout="reference"``: structures
+    and values are the reference's, entry by entry.  The default, ``"auto"``: the compact layouts from AUTO_COMPACT_BYTES of
+    reference J + H values per iterate on (here: with the threshold lowered), the reference's below."""
     import sys
     import types
 
@@ -1382,6 +1383,8 @@ def test_ipopt_adapter_protocol_with_a_stand_in_cyipopt(layout, monkeypatch):
     system, phases, guess = models.two_stage_rocket(ns, 12, 4)
     ref, _, _ = models.two_stage_rocket(_ns("radau", "oracle"), 12, 4)
     seen = {"iters": 0, "options": {}}
+    want_layout = {"auto small": "reference", "auto large": "compact"}.get(layout, layout)
+    layout, asked = want_layout, layout
     rjr, rjc = ref.jacobianstructure()
     rhr, rhc = ref.hessianstructure()
 
@@ -1442,10 +1445,14 @@ def test_ipopt_adapter_protocol_with_a_stand_in_cyipopt(layout, monkeypatch):
     monkeypatch.setitem(sys.modules, "cyipopt", fake)
     from pockit_amd.optimizer import ipopt
 
-    if layout == "compact":
-        solution, info = ipopt.solve(system, guess, {"tol": 1e-8, "print_level": 0})          # (the default)
+    if asked.startswith("auto"):
+        if asked == "auto large":
+            monkeypatch.setattr(ipopt, "AUTO_COMPACT_BYTES", 1)
+        else:
+            assert 8 * (system.plan.nnz_J + system.plan.nnz_H) < ipopt.AUTO_COMPACT_BYTES
+        solution, info = ipopt.solve(system, guess, {"tol": 1e-8, "print_level": 0})          # (the default: "auto")
     else:
-        solution, info = ipopt.solve(system, guess, {"tol": 1e-8, "print_level": 0}, layout="reference")
+        solution, info = ipopt.solve(system, guess, {"tol": 1e-8, "print_level": 0}, layout=layout)
     assert seen["iters"] == 4 and seen["options"] == {"tol": 1e-8, "print_level": 0} and info["status"] == 0
     assert len(solution) == len(phases) + 1 and all(len(v.data) == p.L for v, p in zip(solution, phases))
     assert len(solution[-1]) == system.n_s and system.evaluator.zero_copy is False

@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """GPU box: the five callbacks of example models at their OWN meshes through the host shim (NumPy in / out, a new x per cycle):
-us per callback.  Models: tests/golden/examples/*.model.json.  Usage: example_callbacks_probe.py [name ...]"""
+us per callback.  Models: tests/golden/examples/*.model.json.  Usage: example_callbacks_probe.py [--compact] [name ...]
+(--compact: the compact Jacobian / Hessian layouts, what the IPOPT adapter uses by default)"""
 import json
 import os
 import sys
@@ -12,12 +13,19 @@ import numpy as np  # noqa: E402
 
 import model_io  # noqa: E402
 
-names = sys.argv[1:] or ["orbit_transfer", "rocket_powered_descent", "drone_stabilization", "humanoid_whole_body_control",
+compact = "--compact" in sys.argv
+names = [a for a in sys.argv[1:] if not a.startswith("--")] or ["orbit_transfer", "rocket_powered_descent", "drone_stabilization", "humanoid_whole_body_control",
                          "neural_ode_xor", "planar_quadrotor", "brachistochrone"]
 for name in names:
     with open(os.path.join(ROOT, "tests", "golden", "examples", name + ".model.json")) as fh:
         system = model_io.load_system(json.load(fh))
     plan = system.plan
+    if compact:
+        try:
+            system.set_hessian_layout("compact")
+            system.set_jacobian_layout("compact")
+        except Exception as exc:  # noqa: BLE001 -- a model nonlinear in the integrals has no compact Hessian
+            print(f"{name}: {exc}")
     rng = np.random.default_rng(3)
     x0, lam = rng.uniform(0.6, 1.4, size=plan.n), rng.standard_normal(plan.m)
     calls = [("objective", lambda x: system.objective(x)), ("gradient", lambda x: system.gradient(x)),
