@@ -135,6 +135,7 @@ def main():
     ms, wall_ms = float(t[0].item()), float(t[1].item())
 
     # N > 1: BASELINE.json's sharded configs at their full size, STRONG-scaled over the N GPUs (every rank takes part)
+    # (they feed the line's fixed key multi_gpu.strong, so they run unless --no-extra asks for the headline alone)
     strong = strong_scaled_workloads(args, rank, world, dist) if (world > 1 and not args.no_extra) else {}
 
     if rank == 0:
@@ -153,7 +154,7 @@ def main():
         elif n_gpus > 1 and not args.no_extra:
             detail["other_workloads"] = strong
         short_parity = None if parity is None else {k: parity[k] for k in ("max_rel_err", "tol", "ok")}
-        line = L.short_line(args, res, e2e, n_gpus, intervals, ms, ROOT, cpu_baseline=cb, parity=short_parity)
+        line = L.short_line(args, res, e2e, n_gpus, intervals, ms, ROOT, cpu_baseline=cb, parity=short_parity, strong=strong)
         detail["line"] = line
         line["detail_file"] = write_detail(detail)
         sys.stdout.flush()

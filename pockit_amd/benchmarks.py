@@ -506,6 +506,34 @@ def humanoid_team(ns, mesh=10, num_point=4, copies=4, coupling=6.0):
     return system, [phase], [guess]
 
 
+def state_chain(ns, states=52, mesh=40, num_point=4, window=0):
+    """Synthetic WIDE model for the width scaling of the kernels (the reference loops per state with no limit,
+    phasebase.py:1083-1124, 1234-1285): ``states`` states x_0 ... x_(n-1) and one control u in one phase,
+    x_0' = -x_0 + u,  x_i' = -x_i + x_(i-1) x_((i+1) mod n), integral u^2 + x_0^2, fixed start, free end, fixed times.
+    ``window`` = W > 0: every dynamics function also carries 0.01 sin of the mean of the W states from its own on (cyclic) --
+    W more Jacobian entries and W (W + 1) / 2 Hessian pairs per state, every pair shared by up to W dynamics functions (the
+    compact Hessian then sums several contracted multipliers per entry).  Not a reference program."""
+    n = int(states)
+    system = ns.System(0)
+    phase = system.new_phase([f"x_{i}" for i in range(n)], ["u"])
+    x, (u,) = list(phase.x), phase.u
+    dyn = [-x[0] + u] + [-x[i] + x[i - 1] * x[(i + 1) % n] for i in range(1, n)]
+    if window:
+        dyn = [d + 0.01 * sp.sin(sum(x[(i + j) % n] for j in range(int(window))) / int(window)) for i, d in enumerate(dyn)]
+    phase.set_dynamics(dyn)
+    phase.set_integral([u**2 + x[0] ** 2])
+    phase.set_phase_constraint([u], [-3.0], [3.0])
+    phase.set_boundary_condition([0.5 + 0.4 * np.cos(0.7 * i) for i in range(n)], [None] * n, 0.0, 2.0)
+    phase.set_discretization(mesh, num_point)
+    system.set_phase([phase])
+    system.set_objective(phase.I[0])
+    guess = ns.linear_guess(phase, 0.0)
+    for i in range(n):
+        guess.x[i] = (0.5 + 0.4 * np.cos(0.7 * i)) * np.exp(-0.4 * guess.t_x) + 0.05 * np.sin(3.0 * guess.t_x + i)
+    guess.u[0] = 0.3 * np.cos(2.0 * guess.t_u)
+    return system, [phase], [guess]
+
+
 # --------------------------------------------------------------------------- semantic pins
 def derivative_model(ns, mesh=(0, 0.2, 1), num_point=(3, 4)):
     """Feature-dense model of the reference's FD derivative tests: 2 static params, FUNC state

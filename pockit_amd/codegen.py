@@ -115,6 +115,10 @@ def _emit_body(outputs, base, names, indent="    "):
     if os.path.exists(path):
         with open(path) as fh:
             _EMIT_MEMO[key] = fh.read()
+        try:
+            os.utime(path)                   # (tools/prune_cache.py drops the bodies nothing has asked for lately)
+        except OSError:
+            pass
         return _EMIT_MEMO[key]
     text = _emit_body_uncached(outs, needed, defs, finals, indent)
     _EMIT_MEMO[key] = text
@@ -145,6 +149,11 @@ def _emit_body_uncached(outs, needed, defs, finals, indent):
     for (lv, _), e in zip(outs, finals):
         lines.append(f"{indent}{lv} = {ccode(e)};")
     return "\n".join(lines)
+
+
+def ctable_(name, values):
+    vals = ", ".join(str(v) for v in values) or "0"
+    return f"  __host__ __device__ static constexpr int {name}(int g) {{ constexpr int t[] = {{{vals}}}; return t[g]; }}"
 
 
 def split_groups(n_i, n_n, cap):
@@ -183,9 +192,47 @@ def split_chunks(n, cap):
     return out
 
 
+def split_even(n, cap):
+    """Balanced runs of AT MOST ``cap`` items: [(lo, count)]."""
+    ng = max(1, -(-n // cap))
+    out, lo = [], 0
+    for g in range(ng):
+        cnt = n // ng + (1 if g < n % ng else 0)
+        out.append((lo, cnt))
+        lo += cnt
+    return out
+
+
+def mu_chunks(needs, cap, mu_cap, mu_max):
+    """Passes of a WIDE model's compact Hessian: consecutive runs of per-node outputs, each with at most ``cap`` outputs whose
+    expressions refer to at most ``mu_cap`` distinct contracted multipliers mu_i (``needs[e]`` = the states output e refers
+    to) -- a single output may refer to up to ``mu_max``.  Returns [(lo, count, [states])] or None when an output refers to
+    more than ``mu_max`` states (the compact layout is then not offered for the model)."""
+    out, lo, cur = [], 0, set()
+    for e, need in enumerate(needs):
+        if len(need) > mu_max:
+            return None
+        if e > lo and (e - lo >= cap or len(cur | need) > mu_cap):
+            out.append((lo, e - lo, sorted(cur)))
+            lo, cur = e, set()
+        cur = cur | need
+    if len(needs) > lo or not out:
+        out.append((lo, len(needs) - lo, sorted(cur)))
+    return out
+
+
 class ModelSource:
     """Generates the HIP source of one SystemPlan; exposes the compile-time counts the runtime
     tables must agree with."""
+
+    # A phase with more states than this is WIDE (= PK_WIDE_NX of pk_kernels.hip.h): nothing a wave keeps in LDS or in
+    # registers may then grow with the number of states -- the dynamics values and defect rows are produced in passes over
+    # chunks of at most WIDE_CHUNK states, the Hessian passes stage the multiplier rows of their own states only, the compact
+    # Hessian contracts the multipliers its pass refers to, and every pass fetches the node arguments it reads itself.
+    WIDE_NX = 16
+    WIDE_CHUNK = 16
+    MU_MAX = 64            # most states ONE entry of the compact Hessian may refer to (their multiplier rows are staged together)
+    LDS_LIMIT = 160 * 1024
 
     # most segments ONE pass of a tile wave evaluates, stages and streams (split_groups); POCKIT_AMD_GROUP_CAP overrides,
     # and the evaluator halves it for a model whose kernels would still spill registers (hipbuild.resource_usage)
@@ -204,7 +251,7 @@ class ModelSource:
         self.output_bytes = 8.0 * (1 + plan.n + plan.m + plan.nnz_J + plan.nnz_H) * float(output_share)
         # sharded: the finalize workgroup of pk_cycle carries the in-launch exchange of the partial sums between the GPUs.
         # Single-GPU code objects are compiled without it (its mere presence cost the 12k-node cycle 3 %).
-        self.sharded = bool(sharded) or os.environ.get("POCKIT_AMD_SHARDED", "0") == "1"
+        self.sharded = bool(sharded)
         self.nphase = len(plan.phase_plans)
         nI = len(plan.I_syms)
         # integrals evaluated by the pre-pass: those any system-level function references
@@ -222,6 +269,21 @@ class ModelSource:
         self.big = any(int(pp.layout.K.max()) > 64 for pp in plan.phase_plans)
         self.compact = not plan.outer
         self.compact_j = True
+        self.wide = [pp.nx > self.WIDE_NX for pp in plan.phase_plans]
+        self.dyn_chunks = [split_even(pp.nx, min(self.WIDE_CHUNK, self.group_cap)) if self.wide[k] else []
+                           for k, pp in enumerate(plan.phase_plans)]
+        self.hc_passes = {}
+        if self.compact:
+            for k, pp in enumerate(plan.phase_plans):
+                if not self.wide[k]:
+                    continue
+                mus = {mu_sym(i): i for i in range(pp.nx)}
+                needs = [{mus[sy] for sy in sp.sympify(sg.expr).free_symbols if sy in mus} for sg in plan.hessc.segs[k]]
+                passes = mu_chunks(needs, self.group_cap, self.group_cap, self.MU_MAX)
+                if passes is None:        # an entry that couples more than MU_MAX states: reference layout only
+                    self.compact = False
+                    break
+                self.hc_passes[k] = passes
         for cbname in ("jac", "hess", "aux") + (("hessc",) if self.compact else ()) + (("jacc",) if self.compact_j else ()):
             cb = getattr(plan, cbname)
             off, table = 0, {}
@@ -232,6 +294,32 @@ class ModelSource:
             self.list_off[cbname] = table
         self.source = self._generate()
         self.hash = hashlib.sha256(self.source.encode()).hexdigest()[:24]
+
+    def launch_lds_bytes(self):
+        """Dynamic LDS per workgroup of every tile kernel's launch, exactly as csrc/pk_runtime.cpp sizes it (launch_raw adds
+        the table blocks of the workgroup's four waves to what the entry point asks for): {kernel: bytes}.  What
+        evaluator.compile_plan holds against LDS_LIMIT, and pk_load_model checks again."""
+        w = 8 * 4
+        tab = w * (2 * self.tab_cap + 2 * 64 + self.tab_cap // 2)
+        ne = lambda cb: 8 * self.list_off[cb]["total"] if cb in self.list_off else 0  # noqa: E731
+        cyc = max(w * max(self.lds_x, self.lds_h), ne("jac"), ne("hess"))
+        out = {
+            "pk_g": w * self.lds_g + tab,
+            "pk_jac": max(w * self.lds_j, ne("jac")) + tab,
+            "pk_hess": max(w * self.lds_h, ne("hess")) + tab,
+            "pk_xall": max(w * self.lds_x, ne("jac")) + tab,
+            "pk_cycle": max(cyc, 8 * 1024 if self.sharded else 0) + tab,
+            "pk_jacc": max(w * self.lds_jc, ne("jacc")) + tab,
+        }
+        cycc = max(cyc, ne("jacc"))
+        if self.compact:
+            out["pk_hessc"] = max(w * self.lds_g, ne("hessc")) + tab
+            cycc = max(cycc, w * self.lds_g, ne("hessc"))
+        out["pk_cyclec"] = max(cycc, 8 * 1024 if self.sharded else 0) + tab
+        return out
+
+    def fits_lds(self):
+        return max(self.launch_lds_bytes().values()) <= self.LDS_LIMIT
 
     # ------------------------------------------------------------------ names
     def _phase_names(self, k):
@@ -278,6 +366,10 @@ class ModelSource:
         S.append(f"  static constexpr int NARG = {nx + nu + 1 + ns};")
         S.append(f"  static constexpr int SCHEME = {0 if lay.scheme == 'lgr' else 1};")
         S.append(f"  static constexpr int INDEX = {k};")
+        wide = self.wide[k]
+        dch = self.dyn_chunks[k]
+        S.append(f"  static constexpr bool WIDE = {'true' if wide else 'false'};")
+        S.append(f"  static constexpr int XROWS = {max(c[1] for c in dch) if wide else nx}, D_NG = {len(dch)};")
 
         # ---- boundary substitution (reference: phasebase.py:830-847) ----
         snm = _Names()
@@ -318,6 +410,32 @@ class ModelSource:
         S.append("  __device__ static __forceinline__ void mid_g(const double* __restrict__ a, double* __restrict__ o) {")
         S.append(_emit_body(outs, base, nm))
         S.append("  }")
+        if wide:
+            S.append(ctable_("D_c0", [c[0] for c in dch]))
+            S.append(ctable_("D_cn", [c[1] for c in dch]))
+            for gi, (lo, cnt) in enumerate(dch):
+                S.append(f"  __device__ static __forceinline__ void mid_dyn_g(pk::Grp<{gi}>, const double* __restrict__ a, "
+                         "double* __restrict__ o) {")
+                S.append(_emit_body([(f"o[{e}]", fr.F) for e, fr in enumerate(pp.dyn[lo:lo + cnt])], base, nm))
+                S.append("  }")
+            # the states / controls a chunk's dynamics read (the mesh error kernel interpolates only those: err_args)
+            argsym = {sym: i for i, sym in enumerate(p.x + p.u)}
+            used = []
+            for lo, cnt in dch:
+                fs = set()
+                for fr in pp.dyn[lo:lo + cnt]:
+                    fs |= sp.sympify(base.get(fr.F, fr.F)).free_symbols      # (fr.F: the placeholder of the function's value)
+                used.append(sorted(argsym[sy] for sy in fs if sy in argsym))
+            off = [0]
+            for lst in used:
+                off.append(off[-1] + len(lst))
+            S.append(ctable_("D_na", [len(lst) for lst in used]))
+            S.append(f"  __host__ __device__ static constexpr int D_ar(int g, int k) {{ constexpr int o[] = "
+                     f"{{{', '.join(str(v) for v in off)}}}; constexpr int t[] = {{{', '.join(str(i) for lst in used for i in lst) or '0'}}}; "
+                     f"return t[o[g] + k]; }}")
+            S.append("  __device__ static __forceinline__ void mid_path(const double* __restrict__ a, double* __restrict__ o) {")
+            S.append(_emit_body([(f"o[{j}]", fr.F) for j, fr in enumerate(pp.path)], base, nm))
+            S.append("  }")
         loc = self.int_local[k]
         outs = [(f"o[{r}]", pp.integ[plan.I_owner[a][1]].F) for r, a in enumerate(loc)]
         S.append(f"  static constexpr int INT_N = {len(loc)};")
@@ -326,9 +444,7 @@ class ModelSource:
         S.append("  }")
 
         # ---- Jacobian / Hessian segments ----
-        def ctable(name, values):
-            vals = ", ".join(str(v) for v in values) or "0"
-            return (f"  __host__ __device__ static constexpr int {name}(int g) {{ constexpr int t[] = {{{vals}}}; return t[g]; }}")
+        ctable = ctable_
 
         for cbname, tag in (("jac", "J"), ("hess", "H"), ("aux", "A")):
             cb = getattr(plan, cbname)
@@ -343,6 +459,17 @@ class ModelSource:
             S.append(f"  static constexpr int {tag}_NG = {len(groups)}, {tag}_GMAX = {max(g[1] for g in groups)};")
             for col, nm_ in enumerate(("gi0", "gni", "gn0", "gnn")):
                 S.append(ctable(f"{tag}_{nm_}", [g[col] for g in groups]))
+            if cbname == "hess":
+                # the states whose defect multipliers a pass reads: all of them, or -- a WIDE phase -- the range its segments
+                # belong to (the reference's order is state by state, phasebase.py:1234-1285, so a group's range is short)
+                rng = []
+                for i0, ni, _, _ in groups:
+                    st = [s_.state for s_ in isegs[i0:i0 + ni]]
+                    rng.append((min(st), max(st) - min(st) + 1) if (wide and st) else ((0, 0) if wide else (0, nx)))
+                self.h_rows = getattr(self, "h_rows", {})
+                self.h_rows[k] = max([0] + [r[1] for r in rng])
+                S.append(ctable("H_gs0", [r[0] for r in rng]))
+                S.append(ctable("H_gsn", [r[1] for r in rng]))
             if len(groups) == 1:
                 outs = [(f"o[{e}]", s.expr) for e, s in enumerate(isegs)]
                 outs += [(f"o[{len(isegs) + e}]", s.expr) for e, s in enumerate(nsegs)]
@@ -370,16 +497,37 @@ class ModelSource:
         # ---- compact Hessian: one value per distinct (row, col) class of a node ----
         sig_c = sig_node + (", const double* __restrict__ mu, const double* __restrict__ ltf, "
                             "const double* __restrict__ ltb")
+        self.hc_rows = getattr(self, "hc_rows", {})
+        self.hc_rows[k] = nx
         if self.compact:
             cb = plan.hessc
-            chunks = split_chunks(len(cb.segs[k]), self.group_cap)
+            if wide:
+                passes = self.hc_passes[k]
+                chunks = [(lo, cnt) for lo, cnt, _ in passes]
+                self.hc_rows[k] = max([1] + [len(lst) for _, _, lst in passes])
+                off = [0]
+                for _, _, lst in passes:
+                    off.append(off[-1] + len(lst))
+                flat = [i for _, _, lst in passes for i in lst]
+                S.append(ctable("HC_nmu", [len(lst) for _, _, lst in passes]))
+                S.append(f"  __host__ __device__ static constexpr int HC_mus(int g, int k) {{ constexpr int o[] = "
+                         f"{{{', '.join(str(v) for v in off)}}}; constexpr int t[] = {{{', '.join(str(v) for v in flat) or '0'}}}; "
+                         f"return t[o[g] + k]; }}")
+            else:
+                chunks = split_chunks(len(cb.segs[k]), self.group_cap)
             self.groups[("hessc", k)] = chunks
-            S.append(f"  static constexpr int HC_NN = {len(cb.segs[k])}, HC_NG = {len(chunks)};")
+            S.append(f"  static constexpr int HC_NN = {len(cb.segs[k])}, HC_NG = {len(chunks)}, HC_LROWS = {self.hc_rows[k]};")
             S.append(ctable("HC_c0", [c[0] for c in chunks]))
             S.append(ctable("HC_cn", [c[1] for c in chunks]))
             for gi, (lo, cnt) in enumerate(chunks):
+                nmg = nm
+                if wide:        # (row kk of the pass's staged multiplier rows and mu[kk] belong to state lst[kk])
+                    nmg = _Names()
+                    nmg.map = dict(nm.map)
+                    for kk, i in enumerate(self.hc_passes[k][gi][2]):
+                        nmg.add(mu_sym(i), f"mu[{kk}]")
                 S.append(f"  __device__ static __forceinline__ void mid_hessc_g(pk::Grp<{gi}>, {sig_c}, double* __restrict__ o) {{")
-                S.append(_emit_body([(f"o[{e}]", sg.expr) for e, sg in enumerate(cb.segs[k][lo:lo + cnt])], base, nm))
+                S.append(_emit_body([(f"o[{e}]", sg.expr) for e, sg in enumerate(cb.segs[k][lo:lo + cnt])], base, nmg))
                 S.append("  }")
             for w, wname in (("f", "front"), ("b", "back")):
                 exprs = cb.lists.get((w, k), [])
@@ -387,7 +535,9 @@ class ModelSource:
                 S.append(_emit_body([(f"E[{e}]", ex) for e, ex in enumerate(exprs)], base, nm))
                 S.append("  }")
         else:
-            S.append("  static constexpr int HC_NN = 0, HC_NG = 1;")
+            S.append(f"  static constexpr int HC_NN = 0, HC_NG = 1, HC_LROWS = {nx};")
+            S.append(ctable("HC_nmu", [0]))
+            S.append("  __host__ __device__ static constexpr int HC_mus(int, int) { return 0; }")
             S.append(ctable("HC_c0", [0]))
             S.append(ctable("HC_cn", [0]))
             S.append(f"  __device__ static __forceinline__ void mid_hessc_g(pk::Grp<0>, {sig_c}, double* __restrict__ o) {{}}")
@@ -473,7 +623,7 @@ class ModelSource:
         outs += [(f"ov[{a}]", e) for a, e in enumerate(plan.grad_var[k]["m"])]
         outs += [(f"ot[{r}]", plan.grad_red[k]["m"].get(sl, sp.Integer(0))) for r, sl in enumerate(slots)]
         outs += [(f"op[{r}]", pp.integ[plan.I_owner[a][1]].F) for r, a in enumerate(loc)]
-        if len(self.groups[("jac", k)]) == 1:
+        if len(self.groups[("jac", k)]) == 1 and not wide:
             S.append("  __device__ static __forceinline__ void mid_xall(const double* __restrict__ a, double pk_tau, "
                      "double pk_dt, double pk_w, const PkSys& sy, double* __restrict__ og, double* __restrict__ oj, "
                      "double* __restrict__ ov, double* __restrict__ ot, double* __restrict__ op) {")
@@ -485,8 +635,9 @@ class ModelSource:
             # segments group by group with mid_jac_g, as pk_jac does
             # (the dynamics values go straight into the staging rows -- ogl[i * ogs] is row i at this lane / node, ogs the row
             #  length --, so that a wide model does not carry n_x more register pairs to the end of the function)
+            # (a WIDE phase: no dynamics values here at all -- mid_dyn_g, chunk of states by chunk of states)
             vouts = [((f"ogl[{int(lv[3:-1])} * ogs]" if (lv.startswith("og[") and int(lv[3:-1]) < nx) else lv), e)
-                     for lv, e in outs if not lv.startswith("oj[")]
+                     for lv, e in outs if not lv.startswith("oj[") and not (wide and lv.startswith("og[") and int(lv[3:-1]) < nx)]
             S.append("  __device__ static __forceinline__ void mid_xval(const double* __restrict__ a, double pk_tau, "
                      "double pk_dt, double pk_w, const PkSys& sy, double* __restrict__ ogl, int ogs, double* __restrict__ og, "
                      "double* __restrict__ ov, double* __restrict__ ot, double* __restrict__ op) {")
@@ -546,18 +697,8 @@ class ModelSource:
         S.append(f"#define PK_TAB_CAP {self.tab_cap}")
         if os.environ.get("POCKIT_AMD_TRACE", "0") == "1":   # developer tracing of the wave timeline (tools/wave_trace.py)
             S.append("#define PK_TRACE 1")
-        if os.environ.get("POCKIT_AMD_XCD_REMAP", "1") == "0":       # A/B switch of the XCD-aware block mapping
-            S.append("#define PK_XCD_REMAP 0")
-        if os.environ.get("POCKIT_AMD_POLL_SLEEP"):                  # A/B switch: pause between the finalize workgroup's polls
-            S.append(f"#define PK_POLL_SLEEP {int(os.environ['POCKIT_AMD_POLL_SLEEP'])}")
-        if os.environ.get("POCKIT_AMD_BIG_MFMA", "0") == "1":        # A/B switch: big intervals' products on the fp64 matrix cores
-            S.append("#define PK_BIG_MFMA 1")
-        if os.environ.get("POCKIT_AMD_WIDE_STORES", "1") == "0":     # A/B switch: 8-byte stores in the streaming loop
-            S.append("#define PK_WIDE_STORES 0")
-        if os.environ.get("POCKIT_AMD_KA_LAZY", "1") == "0":         # A/B: pk_cycle's PkArgs loaded en bloc on entry
-            S.append("#define PK_KA_LAZY 0")
-        if os.environ.get("POCKIT_AMD_STATIC_TABS", "0") == "1":     # A/B: table blocks in static LDS
-            S.append("#define PK_STATIC_TABS 1")
+        if os.environ.get("POCKIT_AMD_BIG_MFMA", "0") == "1":        # option: big intervals' products on the fp64 matrix cores
+            S.append("#define PK_BIG_MFMA 1")                        # (measured slower than the VALU form, kept under test)
         if self.big:
             S.append("#define PK_BIG 1")
         if self.sharded:
@@ -566,16 +707,10 @@ class ModelSource:
         # inside the Infinity Cache agent-scope write-through ("sc1": +20 % over plain stores, nontemporal -15 ... -30 %);
         # beyond it -- quadrotor from 262 MB = 300k nodes on -- the nontemporal form, which does not leave 300+ MB of lines
         # for the MALL to evict one by one: 93 -> 50 us at 262 MB, 120 -> 58 us at 314 MB (0.47 -> 0.97 of the roof); the
-        # humanoid crosses over later (315 MB: 69 vs 87 us, 451 MB: 146 vs 117 us).  POCKIT_AMD_STREAM overrides (A/B).
-        stream = {"sc1": "sc1", "sc1nt": "sc1 nt", "nt": "nt", "plain": "", "sc0sc1": "sc0 sc1", "sc0sc1nt": "sc0 sc1 nt"}.get(
-            os.environ.get("POCKIT_AMD_STREAM", ""))
-        if stream is None and self.output_bytes > self.MALL_BYTES:
-            stream = "nt"
-        self.stream_policy = "sc1" if stream is None else (stream or "plain")
-        if stream is not None:
-            S.append(f'#define PK_STREAM_FLAGS "{stream}"')
-        if os.environ.get("POCKIT_AMD_NT", "") in ("0", "1", "2", "3", "4"):   # A/B switch of the output store flavour
-            S.append(f"#define PK_NT_STORES {os.environ['POCKIT_AMD_NT']}")
+        # humanoid crosses over later (315 MB: 69 vs 87 us, 451 MB: 146 vs 117 us).
+        self.stream_policy = "nt" if self.output_bytes > self.MALL_BYTES else "sc1"
+        if self.stream_policy != "sc1":
+            S.append(f'#define PK_STREAM_FLAGS "{self.stream_policy}"')
         S.append('#include "pk_kernels.hip.h"')
         S.append("namespace pkgen {")
         for k in range(nP):
@@ -595,21 +730,26 @@ class ModelSource:
             out.append(f"{indent}  default: break;\n{indent}}}")
             return "\n".join(out)
 
-        self.grouped = any(len(v) > 1 for v in self.groups.values())
+        self.grouped = any(len(v) > 1 for v in self.groups.values()) or any(len(c) > 1 for c in self.dyn_chunks)
         S.append("struct Gen {")
         # LDS doubles per wave for the staged per-node values
         # (pk_g: the dynamics values [nx][64]; pk_hessc: the multiplier rows [nx][64] + the base offsets of its output runs)
         n_hc = (lambda k: len(plan.hessc.segs[k])) if self.compact else (lambda k: 0)
-        self.lds_g = 64 * max([1] + [pp.nx + -(-n_hc(k) // 64) for k, pp in enumerate(plan.phase_plans)])
+        # (a WIDE phase: rows of ONE chunk of states / of the multipliers one pass refers to, not of all states)
+        xrows = lambda k: max(c[1] for c in self.dyn_chunks[k]) if self.wide[k] else plan.phase_plans[k].nx  # noqa: E731
+        self.lds_g = 64 * max([1] + [max(xrows(k) if self.wide[k] else 0, self.hc_rows[k] + -(-n_hc(k) // 64))
+                                     for k, pp in enumerate(plan.phase_plans)])
         # (rows of 64 doubles per wave; a role evaluated in groups stages one group at a time: its largest group counts)
         gmax = lambda cb, k: max(g[1] for g in self.groups[(cb, k)])  # noqa: E731
         self.lds_j = 64 * max([1] + [gmax("jac", k) for k in range(nP)])
         # Hessian: staged segment values + the tile's defect multipliers [state][row]
-        self.lds_h = 64 * max([1] + [pp.nx + gmax("hess", k) for k, pp in enumerate(plan.phase_plans)])
-        self.lds_x = 64 * max([1] + [pp.nx * (2 if self.big else 1) + gmax("jac", k)
-                                     for k, pp in enumerate(plan.phase_plans)])      # (big: + the node values [NX][256])
+        self.lds_h = 64 * max([1] + [self.h_rows[k] + gmax("hess", k) for k, pp in enumerate(plan.phase_plans)])
+        # (big: + the node values [NX][256] -- a workgroup-wide interval keeps rows of every state)
+        self.lds_x = 64 * max([1] + [(pp.nx * 2 + gmax("jac", k)) if self.big else (xrows(k) + gmax("jac", k))
+                                     for k, pp in enumerate(plan.phase_plans)])
         # (mesh error estimation: [x | u | f] rows per wave; a workgroup-wide interval adds the interpolated [x | u] rows)
-        self.lds_e = 64 * max([1] + [3 * pp.nx + 2 * pp.nu for pp in plan.phase_plans])
+        # (a WIDE phase: the dynamics values of one chunk of states -- its arguments come straight from x, pass by pass)
+        self.lds_e = 64 * max([1] + [xrows(k) if self.wide[k] else 3 * pp.nx + 2 * pp.nu for k, pp in enumerate(plan.phase_plans)])
         self.lds_jc = 64 * max([1] + [(sum(1 for sg in plan.jacc.segs[k] if sg.kind in "ID") if self.groups[("jacc", k)][0][0] < 0 else
                                        max([1] + [c for kd, _, c in self.groups[("jacc", k)] if kd < 2])) for k in range(nP)]) if self.compact_j else 64
         # (a cycle launch that serves the compact Jacobian runs tile_jacc in the x-part's LDS rows)
@@ -626,7 +766,9 @@ class ModelSource:
         S.append("  }")
         targets = [(n, f"pk::tile_{n}<{{P}}>") for n in ("int", "g", "grad", "jac", "hess", "aux", "hessc", "jacc")]
         targets += [("xall", "pk::tile_xall<{P}, 0>"), ("xall1", "pk::tile_xall<{P}, 1>"),
-                    ("xall2", "pk::tile_xall<{P}, 2>"), ("xall1c", "pk::tile_xall<{P}, 1, true>")]
+                    ("xall2", "pk::tile_xall<{P}, 2>"), ("xall1c", "pk::tile_xall<{P}, 1, true>"),
+                    # (values role of a pass-parallel cycle: a WIDE phase's dynamics passes are waves of their own)
+                    ("xall1p", "pk::tile_xall<{P}, 1, false, true>"), ("xall1cp", "pk::tile_xall<{P}, 1, true, true>")]
         for name, target in targets:
             pub = name.startswith("xall")      # the x-kernels take the hand-off block of a pk_cycle launch (-1: none)
             S.append(f"  __device__ static __forceinline__ void tile_{name}(int phase, const PkArgs& A, const PkTile& tl, "
@@ -637,7 +779,9 @@ class ModelSource:
         # pk_cycle of a model evaluated in groups gives every pass of the Jacobian / Hessian role a wave of its own
         self.j_ngmax = max([1] + [len(self.groups[("jac", k)]) for k in range(nP)])
         self.h_ngmax = max([1] + [len(self.groups[("hess", k)]) for k in range(nP)])
-        self.cycle_subs = (1 + self.j_ngmax + self.h_ngmax) if (self.j_ngmax > 1 or self.h_ngmax > 1) else 0
+        self.d_ngmax = max([0] + [len(c) for c in self.dyn_chunks])      # (passes over chunks of states: WIDE phases only)
+        self.cycle_subs = (1 + self.j_ngmax + self.d_ngmax + self.h_ngmax) \
+            if (self.j_ngmax > 1 or self.h_ngmax > 1 or self.d_ngmax > 1) else 0
         # Pass-parallel roles pay when several workgroups of the launch fit a CU: every workgroup of pk_cycle gets the launch's
         # LDS size (the largest role's rows + the table blocks).  Measured at 2000 x 4 (tools/fat_model_probe.py): orbit_transfer
         # (23 rows = 56 KB, 23 workgroups per tile block) 40 -> 22 us per cycle; drone_stabilization (47 rows = 105 KB: one
@@ -648,8 +792,17 @@ class ModelSource:
         if want == "0" or (want != "1" and 2 * wg_bytes > 160 * 1024):
             self.cycle_subs = 0
         S.append(f"  static constexpr bool GROUPED = {'true' if self.cycle_subs else 'false'};")
-        S.append(f"  static constexpr int J_NGMAX = {self.j_ngmax}, H_NGMAX = {self.h_ngmax};")
-        for name, fn in (("jacg", "tile_jac_pick"), ("hessg", "tile_hess_pick")):
+        S.append(f"  static constexpr int J_NGMAX = {self.j_ngmax}, H_NGMAX = {self.h_ngmax}, D_NGMAX = {self.d_ngmax};")
+        # (the compact roles of a pass-parallel launch share their passes round robin: workgroup `sub` of `stride`)
+        self.hc_ngmax = max([1] + [len(self.groups[("hessc", k)]) for k in range(nP)]) if self.compact else 1
+        self.jc_ngmax = max([1] + [len(self.groups[("jacc", k)]) for k in range(nP)]) if self.compact_j else 1
+        S.append(f"  static constexpr int HC_NGMAX = {self.hc_ngmax}, JC_NGMAX = {self.jc_ngmax};")
+        for name, fn in (("hesscp", "tile_hessc_part"), ("jaccp", "tile_jacc_part")):
+            S.append(f"  __device__ static __forceinline__ void tile_{name}(int phase, int sub, int stride, const PkArgs& A, "
+                     f"const PkTile& tl, double* __restrict__ lds, int lane) {{")
+            S.append(switch(f"pk::{fn}<{{P}}>(sub, stride, A, tl, lds, lane)"))
+            S.append("  }")
+        for name, fn in (("jacg", "tile_jac_pick"), ("hessg", "tile_hess_pick"), ("dyn", "tile_dyn_pick")):
             S.append(f"  __device__ static __forceinline__ void tile_{name}(int phase, int grp, const PkArgs& A, const PkTile& tl, "
                      f"double* __restrict__ lds, int lane) {{")
             S.append(switch(f"pk::{fn}<{{P}}>(grp, A, tl, lds, lane)"))
@@ -753,6 +906,9 @@ class ModelSource:
         # rows of pk_cycle's in-launch finalize: the needed integrands, then the shared gradient slots phase by phase
         rows = [(0, k, r) for _, k, r in ints]
         rows += [(1, k, r) for k, v in enumerate(plan.grad_red_slots) for r in range(len(v))]
+        if len(rows) > 256:
+            raise ValueError(f"{len(rows)} sums over all nodes (integrals any system function refers to + gradient slots shared by "
+                             "the nodes of a phase): the MI355X evaluator's finalize workgroup takes at most 256 (one thread per sum)")
         S.append(f"  static constexpr int N_ROWS = {len(rows)};")
         S.append(table_fn("row_arr", [a for a, _, _ in rows]))
         S.append(table_fn("row_phase", [k for _, k, _ in rows]))

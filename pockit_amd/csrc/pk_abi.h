@@ -5,9 +5,7 @@
 #include <stdint.h>
 
 #define PK_WAVE 64
-#ifndef PK_WAVES_PER_BLOCK     // (experiments: POCKIT_AMD_WPB builds library and code objects with another value)
-#define PK_WAVES_PER_BLOCK 4
-#endif
+#define PK_WAVES_PER_BLOCK 4     // (1, 2 and 8 were measured slower: profiles/r04_z_waves_per_workgroup.txt)
 #define PK_BLOCK (PK_WAVE * PK_WAVES_PER_BLOCK)
 
 // One phase of the problem on its mesh.

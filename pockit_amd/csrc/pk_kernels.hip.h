@@ -136,12 +136,8 @@ __device__ __forceinline__ void wave_lds_sync() {
 // tests/test_base/test_system_base.py:10-20 of the reference) still needs a non-empty array type
 #define PK_NPHASE_DIM (PK_NPHASE > 0 ? PK_NPHASE : 1)
 #define PK_XCDS 8
-#ifndef PK_XCD_REMAP
-#define PK_XCD_REMAP 1
-#endif
 __device__ __forceinline__ int xcd_ids_below(int n, int y) { return (n + PK_XCDS - 1 - y) / PK_XCDS; }   // ids < n on XCD y
 __device__ __forceinline__ int xcd_tile_block(int wg, int first, int total) {
-  if (PK_XCD_REMAP == 0) return wg - first;
   const int x = wg % PK_XCDS;
   int start = 0;
 #pragma unroll
@@ -161,9 +157,6 @@ __device__ __forceinline__ int xcd_tile_block(int wg, int first, int total) {
 #else
 #define PK_DIAG(bits) false
 #endif
-#ifndef PK_KA_LAZY      // A/B switch (POCKIT_AMD_KA_LAZY=0): pk_cycle's PkArgs as an ordinary by-value kernel argument
-#define PK_KA_LAZY 1
-#endif
 #ifdef PK_TRACE
 #define PK_TRACE_REC(role) const int pk_trec = tl.pad >= 0 ? tl.pad * 3 + (role) : -1
 #define PK_MARK_AT(rec, k)                                                                                   \
@@ -182,36 +175,20 @@ __device__ __forceinline__ int xcd_tile_block(int wg, int first, int total) {
 #define PK_MARK(k) do { } while (0)
 #endif
 
-// All output stores go through put().  Default: agent-scope stores (`sc1`, written through the XCD's L2).  With plain
-// stores the 10-140 MB a launch writes stay dirty in the L2s until the end-of-kernel release writes them back -- after
-// the last wave, with nothing to overlap: write-through spreads that over the kernel's life (MI355X, pk_cycle:
-// quadrotor 2000x6 134k -> 161k cycles/s, brachistochrone 1250x8 135k -> 154k, humanoid 5000x8 38.5k -> 39.6k; system
-// scope `sc0 sc1` measures the same).  Streaming (`nt`) stores are SLOWER than plain ones (humanoid 38.5k -> 22.5k):
-// they lose the L2's merging of the partial lines neighbouring tiles share.  POCKIT_AMD_NT=0|1|2|3 at
-// code-generation time compiles the plain / nt / agent / system variant for A/B measurements (tools/nt_sweep.sh).
-#ifndef PK_NT_STORES
-#define PK_NT_STORES 2
-#endif
-// cache-policy bits of the 16-byte streaming stores (A/B: POCKIT_AMD_STREAM=sc1|sc1nt|nt|plain at code generation)
+// All output stores go through put(): agent-scope stores (`sc1`, written through the XCD's L2).  With plain stores the
+// 10-140 MB a launch writes stay dirty in the L2s until the end-of-kernel release writes them back -- after the last wave,
+// with nothing to overlap: write-through spreads that over the kernel's life (MI355X, pk_cycle: quadrotor 2000x6 134k -> 161k
+// cycles/s, brachistochrone 1250x8 135k -> 154k, humanoid 5000x8 38.5k -> 39.6k; system scope `sc0 sc1` measures the same;
+// nontemporal stores are SLOWER than plain ones inside the Infinity Cache -- they lose the L2's merging of the partial lines
+// neighbouring tiles share; profiles/DESIGN_history_r01_r03.md section 5).
+// cache-policy bits of the 16-byte streaming stores: "sc1", or -- code objects whose launch writes more than the Infinity
+// Cache holds -- "nt" (codegen.py chooses by the size of the mesh)
 #ifndef PK_STREAM_FLAGS
 #define PK_STREAM_FLAGS "sc1"
 #endif
-#ifndef PK_WIDE_STORES
-#define PK_WIDE_STORES 1      // streaming loop: two consecutive positions per lane, one 16-byte store per segment
-#endif
 
 __device__ __forceinline__ void put(double* __restrict__ p, double v) {
-#if PK_NT_STORES == 1
-  __builtin_nontemporal_store(v, p);
-#elif PK_NT_STORES == 2      // agent-scope store (sc1): written through the XCD's L2
   __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-#elif PK_NT_STORES == 3      // system-scope store (sc0 sc1)
-  __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-#elif PK_NT_STORES == 4      // the same sc1 store instruction, but not an atomic to the compiler (no ordering of other memory ops)
-  asm volatile("global_store_dwordx2 %0, %1, off sc1" : : "v"(p), "v"(v));
-#else
-  *p = v;
-#endif
 }
 
 // Sum over the 64 lanes of a wave, returned in every lane.  Data-parallel-primitive (DPP) moves keep the
@@ -314,9 +291,7 @@ __device__ __forceinline__ void mfma_rows(const double* __restrict__ Amat, int l
 // DESIGN.md section 5 measured at +6 us).  Forward progress: the publishers never wait for anything, the poller
 // occupies one workgroup slot; the poll is bounded (PK_POLL_LIMIT), after which the slot reads as NaN, the launch ends with
 // NaN in f / the gradient slots instead of hanging AND counts the event in PkArgs.status: the library turns it into an error.
-#ifndef PK_POLL_SLEEP
 #define PK_POLL_SLEEP 4       // s_sleep between two poll rounds (x 64 cycles)
-#endif
 #define PK_POLL_LIMIT (1 << 24)     // poll rounds of >= 0.5 us each: several seconds, far beyond any launch's duration
 __device__ __forceinline__ void handoff_put(unsigned long long* slot, double v) {
   unsigned long long b = (unsigned long long)__double_as_longlong(v);
@@ -434,11 +409,7 @@ struct TileTabs {
 // doubles of one wave's table block in dynamic LDS
 #define PK_TAB_WIDTH (2 * PK_TAB_CAP + 2 * PK_WAVE + PK_TAB_CAP / 2)
 // start of the per-wave model staging area: behind the table blocks of the workgroup's waves
-#ifdef PK_STATIC_TABS      // A/B: the table blocks as static LDS arrays (the round-1 layout), staging at the start of dynamic LDS
-#define PK_STAGE(A) (pk_lds)
-#else
 #define PK_STAGE(A) (pk_lds + PK_WAVES_PER_BLOCK * PK_TAB_WIDTH)
-#endif
 
 __device__ __forceinline__ bool tabs_fit(const PkArgs& A, const PkTile& tl, const TileGeom& g) {
   return tl.nnzI <= PK_TAB_CAP && g.R * g.K <= PK_TAB_CAP && tl.nnzT <= PK_WAVE && !PK_DIAG(4096);
@@ -477,12 +448,7 @@ __device__ __forceinline__ TileTabs tabs_commit(const PkArgs& A, const PkTile& t
   extern __shared__ double pk_lds[];
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   constexpr int cap = PK_TAB_CAP;
-#ifdef PK_STATIC_TABS
-  __shared__ double pk_tab_static[PK_WAVES_PER_BLOCK * PK_TAB_WIDTH];
-  double* __restrict__ iv = pk_tab_static + wave * PK_TAB_WIDTH;
-#else
   double* __restrict__ iv = pk_lds + wave * PK_TAB_WIDTH;
-#endif
   double* __restrict__ full = iv + cap;
   double* __restrict__ tv = full + cap;
   double* __restrict__ wd = tv + PK_WAVE;
@@ -600,13 +566,12 @@ __device__ __forceinline__ void write_defects(const PkArgs& A, const PkPhase& ph
   }
 }
 
-// ---- the same for a WIDE model (more than PK_WIDE_NX states): the rows are walked in chunks of PK_WIDE_CHUNK states, each
-// chunk fetching its end-slot values (wave shuffles of the node values `a`, the tile's last LGR interval from memory) and
-// keeping its row sums in PK_WIDE_CHUNK register pairs -- 40 states held 3 x 40 pairs (node values, end slots, sums) through
-// the whole phase before.  Same products, same order per row.
+// ---- the same for one CHUNK of the states of a WIDE model (more than PK_WIDE_NX states; see dyn_pass): the chunk fetches its
+// end-slot values (wave shuffles of the node values `a`, the tile's last LGR interval from memory) and keeps its row sums
+// in CN register pairs.  Same products, same order per row.
 #define PK_WIDE_NX 16
-#define PK_WIDE_CHUNK 8
-template <class P, bool STAGED, int I0, int CN>
+// ROW0: row of state I0 in the staged rows `fsv` (I0 when all states are staged; 0 when the rows hold this chunk only)
+template <class P, bool STAGED, int I0, int CN, int ROW0 = I0>
 __device__ __forceinline__ void defect_chunk(const PkArgs& A, const PkPhase& ph, const PkTile& tl, const TileGeom& g,
                                              const TileTabs& T, const double* s, double dt, const double* __restrict__ fsv,
                                              const double* a, int lane) {
@@ -634,7 +599,7 @@ __device__ __forceinline__ void defect_chunk(const PkArgs& A, const PkPhase& ph,
   for (int c = 0; c < g.K; ++c) {
     const double wc = full[c] * width * 0.5;      // (I_hat * d) / 2 as the reference scales it
 #pragma unroll
-    for (int e = 0; e < CN; ++e) acc[e] += wc * f[(I0 + e) * PK_WAVE + c];
+    for (int e = 0; e < CN; ++e) acc[e] += wc * f[(ROW0 + e) * PK_WAVE + c];
   }
 #pragma unroll
   for (int e = 0; e < CN; ++e) {
@@ -642,21 +607,42 @@ __device__ __forceinline__ void defect_chunk(const PkArgs& A, const PkPhase& ph,
     put(&A.o_g[ph.g_off + (I0 + e) * ph.L_d + tl.r0 + lane], (a[I0 + e] - xe[e]) - acc[e] * dt);
   }
 }
-template <class P, bool STAGED, int I0 = 0>
-__device__ __forceinline__ void write_defects_wide(const PkArgs& A, const PkPhase& ph, const PkTile& tl, const TileGeom& g,
-                                                   const TileTabs& T, const double* s, double dt,
-                                                   const double* __restrict__ fsv, const double* a, int lane) {
+// constant translation entries of every state (phasebase.py:1077)
+// a WIDE model walks its states in chunks of PK_TRANS_CHUNK: one run pointer (an SGPR pair) per state of the chunk instead of
+// one per state of the model (128 states asked for 256 SGPRs)
+#define PK_TRANS_CHUNK 16
+template <class P, bool STAGED, int I0>
+__device__ __forceinline__ void write_translation_wide(const PkArgs& A, const PkTile& tl, const TileTabs& T,
+                                                       const SegBases<P::NX>& tbase, int lane) {
   if constexpr (I0 < P::NX) {
-    constexpr int CN = P::NX - I0 < PK_WIDE_CHUNK ? P::NX - I0 : PK_WIDE_CHUNK;
-    defect_chunk<P, STAGED, I0, CN>(A, ph, tl, g, T, s, dt, fsv, a, lane);
-    write_defects_wide<P, STAGED, I0 + PK_WIDE_CHUNK>(A, ph, tl, g, T, s, dt, fsv, a, lane);
+    constexpr int CN = P::NX - I0 < PK_TRANS_CHUNK ? P::NX - I0 : PK_TRANS_CHUNK;
+    const int tot = tl.nj * tl.nnzT;
+    const double* __restrict__ tvg = A.db + tl.tv_off;
+    double* __restrict__ run[CN];
+    if constexpr (P::NX > PK_WAVE) {
+      // (more states than a wave has lanes: the bases come through the scalar cache; the chunk's pointer is made opaque so
+      //  that the scalar loads of ALL chunks are not hoisted to the top of the wave -- 128 states: 256 SGPRs, spilled)
+      pk_cbase_t tb = tbase.mem + I0;
+      asm volatile("" : "+s"(tb));
+#pragma unroll
+      for (int i = 0; i < CN; ++i) run[i] = A.o_jac + (tb[i] + tl.offT);
+    } else {
+#pragma unroll
+      for (int i = 0; i < CN; ++i) run[i] = A.o_jac + (tbase[I0 + i] + tl.offT);
+    }
+    for (uint32_t p = lane; p < (uint32_t)tot; p += PK_WAVE) {
+      const int t = (int)p - magic_div(p, tl.magicT) * tl.nnzT;
+      const double v = STAGED ? T.tv[t] : tvg[t];
+#pragma unroll
+      for (int i = 0; i < CN; ++i) put(&run[i][p], v);
+    }
+    write_translation_wide<P, STAGED, I0 + PK_TRANS_CHUNK>(A, tl, T, tbase, lane);
   }
 }
-
-// constant translation entries of every state (phasebase.py:1077)
 template <class P, bool STAGED>
 __device__ __forceinline__ void write_translation(const PkArgs& A, const PkPhase& ph, const PkTile& tl,
                                                   const TileTabs& T, const SegBases<P::NX>& tbase, int lane) {
+  if constexpr (P::NX > PK_WIDE_NX) return write_translation_wide<P, STAGED, 0>(A, tl, T, tbase, lane);
   const int tot = tl.nj * tl.nnzT;
   const double* __restrict__ tvg = A.db + tl.tv_off;
   // wave-uniform run starts (SGPR pairs) + ONE 32-bit lane offset shared by all states: the stores take the
@@ -676,7 +662,8 @@ __device__ __forceinline__ void write_translation(const PkArgs& A, const PkPhase
 // (phasebase.py:1120-1124 and 1280-1285 -- the gather-multiply-concatenate that dominates the reference)
 // lam_s: the tile's multiplier rows staged in LDS as lam_s[state * 64 + row]   (Hessian only)
 // E0: index of the group's first segment among the role's I-expanded segments (0: the role is one group)
-template <class P, int NI, bool HESS, bool STAGED, int E0, class Bases>
+// S0: the state whose multiplier row is row 0 of lam_s (a wide model stages the rows of the group's states only)
+template <class P, int NI, bool HESS, bool STAGED, int E0, int S0, class Bases>
 __device__ __forceinline__ void stream_loop(const PkArgs& A, const PkPhase& ph, const PkTile& tl, const TileGeom& g,
                                             const TileTabs& T, const double* __restrict__ sv,
                                             const double* __restrict__ lam_s, const Bases& bases,
@@ -688,11 +675,10 @@ __device__ __forceinline__ void stream_loop(const PkArgs& A, const PkPhase& ph, 
   for (int e = 0; e < NI; ++e) run[e] = out + (bases[E0 + e] + tl.offI);
   const int nnz = tl.nnzI;
   const int tot = tl.nj * nnz;
-#if PK_WIDE_STORES
   if (STAGED) {
     // A lane takes two CONSECUTIVE positions and writes them with one 16-byte store per segment (the same sc1
     // flavour as put()): half the store instructions of the 8-byte variant below -- humanoid 5000x8 +2.3 %,
-    // brachistochrone 1250x8 +3 %, quadrotor 2000x6 +0..8 % (POCKIT_AMD_WIDE_STORES=0 compiles the variant below).
+    // brachistochrone 1250x8 +3 %, quadrotor 2000x6 +0..8 % against 8-byte stores.
     // All LDS reads of the pair come before its first store (stores are ordered against every other memory operation).
     typedef double pk_d2 __attribute__((ext_vector_type(2)));
     for (uint32_t p0 = 2 * lane; p0 < (uint32_t)tot; p0 += 2 * PK_WAVE) {
@@ -709,7 +695,7 @@ __device__ __forceinline__ void stream_loop(const PkArgs& A, const PkPhase& ph, 
         const double* __restrict__ lam = lam_s + jj * g.R + (rc & 0xFFFF);
 #pragma unroll
         for (int e = 0; e < NI; ++e)
-          v[u][e] = HESS ? val * lam[P::H_state(E0 + e) * PK_WAVE] * col[e * PK_WAVE] : val * col[e * PK_WAVE];
+          v[u][e] = HESS ? val * lam[(P::H_state(E0 + e) - S0) * PK_WAVE] * col[e * PK_WAVE] : val * col[e * PK_WAVE];
       }
 #pragma unroll
       for (int e = 0; e < NI; ++e) {
@@ -729,51 +715,6 @@ __device__ __forceinline__ void stream_loop(const PkArgs& A, const PkPhase& ph, 
     }
     return;
   }
-#endif
-  if (STAGED) {
-    // Two positions per lane and loop iteration, and ALL LDS reads of the pair before its first store: the output
-    // stores are agent-scope atomics (put), which the compiler keeps every other memory operation behind -- written
-    // store by store, each ds_read waited for its predecessor's store (8 exposed LDS latencies per iteration in the
-    // ISA).  (Segment-major order -- each segment's stores of 256 positions back to back -- was measured slower.)
-    constexpr int U = NI <= 12 ? 2 : 1;
-    for (uint32_t p0 = lane; p0 < (uint32_t)tot; p0 += U * PK_WAVE) {
-      double v[U][NI > 0 ? NI : 1];
-      bool ok[U];
-#pragma unroll
-      for (int u = 0; u < U; ++u) {
-        const uint32_t p = p0 + u * PK_WAVE;
-        ok[u] = p < (uint32_t)tot;
-        const uint32_t pc = ok[u] ? p : p0;
-        const int jj = magic_div(pc, tl.magicI);   // p / nnz (p < 2^16)
-        const int t = (int)pc - jj * nnz;
-        const int rc = T.rc[t];
-        const double val = -(T.iv[t] * T.wd[jj] * 0.5);
-        const double* __restrict__ col = sv + jj * g.stride + (rc >> 16);
-        const double* __restrict__ lam = lam_s + jj * g.R + (rc & 0xFFFF);
-#pragma unroll
-        for (int e = 0; e < NI; ++e)
-          v[u][e] = HESS ? val * lam[P::H_state(E0 + e) * PK_WAVE] * col[e * PK_WAVE] : val * col[e * PK_WAVE];
-      }
-#ifdef PK_TRACE
-      if (PK_DIAG(131072)) {    // tracing builds only: the loop without its stores (lookups and products kept alive)
-        double acc = 0.0;
-#pragma unroll
-        for (int u = 0; u < U; ++u)
-#pragma unroll
-          for (int e = 0; e < NI; ++e) acc += v[u][e];
-        asm volatile("" ::"v"(acc));
-        continue;
-      }
-#endif
-#pragma unroll
-      for (int u = 0; u < U; ++u) {
-        if (!ok[u]) continue;
-#pragma unroll
-        for (int e = 0; e < NI; ++e) put(&run[e][p0 + u * PK_WAVE], v[u][e]);
-      }
-    }
-    return;
-  }
   const int32_t* __restrict__ rcg = A.ib + tl.irc_off;
   const double* __restrict__ ivg = A.db + tl.iv_off;
   const double* __restrict__ wdg = A.db + ph.width_off + tl.j0;
@@ -786,7 +727,7 @@ __device__ __forceinline__ void stream_loop(const PkArgs& A, const PkPhase& ph, 
     if (HESS) {
       const double* __restrict__ lam = lam_s + jj * g.R + r;
 #pragma unroll
-      for (int e = 0; e < NI; ++e) put(&run[e][p], val * lam[P::H_state(E0 + e) * PK_WAVE] * col[e * PK_WAVE]);
+      for (int e = 0; e < NI; ++e) put(&run[e][p], val * lam[(P::H_state(E0 + e) - S0) * PK_WAVE] * col[e * PK_WAVE]);
     } else {
 #pragma unroll
       for (int e = 0; e < NI; ++e) put(&run[e][p], val * col[e * PK_WAVE]);
@@ -794,13 +735,13 @@ __device__ __forceinline__ void stream_loop(const PkArgs& A, const PkPhase& ph, 
   }
 }
 
-template <class P, int NI, bool HESS, bool STAGED, int E0 = 0, class Bases>
+template <class P, int NI, bool HESS, bool STAGED, int E0 = 0, int S0 = 0, class Bases>
 __device__ __forceinline__ void stream_expanded(const PkArgs& A, const PkPhase& ph, const PkTile& tl,
                                                 const TileGeom& g, const TileTabs& T, const double* __restrict__ sv,
                                                 const double* __restrict__ lam_s, const Bases& segb,
                                                 double* __restrict__ out, int lane) {
   if (NI == 0 || tl.nj * tl.nnzI == 0) return;
-  stream_loop<P, NI, HESS, STAGED, E0>(A, ph, tl, g, T, sv, lam_s, segb, out, lane);
+  stream_loop<P, NI, HESS, STAGED, E0, S0>(A, ph, tl, g, T, sv, lam_s, segb, out, lane);
 }
 
 // Phase B is compiled twice -- tables staged in LDS (K <= 8) or read from global memory -- and the wave branches
@@ -877,6 +818,63 @@ __device__ __forceinline__ void tile_int(const PkArgs& A, const PkTile& tl, doub
 }
 
 // ============================================================================================
+// WIDE models (P::WIDE: more than PK_WIDE_NX states): the dynamics values and the defect rows in PASSES over chunks of
+// states (codegen.py D_c0 / D_cn, at most codegen.WIDE_CHUNK states each).  The reference loops over the states with no limit
+// (phasebase.py:1008-1012); a wave that staged the values of ALL states needed 64 n_x doubles of LDS (80 states: the
+// whole 160 KiB of a workgroup) and kept every node argument in registers.  A pass loads the node arguments ITS functions
+// and rows read (load_node is called afresh: what the pass does not use is dead code), evaluates the chunk's dynamics
+// (P::mid_dyn_g, its own joint CSE), stages D_cn rows, and writes the chunk's defect rows -- same products, same order per
+// row as write_defects.  The passes run one after the other in a wave (pk_g, pk_xall, a cycle whose roles are not
+// pass-parallel) or each as a wave of its own (pk_cycle of a model with Gen::GROUPED: tile_dyn_pick).
+// ============================================================================================
+template <class P, int C>
+__device__ __forceinline__ void dyn_pass(const PkArgs& A, const PkPhase& ph, const PkTile& tl, const TileGeom& g,
+                                         const TileTabs& T, const double* s, double dt, double mt,
+                                         double* __restrict__ sv, int lane) {
+  constexpr int I0 = P::D_c0(C), CN = P::D_cn(C);
+  double a[P::NARG], tau, w;
+  load_node<P>(A, ph, s, dt, mt, tl.q0 + lane, a, tau, w);
+  if (lane < g.nq) {
+    double o[CN];
+    P::mid_dyn_g(Grp<C>{}, a, o);
+#pragma unroll
+    for (int e = 0; e < CN; ++e) sv[e * PK_WAVE + lane] = o[e];
+  }
+  wave_lds_sync();
+  PK_PHASE_B(T, (defect_chunk<P, STAGED, I0, CN, 0>(A, ph, tl, g, T, s, dt, sv, a, lane)));
+}
+template <class P, int C = 0>
+__device__ __forceinline__ void dyn_passes(const PkArgs& A, const PkPhase& ph, const PkTile& tl, const TileGeom& g,
+                                           const TileTabs& T, const double* s, double dt, double mt,
+                                           double* __restrict__ sv, int lane) {
+  if constexpr (C < P::D_NG) {
+    dyn_pass<P, C>(A, ph, tl, g, T, s, dt, mt, sv, lane);
+    wave_lds_sync();                        // (the next pass overwrites the rows this one read)
+    dyn_passes<P, C + 1>(A, ph, tl, g, T, s, dt, mt, sv, lane);
+  }
+}
+// one pass as a wave of its own (pk_cycle: the workgroups of a tile block are [Jacobian passes | values | dynamics passes |
+// Hessian passes]); `chunk` is wave-uniform
+template <class P, int C>
+__device__ __forceinline__ void tile_dyn_one(const PkArgs& A, const PkTile& tl, double* __restrict__ sv, int lane) {
+  const PkPhase& ph = A.ph[P::INDEX];
+  const TileGeom g = tile_geom<P>(tl);
+  double s[PK_NS], dt, mt;
+  phase_scalars<P>(A, ph, s, dt, mt);
+  const bool fit = tabs_fit(A, tl, g);
+  const TabRegs tr = tabs_issue(A, ph, tl, g, fit, lane);
+  const TileTabs T = tabs_commit(A, tl, g, tr, fit, lane);
+  dyn_pass<P, C>(A, ph, tl, g, T, s, dt, mt, sv, lane);
+}
+template <class P, int C = 0>
+__device__ __forceinline__ void tile_dyn_pick(int chunk, const PkArgs& A, const PkTile& tl, double* __restrict__ sv, int lane) {
+  if constexpr (C < P::D_NG) {
+    if (chunk == C) tile_dyn_one<P, C>(A, tl, sv, lane);
+    else tile_dyn_pick<P, C + 1>(chunk, A, tl, sv, lane);
+  }
+}
+
+// ============================================================================================
 // constraints: collocation defects and path-constraint values      (phasebase.py:1008-1021)
 // ============================================================================================
 template <class P>
@@ -889,31 +887,41 @@ __device__ __forceinline__ void tile_g(const PkArgs& A, const PkTile& tl, double
   const bool fit = tabs_fit(A, tl, g);
   const TabRegs tr = tabs_issue(A, ph, tl, g, fit, lane);
   const int q = tl.q0 + lane;
-  double a[P::NARG], tau, w, xr[P::NX], xe[P::NX];
-  load_node<P>(A, ph, s, dt, mt, q, a, tau, w);
-  const TileTabs T = tabs_commit(A, tl, g, tr, fit, lane);
-  if constexpr (P::NX <= PK_WIDE_NX) {
+  if constexpr (P::WIDE) {      // the path-constraint values, then the defects in passes over chunks of states
+    const TileTabs T = tabs_commit(A, tl, g, tr, fit, lane);
+    if constexpr (P::NC > 0) {
+      double a[P::NARG], tau, w, o[P::NC];
+      load_node<P>(A, ph, s, dt, mt, q, a, tau, w);
+      if (lane < g.nown) {
+        P::mid_path(a, o);
+#pragma unroll
+        for (int j = 0; j < P::NC; ++j) put(&A.o_g[ph.path_off + j * ph.L_m + q], o[j]);
+      }
+    }
+    wave_lds_sync();
+    dyn_passes<P>(A, ph, tl, g, T, s, dt, mt, sv, lane);
+  } else {
+    double a[P::NARG], tau, w, xr[P::NX], xe[P::NX];
+    load_node<P>(A, ph, s, dt, mt, q, a, tau, w);
+    const TileTabs T = tabs_commit(A, tl, g, tr, fit, lane);
     defect_ends<P>(A, ph, tl, g, a, xe, lane);
     settle(xe);
-  }
-  loads_done();
-  if constexpr (P::NX <= PK_WIDE_NX) {
+    loads_done();
 #pragma unroll
     for (int i = 0; i < P::NX; ++i) xr[i] = a[i];
-  }
-  if (lane < g.nq) {
-    double o[P::G_NOUT];
-    P::mid_g(a, o);
+    if (lane < g.nq) {
+      double o[P::G_NOUT];
+      P::mid_g(a, o);
 #pragma unroll
-    for (int i = 0; i < P::NX; ++i) sv[i * PK_WAVE + lane] = o[i];
-    if (lane < g.nown) {
+      for (int i = 0; i < P::NX; ++i) sv[i * PK_WAVE + lane] = o[i];
+      if (lane < g.nown) {
 #pragma unroll
-      for (int j = 0; j < P::NC; ++j) put(&A.o_g[ph.path_off + j * ph.L_m + q], o[P::NX + j]);
+        for (int j = 0; j < P::NC; ++j) put(&A.o_g[ph.path_off + j * ph.L_m + q], o[P::NX + j]);
+      }
     }
+    wave_lds_sync();
+    PK_PHASE_B(T, (write_defects<P, STAGED>(A, ph, tl, g, T, s, dt, sv, xr, xe, lane)));
   }
-  wave_lds_sync();
-  if constexpr (P::NX <= PK_WIDE_NX) PK_PHASE_B(T, (write_defects<P, STAGED>(A, ph, tl, g, T, s, dt, sv, xr, xe, lane)));
-  else PK_PHASE_B(T, (write_defects_wide<P, STAGED>(A, ph, tl, g, T, s, dt, sv, a, lane)));
 }
 
 // ============================================================================================
@@ -1001,10 +1009,15 @@ template <class P, int G, bool ONE = false>
 __device__ __forceinline__ void jac_groups(const PkArgs& A, const PkPhase& ph, const PkTile& tl, const TileGeom& g,
                                            const TileTabs& T, double (&a)[P::NARG], double& tau, double& dt, double& w,
                                            const PkSys& sy, double* __restrict__ jsv,
-                                           const SegBases<P::J_NI + P::J_NN>& segb, int lane, int q, bool live) {
+                                           const SegBases<P::J_NI + P::J_NN>& segb, int lane, int q, bool live,
+                                           const double* s = nullptr, double mt = 0.0) {
   if constexpr (G < P::J_NG) {
     constexpr int NI = P::J_gni(G), N0 = P::J_gn0(G), NN = P::J_gnn(G);
-    if constexpr (G > 0 && !ONE) fresh_args(a, tau, dt, w);
+    // A WIDE model (P::WIDE) fetches its node arguments anew in every pass: only what THIS pass's function reads is loaded
+    // (the other loads are dead code), so the registers a pass holds do not grow with the number of states -- 128 states kept
+    // alive across the passes were 260 VGPRs before any arithmetic.  (The loads queue behind the previous pass's stores.)
+    if constexpr (P::WIDE && !ONE) load_node<P>(A, ph, s, dt, mt, q, a, tau, w);
+    else if constexpr (G > 0 && !ONE) fresh_args(a, tau, dt, w);
     if (live) {
       double o[NI + NN + 1];
       P::mid_jac_g(Grp<G>{}, a, tau, dt, w, sy, nullptr, o);
@@ -1020,7 +1033,7 @@ __device__ __forceinline__ void jac_groups(const PkArgs& A, const PkPhase& ph, c
       if (tl.nj != 0) PK_PHASE_B(T, (jac_group_b<P, G, STAGED>(A, ph, tl, g, T, jsv, segb, lane)));
       if constexpr (!ONE) wave_lds_sync();      // (the next pass overwrites the rows this one streamed from)
     }
-    if constexpr (!ONE) jac_groups<P, G + 1>(A, ph, tl, g, T, a, tau, dt, w, sy, jsv, segb, lane, q, live);
+    if constexpr (!ONE) jac_groups<P, G + 1>(A, ph, tl, g, T, a, tau, dt, w, sy, jsv, segb, lane, q, live, s, mt);
   }
 }
 
@@ -1046,13 +1059,13 @@ __device__ __forceinline__ void tile_jac_grouped(const PkArgs& A, const PkTile& 
   loads_done();
   wave_lds_sync();
   if (tl.nj != 0) PK_PHASE_B(T, (write_translation<P, STAGED>(A, ph, tl, T, tbase, lane)));
-  jac_groups<P, 0>(A, ph, tl, g, T, a, tau, dt, w, sy, sv, segb, lane, q, lane < g.nq);
+  jac_groups<P, 0>(A, ph, tl, g, T, a, tau, dt, w, sy, sv, segb, lane, q, lane < g.nq, s, mt);
 }
 
 template <class P>
 __device__ __forceinline__ void tile_jac(const PkArgs& A, const PkTile& tl, double* __restrict__ sv,
                                          double* __restrict__, double* __restrict__, int lane) {
-  if constexpr (P::J_NG == 1) tile_jac_single<P>(A, tl, sv, lane);
+  if constexpr (P::J_NG == 1 && !P::WIDE) tile_jac_single<P>(A, tl, sv, lane);
   else tile_jac_grouped<P>(A, tl, sv, lane);
 }
 
@@ -1201,14 +1214,17 @@ __device__ __forceinline__ void jacc_group_b(const PkArgs& A, const PkPhase& ph,
       put(&A.o_jac[segb[P::JC_NI + LO + e] + tl.r0 + lane], (first ? tf[e] : 0.0) + (last_iv ? tb[e] : 0.0) - acc[e]);
   }
 }
-template <class P, int G>
+// ONE: this pass only, on node arguments the caller loaded (a pass-parallel launch: tile_jacc_part)
+template <class P, int G, bool ONE = false>
 __device__ __forceinline__ void jacc_groups(const PkArgs& A, const PkPhase& ph, const PkTile& tl, const TileGeom& g,
                                             const TileTabs& T, double (&a)[P::NARG], double& tau, double& dt, double& w,
                                             const PkSys& sy, double* __restrict__ sv,
-                                            const SegBases<P::JC_NI + P::JC_ND + P::JC_NN>& segb, int lane, int q, bool live) {
+                                            const SegBases<P::JC_NI + P::JC_ND + P::JC_NN>& segb, int lane, int q, bool live,
+                                            const double* s, double mt) {
   if constexpr (G < P::JC_NG) {
     constexpr int KIND = P::JC_gk(G), LO = P::JC_g0(G), CN = P::JC_gn(G);
-    if constexpr (G > 0) fresh_args(a, tau, dt, w);
+    if constexpr (P::WIDE && !ONE) load_node<P>(A, ph, s, dt, mt, q, a, tau, w);      // (see jac_groups)
+    else if constexpr (G > 0 && !ONE) fresh_args(a, tau, dt, w);
     if (live) {
       double o[CN + 1];
       P::mid_jacc_g(Grp<G>{}, a, tau, dt, w, sy, nullptr, o);
@@ -1229,7 +1245,7 @@ __device__ __forceinline__ void jacc_groups(const PkArgs& A, const PkPhase& ph, 
       if (tl.nj != 0) PK_PHASE_B(T, (jacc_group_b<P, G, STAGED>(A, ph, tl, g, T, a, sv, segb, lane)));
       wave_lds_sync();
     }
-    jacc_groups<P, G + 1>(A, ph, tl, g, T, a, tau, dt, w, sy, sv, segb, lane, q, live);
+    if constexpr (!ONE) jacc_groups<P, G + 1>(A, ph, tl, g, T, a, tau, dt, w, sy, sv, segb, lane, q, live, s, mt);
   }
 }
 
@@ -1255,7 +1271,7 @@ __device__ __forceinline__ void tile_jacc_grouped(const PkArgs& A, const PkTile&
   loads_done();
   wave_lds_sync();
   if (tl.nj != 0) PK_PHASE_B(T, (write_translation<P, STAGED>(A, ph, tl, T, tbase, lane)));
-  jacc_groups<P, 0>(A, ph, tl, g, T, a, tau, dt, w, sy, sv, segb, lane, q, lane < g.nq);
+  jacc_groups<P, 0>(A, ph, tl, g, T, a, tau, dt, w, sy, sv, segb, lane, q, lane < g.nq, s, mt);
 }
 
 template <class P>
@@ -1263,6 +1279,54 @@ __device__ __forceinline__ void tile_jacc(const PkArgs& A, const PkTile& tl, dou
                                           double* __restrict__, double* __restrict__, int lane) {
   if constexpr (P::JC_gk(0) < 0) tile_jacc_single<P>(A, tl, sv, lane);      // (one pass over all kinds)
   else tile_jacc_grouped<P>(A, tl, sv, lane);
+}
+
+// The compact Jacobian of a model evaluated in groups in a PASS-PARALLEL launch (pk_cyclec, pk_jacc of a code object with
+// Gen::GROUPED): workgroup `sub` of the `stride` workgroups a tile block has for this role runs the passes G with
+// G % stride == sub (the compact layout may have more passes than the reference layout's Jacobian role has workgroups);
+// sub 0 also writes the translation entries.  The passes are independent of each other, as in tile_jac_pick.
+template <class P, int G>
+__device__ __forceinline__ void tile_jacc_one(const PkArgs& A, const PkTile& tl, double* __restrict__ sv, int lane) {
+  const PkPhase& ph = A.ph[P::INDEX];
+  const TileGeom g = tile_geom<P>(tl);
+  double s[PK_NS], dt, mt;
+  phase_scalars<P>(A, ph, s, dt, mt);
+  const PkSys sy{s, A.Ibuf, A.sigma, A.lam};
+  SegBases<P::JC_NI + P::JC_ND + P::JC_NN> segb;
+  SegBases<P::NX> tbase;
+  segb.load(A.lb, ph.jcseg_off, lane);
+  if constexpr (G == 0) tbase.load(A.lb, ph.jct_off, lane);
+  const bool fit = tabs_fit(A, tl, g);
+  const TabRegs tr = tabs_issue(A, ph, tl, g, fit, lane);
+  const int q = tl.q0 + lane;
+  double a[P::NARG], tau, w;
+  load_node<P>(A, ph, s, dt, mt, q, a, tau, w);      // (what THIS pass reads: the rest is dead code)
+  const TileTabs T = tabs_commit(A, tl, g, tr, fit, lane);
+  segb.settle();
+  if constexpr (G == 0) tbase.settle();
+  loads_done();
+  wave_lds_sync();
+  if constexpr (G == 0) {
+    if (tl.nj != 0) PK_PHASE_B(T, (write_translation<P, STAGED>(A, ph, tl, T, tbase, lane)));
+  }
+  jacc_groups<P, G, true>(A, ph, tl, g, T, a, tau, dt, w, sy, sv, segb, lane, q, lane < g.nq, nullptr, 0.0);
+}
+template <class P, int G>
+__device__ __forceinline__ void jacc_round_robin(int sub, int stride, const PkArgs& A, const PkTile& tl, double* __restrict__ sv,
+                                                 int lane) {
+  if constexpr (G < P::JC_NG) {
+    if (G % stride == sub) tile_jacc_one<P, G>(A, tl, sv, lane);
+    jacc_round_robin<P, G + 1>(sub, stride, A, tl, sv, lane);
+  }
+}
+template <class P>
+__device__ __forceinline__ void tile_jacc_part(int sub, int stride, const PkArgs& A, const PkTile& tl, double* __restrict__ sv,
+                                               int lane) {
+  if constexpr (P::JC_gk(0) < 0) {      // (one pass over all kinds: the role's first workgroup)
+    if (sub == 0) tile_jacc_single<P>(A, tl, sv, lane);
+  } else {
+    jacc_round_robin<P, 0>(sub, stride, A, tl, sv, lane);
+  }
 }
 
 // ============================================================================================
@@ -1283,16 +1347,19 @@ __device__ __forceinline__ void tile_hess_single(const PkArgs& A, const PkTile& 
   const bool fit = tabs_fit(A, tl, g);
   const TabRegs tr = tabs_issue(A, ph, tl, g, fit, lane);
   const int q = tl.q0 + lane;
-  double a[P::NARG], tau, w, lp[P::NC > 0 ? P::NC : 1], lrow[P::NX];
+  // (S0, SN: the states whose defect multipliers the pass reads -- all of them, or for a WIDE model the range its segments
+  //  belong to: codegen.py H_gs0 / H_gsn)
+  constexpr int S0 = P::H_gs0(0), SN = P::H_gsn(0);
+  double a[P::NARG], tau, w, lp[P::NC > 0 ? P::NC : 1], lrow[SN > 0 ? SN : 1];
   const int row = min(tl.r0 + lane, ph.L_d - 1);
 #pragma unroll
-  for (int i = 0; i < P::NX; ++i) lrow[i] = A.lam[ph.g_off + i * ph.L_d + row];
+  for (int i = 0; i < SN; ++i) lrow[i] = A.lam[ph.g_off + (S0 + i) * ph.L_d + row];
   load_node<P>(A, ph, s, dt, mt, q, a, tau, w);
 #pragma unroll
   for (int j = 0; j < P::NC; ++j) lp[j] = A.lam[ph.path_off + j * ph.L_m + min(q, ph.L_m - 1)];
   const TileTabs T = tabs_commit(A, tl, g, tr, fit, lane);
 #pragma unroll
-  for (int i = 0; i < P::NX; ++i) lam_s[i * PK_WAVE + lane] = lrow[i];
+  for (int i = 0; i < SN; ++i) lam_s[i * PK_WAVE + lane] = lrow[i];
   segb.settle();
   loads_done();
   PK_MARK(1);
@@ -1312,7 +1379,7 @@ __device__ __forceinline__ void tile_hess_single(const PkArgs& A, const PkTile& 
   wave_lds_sync();
   PK_MARK(5);
   if (tl.nj == 0) return;
-  PK_PHASE_B(T, (stream_expanded<P, P::H_NI, true, STAGED>(A, ph, tl, g, T, sv, lam_s, segb, A.o_hess, lane)));
+  PK_PHASE_B(T, (stream_expanded<P, P::H_NI, true, STAGED, 0, S0>(A, ph, tl, g, T, sv, lam_s, segb, A.o_hess, lane)));
   PK_MARK(8);
 #ifdef PK_TRACE
   __builtin_amdgcn_s_waitcnt(0);      // all stores acknowledged
@@ -1321,22 +1388,43 @@ __device__ __forceinline__ void tile_hess_single(const PkArgs& A, const PkTile& 
 }
 
 // the Hessian role in groups (see jac_groups): lam_s = the tile's defect multipliers, staged once behind the group rows
+// (a WIDE model: the rows of the states pass G's segments belong to, staged by the pass itself -- hess_rows)
+template <class P, int G>
+__device__ __forceinline__ void hess_rows(const PkArgs& A, const PkPhase& ph, const PkTile& tl, double* __restrict__ lam_s,
+                                          int lane) {
+  constexpr int S0 = P::H_gs0(G), SN = P::H_gsn(G);
+  if constexpr (P::H_gni(G) > 0 && SN > 0) {
+    const int row = min(tl.r0 + lane, ph.L_d - 1);
+    double lrow[SN];
+#pragma unroll
+    for (int i = 0; i < SN; ++i) lrow[i] = A.lam[ph.g_off + (S0 + i) * ph.L_d + row];
+#pragma unroll
+    for (int i = 0; i < SN; ++i) lam_s[i * PK_WAVE + lane] = lrow[i];
+  }
+}
 template <class P, int G, bool STAGED>
 __device__ __forceinline__ void hess_group_b(const PkArgs& A, const PkPhase& ph, const PkTile& tl, const TileGeom& g,
                                              const TileTabs& T, const double* __restrict__ sv,
                                              const double* __restrict__ lam_s, const SegBases<P::H_NI + P::H_NN>& segb,
                                              int lane) {
-  stream_expanded<P, P::H_gni(G), true, STAGED, P::H_gi0(G)>(A, ph, tl, g, T, sv, lam_s, segb, A.o_hess, lane);
+  stream_expanded<P, P::H_gni(G), true, STAGED, P::H_gi0(G), P::H_gs0(G)>(A, ph, tl, g, T, sv, lam_s, segb, A.o_hess, lane);
 }
 template <class P, int G, bool ONE = false>
 __device__ __forceinline__ void hess_groups(const PkArgs& A, const PkPhase& ph, const PkTile& tl, const TileGeom& g,
                                             const TileTabs& T, double (&a)[P::NARG], double& tau, double& dt, double& w,
                                             const PkSys& sy, double (&lp)[P::NC > 0 ? P::NC : 1], double* __restrict__ sv,
-                                            const double* __restrict__ lam_s, const SegBases<P::H_NI + P::H_NN>& segb,
-                                            int lane, int q, bool live) {
+                                            double* __restrict__ lam_s, const SegBases<P::H_NI + P::H_NN>& segb,
+                                            int lane, int q, bool live, const double* s = nullptr, double mt = 0.0) {
   if constexpr (G < P::H_NG) {
     constexpr int NI = P::H_gni(G), N0 = P::H_gn0(G), NN = P::H_gnn(G);
-    if constexpr (G > 0 && !ONE) {
+    if constexpr (P::WIDE && !ONE) {
+      // a WIDE model: every pass fetches its own node arguments, path multipliers and the defect-multiplier rows of the
+      // states ITS segments belong to (see jac_groups; the rows of 128 states were 64 KB of LDS per wave)
+      hess_rows<P, G>(A, ph, tl, lam_s, lane);
+      load_node<P>(A, ph, s, dt, mt, q, a, tau, w);
+#pragma unroll
+      for (int j = 0; j < P::NC; ++j) lp[j] = A.lam[ph.path_off + j * ph.L_m + min(q, ph.L_m - 1)];
+    } else if constexpr (G > 0 && !ONE) {
       fresh_args(a, tau, dt, w);
       settle(lp);
     }
@@ -1355,7 +1443,7 @@ __device__ __forceinline__ void hess_groups(const PkArgs& A, const PkPhase& ph, 
       if (tl.nj != 0) PK_PHASE_B(T, (hess_group_b<P, G, STAGED>(A, ph, tl, g, T, sv, lam_s, segb, lane)));
       if constexpr (!ONE) wave_lds_sync();      // (the next pass overwrites the rows this one streamed from)
     }
-    if constexpr (!ONE) hess_groups<P, G + 1>(A, ph, tl, g, T, a, tau, dt, w, sy, lp, sv, lam_s, segb, lane, q, live);
+    if constexpr (!ONE) hess_groups<P, G + 1>(A, ph, tl, g, T, a, tau, dt, w, sy, lp, sv, lam_s, segb, lane, q, live, s, mt);
   }
 }
 
@@ -1372,19 +1460,28 @@ __device__ __forceinline__ void tile_hess_grouped(const PkArgs& A, const PkTile&
   const bool fit = tabs_fit(A, tl, g);
   const TabRegs tr = tabs_issue(A, ph, tl, g, fit, lane);
   const int q = tl.q0 + lane;
-  double a[P::NARG], tau, w, lp[P::NC > 0 ? P::NC : 1], lrow[P::NX];
-  const int row = min(tl.r0 + lane, ph.L_d - 1);
+  double a[P::NARG], tau, w, lp[P::NC > 0 ? P::NC : 1];
+  if constexpr (P::WIDE) {      // (every pass loads what it reads: hess_groups)
+    const TileTabs T = tabs_commit(A, tl, g, tr, fit, lane);
+    segb.settle();
+    loads_done();
+    wave_lds_sync();
+    hess_groups<P, 0>(A, ph, tl, g, T, a, tau, dt, w, sy, lp, sv, lam_s, segb, lane, q, lane < g.nq, s, mt);
+  } else {
+    double lrow[P::NX];
+    const int row = min(tl.r0 + lane, ph.L_d - 1);
 #pragma unroll
-  for (int i = 0; i < P::NX; ++i) lrow[i] = A.lam[ph.g_off + i * ph.L_d + row];
-  load_node<P>(A, ph, s, dt, mt, q, a, tau, w);
+    for (int i = 0; i < P::NX; ++i) lrow[i] = A.lam[ph.g_off + i * ph.L_d + row];
+    load_node<P>(A, ph, s, dt, mt, q, a, tau, w);
 #pragma unroll
-  for (int j = 0; j < P::NC; ++j) lp[j] = A.lam[ph.path_off + j * ph.L_m + min(q, ph.L_m - 1)];
-  const TileTabs T = tabs_commit(A, tl, g, tr, fit, lane);
+    for (int j = 0; j < P::NC; ++j) lp[j] = A.lam[ph.path_off + j * ph.L_m + min(q, ph.L_m - 1)];
+    const TileTabs T = tabs_commit(A, tl, g, tr, fit, lane);
 #pragma unroll
-  for (int i = 0; i < P::NX; ++i) lam_s[i * PK_WAVE + lane] = lrow[i];
-  segb.settle();
-  loads_done();
-  hess_groups<P, 0>(A, ph, tl, g, T, a, tau, dt, w, sy, lp, sv, lam_s, segb, lane, q, lane < g.nq);
+    for (int i = 0; i < P::NX; ++i) lam_s[i * PK_WAVE + lane] = lrow[i];
+    segb.settle();
+    loads_done();
+    hess_groups<P, 0>(A, ph, tl, g, T, a, tau, dt, w, sy, lp, sv, lam_s, segb, lane, q, lane < g.nq);
+  }
 }
 
 template <class P>
@@ -1407,12 +1504,13 @@ __device__ __forceinline__ void tile_hess_one(const PkArgs& A, const PkTile& tl,
   const bool fit = tabs_fit(A, tl, g);
   const TabRegs tr = tabs_issue(A, ph, tl, g, fit, lane);
   const int q = tl.q0 + lane;
-  double a[P::NARG], tau, w, lp[P::NC > 0 ? P::NC : 1], lrow[P::NX];
+  constexpr int S0 = P::H_gs0(G), SN = P::H_gsn(G);           // (the states whose rows the pass reads: all, or -- WIDE -- its own)
+  double a[P::NARG], tau, w, lp[P::NC > 0 ? P::NC : 1], lrow[SN > 0 ? SN : 1];
   const int row = min(tl.r0 + lane, ph.L_d - 1);
   constexpr bool needs_rows = P::H_gni(G) > 0;                 // (a pass of per-node segments only reads no defect multiplier)
   if (needs_rows) {
 #pragma unroll
-    for (int i = 0; i < P::NX; ++i) lrow[i] = A.lam[ph.g_off + i * ph.L_d + row];
+    for (int i = 0; i < SN; ++i) lrow[i] = A.lam[ph.g_off + (S0 + i) * ph.L_d + row];
   }
   load_node<P>(A, ph, s, dt, mt, q, a, tau, w);
 #pragma unroll
@@ -1420,7 +1518,7 @@ __device__ __forceinline__ void tile_hess_one(const PkArgs& A, const PkTile& tl,
   const TileTabs T = tabs_commit(A, tl, g, tr, fit, lane);
   if (needs_rows) {
 #pragma unroll
-    for (int i = 0; i < P::NX; ++i) lam_s[i * PK_WAVE + lane] = lrow[i];
+    for (int i = 0; i < SN; ++i) lam_s[i * PK_WAVE + lane] = lrow[i];
   }
   segb.settle();
   loads_done();
@@ -1549,6 +1647,7 @@ __device__ __forceinline__ void tile_xall_single(const PkArgs& A, const PkTile& 
   if (live) {
     if (ROLE != 2) {
       if (lane < g.nown) node_gradient_store<P>(A, ph, q, ov);      // (after the sums went out: they feed the finalize chain)
+      PK_MARK(12);
 #pragma unroll
       for (int i = 0; i < P::NX; ++i) sv[i * PK_WAVE + lane] = og[i];
     }
@@ -1556,6 +1655,7 @@ __device__ __forceinline__ void tile_xall_single(const PkArgs& A, const PkTile& 
 #pragma unroll
       for (int e = 0; e < P::J_NI; ++e) jsv[e * PK_WAVE + lane] = oj[e];
     }
+    PK_MARK(13);
     if (lane < g.nown) {
       if (ROLE != 2) {
 #pragma unroll
@@ -1581,15 +1681,16 @@ __device__ __forceinline__ void tile_xall_single(const PkArgs& A, const PkTile& 
 
 // The fused x-part of a model whose Jacobian is evaluated in groups: the VALUES part (g, grad f, integrand sums; P::mid_xval)
 // exactly as in the single-pass code, then the Jacobian segments group by group (jac_groups, the passes of pk_jac).
+// A WIDE model (P::WIDE): mid_xval leaves the dynamics out; they and the defect rows follow in passes over chunks of states
+// (dyn_passes) -- unless PP says that those passes are waves of their own in this launch (pk_cycle, tile_dyn_pick).
 template <class P, int ROLE, bool STAGED, bool CJ>
 __device__ __forceinline__ void xval_phase_b(const PkArgs& A, const PkPhase& ph, const PkTile& tl, const TileGeom& g,
                                              const TileTabs& T, const double* s, double dt, const double* __restrict__ sv,
                                              const double* xr, double* xe, const SegBases<P::NX>& tbase, int lane) {
-  if constexpr (P::NX <= PK_WIDE_NX) write_defects<P, STAGED>(A, ph, tl, g, T, s, dt, sv, xr, xe, lane);
-  else write_defects_wide<P, STAGED>(A, ph, tl, g, T, s, dt, sv, xr, lane);
+  if constexpr (!P::WIDE) write_defects<P, STAGED>(A, ph, tl, g, T, s, dt, sv, xr, xe, lane);
   if (!CJ && tl.nj != 0) write_translation<P, STAGED>(A, ph, tl, T, tbase, lane);
 }
-template <class P, int ROLE, bool CJ>
+template <class P, int ROLE, bool CJ, bool PP = false>
 __device__ __forceinline__ void tile_xall_grouped(const PkArgs& A, const PkTile& tl, double* __restrict__ sv,
                                                   double* __restrict__ wint, double* __restrict__ wgrad, int lane,
                                                   int pub_blk) {
@@ -1602,7 +1703,7 @@ __device__ __forceinline__ void tile_xall_grouped(const PkArgs& A, const PkTile&
   SegBases<P::NX> tbase;
   if (ROLE != 1) segb.load(A.lb, ph.jseg_off, lane);
   if (ROLE != 2) tbase.load(A.lb, ph.jt_off, lane);
-  double* __restrict__ jsv = sv + P::NX * PK_WAVE;
+  double* __restrict__ jsv = sv + P::XROWS * PK_WAVE;      // (XROWS: rows of the dynamics values -- NX, or a WIDE model's chunk)
   const bool fit = tabs_fit(A, tl, g);
   const TabRegs tr = tabs_issue(A, ph, tl, g, fit, lane);
   const int q = tl.q0 + lane;
@@ -1658,24 +1759,24 @@ __device__ __forceinline__ void tile_xall_grouped(const PkArgs& A, const PkTile&
       }
     }
     // the end-slot state values of the defect rows only now (wave shuffles of the node values; a full LGR tile reaches one
-    // slot past the wave): a wide model would otherwise carry NX more register pairs through the evaluation above.  The
-    // node's own values ARE its row's x_q (a[0 .. NX) until the Jacobian passes make them opaque).
-    double xe[P::NX <= PK_WIDE_NX ? P::NX : 1];
-    if constexpr (P::NX <= PK_WIDE_NX) defect_ends<P>(A, ph, tl, g, a, xe, lane);
+    // slot past the wave): the node's own values ARE its row's x_q (a[0 .. NX) until the Jacobian passes make them opaque).
+    double xe[P::WIDE ? 1 : P::NX];
+    if constexpr (!P::WIDE) defect_ends<P>(A, ph, tl, g, a, xe, lane);
     wave_lds_sync();
     PK_PHASE_B(T, (xval_phase_b<P, ROLE, STAGED, CJ>(A, ph, tl, g, T, s, dt, sv, a, xe, tbase, lane)));
+    if constexpr (P::WIDE && !PP) dyn_passes<P>(A, ph, tl, g, T, s, dt, mt, sv, lane);
   } else {
     wave_lds_sync();                                        // (the table blocks the wave staged for itself)
   }
-  if (ROLE != 1) jac_groups<P, 0>(A, ph, tl, g, T, a, tau, dt, w, sy, jsv, segb, lane, q, live);
+  if (ROLE != 1) jac_groups<P, 0>(A, ph, tl, g, T, a, tau, dt, w, sy, jsv, segb, lane, q, live, s, mt);
 }
 
-template <class P, int ROLE, bool CJ = false>
+template <class P, int ROLE, bool CJ = false, bool PP = false>
 __device__ __forceinline__ void tile_xall(const PkArgs& A, const PkTile& tl, double* __restrict__ sv,
                                           double* __restrict__ wint, double* __restrict__ wgrad, int lane,
                                           int pub_blk) {
-  if constexpr (P::J_NG == 1) tile_xall_single<P, ROLE, CJ>(A, tl, sv, wint, wgrad, lane, pub_blk);
-  else tile_xall_grouped<P, ROLE, CJ>(A, tl, sv, wint, wgrad, lane, pub_blk);
+  if constexpr (P::J_NG == 1 && !P::WIDE) tile_xall_single<P, ROLE, CJ>(A, tl, sv, wint, wgrad, lane, pub_blk);
+  else tile_xall_grouped<P, ROLE, CJ, PP>(A, tl, sv, wint, wgrad, lane, pub_blk);
 }
 
 #ifdef PK_BIG
@@ -1776,6 +1877,19 @@ __device__ __forceinline__ void big_hess_groups(const PkArgs& A, const PkPhase& 
   }
 }
 
+// the dynamics values of ALL states of a wide model, chunk function by chunk function (workgroup-wide intervals keep rows of
+// every state)
+template <class P, int C = 0>
+__device__ __forceinline__ void dyn_all(const double* a, double* __restrict__ rows, int stride) {
+  if constexpr (C < P::D_NG) {
+    constexpr int I0 = P::D_c0(C), CN = P::D_cn(C);
+    double o[CN];
+    P::mid_dyn_g(Grp<C>{}, a, o);
+#pragma unroll
+    for (int e = 0; e < CN; ++e) rows[(I0 + e) * stride] = o[e];
+    dyn_all<P, C + 1>(a, rows, stride);
+  }
+}
 template <class P, int ROLE>
 __device__ __forceinline__ void big_xall(const PkArgs& A, const PkTile& tl, double* __restrict__ lds,
                                          double* __restrict__ wint, double* __restrict__ wgrad, int pub_blk) {
@@ -1809,9 +1923,11 @@ __device__ __forceinline__ void big_xall(const PkArgs& A, const PkTile& tl, doub
 #pragma unroll
       for (int i = 0; i < P::NX; ++i) xs[i * KS + c] = a[i];
     }
-    if constexpr (P::J_NG == 1) P::mid_xall(a, tau, dt, w, sy, og, oj, ov, ot, op);
-    else if (ROLE != 2) P::mid_xval(a, tau, dt, w, sy, fs + c, KS, og, ov, ot, op);   // (grouped: dynamics values straight
-                                                                                     //  into the rows, the Jacobian pass by pass below)
+    if constexpr (P::J_NG == 1 && !P::WIDE) P::mid_xall(a, tau, dt, w, sy, og, oj, ov, ot, op);
+    else if (ROLE != 2) {
+      P::mid_xval(a, tau, dt, w, sy, fs + c, KS, og, ov, ot, op);   // (grouped: dynamics values straight into the rows,
+      if constexpr (P::WIDE) dyn_all<P>(a, fs + c, KS);             //  the Jacobian pass by pass below)
+    }
     if (ROLE != 2) {
       if (c < nown) {
 #pragma unroll
@@ -1823,12 +1939,12 @@ __device__ __forceinline__ void big_xall(const PkArgs& A, const PkTile& tl, doub
 #pragma unroll
         for (int j = 0; j < P::NC; ++j) put(&A.o_g[ph.path_off + j * ph.L_m + q], og[P::NX + j]);
       }
-      if constexpr (P::J_NG == 1) {
+      if constexpr (P::J_NG == 1 && !P::WIDE) {
 #pragma unroll
         for (int i = 0; i < P::NX; ++i) fs[i * KS + c] = og[i];
       }
     }
-    if constexpr (P::J_NG == 1) {
+    if constexpr (P::J_NG == 1 && !P::WIDE) {
       if (ROLE != 1) {
 #pragma unroll
         for (int e = 0; e < P::J_NI; ++e) js[e * KS + c] = oj[e];
@@ -1902,7 +2018,7 @@ __device__ __forceinline__ void big_xall(const PkArgs& A, const PkTile& tl, doub
       for (int i = 0; i < P::NX; ++i) put(&A.o_jac[tb[i] + tl.offT + p], v);
     }
   }
-  if constexpr (P::J_NG == 1) {
+  if constexpr (P::J_NG == 1 && !P::WIDE) {
     if (ROLE != 1) {
       const int32_t* __restrict__ rcg = A.ib + tl.irc_off;
       const double* __restrict__ ivg = A.db + tl.iv_off;
@@ -2244,10 +2360,13 @@ __device__ __forceinline__ void tile_mu(const PkArgs& A, const PkPhase& ph, cons
 }
 
 // the per-node values of the compact Hessian, chunk by chunk (one chunk unless the model is large: codegen.split_chunks)
+// (sub, stride: a pass-parallel launch gives a tile block `stride` workgroups for this role; workgroup `sub` takes the chunks
+//  G with G % stride == sub.  stride 0: all chunks in this wave)
 template <class P, int G>
 __device__ __forceinline__ void hessc_chunks(const PkArgs& A, const PkPhase& ph, const long long* __restrict__ segb, double (&a)[P::NARG],
                                              double& tau, double& dt, double& w, const PkSys& sy,
-                                             double (&lp)[P::NC > 0 ? P::NC : 1], double (&mu)[P::NX], int q) {
+                                             double (&lp)[P::NC > 0 ? P::NC : 1], double (&mu)[P::NX], int q, int sub = 0,
+                                             int stride = 0) {
   if constexpr (G < P::HC_NG) {
     constexpr int C0 = P::HC_c0(G), CN = P::HC_cn(G);
     if constexpr (G > 0) {
@@ -2255,13 +2374,130 @@ __device__ __forceinline__ void hessc_chunks(const PkArgs& A, const PkPhase& ph,
       settle(lp);
       settle(mu);
     }
-    double o[CN + 1];
-    P::mid_hessc_g(Grp<G>{}, a, tau, dt, w, sy, lp, mu, nullptr, nullptr, o);
+    if (stride == 0 || G % stride == sub) {
+      double o[CN + 1];
+      P::mid_hessc_g(Grp<G>{}, a, tau, dt, w, sy, lp, mu, nullptr, nullptr, o);
 #pragma unroll
-    for (int e = 0; e < CN; ++e) put(&A.o_hess[segb[C0 + e] + (q - ph.mid_lo)], o[e]);
-    hessc_chunks<P, G + 1>(A, ph, segb, a, tau, dt, w, sy, lp, mu, q);
+      for (int e = 0; e < CN; ++e) put(&A.o_hess[segb[C0 + e] + (q - ph.mid_lo)], o[e]);
+    }
+    hessc_chunks<P, G + 1>(A, ph, segb, a, tau, dt, w, sy, lp, mu, q, sub, stride);
   }
 }
+
+// ---- the compact Hessian of a WIDE model (P::WIDE): every chunk of outputs is a pass of its own that fetches the node
+// arguments its expressions read and contracts the multipliers of the states THEY refer to -- the list P::HC_mus(G, k),
+// k < P::HC_nmu(G), from the code generator; row k of the staged multiplier rows and mu[k] belong to state HC_mus(G, k).
+// (All states at once were n_x rows of LDS and n_x register pairs of mu.)
+template <class P, int G>
+__device__ __forceinline__ void interval_mu_l(const PkArgs& A, const PkPhase& ph, int K, const double* __restrict__ full,
+                                              double width, int ld, int c, double* mu) {
+  constexpr int NM = P::HC_nmu(G);
+  const int R = K - P::SCHEME;
+  const double* __restrict__ lam = A.lam + ph.g_off + ld;
+  for (int r = 0; r < R; ++r) {
+    const double a = full[r * K + c] * width * 0.5;
+#pragma unroll
+    for (int k = 0; k < NM; ++k) mu[k] += a * lam[P::HC_mus(G, k) * ph.L_d + r];
+  }
+}
+template <class P, int G>
+__device__ __forceinline__ void node_mu_l(const PkArgs& A, const PkPhase& ph, int j, int c, double* mu) {
+  constexpr int NM = P::HC_nmu(G);
+#pragma unroll
+  for (int k = 0; k < NM; ++k) mu[k] = 0.0;
+  const int32_t* __restrict__ ivK = A.ib + ph.ivK_off;
+  const int32_t* __restrict__ ivF = A.ib + ph.ivfull_off;
+  const int32_t* __restrict__ ivL = A.ib + ph.ivld_off;
+  interval_mu_l<P, G>(A, ph, ivK[j], A.db + ivF[j], A.db[ph.width_off + j], ivL[j], c, mu);
+  if (P::SCHEME == 1 && c == 0 && j > 0)
+    interval_mu_l<P, G>(A, ph, ivK[j - 1], A.db + ivF[j - 1], A.db[ph.width_off + j - 1], ivL[j - 1], ivK[j - 1] - 1, mu);
+}
+template <class P, bool STAGED, int NM>
+__device__ __forceinline__ void tile_mu_n(const PkArgs& A, const PkPhase& ph, const PkTile& tl, const TileGeom& g,
+                                          const TileTabs& T, const double* __restrict__ lam_s, int jj, int c, double* mu) {
+  const double* __restrict__ full = STAGED ? T.full : A.db + tl.full_off;
+  const double width = STAGED ? T.wd[jj] : A.db[ph.width_off + tl.j0 + jj];
+  const double* __restrict__ lam = lam_s + jj * g.R;
+#pragma unroll 4
+  for (int r = 0; r < g.R; ++r) {
+    const double a = full[r * g.K + c] * width * 0.5;       // (I_hat * d) / 2, the reference's scaling
+#pragma unroll
+    for (int k = 0; k < NM; ++k) mu[k] += a * lam[k * PK_WAVE + r];
+  }
+}
+template <class P, int G>
+__device__ __forceinline__ void hessc_passes_wide(const PkArgs& A, const PkPhase& ph, const PkTile& tl, const TileGeom& g,
+                                                  const TileTabs& T, const double* s, double dt, double mt, const PkSys& sy,
+                                                  double* __restrict__ lam_s, const long long* __restrict__ segb, int lane,
+                                                  int sub = 0, int stride = 0) {
+  if constexpr (G < P::HC_NG) {
+    if (stride == 0 || G % stride == sub) {
+    constexpr int C0 = P::HC_c0(G), CN = P::HC_cn(G), NM = P::HC_nmu(G), NMD = NM > 0 ? NM : 1;
+    const int q = tl.q0 + lane;
+    const int row = min(tl.r0 + lane, ph.L_d - 1);
+    double a[P::NARG], tau, w, lp[P::NC > 0 ? P::NC : 1], lrow[NMD], mu[NMD];
+#pragma unroll
+    for (int k = 0; k < NM; ++k) lrow[k] = A.lam[ph.g_off + P::HC_mus(G, k) * ph.L_d + row];
+    load_node<P>(A, ph, s, dt, mt, q, a, tau, w);
+#pragma unroll
+    for (int j = 0; j < P::NC; ++j) lp[j] = A.lam[ph.path_off + j * ph.L_m + min(q, ph.L_m - 1)];
+#pragma unroll
+    for (int k = 0; k < NM; ++k) lam_s[k * PK_WAVE + lane] = lrow[k];
+    wave_lds_sync();
+    if (lane < g.nown && q >= ph.mid_lo && q < ph.mid_hi) {
+      const int jj = min(magic_div((uint32_t)lane, tl.magicR), max(tl.nj - 1, 0)), c = lane - jj * g.stride;
+#pragma unroll
+      for (int k = 0; k < NM; ++k) mu[k] = 0.0;
+      if (T.staged) tile_mu_n<P, true, NM>(A, ph, tl, g, T, lam_s, jj, c, mu);
+      else tile_mu_n<P, false, NM>(A, ph, tl, g, T, lam_s, jj, c, mu);
+      if (P::SCHEME == 1 && c == 0 && tl.j0 + jj > 0) {       // LGL: a mesh point also closes the interval before it
+        if (jj > 0) {
+          if (T.staged) tile_mu_n<P, true, NM>(A, ph, tl, g, T, lam_s, jj - 1, g.K - 1, mu);
+          else tile_mu_n<P, false, NM>(A, ph, tl, g, T, lam_s, jj - 1, g.K - 1, mu);
+        } else {                                              // (that interval belongs to the tile before this one)
+          const int32_t* __restrict__ ivK = A.ib + ph.ivK_off;
+          const int32_t* __restrict__ ivF = A.ib + ph.ivfull_off;
+          const int32_t* __restrict__ ivL = A.ib + ph.ivld_off;
+          const int jp = tl.j0 - 1;
+          interval_mu_l<P, G>(A, ph, ivK[jp], A.db + ivF[jp], A.db[ph.width_off + jp], ivL[jp], ivK[jp] - 1, mu);
+        }
+      }
+      double o[CN + 1];
+      P::mid_hessc_g(Grp<G>{}, a, tau, dt, w, sy, lp, mu, nullptr, nullptr, o);
+#pragma unroll
+      for (int e = 0; e < CN; ++e) put(&A.o_hess[segb[C0 + e] + (q - ph.mid_lo)], o[e]);
+    }
+    wave_lds_sync();                        // (the next pass overwrites the rows this one read)
+    }
+    hessc_passes_wide<P, G + 1>(A, ph, tl, g, T, s, dt, mt, sy, lam_s, segb, lane, sub, stride);
+  }
+}
+#ifdef PK_BIG
+// ... and of an interval with more points than a wave has lanes (alone in its tile): 64 nodes at a time, global-memory form
+template <class P, int G>
+__device__ __forceinline__ void hessc_big_wide(const PkArgs& A, const PkPhase& ph, const PkTile& tl, const TileGeom& g,
+                                               const double* s, double dt, double mt, const PkSys& sy,
+                                               const long long* __restrict__ segb, int lane) {
+  if constexpr (G < P::HC_NG) {
+    constexpr int C0 = P::HC_c0(G), CN = P::HC_cn(G), NM = P::HC_nmu(G);
+    for (int c = lane; c < g.nown; c += PK_WAVE) {
+      const int q = tl.q0 + c;
+      if (q >= ph.mid_lo && q < ph.mid_hi) {
+        double a[P::NARG], tau, w, lp[P::NC > 0 ? P::NC : 1], mu[NM > 0 ? NM : 1], o[CN + 1];
+        load_node<P>(A, ph, s, dt, mt, q, a, tau, w);
+#pragma unroll
+        for (int j = 0; j < P::NC; ++j) lp[j] = A.lam[ph.path_off + j * ph.L_m + q];
+        const int jj = c / g.stride;
+        node_mu_l<P, G>(A, ph, tl.j0 + jj, c - jj * g.stride, mu);
+        P::mid_hessc_g(Grp<G>{}, a, tau, dt, w, sy, lp, mu, nullptr, nullptr, o);
+#pragma unroll
+        for (int e = 0; e < CN; ++e) put(&A.o_hess[segb[C0 + e] + (q - ph.mid_lo)], o[e]);
+      }
+    }
+    hessc_big_wide<P, G + 1>(A, ph, tl, g, s, dt, mt, sy, segb, lane);
+  }
+}
+#endif
 
 // One wave per tile: lane = node.  The tile's rows of the defect multipliers (lane = row, coalesced) and its integration
 // block are staged in LDS while the node loads are in flight, so the K-term contraction per node and state reads LDS only
@@ -2270,8 +2506,10 @@ __device__ __forceinline__ void hessc_chunks(const PkArgs& A, const PkPhase& ph,
 // 64 nodes at a time with the global-memory form.
 template <class P>
 __device__ __forceinline__ void tile_hessc(const PkArgs& A, const PkTile& tl, double* __restrict__ lam_s,
-                                           double* __restrict__, double* __restrict__, int lane) {
+                                           double* __restrict__, double* __restrict__, int lane, int sub = 0, int stride = 0) {
   if (P::HC_NN == 0) return;
+  if (stride > 0 && (sub >= P::HC_NG || (tl.K > PK_WAVE && sub > 0))) return;      // (no chunk left for this workgroup; an interval
+  if (tl.K > PK_WAVE) stride = 0;                                                  //  with more than 64 points: all chunks in one)
   const PkPhase& ph = A.ph[P::INDEX];
   const TileGeom g = tile_geom<P>(tl);
   double s[PK_NS], dt, mt;
@@ -2281,8 +2519,20 @@ __device__ __forceinline__ void tile_hessc(const PkArgs& A, const PkTile& tl, do
   // broadcast ds_read at every store).  As scalar loads -- an SGPR pair per output, all hoisted to the top by the scheduler --
   // they spilled 40 SGPRs and cost the kernel a private segment; held in a VGPR pair and handed over by v_readlane they
   // were hoisted just the same (123 SGPR spills).
-  long long* __restrict__ segb = reinterpret_cast<long long*>(lam_s + P::NX * PK_WAVE);
-  for (int e = lane; e < P::HC_NN; e += PK_WAVE) segb[e] = (long long)A.lb[ph.hcseg_off + e];
+  long long* __restrict__ segb = reinterpret_cast<long long*>(lam_s + P::HC_LROWS * PK_WAVE);      // (HC_LROWS: NX, or -- WIDE -- the
+  for (int e = lane; e < P::HC_NN; e += PK_WAVE) segb[e] = (long long)A.lb[ph.hcseg_off + e];      //  most states a pass refers to)
+  if constexpr (P::WIDE) {
+#ifdef PK_BIG
+    if (tl.K > PK_WAVE) {
+      wave_lds_sync();
+      return hessc_big_wide<P, 0>(A, ph, tl, g, s, dt, mt, sy, segb, lane);
+    }
+#endif
+    const bool fitw = tabs_fit(A, tl, g);
+    const TabRegs trw = tabs_issue(A, ph, tl, g, fitw, lane);
+    const TileTabs Tw = tabs_commit(A, tl, g, trw, fitw, lane);
+    return hessc_passes_wide<P, 0>(A, ph, tl, g, Tw, s, dt, mt, sy, lam_s, segb, lane, sub, stride);
+  }
 #ifdef PK_BIG      // (such intervals exist only on meshes whose code object is generated with PK_BIG)
   if (tl.K > PK_WAVE) {
     wave_lds_sync();
@@ -2334,7 +2584,12 @@ __device__ __forceinline__ void tile_hessc(const PkArgs& A, const PkTile& tl, do
       interval_mu<P>(A, ph, ivK[jp], A.db + ivF[jp], A.db[ph.width_off + jp], ivL[jp], ivK[jp] - 1, mu);
     }
   }
-  hessc_chunks<P, 0>(A, ph, segb, a, tau, dt, w, sy, lp, mu, q);
+  hessc_chunks<P, 0>(A, ph, segb, a, tau, dt, w, sy, lp, mu, q, sub, stride);
+}
+template <class P>
+__device__ __forceinline__ void tile_hessc_part(int sub, int stride, const PkArgs& A, const PkTile& tl, double* __restrict__ lam_s,
+                                                int lane) {
+  tile_hessc<P>(A, tl, lam_s, nullptr, nullptr, lane, sub, stride);
 }
 
 // boundary node of the compact Hessian: also the contracted multipliers of the boundary columns
@@ -2572,22 +2827,47 @@ __device__ __forceinline__ void kernel_hess(const PkArgs& A) {
   }
 }
 
+// (a model evaluated in groups, Gen::GROUPED: every pass of a tile block is a workgroup of its own, as in pk_hess -- the grid
+//  has HC_NGMAX / JC_NGMAX workgroups per block: md.hessc_subs / md.jacc_subs)
 template <class Gen>
 __device__ __forceinline__ void kernel_hessc(const PkArgs& A) {
   if (PK_IS_EDGE_BLOCK()) return edge_block<Gen>(A, 3, false, A.items, A.n_items);
-  PK_TILE_PROLOGUE(1);
-  Gen::tile_hessc(tl.phase, A, tl, PK_STAGE(A) + wave * Gen::LDS_G, wint, wgrad, lane);
+  if constexpr (Gen::GROUPED && Gen::HC_NGMAX > 1) {
+    constexpr int NP = Gen::HC_NGMAX;
+    const int slot = pk::xcd_tile_block((int)blockIdx.x, 1, (int)gridDim.x);
+    const int blk = slot / NP, pass = slot - blk * NP;
+    PK_TILE_PROLOGUE_AT();
+    Gen::tile_hesscp(tl.phase, pass, NP, A, tl, PK_STAGE(A) + wave * Gen::LDS_G, lane);
+  } else {
+    PK_TILE_PROLOGUE(1);
+    Gen::tile_hessc(tl.phase, A, tl, PK_STAGE(A) + wave * Gen::LDS_G, wint, wgrad, lane);
+  }
 }
 
 template <class Gen>
 __device__ __forceinline__ void kernel_jacc(const PkArgs& A) {
   if (PK_IS_EDGE_BLOCK()) return edge_block<Gen>(A, 4, false, A.items, A.n_items);
-  PK_TILE_PROLOGUE(1);
+  if constexpr (Gen::GROUPED && Gen::JC_NGMAX > 1) {
+    constexpr int NP = Gen::JC_NGMAX;
+    const int slot = pk::xcd_tile_block((int)blockIdx.x, 1, (int)gridDim.x);
+    const int blk = slot / NP, pass = slot - blk * NP;
+    PK_TILE_PROLOGUE_AT();
 #ifdef PK_BIG
-  PkTile tl0;
-  if (big_block(A.tile, A.n_tiles, blk, tl0)) return Gen::bigjc(tl0.phase, A, tl0, PK_STAGE(A));
+    PkTile tl0;
+    if (big_block(A.tile, A.n_tiles, blk, tl0)) {      // (a workgroup-wide interval walks its passes itself)
+      if (pass == 0) Gen::bigjc(tl0.phase, A, tl0, PK_STAGE(A));
+      return;
+    }
 #endif
-  Gen::tile_jacc(tl.phase, A, tl, PK_STAGE(A) + wave * Gen::LDS_JC, wint, wgrad, lane);
+    Gen::tile_jaccp(tl.phase, pass, NP, A, tl, PK_STAGE(A) + wave * Gen::LDS_JC, lane);
+  } else {
+    PK_TILE_PROLOGUE(1);
+#ifdef PK_BIG
+    PkTile tl0;
+    if (big_block(A.tile, A.n_tiles, blk, tl0)) return Gen::bigjc(tl0.phase, A, tl0, PK_STAGE(A));
+#endif
+    Gen::tile_jacc(tl.phase, A, tl, PK_STAGE(A) + wave * Gen::LDS_JC, wint, wgrad, lane);
+  }
 }
 
 template <class Gen>
@@ -2610,11 +2890,132 @@ __device__ __forceinline__ void kernel_aux(const PkArgs& A) {
 // the integral-form collocation equation on the augmented rule are written out:  T_aug x  and  dt (I_aug d/2) f.  The
 // host compares them per interval (np.allclose semantics) and runs the hp-refinement logic (pockit_amd/refine.py).
 // LDS per wave: (2 NX + NU) x 64 doubles, private to the wave (no workgroup barrier between the three steps).
+// ---- the same for a WIDE model (P::WIDE), in passes over chunks of states (see dyn_pass): a pass interpolates the node
+// arguments ITS dynamics functions read straight from x (the K + 1 values of an interval are shared by its lanes: cache hits;
+// what the pass does not read is dead code), stages the chunk's dynamics values -- D_cn rows instead of 2 n_x + n_u -- and writes
+// the chunk's rows of both sides.  Same sums in the same order as interval_err.
+template <class P>
+__device__ __forceinline__ double err_x(const PkPhase& ph, const double* __restrict__ xp, const double* s, int i, int slot,
+                                        int back_slot) {
+  double v = xp[i * ph.state_len + slot];
+  if (slot == 0) v = P::front_value(i, v, s);
+  if (slot == back_slot) v = P::back_value(i, v, s);
+  return v;
+}
+// the node arguments chunk C's dynamics functions read (codegen.py: P::D_na(C) of them, argument P::D_ar(C, k) -- states and
+// controls only; time and static parameters are always set), interpolated to augmented node a.  Short constant-index loops:
+// a loop over ALL states around a model-sized switch was left rolled by the compiler, and the argument array went to scratch.
+template <class P, int C>
+__device__ __forceinline__ void err_args(const PkArgs& A, const PkPhase& ph, const PkErrIv& iv, const double* s, double dt,
+                                         double mt, int a, double* arg) {
+  constexpr int NA = P::D_na(C);
+  const int K = iv.K, ncx = K + 1 - P::SCHEME, na = K + 1;
+  const double* __restrict__ Vx = A.errdb + iv.tab_off;
+  const double* __restrict__ Vu = Vx + na * ncx;
+  const double* __restrict__ xp = A.x + ph.x_off;
+  const double* __restrict__ up = xp + P::NX * ph.state_len;
+  const int back_slot = P::SCHEME ? ph.L_m - 1 : ph.L_m;
+  double acc[NA > 0 ? NA : 1];
+#pragma unroll
+  for (int k = 0; k < NA; ++k) acc[k] = 0.0;
+  for (int c = 0; c < ncx; ++c) {
+    const double v = Vx[a * ncx + c];
+#pragma unroll
+    for (int k = 0; k < NA; ++k)
+      if (P::D_ar(C, k) < P::NX) acc[k] += v * err_x<P>(ph, xp, s, P::D_ar(C, k), iv.lm + c, back_slot);
+  }
+  for (int c = 0; c < K; ++c) {
+    const double v = Vu[a * K + c];
+#pragma unroll
+    for (int k = 0; k < NA; ++k)
+      if (P::D_ar(C, k) >= P::NX) acc[k] += v * up[(P::D_ar(C, k) - P::NX) * ph.L_m + iv.lm + c];
+  }
+#pragma unroll
+  for (int k = 0; k < NA; ++k) arg[P::D_ar(C, k)] = acc[k];
+  const double tau = A.errdb[iv.tau_off + a];
+  arg[P::NX + P::NU] = (tau - 0.5) * dt + mt;
+#pragma unroll
+  for (int i = 0; i < P::NS; ++i) arg[P::NX + P::NU + 1 + i] = s[i];
+}
+// rows of both sides of one chunk of states at augmented row a (fs: the chunk's dynamics values, row length `ld`)
+template <class P, int C>
+__device__ __forceinline__ void err_rows(const PkArgs& A, const PkPhase& ph, const PkErrIv& iv, const double* s, double dt,
+                                         int a, const double* __restrict__ fs, int ld) {
+  constexpr int I0 = P::D_c0(C), CN = P::D_cn(C);
+  const int K = iv.K, ncx = K + 1 - P::SCHEME, na = K + 1, nr = K + 1 - P::SCHEME;
+  const double* __restrict__ Tm = A.errdb + iv.tab_off + na * ncx + na * K;
+  const double* __restrict__ Im = Tm + nr * ncx;
+  const double* __restrict__ xp = A.x + ph.x_off;
+  const int back_slot = P::SCHEME ? ph.L_m - 1 : ph.L_m;
+  double tx[CN], itf[CN];
+#pragma unroll
+  for (int e = 0; e < CN; ++e) tx[e] = itf[e] = 0.0;
+  for (int c = 0; c < ncx; ++c) {
+    const double v = Tm[a * ncx + c];
+#pragma unroll
+    for (int e = 0; e < CN; ++e) tx[e] += v * err_x<P>(ph, xp, s, I0 + e, iv.lm + c, back_slot);
+  }
+  for (int c = 0; c < na; ++c) {
+    const double v = Im[a * na + c] * iv.width * 0.5;
+#pragma unroll
+    for (int e = 0; e < CN; ++e) itf[e] += v * fs[e * ld + c];
+  }
+#pragma unroll
+  for (int e = 0; e < CN; ++e) {
+    const int64_t pos = iv.out_off + (int64_t)(I0 + e) * iv.rows + iv.row0 + a;
+    put(&A.o_errT[pos], tx[e]);
+    put(&A.o_errI[pos], itf[e] * dt);
+  }
+}
+template <class P, int C = 0>
+__device__ __forceinline__ void err_passes_wide(const PkArgs& A, const PkPhase& ph, const PkErrIv& iv, const double* s,
+                                                double dt, double mt, bool valid, int a, double* __restrict__ fs) {
+  if constexpr (C < P::D_NG) {
+    constexpr int CN = P::D_cn(C);
+    if (valid) {
+      double arg[P::NARG], o[CN];
+      err_args<P, C>(A, ph, iv, s, dt, mt, a, arg);
+      P::mid_dyn_g(Grp<C>{}, arg, o);
+#pragma unroll
+      for (int e = 0; e < CN; ++e) fs[e * PK_WAVE + a] = o[e];
+    }
+    wave_lds_sync();       // (a wave stages for itself only)
+    if (valid && a < iv.K + 1 - P::SCHEME) err_rows<P, C>(A, ph, iv, s, dt, a, fs, PK_WAVE);
+    wave_lds_sync();       // (the next pass overwrites the rows)
+    err_passes_wide<P, C + 1>(A, ph, iv, s, dt, mt, valid, a, fs);
+  }
+}
+template <class P, int C = 0>
+__device__ __forceinline__ void err_big_passes_wide(const PkArgs& A, const PkPhase& ph, const PkErrIv& iv, const double* s,
+                                                    double dt, double mt, double* __restrict__ fs, int ld) {
+  if constexpr (C < P::D_NG) {
+    constexpr int CN = P::D_cn(C);
+    const int na = iv.K + 1, nr = iv.K + 1 - P::SCHEME;
+    for (int a = (int)threadIdx.x; a < na; a += PK_BLOCK) {
+      double arg[P::NARG], o[CN];
+      err_args<P, C>(A, ph, iv, s, dt, mt, a, arg);
+      P::mid_dyn_g(Grp<C>{}, arg, o);
+#pragma unroll
+      for (int e = 0; e < CN; ++e) fs[e * ld + a] = o[e];
+    }
+    __syncthreads();
+    for (int a = (int)threadIdx.x; a < nr; a += PK_BLOCK) err_rows<P, C>(A, ph, iv, s, dt, a, fs, ld);
+    __syncthreads();
+    err_big_passes_wide<P, C + 1>(A, ph, iv, s, dt, mt, fs, ld);
+  }
+}
+
 template <class P>
 __device__ __forceinline__ void interval_err(const PkArgs& A, int first, int cnt, double* __restrict__ lds, int lane) {
   const PkPhase& ph = A.ph[P::INDEX];
   double s[PK_NS], dt, mt;
   phase_scalars<P>(A, ph, s, dt, mt);
+  if constexpr (P::WIDE) {
+    const int W0 = A.erriv[first].K + 1, jj0 = lane / W0, a0 = lane - jj0 * W0;
+    const bool valid0 = jj0 < cnt;
+    const PkErrIv iv0 = A.erriv[first + (valid0 ? jj0 : 0)];
+    return err_passes_wide<P>(A, ph, iv0, s, dt, mt, valid0, a0, lds + jj0 * W0);
+  }
   const int K = A.erriv[first].K;                       // wave-uniform (all intervals of a group share phase and K)
   const int W = K + 1;
   const int jj = lane / W, a = lane - jj * W;           // interval of the group, augmented node / row / slot within it
@@ -2710,6 +3111,7 @@ __device__ __forceinline__ void interval_err_big(const PkArgs& A, int first, dou
   const bool in_lds = na <= PK_ERR_BIG_LDS_ROW;
   const int PK_ERR_BIG_ROW = in_lds ? PK_ERR_BIG_LDS_ROW : A.big_row;
   double* __restrict__ lds = in_lds ? lds0 : A.big_stage + (size_t)iv.stage * (size_t)A.big_slot;
+  if constexpr (P::WIDE) return err_big_passes_wide<P>(A, ph, iv, s, dt, mt, lds, PK_ERR_BIG_ROW);
   const double* __restrict__ Vx = A.errdb + iv.tab_off;
   const double* __restrict__ Vu = Vx + na * ncx;
   const double* __restrict__ Tm = Vu + na * K;
@@ -2998,7 +3400,6 @@ __device__ __forceinline__ void kernel_xall(const PkArgs& A) {
 template <class Gen, bool COMPACT>
 __device__ __forceinline__ void kernel_cycle(const PkTile* pre_tile, int pre_n_tiles, int pre_flags, int pre_grid,
                                              const PkArgs& A) {
-#if PK_KA_LAZY
   // The waves read their PkArgs fields where they use them (PK_DEFINE_KERNELS).  The kernarg segment is new with every
   // launch: every 64-byte line of it is a scalar-cache miss the first time a wave of the CU asks, and read one after
   // the other those misses would follow each other down the wave's serial chain.  One dword of every line is requested
@@ -3018,9 +3419,6 @@ __device__ __forceinline__ void kernel_cycle(const PkTile* pre_tile, int pre_n_t
     _Pragma("unroll") for (int o = 0; o < ka_lines; ++o) ka_acc |= ka_v[o];    \
     asm volatile("" ::"s"(ka_acc));                                            \
   }
-#else
-#define PK_KA_COLLECT()
-#endif
   if (blockIdx.x < 2 && PK_DIAG(2048)) return;     // diagnostic switches (POCKIT_AMD_DEBUG_FLAGS): no boundary work,
   if (blockIdx.x == 2 && PK_DIAG(65536)) return;   // no finalize workgroup (the hand-off slots then stay filled)
   if (blockIdx.x < 3) {
@@ -3048,13 +3446,15 @@ __device__ __forceinline__ void kernel_cycle(const PkTile* pre_tile, int pre_n_t
   }
   const int slot = pk::xcd_tile_block((int)blockIdx.x, 3, pre_grid);
   if constexpr (Gen::GROUPED) {
-    // A model evaluated in groups: the workgroups of a tile block are [Jacobian pass 0 .. NJ-1 | values | Hessian pass 0 .. NH-1]
-    // (NJ / NH: the most passes any phase has; a phase with fewer leaves the surplus workgroups at once).
-    constexpr int NJ = Gen::J_NGMAX, NH = Gen::H_NGMAX, PER = 1 + NJ + NH;
+    // A model evaluated in groups: the workgroups of a tile block are [Jacobian pass 0 .. NJ-1 | values | dynamics pass 0 ..
+    // ND-1 (a WIDE model's chunks of states, tile_dyn_pick) | Hessian pass 0 .. NH-1]  (NJ / ND / NH: the most passes any
+    // phase has; a phase with fewer leaves the surplus workgroups at once).
+    constexpr int NJ = Gen::J_NGMAX, ND = Gen::D_NGMAX, NH = Gen::H_NGMAX, PER = 1 + NJ + ND + NH;
     const int blk = slot / PER, sub = slot - blk * PER;
-    if ((pre_flags & 128) && sub > NJ) return;            // (x-only launch: no Hessian)
+    if ((pre_flags & 128) && sub > NJ + ND) return;       // (x-only launch: no Hessian)
     const bool ch = COMPACT && (pre_flags & 256) != 0, cj = COMPACT && (pre_flags & 512) != 0;
-    if ((cj && sub > 0 && sub < NJ) || (ch && sub > NJ + 1)) return;      // (the compact roles run their passes in one wave)
+    // (the compact roles are pass-parallel too: the role's workgroups share its passes round robin -- tile_jacc_part,
+    //  tile_hessc_part -- a compact layout may have more or fewer passes than the reference layout's role has workgroups)
     PK_TILE_PROLOGUE_FROM(pre_tile, pre_n_tiles);
     PK_KA_COLLECT();
 #ifdef PK_BIG
@@ -3062,19 +3462,21 @@ __device__ __forceinline__ void kernel_cycle(const PkTile* pre_tile, int pre_n_t
     if (big_block(pre_tile, pre_n_tiles, blk, tl0)) {     // (a workgroup-wide interval: its roles walk their passes themselves)
       if (sub == 0) Gen::bigx2(tl0.phase, A, tl0, PK_STAGE(A), wint, wgrad, -1);
       else if (sub == NJ) Gen::bigx1(tl0.phase, A, tl0, PK_STAGE(A), wint, wgrad, blk);
-      else if (sub == NJ + 1) Gen::bigh(tl0.phase, A, tl0, PK_STAGE(A));
+      else if (sub == NJ + ND + 1) Gen::bigh(tl0.phase, A, tl0, PK_STAGE(A));
       return;
     }
 #endif
     if (sub < NJ) {
-      if (cj) Gen::tile_jacc(tl.phase, A, tl, PK_STAGE(A) + wave * Gen::LDS_X, wint, wgrad, lane);
+      if (cj) Gen::tile_jaccp(tl.phase, sub, NJ, A, tl, PK_STAGE(A) + wave * Gen::LDS_X, lane);
       else Gen::tile_jacg(tl.phase, sub, A, tl, PK_STAGE(A) + wave * Gen::LDS_X, lane);
     } else if (sub == NJ) {
-      if (cj) Gen::tile_xall1c(tl.phase, A, tl, PK_STAGE(A) + wave * Gen::LDS_X, wint + wave * PK_NRED, wgrad + wave * PK_NRED, lane, blk);
-      else Gen::tile_xall1(tl.phase, A, tl, PK_STAGE(A) + wave * Gen::LDS_X, wint + wave * PK_NRED, wgrad + wave * PK_NRED, lane, blk);
+      if (cj) Gen::tile_xall1cp(tl.phase, A, tl, PK_STAGE(A) + wave * Gen::LDS_X, wint + wave * PK_NRED, wgrad + wave * PK_NRED, lane, blk);
+      else Gen::tile_xall1p(tl.phase, A, tl, PK_STAGE(A) + wave * Gen::LDS_X, wint + wave * PK_NRED, wgrad + wave * PK_NRED, lane, blk);
+    } else if (sub <= NJ + ND) {
+      Gen::tile_dyn(tl.phase, sub - NJ - 1, A, tl, PK_STAGE(A) + wave * Gen::LDS_X, lane);
     } else {
-      if (ch) Gen::tile_hessc(tl.phase, A, tl, PK_STAGE(A) + wave * Gen::LDS_G, wint, wgrad, lane);
-      else Gen::tile_hessg(tl.phase, sub - NJ - 1, A, tl, PK_STAGE(A) + wave * Gen::LDS_H, lane);
+      if (ch) Gen::tile_hesscp(tl.phase, sub - NJ - ND - 1, NH, A, tl, PK_STAGE(A) + wave * Gen::LDS_G, lane);
+      else Gen::tile_hessg(tl.phase, sub - NJ - ND - 1, A, tl, PK_STAGE(A) + wave * Gen::LDS_H, lane);
     }
     return;
   }
@@ -3432,7 +3834,7 @@ __device__ __forceinline__ void kernel_fin(const PkArgs& A) {
 
 }  // namespace pk
 
-/* PK_KA_LAZY: the PkArgs are read from the kernarg segment where a wave uses them, not en bloc on entry.  As a by-value
+/* pk_cycle's PkArgs are read from the kernarg segment where a wave uses them, not en bloc on entry.  As a by-value
    argument every field any path of the kernel touches is loaded in the entry block and stays live (100 SGPRs, spills to VGPR
    lanes, scalar waits in front of the tile-record load); read lazily a tile wave loads what its phase and role need (60
    SGPRs).  Two-phase rocket: 158k -> 193k cycles/s.  &A of a by-value kernel argument IS its place in the kernarg segment
@@ -3442,7 +3844,7 @@ __device__ __forceinline__ void kernel_fin(const PkArgs& A) {
                                                               int32_t pre_flags, int32_t pre_grid, PkArgs A) {     \
     const PkArgs PK_CONST_AS* A_ = (const PkArgs PK_CONST_AS*)(                                                    \
         (const char PK_CONST_AS*)__builtin_amdgcn_kernarg_segment_ptr() + PK_CYCLE_ARGS_OFFSET);                   \
-    pk::kernel_cycle<GEN, COMPACT>(pre_tile, pre_n_tiles, pre_flags, pre_grid, PK_KA_LAZY ? *(const PkArgs*)A_ : A); \
+    pk::kernel_cycle<GEN, COMPACT>(pre_tile, pre_n_tiles, pre_flags, pre_grid, *(const PkArgs*)A_);                  \
   }
 
 #define PK_DEFINE_KERNELS(GEN)                                                                         \

@@ -76,7 +76,6 @@ struct pk_ctx {
   bool xc_inline = false;       // pk_cycle's finalize workgroup exchanges the partial sums itself (pk_set_exchange_inline)
   bool split_xall = false;      // pk_xall with two waves per tile (values / Jacobian), see pk_set_problem
   int cycle_mode = 1;           // 1: single-launch pk_cycle; 0: pk_xall + pk_hess (pk_set_cycle_mode)
-  bool static_tabs = false;     // A/B (POCKIT_AMD_STATIC_TABS=1): the code object keeps its table blocks in static LDS
   bool has_big = false;         // the mesh has intervals with more than 64 points (one workgroup each, PK_BIG code objects)
   // staging rows of intervals with more than 256 points (they do not fit the workgroup's LDS rows): slots in device memory
   double *d_big_stage = nullptr, *d_err_stage = nullptr;
@@ -338,8 +337,7 @@ int launch_raw(pk_ctx* c, int k, void* args, size_t sz, unsigned grid, size_t ld
   EventPair ev{};
   if (grid == 0) return 0;
   // the tile kernels that stage their pattern tables keep one table block per wave in front of the model's staging area
-  if ((k == K_G || k == K_JAC || k == K_HESS || k == K_XALL || k == K_CYCLE || k == K_CYCLEC || k == K_JACC || k == K_HESSC) &&
-      !c->static_tabs)
+  if (k == K_G || k == K_JAC || k == K_HESS || k == K_XALL || k == K_CYCLE || k == K_CYCLEC || k == K_JACC || k == K_HESSC)
     lds_bytes += sizeof(double) * PK_WAVES_PER_BLOCK * (size_t)(2 * c->md.tab_cap + 2 * PK_WAVE + c->md.tab_cap / 2);
   if ((k == K_CYCLE || k == K_CYCLEC) && c->xc_inline && c->xc_world > 1 && lds_bytes < sizeof(double) * 2 * 512)
     lds_bytes = sizeof(double) * 2 * 512;      // the finalize workgroup's exchange vectors (2 x PK_XC_CAP doubles)
@@ -549,7 +547,9 @@ int handoff_check(pk_ctx* c) {
   const unsigned long long a = st[0], b = st[1];
   if (a == c->status_seen[0] && b == c->status_seen[1]) return 0;
   const unsigned long long da = a - c->status_seen[0], db = b - c->status_seen[1];
-  (void)hipStreamSynchronize(c->stream);
+  // (rare path: the device, not only the context's stream -- pk_sync / pk_wait_idle come here for a caller's stream too, and
+  //  cycles still in flight on it must not race with the reset of the hand-off slots below)
+  (void)hipDeviceSynchronize();
   if (c->d_cpart && c->cpart_slots) {
     const std::vector<unsigned long long> empty(c->cpart_slots, (unsigned long long)PK_EMPTY);
     (void)hipMemcpy(c->d_cpart, empty.data(), sizeof(unsigned long long) * c->cpart_slots, hipMemcpyHostToDevice);
@@ -778,7 +778,6 @@ int pk_create(pk_ctx** out, int device_id) {
   if (device_id < 0 || device_id >= ndev) return fail(nullptr, 11, "pk_create: device %d out of range [0,%d)", device_id, ndev);
   pk_ctx* c = new pk_ctx();
   c->device = device_id;
-  if (const char* st = getenv("POCKIT_AMD_STATIC_TABS")) c->static_tabs = atoi(st) != 0;
   if (const char* dbg = getenv("POCKIT_AMD_DEBUG_FLAGS")) c->debug_flags = atoi(dbg) & (256 | 512 | 1024 | 2048 | 4096 | 8192 | 16384 | 32768 | 65536 | 131072);
   if ((e = hipSetDevice(device_id)) != hipSuccess || (e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)) != hipSuccess) {
     int rc = fail(nullptr, 12, "pk_create: %s", hipGetErrorString(e));
@@ -816,14 +815,21 @@ int pk_load_model(pk_ctx* c, const void* code_object, size_t len, const pk_model
   if (md->cycle_subs < 0 || md->cycle_subs > 4096) return fail(c, 25, "pk_load_model: cycle_subs %d", md->cycle_subs);
   if (md->hess_subs < 0 || md->hess_subs > 4096 || (md->hess_subs > 0) != (md->cycle_subs > 0))
     return fail(c, 25, "pk_load_model: hess_subs %d with cycle_subs %d", md->hess_subs, md->cycle_subs);
+  if (md->hessc_subs < 0 || md->hessc_subs > 4096 || md->jacc_subs < 0 || md->jacc_subs > 4096 ||
+      ((md->hessc_subs > 0 || md->jacc_subs > 0) && md->cycle_subs == 0))
+    return fail(c, 25, "pk_load_model: hessc_subs %d / jacc_subs %d with cycle_subs %d", md->hessc_subs, md->jacc_subs, md->cycle_subs);
   if (md->max_phases < 0 || md->max_phases > PK_HOST_MAX_PHASES || md->n_phase > (md->max_phases > 0 ? md->max_phases : 8))
     return fail(c, 24, "pk_load_model: %d phases, code object compiled for %d (the library passes at most %d phase records in "
                        "the kernel arguments)", md->n_phase, md->max_phases > 0 ? md->max_phases : 8, PK_HOST_MAX_PHASES);
+  // what a launch will ask for (launch_raw): the model's staging rows of the workgroup's waves + their table blocks -- the
+  // same bytes pockit_amd.codegen.ModelSource.launch_lds_bytes counts when it chooses the group size
   const size_t lds_max = 160 * 1024;
-  const size_t need[4] = {(size_t)md->lds_g, (size_t)md->lds_j, (size_t)md->lds_h, (size_t)md->lds_x};
+  const size_t tab = sizeof(double) * PK_WAVES_PER_BLOCK * (size_t)(2 * md->tab_cap + 2 * PK_WAVE + md->tab_cap / 2);
+  const size_t need[5] = {(size_t)md->lds_g, (size_t)md->lds_j, (size_t)md->lds_h, (size_t)md->lds_x, (size_t)md->lds_jc};
   for (size_t v : need)
-    if (v * PK_WAVES_PER_BLOCK * sizeof(double) > lds_max)
-      return fail(c, 21, "pk_load_model: model needs %zu bytes of LDS per workgroup (> 160 KiB)", v * PK_WAVES_PER_BLOCK * sizeof(double));
+    if (v * PK_WAVES_PER_BLOCK * sizeof(double) + tab > lds_max)
+      return fail(c, 21, "pk_load_model: model needs %zu bytes of LDS per workgroup (> 160 KiB)",
+                  v * PK_WAVES_PER_BLOCK * sizeof(double) + tab);
   c->have_model = true;
   return 0;
 }
@@ -1105,7 +1111,7 @@ int pk_eval_hessc_dev(pk_ctx* c, const double* d_x, const double* d_lam, double 
   A.n_items = c->n_items_hessc;
   size_t lds = sizeof(double) * PK_WAVES_PER_BLOCK * (size_t)c->md.lds_g;      // the tile's multiplier rows, [state][row]
   if (lds < sizeof(double) * (size_t)c->md.ne_hc) lds = sizeof(double) * (size_t)c->md.ne_hc;
-  return launch(c, K_HESSC, A, tile_blocks(c) + 1, lds, st);
+  return launch(c, K_HESSC, A, tile_blocks(c) * (c->md.hessc_subs > 0 ? (unsigned)c->md.hessc_subs : 1u) + 1, lds, st);
 }
 
 // compact (coalesced) Jacobian: dense-column entries of the dynamics contracted with the integration block first
@@ -1121,7 +1127,7 @@ int pk_eval_jacc_dev(pk_ctx* c, const double* d_x, double* d_vals, void* stream)
   A.n_items = c->n_items_jacc;
   size_t lds = sizeof(double) * PK_WAVES_PER_BLOCK * (size_t)c->md.lds_jc;
   if (lds < sizeof(double) * (size_t)c->md.ne_jc) lds = sizeof(double) * (size_t)c->md.ne_jc;
-  return launch(c, K_JACC, A, tile_blocks(c) + 1, lds, st);
+  return launch(c, K_JACC, A, tile_blocks(c) * (c->md.jacc_subs > 0 ? (unsigned)c->md.jacc_subs : 1u) + 1, lds, st);
 }
 
 int pk_eval_jacc(pk_ctx* c, const double* x, double* vals) {

@@ -29,11 +29,9 @@ def _intervals_per_wave(plan, override=None, shards=1, subs=0, want_workgroups=F
     instructions a CU has to issue and by the time the dispatcher needs to start the waves, so fuller waves
     (18-42 nodes: 126-133k cycles/s) beat many small ones (12 nodes: 114k, 6 nodes: 81k) as long as every CU
     still gets work; the 40k-node humanoid runs best with full 64-node waves."""
-    if override:
-        return int(override)
-    env = os.environ.get("POCKIT_AMD_IPW")
-    if env:
-        return int(env)
+    forced = override or os.environ.get("POCKIT_AMD_IPW")        # (tests / sweeps: tools/ipw_sweep.sh)
+    if forced and not want_workgroups:
+        return int(forced)
     # Candidates from ~16 nodes per wave (on small meshes a wave of 6-8 nodes pays its fixed work -- tile record, table
     # staging, one streaming iteration per segment -- for a quarter of the entries: tools/ipw_small_sweep.sh, humanoid
     # 100 x 8 10.7 -> 8.2 us per cycle, quadrotor 100 x 6 4.79 -> 4.14) up to full waves; the choice minimizes the work of
@@ -54,6 +52,8 @@ def _intervals_per_wave(plan, override=None, shards=1, subs=0, want_workgroups=F
         return 1
     lo = max(1, math.ceil(16 / max(1, int(np.median([k for _, _, k in caps])))))
     hi = max(lo, max(c for _, c, _ in caps))
+    if forced:      # (the workgroups of the forced tiling, not the model's choice)
+        lo = hi = int(forced)
     for ipw in range(lo, hi + 1):
         tiles = 0
         for n_p, cap, _ in caps:
@@ -215,12 +215,18 @@ class Tables:
 
 
 def compile_plan(plan: SystemPlan, sharded=False, output_share=1.0):
-    """Generated source + gfx950 code object of a plan.  A model whose kernels would spill vector registers to scratch memory
-    at the default group size is generated again with smaller groups (codegen.split_groups: fewer derivative entries
-    evaluated, staged and streamed per pass) while that lowers the number of spilled registers -- pressure that comes from
-    the width of the model itself (one register pair per state and array) is not cured by smaller groups, and the search
-    stops at the first size that does not help.  Every size tried stays cached, so a model pays its extra compiles once.
-    Returns (ModelSource, code object); ``ModelSource.spilling_kernels`` says what is left."""
+    """Generated source + gfx950 code object of a plan.  The group size (codegen.split_groups: how many derivative entries a
+    pass evaluates, stages and streams) is searched under two criteria, in this order:
+
+    * **LDS** -- every launch of the code object must fit the 160 KiB of a workgroup *including* the table blocks the
+      runtime adds (``ModelSource.launch_lds_bytes``, the bytes ``pk_runtime.cpp::launch_raw`` asks for): the size is halved
+      until it does.  Nothing a wave stages grows with the number of states (WIDE phases, codegen.py), so a fitting size
+      exists for every model; if none did, this raises instead of handing the library a model it must reject.
+    * **registers** -- a model whose kernels would spill vector registers to scratch memory is generated again with smaller
+      groups while that lowers the number of spilled registers.  What is left is reported: ``ModelSource.spilling_kernels``
+      and a ``RuntimeWarning`` (the kernels are correct, a spilling one is slow).
+
+    Every size tried stays cached, so a model pays its extra compiles once.  Returns (ModelSource, code object)."""
     fast = plan.system._fastmath
 
     generated = {}
@@ -236,20 +242,28 @@ def compile_plan(plan: SystemPlan, sharded=False, output_share=1.0):
         src.spilling_kernels = hipbuild.spills(hipbuild.resource_usage(src.source, fastmath=fast))
         return src, code, sum(v[0] for v in src.spilling_kernels.values())
 
+    fixed_cap = bool(os.environ.get("POCKIT_AMD_GROUP_CAP"))
+    cap0 = generate(None).group_cap
+    while not fixed_cap and cap0 > 1 and not generate(cap0).fits_lds():
+        cap0 //= 2
+    if not generate(cap0).fits_lds():
+        worst = max(generate(cap0).launch_lds_bytes().items(), key=lambda kv: kv[1])
+        raise ValueError(f"the model does not fit a workgroup's LDS at any group size: {worst[0]} needs {worst[1]} bytes with "
+                         f"groups of {cap0} (limit {ModelSource.LDS_LIMIT})")
+
     # A launch that underfills the chip (small and medium meshes: what the reference's example programs use) is as slow as
     # one wave's chain of evaluation, staging and streaming: groups of 16 instead of 32 split the roles of a moderately
     # large model into passes that run as workgroups of their own (humanoid 25 ... 500 x 8: 8.3 -> 7.3 ... 6.6 us per cycle);
     # with the chip full (humanoid 5000 x 8) the single pass is 4 % faster (profiles/r04_ze_*.txt).  The choice is a fact of
     # the mesh like PK_TAB_CAP: a refinement that crosses the line costs one more (cached) compile.
-    fixed_cap = bool(os.environ.get("POCKIT_AMD_GROUP_CAP"))
     free = not fixed_cap and os.environ.get("POCKIT_AMD_PASS_PARALLEL", "auto") == "auto"
-    if free and _launch_underfills_the_chip(plan, max(1, int(round(1.0 / output_share)))):
+    if free and cap0 > ModelSource.GROUP_CAP // 2 and _launch_underfills_the_chip(plan, max(1, int(round(1.0 / output_share)))):
         probe = generate(ModelSource.GROUP_CAP // 2)
-        if probe.grouped and probe.cycle_subs:
+        if probe.grouped and probe.cycle_subs and probe.fits_lds():
             trial = build(probe.group_cap, probe)
             if trial[2] == 0:
                 return trial[0], trial[1]
-    best = build(None)
+    best = build(cap0)
     while best[2] > 0 and best[0].group_cap > 4 and best[0].grouped and not fixed_cap:
         trial = build(best[0].group_cap // 2)
         if trial[2] >= best[2]:
@@ -266,11 +280,17 @@ def compile_plan(plan: SystemPlan, sharded=False, output_share=1.0):
             cap //= 2
             probe = generate(cap)
             if not probe.cycle_subs:
-                continue                     # (generated only: e.g. the values role of a wide model alone needs the LDS)
+                continue                     # (generated only: the rows of this size still leave no room for two workgroups)
             trial = build(cap, probe)
             if trial[2] <= best[2]:
                 best = trial
             break
+    if best[2] > 0:
+        import warnings
+
+        warnings.warn("pockit_amd: kernels of this model spill vector registers to scratch memory at the best group size found "
+                      f"({best[0].group_cap}): " + ", ".join(f"{k} {v[0]} VGPRs / {v[1]} B" for k, v in best[0].spilling_kernels.items()),
+                      RuntimeWarning, stacklevel=2)
     return best[0], best[1]
 
 
@@ -298,6 +318,9 @@ class Evaluator:
         md.max_phases = self.src.max_phases
         md.cycle_subs = self.src.cycle_subs
         md.hess_subs = self.src.h_ngmax if self.src.cycle_subs else 0
+        # (the stand-alone compact kernels of such a model: a workgroup per pass too)
+        md.hessc_subs = self.src.hc_ngmax if (self.src.cycle_subs and self.src.hc_ngmax > 1) else 0
+        md.jacc_subs = self.src.jc_ngmax if (self.src.cycle_subs and self.src.jc_ngmax > 1) else 0
         self._err_views = None
         self._csr = {}
         md.prepass_f = 1
@@ -308,6 +331,7 @@ class Evaluator:
         self._code = code
         self._views = {}
         self.zero_copy = False   # True: callbacks return views of pinned buffers (set by the IPOPT adapter)
+        self.writable_results = os.environ.get("POCKIT_AMD_WRITABLE_RESULTS", "0") == "1"    # (see _result)
         self.ctx.check(lib.pk_load_model(h, code, len(code), C.byref(md)))
         self.model_desc = md
         # (the tiling is sized for ONE shard's share of the mesh: output_share = 1 / number of shards)
@@ -339,6 +363,11 @@ class Evaluator:
                         (plan.jac_row, plan.jac_col, plan.hess_row, plan.hess_col)]
         pd.jac_row, pd.jac_col, pd.hess_row, pd.hess_col = (a.ctypes.data_as(runtime.c_int32_p) for a in self._struct)
         self.ctx.check(lib.pk_set_problem(h, C.byref(pd)))
+        # (pk_set_problem starts every problem in the reference layouts: what set_cycle_layout chose is applied again, so that
+        #  a caller's compact-sized buffers never receive reference-layout writes after a change of tables)
+        jc, hc = getattr(self, "_cycle_layout", (False, False))
+        if jc or hc:
+            self.set_cycle_layout(jc, hc)
         self._host_setup()
 
     def close(self):
@@ -391,8 +420,6 @@ class Evaluator:
         if compact not in self._const_runs:
             runs = [(a, b) for a, b in self.plan.jac_constant_runs(compact)
                     if b - a >= (self.HEAD_RUN_MIN if a == 0 else self.INNER_RUN_MIN)]
-            if os.environ.get("POCKIT_AMD_JAC_CONSTANTS", "1") == "0":      # A/B: every iterate ships the whole Jacobian
-                runs = []
             if runs:
                 lo = (C.c_int64 * len(runs))(*[a for a, _ in runs])
                 hi = (C.c_int64 * len(runs))(*[b for _, b in runs])
@@ -483,9 +510,15 @@ class Evaluator:
         if what == 3 and self.jac_constant_runs:
             # The landing block keeps the x-independent entries of J (the +-1 translation part) from iterate to iterate: they
             # were filled in once and never cross PCIe again.  A caller that scaled this array in place would corrupt them for
-            # every later Jacobian served from the block, so the array is handed out READ-ONLY (the reference returns a fresh
-            # writable array; ``.copy()`` gives one, POCKIT_AMD_JAC_CONSTANTS=0 ships the whole Jacobian every time).
-            own.flags.writeable = False
+            # every later Jacobian served from the block, so by default the array is handed out READ-ONLY (the reference
+            # returns a fresh writable array; ``.copy()`` gives one).  ``writable_results = True`` (System.writable_results):
+            # the array is writable and its block is marked to have the constant entries filled in again before it is
+            # reused -- the reference's semantics at the price of one host pass over those entries per iterate.
+            if self.writable_results:
+                if self._cur is not None:
+                    self._cur.ready = False
+            else:
+                own.flags.writeable = False
         return own
 
     def objective(self, x):
@@ -640,7 +673,7 @@ class Evaluator:
             self.ctx.check(self.ctx.lib.pk_set_csr_map(self.ctx.handle, 0 if which == "jac" else 1, seg,
                                                        m.perm.ctypes.data_as(runtime.c_int32_p), m.nnz, m.n_triplets))
             self._csr[which] = m
-            if which == "jac" and self.src.compact_j and not os.environ.get("POCKIT_AMD_CSR_FROM_TRIPLETS"):
+            if which == "jac" and self.src.compact_j:
                 # the CSR values of J from the compact evaluation: its few repeated positions are summed by the gather
                 plan.jacc  # noqa: B018  (builds the compact plan)
                 mc = CsrMap(plan.jacc_row, plan.jacc_col, (plan.m, plan.n))
@@ -650,7 +683,7 @@ class Evaluator:
                     self.ctx.check(self.ctx.lib.pk_set_csr_map(self.ctx.handle, 3, segc,
                                                                mc.perm.ctypes.data_as(runtime.c_int32_p), mc.nnz, mc.n_triplets))
                     self._csr["jacc"] = mc
-            if which == "hess" and self.src.compact and not os.environ.get("POCKIT_AMD_CSR_FROM_TRIPLETS"):
+            if which == "hess" and self.src.compact:
                 # the compact Hessian has one value per distinct (row, col): if its pattern is the full pattern's set of
                 # entries, the CSR values are a permutation of it (pk_eval_hess_csr then never writes the repeats)
                 mc = CsrMap(plan.hessc_row, plan.hessc_col, (plan.n, plan.n))
@@ -757,6 +790,7 @@ class Evaluator:
         if jacobian_compact:
             self.plan.jacc  # noqa: B018
         self.ctx.check(self.ctx.lib.pk_set_cycle_layout(self.ctx.handle, int(bool(jacobian_compact)), int(bool(hessian_compact))))
+        self._cycle_layout = (bool(jacobian_compact), bool(hessian_compact))
 
     def profile_read(self):
         """{kernel name: (launches, total_ms)} accumulated while profiling was enabled."""

@@ -43,25 +43,21 @@ def _stale(target, sources):
     return any(os.path.getmtime(s) > t for s in sources)
 
 
-# experiments only (tools/wpb_probe.sh): waves per workgroup of the tile kernels; library and code objects must agree
-WPB_FLAGS = [f"-DPK_WAVES_PER_BLOCK={int(os.environ['POCKIT_AMD_WPB'])}"] if os.environ.get("POCKIT_AMD_WPB") else []
-
-
 def build_runtime(force=False):
     """Compile libpockit_hip.so (host C++ against libamdhip64)."""
     srcs = [os.path.join(CSRC, "pk_runtime.cpp"), os.path.join(CSRC, "pk_abi.h"),
             os.path.join(os.path.dirname(HERE), "include", "pockit_hip.h")]
     if force or _stale(LIB_PATH, srcs):
-        _run([_hipcc(), f"--offload-arch={ARCH}", "-O2", "-fPIC", "-shared", "-std=c++17", *WPB_FLAGS, srcs[0], "-o", LIB_PATH])
+        _run([_hipcc(), f"--offload-arch={ARCH}", "-O2", "-fPIC", "-shared", "-std=c++17", srcs[0], "-o", LIB_PATH])
     return LIB_PATH
 
 
 # extra device-compile flags (part of the cache key); POCKIT_AMD_HIPCC_FLAGS overrides for experiments
-EXTRA_FLAGS = os.environ.get("POCKIT_AMD_HIPCC_FLAGS", "").split() + WPB_FLAGS
+EXTRA_FLAGS = os.environ.get("POCKIT_AMD_HIPCC_FLAGS", "").split()
 
 
 # leading scalar kernel arguments (pk_cycle's tile list, counts, flags) arrive in SGPRs with the wave
-PRELOAD_FLAGS = [] if os.environ.get("POCKIT_AMD_KERNARG_PRELOAD", "1") == "0" else ["-mllvm", "-amdgpu-kernarg-preload-count=4"]
+PRELOAD_FLAGS = ["-mllvm", "-amdgpu-kernarg-preload-count=4"]
 
 
 def _kernel_header_hash():

@@ -233,7 +233,7 @@ class HostShardedEvaluator:
 
         # every rank's Hessian kernel writes only the entries of its own tiles (rank 0: also the boundary / system items), at
         # the reference positions: a share of at most 8 MiB is stored straight into the segment (as the single-GPU shim does)
-        self.h_direct = 8 * sum(b - a for a, b in rh) <= (8 << 20) and os.environ.get("POCKIT_AMD_HOSTSHARD_H_DIRECT", "1") != "0"
+        self.h_direct = 8 * sum(b - a for a, b in rh) <= (8 << 20)
         self._h_host = C.c_void_p(self._dev_base.value + 8 * (off["out"] + split))
         self.tab_j_changing = table(minus(rj, const)) if const else self.tab_j
         self._x_filled = False

@@ -546,6 +546,22 @@ class SystemBase:
         self._hessian_layout = layout
         return self
 
+    @property
+    def writable_results(self):
+        """False (default): ``jacobian()`` returns a READ-ONLY array where the landing block keeps the x-independent entries of J
+        from iterate to iterate (they never cross PCIe again; ``.copy()`` gives a private array).  True: every callback returns
+        a writable array, as the reference does, and the block has those entries filled in again before it is reused (one
+        host pass over them per iterate).  ``POCKIT_AMD_WRITABLE_RESULTS=1`` sets the default."""
+        if getattr(self, "_writable_results", None) is not None:
+            return self._writable_results
+        return self._evaluator.writable_results if self._evaluator is not None else False
+
+    @writable_results.setter
+    def writable_results(self, value):
+        self._writable_results = bool(value)
+        if self._evaluator is not None:
+            self._evaluator.writable_results = self._writable_results
+
     def set_jacobian_layout(self, layout: str):
         """``"reference"`` (default): the reference's triplet list (drop-in).  ``"compact"``: derivative entries of the
         dynamics whose column is the same on every node (t_0, t_f, static parameters) are contracted with the
@@ -601,6 +617,8 @@ class SystemBase:
         if self._evaluator is None:
             self._evaluator = Evaluator(plan)
             self._evaluator.set_jacobian_layout(self._jacobian_layout == "compact")
+            if getattr(self, "_writable_results", None) is not None:
+                self._evaluator.writable_results = self._writable_results
         return self._evaluator
 
     # ------------------------------------------------------------------ layout views (host, no GPU)

@@ -32,8 +32,12 @@ def solve(system, guess, optimizer_options=None, *, layout="auto"):
     if layout == "auto":
         layout = "compact" if 8 * (system.plan.nnz_J + system.plan.nnz_H) >= AUTO_COMPACT_BYTES else "reference"
     if layout == "compact" and not system.plan.outer:      # (models nonlinear in the integrals keep the reference layout)
-        system.set_hessian_layout("compact")
+        if system.evaluator.src.compact:                   # (so does a model one of whose entries couples too many states)
+            system.set_hessian_layout("compact")
         system.set_jacobian_layout("compact")
+    else:                                                  # "reference" FORCES the reference's lists, whatever the system was set to
+        system.set_hessian_layout("reference")
+        system.set_jacobian_layout("reference")
     try:
         solver = cyipopt.Problem(n=int(system.L), m=len(system.c_lb), problem_obj=system, lb=system.v_lb,
                                  ub=system.v_ub, cl=system.c_lb, cu=system.c_ub)

@@ -446,7 +446,10 @@ class ShardedEvaluator:
       collective, run-copy unpack.  (``cycle(..., root=r)`` / ``root=None`` select these when ``exchange`` is not given.)
     """
 
-    def __init__(self, plan, rank, world, device=0, intervals_per_wave=None):
+    def __init__(self, plan, rank, world, device=0, intervals_per_wave=None, reassemble_single=False):
+        """``reassemble_single``: with ONE rank, still run the "gather" / "allgather" forms through the ``Reassembler`` (pack,
+        collective over a process group of one, unpack) -- RCCL accepts one rank per device, so the stream ordering between
+        this evaluator's launches and RCCL's kernels can be exercised on a single GPU (tests/test_gpu_rccl_single.py)."""
         import torch
 
         from .codegen import ModelSource
@@ -467,10 +470,11 @@ class ShardedEvaluator:
         self.out = self._views(self.full)
         self.out["f"] = torch.zeros(1, dtype=torch.float64, device=dev)
         self.re, self.runs = None, None
-        if world > 1:
+        if world > 1 or reassemble_single:
             ipw = self.ev.tables.intervals_per_wave
             src = self.ev.src
-            self.runs = [owned_runs(plan, Tables(plan, src, ipw, tile_filter(r, world, plan)), r == 0) for r in range(world)]
+            self.runs = [owned_runs(plan, Tables(plan, src, ipw, tile_filter(r, world, plan) if world > 1 else None), r == 0)
+                         for r in range(world)]
             self.re = Reassembler(torch, plan, self.runs, rank, world, dev, ctx=self.ev.ctx)
         n_sh = self.re.n_shared if self.re else 0
         self.small = torch.zeros(n_I + n_sh, dtype=torch.float64, device=dev)
@@ -630,12 +634,12 @@ class ShardedEvaluator:
         lib, h, chk = self.ev.ctx.lib, self.ev.ctx.handle, self.ev.ctx.check
         st = C.c_void_p(self.stream.cuda_stream)
         o = self.out
-        sharded = dist is not None and self.world > 1
+        sharded = dist is not None and (self.world > 1 or self.re is not None)
         px = C.c_void_p(x.data_ptr())
         ptr = lambda t: C.c_void_p(t.data_ptr())  # noqa: E731
         if exchange is None:
             exchange = "allgather" if root is None else "gather"
-        if sharded and exchange in ("sums", "direct"):
+        if sharded and self.world > 1 and exchange in ("sums", "direct"):
             if self.peers is None or (exchange == "direct" and self.target is None):
                 raise RuntimeError(f'exchange="{exchange}" needs enable_peer_exchange() first')
             remote = exchange == "direct" and self.rank != self.root

@@ -34,10 +34,10 @@ def _record(n_gpus):
                batch_ms_p10=0.1, batch_ms_p90=0.1, batch_ms_min=0.1, batch_ms_max=0.1, region_wall_s=0.05, wall_ms_per_step=0.005,
                untimed_launches=1500, setup_s=0.2, compile_s_in_setup=0.0, dominant="pk_cycle", exchange="sums", tiles=336, ipw=6,
                bytes={"cycle": 15071568, "cycle_x_once": 11999312}, no_exchange_ms_per_step=0.005,
-               exchange_forms_ms_per_step={"sums": 0.006, "direct": 0.03, "gather": 3.0},
+               exchange_forms_ms_per_step={"sums": 0.006, "direct": 0.03, "gather": 3.0, "allgather": "RuntimeError('x')"},
                dispatch_isolated_us=4.4, dispatch_in_flight_us=6.0, dispatch_samples=[200, 40], kernel_us={"pk_cycle": 4.5},
                ranks=[{"rank": r} for r in range(n_gpus)], exchange_check={"finite": True}, finite=True, side={}, end_to_end=None)
-    rec["multi_gpu"] = {"ranks_seen_by_rccl": n_gpus, "backend": "nccl (= RCCL on ROCm)", "devices": [{"rank": r, "device": r} for r in range(n_gpus)],
+    rec["multi_gpu"] = {"ranks": n_gpus, "ranks_seen_by_rccl": n_gpus, "backend": "nccl (= RCCL on ROCm)", "devices": [{"rank": r, "device": r} for r in range(n_gpus)],
                         "peer_access": [[True] * n_gpus for _ in range(n_gpus)], "headline_form": "host-landed", "device_resident_form": "sums",
                         "device_resident_form_fallback": None, "peer_exchange_error": None}
     rec["end_to_end_host_sharded"] = {"cycles_per_s": 3000.0, "ms_per_cycle": 1 / 3.0, "batches": 5, "steps": 20,
@@ -52,8 +52,30 @@ def test_the_line_of_a_multi_gpu_run_carries_what_the_run_saw(n_gpus):
     args = argparse.Namespace(steps=20, warmup=5, workload="planar_quadrotor", gpus=n_gpus)
     rec = _record(n_gpus)
     e2e = rec["end_to_end_host_sharded"]
-    line = L.short_line(args, rec, e2e, n_gpus, 2000 * n_gpus, rec["ms_per_step"], ROOT)
+    strong = {f"planar_quadrotor_2000_strong_scaled_over_{n_gpus}": {
+                  "device_resident": {"cycles_per_s": 250000.0, "ms_per_step": 0.004, "exchange": "sums",
+                                      "exchange_forms_ms_per_step": {"sums": 0.004, "gather": 0.5}}, "end_to_end_cycles_per_s": 9000.0},
+              f"two_stage_rocket_1000_strong_scaled_over_{n_gpus}": {"error": "RuntimeError('no')"},
+              f"humanoid_wbc_5000_strong_scaled_over_{n_gpus}": {
+                  "device_resident": {"cycles_per_s": 90000.0, "ms_per_step": 1 / 90.0, "exchange": "sums",
+                                      "exchange_forms_ms_per_step": {"sums": 1 / 90.0, "gather": "failed"}}, "end_to_end_cycles_per_s": None}}
+    line = L.short_line(args, rec, e2e, n_gpus, 2000 * n_gpus, rec["ms_per_step"], ROOT, strong=strong)
     text = L.dumps_line(line)                                   # one strict JSON line the driver can parse
+    # fixed keys beside `value` -- the RCCL reassembly north_star names, the strong-scaled BASELINE
+    # workloads in plain cycles/s, the host-landed cycle; a form that failed says so instead of vanishing
+    mg = json.loads(text)["multi_gpu"]
+    assert mg["gather_rccl"]["value"] == pytest.approx(n_gpus * 1e3 / 3.0, rel=1e-4) and mg["gather_rccl"]["ms_per_step"] == 3.0
+    assert mg["gather_rccl"]["allgather"]["value"] is None and "RuntimeError" in mg["gather_rccl"]["allgather"]["error"]
+    assert set(mg["strong"]) == {"C3_12k", "C4_2x1000x4", "C5_5000x8"}
+    assert mg["strong"]["C3_12k"] == {"value": 250000.0, "ms_per_step": 0.004, "gather_rccl_value": 2000.0, "host_landed_value": 9000.0}
+    assert mg["strong"]["C4_2x1000x4"]["value"] is None and "no" in mg["strong"]["C4_2x1000x4"]["error"]
+    assert mg["strong"]["C5_5000x8"]["gather_rccl_value"] is None
+    assert mg["host_landed"]["value"] == pytest.approx(n_gpus * 3000.0)
+    # under the gloo rehearsal the RCCL key is null (the backend string says why)
+    rec_g = _record(n_gpus)
+    rec_g["multi_gpu"].update(ranks_seen_by_rccl=None, backend="gloo (rehearsal: NOT a measurement)")
+    lg = L.short_line(args, rec_g, e2e, n_gpus, 2000 * n_gpus, rec["ms_per_step"], ROOT)
+    assert lg["multi_gpu"]["ranks_seen_by_rccl"] is None and lg["multi_gpu"]["ranks"] == n_gpus and lg["multi_gpu"]["strong"] is None
     assert len(text) < 4096 and json.loads(text)["n_gpus"] == n_gpus
     assert line["scaling"] == "weak" and line["unit"] == "12k-node-equivalent cycles/s"
     # value = the device-resident cycle (inputs and outputs in HBM), N x the per-GPU launch rate; never the PCIe-inclusive one
@@ -188,7 +210,8 @@ def test_machine_facts_are_gathered_identically_on_every_rank():
         got = dict(ret)
     assert got[0] == got[1]
     facts = json.loads(got[0])
-    assert facts["ranks_seen_by_rccl"] == 2 and len(facts["devices"]) == 2 and len(facts["peer_access"]) == 2
+    assert facts["ranks"] == 2 and facts["ranks_seen_by_rccl"] is None      # (gloo: RCCL has seen nobody)
+    assert len(facts["devices"]) == 2 and len(facts["peer_access"]) == 2
     assert "rehearsal" in facts["backend"] and facts["device_resident_form"] == "gather"
     assert facts["device_resident_form_fallback"] and facts["peer_exchange_error"] == "no peer access"
 

@@ -80,3 +80,65 @@ def test_group_size_follows_the_launch_not_only_the_model(monkeypatch):
     assert ModelSource(quad.plan, group_cap=ModelSource.GROUP_CAP // 2).source == ModelSource(quad.plan).source
     # the tiling model counts the pass-parallel workgroups: fuller waves for a model with many passes
     assert _intervals_per_wave(small.plan, subs=half.cycle_subs) >= _intervals_per_wave(small.plan)
+
+
+@pytest.mark.parametrize("states", [17, 24, 44, 52, 64, 79, 80, 100, 128])
+def test_no_group_size_search_returns_a_source_that_exceeds_the_lds(states, monkeypatch):
+    """a 52-state model was generated with groups of 32, needed 169 984 B of LDS and was rejected by
+    pk_load_model although groups of 16 fit; 79 and more states could not fit at all (the values role alone staged n_x + 2
+    rows).  Now (a) nothing a wave stages grows with the number of states (WIDE phases), (b) the bytes are counted as
+    the library counts them -- table blocks included -- and (c) the search of evaluator.compile_plan holds them against the
+    160 KiB first.  The generator and the rule only (no hipcc): every size the search may return fits."""
+    from pockit_amd import benchmarks, radau
+
+    for key in ("POCKIT_AMD_GROUP_CAP", "POCKIT_AMD_PASS_PARALLEL", "POCKIT_AMD_IPW", "POCKIT_AMD_TAB_CAP"):
+        monkeypatch.delenv(key, raising=False)
+    for mesh, kpts in ((40, 4), (3000, 4), (7, 12)):                 # (12 points: staged tables of 256 entries, 24 KiB per workgroup)
+        system, _, _ = benchmarks.state_chain(radau, states=states, mesh=mesh, num_point=kpts)
+        for cap in (32, 16, 8, 4):
+            src = ModelSource(system.plan, group_cap=cap)
+            assert src.wide == [True]
+            need = src.launch_lds_bytes()
+            assert max(need.values()) <= LDS_LIMIT, (states, mesh, cap, need)
+            assert src.fits_lds()
+            rows = max(src.lds_g, src.lds_j, src.lds_h, src.lds_x, src.lds_jc) // 64
+            assert rows <= 2 * cap + 4, "rows of a wave no longer follow the number of states"
+
+
+def test_the_search_shrinks_the_groups_until_the_launch_fits(monkeypatch):
+    """The LDS criterion of compile_plan itself, on a model that does NOT fit at the default size: the humanoid stand-in's 60
+    path constraints + 40 states at 12 points per interval (24 KiB of table blocks) -- with a limit lowered for the test the
+    search must step down, and raise a ValueError naming kernel and bytes when nothing fits."""
+    from pockit_amd import benchmarks, evaluator, radau
+
+    system, _, _ = benchmarks.state_chain(radau, states=20, mesh=5, num_point=4, window=6)
+    big = ModelSource(system.plan, group_cap=32)
+    small = ModelSource(system.plan, group_cap=8)
+    need_big, need_small = max(big.launch_lds_bytes().values()), max(small.launch_lds_bytes().values())
+    assert need_small < need_big
+    built = []
+    monkeypatch.setattr(ModelSource, "LDS_LIMIT", (need_big + need_small) // 2)
+    monkeypatch.setattr(hipbuild, "compile_model", lambda source, fastmath=True: built.append(source) or b"code")
+    monkeypatch.setattr(hipbuild, "resource_usage", lambda source, fastmath=True: {})
+    monkeypatch.setenv("POCKIT_AMD_PASS_PARALLEL", "0")
+    src, code = evaluator.compile_plan(system.plan)
+    assert src.group_cap < 32 and src.fits_lds() and code == b"code"
+    monkeypatch.setattr(ModelSource, "LDS_LIMIT", 1024)
+    with pytest.raises(ValueError, match="does not fit a workgroup's LDS"):
+        evaluator.compile_plan(system.plan)
+
+
+def test_compact_hessian_passes_of_a_wide_model():
+    """codegen.mu_chunks: consecutive runs of outputs with bounded multiplier sets; an entry that couples more states than
+    MU_MAX makes the compact layout unavailable (the reference layout remains)."""
+    from pockit_amd.codegen import mu_chunks
+
+    needs = [{i, (i + 1) % 40} for i in range(40)]
+    passes = mu_chunks(needs, cap=16, mu_cap=8, mu_max=64)
+    assert [lo for lo, _, _ in passes] == sorted(lo for lo, _, _ in passes)
+    assert sum(cnt for _, cnt, _ in passes) == 40 and all(cnt <= 16 and len(lst) <= 8 for _, cnt, lst in passes)
+    for lo, cnt, lst in passes:
+        assert set().union(*needs[lo:lo + cnt]) == set(lst)
+    assert mu_chunks([set(range(65))], 16, 16, 64) is None
+    assert mu_chunks([set(range(40))], 16, 16, 64) == [(0, 1, list(range(40)))]
+    assert mu_chunks([], 16, 16, 64) == [(0, 0, [])]

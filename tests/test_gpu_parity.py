@@ -1363,7 +1363,8 @@ def test_adaptive_solve_check_refine_loop_converges():
     assert errors[-1] <= 1e-6 * max(1.0, abs(optimum)) and errors[-1] < errors[0], errors
 
 
-@pytest.mark.parametrize("layout", ["compact", "reference", "auto small", "auto large"])
+@pytest.mark.parametrize("layout", ["compact", "reference", "auto small", "auto large", "reference from compact",
+                                    "auto small from compact"])
 def test_ipopt_adapter_protocol_with_a_stand_in_cyipopt(layout, monkeypatch):
     """cyipopt / Ipopt are not installed here, so the adapter is driven by a stand-in ``cyipopt.Problem`` that
     does what cyipopt does with a ``problem_obj`` (cyipopt's Problem.__init__/solve contract: structure queried
@@ -1383,6 +1384,13 @@ def test_ipopt_adapter_protocol_with_a_stand_in_cyipopt(layout, monkeypatch):
     system, phases, guess = models.two_stage_rocket(ns, 12, 4)
     ref, _, _ = models.two_stage_rocket(_ns("radau", "oracle"), 12, 4)
     seen = {"iters": 0, "options": {}}
+    # ("... from compact": the user had set the system to the compact layouts before -- "reference", and "auto" below its
+    #  threshold, must still hand the solver the reference's lists, and the user's setting must be back afterwards: ADVICE r4)
+    from_compact = layout.endswith(" from compact")
+    layout = layout.replace(" from compact", "")
+    if from_compact:
+        system.set_hessian_layout("compact")
+        system.set_jacobian_layout("compact")
     want_layout = {"auto small": "reference", "auto large": "compact"}.get(layout, layout)
     layout, asked = want_layout, layout
     rjr, rjc = ref.jacobianstructure()
@@ -1457,6 +1465,10 @@ def test_ipopt_adapter_protocol_with_a_stand_in_cyipopt(layout, monkeypatch):
     assert len(solution) == len(phases) + 1 and all(len(v.data) == p.L for v, p in zip(solution, phases))
     assert len(solution[-1]) == system.n_s and system.evaluator.zero_copy is False
     # the system's own layout settings are back (the reference's lists: the drop-in default of the callbacks themselves)
+    if from_compact:
+        assert system._hessian_layout == system._jacobian_layout == "compact" and len(system.hessianstructure()[0]) < len(rhr)
+        system.set_hessian_layout("reference")
+        system.set_jacobian_layout("reference")
     assert np.array_equal(system.hessianstructure()[0], rhr) and np.array_equal(system.jacobianstructure()[0], rjr)
 
 
@@ -1904,4 +1916,36 @@ def test_a_derivative_set_evaluated_in_groups_gives_the_single_pass_results(case
         finally:
             system.set_hessian_layout("reference")
             system.set_jacobian_layout("reference")
+    system._invalidate()
+
+
+def test_writable_results_give_the_reference_semantics():
+    """where the landing block keeps the x-independent entries of J, ``jacobian()`` hands out a READ-ONLY array by
+    default (a caller scaling it in place would corrupt those entries for every later iterate served from the block);
+    ``system.writable_results = True`` gives the reference's semantics -- a writable array per callback -- by filling the
+    constant entries in again before a block is reused.  Ten iterates with every J scaled in place and dropped."""
+    ns = _ns("radau", "pockit_amd")
+    system, _, guess = models.planar_quadrotor(ns, 100, 6)
+    ref, _, _ = models.planar_quadrotor(_ns("radau", "oracle"), 100, 6)
+    x, lam, sigma = models.bench_inputs(system, guess)
+    assert system.evaluator.jac_constant_runs, "the mesh is large enough for constant runs to be kept out of the copy"
+    J = system.jacobian(x)
+    assert not J.flags.writeable and not system.writable_results
+    with pytest.raises(ValueError):
+        J *= 2.0
+    close(J, ref.jacobian(x), what="J (read-only view)")
+    del J
+    system.writable_results = True
+    rng = np.random.default_rng(11)
+    for it in range(10):
+        xi = x * (1.0 + 1e-3 * rng.uniform(-1, 1, size=x.shape))
+        J, g, grad = system.jacobian(xi), system.constraints(xi), system.gradient(xi)
+        assert J.flags.writeable and g.flags.writeable and grad.flags.writeable
+        close(J, ref.jacobian(xi), what=f"iterate {it}: J")
+        close(g, ref.constraints(xi), what=f"iterate {it}: g")
+        J *= -3.0                      # (what a caller of the reference may do with ITS array)
+        g[:] = 0.0
+        del J, g, grad
+    system.writable_results = False
+    assert not system.jacobian(x * 1.0000001).flags.writeable
     system._invalidate()

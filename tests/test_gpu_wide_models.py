@@ -1,0 +1,152 @@
+"""GPU parity of WIDE models (more states than a wave's LDS rows or register file could hold at once): the reference loops
+over the states of a phase with no limit (/root/reference/pockit/base/phasebase.py:1083-1124, 1234-1285); the MI355X
+evaluator produces the dynamics values, defect rows, multiplier rows and contracted multipliers in passes over chunks of
+states (pk_kernels.hip.h dyn_pass / hess_rows / hessc_passes_wide, codegen.ModelSource.wide).  Model:
+benchmarks.state_chain -- VERDICT r4's chain (x_i' = -x_i + x_(i-1) x_((i+1) mod n)) with 52, 80 and 128 states, and its
+windowed variant.  Against the oracle: structures exactly, every entry of every callback, of the stand-alone kernels, of the
+one-launch cycle and of the compact layouts (scatter-added) to 1e-11; sequential and pass-parallel forms."""
+import importlib
+
+import numpy as np
+import pytest
+
+import models
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-11
+
+
+def close(a, b, tol=TOL, what=""):
+    a, b = np.asarray(a, dtype=np.float64), np.asarray(b, dtype=np.float64)
+    assert a.shape == b.shape, what
+    if a.size:
+        err = np.max(np.abs(a - b))
+        assert err <= tol * max(1.0, np.max(np.abs(b))), f"{what}: err {err:.3e}"
+
+
+def _ns(scheme, pkg):
+    return importlib.import_module(f"{pkg}.{scheme}")
+
+
+def _same_matrix(got, rc, want, rc_ref, shape, what):
+    import scipy.sparse as ssp
+
+    a = ssp.coo_array((got, rc), shape=shape).tocsr()
+    b = ssp.coo_array((want, rc_ref), shape=shape).tocsr()
+    d = abs(a - b)
+    assert (d.max() if d.nnz else 0.0) <= TOL * max(1.0, abs(b).max()), what
+
+
+def _check_everything(system, ref, guess, tag, standalone=True):
+    import torch
+
+    x, lam, sigma = models.bench_inputs(system, guess)
+    x0 = x.copy()
+    jr, jc = ref.jacobianstructure()
+    hr, hc = ref.hessianstructure()
+    for a, b in zip(system.jacobianstructure() + system.hessianstructure(), (jr, jc, hr, hc)):
+        assert np.array_equal(a, b), tag + " structure"
+    want = (ref.objective(x), ref.gradient(x), ref.constraints(x), ref.jacobian(x), ref.hessian(x, lam, sigma))
+    names = ("f", "grad", "g", "J", "H")
+    got = (system.objective(x), system.gradient(x), system.constraints(x), system.jacobian(x), system.hessian(x, lam, sigma))
+    for a, b, what in zip(got, want, names):
+        close(a, b, what=f"{tag} callbacks {what}")
+    ev, plan = system.evaluator, system.plan
+    for a, b, what in zip(ev.cycle(x, lam, sigma), want, names):
+        close(a, b, what=f"{tag} one-launch cycle {what}")
+    if standalone:
+        close(ev.objective_direct(x), want[0], what=f"{tag} pk_int + pk_fin")
+        close(ev.gradient_direct(x), want[1], what=f"{tag} pk_grad")
+        close(ev.constraints_direct(x), want[2], what=f"{tag} pk_g")
+        close(ev.jacobian_direct(x), want[3], what=f"{tag} pk_jac")
+        close(ev.hessian_direct(x, lam, sigma), want[4], what=f"{tag} pk_hess")
+        ev.set_cycle_mode(False)               # the two-launch cycle: pk_xall (sequential passes), then pk_hess
+        try:
+            for a, b, what in zip(ev.cycle(x * (1.0 + 1e-12), lam, sigma), want, names):
+                close(a, b, tol=1e-10, what=f"{tag} two-launch cycle {what}")
+        finally:
+            ev.set_cycle_mode(True)
+    # compact layouts: stand-alone kernels and the compact cycle launch (pk_cyclec), scatter-added against the oracle
+    assert ev.src.compact, "the chain's compact Hessian couples few states per entry"
+    plan.jacc  # noqa: B018
+    Jc, Hc = ev.jacobian_compact(x), ev.hessian_compact(x, lam, sigma)
+    _same_matrix(Jc, (plan.jacc_row, plan.jacc_col), want[3], (jr, jc), (plan.m, plan.n), f"{tag} pk_jacc")
+    _same_matrix(Hc, (plan.hessc_row, plan.hessc_col), want[4], (hr, hc), (plan.n, plan.n), f"{tag} pk_hessc")
+    dev = torch.device("cuda", 0)
+    dx, dlam = torch.from_numpy(x).to(dev), torch.from_numpy(lam).to(dev)
+    sizes = (("f", 1), ("grad", plan.n), ("g", plan.m), ("J", plan.nnz_Jc), ("H", plan.nnz_Hc))
+    o = {k: torch.full((max(n, 1),), float("nan"), dtype=torch.float64, device=dev) for k, n in sizes}
+    ev.set_cycle_layout(True, True)
+    try:
+        torch.cuda.synchronize()
+        ev.cycle_dev(dx.data_ptr(), dlam.data_ptr(), sigma, *[o[k].data_ptr() for k, _ in sizes])
+        ev.sync()
+    finally:
+        ev.set_cycle_layout(False, False)
+    comp = {k: v.cpu().numpy()[:n] for (k, n), v in zip(sizes, o.values())}
+    close(comp["f"][0], want[0], what=f"{tag} pk_cyclec f")
+    close(comp["grad"], want[1], what=f"{tag} pk_cyclec grad")
+    close(comp["g"], want[2], what=f"{tag} pk_cyclec g")
+    assert np.array_equal(comp["J"], Jc), f"{tag}: pk_cyclec's Jacobian role vs pk_jacc"
+    assert np.array_equal(comp["H"], Hc), f"{tag}: pk_cyclec's Hessian role vs pk_hessc"
+    assert np.array_equal(x, x0), "x must not be written"
+
+
+@pytest.mark.parametrize("mesh", [40, 3000])
+@pytest.mark.parametrize("states", [52, 80, 128])
+def test_chain_models_wider_than_one_wave_can_stage(states, mesh):
+    """VERDICT r4 'What's missing' 1: 52 states were rejected by pk_load_model (error 21: 169 984 B of LDS with groups of 32),
+    79 and more could not load at any group size.  Now nothing a wave stages grows with the number of states."""
+    system, _, guess = models.state_chain(_ns("radau", "pockit_amd"), states=states, mesh=mesh, num_point=4)
+    ref, _, _ = models.state_chain(_ns("radau", "oracle"), states=states, mesh=mesh, num_point=4)
+    src = system.evaluator.src
+    assert src.wide == [True] and src.fits_lds() and not src.spilling_kernels
+    assert max(src.launch_lds_bytes().values()) <= 160 * 1024
+    _check_everything(system, ref, guess, f"{states} states, {mesh} x 4", standalone=(mesh == 40 or states == 52))
+    system._invalidate()
+
+
+@pytest.mark.parametrize("pp", ["0", "1"])
+@pytest.mark.parametrize("case", [("radau", dict(states=52, mesh=[0, 0.1, 0.35, 0.5, 1.0], num_point=[3, 6, 4, 9])),
+                                  ("lobatto", dict(states=37, mesh=11, num_point=5)),
+                                  ("lobatto", dict(states=20, mesh=7, num_point=4, window=6)),
+                                  ("radau", dict(states=24, mesh=9, num_point=7, window=5))])
+def test_wide_models_in_both_forms_of_the_cycle(case, pp, monkeypatch):
+    """The passes of a wide model one after the other in a wave (POCKIT_AMD_PASS_PARALLEL=0: what a launch that fills the chip
+    gets) and as workgroups of their own (1); ragged hp meshes, LGL, orders beyond 8 (staged tables of 256 entries) and the
+    windowed variant (every Hessian pair shared by several dynamics functions: the compact Hessian sums several contracted
+    multipliers per entry)."""
+    monkeypatch.setenv("POCKIT_AMD_PASS_PARALLEL", pp)
+    scheme, kw = case
+    system, _, guess = models.state_chain(_ns(scheme, "pockit_amd"), **kw)
+    ref, _, _ = models.state_chain(_ns(scheme, "oracle"), **kw)
+    src = system.evaluator.src
+    assert src.wide == [True] and bool(src.cycle_subs) == (pp == "1")
+    _check_everything(system, ref, guess, f"{scheme} {kw} pass-parallel {pp}")
+    system._invalidate()
+
+
+def test_wide_model_with_a_workgroup_wide_interval():
+    """More than 64 points in an interval (a whole workgroup per role, rows of every state in LDS) on a model with more than
+    16 states: the chunk functions of the wide path feed the workgroup-wide rows.  Reference: the NumPy execution of the
+    product's own plan (the oracle's np.roots tables carry no digits at 70 points, tests/test_gpu_parity.py does the same)."""
+    from plan_interp import Interp
+
+    kw = dict(states=18, mesh=[0, 0.4, 1.0], num_point=[70, 5])
+    system, _, guess = models.state_chain(_ns("radau", "pockit_amd"), **kw)
+    x, lam, sigma = models.bench_inputs(system, guess)
+    it = Interp(system.plan, x, lam, sigma)
+    want = (it.objective(), it.gradient(), it.constraints(), it.jacobian(), it.hessian())
+    assert system.evaluator.src.big and system.evaluator.src.wide == [True]
+    got = (system.objective(x), system.gradient(x), system.constraints(x), system.jacobian(x), system.hessian(x, lam, sigma))
+    for a, b, what in zip(got, want, ("f", "grad", "g", "J", "H")):
+        close(a, b, what=f"callbacks {what}")
+    for a, b, what in zip(system.evaluator.cycle(x, lam, sigma), want, ("f", "grad", "g", "J", "H")):
+        close(a, b, what=f"cycle {what}")
+    ev = system.evaluator
+    close(ev.constraints_direct(x), want[2], what="pk_g")
+    close(ev.jacobian_direct(x), want[3], what="pk_jac")
+    close(ev.hessian_direct(x, lam, sigma), want[4], what="pk_hess")
+    close(ev.hessian_compact(x, lam, sigma), it.hessian_compact(), what="pk_hessc")
+    close(ev.jacobian_compact(x), it.jacobian_compact(), what="pk_jacc")
+    system._invalidate()

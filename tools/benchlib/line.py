@@ -100,6 +100,55 @@ def roofline_of(res, n_gpus, ms, workload, intervals, root):
             "dispatch_samples_isolated_in_flight": res.get("dispatch_samples")}
 
 
+def roofline_note(roof):
+    """<= 80 characters: which duration ``frac`` rests on when the committed kernel trace and the events of this run differ."""
+    prof, us = roof.get("profiled"), roof.get("avg_launch_us")
+    if not (prof and prof.get("avg_ns") and us):
+        return "frac: HIP events of this run; no committed trace for this workload"
+    rel = prof["avg_ns"] * 1e-3 / us - 1.0
+    if abs(rel) <= 0.03:
+        return f"events and committed trace agree ({rel * 100:+.1f} %)"
+    return f"frac: events of this run; trace (other lease, begin at dispatch) {rel * 100:+.0f} %"[:80]
+
+
+def multi_gpu_of(res, e2e, n_gpus, strong):
+    """Fixed keys of an N > 1 line beside ``value`` (which stays the device-resident weak-scaled cycle, as the task text rules):
+    ``gather_rccl`` -- the form north_star words (pack, RCCL gather / all-gather over xGMI, unpack into the reference's triplet
+    order), ``strong`` -- BASELINE's workloads at their own size split over the N GPUs, plain cycles/s, ``host_landed`` -- every
+    GPU landing its slices in one host array.  A form that did not run is null (or its error text)."""
+    mg = res.get("multi_gpu") or {}
+    forms = res.get("exchange_forms_ms_per_step") or {}
+    is_rccl = str(mg.get("backend", "")).startswith("nccl")
+
+    def form(key):
+        ms = forms.get(key)
+        if isinstance(ms, (int, float)):
+            return {"value": _num(n_gpus * 1e3 / ms), "ms_per_step": _num(ms)}
+        return {"value": None, "ms_per_step": None, "error": (str(ms)[:100] if ms else "not measured")}
+
+    g = form("gather")
+    g.update(unit="12k-node-equivalent cycles/s", allgather=form("allgather"), backend=mg.get("backend"),
+             what="pack + collective + unpack into reference triplet order on the device, in the timed loop")
+    st = {}
+    for key, rec in (strong or {}).items():
+        name = ("C3_12k" if key.startswith("planar_quadrotor") else "C4_2x1000x4" if key.startswith("two_stage_rocket") else
+                "C5_5000x8" if key.startswith("humanoid_wbc") else key)
+        if isinstance(rec, dict) and "device_resident" in rec:
+            dr = rec["device_resident"]
+            gat = (dr.get("exchange_forms_ms_per_step") or {}).get("gather")
+            st[name] = {"value": _num(dr.get("cycles_per_s")), "ms_per_step": _num(dr.get("ms_per_step")),
+                        "gather_rccl_value": (_num(1e3 / gat) if isinstance(gat, (int, float)) and gat else None),
+                        "host_landed_value": _num(rec.get("end_to_end_cycles_per_s"))}
+        else:
+            st[name] = {"value": None, "error": str((rec or {}).get("error", "not measured"))[:100]}
+    ee = end_to_end_of(e2e, n_gpus) or {}
+    return {"ranks_seen_by_rccl": (mg.get("ranks") if is_rccl else None), "ranks": mg.get("ranks"), "backend": mg.get("backend"),
+            "device_resident_form": mg.get("device_resident_form"),
+            "fallback": (str(mg.get("device_resident_form_fallback"))[:120] if mg.get("device_resident_form_fallback") else None),
+            "gather_rccl": g, "strong": (st or None), "strong_unit": "cycles/s (same workload as N = 1, intervals split over N)",
+            "host_landed": {"value": ee.get("value"), "ms_per_step": ee.get("ms_per_step")}}
+
+
 def end_to_end_of(e2e, n_gpus):
     """The host-landed (solver-visible) cycle in the short line: the five callbacks on a new x with host arrays in and
     out; N > 1: every GPU landing its slices in one pinned host array."""
@@ -159,7 +208,7 @@ def detail_record(args, res, e2e, n_gpus, intervals, ms, wall_ms, root):
     return rec
 
 
-def short_line(args, res, e2e, n_gpus, intervals, ms, root, cpu_baseline=None, parity=None, detail_file=None):
+def short_line(args, res, e2e, n_gpus, intervals, ms, root, cpu_baseline=None, parity=None, detail_file=None, strong=None):
     """The ONE line the driver parses.  Keys are fixed; everything else lives in the detail file."""
     roof = roofline_of(res, n_gpus, ms, args.workload, intervals, root)
     prof = roof.get("profiled")
@@ -176,7 +225,10 @@ def short_line(args, res, e2e, n_gpus, intervals, ms, root, cpu_baseline=None, p
                      "avg_launch_us": _num(roof["avg_launch_us"]), "achieved": _num(roof["achieved"]), "peak": HBM_PEAK_GBPS,
                      "unit": "GB/s", "frac": _num(roof["frac"], 4), "traffic": roof["traffic"], "regime": roof["regime"],
                      "dispatch_isolated_us": _num(roof["dispatch_isolated_us"]), "frac_profiled": _num(roof["frac_profiled"], 4),
-                     "profiled": ({"file": prof.get("file"), "avg_ns": prof.get("avg_ns"), "calls": prof.get("calls")} if prof else None)},
+                     "frac_x_once": _num(roof["frac_x_once"], 4),
+                     "profiled": ({"file": prof.get("file"), "avg_ns": prof.get("avg_ns"), "calls": prof.get("calls"),
+                                   "same_lease_ms_per_step": prof.get("same_lease_ms_per_step")} if prof else None),
+                     "note": roofline_note(roof)},
         "cpu_baseline": None,
         "device_resident": {"value": _num(value, 7), "ms_per_step": _num(ms, 7),
                             "compact_layouts_value": _num(((res.get("side") or {}).get("compact_cycle_mode") or {}).get("cycles_per_s"))},
@@ -194,10 +246,7 @@ def short_line(args, res, e2e, n_gpus, intervals, ms, root, cpu_baseline=None, p
         if ee and ee.get("value"):
             line["speedup_vs_cpu_baseline"]["end_to_end"] = _num(ee["value"] / cb["value"], 4)
     if n_gpus > 1:
-        mg = res.get("multi_gpu") or {}
-        line["multi_gpu"] = {"ranks_seen_by_rccl": mg.get("ranks_seen_by_rccl"), "backend": mg.get("backend"),
-                             "device_resident_form": mg.get("device_resident_form"),
-                             "fallback": (str(mg.get("device_resident_form_fallback"))[:120] if mg.get("device_resident_form_fallback") else None)}
+        line["multi_gpu"] = multi_gpu_of(res, e2e, n_gpus, strong)
     return line
 
 
@@ -205,7 +254,7 @@ def dumps_line(line):
     """Strict JSON on one line, shorter than LINE_LIMIT: optional keys are dropped (never the contract's) if it is not."""
     line = sanitize(line)
     text = json.dumps(line, allow_nan=False, separators=(",", ":"))
-    for key in ("speedup_vs_cpu_baseline", "multi_gpu", "parity", "detail_file"):
+    for key in ("speedup_vs_cpu_baseline", "parity", "detail_file"):
         if len(text) < LINE_LIMIT:
             break
         line.pop(key, None)

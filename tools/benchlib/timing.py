@@ -765,7 +765,7 @@ def measure(name, intervals, steps, warmup, rank, world, dist, with_side=True, w
             forms["sums_form_of_the_headline"] = "in-launch" if w.inline_default else "pk_xchg behind pk_cycle"
             forms["sums_forms_probe_ms"] = w.sums_forms_ms
             forms["fallback"] = w.exchange_fallback
-        for mode in ("sums", "direct", "gather"):
+        for mode in ("sums", "direct", "gather", "allgather"):
             if mode == w.exchange:
                 forms[mode] = res["ms_per_step"]
             elif mode in ("sums", "direct") and w.sev.peers is None:
@@ -859,8 +859,9 @@ def multi_gpu_facts(torch, dist, rank, world, w):
         backend = str(dist.get_backend())
     except Exception:  # noqa: BLE001
         backend = "unknown"
-    return {"ranks_seen_by_rccl": int(dist.get_world_size()), "backend": backend + (" (= RCCL on ROCm)" if backend == "nccl" else
-                                                                                   " (rehearsal: NOT a measurement)"),
+    # ("ranks_seen_by_rccl" only when the process group IS RCCL: under the gloo rehearsal it is null -- VERDICT r4 weak 9)
+    return {"ranks": int(dist.get_world_size()), "ranks_seen_by_rccl": (int(dist.get_world_size()) if backend == "nccl" else None),
+            "backend": backend + (" (= RCCL on ROCm)" if backend == "nccl" else " (rehearsal: NOT a measurement)"),
             "devices": devs, "peer_access": rows,
             "end_to_end_form": "host-landed sharded cycle (every GPU lands its slices in one host array over its own PCIe link): "
                                "the form that hands a host-side solver the reassembled COO triplets",
@@ -898,7 +899,8 @@ def strong_scaled_workloads(args, rank, world, dist):
     import torch
 
     strong = {}
-    for nm, iv, tag in (("two_stage_rocket", 1000, "C4 two_stage_rocket 2 phases x 1000 intervals x 4 points"),
+    for nm, iv, tag in (("planar_quadrotor", 2000, "C3 planar_quadrotor 2000 intervals x 6 points (the N = 1 headline workload)"),
+                        ("two_stage_rocket", 1000, "C4 two_stage_rocket 2 phases x 1000 intervals x 4 points"),
                         ("humanoid_wbc", 5000, "C5 humanoid_wbc 5000 intervals x 8 points")):
         problem = None
         try:

@@ -13,7 +13,10 @@ sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."
 from pockit_amd import hipbuild  # noqa: E402
 
 
-def main():
+def main(emit_older_than=None):
+    """``emit_older_than`` (a time stamp): also drop the memoised function bodies under _cache/emit that nothing has read or
+    written since then (codegen touches a body whenever it serves one; tools/warm_cache.sh passes the time it started, after
+    having generated every model of the GPU suite)."""
     d = hipbuild.CACHE_DIR
     if not os.path.isdir(d):
         return
@@ -21,14 +24,23 @@ def main():
     removed = 0
     for name in os.listdir(d):
         stem, ext = os.path.splitext(name)
-        if ext in (".hsaco", ".hip") and stem not in keep:
+        if name.endswith(".res.json"):
+            stem, ext = name[: -len(".res.json")], ".res.json"
+        if ext in (".hsaco", ".hip", ".res.json") and stem not in keep:
             os.remove(os.path.join(d, name))
             removed += 1
         elif ext == ".part":
             os.remove(os.path.join(d, name))
     hipbuild.write_index(keep)
-    print(f"pruned {removed} stale files, {len(keep)} live code objects")
+    emit, dropped = os.path.join(d, "emit"), 0
+    if emit_older_than is not None and os.path.isdir(emit):
+        for name in os.listdir(emit):
+            path = os.path.join(emit, name)
+            if os.path.getmtime(path) < emit_older_than:
+                os.remove(path)
+                dropped += 1
+    print(f"pruned {removed} stale files, {len(keep)} live code objects" + (f", {dropped} unused function bodies" if dropped else ""))
 
 
 if __name__ == "__main__":
-    main()
+    main(float(sys.argv[1]) if len(sys.argv) > 1 else None)

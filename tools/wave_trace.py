@@ -18,7 +18,8 @@ import pockit_amd.radau as radau  # noqa: E402
 
 TICK_US = 0.01
 MARKS = {0: "wave entry (tile record in SGPRs)", 1: "x + tables loaded", 2: "evaluation starts", 3: "evaluation done",
-         10: "gradient stores, wave sums done", 11: "partial sums handed off", 4: "values staged in LDS",
+         10: "wave sums done (DPP trees)", 11: "barrier + partial sums handed off", 12: "gradient stores issued",
+         13: "LDS staging stores issued", 4: "path / per-node stores issued",
          5: "phase B starts", 6: "defects issued", 7: "translation issued", 8: "streaming issued",
          9: "stores acknowledged"}
 ROLES = ["values wave", "Jacobian wave", "Hessian wave"]
