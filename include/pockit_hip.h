@@ -61,8 +61,8 @@ typedef struct pk_model_desc {
   int32_t max_phases;   /* PK_MAX_PHASES the code object was compiled with (0: 8): phase records in its kernel arguments */
   int32_t cycle_subs;   /* workgroups per tile block of pk_cycle for a model evaluated in groups (1 + passes of J + passes of H); 0: 3 / 2 */
   int32_t hess_subs;    /* workgroups per tile block of pk_hess for such a model (passes of H); 0: 1 */
-  int32_t hessc_subs;   /* ... of pk_hessc (passes of the compact Hessian); 0: 1 */
-  int32_t jacc_subs;    /* ... of pk_jacc (passes of the compact Jacobian); 0: 1 */
+  int32_t hessc_subs;   /* ... of the compact Hessian kernel for such a model (its passes); 0: 1 */
+  int32_t jacc_subs;    /* ... of the compact Jacobian kernel for such a model (its passes); 0: 1 */
 } pk_model_desc;
 
 /* One (model, mesh) instance: sizes plus the table blobs built by pockit_amd/evaluator.py.

@@ -146,11 +146,18 @@ def _key(source: str, fastmath: bool) -> str:
 COMPILE_SECONDS = {"total": 0.0, "count": 0, "last": 0.0}
 
 
-def compile_model(source: str, fastmath: bool = False, keep_source: bool = True) -> bytes:
-    """Return the gfx950 code object of a generated model source (compiling on a cache miss)."""
+def compile_model(source: str, fastmath: bool = False, keep_source: bool = None) -> bytes:
+    """Return the gfx950 code object of a generated model source (compiling on a cache miss).  ``keep_source``: also keep
+    the generated source beside the object (default: only with POCKIT_AMD_KEEP_SOURCE=1 -- 19 MB for the GPU suite's models)."""
+    if keep_source is None:
+        keep_source = os.environ.get("POCKIT_AMD_KEEP_SOURCE", "0") == "1"
+    import zlib
+
     key = _key(source, fastmath)
     os.makedirs(CACHE_DIR, exist_ok=True)
-    path = os.path.join(CACHE_DIR, key + ".hsaco")
+    # (stored deflated: a code object of a large model has 1-3 MB, the cache of the GPU suite 140 MB -- 35 MB deflated -- and
+    #  the whole cache travels to every GPU lease)
+    path = os.path.join(CACHE_DIR, key + ".hsacoz")
     gen = os.path.join(CACHE_DIR, key + ".gen")
     if os.path.exists(path) and not os.path.exists(gen):
         try:
@@ -183,8 +190,8 @@ def compile_model(source: str, fastmath: bool = False, keep_source: bool = True)
             # publish atomically through a name of our own: ranks that start cold together (bench.py under torchrun,
             # the two-process test) all compile the same model and must not share a staging file
             fd, staged = tempfile.mkstemp(dir=CACHE_DIR, prefix=key + ".", suffix=".part")
-            os.close(fd)
-            shutil.copyfile(os.path.join(tmp, "model.hsaco"), staged)
+            with open(os.path.join(tmp, "model.hsaco"), "rb") as fin, os.fdopen(fd, "wb") as fout:
+                fout.write(zlib.compress(fin.read(), 6))
             os.replace(staged, path)
             if keep_source:
                 fd, staged = tempfile.mkstemp(dir=CACHE_DIR, prefix=key + ".", suffix=".part")
@@ -204,4 +211,4 @@ def compile_model(source: str, fastmath: bool = False, keep_source: bool = True)
             except OSError:
                 pass
     with open(path, "rb") as fh:
-        return fh.read()
+        return zlib.decompress(fh.read())

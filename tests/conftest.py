@@ -47,7 +47,7 @@ def pytest_terminal_summary(terminalreporter):
         os.makedirs(dst, exist_ok=True)
         used = 0
         for key in dict.fromkeys(r[0] for r in rows):
-            for ext in (".hsaco", ".gen", ".res.json"):
+            for ext in (".hsacoz", ".gen", ".res.json"):
                 src = os.path.join(hipbuild.CACHE_DIR, key + ext)
                 if os.path.exists(src) and used + os.path.getsize(src) < 48 * 2**20:
                     shutil.copy(src, dst)

@@ -55,6 +55,13 @@ def test_the_short_line_is_strict_json_below_four_kilobytes_with_the_fixed_keys(
         assert key in roof, key
     # frac is reproducible from the line itself: algorithmic bytes / launch duration / peak
     assert roof["frac"] == pytest.approx(roof["algorithmic_bytes_per_launch"] / (roof["avg_launch_us"] * 1e-6) / 1e9 / roof["peak"], rel=1e-3)
+    # beside it the fraction on the bytes that actually move (x read once), the fraction on the committed
+    # kernel trace -- reproducible from the line: bytes / profiled.avg_ns / peak -- and a note of at most 80 characters
+    assert roof["frac_x_once"] == pytest.approx(11999312 / (roof["avg_launch_us"] * 1e-6) / 1e9 / roof["peak"], rel=1e-3)
+    assert roof["frac_x_once"] < roof["frac"] and isinstance(roof["note"], str) and 0 < len(roof["note"]) <= 80
+    if roof["profiled"]:
+        assert roof["frac_profiled"] == pytest.approx(roof["algorithmic_bytes_per_launch"] / roof["profiled"]["avg_ns"] / roof["peak"], rel=1e-3)
+        assert set(roof["profiled"]) == {"file", "avg_ns", "calls", "same_lease_ms_per_step"}
     assert set(back["cpu_baseline"]) == {"value", "unit", "cores", "kind", "sample"} and len(back["cpu_baseline"]["sample"]) <= 200
     assert back["parity"]["ok"] is True and back["config"]["workload"].startswith("planar_quadrotor LGR 2000")
 

@@ -150,3 +150,36 @@ def test_wide_model_with_a_workgroup_wide_interval():
     close(ev.hessian_compact(x, lam, sigma), it.hessian_compact(), what="pk_hessc")
     close(ev.jacobian_compact(x), it.jacobian_compact(), what="pk_jacc")
     system._invalidate()
+
+
+@pytest.mark.parametrize("case", [("radau", dict(states=52, mesh=40, num_point=4)),
+                                  ("radau", dict(states=128, mesh=[0, 0.1, 0.35, 0.5, 1.0], num_point=[3, 6, 4, 9])),
+                                  ("lobatto", dict(states=37, mesh=11, num_point=5)),
+                                  ("radau", dict(states=24, mesh=9, num_point=7, window=5)),
+                                  ("radau", dict(states=18, mesh=[0, 0.4, 1.0], num_point=[66, 5]))])
+def test_mesh_error_estimation_of_wide_models(case):
+    """pk_err in passes over chunks of states (the wave staged 3 n_x + 2 n_u rows before: 128 states asked for 790 KB of LDS
+    and pk_set_mesh_error_tables answered error 72): both sides of the re-collocated equation on every interval against the
+    oracle's restatement of phasebase.py:1339-1372, and against the NumPy execution of the product's own tables
+    (tests/plan_interp.py) -- the reference where an interval has more augmented nodes than a wave has lanes (the oracle's
+    np.roots tables carry no digits there)."""
+    import plan_interp
+    from oracle import refine as oref
+
+    scheme, kw = case
+    system, phases, guess = models.state_chain(_ns(scheme, "pockit_amd"), **kw)
+    x, _, _ = models.bench_inputs(system, guess)
+    data = system.evaluator.mesh_error(x)
+    want = plan_interp.mesh_error(system.plan, x)
+    for k in range(len(phases)):
+        close(data[k][0], want[k][0], what=f"{kw} T (plan tables)")
+        close(data[k][1], want[k][1], what=f"{kw} I (plan tables)")
+    if max(np.atleast_1d(kw["num_point"])) <= 12:
+        ref, rphases, _ = models.state_chain(_ns(scheme, "oracle"), **kw)
+        ref.prepare()
+        s = x[ref.l_s: ref.r_s]
+        for k, rp in enumerate(rphases):
+            T, I = oref.error_data(rp, x[ref.l_p[k]: ref.r_p[k]].copy(), s)
+            close(data[k][0], T, what=f"{kw} T")
+            close(data[k][1], I, what=f"{kw} I")
+    system._invalidate()

@@ -2,8 +2,7 @@
 # GPU box: A/B of build / run switches on the benchmark workloads, alternating runs on one box.
 #   VARIANTS="name[:ENV=val[,ENV=val...]] ..."   (a name alone = the defaults)
 #   WORKLOADS="workload:intervals ..."  REPS=n
-# e.g. VARIANTS="lazy byvalue:POCKIT_AMD_KA_LAZY=0" tools/ab.sh      (how pk_cycle reads its PkArgs; profiles/r02_ka_ab.txt)
-#      VARIANTS="wide narrow:POCKIT_AMD_WIDE_TRANSLATION=0" tools/ab.sh
+# e.g. VARIANTS="auto seq:POCKIT_AMD_PASS_PARALLEL=0" tools/ab.sh      (the surviving switches: INTEGRATION.md section 7)
 for rep in $(seq 1 ${REPS:-2}); do
 for spec in ${VARIANTS:-default}; do
   v=${spec%%:*}

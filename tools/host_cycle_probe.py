@@ -4,7 +4,7 @@ back in host arrays, a new x every cycle) -- where its time goes and what each s
 
   1. the C ABI alone: pk_callback_x x 4 + pk_callback_hess per cycle, time of every call (medians);
   2. the five callbacks of ``System`` (what cyipopt calls): caller-owned arrays / zero-copy views / compact Hessian;
-  3. A/B of the shim's switches (pk_set_host_option, POCKIT_AMD_JAC_CONSTANTS) on 2.;
+  3. A/B of the shim's switches (pk_set_host_option, System.writable_results) on 2.;
   4. the link: one DMA + wait for every transfer of the cycle (the PCIe floor the cycle is read against).
 
 CASE=quadrotor|humanoid|brachistochrone selects the model (default quadrotor 2000 x 6)."""
@@ -122,12 +122,11 @@ ev.set_host_mode(False, False)
 report("prefetch = 0")
 ev.set_host_mode(True, False)
 system._invalidate()
-os.environ["POCKIT_AMD_JAC_CONSTANTS"] = "0"
 system, xs, lam, sigma = build()
+system.writable_results = True             # (writable arrays: the constant entries of J are filled in again per iterate)
 ev = system.evaluator
 lib, h = ev.ctx.lib, ev.ctx.handle
-report("whole Jacobian copied")
-os.environ.pop("POCKIT_AMD_JAC_CONSTANTS")
+report("writable results")
 system._invalidate()
 
 # ---- 4. the link

@@ -1,13 +1,21 @@
 #!/bin/bash
-# GPU box: the round's evidence for profiles/ -- rocprofv3 kernel stats of the driver's bench command (headline workload)
-# and the two HBM-traffic PMC passes (FETCH_SIZE, WRITE_SIZE; each in its own run, no trace domains with --pmc).
-# usage: tools/profile_round.sh <tag> [pmc]     -> gpurun_out/<tag>_kernel_stats.csv, <tag>_bench_under_rocprofv3.json,
-#                                                  with "pmc": <tag>_pmc_FETCH_SIZE.csv, <tag>_pmc_WRITE_SIZE.csv, <tag>_pmc_summary.json
-tag=${1:-r02}
+# GPU box: the round's evidence for profiles/, ALL FROM ONE LEASE (the line's roofline and the committed
+# rocprof summary must be a pair from the same box and minute):
+#   1. the plain bench line of the driver's command                          -> gpurun_out/<tag>_bench_n1.json (+ _bench_detail.json)
+#   2. rocprofv3 --kernel-trace --stats of the same device-resident loop     -> <tag>_kernel_stats.csv, <tag>_bench_under_rocprofv3.json
+#   3. (with "pmc") the two HBM-traffic PMC passes, each in its own run, no trace domains with --pmc
+#                                                                           -> <tag>_pmc_FETCH_SIZE.csv, _WRITE_SIZE.csv, _pmc_summary.json
+#   4. tools/update_pmc_traffic.py <tag>: profiles/pmc_traffic.json's pk_cycle / pk_cycle_profiled from THAT triple, and the
+#      line of step 1 assembled again with them                              -> <tag>_bench_n1_with_profile.json
+# usage: tools/profile_round.sh <tag> [pmc]
+tag=${1:-r05}
 repo=${GRAFT_REPO_ROOT:-$PWD}
 out=$repo/gpurun_out
 mkdir -p "$out"
 cd /tmp && export TMPDIR=/tmp
+python3 "$repo/bench.py" --steps 20 --warmup 5 > "$out/${tag}_bench_n1.json" 2> "$out/${tag}_bench_n1.err" || exit 1
+cp "$repo/bench_detail.json" "$out/${tag}_bench_detail.json" 2>/dev/null
+tail -c 600 "$out/${tag}_bench_n1.json"
 BENCH_ARGS="--steps 20 --warmup 5 --no-extra --no-cpu-baseline --no-end-to-end"
 rocprofv3 --kernel-trace --stats --output-format csv -d "$out/prof_$tag" -o p -- \
   python3 "$repo/bench.py" $BENCH_ARGS > "$out/${tag}_bench_under_rocprofv3.json" 2> "$out/${tag}_rocprof.err"
@@ -15,13 +23,7 @@ rc=$?
 f=$(find "$out/prof_$tag" -name '*kernel_stats.csv' | head -1)
 [ -n "$f" ] && cp "$f" "$out/${tag}_kernel_stats.csv" && head -4 "$f" | cut -c1-160
 find "$out/prof_$tag" -name '*kernel_trace.csv' -delete      # the trace itself is large: keep only the stats
-# the headline's own command (the host-landed cycle: five callbacks, copies up and down): which kernels it runs and how long
-rocprofv3 --kernel-trace --stats --output-format csv -d "$out/prof_${tag}_e2e" -o p -- \
-  python3 "$repo/bench.py" --steps 20 --warmup 5 --no-extra --no-cpu-baseline > "$out/${tag}_bench_e2e_under_rocprofv3.json" 2> "$out/${tag}_rocprof_e2e.err"
-f=$(find "$out/prof_${tag}_e2e" -name '*kernel_stats.csv' | head -1)
-[ -n "$f" ] && cp "$f" "$out/${tag}_kernel_stats_e2e.csv"
-find "$out/prof_${tag}_e2e" -name '*kernel_trace.csv' -delete
-[ "$2" = "pmc" ] || exit $rc
+if [ "$2" = "pmc" ]; then
 for c in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --pmc $c --output-format csv -d "$out/prof_${tag}_pmc_$c" -o p -- python3 "$repo/bench.py" $BENCH_ARGS > /dev/null 2>&1
   g=$(find "$out/prof_${tag}_pmc_$c" -name '*counter_collection.csv' | head -1)
@@ -52,7 +54,9 @@ for c in ("FETCH_SIZE", "WRITE_SIZE"):
         v = v[len(v) // 4:]                      # drop the warm-up launches
         res.setdefault(k, {})[c + "_KB_per_launch"] = sum(v) / len(v)
         res[k][c + "_launches"] = len(v)
-print(json.dumps(res, indent=1))
+print(json.dumps(res, indent=1)[:400])
 json.dump(res, open(f"{out}/{tag}_pmc_summary.json", "w"), indent=1)
 PY
+fi
+python3 "$repo/tools/update_pmc_traffic.py" "$tag" "$out" "$out/pmc_traffic.json"
 exit $rc

@@ -26,7 +26,7 @@ def main(emit_older_than=None):
         stem, ext = os.path.splitext(name)
         if name.endswith(".res.json"):
             stem, ext = name[: -len(".res.json")], ".res.json"
-        if ext in (".hsaco", ".hip", ".res.json") and stem not in keep:
+        if ext in (".hsacoz", ".hsaco", ".hip", ".res.json") and stem not in keep:
             os.remove(os.path.join(d, name))
             removed += 1
         elif ext == ".part":

@@ -10,5 +10,5 @@ python3 tools/prune_cache.py
 python3 -m pytest tests -m gpu -q -n "${JOBS:-6}" -p no:cacheprovider > /dev/null 2>&1
 python3 -c "import __graft_entry__ as g; g.build()"
 python3 tools/prune_cache.py "$stamp"
-ls pockit_amd/_cache/*.hsaco | wc -l
+ls pockit_amd/_cache/*.hsacoz | wc -l
 du -sh pockit_amd/_cache
