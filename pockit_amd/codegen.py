@@ -515,13 +515,10 @@ class ModelSource:
                          f"return t[o[g] + k]; }}")
             else:
                 chunks = split_chunks(len(cb.segs[k]), self.group_cap)
-                # A model evaluated in groups runs the passes of a role as workgroups of their own (pk_cycle / pk_cyclec share
-                # the grid): the compact Hessian gets as many chunks as the reference layout's Hessian role has passes, so that
-                # its per-node chain -- contraction of the multipliers + one chunk's expressions -- is as short as one of theirs
-                # (humanoid 2000 x 4: 2 chunks on 4 workgroups, compact cycle 8.7 us against 7.2 for the reference layouts)
-                want = min(len(self.groups[("hess", k)]), len(cb.segs[k]))
-                if want > len(chunks):
-                    chunks = split_even(len(cb.segs[k]), -(-len(cb.segs[k]) // want))
+                # (More, smaller chunks -- one per pass of the reference layout's Hessian role, to use all of its workgroups in a
+                #  pass-parallel launch -- were measured SLOWER: every chunk repeats the contraction of the multipliers and loses
+                #  the subexpressions it shared; drone_stabilization 2000 x 4 12.2 -> 14.9 us, rocket_powered_descent 11.3 -> 12.7,
+                #  orbit_transfer 8.6 -> 10.3: profiles/r05_d_large_models_at_8k_nodes.txt)
             self.groups[("hessc", k)] = chunks
             S.append(f"  static constexpr int HC_NN = {len(cb.segs[k])}, HC_NG = {len(chunks)}, HC_LROWS = {self.hc_rows[k]};")
             S.append(ctable("HC_c0", [c[0] for c in chunks]))
@@ -561,17 +558,7 @@ class ModelSource:
             if len(ci) + len(cd) <= cap and len(ci) + len(cd) + len(cn) <= cap + cap // 2:
                 jgroups = [(-1, 0, 0)]                      # one pass over everything (the single-pass kernel code)
             else:                                           # runs of one kind each: expanded, dense-column, per-node
-                per_kind = {kind: split_chunks(len(lst), cap) for kind, lst in ((0, ci), (1, cd), (2, cn))}
-                # (... and no fewer passes than the reference layout's Jacobian role has: the workgroups are there, see above)
-                want = len(self.groups[("jac", k)])
-                while sum(1 for v in per_kind.values() for _, c in v if c) < want:
-                    kind = max(per_kind, key=lambda kd: max([c for _, c in per_kind[kd]] + [0]))
-                    biggest = max(c for _, c in per_kind[kind])
-                    if biggest <= 1:
-                        break
-                    n_k = sum(c for _, c in per_kind[kind])
-                    per_kind[kind] = split_even(n_k, biggest - 1) if n_k else per_kind[kind]
-                jgroups = [(kind, lo, cnt) for kind in (0, 1, 2) for lo, cnt in per_kind[kind] if cnt]
+                jgroups = [(kind, lo, cnt) for kind, lst in ((0, ci), (1, cd), (2, cn)) for lo, cnt in split_chunks(len(lst), cap) if cnt]
             self.groups[("jacc", k)] = jgroups
             S.append(f"  static constexpr int JC_NG = {len(jgroups)}, "
                      f"JC_GMAX = {len(ci) + len(cd) if jgroups[0][0] < 0 else max([1] + [c for kd, _, c in jgroups if kd < 2])};")

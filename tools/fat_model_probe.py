@@ -73,7 +73,8 @@ if "--chain" in sys.argv:               # the wide synthetic models of round 5 (
         system.evaluator  # noqa: B018
         probe(f"state_chain {n_states} states", system, time.time() - t0)
     sys.exit(0)
-for name in ("humanoid_whole_body_control", "drone_stabilization", "rocket_powered_descent", "orbit_transfer"):
+only = [a.split("=", 1)[1] for a in sys.argv[1:] if a.startswith("--only=")]
+for name in only or ("humanoid_whole_body_control", "drone_stabilization", "rocket_powered_descent", "orbit_transfer"):
     with open(os.path.join(ROOT, "tests", "golden", "examples", name + ".model.json")) as fh:
         desc = json.load(fh)
     for pd in desc["phases"]:
