@@ -63,6 +63,9 @@ typedef struct pk_model_desc {
   int32_t hess_subs;    /* workgroups per tile block of pk_hess for such a model (passes of H); 0: 1 */
   int32_t hessc_subs;   /* ... of the compact Hessian kernel for such a model (its passes); 0: 1 */
   int32_t jacc_subs;    /* ... of the compact Jacobian kernel for such a model (its passes); 0: 1 */
+  int32_t big_global;   /* 1: intervals with more than 64 points stage their rows in the device staging buffer whatever their
+                           length (PK_BIG_GLOBAL: the rows of every state do not fit a workgroup's LDS); 0: only beyond 256 */
+  int32_t big_rows;     /* rows one such interval stages per sub-slot (0: derived from lds_x / lds_h / lds_jc) */
 } pk_model_desc;
 
 /* One (model, mesh) instance: sizes plus the table blobs built by pockit_amd/evaluator.py.

@@ -231,6 +231,7 @@ class ModelSource:
     # Hessian contracts the multipliers its pass refers to, and every pass fetches the node arguments it reads itself.
     WIDE_NX = 16
     WIDE_CHUNK = 16
+    MAX_ROWS = 256         # sums over all nodes pk_cycle's finalize workgroup takes: one thread each (fin_handoff)
     MU_MAX = 64            # most states ONE entry of the compact Hessian may refer to (their multiplier rows are staged together)
     LDS_LIMIT = 160 * 1024
 
@@ -705,6 +706,7 @@ class ModelSource:
             S.append("#define PK_BIG_MFMA 1")                        # (measured slower than the VALU form, kept under test)
         if self.big:
             S.append("#define PK_BIG 1")
+            S.append("//@PK_BIG_GLOBAL@")      # (decided below, once the groups of every phase are known)
         if self.sharded:
             S.append("#define PK_SHARDED 1")
         # Cache policy of the 16-byte streaming stores, by the size of what one launch writes (profiles/r03_store_policy_*.txt):
@@ -748,8 +750,14 @@ class ModelSource:
         self.lds_j = 64 * max([1] + [gmax("jac", k) for k in range(nP)])
         # Hessian: staged segment values + the tile's defect multipliers [state][row]
         self.lds_h = 64 * max([1] + [self.h_rows[k] + gmax("hess", k) for k, pp in enumerate(plan.phase_plans)])
-        # (big: + the node values [NX][256] -- a workgroup-wide interval keeps rows of every state)
-        self.lds_x = 64 * max([1] + [(pp.nx * 2 + gmax("jac", k)) if self.big else (xrows(k) + gmax("jac", k))
+        # (big: + the node values [NX][256] -- a workgroup-wide interval keeps rows of every state.  Where those rows do not
+        #  fit a workgroup's LDS -- many states -- they live in the device staging buffer that intervals beyond 256 points use
+        #  anyway: PK_BIG_GLOBAL, md.big_global / big_rows)
+        self.big_rows = max([1] + [max(pp.nx * 2 + gmax("jac", k), gmax("hess", k)) for k, pp in enumerate(plan.phase_plans)]) \
+            if self.big else 0
+        tab_bytes = 8 * 4 * (2 * self.tab_cap + 2 * 64 + self.tab_cap // 2)
+        self.big_global = bool(self.big and 8 * 256 * self.big_rows + tab_bytes > self.LDS_LIMIT)
+        self.lds_x = 64 * max([1] + [(pp.nx * 2 + gmax("jac", k)) if (self.big and not self.big_global) else (xrows(k) + gmax("jac", k))
                                      for k, pp in enumerate(plan.phase_plans)])
         # (mesh error estimation: [x | u | f] rows per wave; a workgroup-wide interval adds the interpolated [x | u] rows)
         # (a WIDE phase: the dynamics values of one chunk of states -- its arguments come straight from x, pass by pass)
@@ -910,9 +918,10 @@ class ModelSource:
         # rows of pk_cycle's in-launch finalize: the needed integrands, then the shared gradient slots phase by phase
         rows = [(0, k, r) for _, k, r in ints]
         rows += [(1, k, r) for k, v in enumerate(plan.grad_red_slots) for r in range(len(v))]
-        if len(rows) > 256:
+        if len(rows) > self.MAX_ROWS:
             raise ValueError(f"{len(rows)} sums over all nodes (integrals any system function refers to + gradient slots shared by "
-                             "the nodes of a phase): the MI355X evaluator's finalize workgroup takes at most 256 (one thread per sum)")
+                             f"the nodes of a phase): the MI355X evaluator's finalize workgroup takes at most {self.MAX_ROWS} "
+                             "(one thread per sum)")
         S.append(f"  static constexpr int N_ROWS = {len(rows)};")
         S.append(table_fn("row_arr", [a for a, _, _ in rows]))
         S.append(table_fn("row_phase", [k for _, k, _ in rows]))
@@ -926,4 +935,5 @@ class ModelSource:
         S.append("};")
         S.append("}  // namespace pkgen")
         S.append("PK_DEFINE_KERNELS(pkgen::Gen)")
-        return "\n".join(S) + "\n"
+        return ("\n".join(S) + "\n").replace("//@PK_BIG_GLOBAL@", "#define PK_BIG_GLOBAL 1" if self.big_global else
+                                                "// (workgroup-wide intervals stage their rows in LDS)")

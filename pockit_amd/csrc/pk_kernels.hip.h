@@ -1794,10 +1794,15 @@ __device__ __forceinline__ void tile_xall(const PkArgs& A, const PkTile& tl, dou
 // of a workgroup barrier), rows of PkArgs.big_row doubles.  Everything else is the same code.
 // ============================================================================================
 #define PK_BIG_MAX 256
+// PK_BIG_GLOBAL (code generator): the rows of EVERY workgroup-wide interval live in the staging buffer -- a model whose rows of
+// PK_BIG_MAX doubles do not fit a workgroup's LDS (a workgroup-wide interval keeps rows of every state: 2 n_x + group rows)
+#ifndef PK_BIG_GLOBAL
+#define PK_BIG_GLOBAL 0
+#endif
 // where an interval of K points stages its rows: (row length, base) -- sub-slot u as in pk_abi.h
 struct BigStage { int KS; double* base; };
 __device__ __forceinline__ BigStage big_stage(const PkArgs& A, int K, int slot, int u, double* __restrict__ lds) {
-  if (K <= PK_BIG_MAX) return BigStage{PK_BIG_MAX, lds};
+  if (K <= PK_BIG_MAX && !PK_BIG_GLOBAL) return BigStage{PK_BIG_MAX, lds};
   return BigStage{A.big_row, A.big_stage + ((size_t)slot * 4 + (size_t)u) * (size_t)A.big_slot};
 }
 // ---- workgroup-wide intervals of a model whose derivative set is evaluated in groups (P::J_NG / P::H_NG > 1; see
@@ -3444,6 +3449,9 @@ __device__ __forceinline__ void kernel_cycle(const PkTile* pre_tile, int pre_n_t
 #endif
     return;
   }
+#ifdef PK_TRACE
+  const unsigned long long pk_t_entry = __builtin_amdgcn_s_memrealtime();      // (before the tile record is asked for: mark 14)
+#endif
   const int slot = pk::xcd_tile_block((int)blockIdx.x, 3, pre_grid);
   if constexpr (Gen::GROUPED) {
     // A model evaluated in groups: the workgroups of a tile block are [Jacobian pass 0 .. NJ-1 | values | dynamics pass 0 ..
@@ -3489,6 +3497,12 @@ __device__ __forceinline__ void kernel_cycle(const PkTile* pre_tile, int pre_n_t
   PK_TILE_PROLOGUE_FROM(pre_tile, pre_n_tiles);
   PK_KA_COLLECT();
 #undef PK_KA_COLLECT
+#ifdef PK_TRACE
+  if (A.trace != nullptr && lane == 0 && tl.pad >= 0) {      // role of the record: 0 values / whole tile, 1 Jacobian, 2 Hessian
+    const int role = sub == (split ? 2 : 1) ? 2 : (split && sub == 0 ? 1 : 0);
+    A.trace[(size_t)(tl.pad * 3 + role) * 16 + 14] = pk_t_entry;
+  }
+#endif
 #ifdef PK_BIG
   PkTile tl0;
   if (big_block(pre_tile, pre_n_tiles, blk, tl0)) {

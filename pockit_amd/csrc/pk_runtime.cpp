@@ -815,6 +815,8 @@ int pk_load_model(pk_ctx* c, const void* code_object, size_t len, const pk_model
   if (md->cycle_subs < 0 || md->cycle_subs > 4096) return fail(c, 25, "pk_load_model: cycle_subs %d", md->cycle_subs);
   if (md->hess_subs < 0 || md->hess_subs > 4096 || (md->hess_subs > 0) != (md->cycle_subs > 0))
     return fail(c, 25, "pk_load_model: hess_subs %d with cycle_subs %d", md->hess_subs, md->cycle_subs);
+  if (md->big_global < 0 || md->big_global > 1 || md->big_rows < 0 || md->big_rows > (1 << 20))
+    return fail(c, 25, "pk_load_model: big_global %d / big_rows %d", md->big_global, md->big_rows);
   if (md->hessc_subs < 0 || md->hessc_subs > 4096 || md->jacc_subs < 0 || md->jacc_subs > 4096 ||
       ((md->hessc_subs > 0 || md->jacc_subs > 0) && md->cycle_subs == 0))
     return fail(c, 25, "pk_load_model: hessc_subs %d / jacc_subs %d with cycle_subs %d", md->hessc_subs, md->jacc_subs, md->cycle_subs);
@@ -867,7 +869,7 @@ int pk_set_problem(pk_ctx* c, const pk_problem_desc* pd) {
     int32_t n_stage = 0, kmax = 0;
     for (PkTile& t : tiles) {
       t.stage = 0;
-      if (t.nj > 0 && t.K > 256) {
+      if (t.nj > 0 && t.K > (c->md.big_global ? PK_WAVE : 256)) {
         t.stage = n_stage++;
         if (t.K > kmax) kmax = t.K;
       }
@@ -877,6 +879,7 @@ int pk_set_problem(pk_ctx* c, const pk_problem_desc* pd) {
     if (n_stage) {
       size_t rows = (size_t)(c->md.lds_x > c->md.lds_h ? c->md.lds_x : c->md.lds_h) / PK_WAVE;
       if ((size_t)c->md.lds_jc / PK_WAVE > rows) rows = (size_t)c->md.lds_jc / PK_WAVE;
+      if ((size_t)c->md.big_rows > rows) rows = (size_t)c->md.big_rows;      // (big_global: lds_x is sized for ordinary tiles only)
       c->big_row = (kmax + 7) & ~7;
       const size_t slot = rows * (size_t)c->big_row;
       if (slot > (size_t)INT32_MAX) return fail(c, 33, "pk_set_problem: an interval with %d points is too long for the staging buffer", kmax);

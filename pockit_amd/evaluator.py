@@ -321,6 +321,7 @@ class Evaluator:
         # (the stand-alone compact kernels of such a model: a workgroup per pass too)
         md.hessc_subs = self.src.hc_ngmax if (self.src.cycle_subs and self.src.hc_ngmax > 1) else 0
         md.jacc_subs = self.src.jc_ngmax if (self.src.cycle_subs and self.src.jc_ngmax > 1) else 0
+        md.big_global, md.big_rows = int(self.src.big_global), int(self.src.big_rows)
         self._err_views = None
         self._csr = {}
         md.prepass_f = 1

@@ -142,3 +142,35 @@ def test_compact_hessian_passes_of_a_wide_model():
     assert mu_chunks([set(range(65))], 16, 16, 64) is None
     assert mu_chunks([set(range(40))], 16, 16, 64) == [(0, 1, list(range(40)))]
     assert mu_chunks([], 16, 16, 64) == [(0, 0, [])]
+
+
+@pytest.mark.parametrize("states", [18, 33, 34, 52, 128])
+def test_workgroup_wide_intervals_of_wide_models_fit_too(states):
+    """An interval with more than 64 points keeps rows of every state (2 n_x + group rows of 256 doubles per workgroup): up to
+    ~33 states they fit the LDS; beyond, the generator moves them to the device staging buffer (PK_BIG_GLOBAL, md.big_global /
+    big_rows) and sizes the LDS for the ordinary tiles only -- the launch fits for every width."""
+    from pockit_amd import benchmarks, radau
+
+    system, _, _ = benchmarks.state_chain(radau, states=states, mesh=[0, 0.4, 1.0], num_point=[70, 5])
+    for cap in (32, 16, 8):
+        src = ModelSource(system.plan, group_cap=cap)
+        if src.big_global:
+            assert "#define PK_BIG_GLOBAL 1" in src.source and src.big_rows >= 2 * states and src.fits_lds()
+        else:
+            assert "#define PK_BIG_GLOBAL 1" not in src.source and src.lds_x // 64 >= 2 * states
+    assert ModelSource(system.plan, group_cap=16).fits_lds()
+    assert ModelSource(system.plan, group_cap=32).big_global == (states > 29)
+
+
+def test_more_sums_over_all_nodes_than_the_finalize_workgroup_takes_is_a_clear_error(monkeypatch):
+    """pk_cycle's finalize workgroup keeps one thread per sum over all nodes (the integrals a system function refers
+    to + the gradient slots shared by the nodes of a phase); a model with more than 256 of them failed inside hipcc with a
+    template error.  The generator now raises a ValueError that says what the limit is (here: with the limit lowered, on the
+    12-phase relay whose every phase carries an integral)."""
+    from pockit_amd import benchmarks, radau
+
+    system, _, _ = benchmarks.phase_relay(radau, phases=12, mesh=3, num_point=3)
+    assert "N_ROWS = 23" in ModelSource(system.plan).source      # (12 integrals + 11 hand-over parameters)
+    monkeypatch.setattr(ModelSource, "MAX_ROWS", 22)
+    with pytest.raises(ValueError, match="sums over all nodes"):
+        ModelSource(system.plan)

@@ -1949,3 +1949,40 @@ def test_writable_results_give_the_reference_semantics():
     system.writable_results = False
     assert not system.jacobian(x * 1.0000001).flags.writeable
     system._invalidate()
+
+
+def test_the_cycle_layout_survives_new_tables():
+    """pk_set_problem starts every problem in the reference layouts; an Evaluator whose caller had chosen the compact
+    layouts for cycle_dev (compact-sized device buffers!) must apply them again after ``set_tables`` -- otherwise the next
+    launch writes nnz_J + nnz_H values into buffers sized for nnz_Jc + nnz_Hc."""
+    import torch
+
+    from pockit_amd.evaluator import Tables
+
+    system, _, guess = models.brachistochrone(_ns("radau", "pockit_amd"), mesh=37, num_point=5)
+    plan, ev = system.plan, system.evaluator
+    x, lam, sigma = models.bench_inputs(system, guess)
+    plan.jacc  # noqa: B018
+    dev = torch.device("cuda", 0)
+    dx, dlam = torch.from_numpy(x).to(dev), torch.from_numpy(lam).to(dev)
+    sizes = (1, plan.n, plan.m, plan.nnz_Jc, plan.nnz_Hc)
+    guard = 4096
+
+    def run():
+        o = [torch.full((n + guard,), float("nan"), dtype=torch.float64, device=dev) for n in sizes]
+        torch.cuda.synchronize()
+        ev.cycle_dev(dx.data_ptr(), dlam.data_ptr(), sigma, *[t.data_ptr() for t in o])
+        ev.sync()
+        return [t.cpu().numpy() for t in o]
+
+    ev.set_cycle_layout(True, True)
+    try:
+        before = run()
+        ev.set_tables(Tables(plan, ev.src))
+        after = run()
+    finally:
+        ev.set_cycle_layout(False, False)
+    for a, b, n in zip(after, before, sizes):
+        assert np.array_equal(a[:n], b[:n]) and np.isnan(a[n:]).all() and np.isnan(b[n:]).all(), "values beyond the compact sizes were written"
+    assert plan.nnz_Hc < plan.nnz_H
+    system._invalidate()

@@ -126,18 +126,23 @@ def test_wide_models_in_both_forms_of_the_cycle(case, pp, monkeypatch):
     system._invalidate()
 
 
-def test_wide_model_with_a_workgroup_wide_interval():
-    """More than 64 points in an interval (a whole workgroup per role, rows of every state in LDS) on a model with more than
-    16 states: the chunk functions of the wide path feed the workgroup-wide rows.  Reference: the NumPy execution of the
-    product's own plan (the oracle's np.roots tables carry no digits at 70 points, tests/test_gpu_parity.py does the same)."""
+@pytest.mark.parametrize("case", [dict(states=18, mesh=[0, 0.4, 1.0], num_point=[70, 5]),
+                                  dict(states=40, mesh=[0, 0.3, 1.0], num_point=[5, 66]),
+                                  dict(states=52, mesh=[0, 0.5, 0.6, 1.0], num_point=[4, 130, 3])])
+def test_wide_model_with_a_workgroup_wide_interval(case):
+    """More than 64 points in an interval (a whole workgroup per role, rows of every state) on a model with more than 16
+    states: the chunk functions of the wide path feed the workgroup-wide rows; from ~33 states on those rows no longer fit a
+    workgroup's LDS and live in the device staging buffer that intervals beyond 256 points use (PK_BIG_GLOBAL, round 5 --
+    before, such a model could not load).  Reference: the NumPy execution of the product's own plan (the oracle's np.roots
+    tables carry no digits at these orders, tests/test_gpu_parity.py does the same)."""
     from plan_interp import Interp
 
-    kw = dict(states=18, mesh=[0, 0.4, 1.0], num_point=[70, 5])
-    system, _, guess = models.state_chain(_ns("radau", "pockit_amd"), **kw)
+    system, _, guess = models.state_chain(_ns("radau", "pockit_amd"), **case)
     x, lam, sigma = models.bench_inputs(system, guess)
     it = Interp(system.plan, x, lam, sigma)
     want = (it.objective(), it.gradient(), it.constraints(), it.jacobian(), it.hessian())
-    assert system.evaluator.src.big and system.evaluator.src.wide == [True]
+    src = system.evaluator.src
+    assert src.big and src.wide == [True] and src.big_global == (case["states"] > 33) and src.fits_lds()
     got = (system.objective(x), system.gradient(x), system.constraints(x), system.jacobian(x), system.hessian(x, lam, sigma))
     for a, b, what in zip(got, want, ("f", "grad", "g", "J", "H")):
         close(a, b, what=f"callbacks {what}")

@@ -51,7 +51,8 @@ for rep in range(4):
                                                                  #  POCKIT_AMD_TRACE_B2B=1 traces the last of 3 queued launches)
     ev.ctx.check(lib.pk_trace_read(h, buf.ctypes.data_as(C.POINTER(C.c_uint64)), len(buf)))
     m = buf.reshape(3 * n + 3, 16).astype(np.int64)
-    clk = m[:, 14:].copy()                                        # (marks 14 / 15 hold s_memtime, not the device clock)
+    clk = m[:, 14:].copy()                                        # (marks 14 / 15 of the three extra records hold s_memtime,
+    entry = m[:3 * n, 14].copy()                                  #  mark 14 of a tile wave its device clock at kernel entry)
     m[:, 14:] = 0
     t0 = m[m > 0].min()
     us = np.where(m > 0, (m - t0) * TICK_US, np.nan)
@@ -60,10 +61,19 @@ for rep in range(4):
         continue
     for role in range(3):
         r = us[role:3 * n:3]
-        r = r[~np.isnan(r[:, 0])]
+        ent = entry[role:3 * n:3]
+        ok = ~np.isnan(r[:, 0])
+        r = r[ok]
         if not len(r):
             continue
         print(f"  {ROLES[role]} ({len(r)} waves)")
+        ent = ent[ok]
+        if (ent > 0).any():                                      # kernel entry -> tile record and kernel arguments in SGPRs
+            d = (m[role:3 * n:3, 0][ok][ent > 0] - ent[ent > 0]) * TICK_US
+            e0 = (ent[ent > 0] - t0) * TICK_US
+            print(f"    {'kernel entry':36s} median {np.median(e0):6.2f}  p10 {np.percentile(e0, 10):6.2f}  p90 {np.percentile(e0, 90):6.2f}  "
+                  f"max {e0.max():6.2f}   (entry -> tile record in SGPRs: median {np.median(d):.2f} us, p10 {np.percentile(d, 10):.2f}, "
+                  f"p90 {np.percentile(d, 90):.2f})")
         for k, label in MARKS.items():
             col = r[:, k][~np.isnan(r[:, k])]
             if len(col):
