@@ -231,6 +231,7 @@ class ModelSource:
     # Hessian contracts the multipliers its pass refers to, and every pass fetches the node arguments it reads itself.
     WIDE_NX = 16
     WIDE_CHUNK = 16
+    WIDE_NX_LOW = 8        # (see __init__: wide_nx)
     MAX_ROWS = 256         # sums over all nodes pk_cycle's finalize workgroup takes: one thread each (fin_handoff)
     MU_MAX = 64            # most states ONE entry of the compact Hessian may refer to (their multiplier rows are staged together)
     LDS_LIMIT = 160 * 1024
@@ -243,8 +244,12 @@ class ModelSource:
     # lambda and the tables live there too, and the step was measured between 209 and 262 MB of outputs
     MALL_BYTES = 240_000_000
 
-    def __init__(self, plan: SystemPlan, sharded: bool = False, output_share: float = 1.0, group_cap=None):
+    def __init__(self, plan: SystemPlan, sharded: bool = False, output_share: float = 1.0, group_cap=None, wide_nx=None):
+        """``wide_nx``: a phase with more states than this is evaluated the WIDE way (default WIDE_NX = 16; evaluator.compile_plan
+        lowers it to WIDE_NX_LOW for a pass-parallel model whose cycle kernel would otherwise leave room for one wave per SIMD
+        only: the state-chunked values role needs far fewer registers)."""
         self.plan = plan
+        self.wide_nx = int(wide_nx or self.WIDE_NX)
         self.group_cap = int(group_cap or os.environ.get("POCKIT_AMD_GROUP_CAP") or self.GROUP_CAP)
         self.groups = {}          # (callback, phase) -> [(i0, ni, n0, nn)]
         # Bytes one launch of the cycle writes on THIS evaluator (a shard of a multi-GPU run writes its share): decides the
@@ -270,8 +275,9 @@ class ModelSource:
         self.big = any(int(pp.layout.K.max()) > 64 for pp in plan.phase_plans)
         self.compact = not plan.outer
         self.compact_j = True
-        self.wide = [pp.nx > self.WIDE_NX for pp in plan.phase_plans]
-        self.dyn_chunks = [split_even(pp.nx, min(self.WIDE_CHUNK, self.group_cap)) if self.wide[k] else []
+        self.wide = [pp.nx > self.wide_nx for pp in plan.phase_plans]
+        chunk = self.WIDE_CHUNK if self.wide_nx >= self.WIDE_NX else self.WIDE_NX_LOW
+        self.dyn_chunks = [split_even(pp.nx, min(chunk, self.group_cap)) if self.wide[k] else []
                            for k, pp in enumerate(plan.phase_plans)]
         self.hc_passes = {}
         if self.compact:

@@ -214,6 +214,22 @@ __device__ __forceinline__ double wave_sum(double v) {
   return __hiloint2double(hi, lo);
 }
 
+// The sums over the wave of N per-lane values -> dst[0 .. N) (written by lane 0): ALL trees first -- N independent chains of DPP
+// moves and adds the scheduler interleaves -- then one block of stores.  Tree by tree with the conditional store in between,
+// every tree was a serial chain of its own: a model with 12 static parameters ran 13 of them one after the other in front
+// of the hand-off of its partial sums (drone_stabilization).  Same operations per sum: bit-identical.
+template <int N>
+__device__ __forceinline__ void wave_sums_to(double* v, double* __restrict__ dst, int lane) {
+  if constexpr (N > 0) {
+#pragma unroll
+    for (int r = 0; r < N; ++r) v[r] = wave_sum(v[r]);
+    if (lane == 0) {
+#pragma unroll
+      for (int r = 0; r < N; ++r) dst[r] = v[r];
+    }
+  }
+}
+
 // ---- fp64 matrix cores for the contractions that ARE matrix products: an interval with 64 < K <= 256 points --------
 // Where an interval takes a whole workgroup, its K x K integration / interpolation blocks times the [K x n] per-node values
 // are small GEMMs (phasebase.py:1008-1012 I_m.dot(F), :1339-1372 the augmented products).  v_mfma_f64_16x16x4_f64 computes
@@ -810,11 +826,7 @@ __device__ __forceinline__ void tile_int(const PkArgs& A, const PkTile& tl, doub
 #pragma unroll
     for (int r = 0; r < P::INT_N; ++r) o[r] *= w;
   }
-#pragma unroll
-  for (int r = 0; r < P::INT_N; ++r) {
-    const double v = wave_sum(o[r]);
-    if (lane == 0) wint[r] = v;
-  }
+  wave_sums_to<P::INT_N>(o, wint, lane);
 }
 
 // ============================================================================================
@@ -944,11 +956,7 @@ __device__ __forceinline__ void tile_grad(const PkArgs& A, const PkTile& tl, dou
     load_node<P>(A, ph, s, dt, mt, q, a, tau, w);
     node_gradient<P>(A, ph, q, a, tau, dt, w, sy, ov, orr, false);
   }
-#pragma unroll
-  for (int r = 0; r < P::GR_NR; ++r) {
-    const double v = wave_sum(orr[r]);
-    if (lane == 0) wgrad[r] = v;
-  }
+  wave_sums_to<P::GR_NR>(orr, wgrad, lane);
 }
 
 // ============================================================================================
@@ -1618,16 +1626,8 @@ __device__ __forceinline__ void tile_xall_single(const PkArgs& A, const PkTile& 
     }
   }
   if (ROLE != 2) {
-#pragma unroll
-    for (int r = 0; r < P::INT_N; ++r) {
-      const double v = wave_sum(oi[r]);
-      if (lane == 0) wint[r] = v;
-    }
-#pragma unroll
-    for (int r = 0; r < P::GR_NR; ++r) {
-      const double v = wave_sum(orr[r]);
-      if (lane == 0) wgrad[r] = v;
-    }
+    wave_sums_to<P::INT_N>(oi, wint, lane);
+    wave_sums_to<P::GR_NR>(orr, wgrad, lane);
     PK_MARK(10);
     if (pub_blk >= 0) {
       __syncthreads();                                      // (all four waves of the workgroup have this role)
@@ -1696,6 +1696,8 @@ __device__ __forceinline__ void tile_xall_grouped(const PkArgs& A, const PkTile&
                                                   int pub_blk) {
   const PkPhase& ph = A.ph[P::INDEX];
   const TileGeom g = tile_geom<P>(tl);
+  PK_TRACE_REC(ROLE == 2 ? 1 : 0);
+  PK_MARK(0);
   double s[PK_NS], dt, mt;
   phase_scalars<P>(A, ph, s, dt, mt);
   const PkSys sy{s, A.Ibuf, A.sigma, A.lam};
@@ -1713,6 +1715,7 @@ __device__ __forceinline__ void tile_xall_grouped(const PkArgs& A, const PkTile&
   if (ROLE != 1) segb.settle();
   if (ROLE != 2) tbase.settle();
   loads_done();
+  PK_MARK(1);
   const bool live = lane < g.nq;
   if (ROLE != 2) {
     double oi[P::INT_N > 0 ? P::INT_N : 1], orr[P::GR_NR > 0 ? P::GR_NR : 1];
@@ -1721,30 +1724,34 @@ __device__ __forceinline__ void tile_xall_grouped(const PkArgs& A, const PkTile&
 #pragma unroll
     for (int r = 0; r < P::GR_NR; ++r) orr[r] = 0.0;
     double og[P::G_NOUT], ov[P::NX + P::NU];
+    constexpr bool SUMS_FIRST = P::NX + P::NU + P::NC <= 48;      // (values the stores keep in registers across the sums)
     if (live) {
       double ot[P::GR_NR > 0 ? P::GR_NR : 1], op[P::INT_N > 0 ? P::INT_N : 1];
+      PK_MARK(2);
       P::mid_xval(a, tau, dt, w, sy, sv + lane, PK_WAVE, og, ov, ot, op);      // (dynamics values: straight into the LDS rows)
+      PK_MARK(3);
       if (lane < g.nown) {
 #pragma unroll
         for (int r = 0; r < P::INT_N; ++r) oi[r] = op[r] * w;
 #pragma unroll
         for (int r = 0; r < P::GR_NR; ++r) orr[r] = ot[r];
         node_gradient_eval<P>(ph, q, a, tau, dt, w, sy, ov, orr, true);   // boundary nodes re-evaluate their own entries
-        node_gradient_store<P>(A, ph, q, ov);      // (at once: a wide model's n_x + n_u entries leave the registers here)
+        // The per-node stores (gradient entries, path values) go out at once where the model is so wide that they would crowd
+        // the registers across the sums (SUMS_FIRST false); otherwise BEHIND the hand-off of the partial sums: the finalize
+        // workgroup's chain -- poll across the XCDs while the launch is draining (2.4 us from the last publish to "seen"),
+        // then its own sums -- ends the launch of a model with many sums (drone_stabilization: values waves handed off at
+        // 4.3-5.3 us, the finalize workgroup ended at 10.2 us, everything else at 7.5; profiles/r05_n_drone_wave_timeline_wide.txt)
+        if constexpr (!SUMS_FIRST) {
+          node_gradient_store<P>(A, ph, q, ov);
 #pragma unroll
-        for (int j = 0; j < P::NC; ++j) put(&A.o_g[ph.path_off + j * ph.L_m + q], og[P::NX + j]);
+          for (int j = 0; j < P::NC; ++j) put(&A.o_g[ph.path_off + j * ph.L_m + q], og[P::NX + j]);
+        }
       }
     }
-#pragma unroll
-    for (int r = 0; r < P::INT_N; ++r) {
-      const double v = wave_sum(oi[r]);
-      if (lane == 0) wint[r] = v;
-    }
-#pragma unroll
-    for (int r = 0; r < P::GR_NR; ++r) {
-      const double v = wave_sum(orr[r]);
-      if (lane == 0) wgrad[r] = v;
-    }
+    PK_MARK(12);
+    wave_sums_to<P::INT_N>(oi, wint, lane);
+    wave_sums_to<P::GR_NR>(orr, wgrad, lane);
+    PK_MARK(10);
     if (pub_blk >= 0) {
       __syncthreads();                                      // (all four waves of the workgroup have this role)
       if ((int)threadIdx.x < PK_NRED) {                     // same order as publish_block_partials
@@ -1758,13 +1765,27 @@ __device__ __forceinline__ void tile_xall_grouped(const PkArgs& A, const PkTile&
         handoff_put(A.cpart2 + (size_t)pub_blk * PK_NRED + threadIdx.x, vg);
       }
     }
+    if constexpr (SUMS_FIRST) {
+      if (live && lane < g.nown) {
+        node_gradient_store<P>(A, ph, q, ov);
+#pragma unroll
+        for (int j = 0; j < P::NC; ++j) put(&A.o_g[ph.path_off + j * ph.L_m + q], og[P::NX + j]);
+      }
+    }
     // the end-slot state values of the defect rows only now (wave shuffles of the node values; a full LGR tile reaches one
     // slot past the wave): the node's own values ARE its row's x_q (a[0 .. NX) until the Jacobian passes make them opaque).
+    PK_MARK(11);
     double xe[P::WIDE ? 1 : P::NX];
     if constexpr (!P::WIDE) defect_ends<P>(A, ph, tl, g, a, xe, lane);
     wave_lds_sync();
+    PK_MARK(5);
     PK_PHASE_B(T, (xval_phase_b<P, ROLE, STAGED, CJ>(A, ph, tl, g, T, s, dt, sv, a, xe, tbase, lane)));
+    PK_MARK(7);
     if constexpr (P::WIDE && !PP) dyn_passes<P>(A, ph, tl, g, T, s, dt, mt, sv, lane);
+#ifdef PK_TRACE
+    __builtin_amdgcn_s_waitcnt(0);      // all stores acknowledged
+    PK_MARK(9);
+#endif
   } else {
     wave_lds_sync();                                        // (the table blocks the wave staged for itself)
   }
@@ -3730,24 +3751,23 @@ __device__ __forceinline__ void fin_handoff(const PkArgs& A) {
   }
   PK_MARK_AT(A.n_tiles * 3 + 2, 2);
 #pragma unroll
-  for (int row = 0; row < Gen::N_ROWS; ++row) {
-    const double v = wave_sum(acc[row]);
-    if ((t & 63) == 0) red[row * PK_WAVES_PER_BLOCK + wave] = v;
+  for (int row = 0; row < Gen::N_ROWS; ++row) acc[row] = wave_sum(acc[row]);      // (all trees first: see wave_sums_to)
+  if ((t & 63) == 0) {
+#pragma unroll
+    for (int row = 0; row < Gen::N_ROWS; ++row) red[row * PK_WAVES_PER_BLOCK + wave] = acc[row];
   }
   __syncthreads();
+  if (t < Gen::N_ROWS) {      // thread = row (a chain of N_ROWS one-thread branches was 1 us of the launch's tail for 13 rows)
+    double v = 0.0;
 #pragma unroll
-  for (int row = 0; row < Gen::N_ROWS; ++row)
-    if (t == row) {
-      double v = 0.0;
-#pragma unroll
-      for (int w = 0; w < PK_WAVES_PER_BLOCK; ++w) v += red[row * PK_WAVES_PER_BLOCK + w];
-      tot[row] = v;
-      if (!Gen::row_arr(row)) {                           // integrand row n = row: I_k = dt * sum   (phasebase.py:997-1006)
-        const double Ik = v * dts[Gen::row_phase(row)];
-        Ish[Gen::int_global(row)] = Ik;
-        A.Ibuf[Gen::int_global(row)] = Ik;
-      }
+    for (int w = 0; w < PK_WAVES_PER_BLOCK; ++w) v += red[t * PK_WAVES_PER_BLOCK + w];
+    tot[t] = v;
+    if (!Gen::row_arr(t)) {                               // integrand row n = row: I_k = dt * sum   (phasebase.py:997-1006)
+      const double Ik = v * dts[Gen::row_phase(t)];
+      Ish[Gen::int_global(t)] = Ik;
+      A.Ibuf[Gen::int_global(t)] = Ik;
     }
+  }
   __syncthreads();
   const PkSys sy{ssh, Ish, A.sigma, A.lam};
 #ifdef PK_SHARDED

@@ -231,10 +231,10 @@ def compile_plan(plan: SystemPlan, sharded=False, output_share=1.0):
 
     generated = {}
 
-    def generate(cap):
-        if cap not in generated:
-            generated[cap] = ModelSource(plan, sharded=sharded, output_share=output_share, group_cap=cap)
-        return generated[cap]
+    def generate(cap, wide_nx=None):
+        if (cap, wide_nx) not in generated:
+            generated[(cap, wide_nx)] = ModelSource(plan, sharded=sharded, output_share=output_share, group_cap=cap, wide_nx=wide_nx)
+        return generated[(cap, wide_nx)]
 
     def build(cap, src=None):
         src = src or generate(cap)
@@ -257,14 +257,15 @@ def compile_plan(plan: SystemPlan, sharded=False, output_share=1.0):
     # with the chip full (humanoid 5000 x 8) the single pass is 4 % faster (profiles/r04_ze_*.txt).  The choice is a fact of
     # the mesh like PK_TAB_CAP: a refinement that crosses the line costs one more (cached) compile.
     free = not fixed_cap and os.environ.get("POCKIT_AMD_PASS_PARALLEL", "auto") == "auto"
+    settled = None                    # (the underfill rule's choice: the group-size searches below are skipped, not the rest)
     if free and cap0 > ModelSource.GROUP_CAP // 2 and _launch_underfills_the_chip(plan, max(1, int(round(1.0 / output_share)))):
         probe = generate(ModelSource.GROUP_CAP // 2)
         if probe.grouped and probe.cycle_subs and probe.fits_lds():
             trial = build(probe.group_cap, probe)
             if trial[2] == 0:
-                return trial[0], trial[1]
-    best = build(cap0)
-    while best[2] > 0 and best[0].group_cap > 4 and best[0].grouped and not fixed_cap:
+                settled = trial
+    best = settled or build(cap0)
+    while settled is None and best[2] > 0 and best[0].group_cap > 4 and best[0].grouped and not fixed_cap:
         trial = build(best[0].group_cap // 2)
         if trial[2] >= best[2]:
             break
@@ -285,6 +286,22 @@ def compile_plan(plan: SystemPlan, sharded=False, output_share=1.0):
             if trial[2] <= best[2]:
                 best = trial
             break
+    # A pass-parallel model whose cycle kernel leaves room for ONE wave per SIMD runs its workgroups in two rounds (one
+    # workgroup per CU at a time): the values workgroups of the second round publish their partial sums late and the launch
+    # ends with the finalize workgroup (drone_stabilization at 2000 x 4: 480 workgroups, values waves entering up to 5.4 us
+    # into a 13.3 us launch, profiles/r05_m_drone_wave_timeline.txt).  The register hog is the values role of a phase with
+    # 9 ... 16 states (all states' node values, end slots and row sums at once: 250 VGPRs); evaluated the WIDE way -- chunks of
+    # 8 states -- it needs far fewer.  Tried only there, kept only if it raises the occupancy without spills.
+    src = best[0]
+    if free and src.cycle_subs and best[2] == 0 and src.wide_nx == ModelSource.WIDE_NX and \
+            any(ModelSource.WIDE_NX_LOW < pp.nx <= ModelSource.WIDE_NX for pp in plan.phase_plans):
+        occ = lambda s_: ((hipbuild.resource_usage(s_.source, fastmath=fast) or {}).get("pk_cycle") or {}).get("occupancy", 0)  # noqa: E731
+        if occ(src) == 1:
+            probe = generate(src.group_cap, ModelSource.WIDE_NX_LOW)
+            if probe.cycle_subs and probe.fits_lds():
+                trial = build(src.group_cap, probe)
+                if trial[2] == 0 and occ(trial[0]) > 1:
+                    best = trial
     if best[2] > 0:
         import warnings
 

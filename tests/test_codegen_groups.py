@@ -53,6 +53,14 @@ def test_the_three_large_example_models_fit_and_do_not_spill(name):
     for kernel, u in usage.items():
         assert u.get("vgpr_spill", 0) == 0 and u.get("scratch", 0) == 0, (kernel, u)
     del single
+    if name == "drone_stabilization":
+        # round 5: its 16 states made the values role hold 250 VGPRs -- pk_cycle left room for ONE wave per SIMD, the 480
+        # workgroups of the 2000 x 4 cycle ran in two rounds (13.8 us).  compile_plan now evaluates such a phase the WIDE way
+        # (chunks of 8 states) when that raises the occupancy: 128 VGPRs, 9.8 us (profiles/r05_o_drone_wave_timeline_sums_first.txt)
+        assert src.wide == [True] and src.wide_nx == ModelSource.WIDE_NX_LOW and len(src.dyn_chunks[0]) == 2
+        assert usage["pk_cycle"]["occupancy"] >= 2 and usage["pk_cyclec"]["occupancy"] >= 2
+    else:
+        assert src.wide == [False]
 
 
 def test_group_size_follows_the_launch_not_only_the_model(monkeypatch):

@@ -25,8 +25,24 @@ MARKS = {0: "wave entry (tile record in SGPRs)", 1: "x + tables loaded", 2: "eva
 ROLES = ["values wave", "Jacobian wave", "Hessian wave"]
 name = sys.argv[1] if len(sys.argv) > 1 else "planar_quadrotor"
 intervals = int(sys.argv[2]) if len(sys.argv) > 2 else 2000
-system, _, guess = bench.build_workload(name, intervals, radau)
-x, lam, sigma = models.bench_inputs(system, guess)
+if name.startswith("example:"):          # an example program's model (tests/golden/examples/<name>.model.json) re-meshed to
+    import json                          # `intervals` x argv[3] points: example:drone_stabilization 2000 4
+
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import model_io
+
+    with open(os.path.join(ROOT, "tests", "golden", "examples", name.split(":", 1)[1] + ".model.json")) as fh:
+        desc = json.load(fh)
+    K = int(sys.argv[3]) if len(sys.argv) > 3 else 4
+    for pd in desc["phases"]:
+        pd["mesh"] = [float(v) for v in np.linspace(0.0, 1.0, intervals + 1)]
+        pd["num_point"] = [K] * intervals
+    system = model_io.load_system(desc)
+    rng = np.random.default_rng(7)
+    x, lam, sigma = rng.uniform(0.6, 1.4, size=system.plan.n), rng.standard_normal(system.plan.m), 0.7
+else:
+    system, _, guess = bench.build_workload(name, intervals, radau)
+    x, lam, sigma = models.bench_inputs(system, guess)
 ev = system.evaluator
 lib, h = ev.ctx.lib, ev.ctx.handle
 ev.ctx.check(lib.pk_trace_read(h, None, 0))                      # arm
