@@ -20,6 +20,7 @@ import os
 
 import sympy as sp
 from sympy.printing.c import C99CodePrinter
+from sympy.printing.repr import ReprPrinter
 
 from .model import FIXED, FREE, FUNC
 from .transcription import DT, SIG, TAU, WQ, SystemPlan, lam_path, lam_sys, ltb_sym, ltf_sym, mu_sym
@@ -87,6 +88,27 @@ def _fuse_sincos(exprs):
     return [e.xreplace(repl) for e in exprs], pairs
 
 
+class _MemoRepr(ReprPrinter):
+    """``sympy.srepr`` with every sub-expression printed once per process: the same strings (the emit keys on disk stay
+    valid), but the derivative entries of a model share most of their sub-trees, and ordering an Add's terms for printing
+    is what a warm model set-up spent its time in (humanoid: 22 of 25 s of compile_plan before)."""
+
+    def __init__(self):
+        super().__init__()
+        self.memo = {}
+
+    def _print(self, expr, **kwargs):
+        if kwargs or not isinstance(expr, sp.Basic):
+            return super()._print(expr, **kwargs)
+        got = self.memo.get(expr)
+        if got is None:
+            got = self.memo[expr] = super()._print(expr)
+            if len(self.memo) > 400_000:
+                self.memo.clear()
+        return got
+
+
+_SREPR = _MemoRepr()
 _EMIT_MEMO = {}
 _EMIT_DIR = os.path.join(os.environ.get("POCKIT_AMD_CACHE", os.path.join(os.path.dirname(os.path.abspath(__file__)), "_cache")),
                          "emit")
@@ -107,8 +129,8 @@ def _emit_body(outputs, base, names, indent="    "):
     defs = [names.apply(base[k]) for k in needed]
     finals = [names.apply(e) for _, e in outs]
     key = hashlib.sha256("\x1f".join(
-        ["emit-v1", indent] + [k.name for k in needed] + [sp.srepr(e) for e in defs] +
-        [lv for lv, _ in outs] + [sp.srepr(e) for e in finals]).encode()).hexdigest()[:32]
+        ["emit-v1", indent] + [k.name for k in needed] + [_SREPR.doprint(e) for e in defs] +
+        [lv for lv, _ in outs] + [_SREPR.doprint(e) for e in finals]).encode()).hexdigest()[:32]
     if key in _EMIT_MEMO:
         return _EMIT_MEMO[key]
     path = os.path.join(_EMIT_DIR, key + ".c")
