@@ -534,6 +534,52 @@ def state_chain(ns, states=52, mesh=40, num_point=4, window=0):
     return system, [phase], [guess]
 
 
+def wide_mix(ns, shapes=((60, 3, 10, 4),), statics=6, mesh=40, num_point=4, free_time=True):
+    """Synthetic models that are wide in EVERY direction the modeling API has (the reference loops over states, controls,
+    path constraints, integrals and static parameters with no limit: phasebase.py:1083-1124, 1234-1285, systembase.py:
+    148-187): one phase per entry of ``shapes`` = (states, controls, path constraints, integrals); ``statics`` static
+    parameters enter every dynamics function, the first ones link the phases (terminal time of phase k = initial time of
+    phase k + 1 = a static parameter, FUNC boundaries; the first state of phase k + 1 starts where a static parameter says,
+    which a system constraint ties to nothing else) and, with ``free_time``, the last terminal time.  Not a reference
+    program."""
+    n_ph = len(shapes)
+    n_s = max(int(statics), n_ph + 1)
+    system = ns.System(n_s)
+    s = list(system.s)
+    phases, guesses, obj = [], [], 0
+    for k, (nx, nu, nc, ni) in enumerate(shapes):
+        phase = system.new_phase([f"x{k}_{i}" for i in range(nx)], [f"u{k}_{i}" for i in range(nu)])
+        x, u = list(phase.x), list(phase.u)
+        dyn = [-x[i] + x[i - 1] * u[i % nu] + 0.1 * s[(i + k) % n_s] * x[(i + 1) % nx] for i in range(nx)]
+        phase.set_dynamics(dyn)
+        phase.set_integral([x[j % nx] * u[j % nu] + u[j % nu] ** 2 + 0.05 * sp.cos(x[(3 * j + 1) % nx]) for j in range(ni)])
+        if nc:
+            phase.set_phase_constraint([x[j % nx] ** 2 + u[(j + 1) % nu] ** 2 - 0.2 * x[(j + 2) % nx] for j in range(nc)],
+                                       [-1.0] * nc, [9.0] * nc)
+        t0 = 0.0 if k == 0 else s[k - 1] + 1.0 * k
+        tf = (s[k] + 1.0 * (k + 1)) if (k + 1 < n_ph or free_time) else 1.0 * (k + 1)
+        start = [0.3 + 0.02 * i for i in range(nx)]
+        if k:
+            start[0] = s[n_ph]
+        phase.set_boundary_condition(start, [None] * nx, t0, tf)
+        phase.set_discretization(mesh, num_point)
+        phases.append(phase)
+        obj = obj + sum(phase.I[j] for j in range(ni))
+        g = ns.linear_guess(phase, 0.0)
+        g.t_0, g.t_f = 1.0 * k + (0.1 if k else 0.0), 1.0 * (k + 1) + 0.1
+        for i in range(nx):
+            g.x[i] = (0.3 + 0.02 * i) * np.exp(-0.3 * (g.t_x - g.t_0)) + 0.04 * np.sin(2.0 * g.t_x + i)
+        for i in range(nu):
+            g.u[i] = 0.3 * np.cos(1.5 * g.t_u + i)
+        guesses.append(g)
+    system.set_phase(phases)
+    system.set_objective(obj + sum(0.5 * si**2 for si in s) + (s[n_ph - 1] if free_time else 0))
+    system.set_system_constraint([s[i] - s[i + 1] for i in range(n_ph)] + [s[n_ph] * s[0]], [-5.0] * (n_ph + 1), [5.0] * (n_ph + 1))
+    static = [0.1] * n_s
+    static[n_ph] = 0.3
+    return system, phases, guesses + [static]
+
+
 # --------------------------------------------------------------------------- semantic pins
 def derivative_model(ns, mesh=(0, 0.2, 1), num_point=(3, 4)):
     """Feature-dense model of the reference's FD derivative tests: 2 static params, FUNC state

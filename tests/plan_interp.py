@@ -267,6 +267,7 @@ def mesh_error(plan, x):
             assert recs[int(first) + jj]["K"] == recs[int(first)]["K"] and recs[int(first) + jj]["phase"] == recs[int(first)]["phase"]
         assert int(cnt) * (int(recs[int(first)]["K"]) + 1) <= 64
     assert np.all(seen == 1), "the groups must cover every interval exactly once"
+    fns = {}                                       # (the dynamics functions of a phase are lambdified once, not per interval)
     for rec in recs[order]:
         K = int(rec["K"])
         k = int(rec["phase"])
@@ -290,7 +291,10 @@ def mesh_error(plan, x):
         for sym, v in it.sdict.items():
             vals[sym] = np.full(na, v)
         syms = list(vals)
-        fn = sp.lambdify(syms, [sp.sympify(fr.F).subs(env["base"]) for fr in pp.dyn], modules="numpy")
+        if k not in fns:
+            fns[k] = (syms, sp.lambdify(syms, [sp.sympify(fr.F).subs(env["base"]) for fr in pp.dyn], modules="numpy"))
+        assert fns[k][0] == syms
+        fn = fns[k][1]
         f = [np.broadcast_to(np.asarray(v, dtype=np.float64), (na,)) for v in fn(*[vals[s_] for s_ in syms])]
         for i in range(p.n_x):
             pos = int(rec["out_off"]) + i * int(rec["rows"]) + int(rec["row0"])

@@ -106,6 +106,23 @@ def test_chain_models_wider_than_one_wave_can_stage(states, mesh):
     system._invalidate()
 
 
+@pytest.mark.parametrize("case", [("radau", dict()),      # 60 states, 3 controls, 10 path constraints, 4 integrals, 6 statics, free t_f
+                                  ("radau", dict(shapes=((30, 30, 30, 30),), statics=30, free_time=False)),
+                                  ("lobatto", dict(shapes=((52, 2, 3, 1), (20, 5, 12, 3)), statics=5, mesh=[0, 0.3, 1.0], num_point=[5, 3])),
+                                  ("radau", dict(shapes=((100, 8, 20, 3), (17, 1, 0, 1), (4, 2, 1, 1)), statics=5, mesh=300))])
+def test_models_wide_in_every_direction_of_the_modeling_api(case):
+    """Many controls, path constraints, integrals and static parameters next to many states, several wide phases linked
+    through static parameters (FUNC boundaries and times), a wide phase next to narrow ones: benchmarks.wide_mix against the
+    oracle -- structures, every callback, the stand-alone kernels, both forms of the cycle and the compact layouts."""
+    scheme, kw = case
+    system, _, guess = models.wide_mix(_ns(scheme, "pockit_amd"), **kw)
+    ref, _, _ = models.wide_mix(_ns(scheme, "oracle"), **kw)
+    src = system.evaluator.src
+    assert src.wide[0] and src.fits_lds() and not src.spilling_kernels
+    _check_everything(system, ref, guess, f"wide_mix {scheme} {kw}")
+    system._invalidate()
+
+
 @pytest.mark.parametrize("pp", ["0", "1"])
 @pytest.mark.parametrize("case", [("radau", dict(states=52, mesh=[0, 0.1, 0.35, 0.5, 1.0], num_point=[3, 6, 4, 9])),
                                   ("lobatto", dict(states=37, mesh=11, num_point=5)),
