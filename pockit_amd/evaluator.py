@@ -223,7 +223,7 @@ def compile_plan(plan: SystemPlan, sharded=False, output_share=1.0):
       until it does.  Nothing a wave stages grows with the number of states (WIDE phases, codegen.py), so a fitting size
       exists for every model; if none did, this raises instead of handing the library a model it must reject.
     * **registers** -- a model whose kernels would spill vector registers to scratch memory is generated again with smaller
-      groups while that lowers the number of spilled registers.  What is left is reported: ``ModelSource.spilling_kernels``
+      groups (every size down to 4, the fewest spilled registers win).  What is left is reported: ``ModelSource.spilling_kernels``
       and a ``RuntimeWarning`` (the kernels are correct, a spilling one is slow).
 
     Every size tried stays cached, so a model pays its extra compiles once.  Returns (ModelSource, code object)."""
@@ -265,11 +265,13 @@ def compile_plan(plan: SystemPlan, sharded=False, output_share=1.0):
             if trial[2] == 0:
                 settled = trial
     best = settled or build(cap0)
-    while settled is None and best[2] > 0 and best[0].group_cap > 4 and best[0].grouped and not fixed_cap:
-        trial = build(best[0].group_cap // 2)
-        if trial[2] >= best[2]:
-            break
-        best = trial
+    if settled is None and best[0].grouped and not fixed_cap:
+        cap = best[0].group_cap      # (every size down to 4 while registers still spill: the count is not monotonic in the size --
+        while best[2] > 0 and cap > 4:      # an LGL model of 52 + 20 states spilled 5 VGPRs at 32, more at 16, none at 8)
+            cap //= 2
+            trial = build(cap)
+            if trial[2] < best[2]:
+                best = trial
     # The cycle of a model evaluated in groups is fastest with every pass as a workgroup of its own (ModelSource.cycle_subs,
     # DESIGN.md section 3c), which needs two workgroups of the launch on a CU: when the groups need too much LDS for that,
     # half the size is tried (rocket_powered_descent at 2000 x 4: 22.6 -> 11.3 us per cycle, drone_stabilization 15.2 -> 13.6;
