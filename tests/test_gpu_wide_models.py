@@ -109,7 +109,7 @@ def test_chain_models_wider_than_one_wave_can_stage(states, mesh):
 @pytest.mark.parametrize("case", [("radau", dict()),      # 60 states, 3 controls, 10 path constraints, 4 integrals, 6 statics, free t_f
                                   ("radau", dict(shapes=((30, 30, 30, 30),), statics=30, free_time=False)),
                                   ("lobatto", dict(shapes=((52, 2, 3, 1), (20, 5, 12, 3)), statics=5, mesh=[0, 0.3, 1.0], num_point=[5, 3])),
-                                  ("radau", dict(shapes=((100, 8, 20, 3), (17, 1, 0, 1), (4, 2, 1, 1)), statics=5, mesh=300))])
+                                  ("radau", dict(shapes=((40, 4, 8, 2), (17, 1, 0, 1), (4, 2, 1, 1)), statics=5, mesh=100))])
 def test_models_wide_in_every_direction_of_the_modeling_api(case):
     """Many controls, path constraints, integrals and static parameters next to many states, several wide phases linked
     through static parameters (FUNC boundaries and times), a wide phase next to narrow ones: benchmarks.wide_mix against the
