@@ -266,8 +266,8 @@ def compile_plan(plan: SystemPlan, sharded=False, output_share=1.0):
                 settled = trial
     best = settled or build(cap0)
     if settled is None and best[0].grouped and not fixed_cap:
-        cap = best[0].group_cap      # (every size down to 4 while registers still spill: the count is not monotonic in the size --
-        while best[2] > 0 and cap > 4:      # an LGL model of 52 + 20 states spilled 5 VGPRs at 32, more at 16, none at 8)
+        cap = best[0].group_cap      # (every size down to 4 while registers still spill: the count is not monotonic in the size.
+        while best[2] > 0 and cap > 4:      # Some models keep spills at EVERY size -- DESIGN.md section 11 lists the measured ones)
             cap //= 2
             trial = build(cap)
             if trial[2] < best[2]:
