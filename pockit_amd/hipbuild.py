@@ -210,5 +210,12 @@ def compile_model(source: str, fastmath: bool = False, keep_source: bool = None)
                     fh.write(f"{key} {COMPILE_SECONDS['last']:.1f}\n")
             except OSError:
                 pass
+    used = os.environ.get("POCKIT_AMD_USED_LOG")      # (tests/conftest.py on a GPU box, __graft_entry__.build(): the keys a session
+    if used:                                              #  was served -- tools/prune_cache.py --keep-list ships exactly those)
+        try:
+            with open(used, "a") as fh:
+                fh.write(key + "\n")
+        except OSError:
+            pass
     with open(path, "rb") as fh:
         return zlib.decompress(fh.read())

@@ -18,10 +18,12 @@ def pytest_sessionstart(session):
     out = os.path.join(ROOT, "gpurun_out")
     if os.environ.get("GRAFT_REPO_ROOT") and os.path.isdir(out) and "POCKIT_AMD_COMPILE_LOG" not in os.environ:
         os.environ["POCKIT_AMD_COMPILE_LOG"] = os.path.join(out, "compiled_keys.txt")
-        try:
-            os.remove(os.environ["POCKIT_AMD_COMPILE_LOG"])
-        except OSError:
-            pass
+        os.environ.setdefault("POCKIT_AMD_USED_LOG", os.path.join(out, "used_keys.txt"))      # every object the suite was served
+        for name in ("POCKIT_AMD_COMPILE_LOG", "POCKIT_AMD_USED_LOG"):
+            try:
+                os.remove(os.environ[name])
+            except OSError:
+                pass
 
 
 def pytest_terminal_summary(terminalreporter):

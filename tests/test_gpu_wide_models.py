@@ -113,7 +113,7 @@ def test_chain_models_wider_than_one_wave_can_stage(states, mesh):
                                   ("radau", dict(shapes=((30, 30, 30, 30),), statics=30, free_time=False), True),
                                   ("radau", dict(shapes=((52, 2, 3, 1), (20, 5, 12, 3)), statics=5, mesh=[0, 0.3, 1.0], num_point=[5, 3]), True),
                                   ("lobatto", dict(shapes=((52, 2, 3, 1), (20, 5, 12, 3)), statics=5, mesh=[0, 0.3, 1.0], num_point=[5, 3]), False),
-                                  ("radau", dict(shapes=((40, 4, 8, 2), (17, 1, 0, 1), (4, 2, 1, 1)), statics=5, mesh=100), None)])
+                                  ("radau", dict(shapes=((40, 4, 8, 2), (17, 1, 0, 1), (4, 2, 1, 1)), statics=5, mesh=100), True)])
 def test_models_wide_in_every_direction_of_the_modeling_api(case):
     """Many controls, path constraints, integrals and static parameters next to many states, several wide phases linked
     through static parameters (FUNC boundaries and times), a wide phase next to narrow ones: benchmarks.wide_mix against the
@@ -127,7 +127,7 @@ def test_models_wide_in_every_direction_of_the_modeling_api(case):
         src = system.evaluator.src
     ref, _, _ = models.wide_mix(_ns(scheme, "oracle"), **kw)
     assert src.wide[0] and src.fits_lds()
-    if spill_free is not None:      # (None: not asserted either way)
+    if spill_free is not None:
         assert bool(src.spilling_kernels) == (not spill_free), src.spilling_kernels
     _check_everything(system, ref, guess, f"wide_mix {scheme} {kw}")
     system._invalidate()

@@ -42,5 +42,30 @@ def main(emit_older_than=None):
     print(f"pruned {removed} stale files, {len(keep)} live code objects" + (f", {dropped} unused function bodies" if dropped else ""))
 
 
+def keep_only(list_files):
+    """``--keep-list a.txt [b.txt ...]``: drop every code object whose key is in none of the lists (one key per line, written
+    by hipbuild.compile_model under POCKIT_AMD_USED_LOG: gpurun_out/used_keys.txt of a whole GPU suite run, plus the list of a
+    local ``__graft_entry__.build()``).  A set, not a time stamp: objects that only the GPU box compiles (later models of
+    tests that build several) and that were imported from gpurun_out/cache_new are in the suite's list like all others."""
+    d = hipbuild.CACHE_DIR
+    want = set()
+    for f in list_files:
+        with open(f) as fh:
+            want |= {ln.split()[0] for ln in fh if ln.strip()}
+    live = hipbuild.live_keys()
+    if len(want & live) < 50:
+        raise SystemExit(f"prune_cache: the lists name only {len(want & live)} live objects -- not a whole suite run; nothing removed")
+    removed = 0
+    for name in os.listdir(d):
+        for ext in (".hsacoz", ".res.json", ".gen", ".hip"):
+            if name.endswith(ext) and name[: -len(ext)] in live and name[: -len(ext)] not in want:
+                os.remove(os.path.join(d, name))
+                removed += 1
+    print(f"kept {len(want & live)} of {len(live)} live code objects, removed {removed} files")
+
+
 if __name__ == "__main__":
-    main(float(sys.argv[1]) if len(sys.argv) > 1 else None)
+    if len(sys.argv) > 2 and sys.argv[1] == "--keep-list":
+        keep_only(sys.argv[2:])
+    else:
+        main(float(sys.argv[1]) if len(sys.argv) > 1 else None)
