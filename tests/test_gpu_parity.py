@@ -243,14 +243,26 @@ def test_intervals_with_more_points_than_a_wavefront_has_lanes(case, monkeypatch
     close(ev.constraints_direct(x), want["g"], what="g direct")
     close(ev.jacobian_direct(x), want["J"], what="J direct")
     close(ev.hessian_direct(x, lam, sigma), want["H"], what="H direct")
-    ev.set_cycle_mode(False)                                         # two-launch cycle, unsplit and split x-part
-    f2, grad2, g2, J2, H2 = ev.cycle(x, lam, sigma)
+    # two-launch cycle (pk_xall, then pk_hess with the reductions), unsplit and split x-part -- at a point the context has not
+    # seen, two launches FIRST: an entry a kernel failed to write would show what an older iterate left in the landing block,
+    # which at the same x looks right (tools/two_launch_probe2.py; the same-x form of this check was blind to that)
+    x2 = x * (1.0 + 1.0e-3 * np.random.default_rng(11).uniform(-1.0, 1.0, x.shape))
+    ev.set_cycle_mode(False)
+    try:
+        f2, grad2, g2, J2, H2 = [np.array(v) for v in ev.cycle(x2, lam, sigma)]
+    finally:
+        ev.set_cycle_mode(True)
+    f1, grad1, g1, J1, H1 = [np.array(v) for v in ev.cycle(x2, lam, sigma)]
+    it2 = Interp(system.plan, x2, lam, sigma)
+    close(g1, it2.constraints(), what="g at the second point")
+    close(J1, it2.jacobian(), what="J at the second point")
     if ev.src.cycle_subs:      # every pass a workgroup of its own in pk_cycle / pk_hess, a loop in pk_xall: the compiler
-        for a, b, what in ((J2, J, "J"), (H2, H, "H"), (g2, g, "g")):     # contracts the same expressions differently
+        for a, b, what in ((J2, J1, "J"), (H2, H1, "H"), (g2, g1, "g"), (grad2, grad1, "grad")):     # contracts the same expressions differently
             close(a, b, tol=1e-13, what="two launches against one: " + what)
+        close(f2, f1, tol=1e-13, what="two launches against one: f")
     else:
-        assert np.array_equal(J2, J) and np.array_equal(H2, H) and np.array_equal(g2, g)
-    ev.set_cycle_mode(True)
+        assert np.array_equal(J2, J1) and np.array_equal(H2, H1) and np.array_equal(g2, g1) and np.array_equal(grad2, grad1)
+        assert f2 == f1
     system.set_hessian_layout("compact")                             # compact layout: pk_hessc walks such an interval 64 nodes at a time
     close(system.hessian(x, lam, sigma), it.hessian_compact(), what="compact H")
     system.set_hessian_layout("reference")
