@@ -66,6 +66,9 @@ typedef struct pk_model_desc {
   int32_t big_global;   /* 1: intervals with more than 64 points stage their rows in the device staging buffer whatever their
                            length (PK_BIG_GLOBAL: the rows of every state do not fit a workgroup's LDS); 0: only beyond 256 */
   int32_t big_rows;     /* rows one such interval stages per sub-slot (0: derived from lds_x / lds_h / lds_jc) */
+  int32_t wide;         /* 1: the model has a WIDE phase (its states are evaluated in passes over chunks).  The library then refuses
+                           every launch of the kernel pk_xall with error 27: the sequential values role of such a phase has an open defect
+                           (round 5); the one-launch cycle and the five callbacks do not use that kernel */
 } pk_model_desc;
 
 /* One (model, mesh) instance: sizes plus the table blobs built by pockit_amd/evaluator.py.

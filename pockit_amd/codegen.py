@@ -830,7 +830,19 @@ class ModelSource:
         wg_bytes = 8 * 4 * (max(self.lds_x, self.lds_h, self.lds_g) + 2 * self.tab_cap + 2 * 64 + self.tab_cap // 2)
         want = os.environ.get("POCKIT_AMD_PASS_PARALLEL", "auto")
         if want == "0" or (want != "1" and 2 * wg_bytes > 160 * 1024):
-            self.cycle_subs = 0
+            # A model with a WIDE phase keeps its passes as workgroups of their own whatever the LDS says and whatever the
+            # switch asks for: the SEQUENTIAL values role of such a phase (the dynamics passes inside the values wave,
+            # tile_xall_grouped with PP = false) returned wrong f / grad / g / J for some models and raised GPU memory
+            # faults (round 5, DESIGN.md section 11: an open defect on the compiler's SGPR-spill path of that kernel);
+            # no wide model has shown it in the pass-parallel form.  Containment, not a fix.
+            if any(self.wide) and self.cycle_subs:
+                if want == "0":
+                    import warnings
+
+                    warnings.warn("pockit_amd: POCKIT_AMD_PASS_PARALLEL=0 is ignored for a model with a wide phase (the sequential "
+                                  "form of its values role has an open defect, DESIGN.md section 11)", RuntimeWarning, stacklevel=3)
+            else:
+                self.cycle_subs = 0
         S.append(f"  static constexpr bool GROUPED = {'true' if self.cycle_subs else 'false'};")
         S.append(f"  static constexpr int J_NGMAX = {self.j_ngmax}, H_NGMAX = {self.h_ngmax}, D_NGMAX = {self.d_ngmax};")
         # (the compact roles of a pass-parallel launch share their passes round robin: workgroup `sub` of `stride`)

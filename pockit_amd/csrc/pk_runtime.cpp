@@ -366,6 +366,13 @@ int launch_raw(pk_ctx* c, int k, void* args, size_t sz, unsigned grid, size_t ld
 }
 
 int launch(pk_ctx* c, int k, PkArgs& A, unsigned grid, size_t lds_bytes, hipStream_t st) {
+  // pk_xall runs the values role of a WIDE phase with its dynamics passes inside the values wave: wrong f / grad / g for
+  // some models and GPU memory faults (round 5, an open defect on that kernel's SGPR-spill path).
+  // Every route to it -- the two-launch cycle, a profiled context, pk_set_option("xpart_single", 0), the x-part of a
+  // sharded context with the in-launch exchange, integrals-first models with intervals of more than 64 points -- ends here.
+  if (k == K_XALL && c->md.wide)
+    return fail(c, 27, "pk_xall is not offered for a model with a wide phase (open defect of its sequential values role, DESIGN.md "
+                       "section 11): use the one-launch cycle / the callbacks of an unprofiled context (the default)");
   return launch_raw(c, k, &A, args_bytes(c), grid, lds_bytes, st);
 }
 
@@ -815,6 +822,7 @@ int pk_load_model(pk_ctx* c, const void* code_object, size_t len, const pk_model
   if (md->cycle_subs < 0 || md->cycle_subs > 4096) return fail(c, 25, "pk_load_model: cycle_subs %d", md->cycle_subs);
   if (md->hess_subs < 0 || md->hess_subs > 4096 || (md->hess_subs > 0) != (md->cycle_subs > 0))
     return fail(c, 25, "pk_load_model: hess_subs %d with cycle_subs %d", md->hess_subs, md->cycle_subs);
+  if (md->wide < 0 || md->wide > 1) return fail(c, 25, "pk_load_model: wide %d", md->wide);
   if (md->big_global < 0 || md->big_global > 1 || md->big_rows < 0 || md->big_rows > (1 << 20))
     return fail(c, 25, "pk_load_model: big_global %d / big_rows %d", md->big_global, md->big_rows);
   if (md->hessc_subs < 0 || md->hessc_subs > 4096 || md->jacc_subs < 0 || md->jacc_subs > 4096 ||

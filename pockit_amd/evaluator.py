@@ -341,6 +341,7 @@ class Evaluator:
         md.hessc_subs = self.src.hc_ngmax if (self.src.cycle_subs and self.src.hc_ngmax > 1) else 0
         md.jacc_subs = self.src.jc_ngmax if (self.src.cycle_subs and self.src.jc_ngmax > 1) else 0
         md.big_global, md.big_rows = int(self.src.big_global), int(self.src.big_rows)
+        md.wide = int(any(self.src.wide))      # (the library then refuses pk_xall: _refuse_sequential_values_role)
         self._err_views = None
         self._csr = {}
         md.prepass_f = 1
@@ -352,6 +353,9 @@ class Evaluator:
         self._views = {}
         self.zero_copy = False   # True: callbacks return views of pinned buffers (set by the IPOPT adapter)
         self.writable_results = os.environ.get("POCKIT_AMD_WRITABLE_RESULTS", "0") == "1"    # (see _result)
+        if (md.prepass_grad or md.prepass_g or md.prepass_jac or md.prepass_hess) and self.src.big:
+            # (integrals first AND an interval of more than 64 points: the x-callbacks then run pk_xall behind the prepass)
+            self._refuse_sequential_values_role("a model that needs the integrals first, on a mesh with an interval of more than 64 points,")
         self.ctx.check(lib.pk_load_model(h, code, len(code), C.byref(md)))
         self.model_desc = md
         # (the tiling is sized for ONE shard's share of the mesh: output_share = 1 / number of shards)
@@ -790,6 +794,8 @@ class Evaluator:
 
     def profile(self, enable=True, period=1):
         """Time the kernels whose bit is set in ``enable`` with HIP events; only every ``period``-th launch."""
+        # (the x-CALLBACKS of a profiled context run pk_xall, which the library refuses for a model with a wide phase -- error 27,
+        #  DESIGN.md section 11; profiling around device-resident cycles, what bench.py does, never reaches that kernel)
         self.ctx.check(self.ctx.lib.pk_profile_sampling(self.ctx.handle, int(period)))
         self.ctx.check(self.ctx.lib.pk_profile(self.ctx.handle, int(enable)))
 
@@ -798,8 +804,20 @@ class Evaluator:
         ROCm 7.2 -- DESIGN.md section 5 -- so it is off by default)."""
         self.ctx.check(self.ctx.lib.pk_set_cycle_graph(self.ctx.handle, int(bool(enable))))
 
+    #: what the guarded entry points say (the reason in full: DESIGN.md section 11; the library's own guard is error 27)
+    _WIDE_SEQUENTIAL = ("is not available for a model with a wide phase (more than {nx} states): it runs the values role of such a "
+                        "phase with its dynamics passes inside one wave (pk_xall), a form that returned wrong f / grad / g for "
+                        "some models and raised GPU memory faults -- an open defect (DESIGN.md section 11).  The default "
+                        "one-launch cycle and the five callbacks do not use it")
+
+    def _refuse_sequential_values_role(self, what):
+        if any(self.src.wide):
+            raise NotImplementedError(f"pockit_amd: {what} " + self._WIDE_SEQUENTIAL.format(nx=self.src.wide_nx))
+
     def set_cycle_mode(self, single_launch=True):
         """True (default): one cycle = one launch (pk_cycle).  False: pk_xall, then pk_hess with the reductions."""
+        if not single_launch:
+            self._refuse_sequential_values_role("the two-launch form of the cycle")
         self.ctx.check(self.ctx.lib.pk_set_cycle_mode(self.ctx.handle, int(bool(single_launch))))
 
     def set_cycle_layout(self, jacobian_compact=False, hessian_compact=False):

@@ -20,7 +20,7 @@ class ModelDesc(C.Structure):
     _fields_ = [(n, C.c_int32) for n in
                 ("n_phase", "n_I", "nred", "lds_g", "lds_j", "lds_h", "ne_j", "ne_h", "prepass_f", "prepass_grad",
                  "prepass_g", "prepass_jac", "prepass_hess", "lds_x", "ne_a", "ne_hc", "lds_e", "tab_cap", "sharded",
-                 "lds_jc", "ne_jc", "max_phases", "cycle_subs", "hess_subs", "hessc_subs", "jacc_subs", "big_global", "big_rows")]
+                 "lds_jc", "ne_jc", "max_phases", "cycle_subs", "hess_subs", "hessc_subs", "jacc_subs", "big_global", "big_rows", "wide")]
 
 
 class ProblemDesc(C.Structure):

@@ -31,7 +31,7 @@ def test_struct_sizes_match_the_c_abi():
     assert runtime.ITEM_DTYPE.itemsize == 24
     assert runtime.OUTER_DTYPE.itemsize == 40
     assert runtime.ERRIV_DTYPE.itemsize == 48
-    assert C.sizeof(runtime.ModelDesc) == 28 * 4
+    assert C.sizeof(runtime.ModelDesc) == 29 * 4
 
 
 def test_numpy_mirrors_agree_with_the_compiled_structs(tmp_path):

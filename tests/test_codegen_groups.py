@@ -182,3 +182,28 @@ def test_more_sums_over_all_nodes_than_the_finalize_workgroup_takes_is_a_clear_e
     monkeypatch.setattr(ModelSource, "MAX_ROWS", 22)
     with pytest.raises(ValueError, match="sums over all nodes"):
         ModelSource(system.plan)
+
+
+def test_a_model_with_a_wide_phase_is_built_pass_parallel_only(monkeypatch):
+    """Containment of the round-5 defect: the sequential values role of a wide phase -- the dynamics
+    passes inside the values wave -- returned wrong values for some models and raised GPU faults; such a model keeps its
+    passes as workgroups of their own whatever the mesh size (a full chip preferred the sequential form before), whatever
+    the workgroup's LDS, and whatever POCKIT_AMD_PASS_PARALLEL says ("0" is ignored with a warning).  Models without a wide
+    phase keep the choice."""
+    import warnings
+
+    import pockit_amd.radau as radau
+    from pockit_amd import benchmarks
+
+    for mesh in (40, 3000):
+        system = benchmarks.state_chain(radau, states=52, mesh=mesh, num_point=4)[0]
+        for cap in (32, 16, 8):
+            src = ModelSource(system.plan, group_cap=cap)
+            assert src.wide == [True] and src.cycle_subs > 0 and "GROUPED = true" in src.source, (mesh, cap)
+    monkeypatch.setenv("POCKIT_AMD_PASS_PARALLEL", "0")
+    with warnings.catch_warnings(record=True) as seen:
+        warnings.simplefilter("always")
+        src = ModelSource(benchmarks.state_chain(radau, states=52, mesh=40, num_point=4)[0].plan)
+    assert src.cycle_subs > 0 and any("PASS_PARALLEL=0 is ignored" in str(w.message) for w in seen)
+    narrow = ModelSource(benchmarks.humanoid_wbc(radau, 50, 8)[0].plan, group_cap=16)      # (grouped, no wide phase)
+    assert narrow.wide == [False] and narrow.cycle_subs == 0

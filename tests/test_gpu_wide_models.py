@@ -37,7 +37,7 @@ def _same_matrix(got, rc, want, rc_ref, shape, what):
     assert (d.max() if d.nnz else 0.0) <= TOL * max(1.0, abs(b).max()), what
 
 
-def _check_everything(system, ref, guess, tag, standalone=True, two_launch=True):
+def _check_everything(system, ref, guess, tag, standalone=True):
     import torch
 
     x, lam, sigma = models.bench_inputs(system, guess)
@@ -60,18 +60,22 @@ def _check_everything(system, ref, guess, tag, standalone=True, two_launch=True)
         close(ev.constraints_direct(x), want[2], what=f"{tag} pk_g")
         close(ev.jacobian_direct(x), want[3], what=f"{tag} pk_jac")
         close(ev.hessian_direct(x, lam, sigma), want[4], what=f"{tag} pk_hess")
-        if two_launch:
-            # the two-launch cycle: pk_xall (sequential passes), then pk_hess carrying the reductions -- at a point the
-            # context has NOT seen (x perturbed by 1e-3: the host shim serves an iterate it already holds without a launch,
-            # and a result left over from the one-launch cycle would differ from the oracle here by ~1e-3, not pass at 1e-11)
-            x2 = x * (1.0 + 1.0e-3 * np.random.default_rng(7).uniform(-1.0, 1.0, x.shape))
-            want2 = (ref.objective(x2), ref.gradient(x2), ref.constraints(x2), ref.jacobian(x2), ref.hessian(x2, lam, sigma))
-            ev.set_cycle_mode(False)
-            try:
-                for a, b, what in zip(ev.cycle(x2, lam, sigma), want2, names):
-                    close(a, b, what=f"{tag} two-launch cycle {what}")
-            finally:
-                ev.set_cycle_mode(True)
+    # The two-launch form of the cycle and every other route to pk_xall are REFUSED for a model with a
+    # wide phase (round 5: the sequential values role of such a phase returned wrong f / grad / g / J for some models and
+    # raised GPU memory faults -- DESIGN.md section 11; these models are built pass-parallel only): loudly, by the Python
+    # layer and by the library itself (error 27), instead of a number
+    with pytest.raises(NotImplementedError, match="wide phase"):
+        ev.set_cycle_mode(False)
+    assert ev.src.cycle_subs > 0 and ev.model_desc.wide == 1
+    rc = ev.ctx.lib.pk_set_cycle_mode(ev.ctx.handle, 0)          # (a C caller: the mode is accepted, the launch is not)
+    assert rc == 0
+    try:
+        with pytest.raises(RuntimeError, match="27"):
+            ev.cycle(x * (1.0 + 1.0e-3), lam, sigma)
+    finally:
+        assert ev.ctx.lib.pk_set_cycle_mode(ev.ctx.handle, 1) == 0
+    for a, b, what in zip(ev.cycle(x, lam, sigma), want, names):      # (and the context is as good as before)
+        close(a, b, what=f"{tag} one-launch cycle after the refusal {what}")
     # compact layouts: stand-alone kernels and the compact cycle launch (pk_cyclec), scatter-added against the oracle
     assert ev.src.compact, "the chain's compact Hessian couples few states per entry"
     plan.jacc  # noqa: B018
@@ -135,18 +139,10 @@ def test_models_wide_in_every_direction_of_the_modeling_api(case):
     assert src.wide[0] and src.fits_lds()
     if spill_free is not None:
         assert bool(src.spilling_kernels) == (not spill_free), src.spilling_kernels
-    # KNOWN DEFECT (round 5, open): for the model with 30 states + 30 controls + 30 path constraints +
-    # 30 integrals + 30 statics the TWO-launch form of the cycle (pk_set_cycle_mode 0: pk_xall, then pk_hess) returns wrong
-    # f, grad and g -- one control's node values are read wrongly by pk_xall's values role (production build only; J and H,
-    # the one-launch cycle, the callbacks and every stand-alone kernel are exact), and the same path raised a GPU memory
-    # fault once under POCKIT_AMD_PASS_PARALLEL=0.  The path is therefore NOT executed here for that model (a fault would
-    # take the box down); tools/two_launch_probe2.py / two_launch_probe3.py reproduce it, profiles/r05_s ... r05_y record it.
-    known_bad_two_launch = kw.get("shapes") == ((30, 30, 30, 30),)
-    _check_everything(system, ref, guess, f"wide_mix {scheme} {kw}", two_launch=not known_bad_two_launch)
+    # (the model with 30 of everything is the one whose two-launch cycle was found wrong: that form is refused for every wide
+    #  model now, _check_everything asserts the refusal; tools/two_launch_probe2.py reproduces the defect in an older tree)
+    _check_everything(system, ref, guess, f"wide_mix {scheme} {kw}")
     system._invalidate()
-    if known_bad_two_launch:
-        pytest.skip("everything but the two-launch cycle verified; the two-launch cycle of this model is a KNOWN DEFECT "
-                    "(wrong f / grad / g, DESIGN.md section 11) and is not executed")
 
 
 @pytest.mark.parametrize("pp", ["0", "1"])
@@ -155,16 +151,22 @@ def test_models_wide_in_every_direction_of_the_modeling_api(case):
                                   ("lobatto", dict(states=20, mesh=7, num_point=4, window=6)),
                                   ("radau", dict(states=24, mesh=9, num_point=7, window=5))])
 def test_wide_models_in_both_forms_of_the_cycle(case, pp, monkeypatch):
-    """The passes of a wide model one after the other in a wave (POCKIT_AMD_PASS_PARALLEL=0: what a launch that fills the chip
-    gets) and as workgroups of their own (1); ragged hp meshes, LGL, orders beyond 8 (staged tables of 256 entries) and the
-    windowed variant (every Hessian pair shared by several dynamics functions: the compact Hessian sums several contracted
-    multipliers per entry)."""
+    """Wide models on ragged hp meshes, LGL, orders beyond 8 (staged tables of 256 entries) and the windowed variant (every Hessian
+    pair shared by several dynamics functions: the compact Hessian sums several contracted multipliers per entry), with the
+    switch POCKIT_AMD_PASS_PARALLEL at 1 and at 0: since the end of round 5 a wide model runs its passes as workgroups of their
+    own either way ("0" is ignored with a warning: the sequential form of its values role has an open defect)."""
+    import warnings
+
     monkeypatch.setenv("POCKIT_AMD_PASS_PARALLEL", pp)
     scheme, kw = case
     system, _, guess = models.state_chain(_ns(scheme, "pockit_amd"), **kw)
     ref, _, _ = models.state_chain(_ns(scheme, "oracle"), **kw)
-    src = system.evaluator.src
-    assert src.wide == [True] and bool(src.cycle_subs) == (pp == "1")
+    with warnings.catch_warnings(record=True) as seen:
+        warnings.simplefilter("always")
+        src = system.evaluator.src
+    # (round 5: a wide model is pass-parallel whatever the switch says -- "0" is ignored with a warning, DESIGN.md section 11)
+    assert src.wide == [True] and src.cycle_subs > 0
+    assert (pp == "0") == any("PASS_PARALLEL=0 is ignored" in str(w.message) for w in seen)
     _check_everything(system, ref, guess, f"{scheme} {kw} pass-parallel {pp}")
     system._invalidate()
 

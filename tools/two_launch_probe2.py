@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""GPU box: the two-launch cycle (pk_set_cycle_mode 0: pk_xall, then pk_hess with the reductions) of benchmarks.wide_mix
+"""(Historical: since the containment at the end of round 5 the library refuses pk_xall for a model with a wide phase, error 27 -- this probe reproduces the defect only on a tree before that commit.)
+GPU box: the two-launch cycle (pk_set_cycle_mode 0: pk_xall, then pk_hess with the reductions) of benchmarks.wide_mix
 (30, 30, 30, 30) + 30 statics against the oracle AT POINTS THE CONTEXT HAS NOT SEEN (x (1 + 1e-3 U_k): a result served from an
 earlier iterate would be off by ~1e-3), all five outputs.  Second version of tools/two_launch_probe.py, whose same-x calls
 could not tell a fresh evaluation from a stale one."""

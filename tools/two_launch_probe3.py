@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""GPU box: WHICH entries of grad and g the two-launch cycle of wide_mix (30, 30, 30, 30) + 30 statics gets wrong (index sets
+"""(Historical: since the containment at the end of round 5 the library refuses pk_xall for a model with a wide phase, error 27 -- this probe reproduces the defect only on a tree before that commit.)
+GPU box: WHICH entries of grad and g the two-launch cycle of wide_mix (30, 30, 30, 30) + 30 statics gets wrong (index sets
 mapped to the layout: state / control / static of the variable, defect row of which state / path row / system row)."""
 import importlib
 import os
