@@ -2,8 +2,8 @@
 """Soak of the DEFAULT path over randomly shaped models that are wide in several directions (benchmarks.wide_mix): for each seed
 a shape (states, controls, path constraints, integrals in 4 ... 40, statics 2 ... 34, one or two phases, LGR or LGL, fixed or free
 final time) -- structures, the five callbacks, the one-launch cycle, every stand-alone kernel and the compact layouts against the
-oracle to 1e-11 (tests/test_gpu_wide_models._check_everything with the TWO-launch form left out: that form has an open defect
-for one such model and raised a GPU fault once, DESIGN.md section 11 -- it is not executed on untested shapes).
+oracle to 1e-11, and the refusal of the two-launch form (tests/test_gpu_wide_models._check_everything: since the containment
+of the round-5 defect, DESIGN.md section 11, a model with a wide phase is pass-parallel only and pk_xall is refused for it).
 usage: wide_mix_soak.py [--compile-only] seed [seed ...]     (without a GPU, --compile-only fills the code-object cache)"""
 import importlib
 import os
@@ -49,7 +49,7 @@ def main():
         import test_gpu_wide_models as T
 
         try:
-            T._check_everything(system, ref, guess, f"seed {seed}", two_launch=False)
+            T._check_everything(system, ref, guess, f"seed {seed}")
             verdict = "OK"
         except AssertionError as exc:
             verdict, bad = f"FAILED: {str(exc)[:160]}", bad + 1
