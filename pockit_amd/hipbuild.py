@@ -32,7 +32,9 @@ def _hipcc():
 def _run(cmd):
     res = subprocess.run(cmd, capture_output=True, text=True)
     if res.returncode != 0:
-        raise RuntimeError("command failed: " + " ".join(cmd) + "\n" + res.stderr[-4000:])
+        # (the compiler's own error lines first: the resource remarks of a large model bury them beyond any tail)
+        errs = [ln for ln in res.stderr.splitlines() if "error" in ln.lower() and "remark:" not in ln]
+        raise RuntimeError("command failed: " + " ".join(cmd) + "\n" + "\n".join(errs[:20]) + "\n...\n" + res.stderr[-3000:])
     return res
 
 

@@ -40,11 +40,20 @@ def main():
             if compile_only:
                 from pockit_amd.evaluator import compile_plan
 
-                src, _ = compile_plan(system.plan)
+                try:
+                    src, _ = compile_plan(system.plan)
+                except (RuntimeError, ValueError) as exc:      # (a hipcc failure is a result of the soak, not its end)
+                    print(f"seed {seed} {scheme} {kw}: COMPILE FAILED {str(exc)[:300]!r} ({time.time() - t0:.0f} s)", flush=True)
+                    continue
                 print(f"seed {seed} {scheme} {kw}: cap {src.group_cap} subs {src.cycle_subs} wide {src.wide} spills {src.spilling_kernels} "
                       f"({time.time() - t0:.0f} s)", flush=True)
                 continue
-            src = system.evaluator.src
+            try:
+                src = system.evaluator.src
+            except (RuntimeError, ValueError) as exc:
+                print(f"seed {seed} {scheme} {kw}: COMPILE / LOAD FAILED {str(exc)[:300]!r}", flush=True)
+                bad += 1
+                continue
         ref, _, _ = models.wide_mix(importlib.import_module(f"oracle.{scheme}"), **kw)
         import test_gpu_wide_models as T
 
