@@ -120,12 +120,12 @@ def _parse_resource_usage(stderr: str) -> dict:
     return out
 
 
-def resource_usage(source: str, fastmath: bool = False):
+def resource_usage(source: str, fastmath: bool = False, extra_flags=()):
     """What the compiler said about every kernel of a model's code object (registers, spills, scratch, occupancy): recorded
     by ``compile_model`` beside the object.  None for an object compiled before the record existed."""
     import json
 
-    path = os.path.join(CACHE_DIR, _key(source, fastmath) + ".res.json")
+    path = os.path.join(CACHE_DIR, _key(source, fastmath, extra_flags) + ".res.json")
     if not os.path.exists(path):
         return None
     with open(path) as fh:
@@ -139,23 +139,24 @@ def spills(usage) -> dict:
     return {k: (v.get("vgpr_spill", 0), v.get("scratch", 0)) for k, v in (usage or {}).items() if v.get("vgpr_spill", 0) > 0}
 
 
-def _key(source: str, fastmath: bool) -> str:
-    return hashlib.sha256((source + _kernel_header_hash() + str(bool(fastmath)) + " ".join(PRELOAD_FLAGS + EXTRA_FLAGS)).encode()
-                          ).hexdigest()[:32]
+def _key(source: str, fastmath: bool, extra_flags=()) -> str:
+    # (``extra_flags``: flags of ONE compile -- evaluator.Evaluator.checked's rebuild; empty: the key of every earlier object)
+    return hashlib.sha256((source + _kernel_header_hash() + str(bool(fastmath)) + " ".join(PRELOAD_FLAGS + EXTRA_FLAGS + list(extra_flags))
+                           ).encode()).hexdigest()[:32]
 
 
 # wall-clock seconds this process spent in hipcc for model code objects (cache misses); bench.py reports it
 COMPILE_SECONDS = {"total": 0.0, "count": 0, "last": 0.0}
 
 
-def compile_model(source: str, fastmath: bool = False, keep_source: bool = None) -> bytes:
+def compile_model(source: str, fastmath: bool = False, keep_source: bool = None, extra_flags=()) -> bytes:
     """Return the gfx950 code object of a generated model source (compiling on a cache miss).  ``keep_source``: also keep
     the generated source beside the object (default: only with POCKIT_AMD_KEEP_SOURCE=1 -- 19 MB for the GPU suite's models)."""
     if keep_source is None:
         keep_source = os.environ.get("POCKIT_AMD_KEEP_SOURCE", "0") == "1"
     import zlib
 
-    key = _key(source, fastmath)
+    key = _key(source, fastmath, extra_flags)
     os.makedirs(CACHE_DIR, exist_ok=True)
     # (stored deflated: a code object of a large model has 1-3 MB, the cache of the GPU suite 140 MB -- 35 MB deflated -- and
     #  the whole cache travels to every GPU lease)
@@ -176,7 +177,7 @@ def compile_model(source: str, fastmath: bool = False, keep_source: bool = None)
             with open(src, "w") as fh:
                 fh.write(source)
             cmd = [_hipcc(), f"--offload-arch={ARCH}", "-O3", "-std=c++17", "--genco", f"-I{CSRC}", src, "-o",
-                   os.path.join(tmp, "model.hsaco"), "-Rpass-analysis=kernel-resource-usage"] + PRELOAD_FLAGS + EXTRA_FLAGS
+                   os.path.join(tmp, "model.hsaco"), "-Rpass-analysis=kernel-resource-usage"] + PRELOAD_FLAGS + EXTRA_FLAGS + list(extra_flags)
             if fastmath:  # reassociation subset of fast-math (reference: numba fastmath=True, fastfunc.py:24,35)
                 cmd += ["-fassociative-math", "-freciprocal-math", "-fno-signed-zeros", "-fno-trapping-math"]
             res = _run(cmd)

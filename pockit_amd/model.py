@@ -615,7 +615,7 @@ class SystemBase:
 
         plan = self.plan
         if self._evaluator is None:
-            self._evaluator = Evaluator(plan)
+            self._evaluator = Evaluator.checked(plan)      # (fused kernel verified against the stand-alone ones)
             self._evaluator.set_jacobian_layout(self._jacobian_layout == "compact")
             if getattr(self, "_writable_results", None) is not None:
                 self._evaluator.writable_results = self._writable_results

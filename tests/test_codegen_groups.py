@@ -207,3 +207,15 @@ def test_a_model_with_a_wide_phase_is_built_pass_parallel_only(monkeypatch):
     assert src.cycle_subs > 0 and any("PASS_PARALLEL=0 is ignored" in str(w.message) for w in seen)
     narrow = ModelSource(benchmarks.humanoid_wbc(radau, 50, 8)[0].plan, group_cap=16)      # (grouped, no wide phase)
     assert narrow.wide == [False] and narrow.cycle_subs == 0
+
+
+def test_per_compile_flags_are_part_of_the_cache_key_and_leave_the_old_keys_alone():
+    """Evaluator.checked rebuilds a model with extra hipcc flags when its fused kernel fails the set-up self-check
+    (DESIGN.md section 11): that object must not collide with the default one, and objects compiled before the parameter
+    existed keep their keys."""
+    from pockit_amd import hipbuild
+    from pockit_amd.evaluator import Evaluator
+
+    assert hipbuild._key("source", True) == hipbuild._key("source", True, ())
+    assert hipbuild._key("source", True, Evaluator.SGPR_TO_SCRATCH) != hipbuild._key("source", True)
+    assert Evaluator.SGPR_TO_SCRATCH == ("-mllvm", "-amdgpu-spill-sgpr-to-vgpr=0")

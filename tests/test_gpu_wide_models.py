@@ -233,3 +233,49 @@ def test_mesh_error_estimation_of_wide_models(case):
             close(data[k][0], T, what=f"{kw} T")
             close(data[k][1], I, what=f"{kw} I")
     system._invalidate()
+
+
+def test_the_fused_kernel_is_verified_against_the_stand_alone_kernels_at_set_up():
+    """Round 5 found code objects whose fused kernel (pk_cycle: x-callbacks and one-launch cycle) answered wrongly while every
+    stand-alone kernel was exact (cause open).  ``system.evaluator`` therefore hands out a CHECKED evaluator
+    (Evaluator.checked): probe point through both, rebuild with SGPR spills in scratch memory on a mismatch, raise if that
+    fails too.  Model: soak seed 32 of tools/wide_mix_soak.py (LGL, a wide and a narrow phase) -- its default build is one of
+    the four known-bad ones (x-callbacks wrong by 1.65 relative, profiles/r05_zm_seed32_steps.txt)."""
+    import warnings
+
+    from pockit_amd.evaluator import Evaluator
+
+    kw = dict(shapes=((31, 8, 3, 30), (16, 22, 1, 19)), statics=15, mesh=25, num_point=6, free_time=True)
+    system, _, guess = models.wide_mix(_ns("lobatto", "pockit_amd"), **kw)
+    ref, _, _ = models.wide_mix(_ns("lobatto", "oracle"), **kw)
+    with warnings.catch_warnings(record=True) as seen:
+        warnings.simplefilter("always")
+        plain = Evaluator(system.plan)                      # the unchecked default build
+        ok_plain, worst = plain.self_check()
+        plain.close()
+        try:
+            ev = system.evaluator                           # the checked one
+        except RuntimeError as exc:                         # (both builds failed the check: a loud error, not a number)
+            assert "self-check" in str(exc)
+            return
+    if not ok_plain:      # the defect shows in this build: the checked evaluator must be the rebuilt one, and say so
+        assert ev.hipcc_flags == Evaluator.SGPR_TO_SCRATCH, worst
+        assert any("failed its self-check" in str(w.message) for w in seen)
+    assert ev.self_check()[0]
+    x, lam, sigma = models.bench_inputs(system, guess)
+    want = (ref.objective(x), ref.gradient(x), ref.constraints(x), ref.jacobian(x), ref.hessian(x, lam, sigma))
+    got = (system.objective(x), system.gradient(x), system.constraints(x), system.jacobian(x), system.hessian(x, lam, sigma))
+    for a, b, what in zip(got, want, ("f", "grad", "g", "J", "H")):
+        close(a, b, what=f"checked evaluator, callback {what}")
+    for a, b, what in zip(ev.cycle(x, lam, sigma), want, ("f", "grad", "g", "J", "H")):
+        close(a, b, what=f"checked evaluator, one-launch cycle {what}")
+    system._invalidate()
+
+
+def test_the_self_check_passes_on_ordinary_models():
+    for name, scheme, kw in (("planar_quadrotor", "radau", dict(mesh=40, num_point=6)), ("two_stage_rocket", "lobatto", dict(mesh=20, num_point=4)),
+                             ("humanoid_wbc", "radau", dict(mesh=20, num_point=8)), ("state_chain", "radau", dict(states=52, mesh=40, num_point=4))):
+        system = getattr(models, name)(_ns(scheme, "pockit_amd"), **kw)[0]
+        ev = system.evaluator
+        assert ev.hipcc_flags == () and ev.self_check() == (True, ""), name
+        system._invalidate()
