@@ -185,6 +185,8 @@ int pk_set_result_targets(pk_ctx* ctx, double* f, double* grad, double* g, doubl
  *                     host skips them from then on; every landing array must have been filled once with
  *   pk_fill_jac_constants      (the context's own buffer is filled by pk_set_jac_constant_runs itself).
  *   pk_set_host_option         A/B switches (default): "spin_wait" (1), "lambda_direct" (1), "chunk_upload" (1), "kernel_upload"
+ *                              "separate_x" (0; 1: the five callbacks and the cycle through the stand-alone kernels one after the other,
+ *                              never the fused kernel -- the fallback of a code object whose fused kernel fails its self-check),
  *                     (1), "kernel_download" (8: up to that many MiB per copy), "split_copy" (1), "speculative_hess" (1), "mark_wait" (1: the callbacks wait on a word a one-thread
  *                     kernel stores behind the result copies instead of on the stream's state), "hess_direct"
  *                     (1: a Hessian of at most "kernel_download" MiB is stored into its pinned landing array by the kernel itself),

@@ -182,6 +182,9 @@ struct pk_ctx {
   int small_x_kb = 128;            // (the x threshold of small_direct, in KB: an A/B knob)
   const double* x_src = nullptr;   // where the kernels read the prepared x: d_x, or (small_direct) the pinned staging buffer
   int xpart_single = 1;        // pk_eval_xpart_dev as ONE launch (pk_cycle without its Hessian role) instead of pk_xall + pk_fin
+  bool separate_x = false;     // the five callbacks one after the other through the STAND-ALONE kernels (pk_int + pk_fin, pk_grad, pk_g,
+                               // pk_jac, pk_hess), as for a model that needs the integrals first: what pockit_amd.Evaluator.checked falls back
+                               // to when a code object's fused kernel fails its self-check (round 5)
   int hess_direct = 1;         // the Hessian kernel stores into the pinned landing place itself when H is small enough for the
                                // copy kernel (kernel_download): no launch behind it, its reads of lambda and its stores share
                                // the link in both directions (12k nodes: 97 -> 93 us; at 83 MB the copy is faster)
@@ -1404,7 +1407,7 @@ int pk_eval_cycle_dev(pk_ctx* c, const double* d_x, const double* d_lam, double 
   if (rc) return rc;
   if (!d_lam) return fail(c, 50, "pk_eval_cycle: lambda is required");
   hipStream_t st = pick(c, stream);
-  const bool needs_I = c->md.prepass_grad || c->md.prepass_g || c->md.prepass_jac || c->md.prepass_hess;
+  const bool needs_I = c->md.prepass_grad || c->md.prepass_g || c->md.prepass_jac || c->md.prepass_hess || c->separate_x;
   // general path: the five callbacks one after the other.  A shard (pk_set_shard) may take the single launch too: its
   // finalize workgroup then leaves THIS shard's share of the integrals and of the shared gradient slots for the
   // caller's all-reduce, and f is the caller's to recompute (pk_eval_f_from_integrals_dev).
@@ -1461,7 +1464,7 @@ int pk_eval_cycle_dev_repeat(pk_ctx* c, const double* d_x, const double* d_lam, 
   // pk_set_cycle_graph(1): the whole batch is ONE hipGraph of `count` kernel nodes, captured once and replayed while
   // pointers, sigma, stream and count stay the same -- the host then pays one graph launch per batch instead of `count`
   // kernel launches.  Sharded cycles with the in-launch exchange included (the cycle number lives in device memory).
-  const bool needs_I = c->md.prepass_grad || c->md.prepass_g || c->md.prepass_jac || c->md.prepass_hess;
+  const bool needs_I = c->md.prepass_grad || c->md.prepass_g || c->md.prepass_jac || c->md.prepass_hess || c->separate_x;
   const bool graph = c->use_graph && c->profile_mask == 0 && !xchg && !needs_I && count > 1 && c->cycle_mode == 1 &&
                      !c->external_prepass && d_lam;
   if (graph) {
@@ -1499,7 +1502,7 @@ int pk_eval_cycle_dev_repeat(pk_ctx* c, const double* d_x, const double* d_lam, 
 // whose system functions are nonlinear in the integrals run the callbacks one after the other.
 // can the x-part of an iterate come from ONE pk_cycle launch without its Hessian role?
 static bool xpart_is_one_launch(const pk_ctx* c) {
-  const bool needs_I = c->md.prepass_grad || c->md.prepass_g || c->md.prepass_jac || c->md.prepass_hess;
+  const bool needs_I = c->md.prepass_grad || c->md.prepass_g || c->md.prepass_jac || c->md.prepass_hess || c->separate_x;
   return c->xpart_single && c->cycle_mode == 1 && !needs_I && c->profile_mask == 0 && !(c->xc_inline && c->xc_world > 1);
 }
 
@@ -1507,7 +1510,7 @@ int pk_eval_xpart_dev(pk_ctx* c, const double* d_x, double* d_f, double* d_grad,
   int rc = ready(c);
   if (rc) return rc;
   hipStream_t st = pick(c, stream);
-  const bool needs_I = c->md.prepass_grad || c->md.prepass_g || c->md.prepass_jac || c->md.prepass_hess;
+  const bool needs_I = c->md.prepass_grad || c->md.prepass_g || c->md.prepass_jac || c->md.prepass_hess || c->separate_x;
   if (needs_I && !c->has_big) {
     if (!c->external_prepass && (rc = pk_eval_f_dev(c, d_x, d_f, stream))) return rc;
     if ((rc = pk_eval_grad_dev(c, d_x, d_grad, stream))) return rc;
@@ -1544,7 +1547,7 @@ int pk_set_cycle_layout(pk_ctx* c, int jac_compact, int hess_compact) {
   if (rc) return rc;
   if (jac_compact && c->nnz_Jc <= 0) return fail(c, 52, "pk_set_cycle_layout: no compact Jacobian layout was supplied to pk_set_problem");
   if (hess_compact && c->nnz_Hc <= 0) return fail(c, 51, "pk_set_cycle_layout: no compact Hessian layout was supplied to pk_set_problem");
-  const bool needs_I = c->md.prepass_grad || c->md.prepass_g || c->md.prepass_jac || c->md.prepass_hess;
+  const bool needs_I = c->md.prepass_grad || c->md.prepass_g || c->md.prepass_jac || c->md.prepass_hess || c->separate_x;
   if ((jac_compact || hess_compact) && (needs_I || c->has_big))
     return fail(c, 69, "pk_set_cycle_layout: the compact layouts ride in the single-launch cycle, which this model / mesh does not "
                        "use (system functions nonlinear in the integrals, or an interval with more than 64 points)");
@@ -2266,6 +2269,12 @@ int pk_set_host_option(pk_ctx* c, const char* name, int value) {
   else if (!std::strcmp(name, "speculative_hess")) c->speculative_hess = value != 0;
   else if (!std::strcmp(name, "hess_direct")) c->hess_direct = value != 0;
   else if (!std::strcmp(name, "xpart_single")) c->xpart_single = value != 0;
+  else if (!std::strcmp(name, "separate_x")) {
+    if (value && c->has_big) return fail(c, 67, "pk_set_host_option: separate_x needs a mesh without intervals of more than 64 points "
+                                                "(such a mesh has the fused x-kernel only)");
+    c->separate_x = value != 0;
+    drop_cycle_graph(c);
+  }
   else if (!std::strcmp(name, "small_direct")) c->small_direct = value != 0;
   else if (!std::strcmp(name, "small_x_kb")) c->small_x_kb = value < 0 ? 0 : (value > (1 << 20) ? (1 << 20) : value);
   else if (!std::strcmp(name, "adaptive_prefetch")) { c->adaptive_prefetch = value != 0; c->cur_J_asked = true; }

@@ -214,7 +214,7 @@ class Tables:
         self.intervals_per_wave = ipw
 
 
-def compile_plan(plan: SystemPlan, sharded=False, output_share=1.0, extra_flags=()):
+def compile_plan(plan: SystemPlan, sharded=False, output_share=1.0, extra_flags=(), fixed=None):
     """Generated source + gfx950 code object of a plan.  The group size (codegen.split_groups: how many derivative entries a
     pass evaluates, stages and streams) is searched under two criteria, in this order:
 
@@ -242,6 +242,9 @@ def compile_plan(plan: SystemPlan, sharded=False, output_share=1.0, extra_flags=
         src.spilling_kernels = hipbuild.spills(hipbuild.resource_usage(src.source, fastmath=fast, extra_flags=extra_flags))
         return src, code, sum(v[0] for v in src.spilling_kernels.values())
 
+    if fixed is not None:      # (Evaluator.checked's rebuild: the group size and wide threshold of the build it replaces, ONE compile
+        best = build(int(fixed[0]), generate(int(fixed[0]), fixed[1]))      #  instead of the search -- with the flags of that rebuild
+        return best[0], best[1]                                              #  the search took more than half an hour on a two-phase model)
     fixed_cap = bool(os.environ.get("POCKIT_AMD_GROUP_CAP"))
     cap0 = generate(None).group_cap
     while not fixed_cap and cap0 > 1 and not generate(cap0).fits_lds():
@@ -335,14 +338,27 @@ class Evaluator:
 
         warnings.warn(f"pockit_amd: the fused kernel of this model's code object failed its self-check against the stand-alone "
                       f"kernels ({worst}); rebuilding with SGPR spills in scratch memory (DESIGN.md section 11)", RuntimeWarning, stacklevel=3)
+        fixed = (ev.src.group_cap, ev.src.wide_nx)
         ev.close()
-        ev = cls(plan, hipcc_flags=cls.SGPR_TO_SCRATCH, **kw)
+        ev = cls(plan, hipcc_flags=cls.SGPR_TO_SCRATCH, _fixed=fixed, **kw)
         ok, worst2 = ev.self_check()
-        if not ok:
+        if ok:
+            return ev
+        # Both builds disagree with their own stand-alone kernels, which have been exact in every case seen: serve the model
+        # through THEM (five launches per iterate instead of one -- what a model that needs the integrals first gets anyway).
+        ev.close()
+        ev = cls(plan, **kw)
+        if ev.src.big:      # (a mesh with intervals of more than 64 points has the fused x-kernel only)
             ev.close()
             raise RuntimeError("pockit_amd: the fused kernel of this model's code object fails its self-check against the stand-alone "
                                f"kernels in both builds tried ({worst}; with SGPR spills in scratch memory: {worst2}) -- an open defect "
-                               "(DESIGN.md section 11).  No evaluator is handed out rather than one that answers wrongly")
+                               "(DESIGN.md section 11) -- and this mesh (an interval of more than 64 points) has no stand-alone "
+                               "path.  No evaluator is handed out rather than one that answers wrongly")
+        ev.ctx.check(ev.ctx.lib.pk_set_host_option(ev.ctx.handle, b"separate_x", 1))
+        ev.separate_x = True
+        warnings.warn(f"pockit_amd: both builds of this model fail the self-check of their fused kernel ({worst}; {worst2}): the "
+                      "callbacks are served by the stand-alone kernels, one launch each (slower, exact in every case seen; DESIGN.md "
+                      "section 11)", RuntimeWarning, stacklevel=3)
         return ev
 
     def self_check(self, tol=1.0e-9):
@@ -372,13 +388,14 @@ class Evaluator:
         return ok, worst
 
     def __init__(self, plan: SystemPlan, device: int = 0, intervals_per_wave=None, tile_filter=None, sharded=False,
-                 output_share=1.0, host_helpers=True, hipcc_flags=()):
+                 output_share=1.0, host_helpers=True, hipcc_flags=(), _fixed=None):
         self.plan = plan
         self.hipcc_flags = tuple(hipcc_flags)
+        self.separate_x = False      # (True: Evaluator.checked switched this context to the stand-alone kernels)
         self._want_host_helpers = bool(host_helpers) and tile_filter is None
         # (compiled before the context is created: a box without a GPU -- the build container -- can still fill the
         # code-object cache by constructing evaluators, tools/warm_cache.sh)
-        self.src, code = compile_plan(plan, sharded=sharded, output_share=output_share, extra_flags=self.hipcc_flags)
+        self.src, code = compile_plan(plan, sharded=sharded, output_share=output_share, extra_flags=self.hipcc_flags, fixed=_fixed)
         self.ctx = runtime.Context(device)            # raises RuntimeError without a GPU
         lib, h = self.ctx.lib, self.ctx.handle
         md = runtime.ModelDesc()

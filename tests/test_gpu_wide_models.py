@@ -238,8 +238,9 @@ def test_mesh_error_estimation_of_wide_models(case):
 def test_the_fused_kernel_is_verified_against_the_stand_alone_kernels_at_set_up():
     """Round 5 found code objects whose fused kernel (pk_cycle: x-callbacks and one-launch cycle) answered wrongly while every
     stand-alone kernel was exact (cause open).  ``system.evaluator`` therefore hands out a CHECKED evaluator
-    (Evaluator.checked): probe point through both, rebuild with SGPR spills in scratch memory on a mismatch, raise if that
-    fails too.  Model: soak seed 32 of tools/wide_mix_soak.py (LGL, a wide and a narrow phase) -- its default build is one of
+    (Evaluator.checked): probe point through both; on a mismatch a rebuild with SGPR spills in scratch memory; if that fails
+    too, the stand-alone kernels serve the model (pk_set_host_option "separate_x"; an error only where a mesh has no
+    stand-alone path).  Model: soak seed 32 of tools/wide_mix_soak.py (LGL, a wide and a narrow phase) -- its default build is one of
     the four known-bad ones (x-callbacks wrong by 1.65 relative, profiles/r05_zm_seed32_steps.txt)."""
     import warnings
 
@@ -258,9 +259,10 @@ def test_the_fused_kernel_is_verified_against_the_stand_alone_kernels_at_set_up(
         except RuntimeError as exc:                         # (both builds failed the check: a loud error, not a number)
             assert "self-check" in str(exc)
             return
-    if not ok_plain:      # the defect shows in this build: the checked evaluator must be the rebuilt one, and say so
-        assert ev.hipcc_flags == Evaluator.SGPR_TO_SCRATCH, worst
-        assert any("failed its self-check" in str(w.message) for w in seen)
+    if not ok_plain:      # the defect shows in this build: the checked evaluator is the rebuilt one, or -- when that build fails the
+        # check too, as measured for this model -- a context that serves everything through the stand-alone kernels; and says so
+        assert ev.hipcc_flags == Evaluator.SGPR_TO_SCRATCH or ev.separate_x, worst
+        assert any("self-check" in str(w.message) for w in seen)
     assert ev.self_check()[0]
     x, lam, sigma = models.bench_inputs(system, guess)
     want = (ref.objective(x), ref.gradient(x), ref.constraints(x), ref.jacobian(x), ref.hessian(x, lam, sigma))
