@@ -62,8 +62,23 @@ def main():
             verdict = "OK"
         except AssertionError as exc:
             verdict, bad = f"FAILED: {str(exc)[:160]}", bad + 1
-        print(f"seed {seed} {scheme} {kw}: cap {src.group_cap} subs {src.cycle_subs} spills {bool(src.spilling_kernels)} -> {verdict}", flush=True)
+        ev = system._evaluator
+        how = "stand-alone kernels (both builds failed the self-check)" if getattr(ev, "separate_x", False) else \
+            ("REBUILT with SGPR spills in scratch (default build failed the self-check)" if getattr(ev, "hipcc_flags", ()) else "default build")
+        print(f"seed {seed} {scheme} {kw}: cap {src.group_cap} subs {src.cycle_subs} spills {bool(src.spilling_kernels)} [{how}] -> {verdict}", flush=True)
         system._invalidate()
+    log = os.environ.get("POCKIT_AMD_COMPILE_LOG")      # (objects compiled on the GPU box -- rebuilds of the checked evaluator -- go home)
+    if log and os.path.exists(log) and os.environ.get("GRAFT_REPO_ROOT"):
+        import shutil
+
+        from pockit_amd import hipbuild
+
+        dst = os.path.join(ROOT, "gpurun_out", "cache_new")
+        os.makedirs(dst, exist_ok=True)
+        for key in {ln.split()[0] for ln in open(log) if ln.strip()}:
+            for ext in (".hsacoz", ".gen", ".res.json"):
+                if os.path.exists(os.path.join(hipbuild.CACHE_DIR, key + ext)):
+                    shutil.copy(os.path.join(hipbuild.CACHE_DIR, key + ext), dst)
     if not compile_only:
         print(f"{len(seeds)} models, {bad} failed")
         sys.exit(1 if bad else 0)
