@@ -126,8 +126,8 @@ def test_the_search_shrinks_the_groups_until_the_launch_fits(monkeypatch):
     assert need_small < need_big
     built = []
     monkeypatch.setattr(ModelSource, "LDS_LIMIT", (need_big + need_small) // 2)
-    monkeypatch.setattr(hipbuild, "compile_model", lambda source, fastmath=True: built.append(source) or b"code")
-    monkeypatch.setattr(hipbuild, "resource_usage", lambda source, fastmath=True: {})
+    monkeypatch.setattr(hipbuild, "compile_model", lambda source, fastmath=True, **kw: built.append(source) or b"code")
+    monkeypatch.setattr(hipbuild, "resource_usage", lambda source, fastmath=True, **kw: {})
     monkeypatch.setenv("POCKIT_AMD_PASS_PARALLEL", "0")
     src, code = evaluator.compile_plan(system.plan)
     assert src.group_cap < 32 and src.fits_lds() and code == b"code"
