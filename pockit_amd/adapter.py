@@ -115,5 +115,6 @@ def system_from_reference(ref):
 
 def plan_from_reference_system(ref):
     """The ``SystemPlan`` (layout, triplet structure in the reference's order, value expressions) of a configured
-    reference system: ``Evaluator(plan_from_reference_system(system))`` serves its five callbacks on the GPU."""
+    reference system: ``Evaluator.checked(plan_from_reference_system(system))`` serves its five callbacks on the GPU (the fused kernel verified against
+    the stand-alone ones at set-up)."""
     return system_from_reference(ref).plan
